@@ -1,0 +1,289 @@
+"""pyarrow-facing wrapper of the CPU oracle (oracle/vinum_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+``cpu_baseline`` leg may import this; the product (vinum_amd/) never does.
+
+The classes mirror the reference's pybind11 surface
+(/root/reference/vinum/core/vinum_lib.cpp:54-142): ``next(batch)`` per batch and
+one ``result()`` / ``sorted()``; column order and output types follow
+base_aggregate.cpp:47-68 and agg_func_factory.cpp:13-329.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pyarrow as pa
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "vinum_oracle.c")
+_SO = os.path.join(_HERE, "_build", "libvinum_oracle.so")
+
+COUNT_STAR, COUNT, MIN, MAX, SUM, AVG = range(6)
+ONE_GROUP, SINGLE, MULTI = range(3)
+ASC, DESC = 0, 1
+EQ, NE, GT, GE, LT, LE = range(6)
+I8, I16, I32, I64, U8, U16, U32, U64, F32, F64 = range(10)
+OUT_U64, OUT_I64, OUT_F64, OUT_F32, OUT_DEC128, OUT_I32 = range(6)
+FLAG_SUM32 = 1
+
+_NP = {I8: np.int8, I16: np.int16, I32: np.int32, I64: np.int64, U8: np.uint8, U16: np.uint16,
+       U32: np.uint32, U64: np.uint64, F32: np.float32, F64: np.float64}
+
+
+def build(force=False):
+    """gcc -O2 -shared oracle/vinum_oracle.c -> oracle/_build/libvinum_oracle.so"""
+    if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= os.path.getmtime(_SRC):
+        return _SO
+    os.makedirs(os.path.dirname(_SO), exist_ok=True)
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-o", _SO, _SRC, "-lm"])
+    return _SO
+
+
+class _Col(ctypes.Structure):
+    _fields_ = [("values", ctypes.c_void_p), ("validity", ctypes.c_void_p), ("offset", ctypes.c_int64),
+                ("length", ctypes.c_int64), ("type", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build())
+        L.orc_agg_create.restype = ctypes.c_void_p
+        L.orc_agg_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_agg_destroy.argtypes = [ctypes.c_void_p]
+        L.orc_agg_next.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_agg_ngroups.restype = ctypes.c_int64
+        L.orc_agg_ngroups.argtypes = [ctypes.c_void_p]
+        L.orc_agg_keys.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_agg_func.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_cmp_mask.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int64,
+                                   ctypes.c_int, ctypes.c_void_p]
+        L.orc_filter_col.restype = ctypes.c_int64
+        L.orc_filter_col.argtypes = [ctypes.c_void_p] * 5
+        L.orc_sort_indices.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                       ctypes.c_void_p]
+        L.orc_take_col.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                   ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def physical_type(t: pa.DataType):
+    """Arrow type -> (physical id, flags).  Temporal types map to their storage integers."""
+    T = pa.types
+    if T.is_int8(t): return I8, 0
+    if T.is_int16(t): return I16, 0
+    if T.is_int32(t) or T.is_date32(t): return I32, 0
+    if T.is_time32(t): return I32, FLAG_SUM32
+    if T.is_int64(t) or T.is_date64(t) or T.is_time64(t) or T.is_timestamp(t) or T.is_duration(t): return I64, 0
+    if T.is_uint8(t): return U8, 0
+    if T.is_uint16(t): return U16, 0
+    if T.is_uint32(t): return U32, 0
+    if T.is_uint64(t): return U64, 0
+    if T.is_float32(t): return F32, 0
+    if T.is_float64(t): return F64, 0
+    raise TypeError(f"oracle: unsupported column type {t}")
+
+
+def _col(arr: pa.Array, keep):
+    """Zero-copy view of a primitive Arrow array."""
+    if isinstance(arr, pa.ChunkedArray):
+        arr = arr.combine_chunks()
+    pt, fl = physical_type(arr.type)
+    bufs = arr.buffers()
+    keep.append(arr)
+    c = _Col()
+    c.values = bufs[1].address if bufs[1] is not None else None
+    c.validity = bufs[0].address if (bufs[0] is not None and arr.null_count > 0) else None
+    c.offset = arr.offset
+    c.length = len(arr)
+    c.type = pt
+    c.flags = fl
+    return c
+
+
+def _arrow_from(values: np.ndarray, valid: np.ndarray, t: pa.DataType) -> pa.Array:
+    mask = ~valid.astype(bool)
+    if pa.types.is_decimal(t):
+        import decimal
+        ctx = decimal.Context(prec=60)
+        out = []
+        for i in range(len(valid)):
+            if mask[i]:
+                out.append(None)
+            else:
+                lo = int(values[i, 0]); hi = int(values[i, 1].astype(np.int64))
+                out.append(ctx.create_decimal(hi * (1 << 64) + lo))
+        return pa.array(out, type=t)
+    storage = pa.array(values, mask=mask if mask.any() else None)
+    if storage.type != t:
+        storage = storage.view(t) if _same_width(storage.type, t) else storage.cast(t)
+    return storage
+
+
+def _same_width(a, b):
+    try:
+        return a.bit_width == b.bit_width
+    except Exception:
+        return False
+
+
+def _minmax_out(values_u64: np.ndarray, valid, t: pa.DataType):
+    pt, _ = physical_type(t)
+    if pt in (F32, F64):
+        v = values_u64.view(np.float64).astype(_NP[pt])
+    elif pt in (U8, U16, U32, U64):
+        v = values_u64.astype(_NP[pt])
+    else:
+        v = values_u64.view(np.int64).astype(_NP[pt])
+    return _arrow_from(v, valid, t)
+
+
+class OracleAggregate:
+    """kind in {ONE_GROUP, SINGLE, MULTI}; funcs: list of (func_id, in_col, out_col)."""
+
+    def __init__(self, kind, groupby_cols, agg_cols, funcs):
+        self.kind, self.groupby_cols, self.agg_cols, self.funcs = kind, list(groupby_cols), list(agg_cols), list(funcs)
+        self._h = None
+        self._schema = None
+
+    def _init(self, schema: pa.Schema):
+        self._schema = schema
+        for c in self.groupby_cols + self.agg_cols:
+            if schema.get_field_index(c) < 0:
+                raise RuntimeError("Column not found: " + c)  # base_aggregate.cpp:121-131
+        kt = [physical_type(schema.field(c).type)[0] for c in self.groupby_cols]
+        ft, it, fl = [], [], []
+        for f, col, _ in self.funcs:
+            ft.append(f)
+            if col:
+                p, g = physical_type(schema.field(col).type)
+            else:
+                p, g = U64, 0
+            it.append(p); fl.append(g)
+        A = lambda xs: (ctypes.c_int * max(len(xs), 1))(*xs)
+        self._h = lib().orc_agg_create(self.kind, len(kt), A(kt), len(ft), A(ft), A(it), A(fl))
+        if not self._h:
+            raise RuntimeError("orc_agg_create failed")
+
+    def next(self, batch: pa.RecordBatch):
+        if self._h is None:
+            self._init(batch.schema)
+        keep = []
+        keys = (_Col * max(len(self.groupby_cols), 1))(*[_col(batch.column(batch.schema.get_field_index(c)), keep)
+                                                        for c in self.groupby_cols])
+        ins = []
+        for f, col, _ in self.funcs:
+            ins.append(_col(batch.column(batch.schema.get_field_index(col)), keep) if col else _Col())
+        ins = (_Col * max(len(ins), 1))(*ins)
+        lib().orc_agg_next(self._h, batch.num_rows, keys, ins)
+
+    def result(self) -> pa.RecordBatch:
+        L = lib()
+        n = L.orc_agg_ngroups(self._h)
+        names, arrays = [], []
+        for c in self.agg_cols:
+            j = self.groupby_cols.index(c)
+            vals = np.zeros(n, np.uint64); valid = np.zeros(n, np.uint8)
+            L.orc_agg_keys(self._h, j, vals.ctypes.data, valid.ctypes.data)
+            t = self._schema.field(c).type
+            pt, _ = physical_type(t)
+            if pt == F64: v = vals.view(np.float64)
+            elif pt == F32: v = vals.astype(np.uint32).view(np.float32)
+            else: v = vals.astype(_NP[pt])  # truncation restores the native pattern
+            names.append(c); arrays.append(_arrow_from(v, valid, t))
+        for i, (f, col, out) in enumerate(self.funcs):
+            cell = np.zeros((n, 2), np.uint64); valid = np.zeros(n, np.uint8)
+            kind = L.orc_agg_func(self._h, i, cell.ctypes.data, valid.ctypes.data)
+            in_t = self._schema.field(col).type if col else pa.uint64()
+            lo = np.ascontiguousarray(cell[:, 0])
+            if f in (MIN, MAX):
+                arr = _minmax_out(lo, valid, in_t)
+            elif kind == OUT_U64:
+                arr = _arrow_from(lo, valid, pa.uint64())
+            elif kind == OUT_I64:
+                t = pa.int64()
+                if f == SUM and (pa.types.is_time64(in_t) or pa.types.is_duration(in_t)):
+                    t = in_t  # agg_func_factory.cpp:138-149 (duration: sane type)
+                arr = _arrow_from(lo.view(np.int64), valid, t)
+            elif kind == OUT_I32:
+                arr = _arrow_from(lo.astype(np.uint32).view(np.int32), valid, in_t)
+            elif kind == OUT_F64:
+                arr = _arrow_from(lo.view(np.float64), valid, pa.float64())
+            elif kind == OUT_F32:
+                arr = _arrow_from(lo.astype(np.uint32).view(np.float32), valid, pa.float32())
+            else:
+                arr = _arrow_from(cell, valid, pa.decimal128(38, 0))
+            names.append(out); arrays.append(arr)
+        return pa.RecordBatch.from_arrays(arrays, names=names)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_agg_destroy(self._h)
+            self._h = None
+
+
+def cmp_mask(arr: pa.Array, op: int, literal) -> np.ndarray:
+    """NumPy-semantics comparison of a column with a Python scalar -> bool ndarray."""
+    keep = []
+    c = _col(arr, keep)
+    mask = np.zeros(len(arr), np.uint8)
+    is_f = isinstance(literal, float)
+    lib().orc_cmp_mask(ctypes.byref(c), op, int(is_f), float(literal), int(literal) if not is_f else 0,
+                       int(arr.null_count > 0), mask.ctypes.data)
+    return mask.astype(bool)
+
+
+def filter_batch(batch: pa.RecordBatch, mask: np.ndarray, mask_valid=None) -> pa.RecordBatch:
+    """RecordBatch.filter(mask, null_selection_behavior='emit_null') (record_batch.py:85-90)."""
+    L = lib()
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    mv = None if mask_valid is None else np.ascontiguousarray(mask_valid, dtype=np.uint8)
+    arrays = []
+    for arr in batch.columns:
+        keep = []
+        c = _col(arr, keep)
+        pt, _ = physical_type(arr.type)
+        out = np.zeros(len(arr), _NP[pt]); ov = np.zeros(len(arr), np.uint8)
+        k = L.orc_filter_col(ctypes.byref(c), m.ctypes.data, None if mv is None else mv.ctypes.data,
+                             out.ctypes.data, ov.ctypes.data)
+        arrays.append(_arrow_from(out[:k], ov[:k], arr.type))
+    return pa.RecordBatch.from_arrays(arrays, names=batch.schema.names)
+
+
+class OracleSort:
+    """Sort.next/sorted (sort.cpp:11-63): buffer batches, stable multi-key sort, take all columns."""
+
+    def __init__(self, cols, orders):
+        self.cols, self.orders, self.batches = list(cols), list(orders), []
+
+    def next(self, batch: pa.RecordBatch):
+        self.batches.append(batch)
+
+    def sort_indices(self, table: pa.Table) -> np.ndarray:
+        keep = []
+        cols = (_Col * len(self.cols))(*[_col(table.column(c), keep) for c in self.cols])
+        desc = (ctypes.c_int * len(self.cols))(*self.orders)
+        idx = np.zeros(table.num_rows, np.int64)
+        lib().orc_sort_indices(len(self.cols), cols, desc, table.num_rows, idx.ctypes.data)
+        return idx
+
+    def sorted(self) -> pa.RecordBatch:
+        table = pa.Table.from_batches(self.batches).combine_chunks()
+        idx = self.sort_indices(table)
+        arrays = []
+        for name in table.schema.names:
+            keep = []
+            arr = table.column(name)
+            arr = arr.chunk(0) if arr.num_chunks == 1 else pa.concat_arrays(arr.chunks) if arr.num_chunks else pa.array([], arr.type)
+            c = _col(arr, keep)
+            pt, _ = physical_type(arr.type)
+            out = np.zeros(len(idx), _NP[pt]); ov = np.zeros(len(idx), np.uint8)
+            lib().orc_take_col(ctypes.byref(c), idx.ctypes.data, len(idx), out.ctypes.data, ov.ctypes.data)
+            arrays.append(_arrow_from(out, ov, arr.type))
+        return pa.RecordBatch.from_arrays(arrays, names=table.schema.names)
