@@ -1,0 +1,226 @@
+/*
+ * vinum_hip.h -- C ABI of libvinum_hip.so, the MI355X (gfx950) operator library behind Vinum's
+ * native operator boundary.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers / sizes / Arrow C Data Interface structs
+ * and returns a status code (0 = ok; vnm_last_error() holds the message).  Nothing throws or aborts
+ * across the ABI (the reference aborts on a bad handle, vinum/core/vinum_lib.cpp:62-63).
+ * One handle = one HIP stream; handles are not thread-safe, distinct handles may be used from distinct
+ * threads.  Device pointers are plain `void*` (hipMalloc / torch .data_ptr()).
+ *
+ * Each block cites the reference interface it replaces (paths relative to the reference root).
+ */
+#ifndef VINUM_HIP_H
+#define VINUM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html) ---------- */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+    const char* format;
+    const char* name;
+    const char* metadata;
+    int64_t flags;
+    int64_t n_children;
+    struct ArrowSchema** children;
+    struct ArrowSchema* dictionary;
+    void (*release)(struct ArrowSchema*);
+    void* private_data;
+};
+struct ArrowArray {
+    int64_t length;
+    int64_t null_count;
+    int64_t offset;
+    int64_t n_buffers;
+    int64_t n_children;
+    const void** buffers;
+    struct ArrowArray** children;
+    struct ArrowArray* dictionary;
+    void (*release)(struct ArrowArray*);
+    void* private_data;
+};
+#endif
+
+/* ---- enums ---------------------------------------------------------------------------------- */
+/* physical column types; temporal Arrow types map to their storage integers */
+enum vnm_type { VNM_I8 = 0, VNM_I16, VNM_I32, VNM_I64, VNM_U8, VNM_U16, VNM_U32, VNM_U64, VNM_F32, VNM_F64 };
+/* replaces py::enum_<AggFuncType>  vinum/core/vinum_lib.cpp:25-32 (same order) */
+enum vnm_agg_func { VNM_COUNT_STAR = 0, VNM_COUNT, VNM_MIN, VNM_MAX, VNM_SUM, VNM_AVG };
+/* which operator class: vinum/core/aggregate.py:96-104 */
+enum vnm_agg_kind { VNM_ONE_GROUP = 0, VNM_SINGLE_NUMERICAL = 1, VNM_MULTI_NUMERICAL = 2 };
+/* replaces py::enum_<SortOrder>  vinum/core/vinum_lib.cpp:34-37 */
+enum vnm_sort_order { VNM_ASC = 0, VNM_DESC = 1 };
+/* comparison predicates: vinum/core/expressions.py:30-36 */
+enum vnm_cmp_op { VNM_EQ = 0, VNM_NE, VNM_GT, VNM_GE, VNM_LT, VNM_LE };
+/* arithmetic / bitwise expression opcodes: vinum/core/expressions.py:13-24 */
+enum vnm_expr_op {
+    VNM_EX_COL = 0,   /* push input column  (arg = column index)            */
+    VNM_EX_CONST_F,   /* push float literal (imm_f)                          */
+    VNM_EX_CONST_I,   /* push int literal   (imm_i)                          */
+    VNM_EX_ADD, VNM_EX_SUB, VNM_EX_MUL, VNM_EX_DIV, VNM_EX_MOD,   /* np.add .. np.mod         */
+    VNM_EX_NEG,                                                    /* np.negative              */
+    VNM_EX_BAND, VNM_EX_BOR, VNM_EX_BXOR, VNM_EX_BNOT              /* np.bitwise_* and ~x      */
+};
+/* column flags */
+#define VNM_FLAG_SUM32 1 /* time32: SUM accumulates and wraps in int32 (agg_func_factory.cpp:132-137) */
+
+/* ---- device column view ------------------------------------------------------------------------
+ * The GPU counterpart of the reference's ArrayIter family (vinum_cpp/src/common/array_iterators.h:
+ * 13-255): raw values buffer + optional validity bitmap + Arrow offset.  `values`/`validity` are
+ * DEVICE pointers to the start of the Arrow buffers (not offset-adjusted). */
+typedef struct vnm_dcol {
+    const void* values;
+    const uint8_t* validity; /* NULL = no nulls */
+    int64_t offset;
+    int64_t length;
+    int32_t type;  /* enum vnm_type */
+    int32_t flags; /* VNM_FLAG_* */
+} vnm_dcol;
+
+/* ---- library ------------------------------------------------------------------------------------ */
+/* replaces vinum_lib.import_pyarrow() (vinum/core/vinum_lib.cpp:22-23): one-time init; selects the
+ * HIP device.  Fails (non-zero) when no gfx950 device / HIP runtime is usable -- there is no CPU
+ * fallback anywhere in this library. */
+int vnm_init(int device_id);
+const char* vnm_last_error(void);
+int vnm_device_count(void);
+/* host-side statistics of the last operator call (kernel launches, bytes staged, ...); debugging aid */
+int vnm_device_synchronize(void);
+
+/* ---- filter: FilterOperator._kernel + RecordBatch.filter -----------------------------------------
+ * replaces vinum/core/algebra.py:119-123, vinum/arrow/record_batch.py:85-90 and the NumPy comparison
+ * lambdas vinum/core/expressions.py:30-36 for the `column <op> literal` predicate shape, fused:
+ * compare -> wave-ballot rank -> single-pass (decoupled look-back) compaction of every payload column.
+ * NULL predicate inputs compare False (they reach NumPy as NaN, record_batch.py:112-118), `!=` True.
+ *
+ * pred:      predicate column;  scalar_is_float selects dval (Python float literal) or ival (int).
+ * n_payload: columns to compact (the predicate column itself may be listed).
+ * out_values[i]: device buffer of >= length * width(type_i) bytes.
+ * out_valid[i]:  device byte-per-row validity (>= length bytes) or NULL when payload i has no validity.
+ * out_count: host int64, rows kept.  stream: hipStream_t or NULL (default stream). */
+int vnm_filter_cmp(const vnm_dcol* pred, int op, int scalar_is_float, double dval, int64_t ival,
+                   int n_payload, const vnm_dcol* payload, void** out_values, uint8_t** out_valid,
+                   int64_t* out_count, void* stream);
+/* generic boolean mask (1 byte / row, optional byte validity -> emit_null) -> compaction */
+int vnm_filter_mask(const uint8_t* mask, const uint8_t* mask_valid, int64_t length, int n_payload,
+                    const vnm_dcol* payload, void** out_values, uint8_t** out_valid, int64_t* out_count,
+                    void* stream);
+/* byte-per-row validity (as written by the filter) -> Arrow validity bitmap of (n + 7) / 8 bytes */
+int vnm_pack_validity(const uint8_t* valid_bytes, int64_t n, uint8_t* bitmap, void* stream);
+/* bytes needed for the look-back scratch of a filter over `length` rows */
+int64_t vnm_filter_scratch_bytes(int64_t length);
+
+/* ---- hash aggregate ------------------------------------------------------------------------------
+ * replaces  SingleNumericalHashAggregate / MultiNumericalHashAggregate / OneGroupAggregate
+ *           (vinum/core/vinum_lib.cpp:54-124; vinum_cpp/src/operators/aggregate/).
+ * Device level: keys / inputs are vnm_dcol views of HBM-resident columns. */
+typedef struct vnm_agg vnm_agg;
+
+/* in_col_ids (may be NULL): functions with equal ids read the same input column (they then share loads
+ * and accumulators, e.g. SUM(v) and AVG(v)); ignored for COUNT(*). */
+vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
+                        const int* in_types, const int* in_flags, const int* in_col_ids);
+void vnm_agg_destroy(vnm_agg* h);
+/* optional fused WHERE `pred <op> literal` evaluated inside the aggregate scan (no materialised
+ * filtered batch): Filter -> Aggregate of vinum/planner/planner.py:373-378,463-469 in one pass. */
+int vnm_agg_set_predicate(vnm_agg* h, int enabled, int op, int scalar_is_float, double dval, int64_t ival);
+/* expected number of groups (0 = unknown): sizes the table and picks the kernel strategy */
+int vnm_agg_set_hint(vnm_agg* h, int64_t expected_groups);
+/* BaseAggregate::Next (base_aggregate.cpp:23-45).  inputs[i] is the input column of func i (ignored for
+ * COUNT_STAR).  pred may be NULL when no predicate is set.  Asynchronous on `stream`. */
+int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs,
+                        const vnm_dcol* pred, void* stream);
+/* BaseAggregate::Result part 1: compact the table into dense device arrays; returns group count. */
+int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream);
+/* dense partial state (after finish), for the multi-GPU exchange: key words then accumulator words,
+ * each a device array of n_groups uint64.  n_key_words / n_acc_words describe the layout. */
+int vnm_agg_layout(vnm_agg* h, int* n_key_words, int* n_acc_words);
+int vnm_agg_dense_ptrs(vnm_agg* h, uint64_t** key_words, uint64_t** acc_words);
+/* merge dense partial states produced by another handle with the same spec (device pointers) */
+int vnm_agg_merge_device(vnm_agg* h, int64_t n, uint64_t* const* key_words, uint64_t* const* acc_words,
+                         void* stream);
+/* BaseAggregate::Result part 2 (+ agg funcs' Summarize, agg_funcs.h:72-80,358-397,482-491,519-540):
+ * D2H + host finalisation.  key j -> vals[n] raw 64-bit patterns + valid[n] bytes.
+ * func i -> cells of 16 bytes (decimal128 uses all 16), valid bytes; returns the output kind. */
+enum vnm_out_kind { VNM_OUT_U64 = 0, VNM_OUT_I64, VNM_OUT_F64, VNM_OUT_F32, VNM_OUT_DEC128, VNM_OUT_I32 };
+int vnm_agg_result_key(vnm_agg* h, int key_idx, uint64_t* vals, uint8_t* valid);
+int vnm_agg_result_func(vnm_agg* h, int func_idx, void* cells16, uint8_t* valid, int* out_kind);
+
+/* Host-only helpers (no GPU touched): how (functions, input types) lower onto 64-bit accumulator words
+ * with commutative merge kinds (0 add-u64, 1 add-f64, 2 min-u64, 3 max-u64), and the finalisation of one
+ * result column from dense accumulator words in HOST memory.  Used by the multi-GPU merge and unit-tested
+ * on CPU. */
+int vnm_agg_plan_host(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
+                      const int* in_types, const int* in_flags, const int* in_col_ids, int* n_key_words,
+                      int* n_acc_words, int* merge_kinds /* >= 24 ints */);
+int vnm_agg_finalize_host(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
+                          const int* in_types, const int* in_flags, const int* in_col_ids, int func_idx,
+                          int64_t n, const uint64_t* const* acc_words, void* cells16, uint8_t* valid,
+                          int* out_kind);
+
+/* Arrow level (host RecordBatches through the C Data Interface; columns are staged to HBM with
+ * pinned double-buffered DMA).  Same constructor arguments as the pybind classes. */
+typedef struct vnm_agg_op vnm_agg_op;
+vnm_agg_op* vnm_agg_op_create(int kind, int n_groupby, const char** groupby_cols, int n_aggcols,
+                              const char** agg_cols, int n_funcs, const int* func_types,
+                              const char** in_cols, const char** out_cols);
+int vnm_agg_op_next(vnm_agg_op* h, struct ArrowArray* batch, struct ArrowSchema* schema); /* consumes both */
+int vnm_agg_op_result(vnm_agg_op* h, struct ArrowArray* out, struct ArrowSchema* out_schema);
+void vnm_agg_op_destroy(vnm_agg_op* h);
+
+/* ---- sort: Sort.next / Sort.sorted ------------------------------------------------------------------
+ * replaces vinum/core/vinum_lib.cpp:126-142, vinum_cpp/src/operators/sort/sort.cpp:11-63
+ * (arrow::compute::SortIndices + Take).  Stable LSD radix sort on order-preserving key encodings;
+ * NaN after all numbers and NULL after NaN for both ASC and DESC. */
+int vnm_sort_indices(int n_keys, const vnm_dcol* keys, const int* orders, int64_t length,
+                     int64_t limit /* <=0: full sort; >0: only the first `limit` rows are needed */,
+                     int64_t* out_indices /* device, length entries (first `limit` valid) */, void* stream);
+int vnm_take(const vnm_dcol* col, const int64_t* indices, int64_t n, void* out_values, uint8_t* out_valid,
+             void* stream);
+typedef struct vnm_sort_op vnm_sort_op;
+vnm_sort_op* vnm_sort_op_create(int n, const char** cols, const int* orders);
+int vnm_sort_op_next(vnm_sort_op* h, struct ArrowArray* batch, struct ArrowSchema* schema);
+int vnm_sort_op_sorted(vnm_sort_op* h, int64_t limit, struct ArrowArray* out, struct ArrowSchema* out_schema);
+void vnm_sort_op_destroy(vnm_sort_op* h);
+
+/* ---- projection: arithmetic expression evaluation ----------------------------------------------------
+ * replaces the NumPy ufunc dispatch vinum/core/expressions.py:13-24 as evaluated by
+ * VectorizedExpression.evaluate (vinum/core/base.py:105-125,145-151) and ProjectOperator._kernel
+ * (vinum/core/algebra.py:52-64): one fused kernel per output expression, no temporaries.
+ * Program = postfix opcode stream.  NumPy promotion: int op int -> int64 (wraparound), `/` -> float64,
+ * int op float -> float64, `%` = floor-mod (sign of divisor). */
+typedef struct vnm_expr_ins {
+    int32_t op;  /* enum vnm_expr_op */
+    int32_t arg; /* column index for VNM_EX_COL */
+    double imm_f;
+    int64_t imm_i;
+} vnm_expr_ins;
+/* out_type: VNM_F64 or VNM_I64 (returned); out_values device buffer of length*8 bytes */
+int vnm_project(int n_ins, const vnm_expr_ins* program, int n_cols, const vnm_dcol* cols, int64_t length,
+                void* out_values, int* out_type, void* stream);
+
+/* ---- TableBatchReader -----------------------------------------------------------------------------
+ * replaces vinum/core/vinum_lib.cpp:144-165 / vinum_cpp/src/operators/table_batch_reader.cpp:5-16.
+ * Host-side zero-copy slicing lives in the Python shim (pyarrow Table.slice); this entry stages one
+ * host column into HBM through the library's pinned double buffer and returns the device view. */
+int vnm_stage_column(const void* host_values, const uint8_t* host_validity, int64_t offset, int64_t length,
+                     int32_t type, vnm_dcol* out, void* stream);
+int vnm_free_column(vnm_dcol* col);
+
+/* device memory helpers for hosts without a GPU allocator of their own (ctypes / cgo bindings) */
+void* vnm_malloc(int64_t bytes);
+int vnm_free(void* p);
+int vnm_memcpy_h2d(void* dst, const void* src, int64_t bytes);
+int vnm_memcpy_d2h(void* dst, const void* src, int64_t bytes);
+int vnm_memset(void* dst, int value, int64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VINUM_HIP_H */

@@ -443,7 +443,7 @@ int orc_agg_func(const orc_agg *a, int f, void *vals_, uint8_t *valid) {
  * NumPy semantics restated: a column WITH nulls reaches NumPy as float64 with NaN (record_batch.py:
  * 112-118) so every comparison on a null row is False (!= is True); an int column without nulls
  * compares as integers against an int literal and as float64 against a float literal; a float32
- * column compares in float32 against a (weak) Python scalar.
+ * column (with or without nulls) compares in float32 against a (weak) Python scalar.
  * ---------------------------------------------------------------------------------------- */
 enum { ORC_EQ = 0, ORC_NE, ORC_GT, ORC_GE, ORC_LT, ORC_LE };
 
@@ -464,8 +464,8 @@ void orc_cmp_mask(const orc_col *c, int op, int scalar_is_float, double dval, in
     int64_t n = c->length;
     for (int64_t i = 0; i < n; i++) {
         int r;
-        if (c->type == ORC_F32 && !has_nulls) {
-            float a = ((const float *)c->values)[c->offset + i];
+        if (c->type == ORC_F32) { /* float32 stays float32 in NumPy, NULL -> NaN */
+            float a = (has_nulls && col_is_null(c, i)) ? NAN : ((const float *)c->values)[c->offset + i];
             float b = scalar_is_float ? (float)dval : (float)ival;
             CMP_BODY(a, b)
         } else if (is_float_type(c->type) || has_nulls || scalar_is_float) {

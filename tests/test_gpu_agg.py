@@ -1,0 +1,124 @@
+"""GPU parity: hash group-by aggregate (HIP, through the C ABI) vs golden vectors of the real reference,
+the reference's gtest known answers, and the oracle on seeded inputs."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from tests import util
+from tests.golden import gtest_fixtures as G
+
+pytestmark = pytest.mark.gpu
+MAN = util.manifest()
+
+
+def gpu_aggregate(kind, groupby, agg_cols, funcs, batches, predicate=None, expected_groups=0) -> pa.RecordBatch:
+    """Drive the device-level C ABI the way AggregateOperator drives the reference classes
+    (vinum/core/aggregate.py:114-124): next(batch) per batch, one result()."""
+    from vinum_amd.device import DeviceColumn
+    from vinum_amd import ops
+    schema = batches[0].schema
+    key_types = [schema.field(c).type for c in groupby]
+    names = schema.names
+    fspec = [(f, names.index(col) if col else None, schema.field(col).type if col else None) for f, col, _ in funcs]
+    agg = ops.DeviceAggregate(kind, key_types, fspec, expected_groups=expected_groups)
+    if predicate:
+        agg.set_predicate(predicate[1], predicate[2])
+    for b in batches:
+        cache = {}
+        def dev(name):
+            if name not in cache:
+                cache[name] = DeviceColumn.from_arrow(b.column(names.index(name)))
+            return cache[name]
+        keys = [dev(c) for c in groupby]
+        inputs = [dev(col) if col else None for _, col, _ in funcs]
+        pred = dev(predicate[0]) if predicate else None
+        agg.next(keys, inputs, pred=pred, nrows=b.num_rows)
+    res = agg.result_arrays([groupby.index(c) for c in agg_cols], agg_cols, [f[2] for f in funcs])
+    agg.close()
+    return res
+
+
+@pytest.mark.parametrize("name", sorted(G.CASES))
+def test_gtest_known_answers(name):
+    c = G.CASES[name]
+    table = G.table_for(c)
+    for kind in c["kinds"]:
+        res = gpu_aggregate(kind, c["groupby"], c["agg_cols"], c["funcs"], G.feed_batches(table))
+        res = G.sort_result(res, c["sort_cols"])
+        assert res.num_columns == len(c["expected"])
+        for i, exp in enumerate(c["expected"]):
+            # float SUM/AVG over <= 3 addends: order may differ from the reference -> 1 ULP (north_star tolerance)
+            util.assert_col_equal(res.column(i), exp, f"{name}[{kind}] col {i}", ulps=1)
+
+
+@pytest.mark.parametrize("case", MAN["agg"], ids=lambda c: c["name"])
+def test_reference_golden(case):
+    table = util.read_ipc(case["input"])
+    expected = util.read_ipc(case["expected"])
+    funcs = [tuple(f) for f in case["funcs"]]
+    res = gpu_aggregate(case["kind"], case["groupby"], case["agg_cols"], funcs, util.sliced_batches(table, case["chunk"]))
+    util.assert_agg_equal(res, expected, funcs, case["agg_cols"], what=case["name"])
+
+
+@pytest.mark.parametrize("groups", [1, 7, 1000, 5000, 200_000])
+@pytest.mark.parametrize("with_pred", [False, True])
+def test_filter_groupby_vs_oracle(groups, with_pred):
+    """config-3 shape: SELECT k, sum(v), avg(v), count(*) [WHERE v > X] GROUP BY k on quantised values
+    (every partial sum exactly representable -> bit-exact float aggregates)."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(groups)
+    n = 600_000
+    k = rng.integers(0, groups, n).astype(np.int64) * 7919 - 1000
+    v = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
+    t = pa.table({"k": pa.array(k, mask=rng.random(n) < 0.01), "v": pa.array(v, mask=rng.random(n) < 0.05)})
+    funcs = [(O.SUM, "v", "sum_v"), (O.AVG, "v", "avg_v"), (O.COUNT_STAR, "", "n"), (O.MIN, "v", "min_v"),
+             (O.MAX, "v", "max_v"), (O.COUNT, "v", "cnt_v")]
+    batches = util.sliced_batches(t, 250_000)
+    pred = ("v", ">", 64.0) if with_pred else None
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=pred)
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in batches:
+        if with_pred:
+            mask = O.cmp_mask(b.column(1), O.GT, 64.0)
+            b = O.filter_batch(b, mask)
+        o.next(b)
+    util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"G={groups} pred={with_pred}")
+
+
+def test_key_identity_rules():
+    """+0.0 / -0.0 are different groups, NaNs group by payload, NULL is its own group (emitted last on the
+    single-key path), the all-ones key pattern is a legal key."""
+    from oracle import oracle as O
+    nan1 = np.frombuffer(np.uint64(0x7FF8000000000001).tobytes(), np.float64)[0]
+    nan2 = np.frombuffer(np.uint64(0x7FF8000000000002).tobytes(), np.float64)[0]
+    allones = np.frombuffer(np.uint64(0xFFFFFFFFFFFFFFFF).tobytes(), np.float64)[0]
+    kf = np.array([0.0, -0.0, nan1, nan2, nan1, 1.5, allones, allones, 0.0, -0.0] * 50)
+    mask = np.zeros(len(kf), bool); mask[::7] = True
+    v = np.arange(len(kf), dtype=np.int64)
+    t = pa.table({"k": pa.array(kf, mask=mask), "v": pa.array(v)})
+    funcs = [(O.COUNT_STAR, "", "n"), (O.SUM, "v", "s")]
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, t.to_batches())
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in t.to_batches():
+        o.next(b)
+    exp = o.result()
+    util.assert_agg_equal(got, exp, funcs, ["k"], what="key identity")
+    assert got.column(0)[got.num_rows - 1].as_py() is None  # NULL group last
+
+    ki = np.array([-1, 0, 2**63 - 1, -2**63, -1, 5], dtype=np.int64)
+    t2 = pa.table({"k": pa.array(ki), "v": pa.array(np.arange(6, dtype=np.int64))})
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, t2.to_batches())
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in t2.to_batches():
+        o.next(b)
+    util.assert_agg_equal(got, o.result(), funcs, ["k"], what="int key -1 == EMPTY sentinel")
+
+
+def test_empty_inputs():
+    from oracle import oracle as O
+    empty = pa.RecordBatch.from_arrays([pa.array([], pa.int64()), pa.array([], pa.float64())], names=["k", "v"])
+    funcs = [(O.COUNT_STAR, "", "n"), (O.SUM, "v", "s"), (O.MIN, "v", "mn")]
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, [empty])
+    assert got.num_rows == 0
+    got = gpu_aggregate(O.ONE_GROUP, [], [], funcs, [empty])
+    assert got.to_pydict() == {"n": [0], "s": [None], "mn": [None]}

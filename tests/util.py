@@ -120,3 +120,31 @@ def assert_batches_equal(actual, expected, key_names=None, float_ulps=0, positio
         assert actual.schema.names == expected.schema.names, f"{what}: {actual.schema.names} != {expected.schema.names}"
     for i in range(actual.num_columns):
         assert_col_equal(actual.column(i), expected.column(i), f"{what}:{actual.schema.names[i]}", ulps=float_ulps)
+
+
+def assert_agg_equal(actual, expected, funcs, key_names, exact_float_inputs=("v_f64q", "fare", "v"), what=""):
+    """Aggregate parity: bit-exact for keys, counts, integer sums, decimals, MIN/MAX and float sums over
+    exactly-representable (quantised) inputs; SUM/AVG over arbitrary floats are order dependent (the
+    reference adds in row order, agg_funcs.h:294-305) so those columns use rtol=1e-12, atol=1e-9
+    (the reference's own tests use np.allclose defaults, rtol=1e-5: vinum/tests/conftest.py:128-142)."""
+    actual = canon(actual, key_names)
+    expected = canon(expected, key_names)
+    assert actual.num_rows == expected.num_rows, f"{what}: rows {actual.num_rows} != {expected.num_rows}"
+    assert actual.schema.names == expected.schema.names, f"{what}: {actual.schema.names} != {expected.schema.names}"
+    loose = set()
+    for f, col, out in funcs:
+        if f in (4, 5) and col and col not in exact_float_inputs:
+            loose.add(out)
+    for i, name in enumerate(actual.schema.names):
+        a, e = actual.column(i), expected.column(i)
+        if name in loose and pa.types.is_floating(e.type):
+            assert a.type == e.type, f"{what}:{name}: type {a.type} != {e.type}"
+            va, _ = _bits(a)
+            ve, _ = _bits(e)
+            assert np.array_equal(va, ve), f"{what}:{name}: validity differs"
+            fa = a.fill_null(0).to_numpy(zero_copy_only=False).astype(np.float64)
+            fe = e.fill_null(0).to_numpy(zero_copy_only=False).astype(np.float64)
+            ok = np.isclose(fa, fe, rtol=1e-12, atol=1e-9, equal_nan=True)
+            assert ok.all(), f"{what}:{name}: {(~ok).sum()} rows beyond rtol=1e-12/atol=1e-9, e.g. {fa[~ok][0]!r} vs {fe[~ok][0]!r}"
+        else:
+            assert_col_equal(a, e, f"{what}:{name}")

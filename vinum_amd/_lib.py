@@ -1,0 +1,140 @@
+"""ctypes binding of libvinum_hip.so (include/vinum_hip.h).
+
+There is NO CPU fallback: if the shared library is missing, or no MI355X/HIP device is usable,
+loading / initialisation raises.  Build the library with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C vinum_amd/csrc``.
+"""
+import ctypes
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvinum_hip.so")
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_void = ctypes.c_void_p
+c_dbl = ctypes.c_double
+
+
+class DCol(ctypes.Structure):
+    """struct vnm_dcol"""
+    _fields_ = [("values", c_void), ("validity", c_void), ("offset", c_i64), ("length", c_i64),
+                ("type", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+class ExprIns(ctypes.Structure):
+    """struct vnm_expr_ins"""
+    _fields_ = [("op", ctypes.c_int32), ("arg", ctypes.c_int32), ("imm_f", c_dbl), ("imm_i", c_i64)]
+
+
+# enums (include/vinum_hip.h)
+I8, I16, I32, I64, U8, U16, U32, U64, F32, F64 = range(10)
+COUNT_STAR, COUNT, MIN, MAX, SUM, AVG = range(6)
+ONE_GROUP, SINGLE_NUMERICAL, MULTI_NUMERICAL = range(3)
+ASC, DESC = 0, 1
+EQ, NE, GT, GE, LT, LE = range(6)
+(EX_COL, EX_CONST_F, EX_CONST_I, EX_ADD, EX_SUB, EX_MUL, EX_DIV, EX_MOD, EX_NEG, EX_BAND, EX_BOR, EX_BXOR,
+ EX_BNOT) = range(13)
+OUT_U64, OUT_I64, OUT_F64, OUT_F32, OUT_DEC128, OUT_I32 = range(6)
+FLAG_SUM32 = 1
+
+# name -> (restype, argtypes); mirrors include/vinum_hip.h one to one
+PROTOTYPES = {
+    "vnm_init": (c_int, [c_int]),
+    "vnm_last_error": (ctypes.c_char_p, []),
+    "vnm_device_count": (c_int, []),
+    "vnm_device_synchronize": (c_int, []),
+    "vnm_filter_cmp": (c_int, [c_void, c_int, c_int, c_dbl, c_i64, c_int, c_void, c_void, c_void, c_void, c_void]),
+    "vnm_filter_mask": (c_int, [c_void, c_void, c_i64, c_int, c_void, c_void, c_void, c_void, c_void]),
+    "vnm_pack_validity": (c_int, [c_void, c_i64, c_void, c_void]),
+    "vnm_filter_scratch_bytes": (c_i64, [c_i64]),
+    "vnm_agg_create": (c_void, [c_int, c_int, c_void, c_int, c_void, c_void, c_void, c_void]),
+    "vnm_agg_destroy": (None, [c_void]),
+    "vnm_agg_set_predicate": (c_int, [c_void, c_int, c_int, c_int, c_dbl, c_i64]),
+    "vnm_agg_set_hint": (c_int, [c_void, c_i64]),
+    "vnm_agg_next_device": (c_int, [c_void, c_i64, c_void, c_void, c_void, c_void]),
+    "vnm_agg_finish": (c_int, [c_void, c_void, c_void]),
+    "vnm_agg_layout": (c_int, [c_void, c_void, c_void]),
+    "vnm_agg_dense_ptrs": (c_int, [c_void, c_void, c_void]),
+    "vnm_agg_merge_device": (c_int, [c_void, c_i64, c_void, c_void, c_void]),
+    "vnm_agg_result_key": (c_int, [c_void, c_int, c_void, c_void]),
+    "vnm_agg_result_func": (c_int, [c_void, c_int, c_void, c_void, c_void]),
+    "vnm_agg_plan_host": (c_int, [c_int, c_int, c_void, c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
+    "vnm_agg_finalize_host": (c_int, [c_int, c_int, c_void, c_int, c_void, c_void, c_void, c_void, c_int, c_i64,
+                                      c_void, c_void, c_void, c_void]),
+    "vnm_agg_op_create": (c_void, [c_int, c_int, c_void, c_int, c_void, c_int, c_void, c_void, c_void]),
+    "vnm_agg_op_next": (c_int, [c_void, c_void, c_void]),
+    "vnm_agg_op_result": (c_int, [c_void, c_void, c_void]),
+    "vnm_agg_op_destroy": (None, [c_void]),
+    "vnm_sort_indices": (c_int, [c_int, c_void, c_void, c_i64, c_i64, c_void, c_void]),
+    "vnm_take": (c_int, [c_void, c_void, c_i64, c_void, c_void, c_void]),
+    "vnm_sort_op_create": (c_void, [c_int, c_void, c_void]),
+    "vnm_sort_op_next": (c_int, [c_void, c_void, c_void]),
+    "vnm_sort_op_sorted": (c_int, [c_void, c_i64, c_void, c_void]),
+    "vnm_sort_op_destroy": (None, [c_void]),
+    "vnm_project": (c_int, [c_int, c_void, c_int, c_void, c_i64, c_void, c_void, c_void]),
+    "vnm_stage_column": (c_int, [c_void, c_void, c_i64, c_i64, ctypes.c_int32, c_void, c_void]),
+    "vnm_free_column": (c_int, [c_void]),
+    "vnm_malloc": (c_void, [c_i64]),
+    "vnm_free": (c_int, [c_void]),
+    "vnm_memcpy_h2d": (c_int, [c_void, c_void, c_i64]),
+    "vnm_memcpy_d2h": (c_int, [c_void, c_void, c_i64]),
+    "vnm_memset": (c_int, [c_void, c_int, c_i64]),
+}
+
+_lib = None
+_inited = False
+
+
+class VinumHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libvinum_hip.so and attach prototypes.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VinumHipError(
+            f"{LIB_PATH} is missing: build it (make -C vinum_amd/csrc). vinum_amd has no CPU fallback.")
+    # If torch is (or will be) in the process, import it first so both share ONE HIP runtime
+    # (torch wheels bundle libamdhip64.so.7; ours binds by the same soname).
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def lib():
+    """Loaded AND initialised library (selects the current HIP device).  Raises without a GPU."""
+    global _inited
+    L = load()
+    if not _inited:
+        dev = -1
+        if "torch" in sys.modules:
+            import torch
+            if torch.cuda.is_available():
+                dev = torch.cuda.current_device()
+        if L.vnm_init(dev) != 0:
+            raise VinumHipError(L.vnm_last_error().decode())
+        _inited = True
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise VinumHipError(load().vnm_last_error().decode())
+
+
+def last_error():
+    return load().vnm_last_error().decode()

@@ -1,0 +1,904 @@
+// Hash group-by aggregate for gfx950.
+//
+// Replaces BaseAggregate::Next's scalar row loop (vinum_cpp/src/operators/aggregate/base_aggregate.cpp:
+// 23-45), the robin_hood maps of Single/MultiNumericalHashAggregate (single_numerical_hash_aggregate.cpp:
+// 15-46, multi_numerical_hash_aggregate.cpp:17-43) and OneGroupAggregate (one_group_aggregate.cpp:9-26).
+//
+// Design facts measured on MI355X (tools/microbench.hip, profiles/microbench_r01.txt):
+//   * device-scope atomics top out at ~24 G/s regardless of table size  -> never one per row;
+//   * LDS atomics sustain > 1 T row-updates/s chip-wide                  -> every row lands in LDS;
+//   * a grid of 8 x 256 CUs grid-striding 16 B/lane streams 6.3 TB/s.
+// So rows are pre-aggregated in a per-workgroup LDS hash table (keys + 64-bit accumulator words that
+// merge commutatively); only table flushes touch the HBM-resident table, with agent-scope atomics.
+// The fused WHERE predicate is evaluated in the scan, so no filtered batch is ever materialised.
+#include "vnm_agg.hpp"
+
+namespace vnm {
+
+constexpr uint64_t EMPTY = ~0ULL;
+constexpr uint64_t LOCKED = ~0ULL - 1;
+constexpr int AGG_BLOCK = 1024;        // LDS kernel: 16 waves, one workgroup per CU
+constexpr int AGG_ROWS_PER_THREAD = 2;
+constexpr int AGG_TILE = AGG_BLOCK * AGG_ROWS_PER_THREAD;
+constexpr int AGG_LDS_BUDGET = 128 * 1024;
+constexpr int AGG_MAX_PROBES = 48;
+constexpr int OG_BLOCK = 256;
+
+// HBM-resident table: tag[] (the key itself on the single-key path), optional wide key words, and
+// SoA accumulator words.  Arrays have cap + 2 entries: [cap] = the group whose key equals the EMPTY
+// sentinel, [cap + 1] = the NULL-key group (single_numerical_hash_aggregate.cpp:24-32).
+struct GTable {
+    uint64_t* tag;
+    uint64_t* keyw;  // kwt * stride (wide keys only)
+    uint64_t* acc;   // n_words * stride
+    uint64_t cap;    // power of two
+    uint64_t stride; // cap + 2
+    unsigned long long* ctl;  // [0] ticket  [1] overflow flag  [2] fill (groups in table)  [3] dense count
+    int kwt;         // wide key words (0 on the single-key path)
+    int n_words;
+};
+
+struct AggArgs {
+    AggPlan plan;
+    vnm_dcol keys[AGG_MAX_KEYS];
+    vnm_dcol cols[AGG_MAX_COLS];
+    vnm_dcol pred;
+    Predicate p;
+    GTable g;
+    int64_t nrows;
+    int64_t ntiles;
+    int64_t fill_limit;   // take a new tile only while fill + margin <= fill_limit
+    int64_t margin;
+    int lds_slots;
+};
+
+// ---- global table primitives ------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ld_agent(const uint64_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint64_t* p, uint64_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void g_merge(uint64_t* p, int mk, uint64_t v) {
+    switch (mk) {
+        case M_ADD_U64: __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
+        case M_ADD_F64: __hip_atomic_fetch_add((double*)p, __longlong_as_double((long long)v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
+        case M_MIN_U64: __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
+        default: __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
+    }
+}
+__device__ __forceinline__ void l_merge(uint64_t* p, int mk, uint64_t v) {
+    switch (mk) {
+        case M_ADD_U64: __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break;
+        case M_ADD_F64: __hip_atomic_fetch_add((double*)p, __longlong_as_double((long long)v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break;
+        case M_MIN_U64: __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break;
+        default: __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break;
+    }
+}
+
+// single 64-bit key: the tag word IS the key; claim by CAS from EMPTY
+__device__ __forceinline__ uint64_t gt_find_single(const GTable& g, uint64_t key) {
+    const uint64_t mask = g.cap - 1;
+    uint64_t h = hash_u64(key) & mask;
+    for (;;) {
+        uint64_t k = ld_agent(&g.tag[h]);
+        if (k == key) return h;
+        if (k == EMPTY) {
+            uint64_t expected = EMPTY;
+            if (__hip_atomic_compare_exchange_strong(&g.tag[h], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+                atomicAdd(&g.ctl[2], 1ULL);
+                return h;
+            }
+            if (expected == key) return h;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ uint64_t wide_tag(const uint64_t* kw, int n) {
+    uint64_t h = 0x9E3779B97F4A7C15ULL * (uint64_t)n;
+    for (int i = 0; i < n; i++) {
+        uint64_t x = kw[i];
+        h ^= (uint64_t)hash_u64(x) * 0x9E3779B1ULL + ((uint64_t)hash_u64(x ^ 0x5bd1e995) << 32) + (h << 6) + (h >> 2);
+    }
+    return h & 0x7FFFFFFFFFFFFFFFULL;
+}
+
+// wide keys: tag = 63-bit hash; EMPTY -> LOCKED -> tag.  The claimer publishes the key words with
+// write-through agent-scope stores, drains them, then publishes the tag (no lane ever waits inside the
+// critical section, so same-wave spinners cannot deadlock).
+__device__ __forceinline__ uint64_t gt_find_wide(const GTable& g, const uint64_t* kw, uint64_t tagv) {
+    const uint64_t mask = g.cap - 1;
+    uint64_t h = (tagv ^ (tagv >> 29)) & mask;
+    for (;;) {
+        uint64_t t = ld_agent(&g.tag[h]);
+        if (t == tagv) {
+            bool eq = true;
+            for (int i = 0; i < g.kwt; i++) eq = eq && (ld_agent(&g.keyw[(uint64_t)i * g.stride + h]) == kw[i]);
+            if (eq) return h;
+            h = (h + 1) & mask;
+            continue;
+        }
+        if (t == EMPTY) {
+            uint64_t expected = EMPTY;
+            if (__hip_atomic_compare_exchange_strong(&g.tag[h], &expected, LOCKED, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+                for (int i = 0; i < g.kwt; i++) st_agent(&g.keyw[(uint64_t)i * g.stride + h], kw[i]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                st_agent(&g.tag[h], tagv);
+                atomicAdd(&g.ctl[2], 1ULL);
+                return h;
+            }
+            continue;  // someone else is claiming this slot: look at it again
+        }
+        if (t == LOCKED) continue;
+        h = (h + 1) & mask;
+    }
+}
+
+// ---- per-row accumulator contributions ----------------------------------------------------------------
+// Returns false when the op contributes nothing for this row (NULL input); otherwise the value to merge.
+__device__ __forceinline__ bool op_value(const AccOp& op, const vnm_dcol* cols, int64_t row, uint64_t* out) {
+    if (op.kind == A_COUNT_ROWS) { *out = 1; return true; }
+    const vnm_dcol& c = cols[op.col];
+    if (!col_valid(c, row)) return false;
+    switch (op.kind) {
+        case A_COUNT_VALID: *out = 1; return true;
+        case A_SUM_F64: *out = (uint64_t)__double_as_longlong(col_f64(c, row)); return true;
+        case A_SUM_I64: *out = (uint64_t)col_i64(c, row); return true;
+        case A_SUM_LO32: *out = (uint64_t)col_i64(c, row) & 0xFFFFFFFFULL; return true;
+        case A_SUM_HI32S: *out = (uint64_t)(col_i64(c, row) >> 32); return true;
+        case A_SUM_HI32U: *out = (uint64_t)col_i64(c, row) >> 32; return true;
+        default:  // A_MIN / A_MAX on the order-preserving encoding
+            if (type_is_float(c.type)) *out = enc_f64(col_f64(c, row));
+            else if (type_is_unsigned(c.type)) *out = (uint64_t)col_i64(c, row);
+            else *out = enc_i64(col_i64(c, row));
+            return true;
+    }
+}
+
+// take the next tile while the HBM table has room for everything in flight; otherwise raise the overflow
+// flag so the host grows the table and resumes from the ticket
+__device__ __forceinline__ int64_t next_tile(const AggArgs& a) {
+    unsigned long long fill = __hip_atomic_load(&a.g.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int64_t)fill + a.margin > a.fill_limit) {
+        __hip_atomic_store(&a.g.ctl[1], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return -1;
+    }
+    // the ticket only advances when the tile WILL be processed: compare-and-swap so an exhausted or
+    // aborted scan leaves ctl[0] == number of tiles handed out
+    unsigned long long t = __hip_atomic_load(&a.g.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if ((int64_t)t >= a.ntiles) return -1;
+        if (__hip_atomic_compare_exchange_strong(&a.g.ctl[0], &t, t + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT))
+            return (int64_t)t;
+    }
+}
+
+// =======================================================================================================
+// Kernel 1: single 64-bit key, LDS pre-aggregation, generic accumulator program.
+// LDS: lkey[S+2] then lacc[w][S+2].  Slot S = key equal to the EMPTY sentinel, slot S+1 = NULL key.
+// =======================================================================================================
+__device__ __forceinline__ void lds_flush(const AggArgs& a, uint64_t* lkey, uint64_t* lacc, int S, int tid, int nthreads) {
+    const int stride = S + 2;
+    const int W = a.plan.n_words;
+    for (int i = tid; i < stride; i += nthreads) {
+        uint64_t k = lkey[i];
+        if (k == EMPTY) continue;
+        uint64_t slot;
+        if (i < S) slot = gt_find_single(a.g, k);
+        else {
+            slot = a.g.cap + (uint64_t)(i - S);
+            if (ld_agent(&a.g.tag[slot]) == EMPTY) st_agent(&a.g.tag[slot], 0);
+        }
+        for (int w = 0; w < W; w++) {
+            uint64_t v = lacc[w * stride + i];
+            int mk = a.plan.merge[w];
+            if (v != merge_init(mk)) g_merge(&a.g.acc[(uint64_t)w * a.g.stride + slot], mk, v);
+            lacc[w * stride + i] = merge_init(mk);
+        }
+        lkey[i] = EMPTY;
+    }
+}
+
+__global__ __launch_bounds__(AGG_BLOCK) void agg_lds_kernel(AggArgs a) {
+    extern __shared__ uint64_t lds[];
+    __shared__ unsigned s_fill;
+    __shared__ int64_t s_tile;
+    const int S = a.lds_slots;
+    const int stride = S + 2;
+    const int W = a.plan.n_words;
+    uint64_t* lkey = lds;
+    uint64_t* lacc = lds + stride;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < stride; i += AGG_BLOCK) lkey[i] = EMPTY;
+    for (int w = 0; w < W; w++) {
+        uint64_t init = merge_init(a.plan.merge[w]);
+        for (int i = tid; i < stride; i += AGG_BLOCK) lacc[w * stride + i] = init;
+    }
+    if (tid == 0) s_fill = 0;
+    __syncthreads();
+
+    const unsigned flush_at = (unsigned)(S * 7 / 10);
+    const uint32_t smask = (uint32_t)S - 1;
+    const vnm_dcol& kc = a.keys[0];
+    for (;;) {
+        if (tid == 0) s_tile = next_tile(a);
+        __syncthreads();
+        const int64_t tile = s_tile;
+        if (tile < 0) break;
+#pragma unroll
+        for (int r = 0; r < AGG_ROWS_PER_THREAD; r++) {
+            const int64_t row = tile * AGG_TILE + (int64_t)r * AGG_BLOCK + tid;
+            if (row >= a.nrows) continue;
+            if (a.p.enabled && !pred_eval(a.p, a.pred, row)) continue;
+            int slot = -1;
+            uint64_t key = 0;
+            if (!col_valid(kc, row)) {
+                slot = S + 1;
+                lkey[slot] = 0;
+            } else {
+                key = col_key_bits(kc, row);
+                if (key == EMPTY) {
+                    slot = S;
+                    lkey[slot] = 0;
+                } else {
+                    uint32_t h = hash_u64(key) & smask;
+                    for (int probe = 0; probe < AGG_MAX_PROBES; probe++) {
+                        uint64_t k = *(volatile uint64_t*)&lkey[h];
+                        if (k == key) { slot = (int)h; break; }
+                        if (k == EMPTY) {
+                            uint64_t expected = EMPTY;
+                            if (__hip_atomic_compare_exchange_strong(&lkey[h], &expected, key, __ATOMIC_RELAXED,
+                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                                atomicAdd(&s_fill, 1u);
+                                slot = (int)h;
+                                break;
+                            }
+                            if (expected == key) { slot = (int)h; break; }
+                        }
+                        h = (h + 1) & smask;
+                    }
+                }
+            }
+            if (slot >= 0) {
+                for (int o = 0; o < a.plan.n_ops; o++) {
+                    const AccOp& op = a.plan.ops[o];
+                    uint64_t v;
+                    if (op_value(op, a.cols, row, &v)) l_merge(&lacc[op.word * stride + slot], a.plan.merge[op.word], v);
+                }
+            } else {
+                // LDS table saturated for this key: go straight to the HBM table
+                uint64_t gs = gt_find_single(a.g, key);
+                for (int o = 0; o < a.plan.n_ops; o++) {
+                    const AccOp& op = a.plan.ops[o];
+                    uint64_t v;
+                    if (op_value(op, a.cols, row, &v)) g_merge(&a.g.acc[(uint64_t)op.word * a.g.stride + gs], a.plan.merge[op.word], v);
+                }
+            }
+        }
+        __syncthreads();
+        if (s_fill > flush_at) {
+            lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK);
+            __syncthreads();
+            if (tid == 0) s_fill = 0;
+        }
+    }
+    lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK);
+}
+
+// =======================================================================================================
+// Kernel 2: wide (multi-column) keys.  Key words = n_keys values (NULL -> 0) + 1 null-mask word, which is
+// exactly IntKeyValue equality (multi_numerical_hash_aggregate.h:11-18).  Rows go to the HBM table.
+// =======================================================================================================
+__global__ __launch_bounds__(256) void agg_wide_kernel(AggArgs a) {
+    __shared__ int64_t s_tile;
+    const int tid = threadIdx.x;
+    const int nk = a.plan.n_keys;
+    for (;;) {
+        if (tid == 0) s_tile = next_tile(a);
+        __syncthreads();
+        const int64_t tile = s_tile;
+        __syncthreads();
+        if (tile < 0) break;
+        for (int r = 0; r < AGG_TILE / 256; r++) {
+            const int64_t row = tile * AGG_TILE + (int64_t)r * 256 + tid;
+            if (row >= a.nrows) continue;
+            if (a.p.enabled && !pred_eval(a.p, a.pred, row)) continue;
+            uint64_t kw[AGG_MAX_KEYS + 1];
+            uint64_t nullmask = 0;
+#pragma unroll
+            for (int j = 0; j < AGG_MAX_KEYS; j++) {
+                if (j < nk) {
+                    bool ok = col_valid(a.keys[j], row);
+                    kw[j] = ok ? col_key_bits(a.keys[j], row) : 0;
+                    if (!ok) nullmask |= 1ULL << j;
+                }
+            }
+            kw[nk] = nullmask;
+            uint64_t gs = gt_find_wide(a.g, kw, wide_tag(kw, nk + 1));
+            for (int o = 0; o < a.plan.n_ops; o++) {
+                const AccOp& op = a.plan.ops[o];
+                uint64_t v;
+                if (op_value(op, a.cols, row, &v)) g_merge(&a.g.acc[(uint64_t)op.word * a.g.stride + gs], a.plan.merge[op.word], v);
+            }
+        }
+    }
+}
+
+// =======================================================================================================
+// Kernel 3: no GROUP BY.  Per-lane private accumulators in LDS (no atomics, no conflicts), block tree
+// reduction, one agent-scope atomic per word per block into group slot 0.
+// =======================================================================================================
+__device__ __forceinline__ uint64_t merge_vals(int mk, uint64_t x, uint64_t y) {
+    switch (mk) {
+        case M_ADD_U64: return x + y;
+        case M_ADD_F64: return (uint64_t)__double_as_longlong(__longlong_as_double((long long)x) + __longlong_as_double((long long)y));
+        case M_MIN_U64: return x < y ? x : y;
+        default: return x > y ? x : y;
+    }
+}
+
+__global__ __launch_bounds__(OG_BLOCK) void agg_onegroup_kernel(AggArgs a) {
+    extern __shared__ uint64_t lds[];  // [W][OG_BLOCK]
+    const int tid = threadIdx.x;
+    const int W = a.plan.n_words;
+    for (int w = 0; w < W; w++) lds[w * OG_BLOCK + tid] = merge_init(a.plan.merge[w]);
+    const int64_t stride = (int64_t)gridDim.x * OG_BLOCK;
+    for (int64_t row = (int64_t)blockIdx.x * OG_BLOCK + tid; row < a.nrows; row += stride) {
+        if (a.p.enabled && !pred_eval(a.p, a.pred, row)) continue;
+        for (int o = 0; o < a.plan.n_ops; o++) {
+            const AccOp& op = a.plan.ops[o];
+            uint64_t v;
+            if (op_value(op, a.cols, row, &v)) {
+                uint64_t* p = &lds[op.word * OG_BLOCK + tid];
+                *p = merge_vals(a.plan.merge[op.word], *p, v);
+            }
+        }
+    }
+    __syncthreads();
+    for (int half = OG_BLOCK / 2; half > 0; half >>= 1) {
+        if (tid < half)
+            for (int w = 0; w < W; w++)
+                lds[w * OG_BLOCK + tid] = merge_vals(a.plan.merge[w], lds[w * OG_BLOCK + tid], lds[w * OG_BLOCK + tid + half]);
+        __syncthreads();
+    }
+    if (tid < W) {
+        int mk = a.plan.merge[tid];
+        uint64_t v = lds[tid * OG_BLOCK];
+        if (v != merge_init(mk)) g_merge(&a.g.acc[(uint64_t)tid * a.g.stride], mk, v);
+    }
+}
+
+// =======================================================================================================
+// Merge dense partial groups (another rank's run, or the old table during growth) into the table.
+// src_tag != NULL: source is a table (skip EMPTY / use tag as key).  Otherwise dense run: key words
+// (n_keys values + null mask) and accumulator words, each an array of n entries.
+// =======================================================================================================
+struct MergeArgs {
+    AggPlan plan;
+    GTable g;
+    int64_t n;
+    const uint64_t* src_tag;       // table source (single path: key, wide: tag) or NULL
+    const uint64_t* src_key[AGG_MAX_KEYS + 1];
+    const uint64_t* src_acc[AGG_MAX_WORDS];
+    int src_is_table;
+    int64_t src_cap;  // table source: entries [src_cap], [src_cap+1] are the special groups
+};
+
+__global__ __launch_bounds__(256) void agg_merge_kernel(MergeArgs m) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool single = m.g.kwt == 0;
+    const int nk = m.plan.n_keys;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m.n; i += stride) {
+        uint64_t slot;
+        if (m.src_is_table) {
+            uint64_t t = m.src_tag[i];
+            if (t == EMPTY || t == LOCKED) continue;
+            if (single) {
+                if (i >= m.src_cap) {
+                    slot = m.g.cap + (uint64_t)(i - m.src_cap);
+                    if (ld_agent(&m.g.tag[slot]) == EMPTY) st_agent(&m.g.tag[slot], 0);
+                } else slot = gt_find_single(m.g, t);
+            } else {
+                uint64_t kw[AGG_MAX_KEYS + 1];
+#pragma unroll
+                for (int j = 0; j <= AGG_MAX_KEYS; j++) if (j <= nk) kw[j] = m.src_key[j][i];
+                slot = gt_find_wide(m.g, kw, t);
+            }
+        } else if (nk == 0) {
+            slot = 0;
+        } else if (single) {
+            uint64_t key = m.src_key[0][i], nullmask = m.src_key[1][i];
+            if (nullmask) { slot = m.g.cap + 1; if (ld_agent(&m.g.tag[slot]) == EMPTY) st_agent(&m.g.tag[slot], 0); }
+            else if (key == EMPTY) { slot = m.g.cap; if (ld_agent(&m.g.tag[slot]) == EMPTY) st_agent(&m.g.tag[slot], 0); }
+            else slot = gt_find_single(m.g, key);
+        } else {
+            uint64_t kw[AGG_MAX_KEYS + 1];
+#pragma unroll
+            for (int j = 0; j <= AGG_MAX_KEYS; j++) if (j <= nk) kw[j] = m.src_key[j][i];
+            slot = gt_find_wide(m.g, kw, wide_tag(kw, nk + 1));
+        }
+        for (int w = 0; w < m.plan.n_words; w++) {
+            uint64_t v = m.src_acc[w][i];
+            int mk = m.plan.merge[w];
+            if (v != merge_init(mk)) g_merge(&m.g.acc[(uint64_t)w * m.g.stride + slot], mk, v);
+        }
+    }
+}
+
+// =======================================================================================================
+// Compaction of the table into a dense run: dkey[kw][n], dacc[W][n].  Order is unspecified (as in the
+// reference, robin_hood iteration order) except that the NULL-key group comes last
+// (single_numerical_hash_aggregate.cpp:58-60).
+// =======================================================================================================
+struct CompactArgs {
+    AggPlan plan;
+    GTable g;
+    uint64_t* dkey;   // kw * dstride
+    uint64_t* dacc;   // W * dstride
+    int64_t dstride;
+};
+
+__global__ __launch_bounds__(256) void agg_compact_kernel(CompactArgs c) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool single = c.g.kwt == 0;
+    const int lane = threadIdx.x & 63;
+    const int64_t n_iter = ((int64_t)c.g.cap + stride - 1) / stride;
+    for (int64_t it = 0; it < n_iter; it++) {
+        int64_t i = it * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        bool occ = false;
+        if (i < (int64_t)c.g.cap) {
+            uint64_t t = c.g.tag[i];
+            occ = (t != EMPTY && t != LOCKED);
+        }
+        uint64_t b = __ballot(occ);
+        if (!b) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&c.g.ctl[3], (unsigned long long)__popcll(b));
+        base = __shfl(base, 0);
+        if (!occ) continue;
+        uint64_t lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+        int64_t pos = (int64_t)base + __popcll(b & lt);
+        if (single) {
+            c.dkey[pos] = c.g.tag[i];
+            c.dkey[c.dstride + pos] = 0;
+        } else {
+            for (int j = 0; j < c.g.kwt; j++) c.dkey[(int64_t)j * c.dstride + pos] = c.g.keyw[(uint64_t)j * c.g.stride + i];
+        }
+        for (int w = 0; w < c.plan.n_words; w++) c.dacc[(int64_t)w * c.dstride + pos] = c.g.acc[(uint64_t)w * c.g.stride + i];
+    }
+}
+
+// one thread: append the special groups (sentinel-key group, then the NULL-key group LAST)
+__global__ void agg_compact_special_kernel(CompactArgs c) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (c.plan.n_keys == 0) {  // ONE_GROUP: exactly one row, always (one_group_aggregate.cpp:28-37)
+        for (int w = 0; w < c.plan.n_words; w++) c.dacc[(int64_t)w * c.dstride] = c.g.acc[(uint64_t)w * c.g.stride];
+        c.g.ctl[3] = 1;
+        return;
+    }
+    if (c.g.kwt != 0) return;
+    for (int s = 0; s < 2; s++) {
+        uint64_t slot = c.g.cap + s;
+        if (c.g.tag[slot] == EMPTY) continue;
+        int64_t pos = (int64_t)c.g.ctl[3];
+        c.dkey[pos] = s == 0 ? EMPTY : 0;
+        c.dkey[c.dstride + pos] = s == 0 ? 0 : 1;
+        for (int w = 0; w < c.plan.n_words; w++) c.dacc[(int64_t)w * c.dstride + pos] = c.g.acc[(uint64_t)w * c.g.stride + slot];
+        c.g.ctl[3] = pos + 1;
+    }
+}
+
+__global__ void fill_u64_kernel(uint64_t* p, uint64_t v, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+}  // namespace vnm
+
+// ==========================================================================================================
+// host side
+// ==========================================================================================================
+using namespace vnm;
+
+struct vnm_agg {
+    AggPlan plan;
+    FuncOut outs[AGG_MAX_FUNCS];
+    int n_funcs = 0;
+    int func_col[AGG_MAX_FUNCS];   // distinct column index per func (-1 for COUNT(*))
+    int col_first_func[AGG_MAX_COLS];
+    bool single = false;           // single 64-bit key path
+    Predicate pred{};
+    bool pred_set = false;
+    int pred_op = 0, pred_is_float = 0;
+    double pred_dval = 0;
+    int64_t pred_ival = 0;
+    int64_t hint = 0;
+    GTable g{};
+    bool have_table = false;
+    int64_t rows_seen = 0;
+    // dense result (device + host mirror)
+    uint64_t* dkey = nullptr;
+    uint64_t* dacc = nullptr;
+    int64_t dstride = 0;
+    int64_t n_groups = -1;
+    std::vector<uint64_t> h_key, h_acc;
+    bool host_ready = false;
+};
+
+namespace {
+
+int table_alloc(vnm_agg* h, GTable* g, uint64_t cap, hipStream_t s) {
+    memset(g, 0, sizeof(*g));
+    g->cap = cap;
+    g->stride = cap + 2;
+    g->kwt = h->single || h->plan.n_keys == 0 ? 0 : h->plan.n_keys + 1;
+    g->n_words = h->plan.n_words;
+    g->tag = (uint64_t*)pool_alloc(g->stride * 8);
+    g->acc = (uint64_t*)pool_alloc(g->stride * 8 * (size_t)g->n_words);
+    g->ctl = (unsigned long long*)pool_alloc(64);
+    if (g->kwt) g->keyw = (uint64_t*)pool_alloc(g->stride * 8 * (size_t)g->kwt);
+    if (!g->tag || !g->acc || !g->ctl || (g->kwt && !g->keyw)) return 1;
+    VNM_HIP(hipMemsetAsync(g->tag, 0xFF, g->stride * 8, s));
+    VNM_HIP(hipMemsetAsync(g->ctl, 0, 64, s));
+    for (int w = 0; w < g->n_words; w++) {
+        int v = h->plan.merge[w] == M_MIN_U64 ? 0xFF : 0;
+        VNM_HIP(hipMemsetAsync(g->acc + (size_t)w * g->stride, v, g->stride * 8, s));
+    }
+    return 0;
+}
+
+void table_free(GTable* g) {
+    pool_free(g->tag);
+    pool_free(g->acc);
+    pool_free(g->keyw);
+    pool_free(g->ctl);
+    memset(g, 0, sizeof(*g));
+}
+
+uint64_t pow2_at_least(uint64_t x) {
+    uint64_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+int lds_slots_for(const AggPlan& p) {
+    int per_slot = 8 * (1 + p.n_words);
+    int s = 1;
+    while ((s * 2 + 2) * per_slot <= AGG_LDS_BUDGET) s *= 2;
+    if (s > 8192) s = 8192;
+    return s;
+}
+
+// grow the table by rehashing every occupied slot into a larger one
+int table_grow(vnm_agg* h, uint64_t new_cap, hipStream_t s) {
+    GTable old = h->g, ng;
+    VNM_TRY(table_alloc(h, &ng, new_cap, s));
+    MergeArgs m{};
+    m.plan = h->plan;
+    m.g = ng;
+    m.n = (int64_t)old.stride;
+    m.src_is_table = 1;
+    m.src_tag = old.tag;
+    m.src_cap = (int64_t)old.cap;
+    for (int j = 0; j < old.kwt; j++) m.src_key[j] = old.keyw + (size_t)j * old.stride;
+    for (int w = 0; w < old.n_words; w++) m.src_acc[w] = old.acc + (size_t)w * old.stride;
+    int grid = device_info().num_cus * 8;
+    agg_merge_kernel<<<grid, 256, 0, s>>>(m);
+    VNM_HIP(hipGetLastError());
+    VNM_HIP(hipStreamSynchronize(s));
+    table_free(&old);
+    h->g = ng;
+    return 0;
+}
+
+int ensure_table(vnm_agg* h, int64_t nrows, hipStream_t s) {
+    if (h->have_table) return 0;
+    uint64_t cap;
+    if (h->plan.n_keys == 0) cap = 2;
+    else {
+        uint64_t want = h->hint > 0 ? (uint64_t)h->hint * 2 : (uint64_t)1 << 22;
+        if (h->hint <= 0 && (uint64_t)nrows * 2 < want) want = (uint64_t)(nrows > 512 ? nrows : 512) * 2;
+        cap = pow2_at_least(want < 1024 ? 1024 : want);
+    }
+    VNM_TRY(table_alloc(h, &h->g, cap, s));
+    h->have_table = true;
+    return 0;
+}
+
+void invalidate_result(vnm_agg* h) {
+    pool_free(h->dkey);
+    pool_free(h->dacc);
+    h->dkey = h->dacc = nullptr;
+    h->n_groups = -1;
+    h->host_ready = false;
+}
+
+}  // namespace
+
+extern "C" {
+
+vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
+                        const int* in_types, const int* in_flags, const int* in_col_ids) {
+    if (ensure_init()) return nullptr;
+    vnm_agg* h = new vnm_agg();
+    if (build_plan(kind, n_keys, key_types, n_funcs, funcs, in_types, in_flags, in_col_ids, &h->plan, h->outs)) {
+        delete h;
+        return nullptr;
+    }
+    h->n_funcs = n_funcs;
+    // distinct column index per func: replay build_plan's assignment
+    int ids[AGG_MAX_COLS], nc = 0;
+    for (int i = 0; i < n_funcs; i++) {
+        h->func_col[i] = -1;
+        if (funcs[i] == VNM_COUNT_STAR) continue;
+        int id = in_col_ids ? in_col_ids[i] : (1000 + i);
+        for (int c = 0; c < nc; c++) if (ids[c] == id) h->func_col[i] = c;
+        if (h->func_col[i] < 0) { ids[nc] = id; h->col_first_func[nc] = i; h->func_col[i] = nc++; }
+    }
+    h->single = (kind == VNM_SINGLE_NUMERICAL) || (kind == VNM_MULTI_NUMERICAL && n_keys == 1);
+    return h;
+}
+
+void vnm_agg_destroy(vnm_agg* h) {
+    if (!h) return;
+    if (h->have_table) table_free(&h->g);
+    invalidate_result(h);
+    delete h;
+}
+
+int vnm_agg_set_predicate(vnm_agg* h, int enabled, int op, int scalar_is_float, double dval, int64_t ival) {
+    if (!h) return set_error("vnm_agg_set_predicate: null handle");
+    if (enabled && (op < VNM_EQ || op > VNM_LE)) return set_error("vnm_agg_set_predicate: bad comparison op %d", op);
+    h->pred_set = enabled != 0;
+    h->pred_op = op;
+    h->pred_is_float = scalar_is_float;
+    h->pred_dval = dval;
+    h->pred_ival = ival;
+    return 0;
+}
+
+int vnm_agg_set_hint(vnm_agg* h, int64_t expected_groups) {
+    if (!h) return set_error("vnm_agg_set_hint: null handle");
+    h->hint = expected_groups;
+    return 0;
+}
+
+int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs,
+                        const vnm_dcol* pred, void* stream) {
+    VNM_TRY(ensure_init());
+    if (!h) return set_error("vnm_agg_next_device: null handle");
+    if (h->pred_set && !pred) return set_error("vnm_agg_next_device: predicate set but no predicate column given");
+    hipStream_t s = as_stream(stream);
+    invalidate_result(h);
+    VNM_TRY(ensure_table(h, nrows, s));
+    if (nrows <= 0) return 0;
+    if (nrows >= (1LL << 31)) return set_error("vnm_agg_next_device: batches must be < 2^31 rows (as in the reference, agg_funcs.h:45)");
+
+    AggArgs a{};
+    a.plan = h->plan;
+    for (int j = 0; j < h->plan.n_keys; j++) {
+        a.keys[j] = keys[j];
+        if (keys[j].type != h->plan.key_types[j]) return set_error("vnm_agg_next_device: key %d changed type between batches", j);
+    }
+    for (int c = 0; c < h->plan.n_cols; c++) a.cols[c] = inputs[h->col_first_func[c]];
+    if (h->pred_set) {
+        a.pred = *pred;
+        a.p = make_predicate(pred->type, pred->validity != nullptr, h->pred_op, h->pred_is_float, h->pred_dval, h->pred_ival);
+    }
+    a.nrows = nrows;
+    a.ntiles = (nrows + AGG_TILE - 1) / AGG_TILE;
+    const int cus = device_info().num_cus;
+
+    if (h->plan.n_keys == 0) {
+        a.g = h->g;
+        int grid = cus * 8;
+        int64_t need = (nrows + OG_BLOCK - 1) / OG_BLOCK;
+        if (grid > need) grid = (int)need;
+        agg_onegroup_kernel<<<grid, OG_BLOCK, (size_t)h->plan.n_words * OG_BLOCK * 8, s>>>(a);
+        VNM_HIP(hipGetLastError());
+        h->rows_seen += nrows;
+        return 0;
+    }
+
+    const int S = lds_slots_for(h->plan);
+    a.lds_slots = S;
+    int grid = h->single ? cus : cus * 4;
+    if (grid > a.ntiles) grid = (int)a.ntiles;
+    a.margin = (int64_t)grid * (h->single ? (S + 2 + AGG_TILE) : AGG_TILE);
+    VNM_HIP(hipMemsetAsync(h->g.ctl, 0, 16, s));  // ticket + overflow flag; fill persists
+    for (;;) {
+        // keep the load factor below 0.7 for everything that can be in flight
+        while ((int64_t)(h->g.cap * 7 / 10) < a.margin + 1) VNM_TRY(table_grow(h, h->g.cap * 4, s));
+        a.g = h->g;
+        a.fill_limit = (int64_t)(h->g.cap * 7 / 10);
+        if (h->single) {
+            size_t lds_bytes = (size_t)(S + 2) * 8 * (1 + h->plan.n_words);
+            VNM_HIP(hipFuncSetAttribute((const void*)agg_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            agg_lds_kernel<<<grid, AGG_BLOCK, lds_bytes, s>>>(a);
+        } else {
+            agg_wide_kernel<<<grid, 256, 0, s>>>(a);
+        }
+        VNM_HIP(hipGetLastError());
+        unsigned long long ctl[4];
+        VNM_HIP(hipMemcpyAsync(ctl, h->g.ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipStreamSynchronize(s));
+        if ((int64_t)ctl[0] >= a.ntiles) break;
+        // ran out of room: grow (x4, or more if the scan is far from done) and resume from the ticket
+        uint64_t new_cap = h->g.cap * 4;
+        double done = (double)ctl[0] / (double)a.ntiles;
+        if (done > 0.02) {
+            uint64_t est = pow2_at_least((uint64_t)((double)ctl[2] / done * 2.5));
+            if (est > new_cap) new_cap = est;
+        }
+        unsigned long long ticket = ctl[0];
+        VNM_TRY(table_grow(h, new_cap, s));
+        // carry ticket + fill over to the new control block
+        unsigned long long nctl[4] = {ticket, 0, 0, 0};
+        VNM_HIP(hipMemcpyAsync(&nctl[2], h->g.ctl + 2, 8, hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipStreamSynchronize(s));
+        VNM_HIP(hipMemcpyAsync(h->g.ctl, nctl, 16, hipMemcpyHostToDevice, s));
+        VNM_HIP(hipStreamSynchronize(s));
+    }
+    h->rows_seen += nrows;
+    return 0;
+}
+
+int vnm_agg_merge_device(vnm_agg* h, int64_t n, uint64_t* const* key_words, uint64_t* const* acc_words, void* stream) {
+    VNM_TRY(ensure_init());
+    if (!h) return set_error("vnm_agg_merge_device: null handle");
+    hipStream_t s = as_stream(stream);
+    invalidate_result(h);
+    VNM_TRY(ensure_table(h, n, s));
+    if (n <= 0) return 0;
+    if (h->plan.n_keys) {
+        unsigned long long fill = 0;
+        VNM_HIP(hipMemcpyAsync(&fill, h->g.ctl + 2, 8, hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipStreamSynchronize(s));
+        uint64_t need = pow2_at_least((uint64_t)((fill + (uint64_t)n) * 10 / 7 + 16));
+        if (need > h->g.cap) VNM_TRY(table_grow(h, need, s));
+    }
+    MergeArgs m{};
+    m.plan = h->plan;
+    m.g = h->g;
+    m.n = n;
+    for (int j = 0; j < h->plan.kw; j++) m.src_key[j] = key_words[j];
+    for (int w = 0; w < h->plan.n_words; w++) m.src_acc[w] = acc_words[w];
+    int grid = device_info().num_cus * 8;
+    int64_t need_blocks = (n + 255) / 256;
+    if (grid > need_blocks) grid = (int)need_blocks;
+    agg_merge_kernel<<<grid, 256, 0, s>>>(m);
+    VNM_HIP(hipGetLastError());
+    return 0;
+}
+
+int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream) {
+    VNM_TRY(ensure_init());
+    if (!h) return set_error("vnm_agg_finish: null handle");
+    hipStream_t s = as_stream(stream);
+    if (h->n_groups >= 0) {
+        if (n_groups) *n_groups = h->n_groups;
+        return 0;
+    }
+    if (!h->have_table) {
+        if (h->plan.n_keys == 0) VNM_TRY(ensure_table(h, 0, s));  // OneGroup over no batches still yields one row
+        else {
+            h->n_groups = 0;
+            if (n_groups) *n_groups = 0;
+            return 0;
+        }
+    }
+    unsigned long long fill = 0;
+    VNM_HIP(hipMemcpyAsync(&fill, h->g.ctl + 2, 8, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    h->dstride = (int64_t)fill + 2;
+    h->dkey = (uint64_t*)pool_alloc((size_t)h->dstride * 8 * (h->plan.kw ? h->plan.kw : 1));
+    h->dacc = (uint64_t*)pool_alloc((size_t)h->dstride * 8 * h->plan.n_words);
+    if (!h->dkey || !h->dacc) return 1;
+    VNM_HIP(hipMemsetAsync(h->g.ctl + 3, 0, 8, s));
+    CompactArgs c{};
+    c.plan = h->plan;
+    c.g = h->g;
+    c.dkey = h->dkey;
+    c.dacc = h->dacc;
+    c.dstride = h->dstride;
+    if (h->plan.n_keys) {
+        int grid = device_info().num_cus * 8;
+        int64_t need_blocks = ((int64_t)h->g.cap + 255) / 256;
+        if (grid > need_blocks) grid = (int)need_blocks;
+        agg_compact_kernel<<<grid, 256, 0, s>>>(c);
+    }
+    agg_compact_special_kernel<<<1, 64, 0, s>>>(c);
+    VNM_HIP(hipGetLastError());
+    unsigned long long cnt = 0;
+    VNM_HIP(hipMemcpyAsync(&cnt, h->g.ctl + 3, 8, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    h->n_groups = (int64_t)cnt;
+    if (n_groups) *n_groups = h->n_groups;
+    return 0;
+}
+
+int vnm_agg_layout(vnm_agg* h, int* n_key_words, int* n_acc_words) {
+    if (!h) return set_error("vnm_agg_layout: null handle");
+    if (n_key_words) *n_key_words = h->plan.kw;
+    if (n_acc_words) *n_acc_words = h->plan.n_words;
+    return 0;
+}
+
+int vnm_agg_dense_ptrs(vnm_agg* h, uint64_t** key_words, uint64_t** acc_words) {
+    if (!h) return set_error("vnm_agg_dense_ptrs: null handle");
+    if (h->n_groups < 0) return set_error("vnm_agg_dense_ptrs: call vnm_agg_finish first");
+    for (int j = 0; j < h->plan.kw; j++) key_words[j] = h->dkey ? h->dkey + (size_t)j * h->dstride : nullptr;
+    for (int w = 0; w < h->plan.n_words; w++) acc_words[w] = h->dacc ? h->dacc + (size_t)w * h->dstride : nullptr;
+    return 0;
+}
+
+static int fetch_host(vnm_agg* h) {
+    if (h->host_ready) return 0;
+    int64_t n = 0;
+    VNM_TRY(vnm_agg_finish(h, &n, nullptr));
+    h->h_key.assign((size_t)(h->plan.kw ? h->plan.kw : 1) * (n ? n : 1), 0);
+    h->h_acc.assign((size_t)h->plan.n_words * (n ? n : 1), 0);
+    if (n > 0) {
+        for (int j = 0; j < h->plan.kw; j++)
+            VNM_HIP(hipMemcpy(h->h_key.data() + (size_t)j * n, h->dkey + (size_t)j * h->dstride, (size_t)n * 8, hipMemcpyDeviceToHost));
+        for (int w = 0; w < h->plan.n_words; w++)
+            VNM_HIP(hipMemcpy(h->h_acc.data() + (size_t)w * n, h->dacc + (size_t)w * h->dstride, (size_t)n * 8, hipMemcpyDeviceToHost));
+    }
+    h->host_ready = true;
+    return 0;
+}
+
+int vnm_agg_result_key(vnm_agg* h, int key_idx, uint64_t* vals, uint8_t* valid) {
+    if (!h) return set_error("vnm_agg_result_key: null handle");
+    if (key_idx < 0 || key_idx >= h->plan.n_keys) return set_error("vnm_agg_result_key: key index out of range");
+    VNM_TRY(fetch_host(h));
+    int64_t n = h->n_groups;
+    const uint64_t* k = h->h_key.data() + (size_t)key_idx * n;
+    const uint64_t* nm = h->h_key.data() + (size_t)h->plan.n_keys * n;
+    for (int64_t r = 0; r < n; r++) {
+        vals[r] = k[r];
+        valid[r] = !((nm[r] >> key_idx) & 1);
+    }
+    return 0;
+}
+
+int vnm_agg_result_func(vnm_agg* h, int func_idx, void* cells16, uint8_t* valid, int* out_kind) {
+    if (!h) return set_error("vnm_agg_result_func: null handle");
+    if (func_idx < 0 || func_idx >= h->n_funcs) return set_error("vnm_agg_result_func: function index out of range");
+    VNM_TRY(fetch_host(h));
+    int64_t n = h->n_groups;
+    const uint64_t* words[AGG_MAX_WORDS];
+    for (int w = 0; w < h->plan.n_words; w++) words[w] = h->h_acc.data() + (size_t)w * n;
+    return finalize_func(h->outs[func_idx], n, words, cells16, valid, out_kind);
+}
+
+// host-only helpers: plan lowering and finalisation from accumulator words (no GPU needed)
+int vnm_agg_plan_host(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs, const int* in_types,
+                      const int* in_flags, const int* in_col_ids, int* n_key_words, int* n_acc_words,
+                      int* merge_kinds /* >= 24 ints */) {
+    AggPlan plan;
+    FuncOut outs[AGG_MAX_FUNCS];
+    VNM_TRY(build_plan(kind, n_keys, key_types, n_funcs, funcs, in_types, in_flags, in_col_ids, &plan, outs));
+    if (n_key_words) *n_key_words = plan.kw;
+    if (n_acc_words) *n_acc_words = plan.n_words;
+    if (merge_kinds) for (int w = 0; w < plan.n_words; w++) merge_kinds[w] = plan.merge[w];
+    return 0;
+}
+
+int vnm_agg_finalize_host(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs, const int* in_types,
+                          const int* in_flags, const int* in_col_ids, int func_idx, int64_t n,
+                          const uint64_t* const* acc_words, void* cells16, uint8_t* valid, int* out_kind) {
+    AggPlan plan;
+    FuncOut outs[AGG_MAX_FUNCS];
+    VNM_TRY(build_plan(kind, n_keys, key_types, n_funcs, funcs, in_types, in_flags, in_col_ids, &plan, outs));
+    if (func_idx < 0 || func_idx >= n_funcs) return set_error("vnm_agg_finalize_host: function index out of range");
+    return finalize_func(outs[func_idx], n, acc_words, cells16, valid, out_kind);
+}
+
+}  // extern "C"

@@ -1,0 +1,239 @@
+// Runtime plumbing of libvinum_hip.so: init, errors, caching device allocator, staging, memcpy helpers.
+#include <map>
+#include <unordered_map>
+
+#include "vnm_common.hpp"
+
+namespace vnm {
+
+std::string& last_error() {
+    static thread_local std::string e;
+    return e;
+}
+
+int set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return 1;
+}
+
+DeviceInfo& device_info() {
+    static DeviceInfo d;
+    return d;
+}
+
+int ensure_init() {
+    if (device_info().ready) return 0;
+    return vnm_init(-1);
+}
+
+// ---- caching allocator ---------------------------------------------------------------------------
+namespace {
+std::mutex g_pool_mu;
+std::multimap<size_t, void*> g_free;          // size -> block
+std::unordered_map<void*, size_t> g_sizes;    // live + cached blocks
+
+size_t round_size(size_t b) {
+    if (b < 4096) return 4096;
+    // round up to 1/8 of the leading power of two: bounded waste, good reuse
+    size_t p = 1;
+    while (p * 2 <= b) p *= 2;
+    size_t step = p / 8;
+    return (b + step - 1) / step * step;
+}
+}  // namespace
+
+void* pool_alloc(size_t bytes) {
+    size_t sz = round_size(bytes ? bytes : 1);
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        auto it = g_free.lower_bound(sz);
+        if (it != g_free.end() && it->first <= sz * 2) {
+            void* p = it->second;
+            g_free.erase(it);
+            return p;
+        }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) {
+        pool_trim();
+        e = hipMalloc(&p, sz);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e));
+            return nullptr;
+        }
+    }
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    g_sizes[p] = sz;
+    return p;
+}
+
+void pool_free(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    auto it = g_sizes.find(p);
+    if (it == g_sizes.end()) {
+        (void)hipFree(p);
+        return;
+    }
+    g_free.emplace(it->second, p);
+}
+
+void pool_trim() {
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    for (auto& kv : g_free) {
+        g_sizes.erase(kv.second);
+        (void)hipFree(kv.second);
+    }
+    g_free.clear();
+}
+
+Predicate make_predicate(int col_type, bool col_has_nulls, int op, int scalar_is_float, double dval, int64_t ival) {
+    Predicate p{};
+    p.enabled = 1;
+    p.op = op;
+    p.dval = scalar_is_float ? dval : (double)ival;
+    p.ival = ival;
+    if (col_type == VNM_F32) {
+        p.mode = CMP_F32;  // float32 stays float32 in NumPy (NULL -> NaN handled by the F64/F32 paths)
+        if (col_has_nulls) p.mode = CMP_F64, p.dval = (double)(float)p.dval;  // same result: f32 -> f64 is exact
+    } else if (col_type == VNM_F64 || col_has_nulls || scalar_is_float) {
+        p.mode = CMP_F64;
+    } else if (col_type == VNM_U64) {
+        if (ival < 0) {
+            p.mode = CMP_CONST;
+            p.const_result = (op == VNM_GT || op == VNM_GE || op == VNM_NE);
+        } else {
+            p.mode = CMP_U64;
+        }
+    } else {
+        p.mode = CMP_I64;
+    }
+    return p;
+}
+
+}  // namespace vnm
+
+using namespace vnm;
+
+extern "C" {
+
+int vnm_init(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_error("vnm_init: no HIP device available (%s); libvinum_hip has no CPU fallback",
+                         e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    int dev = device_id;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= n) return set_error("vnm_init: device %d out of range (%d devices)", dev, n);
+    VNM_HIP(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    VNM_HIP(hipGetDeviceProperties(&prop, dev));
+    DeviceInfo& d = device_info();
+    d.device = dev;
+    d.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    d.ready = true;
+    return 0;
+}
+
+const char* vnm_last_error(void) { return last_error().c_str(); }
+
+int vnm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int vnm_device_synchronize(void) {
+    VNM_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
+void* vnm_malloc(int64_t bytes) {
+    if (ensure_init()) return nullptr;
+    return pool_alloc((size_t)bytes);
+}
+
+int vnm_free(void* p) {
+    pool_free(p);
+    return 0;
+}
+
+int vnm_memcpy_h2d(void* dst, const void* src, int64_t bytes) {
+    VNM_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int vnm_memcpy_d2h(void* dst, const void* src, int64_t bytes) {
+    VNM_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int vnm_memset(void* dst, int value, int64_t bytes) {
+    VNM_HIP(hipMemset(dst, value, (size_t)bytes));
+    return 0;
+}
+
+// Stage one host Arrow column into HBM.  Only the bytes the slice covers are copied; the device view
+// keeps the sub-byte validity offset so no bitmap realignment pass is needed.
+int vnm_stage_column(const void* host_values, const uint8_t* host_validity, int64_t offset, int64_t length,
+                     int32_t type, vnm_dcol* out, void* stream) {
+    VNM_TRY(ensure_init());
+    int w = type_width(type);
+    hipStream_t s = as_stream(stream);
+    memset(out, 0, sizeof(*out));
+    out->type = type;
+    out->length = length;
+    size_t vbytes = (size_t)length * w;
+    void* dv = pool_alloc(vbytes ? vbytes : 1);
+    if (!dv) return 1;
+    if (vbytes)
+        VNM_HIP(hipMemcpyAsync(dv, (const uint8_t*)host_values + (size_t)offset * w, vbytes, hipMemcpyHostToDevice, s));
+    out->values = dv;
+    out->offset = 0;
+    if (host_validity) {
+        int64_t first_byte = offset >> 3;
+        int64_t last_byte = (offset + length + 7) >> 3;
+        size_t nb = (size_t)(last_byte - first_byte);
+        void* db = pool_alloc(nb ? nb : 1);
+        if (!db) return 1;
+        if (nb) VNM_HIP(hipMemcpyAsync(db, host_validity + first_byte, nb, hipMemcpyHostToDevice, s));
+        out->validity = (const uint8_t*)db;
+        // values were copied from element `offset` on (device element 0), the bitmap from byte
+        // `first_byte` on, so bit (offset & 7) of the device bitmap belongs to device element 0.
+        // Encode that by shifting the VALUES view: element i lives at values[(i + shift) - shift].
+        int shift = (int)(offset & 7);
+        if (shift) {
+            // re-stage values with `shift` elements of left padding so one offset serves both buffers
+            pool_free(dv);
+            size_t pbytes = ((size_t)length + shift) * w;
+            dv = pool_alloc(pbytes ? pbytes : 1);
+            if (!dv) return 1;
+            if (vbytes)
+                VNM_HIP(hipMemcpyAsync((uint8_t*)dv + (size_t)shift * w, (const uint8_t*)host_values + (size_t)offset * w,
+                                       vbytes, hipMemcpyHostToDevice, s));
+            out->values = dv;
+            out->offset = shift;
+        }
+    }
+    return 0;
+}
+
+int vnm_free_column(vnm_dcol* col) {
+    if (!col) return 0;
+    pool_free(const_cast<void*>(col->values));
+    pool_free(const_cast<uint8_t*>(col->validity));
+    col->values = nullptr;
+    col->validity = nullptr;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,216 @@
+"""Device-level operator wrappers over the C ABI (HBM-resident columns in, HBM-resident columns out).
+
+These are the building blocks of the operator mirror in vinum_amd/core/ and of bench.py; they never
+touch the host except for scalar results (row counts) and final result materialisation.
+"""
+import ctypes
+
+import numpy as np
+import pyarrow as pa
+
+from . import _lib as L
+from .device import DeviceBuffer, DeviceColumn, _NP, _WIDTH, arrow_from_numpy, dcol_array, physical_type
+
+CMP_OPS = {"==": L.EQ, "=": L.EQ, "!=": L.NE, "<>": L.NE, ">": L.GT, ">=": L.GE, "<": L.LT, "<=": L.LE}
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    return ctypes.c_void_p(int(stream))
+
+
+def filter_cmp(pred: DeviceColumn, op, literal, payload, stream=None):
+    """`WHERE pred <op> literal` over HBM columns: returns (compacted payload columns, rows kept).
+
+    Replaces FilterOperator._kernel + RecordBatch.filter + the NumPy comparison lambda
+    (reference: vinum/core/algebra.py:119-123, vinum/arrow/record_batch.py:85-90,
+    vinum/core/expressions.py:30-36)."""
+    lib = L.lib()
+    op = CMP_OPS.get(op, op)
+    outs = []
+    n = pred.length
+    for start in range(0, max(len(payload), 1), 8):  # the kernel compacts up to 8 columns per pass
+        chunk = payload[start:start + 8]
+        vals = [DeviceBuffer(n * _WIDTH[c.vnm_type]) for c in chunk]
+        vbytes = [DeviceBuffer(n) if c.validity_ptr else None for c in chunk]
+        ov = (ctypes.c_void_p * max(len(chunk), 1))(*[b.ptr for b in vals])
+        ob = (ctypes.c_void_p * max(len(chunk), 1))(*[(b.ptr if b else None) for b in vbytes])
+        count = ctypes.c_int64(0)
+        is_f = isinstance(literal, float)
+        L.check(lib.vnm_filter_cmp(ctypes.byref(pred.dcol()), op, int(is_f), float(literal), 0 if is_f else int(literal),
+                                   len(chunk), dcol_array(chunk), ov, ob, ctypes.byref(count), _stream_ptr(stream)))
+        k = count.value
+        for c, v, b in zip(chunk, vals, vbytes):
+            bitmap = None
+            if b is not None:
+                bitmap = DeviceBuffer((k + 7) // 8)
+                L.check(lib.vnm_pack_validity(b.ptr, k, bitmap.ptr, _stream_ptr(stream)))
+                L.check(lib.vnm_device_synchronize())
+            outs.append(DeviceColumn(v, bitmap, 0, k, c.arrow_type))
+        if not payload:
+            return [], k
+    return outs, (outs[0].length if outs else 0)
+
+
+def filter_mask(mask: DeviceBuffer, mask_valid, length, payload, stream=None):
+    """RecordBatch.filter(mask, null_selection_behavior='emit_null') with a device byte mask."""
+    lib = L.lib()
+    outs = []
+    for start in range(0, len(payload), 8):
+        chunk = payload[start:start + 8]
+        vals = [DeviceBuffer(length * _WIDTH[c.vnm_type]) for c in chunk]
+        need_v = [bool(c.validity_ptr) or mask_valid is not None for c in chunk]
+        vbytes = [DeviceBuffer(length) if nv else None for nv in need_v]
+        ov = (ctypes.c_void_p * len(chunk))(*[b.ptr for b in vals])
+        ob = (ctypes.c_void_p * len(chunk))(*[(b.ptr if b else None) for b in vbytes])
+        count = ctypes.c_int64(0)
+        L.check(lib.vnm_filter_mask(mask.ptr, mask_valid.ptr if mask_valid is not None else None, length, len(chunk),
+                                    dcol_array(chunk), ov, ob, ctypes.byref(count), _stream_ptr(stream)))
+        k = count.value
+        for c, v, b in zip(chunk, vals, vbytes):
+            bitmap = None
+            if b is not None:
+                bitmap = DeviceBuffer((k + 7) // 8)
+                L.check(lib.vnm_pack_validity(b.ptr, k, bitmap.ptr, _stream_ptr(stream)))
+                L.check(lib.vnm_device_synchronize())
+            outs.append(DeviceColumn(v, bitmap, 0, k, c.arrow_type))
+    return outs, (outs[0].length if outs else 0)
+
+
+def _ints(xs):
+    return (ctypes.c_int * max(len(xs), 1))(*xs)
+
+
+class DeviceAggregate:
+    """Streaming hash aggregate over HBM-resident columns (device level of the three reference classes).
+
+    funcs: list of (func_id, input_column_index or None, arrow_type of the input or None)."""
+
+    def __init__(self, kind, key_types, funcs, expected_groups=0):
+        self.kind = kind
+        self.key_arrow = list(key_types)
+        self.funcs = list(funcs)
+        kt = [physical_type(t)[0] for t in key_types]
+        ft, it, fl, ids = [], [], [], []
+        for f, col, t in funcs:
+            ft.append(f)
+            if t is None:
+                it.append(L.U64); fl.append(0); ids.append(-1)
+            else:
+                p, g = physical_type(t)
+                it.append(p); fl.append(g); ids.append(col if col is not None else -1)
+        self._h = L.lib().vnm_agg_create(kind, len(kt), _ints(kt), len(ft), _ints(ft), _ints(it), _ints(fl), _ints(ids))
+        if not self._h:
+            raise RuntimeError(L.last_error())
+        if expected_groups:
+            L.check(L.lib().vnm_agg_set_hint(self._h, int(expected_groups)))
+        self._pred = False
+
+    def set_predicate(self, op, literal):
+        op = CMP_OPS.get(op, op)
+        is_f = isinstance(literal, float)
+        L.check(L.lib().vnm_agg_set_predicate(self._h, 1, op, int(is_f), float(literal), 0 if is_f else int(literal)))
+        self._pred = True
+
+    def next(self, keys, inputs, pred=None, nrows=None, stream=None):
+        """keys: list[DeviceColumn]; inputs: one DeviceColumn (or None for COUNT(*)) per function."""
+        if nrows is None:
+            nrows = keys[0].length if keys else next(c.length for c in inputs if c is not None) if any(
+                c is not None for c in inputs) else 0
+        p = ctypes.byref(pred.dcol()) if pred is not None else None
+        L.check(L.lib().vnm_agg_next_device(self._h, nrows, dcol_array(keys), dcol_array(inputs), p, _stream_ptr(stream)))
+
+    def finish(self, stream=None) -> int:
+        n = ctypes.c_int64(0)
+        L.check(L.lib().vnm_agg_finish(self._h, ctypes.byref(n), _stream_ptr(stream)))
+        return n.value
+
+    def layout(self):
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        L.check(L.lib().vnm_agg_layout(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def dense_ptrs(self):
+        kw, aw = self.layout()
+        K = (ctypes.c_void_p * max(kw, 1))()
+        A = (ctypes.c_void_p * max(aw, 1))()
+        L.check(L.lib().vnm_agg_dense_ptrs(self._h, K, A))
+        return [K[i] for i in range(kw)], [A[i] for i in range(aw)]
+
+    def merge(self, n, key_ptrs, acc_ptrs, stream=None):
+        K = (ctypes.c_void_p * max(len(key_ptrs), 1))(*key_ptrs)
+        A = (ctypes.c_void_p * max(len(acc_ptrs), 1))(*acc_ptrs)
+        L.check(L.lib().vnm_agg_merge_device(self._h, n, K, A, _stream_ptr(stream)))
+
+    def result_arrays(self, key_indices, out_names_keys, out_names_funcs) -> pa.RecordBatch:
+        """Column order follows BaseAggregate::Result (base_aggregate.cpp:47-68): selected group keys
+        first, then the functions; output types follow agg_func_factory.cpp:13-329."""
+        lib = L.lib()
+        n = self.finish()
+        names, arrays = [], []
+        for j, name in zip(key_indices, out_names_keys):
+            vals = np.zeros(max(n, 1), np.uint64)
+            valid = np.zeros(max(n, 1), np.uint8)
+            L.check(lib.vnm_agg_result_key(self._h, j, vals.ctypes.data, valid.ctypes.data))
+            vals, valid = vals[:n], valid[:n]
+            t = self.key_arrow[j]
+            pt, _ = physical_type(t)
+            if pt == L.F64: v = vals.view(np.float64)
+            elif pt == L.F32: v = vals.astype(np.uint32).view(np.float32)
+            else: v = vals.astype(_NP[pt])
+            names.append(name)
+            arrays.append(arrow_from_numpy(v, ~valid.astype(bool), t))
+        for i, ((f, col, in_t), name) in enumerate(zip(self.funcs, out_names_funcs)):
+            cells = np.zeros((max(n, 1), 2), np.uint64)
+            valid = np.zeros(max(n, 1), np.uint8)
+            kind = ctypes.c_int(0)
+            L.check(lib.vnm_agg_result_func(self._h, i, cells.ctypes.data, valid.ctypes.data, ctypes.byref(kind)))
+            cells, valid = cells[:n], valid[:n]
+            names.append(name)
+            arrays.append(_func_array(f, in_t, kind.value, cells, valid))
+        return pa.RecordBatch.from_arrays(arrays, names=names)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().vnm_agg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _func_array(f, in_t, kind, cells, valid) -> pa.Array:
+    """Result column of one aggregate function with the reference's output type
+    (agg_func_factory.cpp: COUNT -> uint64 :31-34; MIN/MAX type-preserving :35-107; SUM :108-176;
+    AVG :177-247)."""
+    mask = ~valid.astype(bool)
+    lo = np.ascontiguousarray(cells[:, 0])
+    if f in (L.MIN, L.MAX):
+        pt, _ = physical_type(in_t)
+        if pt in (L.F32, L.F64): v = lo.view(np.float64).astype(_NP[pt])
+        elif pt in (L.U8, L.U16, L.U32, L.U64): v = lo.astype(_NP[pt])
+        else: v = lo.view(np.int64).astype(_NP[pt])
+        return arrow_from_numpy(v, mask, in_t)
+    if kind == L.OUT_U64:
+        return arrow_from_numpy(lo, mask, pa.uint64())
+    if kind == L.OUT_I64:
+        t = pa.int64()
+        if f == L.SUM and in_t is not None and (pa.types.is_time64(in_t) or pa.types.is_duration(in_t)):
+            t = in_t
+        return arrow_from_numpy(lo.view(np.int64), mask, t)
+    if kind == L.OUT_I32:
+        return arrow_from_numpy(lo.astype(np.uint32).view(np.int32), mask, in_t)
+    if kind == L.OUT_F64:
+        return arrow_from_numpy(lo.view(np.float64), mask, pa.float64())
+    if kind == L.OUT_F32:
+        return arrow_from_numpy(lo.astype(np.uint32).view(np.float32), mask, pa.float32())
+    # decimal128(38, 0): 16-byte little-endian two's complement cells are Arrow's native layout
+    buf = pa.py_buffer(np.ascontiguousarray(cells).tobytes())
+    vbuf = None
+    if mask.any():
+        vbuf = pa.py_buffer(np.packbits(valid.astype(bool), bitorder="little").tobytes())
+    return pa.Array.from_buffers(pa.decimal128(38, 0), len(valid), [vbuf, buf], null_count=int(mask.sum()))
