@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""bench.py -- filter -> group-by over HBM-resident Arrow-layout columns on MI355X.
+
+Contract (one JSON line on rank 0):  python bench.py --gpus N --steps K --warmup W
+A "step" = one pass of the hot path over one synthetic batch already resident in HBM:
+    groupby (default, BASELINE.json configs[2]):
+        SELECT k, sum(v), avg(v) FROM t WHERE v > X GROUP BY k       (fused filter + hash aggregate)
+        N = 1e9 rows, int64 key uniform in [0, G), fp64 value = j * 2^-7 (every partial sum exact ->
+        bit-exact float aggregates), X chosen for selectivity 0.5.
+    filter (BASELINE.json configs[1]):
+        WHERE fare_amount > X over a 1e9-row fp64 column -> compacted column.
+Multi-GPU (--gpus N>1, launched by torch.distributed.run): batches shard by rank (weak scaling), every
+rank aggregates its shard, partial groups are exchanged key-partitioned with one RCCL all_to_all and
+merged by their owner.
+
+Extra keys: "roofline" (HIP-event time of the dominant kernel vs 8 TB/s HBM peak) and "cpu_baseline"
+(the reference's CPU path -- NumPy compare + pyarrow filter + the real reference C++ aggregate from
+oracle/_ref when that build is present, else the oracle port -- on a bounded sample, rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="groupby", choices=["groupby", "filter"])
+    ap.add_argument("--rows", type=float, default=1e9)
+    ap.add_argument("--groups", type=float, default=1e8)
+    ap.add_argument("--selectivity", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def gen_data(torch, n, groups, seed, device):
+    """key int64 uniform [0, G); value fp64 = j / 128 with j uniform in [0, 2^14)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    j = torch.randint(0, 1 << 14, (n,), device=device, dtype=torch.int64, generator=g)
+    v = j.to(torch.float64) / 128.0
+    del j
+    k = torch.randint(0, int(groups), (n,), device=device, dtype=torch.int64, generator=g)
+    return k, v
+
+
+def threshold_for(selectivity):
+    # v = j/128, j uniform in [0, 16384): P(v > X) = 1 - (floor(128 X) + 1)/16384
+    jx = int(round((1.0 - selectivity) * 16384)) - 1
+    return max(jx, -1) / 128.0
+
+
+def cpu_baseline(args, x_thr):
+    """The reference's own CPU path on a bounded sample of the same workload."""
+    import pyarrow as pa
+    from oracle import oracle as O
+    from oracle import ref as R
+    rng = np.random.default_rng(123)
+    groups = int(args.groups)
+
+    def make(n):
+        k = rng.integers(0, groups, n).astype(np.int64)
+        v = rng.integers(0, 1 << 14, n).astype(np.float64) / 128.0
+        return pa.RecordBatch.from_arrays([pa.array(k), pa.array(v)], names=["k", "v"])
+
+    use_ref = R.available()
+    funcs = [(O.SUM, "v", "sum_v"), (O.AVG, "v", "avg_v")]
+
+    def run(batches):
+        t0 = time.perf_counter()
+        if args.workload == "filter":
+            for b in batches:
+                x = b.column(1).to_numpy(zero_copy_only=True)          # record_batch.py:112-118
+                mask = x > x_thr                                        # expressions.py:32
+                b.filter(pa.array(mask), null_selection_behavior="emit_null")  # record_batch.py:85-90
+        else:
+            agg = R.RefAggregate(R.SINGLE, ["k"], ["k"], funcs) if use_ref else O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+            for b in batches:
+                x = b.column(1).to_numpy(zero_copy_only=True)
+                fb = b.filter(pa.array(x > x_thr), null_selection_behavior="emit_null")
+                agg.next(fb)
+            agg.result()
+        return time.perf_counter() - t0
+
+    chunk = 1_000_000  # reference batches (its default is 10 000 rows; 1e6 is its best case)
+    probe = [make(chunk) for _ in range(2)]
+    t_probe = run(probe)
+    rate = 2 * chunk / t_probe
+    n_batches = int(max(2, min(60, args.cpu_seconds * rate / chunk)))
+    batches = [make(chunk) for _ in range(n_batches)]
+    t = run(batches)
+    kind = "reference" if (use_ref or args.workload == "filter") else "port"
+    return {"value": n_batches * chunk / t, "unit": "rows/s", "cores": 1, "kind": kind,
+            "sample": f"{n_batches} batches x {chunk} rows of the same synthetic workload "
+                      f"(G={groups}, s={args.selectivity}), single-threaded like the reference executor; "
+                      + ("NumPy compare + pyarrow filter" if args.workload == "filter" else
+                         ("NumPy compare + pyarrow filter + reference SingleNumericalHashAggregate (oracle/_ref)"
+                          if use_ref else "NumPy compare + pyarrow filter + oracle port of the aggregate"))}
+
+
+class CudaArrayView:
+    """Expose a raw device pointer to torch (zero copy) through __cuda_array_interface__."""
+
+    def __init__(self, ptr, n, typestr="<i8"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from vinum_amd import _lib as L
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    import pyarrow as pa
+    lib = L.lib()
+
+    n = int(args.rows)
+    groups = int(args.groups)
+    x_thr = threshold_for(args.selectivity)
+    k, v = gen_data(torch, n, groups, seed=1 + rank, device=device)
+    kcol = DeviceColumn.from_torch(k)
+    vcol = DeviceColumn.from_torch(v)
+    stream = torch.cuda.current_stream().cuda_stream
+    out_buf = None
+    if args.workload == "filter":
+        out_buf = torch.empty(n, dtype=torch.float64, device=device)
+
+    state = {}
+
+    def step():
+        if args.workload == "filter":
+            ov = (ctypes.c_void_p * 1)(out_buf.data_ptr())
+            ob = (ctypes.c_void_p * 1)(None)
+            cnt = ctypes.c_int64(0)
+            d = vcol.dcol()
+            L.check(lib.vnm_filter_cmp(ctypes.byref(d), L.GT, 1, x_thr, 0, 1, ctypes.byref(d), ov, ob,
+                                       ctypes.byref(cnt), ctypes.c_void_p(stream)))
+            state["out_rows"] = cnt.value
+            return
+        agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
+                                  [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())], expected_groups=groups)
+        agg.set_predicate(">", x_thr)
+        agg.next([kcol], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
+        ng = agg.finish(stream=stream)
+        if world > 1:
+            ng = exchange_and_merge(agg, ng)
+        state["out_rows"] = ng
+        state.pop("agg", None)
+        state["agg"] = agg  # keep the last result alive for the sanity check; previous one is freed
+
+    def exchange_and_merge(agg, ng):
+        """Key-partitioned exchange of partial groups (owner = hash(key) mod P), one all_to_all over RCCL."""
+        kp, ap_ = agg.dense_ptrs()
+        words = [torch.as_tensor(CudaArrayView(p, ng), device=device) for p in kp + ap_]
+        key = words[0]
+        owner = ((key * -7046029254386353131) >> 40) % world  # multiplicative hash (wraps in int64)
+        owner = owner.to(torch.int64) % world
+        order = torch.argsort(owner, stable=True)
+        counts = torch.bincount(owner, minlength=world)
+        send = torch.stack([w[order] for w in words], dim=1).contiguous()  # [ng, kw + W]
+        recv_counts = torch.empty_like(counts)
+        dist.all_to_all_single(recv_counts, counts)
+        sc, rc = counts.tolist(), recv_counts.tolist()
+        recv = torch.empty((sum(rc), send.shape[1]), dtype=torch.int64, device=device)
+        dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc)
+        merged = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
+                                     [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
+                                     expected_groups=max(int(recv.shape[0]), 1024))
+        cols = [recv[:, i].contiguous() for i in range(recv.shape[1])]
+        nk = len(kp)
+        merged.merge(recv.shape[0], [c.data_ptr() for c in cols[:nk]], [c.data_ptr() for c in cols[nk:]], stream=stream)
+        out = merged.finish(stream=stream)
+        state["merged"] = merged
+        return out
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    lib.vnm_set_profiling(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kname = b"filter_kernel" if args.workload == "filter" else b"agg_scan"
+    tot_ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+    lib.vnm_profile_query(kname, ctypes.byref(tot_ms), ctypes.byref(cnt))
+    lib.vnm_set_profiling(0)
+    kernel_ms = tot_ms.value / max(args.steps, 1)  # all launches of the dominant kernel within one step
+
+    out_rows = state["out_rows"]
+    if args.workload == "filter":
+        alg_bytes = 8.0 * n + 8.0 * out_rows          # read column once, write survivors
+        workload = f"configs[1]: WHERE fare_amount > {x_thr} over {n:.3g}-row fp64 column (s={args.selectivity}) -> compacted column"
+        dom = "filter_kernel"
+    else:
+        alg_bytes = 16.0 * n + 24.0 * out_rows        # read key+value once, write key,sum,avg per group
+        workload = (f"configs[2]: SELECT k,sum(v),avg(v) WHERE v>{x_thr} GROUP BY k; N={n:.3g} rows/GPU, "
+                    f"G={groups:.3g} int64 keys, s={args.selectivity}")
+        dom = "agg_scan (agg_lds_kernel)"
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+
+    if rank == 0:
+        result = {
+            "metric": "rows/sec + achieved HBM GB/s, filter->group-by over 10^9-row Arrow batches",
+            "value": n * world * args.steps / elapsed,
+            "unit": "rows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64/int64", "data": "synthetic",
+            "config": {"workload": workload, "rows_per_gpu": n, "groups": groups if args.workload == "groupby" else None,
+                       "selectivity": args.selectivity, "result_rows": int(out_rows),
+                       "parallelism": f"batch-sharded x{world}" + (", RCCL all_to_all partial-aggregate exchange" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
+                         "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
+                         "launches_per_step": cnt.value / max(args.steps, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(args, x_thr)
+            except Exception as e:  # the baseline is reporting only; never fail the bench line on it
+                result["cpu_baseline"] = {"value": None, "unit": "rows/s", "cores": 1, "kind": "port",
+                                          "sample": f"failed: {e}"}
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -93,6 +93,11 @@ int vnm_device_count(void);
 /* host-side statistics of the last operator call (kernel launches, bytes staged, ...); debugging aid */
 int vnm_device_synchronize(void);
 
+/* kernel timing with HIP events on the launch stream (bench.py roofline leg): spans are named after the
+ * kernel they bracket ("filter_kernel", "agg_scan", ...) */
+int vnm_set_profiling(int on);
+int vnm_profile_query(const char* name, double* total_ms, int64_t* count);
+
 /* ---- filter: FilterOperator._kernel + RecordBatch.filter -----------------------------------------
  * replaces vinum/core/algebra.py:119-123, vinum/arrow/record_batch.py:85-90 and the NumPy comparison
  * lambdas vinum/core/expressions.py:30-36 for the `column <op> literal` predicate shape, fused:
@@ -158,7 +163,7 @@ int vnm_agg_result_func(vnm_agg* h, int func_idx, void* cells16, uint8_t* valid,
  * on CPU. */
 int vnm_agg_plan_host(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
                       const int* in_types, const int* in_flags, const int* in_col_ids, int* n_key_words,
-                      int* n_acc_words, int* merge_kinds /* >= 24 ints */);
+                      int* n_acc_words, int* merge_kinds /* >= 40 ints */);
 int vnm_agg_finalize_host(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
                           const int* in_types, const int* in_flags, const int* in_col_ids, int func_idx,
                           int64_t n, const uint64_t* const* acc_words, void* cells16, uint8_t* valid,

@@ -45,6 +45,8 @@ PROTOTYPES = {
     "vnm_last_error": (ctypes.c_char_p, []),
     "vnm_device_count": (c_int, []),
     "vnm_device_synchronize": (c_int, []),
+    "vnm_set_profiling": (c_int, [c_int]),
+    "vnm_profile_query": (c_int, [ctypes.c_char_p, c_void, c_void]),
     "vnm_filter_cmp": (c_int, [c_void, c_int, c_int, c_dbl, c_i64, c_int, c_void, c_void, c_void, c_void, c_void]),
     "vnm_filter_mask": (c_int, [c_void, c_void, c_i64, c_int, c_void, c_void, c_void, c_void, c_void]),
     "vnm_pack_validity": (c_int, [c_void, c_i64, c_void, c_void]),

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void agg_merge_kernel(MergeArgs m) {
         uint64_t slot;
         if (m.src_is_table) {
             uint64_t t = m.src_tag[i];
-            if (t == EMPTY || t == LOCKED) continue;
+            if (t == EMPTY || (!single && t == LOCKED)) continue;  // LOCKED (~0 - 1) is an ordinary key on the single path
             if (single) {
                 if (i >= m.src_cap) {
                     slot = m.g.cap + (uint64_t)(i - m.src_cap);
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void agg_compact_kernel(CompactArgs c) {
         bool occ = false;
         if (i < (int64_t)c.g.cap) {
             uint64_t t = c.g.tag[i];
-            occ = (t != EMPTY && t != LOCKED);
+            occ = (t != EMPTY && (single || t != LOCKED));
         }
         uint64_t b = __ballot(occ);
         if (!b) continue;
@@ -700,6 +700,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         int grid = cus * 8;
         int64_t need = (nrows + OG_BLOCK - 1) / OG_BLOCK;
         if (grid > need) grid = (int)need;
+        KernelTimer timer("agg_scan", s);
         agg_onegroup_kernel<<<grid, OG_BLOCK, (size_t)h->plan.n_words * OG_BLOCK * 8, s>>>(a);
         VNM_HIP(hipGetLastError());
         h->rows_seen += nrows;
@@ -717,12 +718,15 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         while ((int64_t)(h->g.cap * 7 / 10) < a.margin + 1) VNM_TRY(table_grow(h, h->g.cap * 4, s));
         a.g = h->g;
         a.fill_limit = (int64_t)(h->g.cap * 7 / 10);
+        {
+        KernelTimer timer("agg_scan", s);
         if (h->single) {
             size_t lds_bytes = (size_t)(S + 2) * 8 * (1 + h->plan.n_words);
             VNM_HIP(hipFuncSetAttribute((const void*)agg_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             agg_lds_kernel<<<grid, AGG_BLOCK, lds_bytes, s>>>(a);
         } else {
             agg_wide_kernel<<<grid, 256, 0, s>>>(a);
+        }
         }
         VNM_HIP(hipGetLastError());
         unsigned long long ctl[4];
@@ -881,7 +885,7 @@ int vnm_agg_result_func(vnm_agg* h, int func_idx, void* cells16, uint8_t* valid,
 // host-only helpers: plan lowering and finalisation from accumulator words (no GPU needed)
 int vnm_agg_plan_host(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs, const int* in_types,
                       const int* in_flags, const int* in_col_ids, int* n_key_words, int* n_acc_words,
-                      int* merge_kinds /* >= 24 ints */) {
+                      int* merge_kinds /* >= 40 ints */) {
     AggPlan plan;
     FuncOut outs[AGG_MAX_FUNCS];
     VNM_TRY(build_plan(kind, n_keys, key_types, n_funcs, funcs, in_types, in_flags, in_col_ids, &plan, outs));

@@ -6,8 +6,8 @@ namespace vnm {
 
 constexpr int AGG_MAX_KEYS = 8;
 constexpr int AGG_MAX_FUNCS = 64;
-constexpr int AGG_MAX_WORDS = 24;   // 64-bit accumulator words per group
-constexpr int AGG_MAX_OPS = 32;     // per-row accumulator updates
+constexpr int AGG_MAX_WORDS = 40;   // 64-bit accumulator words per group
+constexpr int AGG_MAX_OPS = 48;     // per-row accumulator updates
 constexpr int AGG_MAX_COLS = 20;    // distinct input columns
 
 // Per-row accumulator update kinds.  The reference keeps one heap object per (group, function)

@@ -50,6 +50,16 @@ void* pool_alloc(size_t bytes);
 void pool_free(void* p);
 void pool_trim();
 
+// Optional kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+// KernelTimer brackets the dominant kernel of an operator call; elapsed time is resolved lazily.
+struct KernelTimer {
+    explicit KernelTimer(const char* name, hipStream_t s);
+    ~KernelTimer();
+    bool on;
+    int slot;
+    hipStream_t stream;
+};
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // ---------------------------------------------------------------------------------------------
@@ -105,6 +115,17 @@ __device__ __forceinline__ uint64_t col_key_bits(const vnm_dcol& c, int64_t i) {
         case VNM_F64: return ((const uint64_t*)c.values)[k];
         case VNM_F32: return (uint64_t)((const uint32_t*)c.values)[k];
         default: return (uint64_t)col_i64(c, i);
+    }
+}
+
+// raw element bits (zero-extended), for moving values without interpreting them
+__device__ __forceinline__ uint64_t col_raw_bits(const vnm_dcol& c, int64_t i) {
+    int64_t k = c.offset + i;
+    switch (type_width(c.type)) {
+        case 1: return ((const uint8_t*)c.values)[k];
+        case 2: return ((const uint16_t*)c.values)[k];
+        case 4: return ((const uint32_t*)c.values)[k];
+        default: return ((const uint64_t*)c.values)[k];
     }
 }
 

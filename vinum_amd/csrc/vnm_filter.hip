@@ -184,14 +184,14 @@ __global__ __launch_bounds__(FB) void filter_kernel(FilterArgs a) {
                     uint64_t bits;
                     if (reuse) bits = __double_as_longlong(v0[j]);
                     else if (w == 8) bits = ((const uint64_t*)c.values)[c.offset + r0];
-                    else bits = (uint64_t)col_i64(c, r0);
+                    else bits = col_raw_bits(c, r0);
                     s_stage[pos++] = bits;
                 }
                 if (fj & 2u) {
                     uint64_t bits;
                     if (reuse) bits = __double_as_longlong(v1[j]);
                     else if (w == 8) bits = ((const uint64_t*)c.values)[c.offset + r0 + 1];
-                    else bits = (uint64_t)col_i64(c, r0 + 1);
+                    else bits = col_raw_bits(c, r0 + 1);
                     s_stage[pos] = bits;
                 }
             }
@@ -269,10 +269,13 @@ static int launch_filter(FilterArgs& a, int mode, int64_t* out_count, hipStream_
     a.status = scratch + 2;
     int64_t grid = (int64_t)d.num_cus * 8;
     if (grid > a.ntiles) grid = a.ntiles;
+    {
+    KernelTimer timer("filter_kernel", s);
     switch (mode) {
         case CMP_F64: filter_kernel<CMP_F64><<<(int)grid, FB, 0, s>>>(a); break;
         case MODE_MASK: filter_kernel<MODE_MASK><<<(int)grid, FB, 0, s>>>(a); break;
         default: filter_kernel<CMP_I64><<<(int)grid, FB, 0, s>>>(a); break;  // generic pred_eval path
+    }
     }
     VNM_HIP(hipGetLastError());
     unsigned long long total = 0;

@@ -117,9 +117,53 @@ Predicate make_predicate(int col_type, bool col_has_nulls, int op, int scalar_is
     return p;
 }
 
+// ---- kernel timing ------------------------------------------------------------------------------------
+namespace {
+struct TimedSpan { std::string name; hipEvent_t a, b; };
+bool g_profiling = false;
+std::vector<TimedSpan> g_spans;
+}  // namespace
+
+KernelTimer::KernelTimer(const char* name, hipStream_t s) : on(g_profiling), slot(-1), stream(s) {
+    if (!on) return;
+    TimedSpan sp;
+    sp.name = name;
+    if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(sp.a, s);
+    g_spans.push_back(sp);
+    slot = (int)g_spans.size() - 1;
+}
+KernelTimer::~KernelTimer() {
+    if (on && slot >= 0) (void)hipEventRecord(g_spans[slot].b, stream);
+}
+
 }  // namespace vnm
 
 using namespace vnm;
+
+extern "C" {
+int vnm_set_profiling(int on) {
+    g_profiling = on != 0;
+    for (auto& sp : g_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    g_spans.clear();
+    return 0;
+}
+// total milliseconds and launch count of the timed spans whose name matches `name` since
+// vnm_set_profiling(1); synchronises the recorded events
+int vnm_profile_query(const char* name, double* total_ms, int64_t* count) {
+    double tot = 0;
+    int64_t n = 0;
+    for (auto& sp : g_spans) {
+        if (name && sp.name != name) continue;
+        if (hipEventSynchronize(sp.b) != hipSuccess) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { tot += ms; n++; }
+    }
+    if (total_ms) *total_ms = tot;
+    if (count) *count = n;
+    return 0;
+}
+}
 
 extern "C" {
 
