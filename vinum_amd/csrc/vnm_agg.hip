@@ -11,6 +11,8 @@
 // So rows are pre-aggregated in a per-workgroup LDS hash table (keys + 64-bit accumulator words that
 // merge commutatively); only table flushes touch the HBM-resident table, with agent-scope atomics.
 // The fused WHERE predicate is evaluated in the scan, so no filtered batch is ever materialised.
+#include <cstdlib>
+
 #include "vnm_agg.hpp"
 
 namespace vnm {
@@ -50,6 +52,10 @@ struct AggArgs {
     int64_t fill_limit;   // take a new tile only while fill + margin <= fill_limit
     int64_t margin;
     int lds_slots;
+    unsigned int* progress;  // per-block loop index to resume from
+    // hot-shape kernel (single 8-byte key, one float64 input column, no validity bitmaps)
+    int hot_w_rows, hot_w_valid, hot_w_sum;
+    int hot_pred_is_v;
 };
 
 // ---- global table primitives ------------------------------------------------------------------------
@@ -159,23 +165,18 @@ __device__ __forceinline__ bool op_value(const AccOp& op, const vnm_dcol* cols, 
     }
 }
 
-// take the next tile while the HBM table has room for everything in flight; otherwise raise the overflow
-// flag so the host grows the table and resumes from the ticket
-__device__ __forceinline__ int64_t next_tile(const AggArgs& a) {
+// Tiles are statically strided over the grid (tile = block + i * grid): no shared ticket word, so the
+// scan never serialises on one atomic (a CAS ticket per 2048-row tile cost 1.3 s per 1e9 rows).  Before
+// each tile the block checks that the HBM table has room for everything that can be in flight; if not it
+// raises the overflow flag, parks its loop index in progress[block] and exits so the host can grow the
+// table and relaunch the same grid from where every block stopped.
+__device__ __forceinline__ bool table_has_room(const AggArgs& a) {
     unsigned long long fill = __hip_atomic_load(&a.g.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((int64_t)fill + a.margin > a.fill_limit) {
         __hip_atomic_store(&a.g.ctl[1], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return -1;
+        return false;
     }
-    // the ticket only advances when the tile WILL be processed: compare-and-swap so an exhausted or
-    // aborted scan leaves ctl[0] == number of tiles handed out
-    unsigned long long t = __hip_atomic_load(&a.g.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
-        if ((int64_t)t >= a.ntiles) return -1;
-        if (__hip_atomic_compare_exchange_strong(&a.g.ctl[0], &t, t + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT))
-            return (int64_t)t;
-    }
+    return true;
 }
 
 // =======================================================================================================
@@ -226,11 +227,13 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_lds_kernel(AggArgs a) {
     const unsigned flush_at = (unsigned)(S * 7 / 10);
     const uint32_t smask = (uint32_t)S - 1;
     const vnm_dcol& kc = a.keys[0];
-    for (;;) {
-        if (tid == 0) s_tile = next_tile(a);
+    unsigned it = a.progress[blockIdx.x];
+    for (;; it++) {
+        const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
+        if (tile >= a.ntiles) break;
+        if (tid == 0) s_tile = table_has_room(a) ? 1 : 0;
         __syncthreads();
-        const int64_t tile = s_tile;
-        if (tile < 0) break;
+        if (!s_tile) break;
 #pragma unroll
         for (int r = 0; r < AGG_ROWS_PER_THREAD; r++) {
             const int64_t row = tile * AGG_TILE + (int64_t)r * AGG_BLOCK + tid;
@@ -289,6 +292,126 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_lds_kernel(AggArgs a) {
         }
     }
     lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK);
+    if (tid == 0) a.progress[blockIdx.x] = it;
+}
+
+// =======================================================================================================
+// Kernel 1h: the hot shape of the north-star query
+//     SELECT k, {sum|avg|count}(v), count(*) [WHERE p > X] GROUP BY k
+// with an 8-byte key, a float64 input, no validity bitmaps and even Arrow offsets.  Same LDS table and
+// flush protocol as agg_lds_kernel, but every lane issues 16-byte loads (two rows), four requests per
+// column in flight, the predicate / hash / accumulate sequence is straight-line code, and the block only
+// synchronises once per 8192 rows (to decide about flushing).
+// =======================================================================================================
+constexpr int HOT_UNROLL = 4;
+constexpr int HOT_TILE = AGG_BLOCK * 2 * HOT_UNROLL;  // 8192 rows per block iteration
+
+__device__ __forceinline__ void hot_row(const AggArgs& a, uint64_t* lkey, uint64_t* lacc, int S, int stride, uint32_t smask,
+                                        unsigned* s_fill, uint64_t key, double v) {
+    int slot = -1;
+    if (key == EMPTY) {
+        slot = S;
+        lkey[slot] = 0;
+    } else {
+        uint32_t h = hash_u64(key) & smask;
+        for (int probe = 0; probe < AGG_MAX_PROBES; probe++) {
+            uint64_t k = *(volatile uint64_t*)&lkey[h];
+            if (k == key) { slot = (int)h; break; }
+            if (k == EMPTY) {
+                uint64_t expected = EMPTY;
+                if (__hip_atomic_compare_exchange_strong(&lkey[h], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    atomicAdd(s_fill, 1u);
+                    slot = (int)h;
+                    break;
+                }
+                if (expected == key) { slot = (int)h; break; }
+            }
+            h = (h + 1) & smask;
+        }
+    }
+    if (slot >= 0) {
+        if (a.hot_w_rows >= 0) __hip_atomic_fetch_add(&lacc[a.hot_w_rows * stride + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (a.hot_w_valid >= 0) __hip_atomic_fetch_add(&lacc[a.hot_w_valid * stride + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (a.hot_w_sum >= 0) __hip_atomic_fetch_add((double*)&lacc[a.hot_w_sum * stride + slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        uint64_t gs = gt_find_single(a.g, key);
+        if (a.hot_w_rows >= 0) g_merge(&a.g.acc[(uint64_t)a.hot_w_rows * a.g.stride + gs], M_ADD_U64, 1);
+        if (a.hot_w_valid >= 0) g_merge(&a.g.acc[(uint64_t)a.hot_w_valid * a.g.stride + gs], M_ADD_U64, 1);
+        if (a.hot_w_sum >= 0) g_merge(&a.g.acc[(uint64_t)a.hot_w_sum * a.g.stride + gs], M_ADD_F64, (uint64_t)__double_as_longlong(v));
+    }
+}
+
+template <bool HAS_PRED, bool PRED_IS_V>
+__global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
+    extern __shared__ uint64_t lds[];
+    __shared__ unsigned s_fill;
+    __shared__ int s_go;
+    const int S = a.lds_slots;
+    const int stride = S + 2;
+    const int W = a.plan.n_words;
+    uint64_t* lkey = lds;
+    uint64_t* lacc = lds + stride;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < stride; i += AGG_BLOCK) lkey[i] = EMPTY;
+    for (int w = 0; w < W; w++) {
+        uint64_t init = merge_init(a.plan.merge[w]);
+        for (int i = tid; i < stride; i += AGG_BLOCK) lacc[w * stride + i] = init;
+    }
+    if (tid == 0) s_fill = 0;
+    __syncthreads();
+
+    const unsigned flush_at = (unsigned)(S * 6 / 10);
+    const uint32_t smask = (uint32_t)S - 1;
+    const uint64_t* kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
+    const double* vp = (const double*)a.cols[0].values + a.cols[0].offset;
+    const double* pp = (const double*)a.pred.values + a.pred.offset;
+    const int op = a.p.op;
+    const double thr = a.p.dval;
+
+    unsigned it = a.progress[blockIdx.x];
+    for (;; it++) {
+        const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
+        if (tile >= a.ntiles) break;
+        if (tid == 0) s_go = table_has_room(a) ? 1 : 0;
+        __syncthreads();
+        if (!s_go) break;
+        const int64_t base = tile * HOT_TILE + 2 * tid;
+        ulonglong2 kk[HOT_UNROLL];
+        double2 vv[HOT_UNROLL], pv[HOT_UNROLL];
+        if (base + (int64_t)(HOT_UNROLL - 1) * 2 * AGG_BLOCK + 1 < a.nrows) {
+#pragma unroll
+            for (int u = 0; u < HOT_UNROLL; u++) {
+                int64_t r = base + (int64_t)u * 2 * AGG_BLOCK;
+                kk[u] = *(const ulonglong2*)(kp + r);
+                vv[u] = *(const double2*)(vp + r);
+                if (HAS_PRED && !PRED_IS_V) pv[u] = *(const double2*)(pp + r);
+            }
+#pragma unroll
+            for (int u = 0; u < HOT_UNROLL; u++) {
+                double p0 = PRED_IS_V ? vv[u].x : pv[u].x, p1 = PRED_IS_V ? vv[u].y : pv[u].y;
+                if (!HAS_PRED || cmp_apply<double>(op, p0, thr)) hot_row(a, lkey, lacc, S, stride, smask, &s_fill, kk[u].x, vv[u].x);
+                if (!HAS_PRED || cmp_apply<double>(op, p1, thr)) hot_row(a, lkey, lacc, S, stride, smask, &s_fill, kk[u].y, vv[u].y);
+            }
+        } else {
+            for (int u = 0; u < HOT_UNROLL; u++)
+                for (int e = 0; e < 2; e++) {
+                    int64_t r = base + (int64_t)u * 2 * AGG_BLOCK + e;
+                    if (r >= a.nrows) continue;
+                    double p = PRED_IS_V ? vp[r] : (HAS_PRED ? pp[r] : 0.0);
+                    if (!HAS_PRED || cmp_apply<double>(op, p, thr)) hot_row(a, lkey, lacc, S, stride, smask, &s_fill, kp[r], vp[r]);
+                }
+        }
+        __syncthreads();
+        if (s_fill > flush_at) {
+            lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK);
+            __syncthreads();
+            if (tid == 0) s_fill = 0;
+        }
+    }
+    lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK);
+    if (tid == 0) a.progress[blockIdx.x] = it;
 }
 
 // =======================================================================================================
@@ -299,12 +422,14 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggArgs a) {
     __shared__ int64_t s_tile;
     const int tid = threadIdx.x;
     const int nk = a.plan.n_keys;
-    for (;;) {
-        if (tid == 0) s_tile = next_tile(a);
+    unsigned it = a.progress[blockIdx.x];
+    for (;; it++) {
+        const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
+        if (tile >= a.ntiles) break;
         __syncthreads();
-        const int64_t tile = s_tile;
+        if (tid == 0) s_tile = table_has_room(a) ? 1 : 0;
         __syncthreads();
-        if (tile < 0) break;
+        if (!s_tile) break;
         for (int r = 0; r < AGG_TILE / 256; r++) {
             const int64_t row = tile * AGG_TILE + (int64_t)r * 256 + tid;
             if (row >= a.nrows) continue;
@@ -328,6 +453,7 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggArgs a) {
             }
         }
     }
+    if (tid == 0) a.progress[blockIdx.x] = it;
 }
 
 // =======================================================================================================
@@ -709,18 +835,53 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
 
     const int S = lds_slots_for(h->plan);
     a.lds_slots = S;
+    // hot shape: one 8-byte key, every function in {COUNT(*), COUNT, SUM, AVG} over ONE float64 column,
+    // float64 predicate column (or none), no validity bitmaps, even offsets (16-byte aligned pairs)
+    bool hot = h->single && h->plan.n_cols == 1 && type_width(keys[0].type) == 8 && !keys[0].validity &&
+               (keys[0].offset & 1) == 0 && a.cols[0].type == VNM_F64 && !a.cols[0].validity && (a.cols[0].offset & 1) == 0 &&
+               getenv("VNM_AGG_NO_HOT") == nullptr;
+    a.hot_w_rows = a.hot_w_valid = a.hot_w_sum = -1;
+    if (hot) {
+        for (int o = 0; o < h->plan.n_ops && hot; o++) {
+            const AccOp& op = h->plan.ops[o];
+            if (op.kind == A_COUNT_ROWS) a.hot_w_rows = op.word;
+            else if (op.kind == A_COUNT_VALID) a.hot_w_valid = op.word;
+            else if (op.kind == A_SUM_F64) a.hot_w_sum = op.word;
+            else hot = false;
+        }
+    }
+    if (hot && h->pred_set) {
+        hot = a.pred.type == VNM_F64 && !a.pred.validity && (a.pred.offset & 1) == 0 && a.p.mode == CMP_F64;
+        a.hot_pred_is_v = a.pred.values == a.cols[0].values && a.pred.offset == a.cols[0].offset;
+    }
+    if (hot) a.ntiles = (nrows + HOT_TILE - 1) / HOT_TILE;
     int grid = h->single ? cus : cus * 4;
     if (grid > a.ntiles) grid = (int)a.ntiles;
-    a.margin = (int64_t)grid * (h->single ? (S + 2 + AGG_TILE) : AGG_TILE);
-    VNM_HIP(hipMemsetAsync(h->g.ctl, 0, 16, s));  // ticket + overflow flag; fill persists
-    for (;;) {
+    a.margin = (int64_t)grid * (h->single ? (S + 2 + (hot ? HOT_TILE : AGG_TILE)) : AGG_TILE);
+    unsigned int* progress = (unsigned int*)pool_alloc((size_t)grid * 4);
+    if (!progress) return 1;
+    VNM_HIP(hipMemsetAsync(progress, 0, (size_t)grid * 4, s));
+    a.progress = progress;
+    for (int round = 0;; round++) {
         // keep the load factor below 0.7 for everything that can be in flight
         while ((int64_t)(h->g.cap * 7 / 10) < a.margin + 1) VNM_TRY(table_grow(h, h->g.cap * 4, s));
+        VNM_HIP(hipMemsetAsync(h->g.ctl, 0, 16, s));  // [1] overflow flag; [2] fill persists
         a.g = h->g;
         a.fill_limit = (int64_t)(h->g.cap * 7 / 10);
         {
         KernelTimer timer("agg_scan", s);
-        if (h->single) {
+        if (hot) {
+            size_t lds_bytes = (size_t)(S + 2) * 8 * (1 + h->plan.n_words);
+#define VNM_HOT(P, V)                                                                                          \
+    do {                                                                                                       \
+        VNM_HIP(hipFuncSetAttribute((const void*)agg_hot_kernel<P, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        agg_hot_kernel<P, V><<<grid, AGG_BLOCK, lds_bytes, s>>>(a);                                            \
+    } while (0)
+            if (!h->pred_set) VNM_HOT(false, false);
+            else if (a.hot_pred_is_v) VNM_HOT(true, true);
+            else VNM_HOT(true, false);
+#undef VNM_HOT
+        } else if (h->single) {
             size_t lds_bytes = (size_t)(S + 2) * 8 * (1 + h->plan.n_words);
             VNM_HIP(hipFuncSetAttribute((const void*)agg_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             agg_lds_kernel<<<grid, AGG_BLOCK, lds_bytes, s>>>(a);
@@ -732,23 +893,13 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         unsigned long long ctl[4];
         VNM_HIP(hipMemcpyAsync(ctl, h->g.ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
         VNM_HIP(hipStreamSynchronize(s));
-        if ((int64_t)ctl[0] >= a.ntiles) break;
-        // ran out of room: grow (x4, or more if the scan is far from done) and resume from the ticket
+        if (!ctl[1]) break;  // no block ran out of room: every tile was processed
+        // grow (x4, or to the projected final size) and relaunch; blocks resume from progress[]
         uint64_t new_cap = h->g.cap * 4;
-        double done = (double)ctl[0] / (double)a.ntiles;
-        if (done > 0.02) {
-            uint64_t est = pow2_at_least((uint64_t)((double)ctl[2] / done * 2.5));
-            if (est > new_cap) new_cap = est;
-        }
-        unsigned long long ticket = ctl[0];
+        if (h->hint <= 0 && round >= 1) new_cap = h->g.cap * 16;
         VNM_TRY(table_grow(h, new_cap, s));
-        // carry ticket + fill over to the new control block
-        unsigned long long nctl[4] = {ticket, 0, 0, 0};
-        VNM_HIP(hipMemcpyAsync(&nctl[2], h->g.ctl + 2, 8, hipMemcpyDeviceToHost, s));
-        VNM_HIP(hipStreamSynchronize(s));
-        VNM_HIP(hipMemcpyAsync(h->g.ctl, nctl, 16, hipMemcpyHostToDevice, s));
-        VNM_HIP(hipStreamSynchronize(s));
     }
+    pool_free(progress);
     h->rows_seen += nrows;
     return 0;
 }

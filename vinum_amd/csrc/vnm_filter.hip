@@ -13,13 +13,12 @@
 //   * survivors are staged through LDS so the global stores are dense.
 //
 // Roofline: HBM.  Algorithmic bytes = 8*N read + 8*s*N written.
+#include <cstdlib>
+
 #include "vnm_common.hpp"
 
 namespace vnm {
 
-constexpr int FB = 256;                 // threads per workgroup (4 waves)
-constexpr int F_CHUNKS = 8;             // 16-byte requests per lane per tile
-constexpr int F_TILE = FB * 2 * F_CHUNKS;  // 4096 rows
 constexpr int F_MAX_PAYLOAD = 8;
 constexpr int MODE_MASK = 5;
 
@@ -42,6 +41,7 @@ struct FilterArgs {
     int64_t ntiles;
     unsigned long long* ctl;  // [0] ticket, [1] total
     unsigned long long* status;
+    int debug;  // timing experiments only: 1 = skip look-back (outputs are wrong)
 };
 
 __device__ __forceinline__ uint64_t lanemask_lt() {
@@ -49,48 +49,64 @@ __device__ __forceinline__ uint64_t lanemask_lt() {
     return lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
 }
 
-template <int MODE>
+template <int MODE, int FB, bool HOT>
 __global__ __launch_bounds__(FB) void filter_kernel(FilterArgs a) {
-    __shared__ int64_t s_tile;
-    __shared__ uint32_t s_cnt[F_CHUNKS * 4];
-    __shared__ uint32_t s_excl[F_CHUNKS * 4];
-    __shared__ uint32_t s_total;
+    constexpr int F_CHUNKS = 8;             // 16-byte requests per lane per tile
+    constexpr int F_TILE = FB * 2 * F_CHUNKS;
+    constexpr int NW = FB / 64;             // waves per workgroup
+    constexpr int NSEG = F_CHUNKS * NW;     // (chunk, wave) segments per tile, <= 128
+    static_assert(NSEG <= 128, "segment scan handles two segments per lane of wave 0");
+    __shared__ int64_t s_next[2];
+    __shared__ uint32_t s_cnt[NSEG];
+    __shared__ uint32_t s_excl[NSEG];
     __shared__ int64_t s_base;
-    __shared__ uint64_t s_stage[F_TILE];  // 32 KB staging for dense stores
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const uint64_t lt = lanemask_lt();
+    // HOT: float64 predicate column without a validity bitmap (host-checked); values live in registers and
+    // the next tile is prefetched.  Otherwise predicates go through the generic per-element evaluator.
+    constexpr bool hot = HOT;
+    const double* vals = (const double*)a.pred.values;
 
-    for (;;) {
-        if (tid == 0) s_tile = (int64_t)atomicAdd(a.ctl, 1ULL);
-        __syncthreads();
-        const int64_t tile = s_tile;
-        if (tile >= a.ntiles) break;
+    double cv0[F_CHUNKS], cv1[F_CHUNKS];  // values of the tile being processed
+    double nv0[F_CHUNKS], nv1[F_CHUNKS];  // prefetched values of the next tile
+
+    // The loop is software pipelined: the ticket and the loads of tile t+1 are issued BEFORE the
+    // look-back and the stores of tile t, so HBM reads stay in flight across the serial part.
+#define VNM_LOAD_TILE(T, V0, V1)                                                                  \
+    do {                                                                                          \
+        const int64_t pb_ = a.phys_base + (T) * F_TILE + 2 * tid;                                 \
+        const int64_t first_ = a.phys_base + (T) * F_TILE - a.pred.offset;                        \
+        if (first_ >= 0 && first_ + F_TILE <= a.length) {                                         \
+            const double2* src_ = (const double2*)(vals + pb_);                                   \
+            _Pragma("unroll") for (int j = 0; j < F_CHUNKS; j++) {                                \
+                double2 t_ = src_[j * FB];                                                        \
+                V0[j] = t_.x; V1[j] = t_.y;                                                       \
+            }                                                                                     \
+        } else {                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < F_CHUNKS; j++) {                                \
+                int64_t p0 = pb_ + (int64_t)j * (2 * FB);                                         \
+                int64_t r0 = p0 - a.pred.offset;                                                  \
+                V0[j] = (r0 >= 0 && r0 < a.length) ? vals[p0] : 0.0;                              \
+                V1[j] = (r0 + 1 >= 0 && r0 + 1 < a.length) ? vals[p0 + 1] : 0.0;                  \
+            }                                                                                     \
+        }                                                                                         \
+    } while (0)
+
+    if (tid == 0) s_next[1] = (int64_t)atomicAdd(a.ctl, 1ULL);
+    __syncthreads();
+    int64_t tile = s_next[1];
+    if (tile < a.ntiles && hot) VNM_LOAD_TILE(tile, cv0, cv1);
+
+    for (int it = 0; tile < a.ntiles; it++) {
+        if (tid == 0) s_next[it & 1] = (int64_t)atomicAdd(a.ctl, 1ULL);
 
         // physical element index of this lane's first element in chunk 0; logical row = phys - pred.offset
         const int64_t pbase = a.phys_base + tile * F_TILE + 2 * tid;
         uint32_t flags = 0;
         uint32_t rank[F_CHUNKS];
-        double v0[F_CHUNKS], v1[F_CHUNKS];
-
-        if (MODE == CMP_F64 && a.pred.type == VNM_F64) {
-            // hot path: issue all eight 16-byte loads first
-            const double* vals = (const double*)a.pred.values;
-#pragma unroll
-            for (int j = 0; j < F_CHUNKS; j++) {
-                int64_t p0 = pbase + (int64_t)j * (2 * FB);
-                int64_t r0 = p0 - a.pred.offset;
-                if (r0 >= 0 && r0 + 1 < a.length) {
-                    double2 t = *(const double2*)(vals + p0);
-                    v0[j] = t.x; v1[j] = t.y;
-                } else {
-                    v0[j] = (r0 >= 0 && r0 < a.length) ? vals[p0] : 0.0;
-                    v1[j] = (r0 + 1 >= 0 && r0 + 1 < a.length) ? vals[p0 + 1] : 0.0;
-                }
-            }
-        }
 #pragma unroll
         for (int j = 0; j < F_CHUNKS; j++) {
             int64_t p0 = pbase + (int64_t)j * (2 * FB);
@@ -100,11 +116,9 @@ __global__ __launch_bounds__(FB) void filter_kernel(FilterArgs a) {
             if (MODE == MODE_MASK) {
                 if (in0) f0 = a.mask_valid && !a.mask_valid[r0] ? true : a.mask[r0] != 0;
                 if (in1) f1 = a.mask_valid && !a.mask_valid[r1] ? true : a.mask[r1] != 0;
-            } else if (MODE == CMP_F64 && a.pred.type == VNM_F64) {
-                double x0 = (in0 && col_valid(a.pred, r0)) ? v0[j] : __builtin_nan("");
-                double x1 = (in1 && col_valid(a.pred, r1)) ? v1[j] : __builtin_nan("");
-                f0 = in0 && cmp_apply<double>(a.p.op, x0, a.p.dval);
-                f1 = in1 && cmp_apply<double>(a.p.op, x1, a.p.dval);
+            } else if (hot) {
+                f0 = in0 && cmp_apply<double>(a.p.op, cv0[j], a.p.dval);
+                f1 = in1 && cmp_apply<double>(a.p.op, cv1[j], a.p.dval);
             } else {
                 f0 = in0 && pred_eval(a.p, a.pred, r0);
                 f1 = in1 && pred_eval(a.p, a.pred, r1);
@@ -112,23 +126,30 @@ __global__ __launch_bounds__(FB) void filter_kernel(FilterArgs a) {
             uint64_t b0 = __ballot(f0), b1 = __ballot(f1);
             rank[j] = __popcll(b0 & lt) + __popcll(b1 & lt);
             flags |= (f0 ? 1u : 0u) << (2 * j) | (f1 ? 1u : 0u) << (2 * j + 1);
-            if (lane == 0) s_cnt[j * 4 + wave] = __popcll(b0) + __popcll(b1);
+            if (lane == 0) s_cnt[j * NW + wave] = __popcll(b0) + __popcll(b1);
         }
-        __syncthreads();
+        __syncthreads();  // #1: counts and next ticket visible
 
-        // ---- wave 0: scan the 32 segment counts, then decoupled look-back for the tile base ----
+        const int64_t ntile = s_next[it & 1];
+        if (ntile < a.ntiles && hot) VNM_LOAD_TILE(ntile, nv0, nv1);
+
+        // ---- wave 0: scan the segment counts, then decoupled look-back for the tile base ----
         if (wave == 0) {
-            uint32_t c = lane < F_CHUNKS * 4 ? s_cnt[lane] : 0;
+            uint32_t c0 = 2 * lane < NSEG ? s_cnt[2 * lane] : 0;
+            uint32_t c1 = 2 * lane + 1 < NSEG ? s_cnt[2 * lane + 1] : 0;
+            uint32_t c = c0 + c1;
             uint32_t inc = c;
 #pragma unroll
-            for (int d = 1; d < 32; d <<= 1) {
+            for (int d = 1; d < 64; d <<= 1) {
                 uint32_t o = __shfl_up(inc, d);
                 if (lane >= d) inc += o;
             }
-            if (lane < F_CHUNKS * 4) s_excl[lane] = inc - c;
-            uint32_t total = __shfl(inc, 31);
+            if (2 * lane < NSEG) s_excl[2 * lane] = inc - c;
+            if (2 * lane + 1 < NSEG) s_excl[2 * lane + 1] = inc - c + c0;
+            uint32_t total = __shfl(inc, 63);
             int64_t excl = 0;
-            if (tile > 0) {
+            if (tile > 0 && (a.debug & 1)) excl = tile * (F_TILE / 2);
+            else if (tile > 0) {
                 if (lane == 0)
                     __hip_atomic_store(&a.status[tile], ST_AGG | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 int64_t look = tile - 1;
@@ -149,7 +170,6 @@ __global__ __launch_bounds__(FB) void filter_kernel(FilterArgs a) {
                         __builtin_amdgcn_s_sleep(1);
                         continue;
                     }
-                    // wave sum of val
 #pragma unroll
                     for (int d = 32; d > 0; d >>= 1) val += __shfl_xor(val, d);
                     excl += (int64_t)val;
@@ -160,82 +180,281 @@ __global__ __launch_bounds__(FB) void filter_kernel(FilterArgs a) {
             if (lane == 0) {
                 __hip_atomic_store(&a.status[tile], ST_INC | (uint64_t)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_base = excl;
-                s_total = total;
                 if (tile == a.ntiles - 1) a.ctl[1] = (unsigned long long)(excl + total);
             }
         }
-        __syncthreads();
+        __syncthreads();  // #2: tile base known
         const int64_t base = s_base;
-        const uint32_t total = s_total;
 
-        // ---- write survivors, one payload column at a time, staged through LDS for dense stores ----
-        for (int k = 0; k < a.n_payload; k++) {
+        // ---- write survivors: within a wave the survivors of one chunk land on a contiguous range, so
+        // the two store instructions of a chunk together cover whole cache lines ----
+        if (hot) {
+            // the only payload is the predicate column itself: values are still in registers
+            if (a.n_payload && !(a.debug & 4)) {
+                uint64_t* out = (uint64_t*)a.out_values[0] + base;
+#pragma unroll
+                for (int j = 0; j < F_CHUNKS; j++) {
+                    uint32_t fj = (flags >> (2 * j)) & 3u;
+                    uint32_t pos = s_excl[j * NW + wave] + rank[j];
+                    if (fj & 1u) out[pos++] = (uint64_t)__double_as_longlong(cv0[j]);
+                    if (fj & 2u) out[pos] = (uint64_t)__double_as_longlong(cv1[j]);
+                }
+            }
+        } else
+        for (int k = 0; k < ((a.debug & 4) ? 0 : a.n_payload); k++) {
             const vnm_dcol& c = a.payload[k];
             const int w = type_width(c.type);
-            const bool reuse = (k == 0 && a.reuse_pred && MODE == CMP_F64 && a.pred.type == VNM_F64);
-            // (1) survivors -> LDS at their tile-local rank (as 64-bit cells)
+            const bool reuse = false;
 #pragma unroll
             for (int j = 0; j < F_CHUNKS; j++) {
                 uint32_t fj = (flags >> (2 * j)) & 3u;
                 if (!fj) continue;
                 int64_t r0 = pbase + (int64_t)j * (2 * FB) - a.pred.offset;
-                uint32_t pos = s_excl[j * 4 + wave] + rank[j];
-                if (fj & 1u) {
-                    uint64_t bits;
-                    if (reuse) bits = __double_as_longlong(v0[j]);
-                    else if (w == 8) bits = ((const uint64_t*)c.values)[c.offset + r0];
-                    else bits = col_raw_bits(c, r0);
-                    s_stage[pos++] = bits;
-                }
-                if (fj & 2u) {
-                    uint64_t bits;
-                    if (reuse) bits = __double_as_longlong(v1[j]);
-                    else if (w == 8) bits = ((const uint64_t*)c.values)[c.offset + r0 + 1];
-                    else bits = col_raw_bits(c, r0 + 1);
-                    s_stage[pos] = bits;
-                }
-            }
-            __syncthreads();
-            // (2) dense copy LDS -> global
-            if (w == 8) {
-                uint64_t* out = (uint64_t*)a.out_values[k] + base;
-                for (uint32_t i = tid; i < total; i += FB) out[i] = s_stage[i];
-            } else if (w == 4) {
-                uint32_t* out = (uint32_t*)a.out_values[k] + base;
-                for (uint32_t i = tid; i < total; i += FB) out[i] = (uint32_t)s_stage[i];
-            } else if (w == 2) {
-                uint16_t* out = (uint16_t*)a.out_values[k] + base;
-                for (uint32_t i = tid; i < total; i += FB) out[i] = (uint16_t)s_stage[i];
-            } else {
-                uint8_t* out = (uint8_t*)a.out_values[k] + base;
-                for (uint32_t i = tid; i < total; i += FB) out[i] = (uint8_t)s_stage[i];
-            }
-            // (3) validity bytes (only for payloads that carry a bitmap, or emit_null masks)
-            if (a.out_valid[k]) {
-                __syncthreads();
-                uint8_t* stage8 = (uint8_t*)s_stage;
+                int64_t pos = base + s_excl[j * NW + wave] + rank[j];
 #pragma unroll
-                for (int j = 0; j < F_CHUNKS; j++) {
-                    uint32_t fj = (flags >> (2 * j)) & 3u;
-                    if (!fj) continue;
-                    int64_t r0 = pbase + (int64_t)j * (2 * FB) - a.pred.offset;
-                    uint32_t pos = s_excl[j * 4 + wave] + rank[j];
-                    if (fj & 1u) {
-                        bool ok = col_valid(c, r0) && !(MODE == MODE_MASK && a.mask_valid && !a.mask_valid[r0]);
-                        stage8[pos++] = ok;
+                for (int e = 0; e < 2; e++) {
+                    if (!(fj & (1u << e))) continue;
+                    uint64_t bits;
+                    if (reuse) bits = (uint64_t)__double_as_longlong(e ? cv1[j] : cv0[j]);
+                    else bits = col_raw_bits(c, r0 + e);
+                    switch (w) {
+                        case 8: ((uint64_t*)a.out_values[k])[pos] = bits; break;
+                        case 4: ((uint32_t*)a.out_values[k])[pos] = (uint32_t)bits; break;
+                        case 2: ((uint16_t*)a.out_values[k])[pos] = (uint16_t)bits; break;
+                        default: ((uint8_t*)a.out_values[k])[pos] = (uint8_t)bits; break;
                     }
-                    if (fj & 2u) {
-                        bool ok = col_valid(c, r0 + 1) && !(MODE == MODE_MASK && a.mask_valid && !a.mask_valid[r0 + 1]);
-                        stage8[pos] = ok;
-                    }
+                    if (a.out_valid[k])
+                        a.out_valid[k][pos] = col_valid(c, r0 + e) && !(MODE == MODE_MASK && a.mask_valid && !a.mask_valid[r0 + e]);
+                    pos++;
                 }
-                __syncthreads();
-                uint8_t* ov = a.out_valid[k] + base;
-                for (uint32_t i = tid; i < total; i += FB) ov[i] = stage8[i];
             }
-            __syncthreads();
         }
+        // rotate the pipeline
+#pragma unroll
+        for (int j = 0; j < F_CHUNKS; j++) { if (hot) { cv0[j] = nv0[j]; cv1[j] = nv1[j]; } }
+        tile = ntile;
     }
+#undef VNM_LOAD_TILE
+}
+
+// =======================================================================================================
+// Hot filter kernel: float64 predicate column without validity, output = the compacted column itself
+// (BASELINE configs[1]).  Three-stage software pipeline per workgroup so that neither the HBM reads nor
+// the successors of our tiles ever wait on a look-back:
+//     C = loads in flight (ticket just taken)   B = loaded -> counted -> AGGREGATE PUBLISHED
+//     A = counted one iteration ago -> look-back -> stores
+// A tile's aggregate is published as soon as its loads land (it depends on nothing else), and its
+// look-back runs one iteration later, when most predecessors have already published.
+// =======================================================================================================
+// Decoupled look-back over a 256-tile window (four status words per lane requested together).  sw[] holds
+// the window starting at tile - 1 prefetched by the caller.  Returns the exclusive prefix of `tile`.
+__device__ __forceinline__ int64_t lookback(unsigned long long* status, int64_t tile, int lane, uint64_t* sw) {
+    int64_t excl = 0;
+    int64_t look = tile - 1;
+    bool fresh = true;
+    for (;;) {
+        if (!fresh) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int64_t idx = look - (q * 64 + lane);
+                sw[q] = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ST_INC;
+            }
+        }
+        fresh = false;
+        bool done = false, retry = false;
+        int64_t acc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (done || retry) continue;
+            uint64_t flag = sw[q] >> 62;
+            uint64_t incl_mask = __ballot(flag == 2);
+            uint64_t zero_mask = __ballot(flag == 0);
+            uint64_t val = sw[q] & ST_VAL;
+            if (incl_mask) {
+                // only the predecessors up to the nearest inclusive prefix matter
+                int first = __ffsll((unsigned long long)incl_mask) - 1;
+                uint64_t need = first == 0 ? 0ULL : (~0ULL >> (64 - first));
+                if (zero_mask & need) { retry = true; continue; }
+                if (lane > first) val = 0;
+                done = true;
+            } else if (zero_mask) {
+                retry = true;
+                continue;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) val += __shfl_xor(val, d);
+            acc += (int64_t)val;
+        }
+        if (retry) { __builtin_amdgcn_s_sleep(1); continue; }
+        excl += acc;
+        if (done) return excl;
+        look -= 256;
+    }
+}
+
+constexpr int FH_THREADS = 512;
+constexpr int FH_CHUNKS = 8;
+constexpr int FH_TILE = FH_THREADS * 2 * FH_CHUNKS;  // 8192 rows
+constexpr int FH_NW = FH_THREADS / 64;
+constexpr int FH_NSEG = FH_CHUNKS * FH_NW;           // 64: one segment per lane of wave 0
+
+__global__ __launch_bounds__(FH_THREADS) void filter_hot_kernel(FilterArgs a) {
+    __shared__ int64_t s_next[2];
+    __shared__ uint32_t s_cnt[FH_NSEG];
+    __shared__ uint32_t s_excl[2][FH_NSEG];
+    __shared__ int64_t s_base;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint64_t lt = lanemask_lt();
+    const double* vals = (const double*)a.pred.values;
+    const int op = a.p.op;
+    const double thr = a.p.dval;
+
+    // three register sets that ROTATE ROLES (A -> C -> B -> A) instead of being copied: a register copy of
+    // a set whose loads are still in flight would force an s_waitcnt on them and serialise the pipeline
+    double s0v0[FH_CHUNKS], s0v1[FH_CHUNKS], s1v0[FH_CHUNKS], s1v1[FH_CHUNKS], s2v0[FH_CHUNKS], s2v1[FH_CHUNKS];
+    uint32_t s0rank[FH_CHUNKS], s1rank[FH_CHUNKS], s2rank[FH_CHUNKS];
+    uint32_t s0flags = 0, s1flags = 0, s2flags = 0;
+    uint32_t a_total = 0;  // wave 0: total of tile A
+
+#define VNM_LOAD(T, V0, V1)                                                                       \
+    do {                                                                                          \
+        const int64_t pb_ = a.phys_base + (T) * FH_TILE + 2 * tid;                                \
+        const int64_t first_ = a.phys_base + (T) * FH_TILE - a.pred.offset;                       \
+        if (first_ >= 0 && first_ + FH_TILE <= a.length) {                                        \
+            const double2* src_ = (const double2*)(vals + pb_);                                   \
+            _Pragma("unroll") for (int j = 0; j < FH_CHUNKS; j++) {                               \
+                double2 t_ = src_[j * FH_THREADS];                                                \
+                V0[j] = t_.x; V1[j] = t_.y;                                                       \
+            }                                                                                     \
+        } else {                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < FH_CHUNKS; j++) {                               \
+                int64_t p0 = pb_ + (int64_t)j * (2 * FH_THREADS);                                 \
+                int64_t r0 = p0 - a.pred.offset;                                                  \
+                V0[j] = (r0 >= 0 && r0 < a.length) ? vals[p0] : __builtin_nan("");                \
+                V1[j] = (r0 + 1 >= 0 && r0 + 1 < a.length) ? vals[p0 + 1] : __builtin_nan("");    \
+            }                                                                                     \
+        }                                                                                         \
+    } while (0)
+
+    // out-of-range elements of a ragged tile must not survive whatever the operator is
+#define VNM_COUNT(T, V0, V1, FLAGS, RANK)                                                         \
+    do {                                                                                          \
+        const int64_t rb_ = a.phys_base + (T) * FH_TILE + 2 * tid - a.pred.offset;                \
+        FLAGS = 0;                                                                                \
+        _Pragma("unroll") for (int j = 0; j < FH_CHUNKS; j++) {                                   \
+            int64_t r0 = rb_ + (int64_t)j * (2 * FH_THREADS);                                     \
+            bool f0 = r0 >= 0 && r0 < a.length && cmp_apply<double>(op, V0[j], thr);              \
+            bool f1 = r0 + 1 >= 0 && r0 + 1 < a.length && cmp_apply<double>(op, V1[j], thr);      \
+            uint64_t b0 = __ballot(f0), b1 = __ballot(f1);                                        \
+            RANK[j] = __popcll(b0 & lt) + __popcll(b1 & lt);                                      \
+            FLAGS |= (f0 ? 1u : 0u) << (2 * j) | (f1 ? 1u : 0u) << (2 * j + 1);                   \
+            if (lane == 0) s_cnt[j * FH_NW + wave] = __popcll(b0) + __popcll(b1);                 \
+        }                                                                                         \
+    } while (0)
+
+    // Tickets are requested one iteration before they are needed (a returning atomic on the shared ticket
+    // word takes 1-3 us under streaming load); `pending` lives in thread 0 only.  This file is built with
+    // -amdgpu-atomic-optimizer-strategy=None: the optimizer's wave-aggregation epilogue reads the result
+    // back immediately (s_waitcnt vmcnt(0)), which would drain the whole load pipeline every iteration.
+    unsigned long long pending = 0;
+    if (tid == 0) {
+        s_next[1] = (int64_t)__hip_atomic_fetch_add(a.ctl, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = __hip_atomic_fetch_add(a.ctl, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    int64_t tile_a = -1;
+    int64_t tile_b = s_next[1];
+    int64_t tile_c = 0;
+    if (tile_b < a.ntiles) VNM_LOAD(tile_b, s1v0, s1v1);
+    int it = 0;
+
+    // one pipeline step with register sets in roles A (store), B (count + publish), C (load)
+#define VNM_STEP(A, B, C)                                                                                   \
+    {                                                                                                       \
+        const int par = it & 1;                                                                             \
+        it++;                                                                                               \
+        /* (0) wave 0 requests A's 256-tile look-back window FIRST: under streaming load a status read */   \
+        /* queues behind every HBM request this CU already issued, so it goes out before the bulk loads */  \
+        uint64_t sw[4];                                                                                     \
+        if (wave == 0 && tile_a > 0) {                                                                      \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                 \
+                int64_t idx = tile_a - 1 - (q * 64 + lane);                                                 \
+                sw[q] = idx >= 0 ? __hip_atomic_load(&a.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ST_INC; \
+            }                                                                                               \
+        }                                                                                                   \
+        /* (1) hand out the ticket requested one step ago, request the next one */                          \
+        if (tid == 0) {                                                                                     \
+            s_next[par] = (int64_t)pending;                                                                 \
+            pending = __hip_atomic_fetch_add(a.ctl, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      \
+        }                                                                                                   \
+        /* (2) count B (its loads were issued one step ago) */                                              \
+        if (tile_b < a.ntiles) VNM_COUNT(tile_b, B##v0, B##v1, B##flags, B##rank);                          \
+        __syncthreads(); /* #1: s_cnt(B) and the ticket are visible */                                      \
+        tile_c = s_next[par];                                                                               \
+        if (wave != 0 && tile_c < a.ntiles) VNM_LOAD(tile_c, C##v0, C##v1);                                 \
+        if (wave == 0) {                                                                                    \
+            /* (3) publish B's aggregate right away: it depends on nothing but B's loads */                 \
+            uint32_t b_total = 0;                                                                           \
+            if (tile_b < a.ntiles) {                                                                        \
+                uint32_t c = s_cnt[lane];                                                                   \
+                uint32_t inc = c;                                                                           \
+                _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) {                                        \
+                    uint32_t o = __shfl_up(inc, d);                                                         \
+                    if (lane >= d) inc += o;                                                                \
+                }                                                                                           \
+                s_excl[par][lane] = inc - c;                                                                \
+                b_total = __shfl(inc, 63);                                                                  \
+                if (lane == 0)                                                                              \
+                    __hip_atomic_store(&a.status[tile_b], (tile_b > 0 ? ST_AGG : ST_INC) | (uint64_t)b_total, \
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                         \
+            }                                                                                               \
+            /* (4) look-back for A (its aggregate was published one step ago) */                            \
+            if (tile_a >= 0) {                                                                              \
+                int64_t excl = 0;                                                                           \
+                if (tile_a > 0 && (a.debug & 1)) excl = tile_a * (FH_TILE / 2);                             \
+                else if (tile_a > 0) {                                                                      \
+                    excl = lookback(a.status, tile_a, lane, sw);                                            \
+                    if (lane == 0)                                                                          \
+                        __hip_atomic_store(&a.status[tile_a], ST_INC | (uint64_t)(excl + a_total),          \
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                     \
+                }                                                                                           \
+                if (lane == 0) {                                                                            \
+                    s_base = excl;                                                                          \
+                    if (tile_a == a.ntiles - 1) a.ctl[1] = (unsigned long long)(excl + a_total);            \
+                }                                                                                           \
+            }                                                                                               \
+            a_total = b_total;                                                                              \
+            if (tile_c < a.ntiles) VNM_LOAD(tile_c, C##v0, C##v1);                                          \
+        }                                                                                                   \
+        __syncthreads(); /* #2: base(A) and s_excl(B) are visible */                                        \
+        /* (5) stores of A: per wave and chunk the survivors land on a contiguous range */                  \
+        if (tile_a >= 0 && a.n_payload && !(a.debug & 4)) {                                                 \
+            uint64_t* out = (uint64_t*)a.out_values[0] + s_base;                                            \
+            _Pragma("unroll") for (int j = 0; j < FH_CHUNKS; j++) {                                         \
+                uint32_t fj = (A##flags >> (2 * j)) & 3u;                                                   \
+                uint32_t pos = s_excl[par ^ 1][j * FH_NW + wave] + A##rank[j];                              \
+                if (fj & 1u) out[pos++] = (uint64_t)__double_as_longlong(A##v0[j]);                         \
+                if (fj & 2u) out[pos] = (uint64_t)__double_as_longlong(A##v1[j]);                           \
+            }                                                                                               \
+        }                                                                                                   \
+        tile_a = tile_b < a.ntiles ? tile_b : -1;                                                           \
+        tile_b = tile_c;                                                                                    \
+    }
+
+    for (;;) {
+        VNM_STEP(s0, s1, s2)
+        if (!(tile_a >= 0 || tile_b < a.ntiles)) break;
+        VNM_STEP(s1, s2, s0)
+        if (!(tile_a >= 0 || tile_b < a.ntiles)) break;
+        VNM_STEP(s2, s0, s1)
+        if (!(tile_a >= 0 || tile_b < a.ntiles)) break;
+    }
+#undef VNM_STEP
+#undef VNM_LOAD
+#undef VNM_COUNT
 }
 
 // byte-per-row validity -> Arrow bitmap (LSB first), 8 rows per lane
@@ -252,30 +471,67 @@ __global__ void pack_validity_kernel(const uint8_t* bytes, int64_t n, uint8_t* b
     }
 }
 
+template <int MODE, int FB>
+static void launch_variant(const FilterArgs& a, int grid, hipStream_t s) {
+    const bool hot = MODE == CMP_F64 && a.pred.type == VNM_F64 && !a.pred.validity &&
+                     (a.n_payload == 0 || (a.n_payload == 1 && a.reuse_pred && !a.out_valid[0]));
+    if (hot) filter_kernel<MODE, FB, true><<<grid, FB, 0, s>>>(a);
+    else filter_kernel<MODE, FB, false><<<grid, FB, 0, s>>>(a);
+}
+
+// tuning knobs (defaults chosen by measurement, profiles/): VNM_FILTER_THREADS in {256,512,1024},
+// VNM_FILTER_WGS_PER_CU
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 static int launch_filter(FilterArgs& a, int mode, int64_t* out_count, hipStream_t s) {
     DeviceInfo& d = device_info();
+    const bool hot = mode == CMP_F64 && a.pred.type == VNM_F64 && !a.pred.validity &&
+                     (a.n_payload == 0 || (a.n_payload == 1 && a.reuse_pred && !a.out_valid[0])) &&
+                     env_int("VNM_FILTER_PIPE3", 0) != 0;  // 3-stage variant: measured slower (profiles/filter_tuning_r01.md)
+    const bool hot2 = mode == CMP_F64 && a.pred.type == VNM_F64 && !a.pred.validity &&
+                      (a.n_payload == 0 || (a.n_payload == 1 && a.reuse_pred && !a.out_valid[0]));
+    int fb = hot ? FH_THREADS : env_int("VNM_FILTER_THREADS", hot2 ? 1024 : 512);
+    fb = fb >= 1024 ? 1024 : (fb >= 512 ? 512 : 256);
+    const int chunks = 8;
+    const int tile_rows = hot ? FH_TILE : fb * 2 * chunks;
     a.phys_base = a.pred.values ? (a.pred.offset & ~1LL) : 0;
     int64_t span = (a.pred.values ? a.pred.offset : 0) + a.length - a.phys_base;
-    a.ntiles = (span + F_TILE - 1) / F_TILE;
+    a.ntiles = (span + tile_rows - 1) / tile_rows;
     if (a.length == 0 || a.ntiles == 0) {
         *out_count = 0;
         return 0;
     }
-    size_t sbytes = (size_t)(a.ntiles + 2) * 8;
+    size_t sbytes = (size_t)(a.ntiles + 8) * 8;
     unsigned long long* scratch = (unsigned long long*)pool_alloc(sbytes);
     if (!scratch) return 1;
     VNM_HIP(hipMemsetAsync(scratch, 0, sbytes, s));
     a.ctl = scratch;
-    a.status = scratch + 2;
-    int64_t grid = (int64_t)d.num_cus * 8;
+    a.status = scratch + 8;
+    a.debug = env_int("VNM_FILTER_DEBUG", 0);
+    int64_t grid = (int64_t)d.num_cus * env_int("VNM_FILTER_WGS_PER_CU", 2048 / fb);
     if (grid > a.ntiles) grid = a.ntiles;
     {
     KernelTimer timer("filter_kernel", s);
+#define VNM_LAUNCH(M)                                                    \
+    do {                                                                 \
+        if (fb == 1024) launch_variant<M, 1024>(a, (int)grid, s);        \
+        else if (fb == 512) launch_variant<M, 512>(a, (int)grid, s);     \
+        else launch_variant<M, 256>(a, (int)grid, s);                    \
+    } while (0)
+    if (hot) {
+        int64_t g2 = (int64_t)d.num_cus * env_int("VNM_FILTER_WGS_PER_CU", 1);
+        if (g2 > a.ntiles) g2 = a.ntiles;
+        filter_hot_kernel<<<(int)g2, FH_THREADS, 0, s>>>(a);
+    } else
     switch (mode) {
-        case CMP_F64: filter_kernel<CMP_F64><<<(int)grid, FB, 0, s>>>(a); break;
-        case MODE_MASK: filter_kernel<MODE_MASK><<<(int)grid, FB, 0, s>>>(a); break;
-        default: filter_kernel<CMP_I64><<<(int)grid, FB, 0, s>>>(a); break;  // generic pred_eval path
+        case CMP_F64: VNM_LAUNCH(CMP_F64); break;
+        case MODE_MASK: VNM_LAUNCH(MODE_MASK); break;
+        default: VNM_LAUNCH(CMP_I64); break;  // generic pred_eval path
     }
+#undef VNM_LAUNCH
     }
     VNM_HIP(hipGetLastError());
     unsigned long long total = 0;
@@ -292,7 +548,7 @@ using namespace vnm;
 
 extern "C" {
 
-int64_t vnm_filter_scratch_bytes(int64_t length) { return ((length + F_TILE) / F_TILE + 3) * 8; }
+int64_t vnm_filter_scratch_bytes(int64_t length) { return ((length + 4096) / 4096 + 9) * 8; }
 
 int vnm_pack_validity(const uint8_t* valid_bytes, int64_t n, uint8_t* bitmap, void* stream) {
     VNM_TRY(ensure_init());
