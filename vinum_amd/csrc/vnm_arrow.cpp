@@ -1,12 +1,446 @@
-#include "vnm_common.hpp"
+// Arrow-level operator handles: the entry points a binding of the reference's native boundary calls
+// (vinum/core/vinum_lib.cpp:54-142: next(batch) per RecordBatch, one result()/sorted()).
+// Batches cross as Arrow C Data Interface structs (no libarrow dependency); columns are staged into HBM,
+// the device-level operators run there, and results come back as freshly allocated Arrow arrays.
+#include <map>
+#include <memory>
+
+#include "vnm_agg.hpp"
+
 using namespace vnm;
-extern "C" {
-vnm_agg_op* vnm_agg_op_create(int, int, const char**, int, const char**, int, const int*, const char**, const char**) { set_error("not implemented yet"); return nullptr; }
-int vnm_agg_op_next(vnm_agg_op*, struct ArrowArray*, struct ArrowSchema*) { return set_error("not implemented yet"); }
-int vnm_agg_op_result(vnm_agg_op*, struct ArrowArray*, struct ArrowSchema*) { return set_error("not implemented yet"); }
-void vnm_agg_op_destroy(vnm_agg_op*) {}
-vnm_sort_op* vnm_sort_op_create(int, const char**, const int*) { set_error("not implemented yet"); return nullptr; }
-int vnm_sort_op_next(vnm_sort_op*, struct ArrowArray*, struct ArrowSchema*) { return set_error("not implemented yet"); }
-int vnm_sort_op_sorted(vnm_sort_op*, int64_t, struct ArrowArray*, struct ArrowSchema*) { return set_error("not implemented yet"); }
-void vnm_sort_op_destroy(vnm_sort_op*) {}
+
+namespace {
+
+// ---- Arrow C Data Interface helpers ------------------------------------------------------------------
+struct ColType {
+    int type = -1;   // vnm_type or -1 (unsupported)
+    int flags = 0;
+    std::string format;
+};
+
+ColType parse_format(const char* f) {
+    ColType c;
+    c.format = f ? f : "";
+    const std::string& s = c.format;
+    if (s == "c") c.type = VNM_I8;
+    else if (s == "C") c.type = VNM_U8;
+    else if (s == "s") c.type = VNM_I16;
+    else if (s == "S") c.type = VNM_U16;
+    else if (s == "i") c.type = VNM_I32;
+    else if (s == "I") c.type = VNM_U32;
+    else if (s == "l") c.type = VNM_I64;
+    else if (s == "L") c.type = VNM_U64;
+    else if (s == "f") c.type = VNM_F32;
+    else if (s == "g") c.type = VNM_F64;
+    else if (s == "tdD") c.type = VNM_I32;                              // date32
+    else if (s == "tdm") c.type = VNM_I64;                              // date64
+    else if (s == "tts" || s == "ttm") { c.type = VNM_I32; c.flags = VNM_FLAG_SUM32; }  // time32
+    else if (s == "ttu" || s == "ttn") c.type = VNM_I64;                // time64
+    else if (s.rfind("ts", 0) == 0 && s.size() >= 4 && s[3] == ':') c.type = VNM_I64;  // timestamp
+    else if (s == "tDs" || s == "tDm" || s == "tDu" || s == "tDn") c.type = VNM_I64;   // duration
+    return c;
 }
+
+void release_schema(struct ArrowSchema* s) {
+    if (!s || !s->release) return;
+    for (int64_t i = 0; i < s->n_children; i++) {
+        if (s->children[i]) {
+            if (s->children[i]->release) s->children[i]->release(s->children[i]);
+            free(s->children[i]);
+        }
+    }
+    free(s->children);
+    free((void*)s->format);
+    free((void*)s->name);
+    s->release = nullptr;
+}
+
+void release_array(struct ArrowArray* a) {
+    if (!a || !a->release) return;
+    for (int64_t i = 0; i < a->n_children; i++) {
+        if (a->children[i]) {
+            if (a->children[i]->release) a->children[i]->release(a->children[i]);
+            free(a->children[i]);
+        }
+    }
+    free(a->children);
+    for (int64_t i = 0; i < a->n_buffers; i++) free((void*)a->buffers[i]);
+    free(a->buffers);
+    a->release = nullptr;
+}
+
+void make_schema(struct ArrowSchema* s, const std::string& format, const std::string& name, int64_t n_children) {
+    memset(s, 0, sizeof(*s));
+    s->format = strdup(format.c_str());
+    s->name = strdup(name.c_str());
+    s->flags = 2;  // ARROW_FLAG_NULLABLE
+    s->n_children = n_children;
+    s->children = n_children ? (struct ArrowSchema**)calloc((size_t)n_children, sizeof(void*)) : nullptr;
+    for (int64_t i = 0; i < n_children; i++) s->children[i] = (struct ArrowSchema*)calloc(1, sizeof(struct ArrowSchema));
+    s->release = release_schema;
+}
+
+// primitive array with malloc'ed buffers; valid may be NULL (no nulls)
+void make_primitive(struct ArrowArray* a, int64_t n, int width, const void* values, const uint8_t* valid_bytes) {
+    memset(a, 0, sizeof(*a));
+    a->length = n;
+    a->n_buffers = 2;
+    a->buffers = (const void**)calloc(2, sizeof(void*));
+    int64_t nulls = 0;
+    if (valid_bytes) for (int64_t i = 0; i < n; i++) nulls += !valid_bytes[i];
+    a->null_count = nulls;
+    if (nulls) {
+        uint8_t* bm = (uint8_t*)calloc((size_t)((n + 7) / 8 + 1), 1);
+        for (int64_t i = 0; i < n; i++) if (valid_bytes[i]) bm[i >> 3] |= (uint8_t)(1u << (i & 7));
+        a->buffers[0] = bm;
+    }
+    void* data = malloc((size_t)(n ? n : 1) * width);
+    if (n) memcpy(data, values, (size_t)n * width);
+    a->buffers[1] = data;
+    a->release = release_array;
+}
+
+void make_struct(struct ArrowArray* a, int64_t n, int64_t n_children) {
+    memset(a, 0, sizeof(*a));
+    a->length = n;
+    a->n_buffers = 1;
+    a->buffers = (const void**)calloc(1, sizeof(void*));
+    a->n_children = n_children;
+    a->children = n_children ? (struct ArrowArray**)calloc((size_t)n_children, sizeof(void*)) : nullptr;
+    for (int64_t i = 0; i < n_children; i++) a->children[i] = (struct ArrowArray*)calloc(1, sizeof(struct ArrowArray));
+    a->release = release_array;
+}
+
+struct ImportedBatch {
+    struct ArrowArray arr;
+    struct ArrowSchema sch;
+    bool live = false;
+    void drop() {
+        if (!live) return;
+        if (arr.release) arr.release(&arr);
+        if (sch.release) sch.release(&sch);
+        live = false;
+    }
+};
+
+int find_child(const struct ArrowSchema* s, const std::string& name) {
+    for (int64_t i = 0; i < s->n_children; i++)
+        if (s->children[i]->name && name == s->children[i]->name) return (int)i;
+    return -1;
+}
+
+// stage child column `ci` of an imported struct batch into HBM
+int stage_child(const struct ArrowArray* batch, int ci, const ColType& t, vnm_dcol* out, hipStream_t s) {
+    const struct ArrowArray* c = batch->children[ci];
+    const uint8_t* validity = (c->n_buffers > 0 && c->null_count != 0) ? (const uint8_t*)c->buffers[0] : nullptr;
+    const void* values = c->n_buffers > 1 ? c->buffers[1] : nullptr;
+    int64_t off = c->offset + batch->offset;
+    VNM_TRY(vnm_stage_column(values, validity, off, batch->length, t.type, out, (void*)s));
+    out->flags = t.flags;
+    return 0;
+}
+
+}  // namespace
+
+// =========================================================================================================
+// aggregate operator
+// =========================================================================================================
+struct vnm_agg_op {
+    int kind;
+    std::vector<std::string> groupby, agg_cols, in_cols, out_cols;
+    std::vector<int> funcs;
+    vnm_agg* dev = nullptr;
+    bool inited = false;
+    std::vector<int> key_idx, in_idx, aggcol_key;  // child indices; agg_col -> position in groupby
+    std::vector<ColType> key_t, in_t;
+};
+
+static int agg_op_init(vnm_agg_op* h, const struct ArrowSchema* sch) {
+    // lookup_col_indices base_aggregate.cpp:121-131
+    for (auto& c : h->groupby) {
+        int i = find_child(sch, c);
+        if (i < 0) return set_error("Column not found: %s", c.c_str());
+        h->key_idx.push_back(i);
+        h->key_t.push_back(parse_format(sch->children[i]->format));
+        if (h->key_t.back().type < 0) return set_error("Unsupported data type for aggregation column.");
+    }
+    for (auto& c : h->agg_cols) {
+        int pos = -1;
+        for (size_t j = 0; j < h->groupby.size(); j++) if (h->groupby[j] == c) pos = (int)j;
+        if (find_child(sch, c) < 0) return set_error("Column not found: %s", c.c_str());
+        if (pos < 0) return set_error("aggregate column %s is not a group-by column", c.c_str());
+        h->aggcol_key.push_back(pos);
+    }
+    std::vector<int> ktypes, itypes, iflags, ids;
+    for (auto& t : h->key_t) ktypes.push_back(t.type);
+    for (size_t i = 0; i < h->funcs.size(); i++) {
+        if (h->funcs[i] == VNM_COUNT_STAR || h->in_cols[i].empty()) {
+            h->in_idx.push_back(-1);
+            h->in_t.push_back(ColType());
+            itypes.push_back(VNM_U64); iflags.push_back(0); ids.push_back(-1);
+            continue;
+        }
+        int ci = find_child(sch, h->in_cols[i]);
+        if (ci < 0) return set_error("Column not found: %s", h->in_cols[i].c_str());
+        ColType t = parse_format(sch->children[ci]->format);
+        h->in_idx.push_back(ci);
+        h->in_t.push_back(t);
+        if (t.type < 0 && h->funcs[i] != VNM_COUNT) {
+            switch (h->funcs[i]) {
+                case VNM_MIN: case VNM_MAX: return set_error("Column data type is not supported by min()/max().");
+                case VNM_SUM: return set_error("Column data type is not supported by sum().");
+                default: return set_error("Column data type is not supported by avg().");
+            }
+        }
+        if (t.type < 0) return set_error("count() over non-numeric columns is not supported on the GPU path yet");
+        itypes.push_back(t.type); iflags.push_back(t.flags); ids.push_back(ci);
+    }
+    h->dev = vnm_agg_create(h->kind, (int)ktypes.size(), ktypes.data(), (int)h->funcs.size(), h->funcs.data(),
+                            itypes.data(), iflags.data(), ids.data());
+    if (!h->dev) return 1;
+    h->inited = true;
+    return 0;
+}
+
+extern "C" {
+
+vnm_agg_op* vnm_agg_op_create(int kind, int n_groupby, const char** groupby_cols, int n_aggcols, const char** agg_cols,
+                              int n_funcs, const int* func_types, const char** in_cols, const char** out_cols) {
+    if (ensure_init()) return nullptr;
+    if (kind < VNM_ONE_GROUP || kind > VNM_MULTI_NUMERICAL) { set_error("vnm_agg_op_create: bad operator kind %d", kind); return nullptr; }
+    vnm_agg_op* h = new vnm_agg_op();
+    h->kind = kind;
+    for (int i = 0; i < n_groupby; i++) h->groupby.push_back(groupby_cols[i]);
+    for (int i = 0; i < n_aggcols; i++) h->agg_cols.push_back(agg_cols[i]);
+    for (int i = 0; i < n_funcs; i++) {
+        if (func_types[i] < VNM_COUNT_STAR || func_types[i] > VNM_AVG) { set_error("Unrecognized Aggregate function type."); delete h; return nullptr; }
+        h->funcs.push_back(func_types[i]);
+        h->in_cols.push_back(in_cols[i] ? in_cols[i] : "");
+        h->out_cols.push_back(out_cols[i] ? out_cols[i] : "");
+    }
+    return h;
+}
+
+void vnm_agg_op_destroy(vnm_agg_op* h) {
+    if (!h) return;
+    if (h->dev) vnm_agg_destroy(h->dev);
+    delete h;
+}
+
+int vnm_agg_op_next(vnm_agg_op* h, struct ArrowArray* batch, struct ArrowSchema* schema) {
+    if (!h || !batch || !schema) return set_error("vnm_agg_op_next: null argument");
+    ImportedBatch ib;
+    ib.arr = *batch; ib.sch = *schema; ib.live = true;
+    batch->release = nullptr; schema->release = nullptr;  // ownership moved (Arrow C Data Interface move semantics)
+    int rc = 0;
+    if (!h->inited) rc = agg_op_init(h, &ib.sch);
+    std::vector<vnm_dcol> keys(h->key_idx.size()), inputs(h->funcs.size());
+    std::map<int, vnm_dcol> staged;
+    hipStream_t s = nullptr;
+    auto get = [&](int ci, const ColType& t, vnm_dcol* out) -> int {
+        auto it = staged.find(ci);
+        if (it == staged.end()) {
+            vnm_dcol d;
+            VNM_TRY(stage_child(&ib.arr, ci, t, &d, s));
+            it = staged.emplace(ci, d).first;
+        }
+        *out = it->second;
+        return 0;
+    };
+    for (size_t j = 0; !rc && j < h->key_idx.size(); j++) rc = get(h->key_idx[j], h->key_t[j], &keys[j]);
+    for (size_t i = 0; !rc && i < h->funcs.size(); i++) {
+        memset(&inputs[i], 0, sizeof(vnm_dcol));
+        inputs[i].length = ib.arr.length;
+        if (h->in_idx[i] >= 0) rc = get(h->in_idx[i], h->in_t[i], &inputs[i]);
+    }
+    if (!rc) rc = vnm_agg_next_device(h->dev, ib.arr.length, keys.data(), inputs.data(), nullptr, (void*)s);
+    if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = set_error("vnm_agg_op_next: stream synchronisation failed");
+    for (auto& kv : staged) vnm_free_column(&kv.second);
+    ib.drop();
+    return rc;
+}
+
+int vnm_agg_op_result(vnm_agg_op* h, struct ArrowArray* out, struct ArrowSchema* out_schema) {
+    if (!h || !out || !out_schema) return set_error("vnm_agg_op_result: null argument");
+    if (!h->inited) return set_error("vnm_agg_op_result: no batch was ever passed to next()");
+    int64_t n = 0;
+    VNM_TRY(vnm_agg_finish(h->dev, &n, nullptr));
+    const int64_t ncols = (int64_t)h->agg_cols.size() + (int64_t)h->funcs.size();
+    make_struct(out, n, ncols);
+    make_schema(out_schema, "+s", "", ncols);
+    std::vector<uint64_t> vals((size_t)(n ? n : 1));
+    std::vector<uint8_t> valid((size_t)(n ? n : 1));
+    std::vector<uint8_t> cells((size_t)(n ? n : 1) * 16);
+    int col = 0;
+    // group keys that are selected, in agg_cols order (base_aggregate.cpp:99-118, GroupBuilder agg_funcs.h:544-578)
+    for (size_t a = 0; a < h->agg_cols.size(); a++, col++) {
+        int j = h->aggcol_key[a];
+        VNM_TRY(vnm_agg_result_key(h->dev, j, vals.data(), valid.data()));
+        const ColType& t = h->key_t[j];
+        int w = type_width(t.type);
+        std::vector<uint8_t> narrow((size_t)(n ? n : 1) * w);
+        for (int64_t r = 0; r < n; r++) memcpy(&narrow[(size_t)r * w], &vals[r], (size_t)w);  // little endian truncation
+        make_primitive(out->children[col], n, w, narrow.data(), valid.data());
+        make_schema(out_schema->children[col], t.format, h->agg_cols[a], 0);
+    }
+    for (size_t i = 0; i < h->funcs.size(); i++, col++) {
+        int kind = 0;
+        VNM_TRY(vnm_agg_result_func(h->dev, (int)i, cells.data(), valid.data(), &kind));
+        const ColType& t = h->in_t[i];
+        std::string fmt;
+        int w = 8;
+        std::vector<uint8_t> buf((size_t)(n ? n : 1) * 16);
+        auto pack = [&](int width) {
+            w = width;
+            for (int64_t r = 0; r < n; r++) memcpy(&buf[(size_t)r * width], &cells[(size_t)r * 16], (size_t)width);
+        };
+        const int f = h->funcs[i];
+        if (f == VNM_MIN || f == VNM_MAX) {
+            // type preserving (agg_func_factory.cpp:35-107): cells hold the value widened to 64 bits
+            fmt = t.format;
+            w = type_width(t.type);
+            for (int64_t r = 0; r < n; r++) {
+                if (t.type == VNM_F32) { double d; memcpy(&d, &cells[(size_t)r * 16], 8); float fl = (float)d; memcpy(&buf[(size_t)r * 4], &fl, 4); }
+                else memcpy(&buf[(size_t)r * w], &cells[(size_t)r * 16], (size_t)w);
+            }
+        } else if (kind == VNM_OUT_U64) { fmt = "L"; pack(8); }
+        else if (kind == VNM_OUT_I64) {
+            fmt = "l";
+            if (f == VNM_SUM && (t.format == "ttu" || t.format == "ttn" || t.format.rfind("tD", 0) == 0)) fmt = t.format;
+            pack(8);
+        } else if (kind == VNM_OUT_I32) { fmt = t.format; pack(4); }
+        else if (kind == VNM_OUT_F64) { fmt = "g"; pack(8); }
+        else if (kind == VNM_OUT_F32) { fmt = "f"; pack(4); }
+        else { fmt = "d:38,0"; pack(16); }
+        make_primitive(out->children[col], n, w, buf.data(), valid.data());
+        make_schema(out_schema->children[col], fmt, h->out_cols[i], 0);
+    }
+    return 0;
+}
+
+}  // extern "C"
+
+// =========================================================================================================
+// sort operator
+// =========================================================================================================
+struct vnm_sort_op {
+    std::vector<std::string> cols;
+    std::vector<int> orders;
+    std::vector<std::unique_ptr<ImportedBatch>> batches;
+};
+
+extern "C" {
+
+vnm_sort_op* vnm_sort_op_create(int n, const char** cols, const int* orders) {
+    if (ensure_init()) return nullptr;
+    if (n < 1) { set_error("Sort needs at least one column"); return nullptr; }
+    vnm_sort_op* h = new vnm_sort_op();
+    for (int i = 0; i < n; i++) { h->cols.push_back(cols[i]); h->orders.push_back(orders[i] ? VNM_DESC : VNM_ASC); }
+    return h;
+}
+
+void vnm_sort_op_destroy(vnm_sort_op* h) {
+    if (!h) return;
+    for (auto& b : h->batches) b->drop();
+    delete h;
+}
+
+// Sort::Next (sort.cpp:11-13): only buffers the batch
+int vnm_sort_op_next(vnm_sort_op* h, struct ArrowArray* batch, struct ArrowSchema* schema) {
+    if (!h || !batch || !schema) return set_error("vnm_sort_op_next: null argument");
+    auto ib = std::make_unique<ImportedBatch>();
+    ib->arr = *batch; ib->sch = *schema; ib->live = true;
+    batch->release = nullptr; schema->release = nullptr;
+    h->batches.push_back(std::move(ib));
+    return 0;
+}
+
+// Sort::Sorted (sort.cpp:15-63).  limit > 0: only the first `limit` rows are produced (LIMIT pushed into the
+// sort; the reference sorts everything and slices later, same rows).
+int vnm_sort_op_sorted(vnm_sort_op* h, int64_t limit, struct ArrowArray* out, struct ArrowSchema* out_schema) {
+    if (!h || !out || !out_schema) return set_error("vnm_sort_op_sorted: null argument");
+    if (h->batches.empty()) return set_error("Failed to create table from record batches.");
+    const struct ArrowSchema* sch = &h->batches[0]->sch;
+    const int64_t ncols = sch->n_children;
+    int64_t total = 0;
+    for (auto& b : h->batches) total += b->arr.length;
+    std::vector<ColType> types((size_t)ncols);
+    for (int64_t c = 0; c < ncols; c++) {
+        types[c] = parse_format(sch->children[c]->format);
+        if (types[c].type < 0) return set_error("Sort: column '%s' has a type the GPU path does not handle (format %s)",
+                                                sch->children[c]->name, sch->children[c]->format);
+    }
+    std::vector<int> key_col;
+    for (auto& name : h->cols) {
+        int i = find_child(sch, name);
+        if (i < 0) return set_error("Failed to sort table.");
+        key_col.push_back(i);
+    }
+    // Table::FromRecordBatches: concatenate every column on the host, then stage once
+    std::vector<vnm_dcol> dev((size_t)ncols);
+    int rc = 0;
+    for (int64_t c = 0; c < ncols && !rc; c++) {
+        int w = type_width(types[c].type);
+        std::vector<uint8_t> vals((size_t)(total ? total : 1) * w);
+        std::vector<uint8_t> bits;
+        bool any_null = false;
+        for (auto& b : h->batches) if (b->arr.children[c]->null_count != 0 && b->arr.children[c]->buffers[0]) any_null = true;
+        if (any_null) bits.assign((size_t)(total + 7) / 8 + 1, 0);
+        int64_t pos = 0;
+        for (auto& b : h->batches) {
+            const struct ArrowArray* ch = b->arr.children[c];
+            int64_t off = ch->offset + b->arr.offset, len = b->arr.length;
+            if (len) memcpy(&vals[(size_t)pos * w], (const uint8_t*)ch->buffers[1] + (size_t)off * w, (size_t)len * w);
+            if (any_null) {
+                const uint8_t* bm = (ch->null_count != 0) ? (const uint8_t*)ch->buffers[0] : nullptr;
+                for (int64_t i = 0; i < len; i++) {
+                    bool ok = !bm || ((bm[(off + i) >> 3] >> ((off + i) & 7)) & 1);
+                    if (ok) bits[(size_t)(pos + i) >> 3] |= (uint8_t)(1u << ((pos + i) & 7));
+                }
+            }
+            pos += len;
+        }
+        rc = vnm_stage_column(vals.data(), any_null ? bits.data() : nullptr, 0, total, types[c].type, &dev[c], nullptr);
+        dev[c].flags = types[c].flags;
+        if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = set_error("Sort: staging failed");
+    }
+    const int64_t n_out = (limit > 0 && limit < total) ? limit : total;
+    int64_t* idx = nullptr;
+    if (!rc && total > 0) {
+        idx = (int64_t*)pool_alloc((size_t)total * 8);
+        if (!idx) rc = 1;
+        std::vector<vnm_dcol> keys;
+        for (int kc : key_col) keys.push_back(dev[kc]);
+        if (!rc) rc = vnm_sort_indices((int)keys.size(), keys.data(), h->orders.data(), total, n_out < total ? n_out : 0, idx, nullptr);
+    }
+    if (!rc) {
+        make_struct(out, n_out, ncols);
+        make_schema(out_schema, "+s", "", ncols);
+        for (int64_t c = 0; c < ncols && !rc; c++) {
+            int w = type_width(types[c].type);
+            std::vector<uint8_t> hv((size_t)(n_out ? n_out : 1) * w), hb((size_t)(n_out ? n_out : 1));
+            if (n_out > 0) {
+                void* dv = pool_alloc((size_t)n_out * w);
+                uint8_t* db = dev[c].validity ? (uint8_t*)pool_alloc((size_t)n_out) : nullptr;
+                if (!dv || (dev[c].validity && !db)) rc = 1;
+                if (!rc) rc = vnm_take(&dev[c], idx, n_out, dv, db, nullptr);
+                if (!rc && hipMemcpy(hv.data(), dv, (size_t)n_out * w, hipMemcpyDeviceToHost) != hipSuccess) rc = set_error("Sort: D2H failed");
+                if (!rc && db && hipMemcpy(hb.data(), db, (size_t)n_out, hipMemcpyDeviceToHost) != hipSuccess) rc = set_error("Sort: D2H failed");
+                pool_free(dv);
+                pool_free(db);
+            }
+            if (!rc) {
+                make_primitive(out->children[c], n_out, w, hv.data(), dev[c].validity ? hb.data() : nullptr);
+                make_schema(out_schema->children[c], types[c].format, sch->children[c]->name ? sch->children[c]->name : "", 0);
+            }
+        }
+        if (rc) { release_array(out); release_schema(out_schema); }
+    }
+    pool_free(idx);
+    for (auto& d : dev) vnm_free_column(&d);
+    for (auto& b : h->batches) b->drop();
+    h->batches.clear();
+    return rc;
+}
+
+}  // extern "C"

@@ -1,6 +1,450 @@
+// Sort / top-K for gfx950.
+//
+// Replaces Sort::Sorted (vinum_cpp/src/operators/sort/sort.cpp:15-63): arrow::compute::SortIndices over
+// SortOptions{(column, Ascending|Descending)...} followed by compute::Take.  Semantics pinned by the golden
+// vectors generated through the real reference (tests/golden/sort_*.arrow): stable; per key, values first,
+// then NaN, then NULL -- for BOTH directions.
+//
+//   * every key column is turned into an order-preserving unsigned 64-bit code (DESC = complemented code)
+//     plus a 2-bit class (0 value, 1 NaN, 2 NULL);
+//   * full sort: stable LSD radix sort of (code, row id), 8 bits per pass, key columns from last to first,
+//     passes whose digit is identical for every row are skipped (one OR/AND reduction finds them);
+//   * LIMIT K on a single key: a threshold taken from a sorted sample selects ~K..4K candidates in one scan
+//     of the column (8 B/row), only the candidates are sorted -- identical first K rows (ties keep row
+//     order) as the reference's full sort + SliceOperator (vinum/core/algebra.py:229-247).
+// Roofline: HBM.  top-K: 8*N read; full sort: 12 B/row read + 12 B/row written per executed pass.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
 #include "vnm_common.hpp"
-using namespace vnm;
-extern "C" {
-int vnm_sort_indices(int, const vnm_dcol*, const int*, int64_t, int64_t, int64_t*, void*) { return set_error("vnm_sort_indices: not implemented yet"); }
-int vnm_take(const vnm_dcol*, const int64_t*, int64_t, void*, uint8_t*, void*) { return set_error("vnm_take: not implemented yet"); }
+
+namespace vnm {
+
+constexpr int RS_BLOCK = 1024;           // scatter block: 16 waves, 1024 elements per sub-tile
+constexpr int RS_WAVES = RS_BLOCK / 64;
+constexpr int RS_MAX_BLOCKS = 1024;
+
+// ---- key encoding ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void encode_key(const vnm_dcol& c, int64_t row, int desc, uint64_t* code, uint32_t* cls) {
+    if (!col_valid(c, row)) { *code = 0; *cls = 2; return; }
+    uint64_t e;
+    if (type_is_float(c.type)) {
+        double d = col_f64(c, row);
+        if (d != d) { *code = 0; *cls = 1; return; }
+        if (d == 0.0) d = 0.0;  // -0.0 and +0.0 compare equal in Arrow's sort: ties keep row order
+        e = enc_f64(d);
+    } else if (type_is_unsigned(c.type)) {
+        e = (uint64_t)col_i64(c, row);
+    } else {
+        e = enc_i64(col_i64(c, row));
+    }
+    *code = desc ? ~e : e;
+    *cls = 0;
 }
+
+// code[i], cls[i] for row idx[i] (idx == NULL: identity)
+__global__ void sort_encode_kernel(vnm_dcol c, int desc, const uint32_t* idx, int64_t n, uint64_t* code, uint8_t* cls) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t e; uint32_t k;
+        encode_key(c, idx ? (int64_t)idx[i] : i, desc, &e, &k);
+        code[i] = e;
+        cls[i] = (uint8_t)k;
+    }
+}
+
+__global__ void sort_iota_kernel(uint32_t* idx, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) idx[i] = (uint32_t)i;
+}
+__global__ void sort_widen_kernel(const uint32_t* idx, int64_t n, int64_t* out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (int64_t)idx[i];
+}
+__global__ void sort_cls_to_code_kernel(const uint8_t* cls, int64_t n, uint64_t* code) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) code[i] = cls[i];
+}
+
+// OR / AND over all codes: digits where they agree are constant and need no pass.  red[0]=OR, red[1]=AND
+__global__ void sort_orand_kernel(const uint64_t* code, int64_t n, unsigned long long* red) {
+    uint64_t o = 0, a = ~0ULL;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { o |= code[i]; a &= code[i]; }
+    for (int d = 32; d > 0; d >>= 1) { o |= __shfl_xor(o, d); a &= __shfl_xor(a, d); }
+    if ((threadIdx.x & 63) == 0) { atomicOr(&red[0], (unsigned long long)o); atomicAnd(&red[1], (unsigned long long)a); }
+}
+
+// ---- one stable radix pass ------------------------------------------------------------------------------
+// Block b owns the contiguous element range [b*per, (b+1)*per).  counts are digit-major: counts[d*nb + b].
+__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* code, int64_t n, int64_t per, int shift, uint32_t* counts) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&h[(code[i] >> shift) & 255], 1u);
+    __syncthreads();
+    counts[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of counts in (digit, block) order -> global output offsets; one block of 256 threads
+__global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* counts, int nb, unsigned long long* offsets) {
+    __shared__ unsigned long long tot[256];
+    const int d = threadIdx.x;
+    unsigned long long s = 0;
+    for (int b = 0; b < nb; b++) s += counts[(int64_t)d * nb + b];
+    tot[d] = s;
+    __syncthreads();
+    if (d == 0) {
+        unsigned long long run = 0;
+        for (int k = 0; k < 256; k++) { unsigned long long t = tot[k]; tot[k] = run; run += t; }
+    }
+    __syncthreads();
+    unsigned long long run = tot[d];
+    for (int b = 0; b < nb; b++) {
+        offsets[(int64_t)d * nb + b] = run;
+        run += counts[(int64_t)d * nb + b];
+    }
+}
+
+// stable scatter: sub-tiles of RS_BLOCK consecutive elements; rank among equal digits = (elements of earlier
+// waves) + (earlier lanes of the own wave, via eight ballots)
+__global__ __launch_bounds__(RS_BLOCK) void radix_scatter_kernel(const uint64_t* code, const uint32_t* val, int64_t n, int64_t per,
+                                                                 int shift, const unsigned long long* offsets, int nb,
+                                                                 uint64_t* code_out, uint32_t* val_out) {
+    __shared__ unsigned long long run[256];
+    __shared__ uint32_t wcount[RS_WAVES][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 256) run[tid] = offsets[(int64_t)tid * nb + blockIdx.x];
+    for (int i = tid; i < RS_WAVES * 256; i += RS_BLOCK) (&wcount[0][0])[i] = 0;
+    __syncthreads();
+    const uint64_t lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+    int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (int64_t base = lo; base < hi; base += RS_BLOCK) {
+        int64_t i = base + tid;
+        bool in = i < hi;
+        uint64_t c = in ? code[i] : 0;
+        uint32_t v = in ? val[i] : 0;
+        uint32_t dg = (uint32_t)(c >> shift) & 255u;
+        // lanes of this wave with the same digit
+        uint64_t m = __ballot(in);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            uint64_t bb = __ballot((dg >> b) & 1u);
+            m &= ((dg >> b) & 1u) ? bb : ~bb;
+        }
+        uint32_t rank_in_wave = __popcll(m & lt);
+        if (in && rank_in_wave == 0) wcount[wave][dg] = __popcll(m);
+        __syncthreads();
+        if (in) {
+            unsigned long long pos = run[dg] + rank_in_wave;
+            for (int w = 0; w < wave; w++) pos += wcount[w][dg];
+            code_out[pos] = c;
+            val_out[pos] = v;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t s = 0;
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; w++) { s += wcount[w][tid]; wcount[w][tid] = 0; }
+            run[tid] += s;
+        }
+        __syncthreads();
+    }
+}
+
+struct RadixBufs {
+    uint64_t* code[2];
+    uint32_t* val[2];
+    uint32_t* counts;
+    unsigned long long* offsets;
+    unsigned long long* red;
+    int cur = 0;
+    int nb = 0;
+    int64_t per = 0;
+};
+
+static int radix_alloc(RadixBufs* r, int64_t n) {
+    int64_t nb = (n + 16383) / 16384;
+    if (nb > RS_MAX_BLOCKS) nb = RS_MAX_BLOCKS;
+    if (nb < 1) nb = 1;
+    r->nb = (int)nb;
+    r->per = (n + nb - 1) / nb;
+    for (int k = 0; k < 2; k++) {
+        r->code[k] = (uint64_t*)pool_alloc((size_t)(n ? n : 1) * 8);
+        r->val[k] = (uint32_t*)pool_alloc((size_t)(n ? n : 1) * 4);
+        if (!r->code[k] || !r->val[k]) return 1;
+    }
+    r->counts = (uint32_t*)pool_alloc((size_t)256 * nb * 4);
+    r->offsets = (unsigned long long*)pool_alloc((size_t)256 * nb * 8);
+    r->red = (unsigned long long*)pool_alloc(64);
+    return (r->counts && r->offsets && r->red) ? 0 : 1;
+}
+static void radix_free(RadixBufs* r) {
+    for (int k = 0; k < 2; k++) { pool_free(r->code[k]); pool_free(r->val[k]); }
+    pool_free(r->counts); pool_free(r->offsets); pool_free(r->red);
+}
+
+// sort (code[cur], val[cur]) stably by the bytes of code that are not constant
+static int radix_sort_codes(RadixBufs* r, int64_t n, hipStream_t s) {
+    if (n <= 1) return 0;
+    unsigned long long init[2] = {0ULL, ~0ULL}, red[2];
+    VNM_HIP(hipMemcpyAsync(r->red, init, 16, hipMemcpyHostToDevice, s));
+    int g = device_info().num_cus * 4;
+    int64_t need = (n + 255) / 256;
+    if (g > need) g = (int)need;
+    sort_orand_kernel<<<g, 256, 0, s>>>(r->code[r->cur], n, r->red);
+    VNM_HIP(hipMemcpyAsync(red, r->red, 16, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    uint64_t differ = red[0] ^ red[1];
+    for (int byte = 0; byte < 8; byte++) {
+        if (!((differ >> (8 * byte)) & 0xFF)) continue;
+        KernelTimer timer("radix_pass", s);
+        int shift = 8 * byte;
+        radix_hist_kernel<<<r->nb, 256, 0, s>>>(r->code[r->cur], n, r->per, shift, r->counts);
+        radix_scan_kernel<<<1, 256, 0, s>>>(r->counts, r->nb, r->offsets);
+        radix_scatter_kernel<<<r->nb, RS_BLOCK, 0, s>>>(r->code[r->cur], r->val[r->cur], n, r->per, shift, r->offsets, r->nb,
+                                                        r->code[r->cur ^ 1], r->val[r->cur ^ 1]);
+        r->cur ^= 1;
+    }
+    VNM_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- top-K candidate selection ----------------------------------------------------------------------------
+__global__ void topk_sample_kernel(vnm_dcol c, int desc, int64_t n, int64_t m, uint64_t* code, uint8_t* cls) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+        int64_t row = (int64_t)(((__int128)i * n) / m);
+        uint64_t e; uint32_t k;
+        encode_key(c, row, desc, &e, &k);
+        code[i] = e;
+        cls[i] = (uint8_t)k;
+    }
+}
+
+// keep rows whose (class, code) <= (t_cls, t_code); unordered wave-aggregated append of (code, class, row)
+__global__ void topk_select_kernel(vnm_dcol c, int desc, int64_t n, uint32_t t_cls, uint64_t t_code, int64_t cap,
+                                   unsigned long long* count, uint64_t* code, uint8_t* cls, uint32_t* rows) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t iters = (n + stride - 1) / stride;
+    for (int64_t it = 0; it < iters; it++) {
+        int64_t i = it * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        bool keep = false;
+        uint64_t e = 0; uint32_t k = 0;
+        if (i < n) {
+            encode_key(c, i, desc, &e, &k);
+            keep = k < t_cls || (k == t_cls && e <= t_code);
+        }
+        uint64_t b = __ballot(keep);
+        if (!b) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(b));
+        base = __shfl(base, 0);
+        if (keep) {
+            uint64_t lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+            int64_t pos = (int64_t)base + __popcll(b & lt);
+            if (pos < cap) { code[pos] = e; cls[pos] = (uint8_t)k; rows[pos] = (uint32_t)i; }
+        }
+    }
+}
+
+__global__ void gather_u8_kernel(const uint8_t* src, const uint32_t* idx, int64_t n, uint64_t* out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = src[idx[i]];
+}
+__global__ void gather_u64_kernel(const uint64_t* src, const uint32_t* idx, int64_t n, uint64_t* out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = src[idx[i]];
+}
+__global__ void gather_u32_kernel(const uint32_t* src, const uint32_t* idx, int64_t n, uint32_t* out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = src[idx[i]];
+}
+__global__ void u32_to_code_kernel(const uint32_t* src, int64_t n, uint64_t* out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = src[i];
+}
+
+__global__ void take_kernel(vnm_dcol c, const int64_t* idx, int64_t n, void* out, uint8_t* out_valid) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int w = type_width(c.type);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        int64_t r = idx[i];
+        uint64_t bits = col_raw_bits(c, r);
+        switch (w) {
+            case 8: ((uint64_t*)out)[i] = bits; break;
+            case 4: ((uint32_t*)out)[i] = (uint32_t)bits; break;
+            case 2: ((uint16_t*)out)[i] = (uint16_t)bits; break;
+            default: ((uint8_t*)out)[i] = (uint8_t)bits; break;
+        }
+        if (out_valid) out_valid[i] = col_valid(c, r);
+    }
+}
+
+static int grid_for(int64_t n) {
+    int g = device_info().num_cus * 8;
+    int64_t need = (n + 255) / 256;
+    if (need < 1) need = 1;
+    return g > need ? (int)need : g;
+}
+
+// full stable multi-key sort; result: row ids (uint32) in r->val[r->cur]
+static int full_sort(int n_keys, const vnm_dcol* keys, const int* orders, int64_t n, RadixBufs* r, hipStream_t s) {
+    uint8_t* cls = (uint8_t*)pool_alloc((size_t)(n ? n : 1));
+    if (!cls) return 1;
+    sort_iota_kernel<<<grid_for(n), 256, 0, s>>>(r->val[r->cur], n);
+    for (int k = n_keys - 1; k >= 0; k--) {
+        // codes of key k in the current row order
+        sort_encode_kernel<<<grid_for(n), 256, 0, s>>>(keys[k], orders[k] == VNM_DESC, r->val[r->cur], n, r->code[r->cur], cls);
+        VNM_TRY(radix_sort_codes(r, n, s));
+        // class pass (values < NaN < NULL), more significant than the code: cls was computed in the order BEFORE
+        // the code passes, so recompute it in the current order
+        bool has_cls = keys[k].validity != nullptr || type_is_float(keys[k].type);
+        if (has_cls) {
+            sort_encode_kernel<<<grid_for(n), 256, 0, s>>>(keys[k], orders[k] == VNM_DESC, r->val[r->cur], n, r->code[r->cur ^ 1], cls);
+            sort_cls_to_code_kernel<<<grid_for(n), 256, 0, s>>>(cls, n, r->code[r->cur]);
+            VNM_TRY(radix_sort_codes(r, n, s));
+        }
+    }
+    VNM_HIP(hipGetLastError());
+    pool_free(cls);
+    return 0;
+}
+
+}  // namespace vnm
+
+using namespace vnm;
+
+extern "C" {
+
+int vnm_sort_indices(int n_keys, const vnm_dcol* keys, const int* orders, int64_t length, int64_t limit,
+                     int64_t* out_indices, void* stream) {
+    VNM_TRY(ensure_init());
+    if (n_keys < 1 || n_keys > 16) return set_error("vnm_sort_indices: 1..16 sort keys");
+    if (length >= (1LL << 32)) return set_error("vnm_sort_indices: at most 2^32 - 1 rows per sort");
+    for (int k = 0; k < n_keys; k++)
+        if (keys[k].length != length) return set_error("vnm_sort_indices: key %d length mismatch", k);
+    if (length == 0) return 0;
+    hipStream_t s = as_stream(stream);
+    const int64_t n = length;
+
+    // ---- LIMIT K fast path: one scan selects the candidates ----
+    const bool try_topk = limit > 0 && n_keys == 1 && limit * 8 < n && n >= (1 << 16) && getenv("VNM_SORT_NO_TOPK") == nullptr;
+    if (try_topk) {
+        const int desc = orders[0] == VNM_DESC;
+        const int64_t m = std::min<int64_t>(n, 1 << 18);
+        RadixBufs sr{};
+        VNM_TRY(radix_alloc(&sr, m));
+        uint8_t* scls = (uint8_t*)pool_alloc((size_t)m);
+        if (!scls) return 1;
+        topk_sample_kernel<<<grid_for(m), 256, 0, s>>>(keys[0], desc, n, m, sr.code[0], scls);
+        sort_iota_kernel<<<grid_for(m), 256, 0, s>>>(sr.val[0], m);
+        // sort the sample by (cls, code): code passes then class pass
+        int rc = radix_sort_codes(&sr, m, s);
+        uint64_t* scode_sorted = (uint64_t*)pool_alloc((size_t)m * 8);
+        if (rc || !scode_sorted) return 1;
+        VNM_HIP(hipMemcpyAsync(scode_sorted, sr.code[sr.cur], (size_t)m * 8, hipMemcpyDeviceToDevice, s));
+        gather_u8_kernel<<<grid_for(m), 256, 0, s>>>(scls, sr.val[sr.cur], m, sr.code[sr.cur]);
+        // keep the code order as the stable secondary key: values = positions in the code-sorted sample
+        sort_iota_kernel<<<grid_for(m), 256, 0, s>>>(sr.val[sr.cur], m);
+        rc = radix_sort_codes(&sr, m, s);
+        if (rc) return 1;
+        // rank of the threshold in the sample: expected rank of the K-th row + safety margin
+        double frac = (double)limit / (double)n;
+        int64_t rnk = (int64_t)(frac * (double)m * 1.5) + 64 + (int64_t)(6.0 * sqrt(frac * (double)m + 1.0));
+        bool ok = rnk < m - 1;
+        uint32_t t_cls = 0;
+        uint64_t t_code = 0;
+        if (ok) {
+            uint32_t pos_in_code_sorted = 0;
+            uint64_t cls64 = 0;
+            VNM_HIP(hipMemcpyAsync(&pos_in_code_sorted, sr.val[sr.cur] + rnk, 4, hipMemcpyDeviceToHost, s));
+            VNM_HIP(hipMemcpyAsync(&cls64, sr.code[sr.cur] + rnk, 8, hipMemcpyDeviceToHost, s));
+            VNM_HIP(hipStreamSynchronize(s));
+            VNM_HIP(hipMemcpyAsync(&t_code, scode_sorted + pos_in_code_sorted, 8, hipMemcpyDeviceToHost, s));
+            VNM_HIP(hipStreamSynchronize(s));
+            t_cls = (uint32_t)cls64;
+        }
+        pool_free(scode_sorted);
+        pool_free(scls);
+        radix_free(&sr);
+        if (ok) {
+            const int64_t cap = std::max<int64_t>(limit * 4 + 65536, 1 << 20);
+            RadixBufs cr{};
+            VNM_TRY(radix_alloc(&cr, cap));
+            uint8_t* ccls = (uint8_t*)pool_alloc((size_t)cap);
+            uint32_t* crows = (uint32_t*)pool_alloc((size_t)cap * 4);
+            unsigned long long* cnt = (unsigned long long*)pool_alloc(64);
+            if (!ccls || !crows || !cnt) return 1;
+            VNM_HIP(hipMemsetAsync(cnt, 0, 8, s));
+            {
+                KernelTimer timer("topk_select", s);
+                topk_select_kernel<<<device_info().num_cus * 8, 256, 0, s>>>(keys[0], desc, n, t_cls, t_code, cap, cnt, cr.code[0], ccls, crows);
+            }
+            unsigned long long found = 0;
+            VNM_HIP(hipMemcpyAsync(&found, cnt, 8, hipMemcpyDeviceToHost, s));
+            VNM_HIP(hipStreamSynchronize(s));
+            int rc2 = 0;
+            bool done = false;
+            if ((int64_t)found >= limit && (int64_t)found <= cap) {
+                const int64_t c = (int64_t)found;
+                // canonical order: by row id, then (stable) by code, then by class
+                cr.nb = (int)std::min<int64_t>((c + 16383) / 16384, RS_MAX_BLOCKS);
+                if (cr.nb < 1) cr.nb = 1;
+                cr.per = (c + cr.nb - 1) / cr.nb;
+                uint64_t* code_keep = (uint64_t*)pool_alloc((size_t)c * 8);
+                if (!code_keep) return 1;
+                VNM_HIP(hipMemcpyAsync(code_keep, cr.code[0], (size_t)c * 8, hipMemcpyDeviceToDevice, s));
+                // pass group 1: key = row id, value = candidate slot
+                u32_to_code_kernel<<<grid_for(c), 256, 0, s>>>(crows, c, cr.code[0]);
+                sort_iota_kernel<<<grid_for(c), 256, 0, s>>>(cr.val[0], c);
+                cr.cur = 0;
+                rc2 = radix_sort_codes(&cr, c, s);
+                // pass group 2: key = code of the slot
+                if (!rc2) { gather_u64_kernel<<<grid_for(c), 256, 0, s>>>(code_keep, cr.val[cr.cur], c, cr.code[cr.cur]); rc2 = radix_sort_codes(&cr, c, s); }
+                // pass group 3: key = class of the slot
+                if (!rc2) { gather_u8_kernel<<<grid_for(c), 256, 0, s>>>(ccls, cr.val[cr.cur], c, cr.code[cr.cur]); rc2 = radix_sort_codes(&cr, c, s); }
+                if (!rc2) {
+                    // slots -> row ids -> int64 output (first `limit` entries)
+                    gather_u32_kernel<<<grid_for(limit), 256, 0, s>>>(crows, cr.val[cr.cur], limit, cr.val[cr.cur ^ 1]);
+                    sort_widen_kernel<<<grid_for(limit), 256, 0, s>>>(cr.val[cr.cur ^ 1], limit, out_indices);
+                    VNM_HIP(hipGetLastError());
+                    VNM_HIP(hipStreamSynchronize(s));
+                    done = true;
+                }
+                pool_free(code_keep);
+            }
+            pool_free(ccls); pool_free(crows); pool_free(cnt);
+            radix_free(&cr);
+            if (rc2) return rc2;
+            if (done) return 0;
+        }
+        // fall through to the full sort (ties / NaN / NULL heavy data, or an unlucky sample)
+    }
+
+    RadixBufs r{};
+    VNM_TRY(radix_alloc(&r, n));
+    int rc = full_sort(n_keys, keys, orders, n, &r, s);
+    if (!rc) {
+        sort_widen_kernel<<<grid_for(n), 256, 0, s>>>(r.val[r.cur], n, out_indices);
+        if (hipGetLastError() != hipSuccess) rc = set_error("vnm_sort_indices: kernel launch failed");
+        if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = set_error("vnm_sort_indices: stream sync failed");
+    }
+    radix_free(&r);
+    return rc;
+}
+
+int vnm_take(const vnm_dcol* col, const int64_t* indices, int64_t n, void* out_values, uint8_t* out_valid, void* stream) {
+    VNM_TRY(ensure_init());
+    if (!col || (n > 0 && (!indices || !out_values))) return set_error("vnm_take: null argument");
+    if (col->validity && !out_valid) return set_error("vnm_take: column has nulls but no out_valid buffer");
+    if (n <= 0) return 0;
+    take_kernel<<<grid_for(n), 256, 0, as_stream(stream)>>>(*col, indices, n, out_values, out_valid);
+    VNM_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -214,3 +214,84 @@ def _func_array(f, in_t, kind, cells, valid) -> pa.Array:
     if mask.any():
         vbuf = pa.py_buffer(np.packbits(valid.astype(bool), bitorder="little").tobytes())
     return pa.Array.from_buffers(pa.decimal128(38, 0), len(valid), [vbuf, buf], null_count=int(mask.sum()))
+
+
+# ---- sort / take --------------------------------------------------------------------------------------
+def sort_indices(keys, orders, limit=0, stream=None) -> DeviceBuffer:
+    """arrow::compute::SortIndices as used by Sort::Sorted (vinum_cpp/src/operators/sort/sort.cpp:22-37):
+    stable multi-key, NaN after values and NULL after NaN for both directions.  Returns int64 row ids in HBM
+    (the first `limit` entries when limit > 0)."""
+    n = keys[0].length
+    out = DeviceBuffer(max(n, 1) * 8)
+    od = (ctypes.c_int * len(orders))(*orders)
+    L.check(L.lib().vnm_sort_indices(len(keys), dcol_array(keys), od, n, int(limit), out.ptr, _stream_ptr(stream)))
+    return out
+
+
+def take(col: DeviceColumn, indices: DeviceBuffer, n, stream=None) -> DeviceColumn:
+    """compute::Take for one column (sort.cpp:40)."""
+    lib = L.lib()
+    vals = DeviceBuffer(max(n, 1) * _WIDTH[col.vnm_type])
+    vb = DeviceBuffer(max(n, 1)) if col.validity_ptr else None
+    L.check(lib.vnm_take(ctypes.byref(col.dcol()), indices.ptr, n, vals.ptr, vb.ptr if vb else None, _stream_ptr(stream)))
+    bitmap = None
+    if vb is not None:
+        bitmap = DeviceBuffer((n + 7) // 8)
+        L.check(lib.vnm_pack_validity(vb.ptr, n, bitmap.ptr, _stream_ptr(stream)))
+        L.check(lib.vnm_device_synchronize())
+    return DeviceColumn(vals, bitmap, 0, n, col.arrow_type)
+
+
+# ---- projection ------------------------------------------------------------------------------------------
+_EX = {"add": L.EX_ADD, "sub": L.EX_SUB, "mul": L.EX_MUL, "div": L.EX_DIV, "mod": L.EX_MOD, "neg": L.EX_NEG,
+       "band": L.EX_BAND, "bor": L.EX_BOR, "bxor": L.EX_BXOR, "bnot": L.EX_BNOT,
+       "+": L.EX_ADD, "-": L.EX_SUB, "*": L.EX_MUL, "/": L.EX_DIV, "%": L.EX_MOD}
+
+
+def compile_expr(expr, col_index):
+    """Nested prefix expression -> postfix vnm_expr_ins list.
+    expr := column name | int | float | (op, expr[, expr...]); n-ary chains fold left like
+    VectorizedExpression._apply_binary_args_function (vinum/core/base.py:145-151)."""
+    out = []
+
+    def emit(e):
+        if isinstance(e, str):
+            out.append((L.EX_COL, col_index[e], 0.0, 0))
+        elif isinstance(e, bool):
+            raise TypeError("boolean literals are not arithmetic operands")
+        elif isinstance(e, int):
+            out.append((L.EX_CONST_I, 0, 0.0, int(e)))
+        elif isinstance(e, float):
+            out.append((L.EX_CONST_F, 0, float(e), 0))
+        else:
+            op = _EX[e[0]]
+            args = e[1:]
+            if op in (L.EX_NEG, L.EX_BNOT):
+                emit(args[0])
+                out.append((op, 0, 0.0, 0))
+            else:
+                emit(args[0])
+                for a in args[1:]:
+                    emit(a)
+                    out.append((op, 0, 0.0, 0))
+    emit(expr)
+    prog = (L.ExprIns * len(out))()
+    for i, (op, arg, f, k) in enumerate(out):
+        prog[i].op, prog[i].arg, prog[i].imm_f, prog[i].imm_i = op, arg, f, k
+    return prog
+
+
+def project(expr, columns: dict, length=None, stream=None) -> DeviceColumn:
+    """One fused kernel per output expression (replaces the per-node NumPy ufunc passes of
+    vinum/core/expressions.py:13-24).  columns: name -> DeviceColumn."""
+    names = list(columns)
+    cols = [columns[n] for n in names]
+    if length is None:
+        length = cols[0].length if cols else 1
+    prog = compile_expr(expr, {n: i for i, n in enumerate(names)})
+    out = DeviceBuffer(max(length, 1) * 8)
+    ot = ctypes.c_int(0)
+    L.check(L.lib().vnm_project(len(prog), prog, len(cols), dcol_array(cols), length, out.ptr, ctypes.byref(ot),
+                                _stream_ptr(stream)))
+    t = pa.float64() if ot.value == L.F64 else pa.int64()
+    return DeviceColumn(out, None, 0, length, t)
