@@ -122,3 +122,46 @@ def test_empty_inputs():
     assert got.num_rows == 0
     got = gpu_aggregate(O.ONE_GROUP, [], [], funcs, [empty])
     assert got.to_pydict() == {"n": [0], "s": [None], "mn": [None]}
+
+
+@pytest.mark.parametrize("groups", [5_000, 200_000])
+@pytest.mark.parametrize("levels", [1, 2])
+@pytest.mark.parametrize("with_pred", [False, True])
+def test_partitioned_path_vs_oracle(groups, levels, with_pred, monkeypatch):
+    """Large-G path: rows are radix partitioned (1 or 2 levels) and aggregated per partition in LDS.
+    Same query shape as BASELINE configs[2]; quantised values -> bit-exact; two batches exercise the
+    run -> table merge; the all-ones key (the table's EMPTY sentinel) must survive."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_PART_L1_MAX", "4" if levels == 2 else "256")
+    rng = np.random.default_rng(groups + levels)
+    n = 700_001
+    k = rng.integers(0, groups, n).astype(np.int64) * 1_000_003 - 77
+    k[rng.integers(0, n, 5)] = -1
+    v = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
+    t = pa.table({"k": pa.array(k), "v": pa.array(v)})
+    funcs = [(O.SUM, "v", "sum_v"), (O.AVG, "v", "avg_v"), (O.COUNT_STAR, "", "n"), (O.COUNT, "v", "cnt_v")]
+    pred = ("v", ">", 64.0) if with_pred else None
+    for batches in (t.to_batches(), util.sliced_batches(t, 400_000)):
+        got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=pred, expected_groups=groups)
+        o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+        for b in batches:
+            if with_pred:
+                b = O.filter_batch(b, O.cmp_mask(b.column(1), O.GT, 64.0))
+            o.next(b)
+        util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"partitioned G={groups} L={levels} pred={with_pred}")
+
+
+def test_partitioned_path_wrong_hint_falls_back():
+    """A hint far below the real group count overflows the per-partition LDS tables; the operator must
+    notice and produce the right answer through the general path."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(1)
+    n = 900_000
+    t = pa.table({"k": pa.array(rng.integers(0, 800_000, n).astype(np.int64)),
+                  "v": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0)})
+    funcs = [(O.SUM, "v", "sum_v"), (O.COUNT_STAR, "", "n")]
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, t.to_batches(), expected_groups=3000)
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in t.to_batches():
+        o.next(b)
+    util.assert_agg_equal(got, o.result(), funcs, ["k"], what="wrong hint")

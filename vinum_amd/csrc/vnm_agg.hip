@@ -11,6 +11,7 @@
 // So rows are pre-aggregated in a per-workgroup LDS hash table (keys + 64-bit accumulator words that
 // merge commutatively); only table flushes touch the HBM-resident table, with agent-scope atomics.
 // The fused WHERE predicate is evaluated in the scan, so no filtered batch is ever materialised.
+#include <algorithm>
 #include <cstdlib>
 
 #include "vnm_agg.hpp"
@@ -87,7 +88,11 @@ __device__ __forceinline__ void l_merge(uint64_t* p, int mk, uint64_t v) {
 __device__ __forceinline__ uint64_t gt_find_single(const GTable& g, uint64_t key) {
     const uint64_t mask = g.cap - 1;
     uint64_t h = hash_u64(key) & mask;
-    for (;;) {
+    for (uint64_t probes = 0;; probes++) {
+        if (probes > mask) {  // table full: cannot happen while the room checks hold; never spin forever
+            __hip_atomic_store(&g.ctl[1], 2ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return g.cap;
+        }
         uint64_t k = ld_agent(&g.tag[h]);
         if (k == key) return h;
         if (k == EMPTY) {
@@ -620,6 +625,312 @@ __global__ void agg_compact_special_kernel(CompactArgs c) {
     }
 }
 
+// =======================================================================================================
+// Radix-partitioned aggregation for LARGE group counts (hot shape only).
+//
+// When the groups do not fit an LDS table, per-row updates would have to go to the HBM table, and agent
+// scope atomics cap at ~24 G/s (profiles/microbench_r01.txt) -- 285 ms for the 1e9-row / 1e8-group query.
+// Instead the surviving (key, value) pairs are radix partitioned by hash bits, streaming and atomic-free:
+//   pass 1  rows -> 256 partitions           (filter fused; LDS counting sort per 4096-row tile, runs of
+//                                              consecutive 16-byte entries written per partition)
+//   pass 2  each partition -> 512 sub-parts   (same kernel, next hash bits; only when G > ~280k)
+//   pass 3  one workgroup per final partition aggregates it in an LDS table and appends dense groups.
+// Every (partition, producer) pair owns a private output region, so no cursor is shared.
+// Traffic: 16 N read + 16 sN written/read per level + 24 G' written.
+// =======================================================================================================
+constexpr int PT_BLOCK = 1024;
+constexpr int PT_ITEMS = 4;
+constexpr int PT_TILE = PT_BLOCK * PT_ITEMS;  // 4096 rows or entries per tile
+constexpr int PT_MAXP = 512;
+constexpr int PA_BLOCK = 512;
+constexpr int PA_SLOTS = 2048;
+
+struct PartArgs {
+    // source A: raw columns (pass 1)
+    const uint64_t* kp;
+    const double* vp;
+    const double* pp;
+    int has_pred, pred_is_v, op;
+    double thr;
+    int64_t nrows;
+    // source B: entry regions written by the previous level (pass 2)
+    const ulonglong2* in_entries;
+    const uint32_t* in_counts;
+    int64_t in_cap;
+    int in_regions;      // regions per input partition
+    int in_split;        // workgroups per input partition (each takes in_regions / in_split regions)
+    // output regions: region id = out_base(blockIdx) + p * out_stride
+    ulonglong2* out_entries;
+    uint32_t* out_counts;
+    int64_t out_cap;
+    int nparts;          // 256 or 512
+    int shift;           // partition = (hash >> shift) & (nparts - 1)
+    unsigned long long* flags;  // [0] overflow
+};
+
+template <bool FROM_ROWS>
+__global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
+    __shared__ ulonglong2 stage[PT_TILE];
+    __shared__ uint16_t part_of[PT_TILE];
+    __shared__ uint32_t cnt[PT_MAXP], off[PT_MAXP], cursor[PT_MAXP];
+    __shared__ uint32_t s_total;
+    __shared__ uint32_t wtot[PT_MAXP / 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int np = a.nparts;
+    const uint32_t pmask = (uint32_t)np - 1;
+    const int npad = np < 64 ? 64 : np;  // scan width: whole waves (counts beyond np stay zero)
+    for (int i = tid; i < PT_MAXP; i += PT_BLOCK) { cnt[i] = 0; cursor[i] = 0; }
+    __syncthreads();
+
+    // output region of partition p for this producer
+    int64_t out_base, out_stride;
+    int64_t ntiles = 0, src_first = 0;
+    if (FROM_ROWS) {
+        out_base = blockIdx.x; out_stride = gridDim.x;
+        ntiles = (a.nrows + PT_TILE - 1) / PT_TILE;
+    } else {
+        const int pin = blockIdx.x / a.in_split, g = blockIdx.x % a.in_split;
+        out_base = (int64_t)pin * np * a.in_split + g; out_stride = a.in_split;
+        src_first = (int64_t)pin * a.in_regions;
+    }
+
+    auto process_tile = [&](int nitems, auto&& load_item) {
+        // A: local rank inside the partition (LDS returning atomic)
+        uint32_t myp[PT_ITEMS], myr[PT_ITEMS];
+        ulonglong2 mye[PT_ITEMS];
+#pragma unroll
+        for (int k = 0; k < PT_ITEMS; k++) {
+            myp[k] = 0xFFFFFFFFu;
+            ulonglong2 e;
+            if (load_item(k, &e)) {
+                uint32_t p = (hash_u64(e.x) >> a.shift) & pmask;
+                myp[k] = p;
+                mye[k] = e;
+                myr[k] = atomicAdd(&cnt[p], 1u);
+            }
+        }
+        __syncthreads();
+        // B: exclusive scan of cnt[0..np): wave scans, then the totals of the preceding waves are added
+        if (tid < npad) {
+            uint32_t c = cnt[tid], inc = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+            off[tid] = inc - c;
+            if (lane == 63) wtot[tid >> 6] = inc;
+        }
+        __syncthreads();
+        if (tid < npad) {
+            uint32_t add = 0;
+            for (int w = 0; w < (tid >> 6); w++) add += wtot[w];
+            off[tid] += add;
+            if (tid == npad - 1) s_total = off[tid] + cnt[tid];
+        }
+        __syncthreads();
+        // C: entries -> LDS stage, grouped by partition
+#pragma unroll
+        for (int k = 0; k < PT_ITEMS; k++) {
+            if (myp[k] != 0xFFFFFFFFu) {
+                uint32_t pos = off[myp[k]] + myr[k];
+                stage[pos] = mye[k];
+                part_of[pos] = (uint16_t)myp[k];
+            }
+        }
+        __syncthreads();
+        // D: copy out: consecutive lanes write consecutive 16-byte entries of one partition's run
+        const uint32_t total = s_total;
+        for (uint32_t i = tid; i < total; i += PT_BLOCK) {
+            uint32_t p = part_of[i];
+            uint32_t j = cursor[p] + (i - off[p]);
+            if (j < (uint32_t)a.out_cap) a.out_entries[(out_base + (int64_t)p * out_stride) * a.out_cap + j] = stage[i];
+            else __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        // E: advance cursors
+        if (tid < np) { cursor[tid] += cnt[tid]; cnt[tid] = 0; }
+        __syncthreads();
+        (void)nitems;
+    };
+
+    if (FROM_ROWS) {
+        for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int64_t base = tile * PT_TILE;
+            // two 16-byte loads per column: rows (base + 2 tid, +1) and (base + 2048 + 2 tid, +1)
+            ulonglong2 kk[2];
+            double2 vv[2], pv[2];
+            const bool full = base + PT_TILE <= a.nrows;
+            if (full) {
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    int64_t r = base + (int64_t)u * 2 * PT_BLOCK + 2 * tid;
+                    kk[u] = *(const ulonglong2*)(a.kp + r);
+                    vv[u] = *(const double2*)(a.vp + r);
+                    if (a.has_pred && !a.pred_is_v) pv[u] = *(const double2*)(a.pp + r);
+                }
+            }
+            process_tile(PT_ITEMS, [&](int k, ulonglong2* e) -> bool {
+                const int u = k >> 1, el = k & 1;
+                int64_t r = base + (int64_t)u * 2 * PT_BLOCK + 2 * tid + el;
+                if (r >= a.nrows) return false;
+                uint64_t key; double v, p;
+                if (full) {
+                    key = el ? kk[u].y : kk[u].x;
+                    v = el ? vv[u].y : vv[u].x;
+                    p = a.pred_is_v ? v : (el ? pv[u].y : pv[u].x);
+                } else {
+                    key = a.kp[r]; v = a.vp[r]; p = a.has_pred ? (a.pred_is_v ? v : a.pp[r]) : 0.0;
+                }
+                if (a.has_pred && !cmp_apply<double>(a.op, p, a.thr)) return false;
+                e->x = key;
+                e->y = (unsigned long long)__double_as_longlong(v);
+                return true;
+            });
+        }
+    } else {
+        const int per = a.in_regions / a.in_split;
+        const int g = blockIdx.x % a.in_split;
+        for (int rj = 0; rj < per; rj++) {
+            const int64_t region = src_first + (int64_t)g * per + rj;
+            const uint32_t n = a.in_counts[region];
+            const ulonglong2* src = a.in_entries + region * a.in_cap;
+            for (uint32_t b0 = 0; b0 < n; b0 += PT_TILE) {
+                process_tile(PT_ITEMS, [&](int k, ulonglong2* e) -> bool {
+                    uint32_t i = b0 + (uint32_t)k * PT_BLOCK + tid;
+                    if (i >= n) return false;
+                    *e = src[i];
+                    return true;
+                });
+            }
+        }
+    }
+    if (tid < np) a.out_counts[out_base + (int64_t)tid * out_stride] = cursor[tid];
+}
+
+struct PartAggArgs {
+    const ulonglong2* entries;
+    const uint32_t* counts;
+    int64_t cap;
+    int regions;          // regions per final partition
+    int64_t nfinal;       // number of final partitions
+    int w_rows, w_valid, w_sum, n_words;
+    uint64_t* dkey;       // [2][dstride]
+    uint64_t* dacc;       // [W][dstride]
+    int64_t dstride;
+    unsigned long long* flags;  // [0] overflow  [1] dense count
+    // few final partitions: `splits` workgroups share one partition (regions rj % splits == part) and merge
+    // their LDS tables into the HBM table instead of appending dense groups
+    int splits;
+    int to_table;
+    GTable g;
+    int64_t table_limit;
+};
+
+__global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
+    __shared__ uint64_t lkey[PA_SLOTS + 1];
+    __shared__ uint64_t lsum[PA_SLOTS + 1];
+    __shared__ uint32_t lcnt[PA_SLOTS + 1];
+    __shared__ uint32_t s_n, s_fail;
+    __shared__ unsigned long long s_base;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t smask = PA_SLOTS - 1;
+    for (int64_t unit = blockIdx.x; unit < a.nfinal * a.splits; unit += gridDim.x) {
+        const int64_t f = unit / a.splits;
+        const int part = (int)(unit % a.splits);
+        for (int i = tid; i <= PA_SLOTS; i += PA_BLOCK) { lkey[i] = EMPTY; lsum[i] = 0; lcnt[i] = 0; }
+        if (tid == 0) { s_n = 0; s_fail = 0; }
+        __syncthreads();
+        for (int rj = part; rj < a.regions; rj += a.splits) {
+            const int64_t region = f * a.regions + rj;
+            const uint32_t n = a.counts[region];
+            const ulonglong2* src = a.entries + region * a.cap;
+            for (uint32_t i = tid; i < n; i += PA_BLOCK) {
+                ulonglong2 e = src[i];
+                const uint64_t key = e.x;
+                int slot = -1;
+                if (key == EMPTY) { slot = PA_SLOTS; lkey[slot] = 0; }
+                else {
+                    uint32_t h = hash_u64(key) & smask;
+                    for (int probe = 0; probe < PA_SLOTS; probe++) {
+                        uint64_t k = *(volatile uint64_t*)&lkey[h];
+                        if (k == key) { slot = (int)h; break; }
+                        if (k == EMPTY) {
+                            uint64_t expected = EMPTY;
+                            if (__hip_atomic_compare_exchange_strong(&lkey[h], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                                if (atomicAdd(&s_n, 1u) >= (uint32_t)(PA_SLOTS * 9 / 10)) s_fail = 1;
+                                slot = (int)h;
+                                break;
+                            }
+                            if (expected == key) { slot = (int)h; break; }
+                        }
+                        h = (h + 1) & smask;
+                        if (s_fail) break;
+                    }
+                }
+                if (slot >= 0) {
+                    __hip_atomic_fetch_add((double*)&lsum[slot], __longlong_as_double((long long)e.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    atomicAdd(&lcnt[slot], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (s_fail) {  // more groups than the LDS table holds: tell the host to use the general path
+            if (tid == 0) __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (a.to_table) {
+            // merge this workgroup's table into the HBM table (G * splits * words atomics in total: small)
+            if (tid == 0) {
+                unsigned long long fill = __hip_atomic_load(&a.g.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int64_t)(fill + s_n) > a.table_limit) s_fail = 1;
+            }
+            __syncthreads();
+            if (s_fail) {
+                if (tid == 0) __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            for (int i = tid; i <= PA_SLOTS; i += PA_BLOCK) {
+                uint64_t k = lkey[i];
+                if (k == EMPTY) continue;
+                uint64_t slot;
+                if (i < PA_SLOTS) slot = gt_find_single(a.g, k);
+                else { slot = a.g.cap; if (ld_agent(&a.g.tag[slot]) == EMPTY) st_agent(&a.g.tag[slot], 0); }
+                if (a.w_rows >= 0) g_merge(&a.g.acc[(uint64_t)a.w_rows * a.g.stride + slot], M_ADD_U64, lcnt[i]);
+                if (a.w_valid >= 0) g_merge(&a.g.acc[(uint64_t)a.w_valid * a.g.stride + slot], M_ADD_U64, lcnt[i]);
+                if (a.w_sum >= 0) g_merge(&a.g.acc[(uint64_t)a.w_sum * a.g.stride + slot], M_ADD_F64, lsum[i]);
+            }
+            __syncthreads();
+            continue;
+        }
+        // compact: reserve a dense range for this partition's groups, then write them
+        const uint32_t ngroups = s_n + (lkey[PA_SLOTS] != EMPTY ? 1u : 0u);
+        if (tid == 0) { s_base = atomicAdd(&a.flags[1], (unsigned long long)ngroups); s_n = 0; }
+        __syncthreads();
+        if ((int64_t)(s_base + ngroups) > a.dstride) {
+            if (tid == 0) __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        for (int i0 = 0; i0 <= PA_SLOTS; i0 += PA_BLOCK) {
+            int i = i0 + tid;
+            bool occ = i <= PA_SLOTS && lkey[i] != EMPTY;
+            uint64_t b = __ballot(occ);
+            uint32_t wbase = 0;
+            if (lane == 0 && b) wbase = atomicAdd(&s_n, (uint32_t)__popcll(b));
+            wbase = __shfl(wbase, 0);
+            if (occ) {
+                uint64_t lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+                int64_t pos = (int64_t)s_base + wbase + __popcll(b & lt);
+                a.dkey[pos] = i == PA_SLOTS ? EMPTY : lkey[i];
+                a.dkey[a.dstride + pos] = 0;
+                if (a.w_rows >= 0) a.dacc[(int64_t)a.w_rows * a.dstride + pos] = lcnt[i];
+                if (a.w_valid >= 0) a.dacc[(int64_t)a.w_valid * a.dstride + pos] = lcnt[i];
+                if (a.w_sum >= 0) a.dacc[(int64_t)a.w_sum * a.dstride + pos] = lsum[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void fill_u64_kernel(uint64_t* p, uint64_t v, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
@@ -655,6 +966,12 @@ struct vnm_agg {
     int64_t n_groups = -1;
     std::vector<uint64_t> h_key, h_acc;
     bool host_ready = false;
+    // dense run produced by the partitioned path (not yet merged into the HBM table)
+    uint64_t* run_key = nullptr;
+    uint64_t* run_acc = nullptr;
+    int64_t run_stride = 0, run_n = 0;
+    bool have_run = false;
+    bool result_is_run = false;
 };
 
 namespace {
@@ -738,14 +1055,169 @@ int ensure_table(vnm_agg* h, int64_t nrows, hipStream_t s) {
 }
 
 void invalidate_result(vnm_agg* h) {
-    pool_free(h->dkey);
-    pool_free(h->dacc);
+    if (!h->result_is_run) {
+        pool_free(h->dkey);
+        pool_free(h->dacc);
+    }
+    h->result_is_run = false;
     h->dkey = h->dacc = nullptr;
     h->n_groups = -1;
     h->host_ready = false;
 }
 
+// ---- partitioned path orchestration -------------------------------------------------------------------
+int env_i64(const char* name, int64_t dflt) {
+    const char* v = getenv(name);
+    return v ? (int)atoll(v) : (int)dflt;
+}
+
+void drop_run(vnm_agg* h) {
+    pool_free(h->run_key);
+    pool_free(h->run_acc);
+    h->run_key = h->run_acc = nullptr;
+    h->have_run = false;
+    h->run_n = h->run_stride = 0;
+}
+
+// returns 0 = done (run stored), 2 = not applicable / overflowed (caller uses the general path), 1 = error
+int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s) {
+    const int cus = device_info().num_cus;
+    // final partitions sized for ~900 groups each: enough keys per partition that their sizes concentrate
+    // (few keys per partition -> Poisson imbalance overflows the fixed-capacity regions), few enough for
+    // the 2048-slot LDS table of pass 3
+    const int64_t per_final = env_i64("VNM_AGG_PART_GROUPS", 900);
+    int64_t nfin = 2;
+    while (nfin * per_final < h->hint) nfin *= 2;
+    const int64_t l1_max = env_i64("VNM_AGG_PART_L1_MAX", 256);
+    if (nfin > l1_max * 512) return 2;  // would need a third level
+    const int levels = nfin > l1_max ? 2 : 1;
+    const int np1 = levels == 2 ? (int)l1_max : (int)nfin;
+    const int np2 = levels == 2 ? (int)(nfin / l1_max) : 0;
+    const int split2 = 2;
+    const int grid1 = (int)std::min<int64_t>((int64_t)cus * 2, (nrows + PT_TILE - 1) / PT_TILE);
+    const int64_t tiles_per_wg = ((nrows + PT_TILE - 1) / PT_TILE + grid1 - 1) / grid1;
+    const int64_t rows_per_wg = tiles_per_wg * PT_TILE;
+    const int64_t cap1 = rows_per_wg / np1 + rows_per_wg / np1 / 5 + 512;
+    unsigned long long* flags = (unsigned long long*)pool_alloc(64);
+    ulonglong2* e1 = (ulonglong2*)pool_alloc((size_t)np1 * grid1 * cap1 * 16);
+    uint32_t* c1 = (uint32_t*)pool_alloc((size_t)np1 * grid1 * 4);
+    if (!flags || !e1 || !c1) return 1;
+    VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
+    PartArgs p1{};
+    p1.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
+    p1.vp = (const double*)a.cols[0].values + a.cols[0].offset;
+    p1.pp = h->pred_set ? (const double*)a.pred.values + a.pred.offset : nullptr;
+    p1.has_pred = h->pred_set; p1.pred_is_v = a.hot_pred_is_v; p1.op = a.p.op; p1.thr = a.p.dval;
+    p1.nrows = nrows;
+    p1.out_entries = e1; p1.out_counts = c1; p1.out_cap = cap1;
+    int lg1 = 0;
+    while ((1 << lg1) < np1) lg1++;
+    p1.nparts = np1; p1.shift = 32 - lg1; p1.flags = flags;
+    {
+        KernelTimer timer("agg_part_scatter1", s);
+        part_scatter_kernel<true><<<grid1, PT_BLOCK, 0, s>>>(p1);
+    }
+    VNM_HIP(hipGetLastError());
+
+    const ulonglong2* fin_e = e1;
+    const uint32_t* fin_c = c1;
+    int64_t fin_cap = cap1, nfinal = np1;
+    int fin_regions = grid1;
+    ulonglong2* e2 = nullptr;
+    uint32_t* c2 = nullptr;
+    if (levels == 2) {
+        // worst case: every row survived and spread evenly; 25 % slack + constant
+        const int64_t per_pg = (int64_t)grid1 * rows_per_wg / np1 / split2;
+        const int64_t cap2 = per_pg / np2 + per_pg / np2 / 4 + 256;
+        e2 = (ulonglong2*)pool_alloc((size_t)np1 * np2 * split2 * cap2 * 16);
+        c2 = (uint32_t*)pool_alloc((size_t)np1 * np2 * split2 * 4);
+        if (!e2 || !c2) return 1;
+        PartArgs p2{};
+        p2.in_entries = e1; p2.in_counts = c1; p2.in_cap = cap1; p2.in_regions = grid1; p2.in_split = split2;
+        p2.out_entries = e2; p2.out_counts = c2; p2.out_cap = cap2;
+        p2.nparts = np2; p2.shift = 15; p2.flags = flags;  // hash bits [23:15] (pass 1 used [31:24])
+        // the regions of one input partition are split evenly over split2 workgroups
+        if (grid1 % split2 != 0) p2.in_split = 1;
+        {
+            KernelTimer timer("agg_part_scatter2", s);
+            part_scatter_kernel<false><<<np1 * p2.in_split, PT_BLOCK, 0, s>>>(p2);
+        }
+        VNM_HIP(hipGetLastError());
+        fin_e = e2; fin_c = c2; fin_cap = cap2; nfinal = (int64_t)np1 * np2; fin_regions = p2.in_split;
+    }
+
+    // few final partitions cannot fill the chip with one workgroup each: split them and merge through the
+    // HBM table (only legal while the table holds nothing else, so a failed attempt can simply be dropped)
+    int splits = 1;
+    if (nfinal < (int64_t)cus * 4) {
+        splits = (int)std::min<int64_t>(256, ((int64_t)cus * 8 + nfinal - 1) / nfinal);
+        if (splits > fin_regions) splits = fin_regions;
+    }
+    const bool to_table = splits > 1;
+    if (to_table && (h->have_table || h->have_run)) {
+        pool_free(e1); pool_free(c1); pool_free(e2); pool_free(c2); pool_free(flags);
+        return 2;
+    }
+    // dense output sized from the hint (guarded in the kernel)
+    const int64_t dstride = to_table ? 2 : std::min<int64_t>(nrows, h->hint * 2 + (1 << 20)) + 2;
+    uint64_t* rk = (uint64_t*)pool_alloc((size_t)dstride * 8 * 2);
+    uint64_t* ra = (uint64_t*)pool_alloc((size_t)dstride * 8 * h->plan.n_words);
+    if (!rk || !ra) return 1;
+    PartAggArgs pa{};
+    pa.splits = splits;
+    pa.to_table = to_table;
+    if (to_table) {
+        VNM_TRY(ensure_table(h, nrows, s));
+        // every resident workgroup may pass the room check and then insert a full LDS table at once
+        const int64_t g3max = std::min<int64_t>(nfinal * splits, (int64_t)cus * 4);
+        const uint64_t want = pow2_at_least(std::max<uint64_t>((uint64_t)h->hint * 4 + 8192, (uint64_t)(g3max * PA_SLOTS * 2)));
+        if (h->g.cap < want) VNM_TRY(table_grow(h, want, s));
+        pa.g = h->g;
+        pa.table_limit = (int64_t)(h->g.cap * 8 / 10) - g3max * PA_SLOTS;
+    }
+    pa.entries = fin_e; pa.counts = fin_c; pa.cap = fin_cap; pa.regions = fin_regions; pa.nfinal = nfinal;
+    pa.w_rows = a.hot_w_rows; pa.w_valid = a.hot_w_valid; pa.w_sum = a.hot_w_sum; pa.n_words = h->plan.n_words;
+    pa.dkey = rk; pa.dacc = ra; pa.dstride = dstride; pa.flags = flags;
+    {
+        KernelTimer timer("agg_part_final", s);
+        int g3 = (int)std::min<int64_t>(nfinal * splits, (int64_t)cus * 4);
+        part_agg_kernel<<<g3, PA_BLOCK, 0, s>>>(pa);
+    }
+    VNM_HIP(hipGetLastError());
+    unsigned long long fl[2];
+    VNM_HIP(hipMemcpyAsync(fl, flags, 16, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    pool_free(e1); pool_free(c1); pool_free(e2); pool_free(c2); pool_free(flags);
+    if (fl[0]) {  // skewed partitions / more groups than hinted: use the general path for this batch
+        pool_free(rk); pool_free(ra);
+        if (to_table) { table_free(&h->g); h->have_table = false; }  // drop the partial merge
+        return 2;
+    }
+    if (to_table) {  // the groups already live in the HBM table
+        pool_free(rk); pool_free(ra);
+        return 0;
+    }
+    h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
+    h->have_run = true;
+    return 0;
+}
+
 }  // namespace
+
+// fold a pending run into the HBM table (needed as soon as a second source of groups shows up)
+static int merge_run_into_table(vnm_agg* h, hipStream_t s) {
+    if (!h->have_run) return 0;
+    uint64_t* kw[2] = {h->run_key, h->run_key + h->run_stride};
+    uint64_t* aw[AGG_MAX_WORDS];
+    for (int w = 0; w < h->plan.n_words; w++) aw[w] = h->run_acc + (size_t)w * h->run_stride;
+    const int64_t n = h->run_n;
+    h->have_run = false;  // vnm_agg_merge_device must not recurse into us
+    int rc = vnm_agg_merge_device(h, n, kw, aw, (void*)s);
+    if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = set_error("merge_run_into_table: stream sync failed");
+    h->have_run = true;
+    drop_run(h);
+    return rc;
+}
 
 extern "C" {
 
@@ -775,6 +1247,7 @@ void vnm_agg_destroy(vnm_agg* h) {
     if (!h) return;
     if (h->have_table) table_free(&h->g);
     invalidate_result(h);
+    drop_run(h);
     delete h;
 }
 
@@ -802,8 +1275,10 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     if (h->pred_set && !pred) return set_error("vnm_agg_next_device: predicate set but no predicate column given");
     hipStream_t s = as_stream(stream);
     invalidate_result(h);
-    VNM_TRY(ensure_table(h, nrows, s));
-    if (nrows <= 0) return 0;
+    if (nrows <= 0) {
+        if (h->plan.n_keys == 0 || h->hint <= 0) VNM_TRY(ensure_table(h, nrows, s));
+        return 0;
+    }
     if (nrows >= (1LL << 31)) return set_error("vnm_agg_next_device: batches must be < 2^31 rows (as in the reference, agg_funcs.h:45)");
 
     AggArgs a{};
@@ -822,6 +1297,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     const int cus = device_info().num_cus;
 
     if (h->plan.n_keys == 0) {
+        VNM_TRY(ensure_table(h, nrows, s));
         a.g = h->g;
         int grid = cus * 8;
         int64_t need = (nrows + OG_BLOCK - 1) / OG_BLOCK;
@@ -854,6 +1330,14 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         hot = a.pred.type == VNM_F64 && !a.pred.validity && (a.pred.offset & 1) == 0 && a.p.mode == CMP_F64;
         a.hot_pred_is_v = a.pred.values == a.cols[0].values && a.pred.offset == a.cols[0].offset;
     }
+    // many groups: radix-partitioned path (no per-row HBM atomics); falls through when it does not apply
+    if (hot && h->hint > env_i64("VNM_AGG_PART_MIN_GROUPS", 2400) && getenv("VNM_AGG_NO_PART") == nullptr) {
+        if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
+        int prc = partitioned_aggregate(h, a, nrows, s);
+        if (prc == 0) { h->rows_seen += nrows; return 0; }
+        if (prc == 1) return 1;
+    }
+    VNM_TRY(ensure_table(h, nrows, s));
     if (hot) a.ntiles = (nrows + HOT_TILE - 1) / HOT_TILE;
     int grid = h->single ? cus : cus * 4;
     if (grid > a.ntiles) grid = (int)a.ntiles;
@@ -893,6 +1377,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         unsigned long long ctl[4];
         VNM_HIP(hipMemcpyAsync(ctl, h->g.ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
         VNM_HIP(hipStreamSynchronize(s));
+        if (ctl[1] == 2) return set_error("aggregate: HBM hash table overflow (internal error)");
         if (!ctl[1]) break;  // no block ran out of room: every tile was processed
         // grow (x4, or to the projected final size) and relaunch; blocks resume from progress[]
         uint64_t new_cap = h->g.cap * 4;
@@ -940,6 +1425,13 @@ int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream) {
         if (n_groups) *n_groups = h->n_groups;
         return 0;
     }
+    if (h->have_run && !h->have_table) {  // the partitioned path already produced the dense result
+        h->dkey = h->run_key; h->dacc = h->run_acc; h->dstride = h->run_stride; h->n_groups = h->run_n;
+        h->result_is_run = true;
+        if (n_groups) *n_groups = h->n_groups;
+        return 0;
+    }
+    if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
     if (!h->have_table) {
         if (h->plan.n_keys == 0) VNM_TRY(ensure_table(h, 0, s));  // OneGroup over no batches still yields one row
         else {
