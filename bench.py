@@ -175,29 +175,24 @@ def main():
         state["agg"] = agg  # keep the last result alive for the sanity check; previous one is freed
 
     def exchange_and_merge(agg, ng):
-        """Key-partitioned exchange of partial groups (owner = hash(key) mod P), one all_to_all over RCCL."""
+        """Key-partitioned exchange of partial groups (owner = hash(key words) mod P): ONE all_to_all over RCCL,
+        then the owner merges what it received (vinum_amd/distributed.py)."""
+        from vinum_amd import distributed as D
         kp, ap_ = agg.dense_ptrs()
         words = [torch.as_tensor(CudaArrayView(p, ng), device=device) for p in kp + ap_]
-        key = words[0]
-        owner = ((key * -7046029254386353131) >> 40) % world  # multiplicative hash (wraps in int64)
-        owner = owner.to(torch.int64) % world
-        order = torch.argsort(owner, stable=True)
-        counts = torch.bincount(owner, minlength=world)
-        send = torch.stack([w[order] for w in words], dim=1).contiguous()  # [ng, kw + W]
-        recv_counts = torch.empty_like(counts)
-        dist.all_to_all_single(recv_counts, counts)
-        sc, rc = counts.tolist(), recv_counts.tolist()
-        recv = torch.empty((sum(rc), send.shape[1]), dtype=torch.int64, device=device)
-        dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc)
-        merged = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
-                                     [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
-                                     expected_groups=max(int(recv.shape[0]), 1024))
-        cols = [recv[:, i].contiguous() for i in range(recv.shape[1])]
-        nk = len(kp)
-        merged.merge(recv.shape[0], [c.data_ptr() for c in cols[:nk]], [c.data_ptr() for c in cols[nk:]], stream=stream)
-        out = merged.finish(stream=stream)
-        state["merged"] = merged
-        return out
+
+        def merge(cols):
+            merged = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
+                                         [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
+                                         expected_groups=max(int(cols[0].numel()), 1024))
+            nk = len(kp)
+            merged.merge(int(cols[0].numel()), [c.data_ptr() for c in cols[:nk]], [c.data_ptr() for c in cols[nk:]],
+                         stream=stream)
+            out = merged.finish(stream=stream)
+            state["merged"] = (merged, cols)
+            return out
+
+        return D.exchange_partials(words, len(kp), merge)
 
     def sync_all():
         torch.cuda.synchronize()

@@ -1,0 +1,86 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the partial-aggregate exchange (ownership hash, bucketing,
+variable-size all_to_all, owner-side merge).  The device merge is replaced by a NumPy stand-in that applies the
+same merge kinds the library reports (vnm_agg_plan_host) -- the exchange logic is what is under test."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _partial(keys, vals):
+    """dense run of one rank: [key, nullmask] + [count(u64), sum(f64 bits)] as int64 tensors"""
+    uk, inv = np.unique(keys, return_inverse=True)
+    cnt = np.bincount(inv).astype(np.uint64)
+    sm = np.bincount(inv, weights=vals)
+    return [torch.from_numpy(uk.astype(np.int64)), torch.zeros(len(uk), dtype=torch.int64),
+            torch.from_numpy(cnt.view(np.int64)), torch.from_numpy(sm.view(np.int64))]
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vinum_amd import distributed as D
+    rng = np.random.default_rng(1000 + rank)
+    n = 50_000
+    keys = rng.integers(-500, 500, n).astype(np.int64) * 7919
+    vals = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
+    words = _partial(keys, vals)
+
+    def merge(cols):
+        k = cols[0].numpy()
+        uk, inv = np.unique(k, return_inverse=True)
+        cnt = np.zeros(len(uk), np.uint64)
+        np.add.at(cnt, inv, cols[2].numpy().view(np.uint64))          # merge kind 0: add-u64
+        sm = np.zeros(len(uk), np.float64)
+        np.add.at(sm, inv, cols[3].numpy().view(np.float64))          # merge kind 1: add-f64
+        return uk, cnt, sm
+
+    uk, cnt, sm = D.exchange_partials(words, 2, merge)
+    # every key this rank ended up with must be owned by it
+    own = D.owner_of([torch.from_numpy(uk), torch.zeros(len(uk), dtype=torch.int64)], world).numpy()
+    assert (own == rank).all()
+    np.savez(os.path.join(tmp, f"out_{rank}.npz"), k=uk, c=cnt, s=sm, in_k=keys, in_v=vals)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partial_aggregate_exchange_gloo(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(tmp_path / f"out_{r}.npz") for r in range(world)]
+    all_k = np.concatenate([o["in_k"] for o in outs])
+    all_v = np.concatenate([o["in_v"] for o in outs])
+    uk, inv = np.unique(all_k, return_inverse=True)
+    exp_c = np.bincount(inv).astype(np.uint64)
+    exp_s = np.bincount(inv, weights=all_v)
+    got_k = np.concatenate([o["k"] for o in outs])
+    got_c = np.concatenate([o["c"] for o in outs])
+    got_s = np.concatenate([o["s"] for o in outs])
+    order = np.argsort(got_k)
+    assert np.array_equal(got_k[order], uk), "owners' shards must partition the key space exactly"
+    assert np.array_equal(got_c[order], exp_c)
+    assert np.array_equal(got_s[order], exp_s)   # quantised values: sums are exact in any order
+
+
+def test_bucket_by_owner_is_a_permutation():
+    from vinum_amd import distributed as D
+    rng = np.random.default_rng(0)
+    k = torch.from_numpy(rng.integers(-2**62, 2**62, 10_000).astype(np.int64))
+    nm = torch.from_numpy((rng.random(10_000) < 0.01).astype(np.int64))
+    w = torch.arange(10_000, dtype=torch.int64)
+    for world in (1, 2, 4, 8):
+        send, counts = D.bucket_by_owner([k, nm, w], 2, world)
+        assert int(counts.sum()) == 10_000 and sorted(send[:, 2].tolist()) == list(range(10_000))
+        own = D.owner_of([send[:, 0], send[:, 1]], world)
+        assert torch.equal(own, torch.repeat_interleave(torch.arange(world), counts))
+        if world > 1:
+            assert counts.float().std() < 0.2 * counts.float().mean() + 50   # balanced ownership

@@ -1,0 +1,88 @@
+"""The five BASELINE.json configs at small N through the build's own operator chain (vinum_amd.query.select),
+checked against the oracle / pyarrow."""
+import io
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.compute as pc
+import pyarrow.csv as pacsv
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _taxi_csv(n, seed=0):
+    """config 1 input: taxi schema (README.rst:121-139, test_io.py:7-15), passenger_count in 0..6 with the
+    empirical weights of vinum/tests/test_io.py:18."""
+    rng = np.random.default_rng(seed)
+    w = np.array([165, 34808, 7386, 2183, 1016, 3453, 989], float)
+    pcnt = rng.choice(7, n, p=w / w.sum())
+    fare = np.round(rng.lognormal(2.2, 0.6, n), 2)
+    t = pa.table({"key": pa.array([f"k{i}" for i in range(n)]), "fare_amount": fare,
+                  "pickup_longitude": rng.normal(-73.9, 0.1, n), "passenger_count": pcnt.astype(np.int64)})
+    buf = io.BytesIO()
+    pacsv.write_csv(t, buf)
+    return buf.getvalue(), t
+
+
+def test_config1_groupby_passenger_count_stream_csv():
+    from vinum_amd.query import select
+    from vinum_amd.core import AggregateFunction as F
+    data, t = _taxi_csv(200_000)
+    reader = pacsv.open_csv(io.BytesIO(data), read_options=pacsv.ReadOptions(block_size=1 << 20))
+    got = select(reader, columns=["passenger_count"], group_by=["passenger_count"],
+                 aggregates=[F("count", None, "cnt"), F("avg", "fare_amount", "avg_fare")]).sort_by("passenger_count")
+    exp = t.group_by("passenger_count").aggregate([("fare_amount", "count"), ("fare_amount", "mean")]).sort_by("passenger_count")
+    assert got.column("passenger_count").to_pylist() == exp.column("passenger_count").to_pylist()
+    assert got.column("cnt").to_pylist() == exp.column("fare_amount_count").to_pylist()
+    assert np.allclose(got.column("avg_fare").to_numpy(), exp.column("fare_amount_mean").to_numpy(), rtol=1e-12)
+
+
+def test_config2_filter():
+    from vinum_amd.query import select
+    rng = np.random.default_rng(2)
+    n = 300_000
+    t = pa.table({"fare_amount": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0, mask=rng.random(n) < 0.01),
+                  "id": np.arange(n)})
+    got = select(t, columns=["fare_amount", "id"], where=("fare_amount", ">", 64.0))
+    m = pc.fill_null(pc.greater(t.column("fare_amount"), 64.0), False)
+    util.assert_batches_equal(got.combine_chunks().to_batches()[0], t.filter(m).combine_chunks().to_batches()[0], what="config2")
+
+
+def test_config3_filter_groupby():
+    from oracle import oracle as O
+    from vinum_amd.query import select
+    from vinum_amd.core import AggregateFunction as F
+    rng = np.random.default_rng(3)
+    n = 400_000
+    t = pa.table({"k": rng.integers(0, 50_000, n).astype(np.int64), "v": rng.integers(0, 2**14, n).astype(np.float64) / 128.0})
+    got = select(t, columns=["k"], where=("v", ">", 64.0), group_by=["k"],
+                 aggregates=[F("sum", "v", "s"), F("avg", "v", "a")], expected_groups=50_000)
+    funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a")]
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in t.to_batches():
+        o.next(O.filter_batch(b, O.cmp_mask(b.column(1), O.GT, 64.0)))
+    util.assert_agg_equal(got.combine_chunks().to_batches()[0], o.result(), funcs, ["k"], what="config3")
+
+
+def test_config5_orderby_limit_projection():
+    from oracle import oracle as O
+    from vinum_amd.query import select
+    rng = np.random.default_rng(5)
+    n = 500_000
+    v = rng.normal(11, 9, n)
+    v[rng.random(n) < 0.001] = np.nan
+    t = pa.table({"v": pa.array(v, mask=rng.random(n) < 0.001), "a": rng.normal(0, 3, n), "b": rng.lognormal(0, 1, n)})
+    got = select(t, columns=["v", ("e1", ("add", ("mul", "v", 2), 1)), ("e2", ("sub", "v", "a")), ("e3", ("mul", "a", "b"))],
+                 order_by=["v"], sort_order=[1], limit=1000)
+    s = O.OracleSort(["v"], [1])
+    for b in t.to_batches():
+        s.next(b)
+    top = s.sorted().slice(0, 1000)
+    nv = top.column(0).to_numpy(zero_copy_only=False)
+    na, nb = top.column(1).to_numpy(), top.column(2).to_numpy()
+    util.assert_col_equal(got.column("v").combine_chunks(), top.column(0), "v")
+    for name, ref in [("e1", nv * 2 + 1), ("e2", nv - na), ("e3", na * nb)]:
+        assert np.array_equal(got.column(name).to_numpy().view(np.uint64), ref.view(np.uint64)), name

@@ -1,0 +1,152 @@
+"""GPU counterparts of the reference's Python physical operators (vinum/core/algebra.py)."""
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import pyarrow as pa
+
+from .. import get_batch_size, ops
+from .. import _lib as L
+from ..device import DeviceColumn, is_supported
+from .base import DeviceRecordBatch, Operator
+
+
+class TableReaderOperator(Operator):
+    """algebra.py:250-265 + table_batch_reader.cpp: slices the table into batches of vinum_amd.get_batch_size() rows
+    (2^24 by default -- the reference's 10 000 would mean 1e5 launches per 1e9 rows) and stages them into HBM.
+    `columns` prunes what is staged (the planner's pruning projection, planner.py:367-371)."""
+
+    def __init__(self, table: pa.Table, columns: Optional[Sequence[str]] = None):
+        super().__init__(None)
+        self._table = table.select(list(columns)) if columns is not None else table
+
+    def next(self):
+        for b in self._table.to_batches(max_chunksize=get_batch_size()):
+            yield DeviceRecordBatch.from_arrow(b)
+
+
+class FileReaderOperator(Operator):
+    """algebra.py:268-279: pulls from a pyarrow streaming reader (pyarrow.csv.open_csv, io/arrow.py:58-61) until
+    StopIteration.  Only GPU-representable columns are staged."""
+
+    def __init__(self, reader, columns: Optional[Sequence[str]] = None):
+        super().__init__(None)
+        self._reader, self._columns = reader, columns
+
+    def next(self):
+        while True:
+            try:
+                batch = self._reader.read_next_batch()
+            except StopIteration:
+                break
+            names = self._columns if self._columns is not None else [f.name for f in batch.schema if is_supported(f.type)]
+            yield DeviceRecordBatch.from_arrow(batch.select(list(names)))
+
+
+class FilterOperator(Operator):
+    """algebra.py:108-123: `WHERE column <op> literal`; every column of the batch is compacted (no selection
+    vectors in the reference either).  predicate = (column, op, literal)."""
+
+    def __init__(self, predicate: Tuple[str, str, object], parent_operator: Operator):
+        super().__init__(parent_operator)
+        self.predicate = predicate
+
+    def _kernel(self, batch: DeviceRecordBatch) -> DeviceRecordBatch:
+        col, op, lit = self.predicate
+        names = batch.column_names
+        outs, k = ops.filter_cmp(batch.column(col), op, lit, [batch.columns[n] for n in names])
+        return DeviceRecordBatch(dict(zip(names, outs)), k)
+
+
+class ProjectOperator(Operator):
+    """algebra.py:28-105: expressions (prefix tuples, see ops.compile_expr) or plain column names -> output columns.
+    keep_input_table appends instead of replacing (:56-62)."""
+
+    def __init__(self, arguments: Sequence, parent_operator: Operator, col_names: Optional[Sequence[str]] = None,
+                 keep_input_table: bool = False):
+        super().__init__(parent_operator)
+        self._arguments = list(arguments)
+        self._col_names = list(col_names) if col_names is not None else [a if isinstance(a, str) else f"expr_{i}"
+                                                                          for i, a in enumerate(arguments)]
+        self._keep = keep_input_table
+
+    def _kernel(self, batch: DeviceRecordBatch) -> DeviceRecordBatch:
+        out = dict(batch.columns) if self._keep else {}
+        n = batch.num_rows
+        for name, arg in zip(self._col_names, self._arguments):
+            if isinstance(arg, str):
+                out[name] = batch.column(arg)
+            else:
+                used = {c: batch.columns[c] for c in _columns_of(arg)}
+                out[name] = ops.project(arg, used, length=n if used else max(n, 1))   # scalars repeat (:77-87)
+        return DeviceRecordBatch(out, n if out and any(not isinstance(a, (int, float)) for a in self._arguments) else n)
+
+
+def _columns_of(expr) -> List[str]:
+    if isinstance(expr, str):
+        return [expr]
+    if isinstance(expr, tuple):
+        seen = []
+        for e in expr[1:]:
+            for c in _columns_of(e):
+                if c not in seen:
+                    seen.append(c)
+        return seen
+    return []
+
+
+class SortOperator(Operator):
+    """algebra.py:126-201 + sort.cpp: buffers every batch, one stable multi-key sort, all columns taken.
+    limit > 0 pushes LIMIT into the sort (same rows as sorting everything, then SliceOperator)."""
+
+    def __init__(self, columns: Sequence[str], sort_order: Sequence[int], parent_operator: Operator, limit: int = 0):
+        super().__init__(parent_operator)
+        self._cols, self._orders, self._limit = list(columns), [int(o) for o in sort_order], int(limit)
+
+    def next(self):
+        batches = [b.to_arrow() for b in self._parent_operator.next()]
+        if not batches:
+            return
+        table = pa.Table.from_batches(batches).combine_chunks()       # Table::FromRecordBatches (sort.cpp:16)
+        for f in table.schema:
+            if f.name in self._cols and pa.types.is_boolean(f.type):   # algebra.py:191-201
+                raise RuntimeError("Sorting by boolean column is not supported yet. "
+                                   "Please use float(bool_column) as a workaround.")
+        dev = {n: DeviceColumn.from_arrow(table.column(n)) for n in table.schema.names}
+        n = table.num_rows
+        k = self._limit if 0 < self._limit < n else 0
+        idx = ops.sort_indices([dev[c] for c in self._cols], self._orders, limit=k)
+        m = k if k else n
+        yield DeviceRecordBatch({name: ops.take(col, idx, m) for name, col in dev.items()}, m)
+
+
+class SliceOperator(Operator):
+    """algebra.py:204-247: LIMIT / OFFSET over the batch stream."""
+
+    def __init__(self, limit: int, offset: int, parent_operator: Operator):
+        super().__init__(parent_operator)
+        self._limit, self._offset = limit, offset
+
+    def next(self):
+        returned, cur = 0, 0
+        for batch in self._parent_operator.next():
+            if returned >= self._limit:
+                break
+            if self._offset >= cur + batch.num_rows:
+                cur += batch.num_rows
+                continue
+            off = max(self._offset - cur, 0)
+            size = min(self._limit - returned, batch.num_rows - off)
+            if size < batch.num_rows:
+                ab = batch.to_arrow().slice(off, size)
+                yield DeviceRecordBatch.from_arrow(ab)
+            else:
+                yield batch
+            returned += size
+            cur += off + size
+
+
+class MaterializeTableOperator(Operator):
+    """algebra.py:290-295: pulls everything, returns one pyarrow Table (the only D2H of the pipeline)."""
+
+    def next(self):
+        batches = [b.to_arrow() for b in self._parent_operator.next()]
+        yield pa.Table.from_batches(batches) if batches else pa.table({})

@@ -1,0 +1,46 @@
+"""Operator protocol (mirror of vinum/core/base.py:226-260): a linear chain of pull-based operators, each a
+generator over record batches -- here the batches live in HBM."""
+from typing import Dict, Iterable, List
+
+import pyarrow as pa
+
+from ..device import DeviceColumn
+
+
+class DeviceRecordBatch:
+    """Named HBM-resident columns of equal length (device counterpart of vinum/arrow/record_batch.py)."""
+
+    def __init__(self, columns: Dict[str, DeviceColumn], num_rows: int = None):
+        self.columns = dict(columns)
+        self.num_rows = num_rows if num_rows is not None else (next(iter(columns.values())).length if columns else 0)
+
+    @staticmethod
+    def from_arrow(batch: pa.RecordBatch) -> "DeviceRecordBatch":
+        return DeviceRecordBatch({n: DeviceColumn.from_arrow(batch.column(i)) for i, n in enumerate(batch.schema.names)},
+                                 batch.num_rows)
+
+    @property
+    def column_names(self) -> List[str]:
+        return list(self.columns)
+
+    def column(self, name: str) -> DeviceColumn:
+        if name not in self.columns:
+            raise ValueError(f'Column "{name}" is not found.')   # record_batch.py:74-75
+        return self.columns[name]
+
+    def to_arrow(self) -> pa.RecordBatch:
+        return pa.RecordBatch.from_arrays([c.to_arrow() for c in self.columns.values()], names=list(self.columns))
+
+
+class Operator:
+    """next() yields batches; subclasses override _kernel (base.py:254-267) or next()."""
+
+    def __init__(self, parent_operator: "Operator" = None):
+        self._parent_operator = parent_operator
+
+    def next(self) -> Iterable[DeviceRecordBatch]:
+        for batch in self._parent_operator.next():
+            yield self._kernel(batch)
+
+    def _kernel(self, batch: DeviceRecordBatch) -> DeviceRecordBatch:
+        raise NotImplementedError

@@ -1,0 +1,68 @@
+"""Multi-GPU group-by: batch-sharded partial aggregates + ONE key-partitioned exchange.
+
+The reference has no distributed code at all; what makes sharding legal is structural: operators consume
+independent RecordBatches and every aggregate state is a commutative monoid per group (base_aggregate.cpp:23-45
+only ever Init()s or Update()s a group's state).  So each rank aggregates its own batches into a dense run of
+partial groups (key words + 64-bit accumulator words that merge by add / min / max), then
+
+    owner(key) = mix(key words) mod P
+    all_to_all of the runs, bucketed by owner           (RCCL over xGMI: the full mesh, not a ring)
+    the owner merges what it received                   (same merge kinds as the LDS / HBM tables)
+
+and the final result is the concatenation of the owners' shards (row order is unspecified in the reference
+anyway, robin_hood iteration order).  One process per GPU; torch.distributed is only the transport.
+
+The merge itself is a device operation (DeviceAggregate.merge); this module takes it as a callable so that the
+CPU tests (gloo, world_size 2) can exercise the ownership / exchange logic with a host stand-in.
+"""
+import torch
+import torch.distributed as dist
+
+_MIX = -7046029254386353131  # 0x9E3779B97F4A7C15 as int64
+
+
+def owner_of(key_words, world: int) -> torch.Tensor:
+    """Owner rank per partial group.  key_words: list of int64 tensors (n_keys value words + null-mask word)."""
+    h = torch.zeros_like(key_words[0])
+    for w in key_words:
+        h = (h ^ w) * _MIX            # wraps in int64: a multiplicative hash per word
+        h = h ^ (h >> 29)
+    return ((h >> 17) & 0x7FFFFFFF) % world
+
+
+def bucket_by_owner(words, n_key_words: int, world: int):
+    """words: list of int64 tensors of equal length (key words first).  Returns (rows [n, n_words] grouped by
+    owner, counts [world])."""
+    if len(words[0]) == 0:
+        return torch.empty((0, len(words)), dtype=torch.int64, device=words[0].device), \
+            torch.zeros(world, dtype=torch.int64, device=words[0].device)
+    owner = owner_of(words[:n_key_words], world)
+    order = torch.argsort(owner, stable=True)
+    counts = torch.bincount(owner, minlength=world)
+    send = torch.stack([w[order] for w in words], dim=1).contiguous()
+    return send, counts
+
+
+def exchange(send: torch.Tensor, counts: torch.Tensor, group=None) -> torch.Tensor:
+    """all_to_all of variable-size row blocks; returns the rows this rank owns."""
+    world = dist.get_world_size(group)
+    recv_counts = torch.empty_like(counts)
+    dist.all_to_all_single(recv_counts, counts, group=group)
+    sc, rc = counts.tolist(), recv_counts.tolist()
+    ncol = send.shape[1]
+    recv = torch.empty((sum(rc), ncol), dtype=send.dtype, device=send.device)
+    # flat 1-D buffers with element-count splits: the form both RCCL and gloo accept
+    dist.all_to_all_single(recv.view(-1), send.view(-1), output_split_sizes=[c * ncol for c in rc],
+                           input_split_sizes=[c * ncol for c in sc], group=group)
+    assert world == len(sc)
+    return recv
+
+
+def exchange_partials(words, n_key_words: int, merge, group=None):
+    """words: this rank's dense run (list of int64 tensors).  merge(list_of_word_tensors) -> anything: called with
+    the rows this rank owns (possibly from several ranks, duplicates across ranks included)."""
+    world = dist.get_world_size(group)
+    send, counts = bucket_by_owner(words, n_key_words, world)
+    recv = exchange(send, counts, group)
+    cols = [recv[:, i].contiguous() for i in range(recv.shape[1])]
+    return merge(cols)
