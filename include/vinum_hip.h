@@ -163,7 +163,11 @@ int vnm_agg_result_func(vnm_agg* h, int func_idx, void* cells16, uint8_t* valid,
  * on CPU. */
 int vnm_agg_plan_host(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
                       const int* in_types, const int* in_flags, const int* in_col_ids, int* n_key_words,
-                      int* n_acc_words, int* merge_kinds /* >= 40 ints */);
+                      int* n_acc_words, int* merge_kinds /* >= 40 ints */, int* n_ops,
+                      int* op_kind_col_word /* >= 3 * 48 ints: per-row update kind, distinct input column, word;
+                                               kinds: 0 count rows, 1 count valid, 2 sum f64, 3 sum i64 (wrap),
+                                               4 sum low 32 bits, 5 sum high 32 (signed), 6 sum high 32 (unsigned),
+                                               7 min, 8 max (on the order-preserving 64-bit encoding) */);
 int vnm_agg_finalize_host(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
                           const int* in_types, const int* in_flags, const int* in_col_ids, int func_idx,
                           int64_t n, const uint64_t* const* acc_words, void* cells16, uint8_t* valid,

@@ -62,7 +62,8 @@ PROTOTYPES = {
     "vnm_agg_merge_device": (c_int, [c_void, c_i64, c_void, c_void, c_void]),
     "vnm_agg_result_key": (c_int, [c_void, c_int, c_void, c_void]),
     "vnm_agg_result_func": (c_int, [c_void, c_int, c_void, c_void, c_void]),
-    "vnm_agg_plan_host": (c_int, [c_int, c_int, c_void, c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
+    "vnm_agg_plan_host": (c_int, [c_int, c_int, c_void, c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_void,
+                                  c_void, c_void]),
     "vnm_agg_finalize_host": (c_int, [c_int, c_int, c_void, c_int, c_void, c_void, c_void, c_void, c_int, c_i64,
                                       c_void, c_void, c_void, c_void]),
     "vnm_agg_op_create": (c_void, [c_int, c_int, c_void, c_int, c_void, c_int, c_void, c_void, c_void]),

@@ -1528,13 +1528,20 @@ int vnm_agg_result_func(vnm_agg* h, int func_idx, void* cells16, uint8_t* valid,
 // host-only helpers: plan lowering and finalisation from accumulator words (no GPU needed)
 int vnm_agg_plan_host(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs, const int* in_types,
                       const int* in_flags, const int* in_col_ids, int* n_key_words, int* n_acc_words,
-                      int* merge_kinds /* >= 40 ints */) {
+                      int* merge_kinds /* >= 40 ints */, int* n_ops, int* op_kind_col_word /* >= 3 * 48 ints */) {
     AggPlan plan;
     FuncOut outs[AGG_MAX_FUNCS];
     VNM_TRY(build_plan(kind, n_keys, key_types, n_funcs, funcs, in_types, in_flags, in_col_ids, &plan, outs));
     if (n_key_words) *n_key_words = plan.kw;
     if (n_acc_words) *n_acc_words = plan.n_words;
     if (merge_kinds) for (int w = 0; w < plan.n_words; w++) merge_kinds[w] = plan.merge[w];
+    if (n_ops) *n_ops = plan.n_ops;
+    if (op_kind_col_word)
+        for (int o = 0; o < plan.n_ops; o++) {
+            op_kind_col_word[3 * o] = plan.ops[o].kind;
+            op_kind_col_word[3 * o + 1] = plan.ops[o].col;
+            op_kind_col_word[3 * o + 2] = plan.ops[o].word;
+        }
     return 0;
 }
 
