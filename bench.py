@@ -130,9 +130,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # VNM_BENCH_FORCE_EXCHANGE=1 runs the RCCL exchange + merge step with a single rank too (self-test of the
+    # N > 1 code path on a 1-GPU box)
+    force_exchange = os.environ.get("VNM_BENCH_FORCE_EXCHANGE") == "1"
+    if world > 1 or force_exchange:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     from vinum_amd import _lib as L
     from vinum_amd import ops
@@ -168,7 +173,7 @@ def main():
         agg.set_predicate(">", x_thr)
         agg.next([kcol], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
         ng = agg.finish(stream=stream)
-        if world > 1:
+        if world > 1 or force_exchange:
             ng = exchange_and_merge(agg, ng)
         state["out_rows"] = ng
         state.pop("agg", None)
@@ -237,13 +242,22 @@ def main():
         alg_bytes = 16.0 * n + 24.0 * out_rows        # read key+value once, write key,sum,avg per group
         workload = (f"configs[2]: SELECT k,sum(v),avg(v) WHERE v>{x_thr} GROUP BY k; N={n:.3g} rows/GPU, "
                     f"G={groups:.3g} int64 keys, s={args.selectivity}")
-        dom = dom_name
+        dom = " + ".join(spans) + f" (dominant: {dom_name})" if len(spans) > 1 else dom_name
     # per-kernel algorithmic bytes: the scan kernels read key+value once (16 N) and write the groups; a
     # partition pass of the large-G path reads 16 N and its successors re-read the surviving pairs -- the
     # roofline of THE QUERY is always computed from the query's algorithmic bytes over the SUM of its kernels
     total_kernel_ms = sum(v[0] for v in spans.values()) if spans else 0.0
     achieved = alg_bytes / (total_kernel_ms * 1e-3) / 1e9 if total_kernel_ms > 0 else 0.0
 
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            tj = json.load(f)
+        key = f"{args.workload}_N{n:.0e}_G{groups:.0e}_s{args.selectivity}"
+        if key in tj:
+            traffic = tj[key]["bytes_per_step"]
+    except Exception:
+        pass
     if rank == 0:
         result = {
             "metric": "rows/sec + achieved HBM GB/s, filter->group-by over 10^9-row Arrow batches",
@@ -257,7 +271,9 @@ def main():
                        "selectivity": args.selectivity, "result_rows": int(out_rows),
                        "parallelism": f"batch-sharded x{world}" + (", RCCL all_to_all partial-aggregate exchange" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/r01_rocprofv3_pmc_groupby_1e8.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 per the gfx950 note)" if traffic else None,
+                         "kernel": dom,
                          "kernel_ms": total_kernel_ms, "dominant_kernel_ms": kernel_ms,
                          "kernels_ms": {k: round(v[0], 4) for k, v in spans.items()},
                          "algorithmic_bytes": alg_bytes,
@@ -270,7 +286,7 @@ def main():
                 result["cpu_baseline"] = {"value": None, "unit": "rows/s", "cores": 1, "kind": "port",
                                           "sample": f"failed: {e}"}
         print(json.dumps(result))
-    if world > 1:
+    if world > 1 or force_exchange:
         dist.barrier()
         dist.destroy_process_group()
 
