@@ -135,6 +135,7 @@ def main():
     force_exchange = os.environ.get("VNM_BENCH_FORCE_EXCHANGE") == "1"
     if world > 1 or force_exchange:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
@@ -285,10 +286,14 @@ def main():
             except Exception as e:  # the baseline is reporting only; never fail the bench line on it
                 result["cpu_baseline"] = {"value": None, "unit": "rows/s", "cores": 1, "kind": "port",
                                           "sample": f"failed: {e}"}
-        print(json.dumps(result))
+    else:
+        result = None
     if world > 1 or force_exchange:
         dist.barrier()
         dist.destroy_process_group()
+    if result is not None:
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)   # the LAST line of stdout (RCCL prints banners of its own)
 
 
 if __name__ == "__main__":
