@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="groupby", choices=["groupby", "filter"])
+    ap.add_argument("--workload", default="groupby", choices=["groupby", "filter", "topk", "project"])
+    ap.add_argument("--limit", type=int, default=10)
     ap.add_argument("--rows", type=float, default=1e9)
     ap.add_argument("--groups", type=float, default=1e8)
     ap.add_argument("--selectivity", type=float, default=0.5)
@@ -156,6 +157,16 @@ def main():
     out_buf = None
     if args.workload == "filter":
         out_buf = torch.empty(n, dtype=torch.float64, device=device)
+    if args.workload in ("topk", "project"):
+        # configs[4]: v ~ N(11, 9) seed 2, two more fp64 columns for `v*2+1, v-a, a*b`
+        gg = torch.Generator(device=device); gg.manual_seed(2 + rank)
+        del k
+        v = torch.randn(n, device=device, dtype=torch.float64, generator=gg) * 3.0 + 11.0
+        vcol = DeviceColumn.from_torch(v)
+        if args.workload == "project":
+            ca = torch.randn(n, device=device, dtype=torch.float64, generator=gg)
+            cb = torch.rand(n, device=device, dtype=torch.float64, generator=gg)
+            acol, bcol = DeviceColumn.from_torch(ca), DeviceColumn.from_torch(cb)
 
     state = {}
 
@@ -168,6 +179,17 @@ def main():
             L.check(lib.vnm_filter_cmp(ctypes.byref(d), L.GT, 1, x_thr, 0, 1, ctypes.byref(d), ov, ob,
                                        ctypes.byref(cnt), ctypes.c_void_p(stream)))
             state["out_rows"] = cnt.value
+            return
+        if args.workload == "topk":
+            idx = ops.sort_indices([vcol], [L.DESC], limit=args.limit, stream=stream)
+            state["out_rows"] = args.limit
+            state["idx"] = idx
+            return
+        if args.workload == "project":
+            cols = {"v": vcol, "a": acol, "b": bcol}
+            state["outs"] = [ops.project(e, cols, length=n, stream=stream)
+                             for e in (("add", ("mul", "v", 2), 1), ("sub", "v", "a"), ("mul", "a", "b"))]
+            state["out_rows"] = n
             return
         agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
                                   [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())], expected_groups=groups)
@@ -220,8 +242,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    names = [b"filter_kernel"] if args.workload == "filter" else [b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2",
-                                                                   b"agg_part_final"]
+    names = {"filter": [b"filter_kernel"], "topk": [b"topk_select", b"radix_pass"], "project": [b"project_kernel"]}.get(
+        args.workload, [b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final"])
     spans = {}
     for nm in names:
         tot_ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
@@ -239,10 +261,20 @@ def main():
         alg_bytes = 8.0 * n + 8.0 * out_rows          # read column once, write survivors
         workload = f"configs[1]: WHERE fare_amount > {x_thr} over {n:.3g}-row fp64 column (s={args.selectivity}) -> compacted column"
         dom = "filter_kernel"
+    elif args.workload == "topk":
+        alg_bytes = 8.0 * n + 8.0 * args.limit       # SURVEY.md §8d config 5, top-K variant
+        workload = f"configs[4]: ORDER BY v DESC LIMIT {args.limit} over {n:.3g} fp64 rows (top-K variant, row ids out)"
+        dom = "topk_select"
+    elif args.workload == "project":
+        alg_bytes = 8.0 * n * 3 + 8.0 * n * 3       # three distinct inputs, three outputs
+        workload = f"configs[4]: projection v*2+1, v-a, a*b over {n:.3g} fp64 rows"
+        dom = "project_kernel"
     else:
         alg_bytes = 16.0 * n + 24.0 * out_rows        # read key+value once, write key,sum,avg per group
         workload = (f"configs[2]: SELECT k,sum(v),avg(v) WHERE v>{x_thr} GROUP BY k; N={n:.3g} rows/GPU, "
                     f"G={groups:.3g} int64 keys, s={args.selectivity}")
+        pass
+    if args.workload not in ("filter",):
         dom = " + ".join(spans) + f" (dominant: {dom_name})" if len(spans) > 1 else dom_name
     # per-kernel algorithmic bytes: the scan kernels read key+value once (16 N) and write the groups; a
     # partition pass of the large-G path reads 16 N and its successors re-read the surviving pairs -- the
@@ -280,7 +312,7 @@ def main():
                          "algorithmic_bytes": alg_bytes,
                          "launches_per_step": cnt.value / max(args.steps, 1)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload in ("groupby", "filter"):
             try:
                 result["cpu_baseline"] = cpu_baseline(args, x_thr)
             except Exception as e:  # the baseline is reporting only; never fail the bench line on it

@@ -639,9 +639,14 @@ __global__ void agg_compact_special_kernel(CompactArgs c) {
 // Traffic: 16 N read + 16 sN written/read per level + 24 G' written.
 // =======================================================================================================
 constexpr int PT_BLOCK = 1024;
-constexpr int PT_ITEMS = 4;
+#ifndef VNM_PT_ITEMS
+#define VNM_PT_ITEMS 8   // 8192-item tiles: one workgroup per CU, but write runs twice as long (measured 14.1 vs 15.3 ms at G=1e8)
+#endif
+constexpr int PT_ITEMS = VNM_PT_ITEMS;
+constexpr int PT_PAIRS = PT_ITEMS / 2;
 constexpr int PT_TILE = PT_BLOCK * PT_ITEMS;  // 4096 rows or entries per tile
 constexpr int PT_MAXP = 512;
+constexpr int PT_MAX_REGIONS = 256;  // input regions per pass-2 workgroup (keeps two workgroups per CU in LDS)
 constexpr int PA_BLOCK = 512;
 constexpr int PA_SLOTS = 2048;
 
@@ -695,7 +700,10 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
         src_first = (int64_t)pin * a.in_regions;
     }
 
-    auto process_tile = [&](int nitems, auto&& load_item) {
+    // One tile = PT_TILE items.  get_item(k, &e) extracts item k of the CURRENT tile from registers;
+    // prefetch_next() is called right after the last use of those registers (end of phase A) and issues the
+    // loads of the NEXT tile into the same registers, so HBM reads stay in flight during phases B..E.
+    auto process_tile = [&](auto&& get_item, auto&& prefetch_next) {
         // A: local rank inside the partition (LDS returning atomic)
         uint32_t myp[PT_ITEMS], myr[PT_ITEMS];
         ulonglong2 mye[PT_ITEMS];
@@ -703,13 +711,14 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
         for (int k = 0; k < PT_ITEMS; k++) {
             myp[k] = 0xFFFFFFFFu;
             ulonglong2 e;
-            if (load_item(k, &e)) {
+            if (get_item(k, &e)) {
                 uint32_t p = (hash_u64(e.x) >> a.shift) & pmask;
                 myp[k] = p;
                 mye[k] = e;
                 myr[k] = atomicAdd(&cnt[p], 1u);
             }
         }
+        prefetch_next();
         __syncthreads();
         // B: exclusive scan of cnt[0..np): wave scans, then the totals of the preceding waves are added
         if (tid < npad) {
@@ -749,26 +758,29 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
         // E: advance cursors
         if (tid < np) { cursor[tid] += cnt[tid]; cnt[tid] = 0; }
         __syncthreads();
-        (void)nitems;
     };
 
     if (FROM_ROWS) {
-        for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // two 16-byte loads per column: rows (base + 2 tid, +1) and (base + 2048 + 2 tid, +1)
+        ulonglong2 kk[PT_PAIRS];
+        double2 vv[PT_PAIRS], pv[PT_PAIRS];
+        auto load_rows = [&](int64_t tile) {
             const int64_t base = tile * PT_TILE;
-            // two 16-byte loads per column: rows (base + 2 tid, +1) and (base + 2048 + 2 tid, +1)
-            ulonglong2 kk[2];
-            double2 vv[2], pv[2];
-            const bool full = base + PT_TILE <= a.nrows;
-            if (full) {
+            if (tile < ntiles && base + PT_TILE <= a.nrows) {
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
+                for (int u = 0; u < PT_PAIRS; u++) {
                     int64_t r = base + (int64_t)u * 2 * PT_BLOCK + 2 * tid;
                     kk[u] = *(const ulonglong2*)(a.kp + r);
                     vv[u] = *(const double2*)(a.vp + r);
                     if (a.has_pred && !a.pred_is_v) pv[u] = *(const double2*)(a.pp + r);
                 }
             }
-            process_tile(PT_ITEMS, [&](int k, ulonglong2* e) -> bool {
+        };
+        load_rows(blockIdx.x);
+        for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int64_t base = tile * PT_TILE;
+            const bool full = base + PT_TILE <= a.nrows;
+            process_tile([&](int k, ulonglong2* e) -> bool {
                 const int u = k >> 1, el = k & 1;
                 int64_t r = base + (int64_t)u * 2 * PT_BLOCK + 2 * tid + el;
                 if (r >= a.nrows) return false;
@@ -784,23 +796,44 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
                 e->x = key;
                 e->y = (unsigned long long)__double_as_longlong(v);
                 return true;
-            });
+            }, [&]() { load_rows(tile + gridDim.x); });
         }
     } else {
-        const int per = a.in_regions / a.in_split;
+        // the input regions of this workgroup are read as ONE concatenated stream (prefix sums of the region
+        // counts in LDS, binary search per item), so every tile is full
+        __shared__ uint32_t rstart[PT_MAX_REGIONS + 1];
+        const int per_max = (a.in_regions + a.in_split - 1) / a.in_split;
         const int g = blockIdx.x % a.in_split;
-        for (int rj = 0; rj < per; rj++) {
-            const int64_t region = src_first + (int64_t)g * per + rj;
-            const uint32_t n = a.in_counts[region];
-            const ulonglong2* src = a.in_entries + region * a.in_cap;
-            for (uint32_t b0 = 0; b0 < n; b0 += PT_TILE) {
-                process_tile(PT_ITEMS, [&](int k, ulonglong2* e) -> bool {
-                    uint32_t i = b0 + (uint32_t)k * PT_BLOCK + tid;
-                    if (i >= n) return false;
-                    *e = src[i];
-                    return true;
-                });
+        const int first = g * per_max;
+        const int per = first + per_max <= a.in_regions ? per_max : (a.in_regions > first ? a.in_regions - first : 0);
+        const int64_t region0 = src_first + first;
+        if (tid == 0) {
+            uint32_t run = 0;
+            for (int rj = 0; rj < per; rj++) { rstart[rj] = run; run += a.in_counts[region0 + rj]; }
+            rstart[per] = run;
+        }
+        __syncthreads();
+        const uint32_t total_in = rstart[per];
+        ulonglong2 eb[PT_ITEMS];
+        auto load_entries = [&](uint32_t t0) {
+#pragma unroll
+            for (int k = 0; k < PT_ITEMS; k++) {
+                uint32_t v = t0 + (uint32_t)k * PT_BLOCK + tid;
+                if (v < total_in) {
+                    int lo = 0, hi = per;  // largest rj with rstart[rj] <= v
+                    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (rstart[mid] <= v) lo = mid; else hi = mid; }
+                    eb[k] = a.in_entries[(region0 + lo) * a.in_cap + (v - rstart[lo])];
+                }
             }
+        };
+        load_entries(0);
+        for (uint32_t t0 = 0; t0 < total_in; t0 += PT_TILE) {
+            process_tile([&](int k, ulonglong2* e) -> bool {
+                uint32_t v = t0 + (uint32_t)k * PT_BLOCK + tid;
+                if (v >= total_in) return false;
+                *e = eb[k];
+                return true;
+            }, [&]() { load_entries(t0 + PT_TILE); });
         }
     }
     if (tid < np) a.out_counts[out_base + (int64_t)tid * out_stride] = cursor[tid];
@@ -843,8 +876,19 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
             const int64_t region = f * a.regions + rj;
             const uint32_t n = a.counts[region];
             const ulonglong2* src = a.entries + region * a.cap;
-            for (uint32_t i = tid; i < n; i += PA_BLOCK) {
-                ulonglong2 e = src[i];
+            for (uint32_t i0 = 0; i0 < n; i0 += PA_BLOCK * 4) {
+              // four independent 16-byte loads in flight per lane before the (serial) LDS insertions
+              ulonglong2 eb[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                  uint32_t i = i0 + (uint32_t)u * PA_BLOCK + tid;
+                  if (i < n) eb[u] = src[i];
+              }
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                uint32_t i = i0 + (uint32_t)u * PA_BLOCK + tid;
+                if (i >= n) continue;
+                ulonglong2 e = eb[u];
                 const uint64_t key = e.x;
                 int slot = -1;
                 if (key == EMPTY) { slot = PA_SLOTS; lkey[slot] = 0; }
@@ -871,6 +915,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
                     __hip_atomic_fetch_add((double*)&lsum[slot], __longlong_as_double((long long)e.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     atomicAdd(&lcnt[slot], 1u);
                 }
+              }
             }
         }
         __syncthreads();
@@ -1093,8 +1138,8 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     const int levels = nfin > l1_max ? 2 : 1;
     const int np1 = levels == 2 ? (int)l1_max : (int)nfin;
     const int np2 = levels == 2 ? (int)(nfin / l1_max) : 0;
-    const int split2 = 2;
     const int grid1 = (int)std::min<int64_t>((int64_t)cus * 2, (nrows + PT_TILE - 1) / PT_TILE);
+    const int split2 = std::max(2, (grid1 + PT_MAX_REGIONS - 1) / PT_MAX_REGIONS);  // pass-2 workgroups per partition
     const int64_t tiles_per_wg = ((nrows + PT_TILE - 1) / PT_TILE + grid1 - 1) / grid1;
     const int64_t rows_per_wg = tiles_per_wg * PT_TILE;
     const int64_t cap1 = rows_per_wg / np1 + rows_per_wg / np1 / 5 + 512;
@@ -1136,8 +1181,6 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         p2.in_entries = e1; p2.in_counts = c1; p2.in_cap = cap1; p2.in_regions = grid1; p2.in_split = split2;
         p2.out_entries = e2; p2.out_counts = c2; p2.out_cap = cap2;
         p2.nparts = np2; p2.shift = 15; p2.flags = flags;  // hash bits [23:15] (pass 1 used [31:24])
-        // the regions of one input partition are split evenly over split2 workgroups
-        if (grid1 % split2 != 0) p2.in_split = 1;
         {
             KernelTimer timer("agg_part_scatter2", s);
             part_scatter_kernel<false><<<np1 * p2.in_split, PT_BLOCK, 0, s>>>(p2);
