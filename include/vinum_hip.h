@@ -65,8 +65,14 @@ enum vnm_expr_op {
     VNM_EX_CONST_I,   /* push int literal   (imm_i)                          */
     VNM_EX_ADD, VNM_EX_SUB, VNM_EX_MUL, VNM_EX_DIV, VNM_EX_MOD,   /* np.add .. np.mod         */
     VNM_EX_NEG,                                                    /* np.negative              */
-    VNM_EX_BAND, VNM_EX_BOR, VNM_EX_BXOR, VNM_EX_BNOT              /* np.bitwise_* and ~x      */
+    VNM_EX_BAND, VNM_EX_BOR, VNM_EX_BXOR, VNM_EX_BNOT,             /* np.bitwise_* and ~x      */
+    /* predicates (vinum/core/expressions.py:27-48): the result is a boolean mask */
+    VNM_EX_EQ, VNM_EX_NE, VNM_EX_GT, VNM_EX_GE, VNM_EX_LT, VNM_EX_LE, /* NumPy comparison lambdas :30-36 */
+    VNM_EX_AND, VNM_EX_OR, VNM_EX_NOT,                             /* pc.and_ / pc.or_ / pc.invert :27-29 */
+    VNM_EX_IS_NULL, VNM_EX_IS_NOT_NULL                             /* pc.is_null / pc.is_valid :37-38 (arg = column) */
 };
+/* out_type of vnm_project when the expression is a predicate: out_values is a byte mask (1 byte per row) */
+#define VNM_MASK_U8 100
 /* column flags */
 #define VNM_FLAG_SUM32 1 /* time32: SUM accumulates and wraps in int32 (agg_func_factory.cpp:132-137) */
 
@@ -210,7 +216,8 @@ typedef struct vnm_expr_ins {
     double imm_f;
     int64_t imm_i;
 } vnm_expr_ins;
-/* out_type: VNM_F64 or VNM_I64 (returned); out_values device buffer of length*8 bytes */
+/* out_type (returned): VNM_F64 / VNM_I64 with out_values = length*8 bytes, or VNM_MASK_U8 (predicate) with
+ * out_values = length bytes (BETWEEN / IN are compiled to AND / OR chains by the caller). */
 int vnm_project(int n_ins, const vnm_expr_ins* program, int n_cols, const vnm_dcol* cols, int64_t length,
                 void* out_values, int* out_type, void* stream);
 

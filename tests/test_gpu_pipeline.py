@@ -86,3 +86,38 @@ def test_config5_orderby_limit_projection():
     util.assert_col_equal(got.column("v").combine_chunks(), top.column(0), "v")
     for name, ref in [("e1", nv * 2 + 1), ("e2", nv - na), ("e3", na * nb)]:
         assert np.array_equal(got.column(name).to_numpy().view(np.uint64), ref.view(np.uint64)), name
+
+
+def test_where_expression_trees_match_numpy_and_arrow():
+    """General WHERE trees: comparisons between columns / literals, AND / OR / NOT,
+    IS [NOT] NULL, BETWEEN, IN -- evaluated exactly as the reference's callables do it (NumPy on NaN-converted
+    columns, vinum/core/expressions.py:27-48), then RecordBatch.filter."""
+    from vinum_amd.query import select
+    rng = np.random.default_rng(11)
+    n = 200_000
+    t = pa.table({
+        "a": pa.array(rng.integers(-50, 50, n).astype(np.int64), mask=rng.random(n) < 0.05),
+        "b": pa.array(rng.integers(-50, 50, n).astype(np.int64)),
+        "x": pa.array(np.round(rng.normal(0, 10, n), 1), mask=rng.random(n) < 0.05),
+        "id": pa.array(np.arange(n, dtype=np.int64)),
+    })
+    A = t.column("a").to_numpy(zero_copy_only=False)   # NULL -> NaN (record_batch.py:112-118)
+    B = t.column("b").to_numpy()
+    X = t.column("x").to_numpy(zero_copy_only=False)
+    a_null = np.array(t.column("a").is_null())
+    cases = [
+        (("and", ("gt", "a", 5), ("lt", "x", 3.5)), (A > 5) & (X < 3.5)),
+        (("or", ("ge", "a", "b"), ("is_null", "a")), (A >= B) | a_null),
+        (("not", ("eq", "b", 7)), ~(B == 7)),
+        (("between", "x", -2.5, 4), np.logical_and(X >= -2.5, X <= 4)),
+        (("not_between", "a", -10, 10), np.logical_or(A < -10, A > 10)),
+        (("in", "b", [1, 2, 3, 40]), np.isin(B, [1, 2, 3, 40])),
+        (("not_in", "a", [0, 1]), np.isin(A, [0, 1], invert=True)),
+        (("and", ("is_not_null", "x"), ("ne", ("add", "a", "b"), 0), ("gt", ("mul", "x", 2), "b")),
+         np.array(t.column("x").is_valid()) & ((A + B) != 0) & ((X * 2) > B)),
+    ]
+    for expr, mask in cases:
+        got = select(t, columns=["a", "b", "x", "id"], where=expr)
+        exp = t.filter(pa.array(mask))
+        util.assert_batches_equal(got.combine_chunks().to_batches()[0] if got.num_rows else got.to_batches()[0] if got.to_batches() else exp.slice(0, 0).combine_chunks().to_batches()[0],
+                                  exp.combine_chunks().to_batches()[0], what=str(expr))

@@ -35,7 +35,8 @@ ONE_GROUP, SINGLE_NUMERICAL, MULTI_NUMERICAL = range(3)
 ASC, DESC = 0, 1
 EQ, NE, GT, GE, LT, LE = range(6)
 (EX_COL, EX_CONST_F, EX_CONST_I, EX_ADD, EX_SUB, EX_MUL, EX_DIV, EX_MOD, EX_NEG, EX_BAND, EX_BOR, EX_BXOR,
- EX_BNOT) = range(13)
+ EX_BNOT, EX_EQ, EX_NE, EX_GT, EX_GE, EX_LT, EX_LE, EX_AND, EX_OR, EX_NOT, EX_IS_NULL, EX_IS_NOT_NULL) = range(24)
+MASK_U8 = 100
 OUT_U64, OUT_I64, OUT_F64, OUT_F32, OUT_DEC128, OUT_I32 = range(6)
 FLAG_SUM32 = 1
 

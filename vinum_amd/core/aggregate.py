@@ -31,7 +31,7 @@ class AggregateOperator(Operator):
         # Filter -> Aggregate fusion (planner.py:373-378 + 463-469 in one scan): a directly preceding
         # `column <op> literal` filter is folded into the aggregate kernel, no filtered batch is materialised
         self._fused_pred: Optional[Tuple[str, str, object]] = None
-        if isinstance(parent_operator, FilterOperator):
+        if isinstance(parent_operator, FilterOperator) and FilterOperator.is_simple(parent_operator.predicate):
             self._fused_pred = parent_operator.predicate
             parent_operator = parent_operator._parent_operator
         super().__init__(parent_operator)

@@ -49,10 +49,22 @@ class FilterOperator(Operator):
         super().__init__(parent_operator)
         self.predicate = predicate
 
+    @staticmethod
+    def is_simple(pred) -> bool:
+        """`column <op> literal`: the shape that runs fused (and can be folded into an aggregate scan)."""
+        return (isinstance(pred, tuple) and len(pred) == 3 and isinstance(pred[0], str) and pred[1] in ops.CMP_OPS
+                and isinstance(pred[2], (int, float)) and not isinstance(pred[2], bool))
+
     def _kernel(self, batch: DeviceRecordBatch) -> DeviceRecordBatch:
-        col, op, lit = self.predicate
         names = batch.column_names
-        outs, k = ops.filter_cmp(batch.column(col), op, lit, [batch.columns[n] for n in names])
+        cols = [batch.columns[n] for n in names]
+        if self.is_simple(self.predicate):
+            col, op, lit = self.predicate
+            outs, k = ops.filter_cmp(batch.column(col), op, lit, cols)
+        else:
+            # general boolean expression tree: one fused mask kernel, then one compaction pass
+            mask = ops.predicate_mask(self.predicate, batch.columns, batch.num_rows)
+            outs, k = ops.filter_mask(mask, None, batch.num_rows, cols)
         return DeviceRecordBatch(dict(zip(names, outs)), k)
 
 
@@ -81,16 +93,7 @@ class ProjectOperator(Operator):
 
 
 def _columns_of(expr) -> List[str]:
-    if isinstance(expr, str):
-        return [expr]
-    if isinstance(expr, tuple):
-        seen = []
-        for e in expr[1:]:
-            for c in _columns_of(e):
-                if c not in seen:
-                    seen.append(c)
-        return seen
-    return []
+    return ops.columns_of(expr)
 
 
 class SortOperator(Operator):

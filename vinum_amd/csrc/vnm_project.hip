@@ -35,6 +35,7 @@ struct ProjArgs {
     vnm_dcol cols[PJ_MAX_COLS];
     int64_t length;
     uint64_t* out;
+    uint8_t* out_mask;  // predicate programs write a byte mask instead
 };
 
 __device__ __forceinline__ double np_fmod(double a, double b) {
@@ -85,6 +86,26 @@ __global__ __launch_bounds__(PJ_BLOCK) void project_kernel(ProjArgs a) {
                     break;
                 }
                 case VNM_EX_BNOT: stack[sp - 1][tid] = ~stack[sp - 1][tid]; break;
+                case VNM_EX_NOT: stack[sp - 1][tid] = stack[sp - 1][tid] ^ 1ULL; break;
+                case VNM_EX_IS_NULL: stack[sp++][tid] = col_valid(a.cols[in.arg], row) ? 0ULL : 1ULL; break;
+                case VNM_EX_IS_NOT_NULL: stack[sp++][tid] = col_valid(a.cols[in.arg], row) ? 1ULL : 0ULL; break;
+                case VNM_EX_AND: { uint64_t xb = stack[--sp][tid]; stack[sp - 1][tid] &= xb; break; }
+                case VNM_EX_OR: { uint64_t xb = stack[--sp][tid]; stack[sp - 1][tid] |= xb; break; }
+                case VNM_EX_EQ: case VNM_EX_NE: case VNM_EX_GT: case VNM_EX_GE: case VNM_EX_LT: case VNM_EX_LE: {
+                    uint64_t xb = stack[--sp][tid];
+                    uint64_t xa = stack[sp - 1][tid];
+                    const int cop = in.op - VNM_EX_EQ;  // same order as enum vnm_cmp_op
+                    bool r;
+                    if (in.cvt_a || in.cvt_b || in.arg) {  // float comparison (arg = 1: both operands already float)
+                        double da = in.cvt_a ? (double)(int64_t)xa : __longlong_as_double((long long)xa);
+                        double db = in.cvt_b ? (double)(int64_t)xb : __longlong_as_double((long long)xb);
+                        r = cmp_apply<double>(cop, da, db);
+                    } else {
+                        r = cmp_apply<int64_t>(cop, (int64_t)xa, (int64_t)xb);
+                    }
+                    stack[sp - 1][tid] = r ? 1ULL : 0ULL;
+                    break;
+                }
                 default: {
                     uint64_t xb = stack[--sp][tid];
                     uint64_t xa = stack[sp - 1][tid];
@@ -117,7 +138,8 @@ __global__ __launch_bounds__(PJ_BLOCK) void project_kernel(ProjArgs a) {
                 }
             }
         }
-        a.out[row] = stack[0][tid];
+        if (a.out_mask) a.out_mask[row] = (uint8_t)stack[0][tid];
+        else a.out[row] = stack[0][tid];
     }
 }
 
@@ -144,8 +166,9 @@ int vnm_project(int n_ins, const vnm_expr_ins* program, int n_cols, const vnm_dc
         if (cols[c].length != length) return set_error("Select expressions have unequal sizes. This is not permitted.");
         a.cols[c] = cols[c];
     }
-    // abstract interpretation: type of every stack slot (NumPy result_type over {int64, float64})
-    bool isf[PJ_STACK];
+    // abstract interpretation: type of every stack slot (NumPy result_type over {int64, float64}; bool masks)
+    enum { T_I = 0, T_F = 1, T_B = 2 };
+    int ty[PJ_STACK];
     int sp = 0;
     for (int i = 0; i < n_ins; i++) {
         const vnm_expr_ins& in = program[i];
@@ -155,29 +178,60 @@ int vnm_project(int n_ins, const vnm_expr_ins* program, int n_cols, const vnm_dc
         o.imm_f = in.imm_f;
         o.imm_i = in.imm_i;
         o.cvt_a = o.cvt_b = 0;
+        o.is_f = 0;
         switch (in.op) {
             case VNM_EX_COL:
                 if (in.arg < 0 || in.arg >= n_cols) return set_error("vnm_project: column index %d out of range", in.arg);
                 if (sp >= PJ_STACK) return set_error("vnm_project: expression too deep");
                 o.is_f = (cols[in.arg].type == VNM_F64) || cols[in.arg].validity != nullptr;
-                isf[sp++] = o.is_f;
+                ty[sp++] = o.is_f ? T_F : T_I;
                 break;
             case VNM_EX_CONST_F:
             case VNM_EX_CONST_I:
                 if (sp >= PJ_STACK) return set_error("vnm_project: expression too deep");
                 o.is_f = in.op == VNM_EX_CONST_F;
-                isf[sp++] = o.is_f;
+                ty[sp++] = o.is_f ? T_F : T_I;
+                break;
+            case VNM_EX_IS_NULL:
+            case VNM_EX_IS_NOT_NULL:
+                if (in.arg < 0 || in.arg >= n_cols) return set_error("vnm_project: column index %d out of range", in.arg);
+                if (sp >= PJ_STACK) return set_error("vnm_project: expression too deep");
+                ty[sp++] = T_B;
                 break;
             case VNM_EX_NEG:
             case VNM_EX_BNOT:
                 if (sp < 1) return set_error("vnm_project: malformed program (stack underflow)");
-                if (in.op == VNM_EX_BNOT && isf[sp - 1]) return set_error("ufunc 'invert' not supported for float inputs");
-                o.is_f = isf[sp - 1];
+                if (ty[sp - 1] == T_B) return set_error("vnm_project: arithmetic on a boolean mask is not supported");
+                if (in.op == VNM_EX_BNOT && ty[sp - 1] == T_F) return set_error("ufunc 'invert' not supported for float inputs");
+                o.is_f = ty[sp - 1] == T_F;
                 break;
+            case VNM_EX_NOT:
+                if (sp < 1) return set_error("vnm_project: malformed program (stack underflow)");
+                if (ty[sp - 1] != T_B) return set_error("NOT expects a boolean operand");
+                break;
+            case VNM_EX_AND:
+            case VNM_EX_OR:
+                if (sp < 2) return set_error("vnm_project: malformed program (stack underflow)");
+                if (ty[sp - 1] != T_B || ty[sp - 2] != T_B) return set_error("AND / OR expect boolean operands");
+                sp--;
+                break;
+            case VNM_EX_EQ: case VNM_EX_NE: case VNM_EX_GT: case VNM_EX_GE: case VNM_EX_LT: case VNM_EX_LE: {
+                if (sp < 2) return set_error("vnm_project: malformed program (stack underflow)");
+                int tb = ty[sp - 1], ta = ty[sp - 2];
+                if (ta == T_B || tb == T_B) return set_error("vnm_project: comparing boolean masks is not supported");
+                bool anyf = ta == T_F || tb == T_F;  // NumPy compares in float64 as soon as one side is float
+                o.cvt_a = anyf && ta == T_I;
+                o.cvt_b = anyf && tb == T_I;
+                o.arg = anyf ? 1 : 0;
+                sp--;
+                ty[sp - 1] = T_B;
+                break;
+            }
             case VNM_EX_ADD: case VNM_EX_SUB: case VNM_EX_MUL: case VNM_EX_DIV: case VNM_EX_MOD:
             case VNM_EX_BAND: case VNM_EX_BOR: case VNM_EX_BXOR: {
                 if (sp < 2) return set_error("vnm_project: malformed program (stack underflow)");
-                bool fb = isf[sp - 1], fa = isf[sp - 2];
+                if (ty[sp - 1] == T_B || ty[sp - 2] == T_B) return set_error("vnm_project: arithmetic on a boolean mask is not supported");
+                bool fb = ty[sp - 1] == T_F, fa = ty[sp - 2] == T_F;
                 bool bitop = in.op >= VNM_EX_BAND;
                 if (bitop && (fa || fb)) return set_error("ufunc 'bitwise' not supported for float inputs");
                 bool rf = fa || fb || in.op == VNM_EX_DIV;
@@ -185,14 +239,15 @@ int vnm_project(int n_ins, const vnm_expr_ins* program, int n_cols, const vnm_dc
                 o.cvt_a = rf && !fa;
                 o.cvt_b = rf && !fb;
                 sp--;
-                isf[sp - 1] = rf;
+                ty[sp - 1] = rf ? T_F : T_I;
                 break;
             }
             default: return set_error("vnm_project: unknown opcode %d", in.op);
         }
     }
     if (sp != 1) return set_error("vnm_project: malformed program (final stack depth %d)", sp);
-    if (out_type) *out_type = isf[0] ? VNM_F64 : VNM_I64;
+    if (out_type) *out_type = ty[0] == T_B ? VNM_MASK_U8 : (ty[0] == T_F ? VNM_F64 : VNM_I64);
+    if (ty[0] == T_B) { a.out_mask = (uint8_t*)out_values; a.out = nullptr; }
     if (length <= 0) return 0;
     int grid = device_info().num_cus * 8;
     int64_t need = (length + PJ_BLOCK - 1) / PJ_BLOCK;

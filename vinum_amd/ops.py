@@ -245,7 +245,31 @@ def take(col: DeviceColumn, indices: DeviceBuffer, n, stream=None) -> DeviceColu
 # ---- projection ------------------------------------------------------------------------------------------
 _EX = {"add": L.EX_ADD, "sub": L.EX_SUB, "mul": L.EX_MUL, "div": L.EX_DIV, "mod": L.EX_MOD, "neg": L.EX_NEG,
        "band": L.EX_BAND, "bor": L.EX_BOR, "bxor": L.EX_BXOR, "bnot": L.EX_BNOT,
-       "+": L.EX_ADD, "-": L.EX_SUB, "*": L.EX_MUL, "/": L.EX_DIV, "%": L.EX_MOD}
+       "+": L.EX_ADD, "-": L.EX_SUB, "*": L.EX_MUL, "/": L.EX_DIV, "%": L.EX_MOD,
+       "eq": L.EX_EQ, "ne": L.EX_NE, "gt": L.EX_GT, "ge": L.EX_GE, "lt": L.EX_LT, "le": L.EX_LE,
+       "==": L.EX_EQ, "=": L.EX_EQ, "!=": L.EX_NE, "<>": L.EX_NE, ">": L.EX_GT, ">=": L.EX_GE, "<": L.EX_LT, "<=": L.EX_LE,
+       "and": L.EX_AND, "or": L.EX_OR, "not": L.EX_NOT}
+
+
+def _desugar(e):
+    """BETWEEN / IN rewrite onto the primitive predicates, exactly what the reference's callables compute:
+    between -> logical_and(x >= low, x <= high), not_between -> logical_or(x < low, x > high)
+    (vinum/core/expressions.py:43-48); in / not_in -> np.isin(x, values[, invert]) (:39-40)."""
+    if not isinstance(e, tuple):
+        return e
+    op, args = e[0], [_desugar(x) for x in e[1:]]
+    if op == "between":
+        return ("and", ("ge", args[0], args[1]), ("le", args[0], args[2]))
+    if op == "not_between":
+        return ("or", ("lt", args[0], args[1]), ("gt", args[0], args[2]))
+    if op in ("in", "not_in"):
+        vals = list(e[2])
+        if not vals:
+            raise ValueError("IN with an empty list")
+        if op == "in":
+            return ("or",) + tuple(("eq", args[0], v) for v in vals) if len(vals) > 1 else ("eq", args[0], vals[0])
+        return ("and",) + tuple(("ne", args[0], v) for v in vals) if len(vals) > 1 else ("ne", args[0], vals[0])
+    return (op,) + tuple(args)
 
 
 def compile_expr(expr, col_index):
@@ -263,10 +287,12 @@ def compile_expr(expr, col_index):
             out.append((L.EX_CONST_I, 0, 0.0, int(e)))
         elif isinstance(e, float):
             out.append((L.EX_CONST_F, 0, float(e), 0))
+        elif e[0] in ("is_null", "is_not_null"):
+            out.append((L.EX_IS_NULL if e[0] == "is_null" else L.EX_IS_NOT_NULL, col_index[e[1]], 0.0, 0))
         else:
             op = _EX[e[0]]
             args = e[1:]
-            if op in (L.EX_NEG, L.EX_BNOT):
+            if op in (L.EX_NEG, L.EX_BNOT, L.EX_NOT):
                 emit(args[0])
                 out.append((op, 0, 0.0, 0))
             else:
@@ -274,7 +300,7 @@ def compile_expr(expr, col_index):
                 for a in args[1:]:
                     emit(a)
                     out.append((op, 0, 0.0, 0))
-    emit(expr)
+    emit(_desugar(expr))
     prog = (L.ExprIns * len(out))()
     for i, (op, arg, f, k) in enumerate(out):
         prog[i].op, prog[i].arg, prog[i].imm_f, prog[i].imm_i = op, arg, f, k
@@ -293,5 +319,37 @@ def project(expr, columns: dict, length=None, stream=None) -> DeviceColumn:
     ot = ctypes.c_int(0)
     L.check(L.lib().vnm_project(len(prog), prog, len(cols), dcol_array(cols), length, out.ptr, ctypes.byref(ot),
                                 _stream_ptr(stream)))
+    if ot.value == L.MASK_U8:
+        return DeviceColumn(out, None, 0, length, pa.uint8())   # byte mask (predicate program)
     t = pa.float64() if ot.value == L.F64 else pa.int64()
     return DeviceColumn(out, None, 0, length, t)
+
+
+def columns_of(expr):
+    """Column names referenced by a (possibly sugared) expression, in first-use order."""
+    seen = []
+
+    def walk(e):
+        if isinstance(e, str):
+            if e not in seen:
+                seen.append(e)
+        elif isinstance(e, tuple):
+            if e[0] in ("is_null", "is_not_null"):
+                walk(e[1])
+            elif e[0] in ("in", "not_in"):
+                walk(e[1])
+            else:
+                for x in e[1:]:
+                    walk(x)
+    walk(expr)
+    return seen
+
+
+def predicate_mask(expr, columns: dict, length, stream=None) -> DeviceBuffer:
+    """Evaluate a boolean expression tree (comparisons, AND/OR/NOT, IS [NOT] NULL, BETWEEN, IN) into a
+    device byte mask -- the masks the reference builds with NumPy / pyarrow.compute one node at a time
+    (vinum/core/expressions.py:27-48).  NULL operands compare False (NaN), `!=` True."""
+    col = project(expr, {n: columns[n] for n in columns_of(expr)}, length=length, stream=stream)
+    if col.arrow_type != pa.uint8():
+        raise TypeError("WHERE expects a boolean expression")
+    return col._values

@@ -52,7 +52,10 @@ def _needed_columns(columns, where, group_by, aggregates, order_by):
         for x in ([c] if isinstance(c, str) else _columns_of(c[1])):
             add(x)
     if where:
-        add(where[0])
+        from .ops import columns_of
+        from .core.algebra import FilterOperator
+        for c in ([where[0]] if FilterOperator.is_simple(where) else columns_of(where)):
+            add(c)
     for c in group_by:
         add(c)
     for f in aggregates:
