@@ -21,7 +21,7 @@ namespace vnm {
 constexpr uint64_t EMPTY = ~0ULL;
 constexpr uint64_t LOCKED = ~0ULL - 1;
 constexpr int AGG_BLOCK = 1024;        // LDS kernel: 16 waves, one workgroup per CU
-constexpr int AGG_ROWS_PER_THREAD = 2;
+constexpr int AGG_ROWS_PER_THREAD = 8;
 constexpr int AGG_TILE = AGG_BLOCK * AGG_ROWS_PER_THREAD;
 constexpr int AGG_LDS_BUDGET = 128 * 1024;
 constexpr int AGG_MAX_PROBES = 48;
