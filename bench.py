@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--selectivity", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-hint", action="store_true", help="do not tell the operator the group count (it estimates it)")
     return ap.parse_args()
 
 
@@ -192,7 +193,8 @@ def main():
             state["out_rows"] = n
             return
         agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
-                                  [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())], expected_groups=groups)
+                                  [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
+                                  expected_groups=0 if args.no_hint else groups)
         agg.set_predicate(">", x_thr)
         agg.next([kcol], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
         ng = agg.finish(stream=stream)
@@ -243,7 +245,7 @@ def main():
         elapsed = float(t.item())
 
     names = {"filter": [b"filter_kernel"], "topk": [b"topk_select", b"radix_pass"], "project": [b"project_kernel"]}.get(
-        args.workload, [b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final"])
+        args.workload, [b"agg_estimate", b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final"])
     spans = {}
     for nm in names:
         tot_ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)

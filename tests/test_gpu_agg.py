@@ -165,3 +165,21 @@ def test_partitioned_path_wrong_hint_falls_back():
     for b in t.to_batches():
         o.next(b)
     util.assert_agg_equal(got, o.result(), funcs, ["k"], what="wrong hint")
+
+
+@pytest.mark.parametrize("groups", [50, 20_000, 400_000])
+def test_hintless_operator_estimates_cardinality(groups, monkeypatch):
+    """No expected_groups: the operator samples the first batch (scratch table, then HyperLogLog), picks the LDS
+    or the partitioned path itself, and still matches the oracle bit for bit."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "1000")
+    rng = np.random.default_rng(groups)
+    n = 800_000
+    t = pa.table({"k": pa.array(rng.integers(0, groups, n).astype(np.int64) * 31 + 5),
+                  "v": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0)})
+    funcs = [(O.SUM, "v", "sum_v"), (O.AVG, "v", "avg_v"), (O.COUNT_STAR, "", "n")]
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, t.to_batches(), predicate=("v", "<=", 100.0))
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in t.to_batches():
+        o.next(O.filter_batch(b, O.cmp_mask(b.column(1), O.LE, 100.0)))
+    util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"hintless G={groups}")

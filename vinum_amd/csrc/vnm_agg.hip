@@ -12,6 +12,7 @@
 // merge commutatively); only table flushes touch the HBM-resident table, with agent-scope atomics.
 // The fused WHERE predicate is evaluated in the scan, so no filtered batch is ever materialised.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "vnm_agg.hpp"
@@ -976,6 +977,42 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
     }
 }
 
+// Cardinality estimate for operators that were given no hint: insert a strided sample of the keys into a
+// scratch table (tags only) and count the distinct ones.  Solving d = G (1 - exp(-m / G)) for G (uniform
+// model) on the host then sizes the partitions; an underestimate only costs the fallback to the general path.
+__global__ void agg_sample_kernel(const uint64_t* keys, int64_t nrows, int64_t m, GTable g) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+        int64_t row = (int64_t)(((__int128)i * nrows) / m);
+        uint64_t key = keys[row];
+        if (key != EMPTY) gt_find_single(g, key);
+    }
+}
+
+// HyperLogLog over a strided sample (4096 registers, ~1.6 % error): LDS max per workgroup, then one
+// agent-scope max per register per workgroup.  Used for the large sample tier, where inserting every key into
+// a scratch table would cost tens of milliseconds of atomics.
+constexpr int HLL_BITS = 12;
+constexpr int HLL_M = 1 << HLL_BITS;
+__global__ __launch_bounds__(1024) void agg_hll_kernel(const uint64_t* keys, int64_t nrows, int64_t m, unsigned int* regs) {
+    __shared__ unsigned int lreg[HLL_M];
+    for (int i = threadIdx.x; i < HLL_M; i += blockDim.x) lreg[i] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+        int64_t row = (int64_t)(((__int128)i * nrows) / m);
+        uint64_t key = keys[row];
+        uint64_t h = ((uint64_t)hash_u64(key) << 32) | hash_u64(key * 0x9E3779B97F4A7C15ULL + 0x7F4A7C15ULL);
+        unsigned idx = (unsigned)(h & (HLL_M - 1));
+        uint64_t rest = h >> HLL_BITS;
+        unsigned rank = rest ? (unsigned)__clzll((long long)(rest << HLL_BITS)) + 1u : (unsigned)(64 - HLL_BITS + 1);
+        atomicMax(&lreg[idx], rank);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HLL_M; i += blockDim.x)
+        if (lreg[i]) atomicMax(&regs[i], lreg[i]);
+}
+
 __global__ void fill_u64_kernel(uint64_t* p, uint64_t v, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
@@ -1017,6 +1054,7 @@ struct vnm_agg {
     int64_t run_stride = 0, run_n = 0;
     bool have_run = false;
     bool result_is_run = false;
+    bool estimated = false;  // hint came from estimate_groups()
 };
 
 namespace {
@@ -1124,6 +1162,73 @@ void drop_run(vnm_agg* h) {
     h->run_n = h->run_stride = 0;
 }
 
+// distinct-key estimate from a strided sample (tiered: a small sample settles small G cheaply)
+int estimate_groups(vnm_agg* h, const vnm_dcol& key, int64_t nrows, int64_t* est, hipStream_t s) {
+    const uint64_t* kp = (const uint64_t*)key.values + key.offset;
+    int64_t sizes[2] = {std::min<int64_t>(nrows, 1 << 18), std::min<int64_t>(nrows, 1 << 24)};
+    *est = 0;
+    // tier 0: small sample into a scratch table (exact distinct count of the sample, ~50 us)
+    {
+        const int64_t m = sizes[0];
+        GTable t{};
+        t.cap = pow2_at_least((uint64_t)m * 2);
+        t.stride = t.cap + 2;
+        t.tag = (uint64_t*)pool_alloc(t.stride * 8);
+        t.ctl = (unsigned long long*)pool_alloc(64);
+        if (!t.tag || !t.ctl) return 1;
+        VNM_HIP(hipMemsetAsync(t.tag, 0xFF, t.stride * 8, s));
+        VNM_HIP(hipMemsetAsync(t.ctl, 0, 64, s));
+        int grid = (int)std::min<int64_t>((m + 255) / 256, (int64_t)device_info().num_cus * 8);
+        agg_sample_kernel<<<grid, 256, 0, s>>>(kp, nrows, m, t);
+        VNM_HIP(hipGetLastError());
+        unsigned long long d = 0;
+        VNM_HIP(hipMemcpyAsync(&d, t.ctl + 2, 8, hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipStreamSynchronize(s));
+        pool_free(t.tag);
+        pool_free(t.ctl);
+        if (d == 0) d = 1;
+        if ((double)d / (double)m < 0.125 || m == nrows) {  // the sample saw (nearly) every group
+            *est = (int64_t)((double)d * (m == nrows ? 1.0 : 1.15)) + 1;
+            return 0;
+        }
+    }
+    // tier 1: HyperLogLog over a 16 M-key sample, then the uniform model d = G (1 - exp(-m / G)) solved for G
+    {
+        const int64_t m = sizes[1];
+        unsigned int* regs = (unsigned int*)pool_alloc(HLL_M * 4);
+        if (!regs) return 1;
+        VNM_HIP(hipMemsetAsync(regs, 0, HLL_M * 4, s));
+        int grid = (int)std::min<int64_t>((m + 1023) / 1024, (int64_t)device_info().num_cus);
+        agg_hll_kernel<<<grid, 1024, 0, s>>>(kp, nrows, m, regs);
+        VNM_HIP(hipGetLastError());
+        std::vector<unsigned int> hr(HLL_M);
+        VNM_HIP(hipMemcpyAsync(hr.data(), regs, HLL_M * 4, hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipStreamSynchronize(s));
+        pool_free(regs);
+        double sum = 0;
+        int zeros = 0;
+        for (int i = 0; i < HLL_M; i++) { sum += ldexp(1.0, -(int)hr[i]); zeros += hr[i] == 0; }
+        const double alpha = 0.7213 / (1.0 + 1.079 / HLL_M);
+        double d = alpha * (double)HLL_M * (double)HLL_M / sum;
+        if (d <= 2.5 * HLL_M && zeros) d = (double)HLL_M * log((double)HLL_M / zeros);  // linear counting
+        if (d > (double)m) d = (double)m;
+        if (d < 1) d = 1;
+        const double frac = d / (double)m;
+        // solve d/m = (1 - exp(-x)) / x for x = m / G by bisection
+        double lo = 1e-9, hi = 64.0;
+        for (int it = 0; it < 80; it++) {
+            double x = 0.5 * (lo + hi);
+            double f = (1.0 - exp(-x)) / x;
+            if (f > frac) lo = x; else hi = x;
+        }
+        double G = (double)m / (0.5 * (lo + hi));
+        if (frac > 0.97) G = (double)m * 30.0;  // beyond the resolution of the sample: at least this many
+        if (G > (double)nrows) G = (double)nrows;
+        *est = (int64_t)(G * 1.2) + 1;
+    }
+    return 0;
+}
+
 // returns 0 = done (run stored), 2 = not applicable / overflowed (caller uses the general path), 1 = error
 int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s) {
     const int cus = device_info().num_cus;
@@ -1134,7 +1239,11 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     int64_t nfin = 2;
     while (nfin * per_final < h->hint) nfin *= 2;
     const int64_t l1_max = env_i64("VNM_AGG_PART_L1_MAX", 256);
-    if (nfin > l1_max * 512) return 2;  // would need a third level
+    if (nfin > l1_max * 512) {
+        // two levels give at most l1_max * 512 partitions: still fine while a partition's groups fit the LDS table
+        if (h->hint / (l1_max * 512) > 1600) return 2;  // would need a third level
+        nfin = l1_max * 512;
+    }
     const int levels = nfin > l1_max ? 2 : 1;
     const int np1 = levels == 2 ? (int)l1_max : (int)nfin;
     const int np2 = levels == 2 ? (int)(nfin / l1_max) : 0;
@@ -1372,6 +1481,17 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     if (hot && h->pred_set) {
         hot = a.pred.type == VNM_F64 && !a.pred.validity && (a.pred.offset & 1) == 0 && a.p.mode == CMP_F64;
         a.hot_pred_is_v = a.pred.values == a.cols[0].values && a.pred.offset == a.cols[0].offset;
+    }
+    // no hint from the caller: estimate the group count once from a sample of the first large batch
+    if (hot && h->hint == 0 && !h->estimated && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
+        getenv("VNM_AGG_NO_ESTIMATE") == nullptr) {
+        int64_t est = 0;
+        {
+            KernelTimer timer("agg_estimate", s);
+            VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s));
+        }
+        h->hint = est;
+        h->estimated = true;
     }
     // many groups: radix-partitioned path (no per-row HBM atomics); falls through when it does not apply
     if (hot && h->hint > env_i64("VNM_AGG_PART_MIN_GROUPS", 2400) && getenv("VNM_AGG_NO_PART") == nullptr) {
