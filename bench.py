@@ -122,6 +122,9 @@ class CudaArrayView:
 
 def main():
     args = parse()
+    # RCCL / HIP runtime banners are written to fd 1 by native code: keep the real stdout for the ONE JSON line
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -205,24 +208,34 @@ def main():
         state["agg"] = agg  # keep the last result alive for the sanity check; previous one is freed
 
     def exchange_and_merge(agg, ng):
-        """Key-partitioned exchange of partial groups (owner = hash(key words) mod P): ONE all_to_all over RCCL,
-        then the owner merges what it received (vinum_amd/distributed.py)."""
+        """Key-partitioned exchange of partial groups (owner = mix(key words) mod P): the run is bucketed by owner
+        on the device, ONE all_to_all over RCCL moves it, the owner merges what it received
+        (vinum_amd/distributed.py)."""
         from vinum_amd import distributed as D
-        kp, ap_ = agg.dense_ptrs()
-        words = [torch.as_tensor(CudaArrayView(p, ng), device=device) for p in kp + ap_]
+        kw, aw = agg.layout()
+        t_a = time.perf_counter()
+        send = torch.empty((max(ng, 1), kw + aw), dtype=torch.int64, device=device)
+        counts = agg.bucket_by_owner(world, send.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        t_b = time.perf_counter()
 
-        def merge(cols):
+        def merge(recv):
+            torch.cuda.synchronize()
+            t_c = time.perf_counter()
             merged = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
                                          [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
-                                         expected_groups=max(int(cols[0].numel()), 1024))
-            nk = len(kp)
-            merged.merge(int(cols[0].numel()), [c.data_ptr() for c in cols[:nk]], [c.data_ptr() for c in cols[nk:]],
-                         stream=stream)
+                                         expected_groups=max(int(recv.shape[0]), 1024))
+            merged.merge_rows(int(recv.shape[0]), recv.data_ptr(), stream=stream)
             out = merged.finish(stream=stream)
-            state["merged"] = (merged, cols)
+            torch.cuda.synchronize()
+            ph = state.setdefault("phases", {"bucket": 0.0, "all_to_all": 0.0, "merge": 0.0})
+            ph["bucket"] += (t_b - t_a) * 1e3
+            ph["all_to_all"] += (t_c - t_b) * 1e3
+            ph["merge"] += (time.perf_counter() - t_c) * 1e3
+            state["merged"] = (merged, recv)
             return out
 
-        return D.exchange_partials(words, len(kp), merge)
+        return D.exchange_bucketed(send[:ng], counts, merge)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -233,6 +246,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
+    state.pop("phases", None)
     lib.vnm_set_profiling(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -313,6 +327,8 @@ def main():
                          "kernels_ms": {k: round(v[0], 4) for k, v in spans.items()},
                          "algorithmic_bytes": alg_bytes,
                          "launches_per_step": cnt.value / max(args.steps, 1)},
+            "exchange_ms_per_step": ({k2: round(v2 / max(args.steps, 1), 3) for k2, v2 in state["phases"].items()}
+                                     if "phases" in state else None),
         }
         if world == 1 and not args.no_cpu_baseline and args.workload in ("groupby", "filter"):
             try:
@@ -325,9 +341,11 @@ def main():
     if world > 1 or force_exchange:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
     if result is not None:
-        sys.stdout.flush()
-        print(json.dumps(result), flush=True)   # the LAST line of stdout (RCCL prints banners of its own)
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    os.close(real_stdout)
+    os._exit(0)   # skip native atexit chatter; everything is flushed and the process group is destroyed
 
 
 if __name__ == "__main__":

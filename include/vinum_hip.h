@@ -153,9 +153,15 @@ int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream);
  * each a device array of n_groups uint64.  n_key_words / n_acc_words describe the layout. */
 int vnm_agg_layout(vnm_agg* h, int* n_key_words, int* n_acc_words);
 int vnm_agg_dense_ptrs(vnm_agg* h, uint64_t** key_words, uint64_t** acc_words);
+/* multi-GPU exchange helper: the finished dense run as rows [n_groups][n_key_words + n_acc_words] (device,
+ * row-major) grouped by owner rank, owner = mix(key words) mod world exactly as vinum_amd/distributed.py::owner_of;
+ * counts_host[world] receives the rows per owner. */
+int vnm_agg_bucket_by_owner(vnm_agg* h, int world, uint64_t* out_rows, int64_t* counts_host, void* stream);
 /* merge dense partial states produced by another handle with the same spec (device pointers) */
 int vnm_agg_merge_device(vnm_agg* h, int64_t n, uint64_t* const* key_words, uint64_t* const* acc_words,
                          void* stream);
+/* merge row-major partial groups [n][n_key_words + n_acc_words] (layout of vnm_agg_bucket_by_owner) */
+int vnm_agg_merge_rows(vnm_agg* h, int64_t n, const uint64_t* rows, void* stream);
 /* BaseAggregate::Result part 2 (+ agg funcs' Summarize, agg_funcs.h:72-80,358-397,482-491,519-540):
  * D2H + host finalisation.  key j -> vals[n] raw 64-bit patterns + valid[n] bytes.
  * func i -> cells of 16 bytes (decimal128 uses all 16), valid bytes; returns the output kind. */

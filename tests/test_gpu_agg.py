@@ -183,3 +183,46 @@ def test_hintless_operator_estimates_cardinality(groups, monkeypatch):
     for b in t.to_batches():
         o.next(O.filter_batch(b, O.cmp_mask(b.column(1), O.LE, 100.0)))
     util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"hintless G={groups}")
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_bucket_by_owner_and_merge_rows_roundtrip(world):
+    """Multi-GPU building blocks on one GPU: the device bucketing must agree with distributed.owner_of, and
+    merging every bucket back (what the owners do after the all_to_all) must reproduce the aggregate."""
+    import torch
+    from oracle import oracle as O
+    from vinum_amd import distributed as D
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    rng = np.random.default_rng(world)
+    n = 300_000
+    k = rng.integers(-20_000, 20_000, n).astype(np.int64)
+    v = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
+    kt, vt = torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda()
+    spec = [(O.SUM, 1, pa.float64()), (O.COUNT_STAR, None, None)]
+    agg = ops.DeviceAggregate(O.SINGLE, [pa.int64()], spec)
+    agg.next([DeviceColumn.from_torch(kt)], [DeviceColumn.from_torch(vt), None], nrows=n)
+    ng = agg.finish()
+    kw, aw = agg.layout()
+    rows = torch.empty((ng, kw + aw), dtype=torch.int64, device="cuda")
+    counts = agg.bucket_by_owner(world, rows.data_ptr())
+    assert sum(counts) == ng
+    own = D.owner_of([rows[:, j] for j in range(kw)], world).cpu()
+    assert torch.equal(own, torch.repeat_interleave(torch.arange(world), torch.tensor(counts)))
+    total = {}
+    start = 0
+    for o in range(world):                       # each owner merges its bucket into a fresh operator
+        part = rows[start:start + counts[o]].contiguous()
+        start += counts[o]
+        m = ops.DeviceAggregate(O.SINGLE, [pa.int64()], spec)
+        m.merge_rows(part.shape[0], part.data_ptr())
+        res = m.result_arrays([0], ["k"], ["s", "n"])
+        for kk, ss, nn in zip(res.column(0).to_pylist(), res.column(1).to_pylist(), res.column(2).to_pylist()):
+            assert kk not in total
+            total[kk] = (ss, nn)
+    uk, inv = np.unique(k, return_inverse=True)
+    exp_s = np.bincount(inv, weights=v)
+    exp_n = np.bincount(inv)
+    assert len(total) == len(uk)
+    for i, kk in enumerate(uk.tolist()):
+        assert total[kk] == (exp_s[i], exp_n[i])

@@ -60,7 +60,9 @@ PROTOTYPES = {
     "vnm_agg_finish": (c_int, [c_void, c_void, c_void]),
     "vnm_agg_layout": (c_int, [c_void, c_void, c_void]),
     "vnm_agg_dense_ptrs": (c_int, [c_void, c_void, c_void]),
+    "vnm_agg_bucket_by_owner": (c_int, [c_void, c_int, c_void, c_void, c_void]),
     "vnm_agg_merge_device": (c_int, [c_void, c_i64, c_void, c_void, c_void]),
+    "vnm_agg_merge_rows": (c_int, [c_void, c_i64, c_void, c_void]),
     "vnm_agg_result_key": (c_int, [c_void, c_int, c_void, c_void]),
     "vnm_agg_result_func": (c_int, [c_void, c_int, c_void, c_void, c_void]),
     "vnm_agg_plan_host": (c_int, [c_int, c_int, c_void, c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_void,

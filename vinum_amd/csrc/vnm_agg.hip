@@ -86,7 +86,9 @@ __device__ __forceinline__ void l_merge(uint64_t* p, int mk, uint64_t v) {
 }
 
 // single 64-bit key: the tag word IS the key; claim by CAS from EMPTY
-__device__ __forceinline__ uint64_t gt_find_single(const GTable& g, uint64_t key) {
+// New groups are counted into a block-local LDS counter (*newc) and folded into the table's fill word once per
+// tile: one agent-scope atomic per NEW GROUP on a single word capped merges at ~1 group/ns (122 ms per 1e8).
+__device__ __forceinline__ uint64_t gt_find_single(const GTable& g, uint64_t key, unsigned* newc) {
     const uint64_t mask = g.cap - 1;
     uint64_t h = hash_u64(key) & mask;
     for (uint64_t probes = 0;; probes++) {
@@ -100,7 +102,7 @@ __device__ __forceinline__ uint64_t gt_find_single(const GTable& g, uint64_t key
             uint64_t expected = EMPTY;
             if (__hip_atomic_compare_exchange_strong(&g.tag[h], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_AGENT)) {
-                atomicAdd(&g.ctl[2], 1ULL);
+                atomicAdd(newc, 1u);
                 return h;
             }
             if (expected == key) return h;
@@ -121,7 +123,7 @@ __device__ __forceinline__ uint64_t wide_tag(const uint64_t* kw, int n) {
 // wide keys: tag = 63-bit hash; EMPTY -> LOCKED -> tag.  The claimer publishes the key words with
 // write-through agent-scope stores, drains them, then publishes the tag (no lane ever waits inside the
 // critical section, so same-wave spinners cannot deadlock).
-__device__ __forceinline__ uint64_t gt_find_wide(const GTable& g, const uint64_t* kw, uint64_t tagv) {
+__device__ __forceinline__ uint64_t gt_find_wide(const GTable& g, const uint64_t* kw, uint64_t tagv, unsigned* newc) {
     const uint64_t mask = g.cap - 1;
     uint64_t h = (tagv ^ (tagv >> 29)) & mask;
     for (;;) {
@@ -140,7 +142,7 @@ __device__ __forceinline__ uint64_t gt_find_wide(const GTable& g, const uint64_t
                 for (int i = 0; i < g.kwt; i++) st_agent(&g.keyw[(uint64_t)i * g.stride + h], kw[i]);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 st_agent(&g.tag[h], tagv);
-                atomicAdd(&g.ctl[2], 1ULL);
+                atomicAdd(newc, 1u);
                 return h;
             }
             continue;  // someone else is claiming this slot: look at it again
@@ -148,6 +150,12 @@ __device__ __forceinline__ uint64_t gt_find_wide(const GTable& g, const uint64_t
         if (t == LOCKED) continue;
         h = (h + 1) & mask;
     }
+}
+
+// one thread per block folds the block's new-group count into the table's fill word
+__device__ __forceinline__ void fold_new(const GTable& g, unsigned* s_new) {
+    unsigned v = atomicExch(s_new, 0u);
+    if (v) atomicAdd(&g.ctl[2], (unsigned long long)v);
 }
 
 // ---- per-row accumulator contributions ----------------------------------------------------------------
@@ -176,7 +184,8 @@ __device__ __forceinline__ bool op_value(const AccOp& op, const vnm_dcol* cols, 
 // each tile the block checks that the HBM table has room for everything that can be in flight; if not it
 // raises the overflow flag, parks its loop index in progress[block] and exits so the host can grow the
 // table and relaunch the same grid from where every block stopped.
-__device__ __forceinline__ bool table_has_room(const AggArgs& a) {
+__device__ __forceinline__ bool table_has_room(const AggArgs& a, unsigned* s_new) {
+    fold_new(a.g, s_new);
     unsigned long long fill = __hip_atomic_load(&a.g.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((int64_t)fill + a.margin > a.fill_limit) {
         __hip_atomic_store(&a.g.ctl[1], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -189,14 +198,14 @@ __device__ __forceinline__ bool table_has_room(const AggArgs& a) {
 // Kernel 1: single 64-bit key, LDS pre-aggregation, generic accumulator program.
 // LDS: lkey[S+2] then lacc[w][S+2].  Slot S = key equal to the EMPTY sentinel, slot S+1 = NULL key.
 // =======================================================================================================
-__device__ __forceinline__ void lds_flush(const AggArgs& a, uint64_t* lkey, uint64_t* lacc, int S, int tid, int nthreads) {
+__device__ __forceinline__ void lds_flush(const AggArgs& a, uint64_t* lkey, uint64_t* lacc, int S, int tid, int nthreads, unsigned* s_new) {
     const int stride = S + 2;
     const int W = a.plan.n_words;
     for (int i = tid; i < stride; i += nthreads) {
         uint64_t k = lkey[i];
         if (k == EMPTY) continue;
         uint64_t slot;
-        if (i < S) slot = gt_find_single(a.g, k);
+        if (i < S) slot = gt_find_single(a.g, k, s_new);
         else {
             slot = a.g.cap + (uint64_t)(i - S);
             if (ld_agent(&a.g.tag[slot]) == EMPTY) st_agent(&a.g.tag[slot], 0);
@@ -213,7 +222,7 @@ __device__ __forceinline__ void lds_flush(const AggArgs& a, uint64_t* lkey, uint
 
 __global__ __launch_bounds__(AGG_BLOCK) void agg_lds_kernel(AggArgs a) {
     extern __shared__ uint64_t lds[];
-    __shared__ unsigned s_fill;
+    __shared__ unsigned s_fill, s_new;
     __shared__ int64_t s_tile;
     const int S = a.lds_slots;
     const int stride = S + 2;
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_lds_kernel(AggArgs a) {
         uint64_t init = merge_init(a.plan.merge[w]);
         for (int i = tid; i < stride; i += AGG_BLOCK) lacc[w * stride + i] = init;
     }
-    if (tid == 0) s_fill = 0;
+    if (tid == 0) { s_fill = 0; s_new = 0; }
     __syncthreads();
 
     const unsigned flush_at = (unsigned)(S * 7 / 10);
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_lds_kernel(AggArgs a) {
     for (;; it++) {
         const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
         if (tile >= a.ntiles) break;
-        if (tid == 0) s_tile = table_has_room(a) ? 1 : 0;
+        if (tid == 0) s_tile = table_has_room(a, &s_new) ? 1 : 0;
         __syncthreads();
         if (!s_tile) break;
 #pragma unroll
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_lds_kernel(AggArgs a) {
                 }
             } else {
                 // LDS table saturated for this key: go straight to the HBM table
-                uint64_t gs = gt_find_single(a.g, key);
+                uint64_t gs = gt_find_single(a.g, key, &s_new);
                 for (int o = 0; o < a.plan.n_ops; o++) {
                     const AccOp& op = a.plan.ops[o];
                     uint64_t v;
@@ -292,13 +301,14 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_lds_kernel(AggArgs a) {
         }
         __syncthreads();
         if (s_fill > flush_at) {
-            lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK);
+            lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK, &s_new);
             __syncthreads();
             if (tid == 0) s_fill = 0;
         }
     }
-    lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK);
-    if (tid == 0) a.progress[blockIdx.x] = it;
+    lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK, &s_new);
+    __syncthreads();
+    if (tid == 0) { fold_new(a.g, &s_new); a.progress[blockIdx.x] = it; }
 }
 
 // =======================================================================================================
@@ -313,7 +323,7 @@ constexpr int HOT_UNROLL = 4;
 constexpr int HOT_TILE = AGG_BLOCK * 2 * HOT_UNROLL;  // 8192 rows per block iteration
 
 __device__ __forceinline__ void hot_row(const AggArgs& a, uint64_t* lkey, uint64_t* lacc, int S, int stride, uint32_t smask,
-                                        unsigned* s_fill, uint64_t key, double v) {
+                                        unsigned* s_fill, unsigned* s_new, uint64_t key, double v) {
     int slot = -1;
     if (key == EMPTY) {
         slot = S;
@@ -341,7 +351,7 @@ __device__ __forceinline__ void hot_row(const AggArgs& a, uint64_t* lkey, uint64
         if (a.hot_w_valid >= 0) __hip_atomic_fetch_add(&lacc[a.hot_w_valid * stride + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (a.hot_w_sum >= 0) __hip_atomic_fetch_add((double*)&lacc[a.hot_w_sum * stride + slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
-        uint64_t gs = gt_find_single(a.g, key);
+        uint64_t gs = gt_find_single(a.g, key, s_new);
         if (a.hot_w_rows >= 0) g_merge(&a.g.acc[(uint64_t)a.hot_w_rows * a.g.stride + gs], M_ADD_U64, 1);
         if (a.hot_w_valid >= 0) g_merge(&a.g.acc[(uint64_t)a.hot_w_valid * a.g.stride + gs], M_ADD_U64, 1);
         if (a.hot_w_sum >= 0) g_merge(&a.g.acc[(uint64_t)a.hot_w_sum * a.g.stride + gs], M_ADD_F64, (uint64_t)__double_as_longlong(v));
@@ -351,7 +361,7 @@ __device__ __forceinline__ void hot_row(const AggArgs& a, uint64_t* lkey, uint64
 template <bool HAS_PRED, bool PRED_IS_V>
 __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
     extern __shared__ uint64_t lds[];
-    __shared__ unsigned s_fill;
+    __shared__ unsigned s_fill, s_new;
     __shared__ int s_go;
     const int S = a.lds_slots;
     const int stride = S + 2;
@@ -365,7 +375,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
         uint64_t init = merge_init(a.plan.merge[w]);
         for (int i = tid; i < stride; i += AGG_BLOCK) lacc[w * stride + i] = init;
     }
-    if (tid == 0) s_fill = 0;
+    if (tid == 0) { s_fill = 0; s_new = 0; }
     __syncthreads();
 
     const unsigned flush_at = (unsigned)(S * 6 / 10);
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
     for (;; it++) {
         const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
         if (tile >= a.ntiles) break;
-        if (tid == 0) s_go = table_has_room(a) ? 1 : 0;
+        if (tid == 0) s_go = table_has_room(a, &s_new) ? 1 : 0;
         __syncthreads();
         if (!s_go) break;
         const int64_t base = tile * HOT_TILE + 2 * tid;
@@ -397,8 +407,8 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
 #pragma unroll
             for (int u = 0; u < HOT_UNROLL; u++) {
                 double p0 = PRED_IS_V ? vv[u].x : pv[u].x, p1 = PRED_IS_V ? vv[u].y : pv[u].y;
-                if (!HAS_PRED || cmp_apply<double>(op, p0, thr)) hot_row(a, lkey, lacc, S, stride, smask, &s_fill, kk[u].x, vv[u].x);
-                if (!HAS_PRED || cmp_apply<double>(op, p1, thr)) hot_row(a, lkey, lacc, S, stride, smask, &s_fill, kk[u].y, vv[u].y);
+                if (!HAS_PRED || cmp_apply<double>(op, p0, thr)) hot_row(a, lkey, lacc, S, stride, smask, &s_fill, &s_new, kk[u].x, vv[u].x);
+                if (!HAS_PRED || cmp_apply<double>(op, p1, thr)) hot_row(a, lkey, lacc, S, stride, smask, &s_fill, &s_new, kk[u].y, vv[u].y);
             }
         } else {
             for (int u = 0; u < HOT_UNROLL; u++)
@@ -406,18 +416,19 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                     int64_t r = base + (int64_t)u * 2 * AGG_BLOCK + e;
                     if (r >= a.nrows) continue;
                     double p = PRED_IS_V ? vp[r] : (HAS_PRED ? pp[r] : 0.0);
-                    if (!HAS_PRED || cmp_apply<double>(op, p, thr)) hot_row(a, lkey, lacc, S, stride, smask, &s_fill, kp[r], vp[r]);
+                    if (!HAS_PRED || cmp_apply<double>(op, p, thr)) hot_row(a, lkey, lacc, S, stride, smask, &s_fill, &s_new, kp[r], vp[r]);
                 }
         }
         __syncthreads();
         if (s_fill > flush_at) {
-            lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK);
+            lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK, &s_new);
             __syncthreads();
             if (tid == 0) s_fill = 0;
         }
     }
-    lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK);
-    if (tid == 0) a.progress[blockIdx.x] = it;
+    lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK, &s_new);
+    __syncthreads();
+    if (tid == 0) { fold_new(a.g, &s_new); a.progress[blockIdx.x] = it; }
 }
 
 // =======================================================================================================
@@ -426,6 +437,9 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
 // =======================================================================================================
 __global__ __launch_bounds__(256) void agg_wide_kernel(AggArgs a) {
     __shared__ int64_t s_tile;
+    __shared__ unsigned s_new;
+    if (threadIdx.x == 0) s_new = 0;
+    __syncthreads();
     const int tid = threadIdx.x;
     const int nk = a.plan.n_keys;
     unsigned it = a.progress[blockIdx.x];
@@ -433,7 +447,7 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggArgs a) {
         const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
         if (tile >= a.ntiles) break;
         __syncthreads();
-        if (tid == 0) s_tile = table_has_room(a) ? 1 : 0;
+        if (tid == 0) s_tile = table_has_room(a, &s_new) ? 1 : 0;
         __syncthreads();
         if (!s_tile) break;
         for (int r = 0; r < AGG_TILE / 256; r++) {
@@ -451,7 +465,7 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggArgs a) {
                 }
             }
             kw[nk] = nullmask;
-            uint64_t gs = gt_find_wide(a.g, kw, wide_tag(kw, nk + 1));
+            uint64_t gs = gt_find_wide(a.g, kw, wide_tag(kw, nk + 1), &s_new);
             for (int o = 0; o < a.plan.n_ops; o++) {
                 const AccOp& op = a.plan.ops[o];
                 uint64_t v;
@@ -459,7 +473,8 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggArgs a) {
             }
         }
     }
-    if (tid == 0) a.progress[blockIdx.x] = it;
+    __syncthreads();
+    if (tid == 0) { fold_new(a.g, &s_new); a.progress[blockIdx.x] = it; }
 }
 
 // =======================================================================================================
@@ -520,9 +535,13 @@ struct MergeArgs {
     const uint64_t* src_acc[AGG_MAX_WORDS];
     int src_is_table;
     int64_t src_cap;  // table source: entries [src_cap], [src_cap+1] are the special groups
+    int64_t src_stride;  // element stride of the dense source arrays (1 = SoA, n_words = row-major rows)
 };
 
 __global__ __launch_bounds__(256) void agg_merge_kernel(MergeArgs m) {
+    __shared__ unsigned s_new;
+    if (threadIdx.x == 0) s_new = 0;
+    __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const bool single = m.g.kwt == 0;
     const int nk = m.plan.n_keys;
@@ -535,32 +554,34 @@ __global__ __launch_bounds__(256) void agg_merge_kernel(MergeArgs m) {
                 if (i >= m.src_cap) {
                     slot = m.g.cap + (uint64_t)(i - m.src_cap);
                     if (ld_agent(&m.g.tag[slot]) == EMPTY) st_agent(&m.g.tag[slot], 0);
-                } else slot = gt_find_single(m.g, t);
+                } else slot = gt_find_single(m.g, t, &s_new);
             } else {
                 uint64_t kw[AGG_MAX_KEYS + 1];
 #pragma unroll
                 for (int j = 0; j <= AGG_MAX_KEYS; j++) if (j <= nk) kw[j] = m.src_key[j][i];
-                slot = gt_find_wide(m.g, kw, t);
+                slot = gt_find_wide(m.g, kw, t, &s_new);
             }
         } else if (nk == 0) {
             slot = 0;
         } else if (single) {
-            uint64_t key = m.src_key[0][i], nullmask = m.src_key[1][i];
+            uint64_t key = m.src_key[0][i * m.src_stride], nullmask = m.src_key[1][i * m.src_stride];
             if (nullmask) { slot = m.g.cap + 1; if (ld_agent(&m.g.tag[slot]) == EMPTY) st_agent(&m.g.tag[slot], 0); }
             else if (key == EMPTY) { slot = m.g.cap; if (ld_agent(&m.g.tag[slot]) == EMPTY) st_agent(&m.g.tag[slot], 0); }
-            else slot = gt_find_single(m.g, key);
+            else slot = gt_find_single(m.g, key, &s_new);
         } else {
             uint64_t kw[AGG_MAX_KEYS + 1];
 #pragma unroll
-            for (int j = 0; j <= AGG_MAX_KEYS; j++) if (j <= nk) kw[j] = m.src_key[j][i];
-            slot = gt_find_wide(m.g, kw, wide_tag(kw, nk + 1));
+            for (int j = 0; j <= AGG_MAX_KEYS; j++) if (j <= nk) kw[j] = m.src_key[j][i * m.src_stride];
+            slot = gt_find_wide(m.g, kw, wide_tag(kw, nk + 1), &s_new);
         }
         for (int w = 0; w < m.plan.n_words; w++) {
-            uint64_t v = m.src_acc[w][i];
+            uint64_t v = m.src_acc[w][i * (m.src_is_table ? 1 : m.src_stride)];
             int mk = m.plan.merge[w];
             if (v != merge_init(mk)) g_merge(&m.g.acc[(uint64_t)w * m.g.stride + slot], mk, v);
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) fold_new(m.g, &s_new);
 }
 
 // =======================================================================================================
@@ -864,9 +885,11 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
     __shared__ uint64_t lsum[PA_SLOTS + 1];
     __shared__ uint32_t lcnt[PA_SLOTS + 1];
     __shared__ uint32_t s_n, s_fail;
+    __shared__ unsigned s_new;
     __shared__ unsigned long long s_base;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t smask = PA_SLOTS - 1;
+    if (tid == 0) s_new = 0;
     for (int64_t unit = blockIdx.x; unit < a.nfinal * a.splits; unit += gridDim.x) {
         const int64_t f = unit / a.splits;
         const int part = (int)(unit % a.splits);
@@ -927,6 +950,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
         if (a.to_table) {
             // merge this workgroup's table into the HBM table (G * splits * words atomics in total: small)
             if (tid == 0) {
+                fold_new(a.g, &s_new);
                 unsigned long long fill = __hip_atomic_load(&a.g.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((int64_t)(fill + s_n) > a.table_limit) s_fail = 1;
             }
@@ -939,13 +963,14 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
                 uint64_t k = lkey[i];
                 if (k == EMPTY) continue;
                 uint64_t slot;
-                if (i < PA_SLOTS) slot = gt_find_single(a.g, k);
+                if (i < PA_SLOTS) slot = gt_find_single(a.g, k, &s_new);
                 else { slot = a.g.cap; if (ld_agent(&a.g.tag[slot]) == EMPTY) st_agent(&a.g.tag[slot], 0); }
                 if (a.w_rows >= 0) g_merge(&a.g.acc[(uint64_t)a.w_rows * a.g.stride + slot], M_ADD_U64, lcnt[i]);
                 if (a.w_valid >= 0) g_merge(&a.g.acc[(uint64_t)a.w_valid * a.g.stride + slot], M_ADD_U64, lcnt[i]);
                 if (a.w_sum >= 0) g_merge(&a.g.acc[(uint64_t)a.w_sum * a.g.stride + slot], M_ADD_F64, lsum[i]);
             }
             __syncthreads();
+            if (tid == 0) fold_new(a.g, &s_new);
             continue;
         }
         // compact: reserve a dense range for this partition's groups, then write them
@@ -981,12 +1006,17 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
 // scratch table (tags only) and count the distinct ones.  Solving d = G (1 - exp(-m / G)) for G (uniform
 // model) on the host then sizes the partitions; an underestimate only costs the fallback to the general path.
 __global__ void agg_sample_kernel(const uint64_t* keys, int64_t nrows, int64_t m, GTable g) {
+    __shared__ unsigned s_new;
+    if (threadIdx.x == 0) s_new = 0;
+    __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
         int64_t row = (int64_t)(((__int128)i * nrows) / m);
         uint64_t key = keys[row];
-        if (key != EMPTY) gt_find_single(g, key);
+        if (key != EMPTY) gt_find_single(g, key, &s_new);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) fold_new(g, &s_new);
 }
 
 // HyperLogLog over a strided sample (4096 registers, ~1.6 % error): LDS max per workgroup, then one
@@ -1011,6 +1041,105 @@ __global__ __launch_bounds__(1024) void agg_hll_kernel(const uint64_t* keys, int
     __syncthreads();
     for (int i = threadIdx.x; i < HLL_M; i += blockDim.x)
         if (lreg[i]) atomicMax(&regs[i], lreg[i]);
+}
+
+// ---- multi-GPU: bucket the dense run by owner rank -------------------------------------------------------
+// owner(key words) must equal vinum_amd/distributed.py::owner_of (int64 wrap-around arithmetic).
+__device__ __forceinline__ int owner_of_words(const uint64_t* const* kw, int nkw, int64_t i, int world) {
+    int64_t hh = 0;
+    for (int j = 0; j < nkw; j++) {
+        hh = (int64_t)(((uint64_t)hh ^ kw[j][i]) * 0x9E3779B97F4A7C15ULL);
+        hh ^= (hh >> 29);  // arithmetic shift, like torch's int64 >>
+    }
+    return (int)(((hh >> 17) & 0x7FFFFFFF) % world);
+}
+
+struct BucketArgs {
+    const uint64_t* words[AGG_MAX_KEYS + 1 + AGG_MAX_WORDS];
+    int nkw, nw;      // key words, total words
+    int64_t n, per;   // rows, rows per block (block b owns the contiguous rows [b*per, (b+1)*per))
+    int world, nb;
+    unsigned long long* blk;       // [world][nb] per-block counts (pass 0) -> exclusive offsets (after the scan)
+    unsigned long long* totals;    // [world]
+    uint64_t* out;                 // [n][nw] row-major, grouped by owner
+};
+
+// A stable, atomic-free partition by owner (a one-digit radix scatter): per-block counts, one scan, then every
+// block re-reads its rows and places them with ballot ranks.  (A shared cursor per owner serialises on one
+// atomic word: 37 ms per 1e8 groups.)
+constexpr int BK_MAX_WORLD = 64;
+
+__global__ __launch_bounds__(256) void agg_bucket_count_kernel(BucketArgs b) {
+    __shared__ unsigned cnt[BK_MAX_WORLD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < BK_MAX_WORLD) cnt[tid] = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * b.per, hi = lo + b.per < b.n ? lo + b.per : b.n;
+    for (int64_t base = lo; base < hi; base += 256) {
+        const int64_t i = base + tid;
+        const int own = i < hi ? owner_of_words(b.words, b.nkw, i, b.world) : -1;
+        for (int o = 0; o < b.world; o++) {
+            uint64_t m = __ballot(own == o);
+            if (m && lane == 0) atomicAdd(&cnt[o], (unsigned)__popcll(m));
+        }
+    }
+    __syncthreads();
+    if (tid < b.world) b.blk[(int64_t)tid * b.nb + blockIdx.x] = cnt[tid];
+}
+
+__global__ void agg_bucket_scan_kernel(BucketArgs b) {
+    __shared__ unsigned long long tot[BK_MAX_WORLD];
+    const int o = threadIdx.x;
+    if (o < b.world) {
+        unsigned long long s = 0;
+        for (int k = 0; k < b.nb; k++) s += b.blk[(int64_t)o * b.nb + k];
+        tot[o] = s;
+        b.totals[o] = s;
+    }
+    __syncthreads();
+    if (o < b.world) {
+        unsigned long long run = 0;
+        for (int k = 0; k < o; k++) run += tot[k];
+        for (int k = 0; k < b.nb; k++) {
+            unsigned long long c = b.blk[(int64_t)o * b.nb + k];
+            b.blk[(int64_t)o * b.nb + k] = run;
+            run += c;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void agg_bucket_scatter_kernel(BucketArgs b) {
+    __shared__ unsigned long long run[BK_MAX_WORLD];
+    __shared__ unsigned wcount[4][BK_MAX_WORLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < b.world) run[tid] = b.blk[(int64_t)tid * b.nb + blockIdx.x];
+    for (int i = tid; i < 4 * BK_MAX_WORLD; i += 256) (&wcount[0][0])[i] = 0;
+    __syncthreads();
+    const uint64_t lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+    const int64_t lo = (int64_t)blockIdx.x * b.per, hi = lo + b.per < b.n ? lo + b.per : b.n;
+    for (int64_t base = lo; base < hi; base += 256) {
+        const int64_t i = base + tid;
+        const int own = i < hi ? owner_of_words(b.words, b.nkw, i, b.world) : -1;
+        unsigned rank = 0;
+        for (int o = 0; o < b.world; o++) {
+            uint64_t m = __ballot(own == o);
+            if (own == o) rank = __popcll(m & lt);
+            if (m && lane == 0) wcount[wave][o] = (unsigned)__popcll(m);
+        }
+        __syncthreads();
+        if (own >= 0) {
+            unsigned long long pos = run[own] + rank;
+            for (int w = 0; w < wave; w++) pos += wcount[w][own];
+            for (int w = 0; w < b.nw; w++) b.out[pos * b.nw + w] = b.words[w][i];
+        }
+        __syncthreads();
+        if (tid < b.world) {
+            unsigned s = 0;
+            for (int w = 0; w < 4; w++) { s += wcount[w][tid]; wcount[w][tid] = 0; }
+            run[tid] += s;
+        }
+        __syncthreads();
+    }
 }
 
 __global__ void fill_u64_kernel(uint64_t* p, uint64_t v, int64_t n) {
@@ -1055,6 +1184,7 @@ struct vnm_agg {
     bool have_run = false;
     bool result_is_run = false;
     bool estimated = false;  // hint came from estimate_groups()
+    int64_t merge_stride = 0;  // set by vnm_agg_merge_rows around vnm_agg_merge_device
 };
 
 namespace {
@@ -1110,6 +1240,7 @@ int table_grow(vnm_agg* h, uint64_t new_cap, hipStream_t s) {
     m.g = ng;
     m.n = (int64_t)old.stride;
     m.src_is_table = 1;
+    m.src_stride = 1;
     m.src_tag = old.tag;
     m.src_cap = (int64_t)old.cap;
     for (int j = 0; j < old.kwt; j++) m.src_key[j] = old.keyw + (size_t)j * old.stride;
@@ -1570,6 +1701,7 @@ int vnm_agg_merge_device(vnm_agg* h, int64_t n, uint64_t* const* key_words, uint
     m.plan = h->plan;
     m.g = h->g;
     m.n = n;
+    m.src_stride = h->merge_stride > 0 ? h->merge_stride : 1;
     for (int j = 0; j < h->plan.kw; j++) m.src_key[j] = key_words[j];
     for (int w = 0; w < h->plan.n_words; w++) m.src_acc[w] = acc_words[w];
     int grid = device_info().num_cus * 8;
@@ -1578,6 +1710,21 @@ int vnm_agg_merge_device(vnm_agg* h, int64_t n, uint64_t* const* key_words, uint
     agg_merge_kernel<<<grid, 256, 0, s>>>(m);
     VNM_HIP(hipGetLastError());
     return 0;
+}
+
+// merge row-major partial groups [n][n_key_words + n_acc_words] (what vnm_agg_bucket_by_owner produces and the
+// all_to_all delivers) into this handle
+int vnm_agg_merge_rows(vnm_agg* h, int64_t n, const uint64_t* rows, void* stream) {
+    if (!h) return set_error("vnm_agg_merge_rows: null handle");
+    const int nw = h->plan.kw + h->plan.n_words;
+    uint64_t* kw[AGG_MAX_KEYS + 1];
+    uint64_t* aw[AGG_MAX_WORDS];
+    for (int j = 0; j < h->plan.kw; j++) kw[j] = const_cast<uint64_t*>(rows) + j;
+    for (int w = 0; w < h->plan.n_words; w++) aw[w] = const_cast<uint64_t*>(rows) + h->plan.kw + w;
+    h->merge_stride = nw;
+    int rc = vnm_agg_merge_device(h, n, kw, aw, stream);
+    h->merge_stride = 0;
+    return rc;
 }
 
 int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream) {
@@ -1630,6 +1777,50 @@ int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream) {
     VNM_HIP(hipStreamSynchronize(s));
     h->n_groups = (int64_t)cnt;
     if (n_groups) *n_groups = h->n_groups;
+    return 0;
+}
+
+// Multi-GPU exchange helper: writes the finished dense run as rows of (key words, accumulator words) grouped
+// by owner rank (vinum_amd/distributed.py::owner_of) into out_rows [n_groups][n_key_words + n_acc_words] and
+// the per-owner row counts into counts_host[world].
+int vnm_agg_bucket_by_owner(vnm_agg* h, int world, uint64_t* out_rows, int64_t* counts_host, void* stream) {
+    VNM_TRY(ensure_init());
+    if (!h || world < 1 || world > 64 || !counts_host) return set_error("vnm_agg_bucket_by_owner: bad argument");
+    hipStream_t s = as_stream(stream);
+    int64_t n = 0;
+    VNM_TRY(vnm_agg_finish(h, &n, stream));
+    for (int o = 0; o < world; o++) counts_host[o] = 0;
+    if (n == 0) return 0;
+    BucketArgs b{};
+    b.nkw = h->plan.kw;
+    b.nw = h->plan.kw + h->plan.n_words;
+    for (int j = 0; j < h->plan.kw; j++) b.words[j] = h->dkey + (size_t)j * h->dstride;
+    for (int w = 0; w < h->plan.n_words; w++) b.words[h->plan.kw + w] = h->dacc + (size_t)w * h->dstride;
+    b.n = n;
+    b.world = world;
+    b.out = out_rows;
+    if (h->plan.kw == 0) {  // ONE_GROUP: a single row, owner 0
+        for (int w = 0; w < h->plan.n_words; w++)
+            VNM_HIP(hipMemcpyAsync(out_rows + w, h->dacc + (size_t)w * h->dstride, 8, hipMemcpyDeviceToDevice, s));
+        VNM_HIP(hipStreamSynchronize(s));
+        counts_host[0] = n;
+        return 0;
+    }
+    b.nb = (int)std::min<int64_t>((n + 4095) / 4096, (int64_t)device_info().num_cus * 8);
+    b.per = ((n + b.nb - 1) / b.nb + 255) / 256 * 256;
+    unsigned long long* ctr = (unsigned long long*)pool_alloc(((size_t)world * b.nb + BK_MAX_WORLD) * 8);
+    if (!ctr) return 1;
+    b.blk = ctr;
+    b.totals = ctr + (size_t)world * b.nb;
+    agg_bucket_count_kernel<<<b.nb, 256, 0, s>>>(b);
+    agg_bucket_scan_kernel<<<1, BK_MAX_WORLD, 0, s>>>(b);
+    agg_bucket_scatter_kernel<<<b.nb, 256, 0, s>>>(b);
+    VNM_HIP(hipGetLastError());
+    unsigned long long tot[BK_MAX_WORLD];
+    VNM_HIP(hipMemcpyAsync(tot, b.totals, sizeof(unsigned long long) * world, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    for (int o = 0; o < world; o++) counts_host[o] = (int64_t)tot[o];
+    pool_free(ctr);
     return 0;
 }
 

@@ -43,19 +43,53 @@ def bucket_by_owner(words, n_key_words: int, world: int):
     return send, counts
 
 
+_MAX_ELEMS_PER_PEER = 1 << 27  # 1 GiB of int64 per peer per all_to_all round (keeps byte counts far below 2^31..2^32)
+
+
 def exchange(send: torch.Tensor, counts: torch.Tensor, group=None) -> torch.Tensor:
-    """all_to_all of variable-size row blocks; returns the rows this rank owns."""
+    """all_to_all of variable-size row blocks (grouped by destination rank); returns the rows this rank owns,
+    grouped by source rank.  Large exchanges run in several rounds of at most 1 GiB per peer."""
     world = dist.get_world_size(group)
+    ncol = send.shape[1]
     recv_counts = torch.empty_like(counts)
     dist.all_to_all_single(recv_counts, counts, group=group)
     sc, rc = counts.tolist(), recv_counts.tolist()
-    ncol = send.shape[1]
-    recv = torch.empty((sum(rc), ncol), dtype=send.dtype, device=send.device)
-    # flat 1-D buffers with element-count splits: the form both RCCL and gloo accept
-    dist.all_to_all_single(recv.view(-1), send.view(-1), output_split_sizes=[c * ncol for c in rc],
-                           input_split_sizes=[c * ncol for c in sc], group=group)
     assert world == len(sc)
+    rows_per_round = max(1, _MAX_ELEMS_PER_PEER // ncol)
+    biggest = torch.tensor([max(sc + rc)], dtype=torch.int64, device=send.device)
+    dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
+    rounds = max(1, -(-int(biggest.item()) // rows_per_round))
+    recv = torch.empty((sum(rc), ncol), dtype=send.dtype, device=send.device)
+    s_off = [0] * world
+    r_off = [0] * world
+    for o in range(1, world):
+        s_off[o] = s_off[o - 1] + sc[o - 1]
+        r_off[o] = r_off[o - 1] + rc[o - 1]
+    if rounds == 1:
+        # flat 1-D buffers with element-count splits: the form both RCCL and gloo accept
+        dist.all_to_all_single(recv.view(-1), send.view(-1), output_split_sizes=[c * ncol for c in rc],
+                               input_split_sizes=[c * ncol for c in sc], group=group)
+        return recv
+    for r in range(rounds):
+        lo = r * rows_per_round
+        s_n = [max(0, min(c - lo, rows_per_round)) for c in sc]
+        r_n = [max(0, min(c - lo, rows_per_round)) for c in rc]
+        s_buf = torch.cat([send[s_off[o] + lo: s_off[o] + lo + s_n[o]] for o in range(world)]).contiguous()
+        r_buf = torch.empty((sum(r_n), ncol), dtype=send.dtype, device=send.device)
+        dist.all_to_all_single(r_buf.view(-1), s_buf.view(-1), output_split_sizes=[c * ncol for c in r_n],
+                               input_split_sizes=[c * ncol for c in s_n], group=group)
+        pos = 0
+        for o in range(world):
+            recv[r_off[o] + lo: r_off[o] + lo + r_n[o]] = r_buf[pos: pos + r_n[o]]
+            pos += r_n[o]
     return recv
+
+
+def exchange_bucketed(send: torch.Tensor, counts, merge, group=None):
+    """send: rows [n, n_words] already grouped by owner (vnm_agg_bucket_by_owner), counts: rows per owner."""
+    c = torch.tensor(list(counts), dtype=torch.int64, device=send.device)
+    recv = exchange(send, c, group)
+    return merge(recv)
 
 
 def exchange_partials(words, n_key_words: int, merge, group=None):

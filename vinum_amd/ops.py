@@ -138,10 +138,19 @@ class DeviceAggregate:
         L.check(L.lib().vnm_agg_dense_ptrs(self._h, K, A))
         return [K[i] for i in range(kw)], [A[i] for i in range(aw)]
 
+    def bucket_by_owner(self, world, out_rows_ptr, stream=None):
+        """Rows of the finished run grouped by owner rank (multi-GPU exchange); returns the per-owner counts."""
+        counts = (ctypes.c_int64 * world)()
+        L.check(L.lib().vnm_agg_bucket_by_owner(self._h, world, out_rows_ptr, counts, _stream_ptr(stream)))
+        return list(counts)
+
     def merge(self, n, key_ptrs, acc_ptrs, stream=None):
         K = (ctypes.c_void_p * max(len(key_ptrs), 1))(*key_ptrs)
         A = (ctypes.c_void_p * max(len(acc_ptrs), 1))(*acc_ptrs)
         L.check(L.lib().vnm_agg_merge_device(self._h, n, K, A, _stream_ptr(stream)))
+
+    def merge_rows(self, n, rows_ptr, stream=None):
+        L.check(L.lib().vnm_agg_merge_rows(self._h, n, rows_ptr, _stream_ptr(stream)))
 
     def result_arrays(self, key_indices, out_names_keys, out_names_funcs) -> pa.RecordBatch:
         """Column order follows BaseAggregate::Result (base_aggregate.cpp:47-68): selected group keys
