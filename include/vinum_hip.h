@@ -160,6 +160,19 @@ int vnm_agg_bucket_by_owner(vnm_agg* h, int world, uint64_t* out_rows, int64_t* 
 /* merge dense partial states produced by another handle with the same spec (device pointers) */
 int vnm_agg_merge_device(vnm_agg* h, int64_t n, uint64_t* const* key_words, uint64_t* const* acc_words,
                          void* stream);
+/* Partition-aligned exchange for large G (single 8-byte key, add-merge words): the partitioned path leaves the
+ * groups of hash partition f contiguous and every rank uses the same hash bits, so owner(f) = f * world / F and
+ * the owner merges partition by partition in LDS (no HBM atomics).
+ *   vnm_agg_run_partitions: F when the finished result is such a run, else 0 (all ranks must agree).
+ *   vnm_agg_run_reorder:    rows in partition order [n][2 + n_acc_words], device uint32 row counts per partition,
+ *                           host row counts per owner.
+ *   vnm_agg_merge_partitioned: on an EMPTY handle: received rows grouped by source rank, row offsets of the
+ *                           source blocks (host, world + 1), device uint32 counts [world][nlocal]. */
+int64_t vnm_agg_run_partitions(vnm_agg* h);
+int vnm_agg_run_reorder(vnm_agg* h, int world, uint64_t* out_rows, uint32_t* out_part_counts,
+                        int64_t* owner_counts_host, void* stream);
+int vnm_agg_merge_partitioned(vnm_agg* h, int world, int64_t nlocal, const uint64_t* rows,
+                              const int64_t* src_row_offsets_host, const uint32_t* part_counts, void* stream);
 /* merge row-major partial groups [n][n_key_words + n_acc_words] (layout of vnm_agg_bucket_by_owner) */
 int vnm_agg_merge_rows(vnm_agg* h, int64_t n, const uint64_t* rows, void* stream);
 /* BaseAggregate::Result part 2 (+ agg funcs' Summarize, agg_funcs.h:72-80,358-397,482-491,519-540):

@@ -226,3 +226,59 @@ def test_bucket_by_owner_and_merge_rows_roundtrip(world):
     assert len(total) == len(uk)
     for i, kk in enumerate(uk.tolist()):
         assert total[kk] == (exp_s[i], exp_n[i])
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_partition_aligned_exchange_simulated(world):
+    """Partition-aligned multi-GPU merge on one GPU: `world` operators play the ranks (same hint -> same hash
+    partitions), their runs are reordered by partition, the blocks are routed by hand exactly as the all_to_all
+    would, and every owner merges its partitions in LDS.  The union must equal the oracle on the union of the data."""
+    import torch
+    from oracle import oracle as O
+    from vinum_amd import distributed as D
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    G = 300_000
+    n = 400_000
+    spec = [(O.SUM, 1, pa.float64()), (O.AVG, 1, pa.float64())]
+    funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a")]
+    aggs, tables, sends, pcs, counts = [], [], [], [], []
+    for r in range(world):
+        rng = np.random.default_rng(50 + r)
+        k = rng.integers(0, G, n).astype(np.int64) * 13 - 7
+        k[:3] = -1
+        v = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
+        tables.append(pa.table({"k": k, "v": v}))
+        kt, vt = torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda()
+        # a generous hint gives >= 1024 final partitions, i.e. one workgroup per partition and a directory
+        a = ops.DeviceAggregate(O.SINGLE, [pa.int64()], spec, expected_groups=2_000_000)
+        a.next([DeviceColumn.from_torch(kt)], [DeviceColumn.from_torch(vt)] * 2, nrows=n)
+        nfin = a.run_partitions()
+        assert nfin > 0, "the partitioned path must have produced a partition-structured run"
+        ng = a.finish()
+        kw, aw = a.layout()
+        send = torch.empty((ng, kw + aw), dtype=torch.int64, device="cuda")
+        pc = torch.empty(nfin, dtype=torch.int32, device="cuda")
+        counts.append(a.run_reorder(world, send.data_ptr(), pc.data_ptr()))
+        assert sum(counts[-1]) == ng and int(pc.sum()) == ng
+        aggs.append(a); sends.append(send); pcs.append(pc)
+    bounds = [D.first_partition(o, nfin, world) for o in range(world + 1)]
+    got_batches = []
+    for o in range(world):                                  # what owner o receives
+        blocks, pcr, offs = [], [], [0]
+        for r in range(world):
+            start = sum(counts[r][:o])
+            blocks.append(sends[r][start:start + counts[r][o]])
+            pcr.append(pcs[r][bounds[o]:bounds[o + 1]])
+            offs.append(offs[-1] + counts[r][o])
+        recv = torch.cat(blocks).contiguous()
+        pc_recv = torch.cat(pcr).contiguous()
+        m = ops.DeviceAggregate(O.SINGLE, [pa.int64()], spec)
+        m.merge_partitioned(world, bounds[o + 1] - bounds[o], recv.data_ptr(), offs, pc_recv.data_ptr())
+        got_batches.append(m.result_arrays([0], ["k"], ["s", "a"]))
+    got = pa.Table.from_batches(got_batches).combine_chunks().to_batches()[0]
+    o_ = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for t in tables:
+        for b in t.to_batches():
+            o_.next(b)
+    util.assert_agg_equal(got, o_.result(), funcs, ["k"], what=f"partition-aligned world={world}")

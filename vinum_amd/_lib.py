@@ -62,6 +62,9 @@ PROTOTYPES = {
     "vnm_agg_dense_ptrs": (c_int, [c_void, c_void, c_void]),
     "vnm_agg_bucket_by_owner": (c_int, [c_void, c_int, c_void, c_void, c_void]),
     "vnm_agg_merge_device": (c_int, [c_void, c_i64, c_void, c_void, c_void]),
+    "vnm_agg_run_partitions": (c_i64, [c_void]),
+    "vnm_agg_run_reorder": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void]),
+    "vnm_agg_merge_partitioned": (c_int, [c_void, c_int, c_i64, c_void, c_void, c_void, c_void]),
     "vnm_agg_merge_rows": (c_int, [c_void, c_i64, c_void, c_void]),
     "vnm_agg_result_key": (c_int, [c_void, c_int, c_void, c_void]),
     "vnm_agg_result_func": (c_int, [c_void, c_int, c_void, c_void, c_void]),

@@ -878,6 +878,7 @@ struct PartAggArgs {
     int to_table;
     GTable g;
     int64_t table_limit;
+    unsigned long long* dir;  // [2 * nfinal]: (first dense row, row count) of every final partition, or NULL
 };
 
 __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
@@ -975,7 +976,11 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
         }
         // compact: reserve a dense range for this partition's groups, then write them
         const uint32_t ngroups = s_n + (lkey[PA_SLOTS] != EMPTY ? 1u : 0u);
-        if (tid == 0) { s_base = atomicAdd(&a.flags[1], (unsigned long long)ngroups); s_n = 0; }
+        if (tid == 0) {
+            s_base = atomicAdd(&a.flags[1], (unsigned long long)ngroups);
+            s_n = 0;
+            if (a.dir) { a.dir[2 * f] = s_base; a.dir[2 * f + 1] = ngroups; }
+        }
         __syncthreads();
         if ((int64_t)(s_base + ngroups) > a.dstride) {
             if (tid == 0) __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1142,6 +1147,145 @@ __global__ __launch_bounds__(256) void agg_bucket_scatter_kernel(BucketArgs b) {
     }
 }
 
+// ---- partition-aligned multi-GPU exchange ------------------------------------------------------------------
+// The partitioned path leaves the groups of final partition f contiguous (directory dir[f] = (first row, rows)).
+// Every rank uses the same hash bits, so partition f holds the same keys everywhere and owner(f) = f * P / F.
+// Sender: rows are copied in partition order (row-major [key, nullmask, words...]).  Owner: one workgroup per
+// owned partition loads that partition's segments from all P sources into an LDS table and writes the merged
+// groups -- streaming, no HBM atomics.
+struct RunReorderArgs {
+    const uint64_t* words[2 + AGG_MAX_WORDS];
+    int nw;                            // 2 key words + accumulator words
+    int64_t nfin;
+    const unsigned long long* dir;     // [2 * nfin]
+    unsigned long long* prefix;        // [nfin + 1] exclusive prefix of the row counts (in partition order)
+    uint64_t* out;                     // [n][nw]
+    uint32_t* part_counts;             // [nfin]
+};
+
+__global__ void run_prefix_kernel(RunReorderArgs a) {  // single block: serial over chunks, parallel inside
+    __shared__ unsigned long long carry;
+    __shared__ unsigned long long wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < a.nfin; base += blockDim.x) {
+        int64_t f = base + tid;
+        unsigned long long c = f < a.nfin ? a.dir[2 * f + 1] : 0, inc = c;
+        for (int d = 1; d < 64; d <<= 1) { unsigned long long o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned long long add = carry;
+        for (int w = 0; w < wave; w++) add += wsum[w];
+        if (f < a.nfin) { a.prefix[f] = add + inc - c; a.part_counts[f] = (uint32_t)c; }
+        __syncthreads();
+        if (tid == blockDim.x - 1) carry = add + inc;
+        __syncthreads();
+    }
+    if (tid == 0) a.prefix[a.nfin] = carry;
+}
+
+__global__ __launch_bounds__(256) void run_reorder_kernel(RunReorderArgs a) {
+    for (int64_t f = blockIdx.x; f < a.nfin; f += gridDim.x) {
+        const unsigned long long src = a.dir[2 * f], cnt = a.dir[2 * f + 1], dst = a.prefix[f];
+        for (unsigned long long e = threadIdx.x; e < cnt * a.nw; e += blockDim.x) {
+            unsigned long long r = e / a.nw;
+            int w = (int)(e % a.nw);
+            a.out[(dst + r) * a.nw + w] = a.words[w][src + r];
+        }
+    }
+}
+
+struct PartMergeArgs {
+    const uint64_t* rows;              // all received rows, grouped by source rank, each in partition order
+    const unsigned long long* src_prefix;  // [world][nlocal + 1] row offsets (absolute, into rows)
+    int world;
+    int64_t nlocal;
+    int nw, n_words;
+    int merge[AGG_MAX_WORDS];
+    uint64_t* dkey;                    // [2][dstride]
+    uint64_t* dacc;                    // [W][dstride]
+    int64_t dstride;
+    unsigned long long* flags;         // [0] overflow [1] dense count
+};
+constexpr int PM_MAX_WORDS = 3;
+
+__global__ __launch_bounds__(PA_BLOCK) void part_merge_kernel(PartMergeArgs a) {
+    __shared__ uint64_t lkey[PA_SLOTS + 1];
+    __shared__ uint64_t lw[PM_MAX_WORDS][PA_SLOTS + 1];
+    __shared__ uint32_t s_n, s_fail;
+    __shared__ unsigned long long s_base;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t smask = PA_SLOTS - 1;
+    for (int64_t f = blockIdx.x; f < a.nlocal; f += gridDim.x) {
+        for (int i = tid; i <= PA_SLOTS; i += PA_BLOCK) {
+            lkey[i] = EMPTY;
+            for (int w = 0; w < a.n_words; w++) lw[w][i] = 0;
+        }
+        if (tid == 0) { s_n = 0; s_fail = 0; }
+        __syncthreads();
+        for (int r = 0; r < a.world; r++) {
+            const unsigned long long lo = a.src_prefix[(int64_t)r * (a.nlocal + 1) + f];
+            const unsigned long long hi = a.src_prefix[(int64_t)r * (a.nlocal + 1) + f + 1];
+            for (unsigned long long i = lo + tid; i < hi; i += PA_BLOCK) {
+                const uint64_t* row = a.rows + i * a.nw;
+                const uint64_t key = row[0];
+                int slot = -1;
+                if (key == EMPTY) { slot = PA_SLOTS; lkey[slot] = 0; }
+                else {
+                    uint32_t h = hash_u64(key) & smask;
+                    for (int probe = 0; probe < PA_SLOTS; probe++) {
+                        uint64_t k = *(volatile uint64_t*)&lkey[h];
+                        if (k == key) { slot = (int)h; break; }
+                        if (k == EMPTY) {
+                            uint64_t expected = EMPTY;
+                            if (__hip_atomic_compare_exchange_strong(&lkey[h], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                                if (atomicAdd(&s_n, 1u) >= (uint32_t)(PA_SLOTS * 9 / 10)) s_fail = 1;
+                                slot = (int)h;
+                                break;
+                            }
+                            if (expected == key) { slot = (int)h; break; }
+                        }
+                        h = (h + 1) & smask;
+                        if (s_fail) break;
+                    }
+                }
+                if (slot >= 0)
+                    for (int w = 0; w < a.n_words; w++) l_merge(&lw[w][slot], a.merge[w], row[2 + w]);
+            }
+        }
+        __syncthreads();
+        if (s_fail) {
+            if (tid == 0) __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        const uint32_t ngroups = s_n + (lkey[PA_SLOTS] != EMPTY ? 1u : 0u);
+        if (tid == 0) { s_base = atomicAdd(&a.flags[1], (unsigned long long)ngroups); s_n = 0; }
+        __syncthreads();
+        if ((int64_t)(s_base + ngroups) > a.dstride) {
+            if (tid == 0) __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        for (int i0 = 0; i0 <= PA_SLOTS; i0 += PA_BLOCK) {
+            int i = i0 + tid;
+            bool occ = i <= PA_SLOTS && lkey[i] != EMPTY;
+            uint64_t b = __ballot(occ);
+            uint32_t wbase = 0;
+            if (lane == 0 && b) wbase = atomicAdd(&s_n, (uint32_t)__popcll(b));
+            wbase = __shfl(wbase, 0);
+            if (occ) {
+                uint64_t lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+                int64_t pos = (int64_t)s_base + wbase + __popcll(b & lt);
+                a.dkey[pos] = i == PA_SLOTS ? EMPTY : lkey[i];
+                a.dkey[a.dstride + pos] = 0;
+                for (int w = 0; w < a.n_words; w++) a.dacc[(int64_t)w * a.dstride + pos] = lw[w][i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void fill_u64_kernel(uint64_t* p, uint64_t v, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
@@ -1185,6 +1329,8 @@ struct vnm_agg {
     bool result_is_run = false;
     bool estimated = false;  // hint came from estimate_groups()
     int64_t merge_stride = 0;  // set by vnm_agg_merge_rows around vnm_agg_merge_device
+    unsigned long long* run_dir = nullptr;  // partition directory of the run (partitioned path, one workgroup per partition)
+    int64_t run_nfin = 0;
 };
 
 namespace {
@@ -1288,6 +1434,9 @@ int env_i64(const char* name, int64_t dflt) {
 void drop_run(vnm_agg* h) {
     pool_free(h->run_key);
     pool_free(h->run_acc);
+    pool_free(h->run_dir);
+    h->run_dir = nullptr;
+    h->run_nfin = 0;
     h->run_key = h->run_acc = nullptr;
     h->have_run = false;
     h->run_n = h->run_stride = 0;
@@ -1446,7 +1595,13 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     uint64_t* rk = (uint64_t*)pool_alloc((size_t)dstride * 8 * 2);
     uint64_t* ra = (uint64_t*)pool_alloc((size_t)dstride * 8 * h->plan.n_words);
     if (!rk || !ra) return 1;
+    unsigned long long* dir = nullptr;
+    if (!to_table) {
+        dir = (unsigned long long*)pool_alloc((size_t)nfinal * 16);
+        if (!dir) return 1;
+    }
     PartAggArgs pa{};
+    pa.dir = dir;
     pa.splits = splits;
     pa.to_table = to_table;
     if (to_table) {
@@ -1472,7 +1627,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     VNM_HIP(hipStreamSynchronize(s));
     pool_free(e1); pool_free(c1); pool_free(e2); pool_free(c2); pool_free(flags);
     if (fl[0]) {  // skewed partitions / more groups than hinted: use the general path for this batch
-        pool_free(rk); pool_free(ra);
+        pool_free(rk); pool_free(ra); pool_free(dir);
         if (to_table) { table_free(&h->g); h->have_table = false; }  // drop the partial merge
         return 2;
     }
@@ -1481,6 +1636,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         return 0;
     }
     h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
+    h->run_dir = dir; h->run_nfin = nfinal;
     h->have_run = true;
     return 0;
 }
@@ -1821,6 +1977,107 @@ int vnm_agg_bucket_by_owner(vnm_agg* h, int world, uint64_t* out_rows, int64_t* 
     VNM_HIP(hipStreamSynchronize(s));
     for (int o = 0; o < world; o++) counts_host[o] = (int64_t)tot[o];
     pool_free(ctr);
+    return 0;
+}
+
+// ---- partition-aligned exchange (multi-GPU, large G) ------------------------------------------------------
+// Number of final partitions when the finished result is a partition-structured run (partitioned path,
+// nothing merged into it since), else 0.  All ranks must report the same non-zero value to use this exchange.
+int64_t vnm_agg_run_partitions(vnm_agg* h) {
+    if (!h) return 0;
+    int64_t n = 0;
+    if (vnm_agg_finish(h, &n, nullptr) != 0) return 0;
+    return (h->result_is_run && h->run_dir) ? h->run_nfin : 0;
+}
+
+// Rows of the run in partition order, row-major [n][2 + n_acc_words]; per-partition row counts (device,
+// uint32[nfin]); rows per owner (host) with owner(f) = f * world / nfin.
+int vnm_agg_run_reorder(vnm_agg* h, int world, uint64_t* out_rows, uint32_t* out_part_counts, int64_t* owner_counts_host,
+                        void* stream) {
+    VNM_TRY(ensure_init());
+    if (!h || world < 1 || !out_part_counts || !owner_counts_host) return set_error("vnm_agg_run_reorder: bad argument");
+    if (!vnm_agg_run_partitions(h)) return set_error("vnm_agg_run_reorder: the result is not a partition-structured run");
+    hipStream_t s = as_stream(stream);
+    RunReorderArgs a{};
+    a.nw = 2 + h->plan.n_words;
+    a.words[0] = h->run_key;
+    a.words[1] = h->run_key + h->run_stride;
+    for (int w = 0; w < h->plan.n_words; w++) a.words[2 + w] = h->run_acc + (size_t)w * h->run_stride;
+    a.nfin = h->run_nfin;
+    a.dir = h->run_dir;
+    a.out = out_rows;
+    a.part_counts = out_part_counts;
+    a.prefix = (unsigned long long*)pool_alloc((size_t)(a.nfin + 1) * 8);
+    if (!a.prefix) return 1;
+    run_prefix_kernel<<<1, 1024, 0, s>>>(a);
+    run_reorder_kernel<<<(int)std::min<int64_t>(a.nfin, (int64_t)device_info().num_cus * 8), 256, 0, s>>>(a);
+    VNM_HIP(hipGetLastError());
+    std::vector<unsigned long long> bounds((size_t)world + 1);
+    for (int o = 0; o <= world; o++) {
+        int64_t f = (int64_t)o * a.nfin / world;  // first partition of owner o (inverse of owner(f) = f * world / nfin)
+        while (f < a.nfin && f > 0 && (f * world) / a.nfin < o) f++;
+        VNM_HIP(hipMemcpyAsync(&bounds[o], a.prefix + f, 8, hipMemcpyDeviceToHost, s));
+    }
+    VNM_HIP(hipStreamSynchronize(s));
+    for (int o = 0; o < world; o++) owner_counts_host[o] = (int64_t)(bounds[o + 1] - bounds[o]);
+    pool_free(a.prefix);
+    return 0;
+}
+
+// Owner side: merge the segments received from all ranks.  rows: received rows grouped by source rank (each in
+// partition order); src_row_offsets_host[world + 1]: row offset of every source block; part_counts: device
+// uint32 [world][nlocal] rows per (source, owned partition).  The merged groups become this handle's result.
+int vnm_agg_merge_partitioned(vnm_agg* h, int world, int64_t nlocal, const uint64_t* rows, const int64_t* src_row_offsets_host,
+                              const uint32_t* part_counts, void* stream) {
+    VNM_TRY(ensure_init());
+    if (!h || world < 1 || nlocal < 1) return set_error("vnm_agg_merge_partitioned: bad argument");
+    if (h->have_table || h->have_run) return set_error("vnm_agg_merge_partitioned: the handle must be empty");
+    if (h->plan.n_words > PM_MAX_WORDS) return set_error("vnm_agg_merge_partitioned: at most %d accumulator words", PM_MAX_WORDS);
+    for (int w = 0; w < h->plan.n_words; w++)
+        if (h->plan.merge[w] != M_ADD_U64 && h->plan.merge[w] != M_ADD_F64) return set_error("vnm_agg_merge_partitioned: add-merge words only");
+    hipStream_t s = as_stream(stream);
+    invalidate_result(h);
+    // per-source exclusive prefix over the owned partitions -> absolute row offsets
+    std::vector<uint32_t> pc((size_t)world * nlocal);
+    VNM_HIP(hipMemcpyAsync(pc.data(), part_counts, pc.size() * 4, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    std::vector<unsigned long long> pre((size_t)world * (nlocal + 1));
+    int64_t total = 0;
+    for (int r = 0; r < world; r++) {
+        unsigned long long run = (unsigned long long)src_row_offsets_host[r];
+        for (int64_t f = 0; f < nlocal; f++) { pre[(size_t)r * (nlocal + 1) + f] = run; run += pc[(size_t)r * nlocal + f]; }
+        pre[(size_t)r * (nlocal + 1) + nlocal] = run;
+        if ((int64_t)run != src_row_offsets_host[r + 1]) return set_error("vnm_agg_merge_partitioned: partition counts of source %d do not add up", r);
+        total = (int64_t)run;
+    }
+    unsigned long long* dpre = (unsigned long long*)pool_alloc(pre.size() * 8);
+    unsigned long long* flags = (unsigned long long*)pool_alloc(64);
+    const int64_t dstride = total + 2;
+    uint64_t* rk = (uint64_t*)pool_alloc((size_t)dstride * 16);
+    uint64_t* ra = (uint64_t*)pool_alloc((size_t)dstride * 8 * h->plan.n_words);
+    if (!dpre || !flags || !rk || !ra) return 1;
+    VNM_HIP(hipMemcpyAsync(dpre, pre.data(), pre.size() * 8, hipMemcpyHostToDevice, s));
+    VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
+    PartMergeArgs m{};
+    m.rows = rows; m.src_prefix = dpre; m.world = world; m.nlocal = nlocal;
+    m.nw = 2 + h->plan.n_words; m.n_words = h->plan.n_words;
+    for (int w = 0; w < h->plan.n_words; w++) m.merge[w] = h->plan.merge[w];
+    m.dkey = rk; m.dacc = ra; m.dstride = dstride; m.flags = flags;
+    {
+        KernelTimer timer("agg_part_merge", s);
+        part_merge_kernel<<<(int)std::min<int64_t>(nlocal, (int64_t)device_info().num_cus * 4), PA_BLOCK, 0, s>>>(m);
+    }
+    VNM_HIP(hipGetLastError());
+    unsigned long long fl[2];
+    VNM_HIP(hipMemcpyAsync(fl, flags, 16, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    pool_free(dpre); pool_free(flags);
+    if (fl[0]) {
+        pool_free(rk); pool_free(ra);
+        return set_error("vnm_agg_merge_partitioned: a partition holds more groups than the LDS table (use vnm_agg_merge_rows)");
+    }
+    h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
+    h->have_run = true;
     return 0;
 }
 

@@ -100,3 +100,45 @@ def exchange_partials(words, n_key_words: int, merge, group=None):
     recv = exchange(send, counts, group)
     cols = [recv[:, i].contiguous() for i in range(recv.shape[1])]
     return merge(cols)
+
+
+def first_partition(owner: int, nfin: int, world: int) -> int:
+    """First hash partition owned by `owner` (owner(f) = f * world // nfin)."""
+    return -(-owner * nfin // world)
+
+
+def exchange_partition_aligned(agg, make_merged, device, group=None):
+    """Large-G exchange: every rank holds a partition-structured run with the SAME number of hash partitions F.
+    Rows travel in partition order, the per-partition row counts travel with them, and each owner merges its
+    partitions in LDS (vnm_agg_merge_partitioned) -- no HBM atomics on the receiving side.
+    Returns the merged DeviceAggregate, or None when the ranks do not all hold such a run (caller falls back to
+    the owner-bucketed exchange)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    nfin = agg.run_partitions()
+    t = torch.tensor([nfin, -nfin], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    if int(t[0]) <= 0 or int(t[0]) != -int(t[1]) or nfin < world:
+        return None
+    n = agg.finish()
+    kw, aw = agg.layout()
+    send = torch.empty((max(n, 1), kw + aw), dtype=torch.int64, device=device)
+    pc = torch.empty(nfin, dtype=torch.int32, device=device)
+    counts = agg.run_reorder(world, send.data_ptr(), pc.data_ptr())
+    recv = exchange(send[:n], torch.tensor(counts, dtype=torch.int64, device=device), group)
+    # per-partition counts: owner o gets pc[first(o):first(o+1)] from every rank
+    bounds = [first_partition(o, nfin, world) for o in range(world + 1)]
+    nlocal = bounds[rank + 1] - bounds[rank]
+    pc_recv = torch.empty(world * nlocal, dtype=torch.int32, device=device)
+    dist.all_to_all_single(pc_recv, pc, output_split_sizes=[nlocal] * world,
+                           input_split_sizes=[bounds[o + 1] - bounds[o] for o in range(world)], group=group)
+    # row offsets of the source blocks inside recv
+    rc = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_to_all_single(rc, torch.tensor(counts, dtype=torch.int64, device=device), group=group)
+    offs = [0]
+    for c in rc.tolist():
+        offs.append(offs[-1] + c)
+    merged = make_merged()
+    merged.merge_partitioned(world, nlocal, recv.data_ptr(), offs, pc_recv.data_ptr())
+    merged._keep = (recv, pc_recv)
+    return merged

@@ -149,6 +149,19 @@ class DeviceAggregate:
         A = (ctypes.c_void_p * max(len(acc_ptrs), 1))(*acc_ptrs)
         L.check(L.lib().vnm_agg_merge_device(self._h, n, K, A, _stream_ptr(stream)))
 
+    def run_partitions(self) -> int:
+        """F > 0 when the finished result is a partition-structured run (partition-aligned exchange possible)."""
+        return int(L.lib().vnm_agg_run_partitions(self._h))
+
+    def run_reorder(self, world, rows_ptr, part_counts_ptr, stream=None):
+        counts = (ctypes.c_int64 * world)()
+        L.check(L.lib().vnm_agg_run_reorder(self._h, world, rows_ptr, part_counts_ptr, counts, _stream_ptr(stream)))
+        return list(counts)
+
+    def merge_partitioned(self, world, nlocal, rows_ptr, src_row_offsets, part_counts_ptr, stream=None):
+        offs = (ctypes.c_int64 * (world + 1))(*src_row_offsets)
+        L.check(L.lib().vnm_agg_merge_partitioned(self._h, world, nlocal, rows_ptr, offs, part_counts_ptr, _stream_ptr(stream)))
+
     def merge_rows(self, n, rows_ptr, stream=None):
         L.check(L.lib().vnm_agg_merge_rows(self._h, n, rows_ptr, _stream_ptr(stream)))
 
