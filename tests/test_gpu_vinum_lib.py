@@ -87,3 +87,31 @@ def test_table_batch_reader():
             break
         sizes.append(b.num_rows)
     assert sizes == [4, 4, 2]
+
+
+def test_large_batches_through_pinned_staging():
+    """Batches far above the 32 MiB pinned ring (and above the estimator threshold): Arrow buffers -> pinned
+    double buffer -> HBM -> hint-less aggregate (estimated cardinality) -> Arrow result, vs the oracle."""
+    from oracle import oracle as O
+    vl = _lib()
+    rng = np.random.default_rng(77)
+    n = 6_000_000
+    t = pa.table({"k": pa.array(rng.integers(0, 200_000, n).astype(np.int64)),
+                  "v": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0),
+                  "w": pa.array(rng.integers(-1000, 1000, n).astype(np.int64), mask=rng.random(n) < 0.1)})
+    funcs = [(O.SUM, "v", "sv"), (O.AVG, "v", "av"), (O.COUNT_STAR, "", "n")]
+    agg = _agg(1, ["k"], ["k"], funcs)
+    for b in t.to_batches(max_chunksize=4_500_000):
+        agg.next(b)
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in t.to_batches():
+        o.next(b)
+    util.assert_agg_equal(agg.result(), o.result(), funcs, ["k"], what="large batches")
+    funcs2 = [(O.SUM, "w", "sw"), (O.MIN, "w", "mn"), (O.MAX, "v", "mx"), (O.COUNT, "w", "cw")]
+    agg = _agg(1, ["k"], ["k"], funcs2)
+    for b in t.to_batches(max_chunksize=4_500_000):
+        agg.next(b)
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs2)
+    for b in t.to_batches():
+        o.next(b)
+    util.assert_agg_equal(agg.result(), o.result(), funcs2, ["k"], what="large batches generic")

@@ -137,6 +137,62 @@ KernelTimer::~KernelTimer() {
     if (on && slot >= 0) (void)hipEventRecord(g_spans[slot].b, stream);
 }
 
+
+// ---- pinned double-buffered H2D staging ------------------------------------------------------------------
+// Arrow buffers are pageable host memory.  Copying them with hipMemcpyAsync directly makes the runtime bounce
+// every chunk through its own staging synchronously; here two pinned 32 MiB buffers alternate: while the DMA
+// engine drains one, the CPU fills the other (copy stream separate from the compute stream of the caller).
+namespace {
+constexpr size_t STAGE_BYTES = 32u << 20;
+struct Stager {
+    void* pin[2] = {nullptr, nullptr};
+    hipEvent_t done[2];
+    hipStream_t copy = nullptr;
+    bool ok = false;
+    bool init() {
+        if (ok) return true;
+        if (hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) return false;
+        for (int i = 0; i < 2; i++) {
+            if (hipHostMalloc(&pin[i], STAGE_BYTES, hipHostMallocDefault) != hipSuccess) return false;
+            if (hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) return false;
+        }
+        ok = true;
+        return true;
+    }
+};
+Stager& stager() { static Stager s; return s; }
+std::mutex g_stage_mu;
+}  // namespace
+
+// host (pageable) -> device, through the pinned ring; returns when the last DMA has been enqueued AND completed
+// for the caller's stream (the caller's kernels may start right after: we make `stream` wait on the copy stream)
+static int staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return 0;
+    std::lock_guard<std::mutex> g(g_stage_mu);
+    Stager& st = stager();
+    if (bytes < (1u << 20) || !st.init()) {  // small copies: not worth the ring
+        VNM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+        return 0;
+    }
+    size_t off = 0;
+    int slot = 0;
+    bool used[2] = {false, false};
+    while (off < bytes) {
+        size_t n = bytes - off < STAGE_BYTES ? bytes - off : STAGE_BYTES;
+        if (used[slot]) VNM_HIP(hipEventSynchronize(st.done[slot]));  // the DMA that read this buffer is finished
+        memcpy(st.pin[slot], (const uint8_t*)src + off, n);
+        VNM_HIP(hipMemcpyAsync((uint8_t*)dst + off, st.pin[slot], n, hipMemcpyHostToDevice, st.copy));
+        VNM_HIP(hipEventRecord(st.done[slot], st.copy));
+        used[slot] = true;
+        off += n;
+        slot ^= 1;
+    }
+    // order the caller's stream after the copies, and keep the pinned buffers safe for the next call
+    for (int i = 0; i < 2; i++)
+        if (used[i]) { VNM_HIP(hipStreamWaitEvent(stream, st.done[i], 0)); VNM_HIP(hipEventSynchronize(st.done[i])); }
+    return 0;
+}
+
 }  // namespace vnm
 
 using namespace vnm;
@@ -240,7 +296,7 @@ int vnm_stage_column(const void* host_values, const uint8_t* host_validity, int6
     void* dv = pool_alloc(vbytes ? vbytes : 1);
     if (!dv) return 1;
     if (vbytes)
-        VNM_HIP(hipMemcpyAsync(dv, (const uint8_t*)host_values + (size_t)offset * w, vbytes, hipMemcpyHostToDevice, s));
+        VNM_TRY(staged_h2d(dv, (const uint8_t*)host_values + (size_t)offset * w, vbytes, s));
     out->values = dv;
     out->offset = 0;
     if (host_validity) {
@@ -249,7 +305,7 @@ int vnm_stage_column(const void* host_values, const uint8_t* host_validity, int6
         size_t nb = (size_t)(last_byte - first_byte);
         void* db = pool_alloc(nb ? nb : 1);
         if (!db) return 1;
-        if (nb) VNM_HIP(hipMemcpyAsync(db, host_validity + first_byte, nb, hipMemcpyHostToDevice, s));
+        if (nb) VNM_TRY(staged_h2d(db, host_validity + first_byte, nb, s));
         out->validity = (const uint8_t*)db;
         // values were copied from element `offset` on (device element 0), the bitmap from byte
         // `first_byte` on, so bit (offset & 7) of the device bitmap belongs to device element 0.
@@ -262,8 +318,7 @@ int vnm_stage_column(const void* host_values, const uint8_t* host_validity, int6
             dv = pool_alloc(pbytes ? pbytes : 1);
             if (!dv) return 1;
             if (vbytes)
-                VNM_HIP(hipMemcpyAsync((uint8_t*)dv + (size_t)shift * w, (const uint8_t*)host_values + (size_t)offset * w,
-                                       vbytes, hipMemcpyHostToDevice, s));
+                VNM_TRY(staged_h2d((uint8_t*)dv + (size_t)shift * w, (const uint8_t*)host_values + (size_t)offset * w, vbytes, s));
             out->values = dv;
             out->offset = shift;
         }
