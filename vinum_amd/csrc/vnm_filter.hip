@@ -41,6 +41,8 @@ struct FilterArgs {
     int64_t ntiles;
     unsigned long long* ctl;  // [0] ticket, [1] total
     unsigned long long* status;
+    unsigned long long* gstatus;  // one word per group of 64 tiles (two-level look-back)
+    int lb_sleep;  // look-back back-off between polls, in units of s_sleep(1)
     int debug;  // timing experiments only: 1 = skip look-back (outputs are wrong)
 };
 
@@ -49,14 +51,96 @@ __device__ __forceinline__ uint64_t lanemask_lt() {
     return lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
 }
 
-template <int MODE, int FB, bool HOT>
-__global__ __launch_bounds__(FB) void filter_kernel(FilterArgs a) {
-    constexpr int F_CHUNKS = 8;             // 16-byte requests per lane per tile
-    constexpr int F_TILE = FB * 2 * F_CHUNKS;
-    constexpr int NW = FB / 64;             // waves per workgroup
-    constexpr int NSEG = F_CHUNKS * NW;     // (chunk, wave) segments per tile, <= 128
-    static_assert(NSEG <= 128, "segment scan handles two segments per lane of wave 0");
-    __shared__ int64_t s_next[2];
+__device__ __forceinline__ void lb_backoff(int n) {
+    for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(1);
+}
+
+// Two-level decoupled look-back.  With one level the inclusive-prefix frontier advances by at most one
+// window (64-256 tiles) per status round trip (~2 us under load): 128 tiles/us, i.e. >= 1.9 ms for the 244k
+// tiles of 1e9 rows.  Tiles are grouped by 64: a tile first sums the aggregates of its predecessors inside
+// its own group; the last tile of a group publishes the group aggregate as soon as those are visible
+// (independent of any prefix), and prefixes then travel over group words, 64 groups = 4096 tiles per round.
+// Returns the exclusive prefix of `tile`; `total` is the tile's own survivor count.
+__device__ __forceinline__ int64_t lookback2(unsigned long long* status, unsigned long long* gstatus, int64_t tile,
+                                             int lane, uint32_t total, uint64_t& rounds, int nsleep) {
+    const int64_t g = tile >> 6;
+    const int r = (int)(tile & 63);
+    int64_t local = 0;
+    bool have_inc = false;
+    if (r > 0) {
+        for (;;) {
+            rounds++;
+            uint64_t s = lane < r ? __hip_atomic_load(&status[tile - 1 - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            uint64_t flag = s >> 62;
+            uint64_t incl_mask = __ballot(lane < r && flag == 2);
+            uint64_t zero_mask = __ballot(lane < r && flag == 0);
+            uint64_t val = lane < r ? (s & ST_VAL) : 0;
+            if (incl_mask) {
+                int first = __ffsll((unsigned long long)incl_mask) - 1;
+                uint64_t need = first == 0 ? 0ULL : (~0ULL >> (64 - first));
+                if (zero_mask & need) { lb_backoff(nsleep); continue; }
+                if (lane > first) val = 0;
+                have_inc = true;
+            } else if (zero_mask) {
+                lb_backoff(nsleep);
+                continue;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) val += __shfl_xor(val, d);
+            local = (int64_t)val;
+            break;
+        }
+    }
+    if (have_inc) return local;
+    if (r == 63 && lane == 0)  // the whole group is known: publish its aggregate before chasing the prefix
+        __hip_atomic_store(&gstatus[g], (g > 0 ? ST_AGG : ST_INC) | (uint64_t)(local + total), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    int64_t gp = 0;
+    int64_t look = g - 1;
+    while (look >= 0) {
+        rounds++;
+        int64_t idx = look - lane;
+        uint64_t s = idx >= 0 ? __hip_atomic_load(&gstatus[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ST_INC;
+        uint64_t flag = s >> 62;
+        uint64_t incl_mask = __ballot(flag == 2);
+        uint64_t zero_mask = __ballot(flag == 0);
+        uint64_t val = s & ST_VAL;
+        if (incl_mask) {
+            int first = __ffsll((unsigned long long)incl_mask) - 1;
+            uint64_t need = first == 0 ? 0ULL : (~0ULL >> (64 - first));
+            if (zero_mask & need) { lb_backoff(nsleep); continue; }
+            if (lane > first) val = 0;
+        } else if (zero_mask) {
+            lb_backoff(nsleep);
+            continue;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) val += __shfl_xor(val, d);
+        gp += (int64_t)val;
+        if (incl_mask) break;
+        look -= 64;
+    }
+    return gp + local;
+}
+
+// =======================================================================================================
+// Filter kernel: one tile per workgroup, tile = blockIdx.x, several workgroups per CU — while one waits for
+// its look-back the others stream.  No ticket atomics (a single ticket word saturates at ~90 returning
+// atomics/us).  Deadlock freedom rests on the dispatcher handing out the workgroups of a 1-D grid in
+// increasing index order within each XCD (round-robin across XCDs): the lowest unfinished tile is always
+// running or next in line on its XCD, so it never waits on a tile that cannot start.
+//   HOT: float64 predicate column without validity whose survivors are the only output (BASELINE
+//   configs[1]): 16-byte loads, values stay in registers.  Otherwise predicates go through the generic
+//   per-element evaluator and payload columns are gathered after the tile base is known.
+// Within a wave the survivors of one chunk land on a contiguous output range, so the store instructions of
+// a chunk together cover whole cache lines.
+// =======================================================================================================
+template <int MODE, int FB, int CH, bool HOT, bool STATS>
+__global__ __launch_bounds__(FB) void filter_tile_kernel(FilterArgs a) {
+    constexpr int TILE = FB * 2 * CH;
+    constexpr int NW = FB / 64;
+    constexpr int NSEG = CH * NW;  // (chunk, wave) segments
+    static_assert(NSEG <= 64 && CH <= 8, "one segment per lane of wave 0; ranks are packed 8 bits per chunk");
     __shared__ uint32_t s_cnt[NSEG];
     __shared__ uint32_t s_excl[NSEG];
     __shared__ int64_t s_base;
@@ -65,396 +149,133 @@ __global__ __launch_bounds__(FB) void filter_kernel(FilterArgs a) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const uint64_t lt = lanemask_lt();
-    // HOT: float64 predicate column without a validity bitmap (host-checked); values live in registers and
-    // the next tile is prefetched.  Otherwise predicates go through the generic per-element evaluator.
-    constexpr bool hot = HOT;
-    const double* vals = (const double*)a.pred.values;
+    const int64_t tile = blockIdx.x;
+    // physical element index of this lane's first element in chunk 0; logical row = phys - pred.offset
+    const int64_t pb = a.phys_base + tile * TILE + 2 * tid;
+    const int64_t first = a.phys_base + tile * TILE - a.pred.offset;
+    const bool full = first >= 0 && first + TILE <= a.length;
 
-    double cv0[F_CHUNKS], cv1[F_CHUNKS];  // values of the tile being processed
-    double nv0[F_CHUNKS], nv1[F_CHUNKS];  // prefetched values of the next tile
-
-    // The loop is software pipelined: the ticket and the loads of tile t+1 are issued BEFORE the
-    // look-back and the stores of tile t, so HBM reads stay in flight across the serial part.
-#define VNM_LOAD_TILE(T, V0, V1)                                                                  \
-    do {                                                                                          \
-        const int64_t pb_ = a.phys_base + (T) * F_TILE + 2 * tid;                                 \
-        const int64_t first_ = a.phys_base + (T) * F_TILE - a.pred.offset;                        \
-        if (first_ >= 0 && first_ + F_TILE <= a.length) {                                         \
-            const double2* src_ = (const double2*)(vals + pb_);                                   \
-            _Pragma("unroll") for (int j = 0; j < F_CHUNKS; j++) {                                \
-                double2 t_ = src_[j * FB];                                                        \
-                V0[j] = t_.x; V1[j] = t_.y;                                                       \
-            }                                                                                     \
-        } else {                                                                                  \
-            _Pragma("unroll") for (int j = 0; j < F_CHUNKS; j++) {                                \
-                int64_t p0 = pb_ + (int64_t)j * (2 * FB);                                         \
-                int64_t r0 = p0 - a.pred.offset;                                                  \
-                V0[j] = (r0 >= 0 && r0 < a.length) ? vals[p0] : 0.0;                              \
-                V1[j] = (r0 + 1 >= 0 && r0 + 1 < a.length) ? vals[p0 + 1] : 0.0;                  \
-            }                                                                                     \
-        }                                                                                         \
-    } while (0)
-
-    if (tid == 0) s_next[1] = (int64_t)atomicAdd(a.ctl, 1ULL);
-    __syncthreads();
-    int64_t tile = s_next[1];
-    if (tile < a.ntiles && hot) VNM_LOAD_TILE(tile, cv0, cv1);
-
-    for (int it = 0; tile < a.ntiles; it++) {
-        if (tid == 0) s_next[it & 1] = (int64_t)atomicAdd(a.ctl, 1ULL);
-
-        // physical element index of this lane's first element in chunk 0; logical row = phys - pred.offset
-        const int64_t pbase = a.phys_base + tile * F_TILE + 2 * tid;
-        uint32_t flags = 0;
-        uint32_t rank[F_CHUNKS];
+    double v0[CH], v1[CH];
+    if (HOT) {
+        const double* vals = (const double*)a.pred.values;
+        if (full) {
+            const double2* src = (const double2*)(vals + pb);
 #pragma unroll
-        for (int j = 0; j < F_CHUNKS; j++) {
-            int64_t p0 = pbase + (int64_t)j * (2 * FB);
-            int64_t r0 = p0 - a.pred.offset, r1 = r0 + 1;
-            bool in0 = r0 >= 0 && r0 < a.length, in1 = r1 >= 0 && r1 < a.length;
-            bool f0 = false, f1 = false;
-            if (MODE == MODE_MASK) {
-                if (in0) f0 = a.mask_valid && !a.mask_valid[r0] ? true : a.mask[r0] != 0;
-                if (in1) f1 = a.mask_valid && !a.mask_valid[r1] ? true : a.mask[r1] != 0;
-            } else if (hot) {
-                f0 = in0 && cmp_apply<double>(a.p.op, cv0[j], a.p.dval);
-                f1 = in1 && cmp_apply<double>(a.p.op, cv1[j], a.p.dval);
-            } else {
-                f0 = in0 && pred_eval(a.p, a.pred, r0);
-                f1 = in1 && pred_eval(a.p, a.pred, r1);
+            for (int j = 0; j < CH; j++) {
+                double2 t = src[j * FB];
+                v0[j] = t.x; v1[j] = t.y;
             }
-            uint64_t b0 = __ballot(f0), b1 = __ballot(f1);
-            rank[j] = __popcll(b0 & lt) + __popcll(b1 & lt);
-            flags |= (f0 ? 1u : 0u) << (2 * j) | (f1 ? 1u : 0u) << (2 * j + 1);
-            if (lane == 0) s_cnt[j * NW + wave] = __popcll(b0) + __popcll(b1);
+        } else {
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                int64_t p0 = pb + (int64_t)j * (2 * FB);
+                int64_t r0 = p0 - a.pred.offset;
+                v0[j] = (r0 >= 0 && r0 < a.length) ? vals[p0] : 0.0;
+                v1[j] = (r0 + 1 >= 0 && r0 + 1 < a.length) ? vals[p0 + 1] : 0.0;
+            }
         }
-        __syncthreads();  // #1: counts and next ticket visible
-
-        const int64_t ntile = s_next[it & 1];
-        if (ntile < a.ntiles && hot) VNM_LOAD_TILE(ntile, nv0, nv1);
-
-        // ---- wave 0: scan the segment counts, then decoupled look-back for the tile base ----
-        if (wave == 0) {
-            uint32_t c0 = 2 * lane < NSEG ? s_cnt[2 * lane] : 0;
-            uint32_t c1 = 2 * lane + 1 < NSEG ? s_cnt[2 * lane + 1] : 0;
-            uint32_t c = c0 + c1;
-            uint32_t inc = c;
+    }
+    uint32_t flags = 0, rank[2] = {0, 0};  // 2 flag bits and an 8-bit in-wave rank per chunk
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                uint32_t o = __shfl_up(inc, d);
-                if (lane >= d) inc += o;
-            }
-            if (2 * lane < NSEG) s_excl[2 * lane] = inc - c;
-            if (2 * lane + 1 < NSEG) s_excl[2 * lane + 1] = inc - c + c0;
-            uint32_t total = __shfl(inc, 63);
-            int64_t excl = 0;
-            if (tile > 0 && (a.debug & 1)) excl = tile * (F_TILE / 2);
-            else if (tile > 0) {
-                if (lane == 0)
-                    __hip_atomic_store(&a.status[tile], ST_AGG | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int64_t look = tile - 1;
-                for (;;) {
-                    int64_t idx = look - lane;
-                    uint64_t s = idx >= 0 ? __hip_atomic_load(&a.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ST_INC;
-                    uint64_t flag = s >> 62;
-                    uint64_t incl_mask = __ballot(flag == 2);
-                    uint64_t zero_mask = __ballot(flag == 0);
-                    uint64_t val = s & ST_VAL;
-                    if (incl_mask) {
-                        // only the predecessors up to the nearest inclusive prefix matter
-                        int first = __ffsll((unsigned long long)incl_mask) - 1;
-                        uint64_t need = first == 0 ? 0ULL : (~0ULL >> (64 - first));
-                        if (zero_mask & need) { __builtin_amdgcn_s_sleep(1); continue; }
-                        if (lane > first) val = 0;
-                    } else if (zero_mask) {
-                        __builtin_amdgcn_s_sleep(1);
-                        continue;
-                    }
+    for (int j = 0; j < CH; j++) {
+        const int64_t r0 = pb - a.pred.offset + (int64_t)j * (2 * FB), r1 = r0 + 1;
+        const bool in0 = full || (r0 >= 0 && r0 < a.length), in1 = full || (r1 >= 0 && r1 < a.length);
+        bool f0 = false, f1 = false;
+        if (MODE == MODE_MASK) {
+            if (in0) f0 = a.mask_valid && !a.mask_valid[r0] ? true : a.mask[r0] != 0;
+            if (in1) f1 = a.mask_valid && !a.mask_valid[r1] ? true : a.mask[r1] != 0;
+        } else if (HOT) {
+            f0 = in0 && cmp_apply<double>(a.p.op, v0[j], a.p.dval);
+            f1 = in1 && cmp_apply<double>(a.p.op, v1[j], a.p.dval);
+        } else {
+            f0 = in0 && pred_eval(a.p, a.pred, r0);
+            f1 = in1 && pred_eval(a.p, a.pred, r1);
+        }
+        uint64_t b0 = __ballot(f0), b1 = __ballot(f1);
+        rank[j >> 2] |= (uint32_t)(__popcll(b0 & lt) + __popcll(b1 & lt)) << (8 * (j & 3));
+        flags |= (f0 ? 1u : 0u) << (2 * j) | (f1 ? 1u : 0u) << (2 * j + 1);
+        if (lane == 0) s_cnt[j * NW + wave] = __popcll(b0) + __popcll(b1);
+    }
+    __syncthreads();
+    // ---- wave 0: scan the segment counts, publish the tile aggregate, look back for the tile base ----
+    if (wave == 0) {
+        uint32_t c = lane < NSEG ? s_cnt[lane] : 0;
+        uint32_t inc = c;
 #pragma unroll
-                    for (int d = 32; d > 0; d >>= 1) val += __shfl_xor(val, d);
-                    excl += (int64_t)val;
-                    if (incl_mask) break;
-                    look -= 64;
-                }
-            }
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane < NSEG) s_excl[lane] = inc - c;
+        const uint32_t total = __shfl(inc, 63);
+        int64_t excl = 0;
+        if (tile == 0) {
+            if (lane == 0) __hip_atomic_store(&a.status[0], ST_INC | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (a.debug & 1) {
+            excl = tile * (TILE / 2);
+        } else {
+            if (lane == 0) __hip_atomic_store(&a.status[tile], ST_AGG | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint64_t rounds = 0;
+            uint64_t t0 = STATS ? __builtin_readcyclecounter() : 0;
+            excl = lookback2(a.status, a.gstatus, tile, lane, total, rounds, a.lb_sleep);
             if (lane == 0) {
                 __hip_atomic_store(&a.status[tile], ST_INC | (uint64_t)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_base = excl;
-                if (tile == a.ntiles - 1) a.ctl[1] = (unsigned long long)(excl + total);
+                if ((tile & 63) == 63)
+                    __hip_atomic_store(&a.gstatus[tile >> 6], ST_INC | (uint64_t)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (STATS && lane == 0) {
+                atomicAdd(a.ctl + 2, (unsigned long long)rounds);
+                atomicAdd(a.ctl + 3, (unsigned long long)(__builtin_readcyclecounter() - t0));
+                atomicAdd(a.ctl + 4, 1ULL);
             }
         }
-        __syncthreads();  // #2: tile base known
-        const int64_t base = s_base;
-
-        // ---- write survivors: within a wave the survivors of one chunk land on a contiguous range, so
-        // the two store instructions of a chunk together cover whole cache lines ----
-        if (hot) {
-            // the only payload is the predicate column itself: values are still in registers
-            if (a.n_payload && !(a.debug & 4)) {
-                uint64_t* out = (uint64_t*)a.out_values[0] + base;
-#pragma unroll
-                for (int j = 0; j < F_CHUNKS; j++) {
-                    uint32_t fj = (flags >> (2 * j)) & 3u;
-                    uint32_t pos = s_excl[j * NW + wave] + rank[j];
-                    if (fj & 1u) out[pos++] = (uint64_t)__double_as_longlong(cv0[j]);
-                    if (fj & 2u) out[pos] = (uint64_t)__double_as_longlong(cv1[j]);
-                }
-            }
-        } else
-        for (int k = 0; k < ((a.debug & 4) ? 0 : a.n_payload); k++) {
-            const vnm_dcol& c = a.payload[k];
-            const int w = type_width(c.type);
-            const bool reuse = false;
-#pragma unroll
-            for (int j = 0; j < F_CHUNKS; j++) {
-                uint32_t fj = (flags >> (2 * j)) & 3u;
-                if (!fj) continue;
-                int64_t r0 = pbase + (int64_t)j * (2 * FB) - a.pred.offset;
-                int64_t pos = base + s_excl[j * NW + wave] + rank[j];
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    if (!(fj & (1u << e))) continue;
-                    uint64_t bits;
-                    if (reuse) bits = (uint64_t)__double_as_longlong(e ? cv1[j] : cv0[j]);
-                    else bits = col_raw_bits(c, r0 + e);
-                    switch (w) {
-                        case 8: ((uint64_t*)a.out_values[k])[pos] = bits; break;
-                        case 4: ((uint32_t*)a.out_values[k])[pos] = (uint32_t)bits; break;
-                        case 2: ((uint16_t*)a.out_values[k])[pos] = (uint16_t)bits; break;
-                        default: ((uint8_t*)a.out_values[k])[pos] = (uint8_t)bits; break;
-                    }
-                    if (a.out_valid[k])
-                        a.out_valid[k][pos] = col_valid(c, r0 + e) && !(MODE == MODE_MASK && a.mask_valid && !a.mask_valid[r0 + e]);
-                    pos++;
-                }
-            }
+        if (lane == 0) {
+            s_base = excl;
+            if (tile == a.ntiles - 1) a.ctl[1] = (unsigned long long)(excl + total);
         }
-        // rotate the pipeline
-#pragma unroll
-        for (int j = 0; j < F_CHUNKS; j++) { if (hot) { cv0[j] = nv0[j]; cv1[j] = nv1[j]; } }
-        tile = ntile;
-    }
-#undef VNM_LOAD_TILE
-}
-
-// =======================================================================================================
-// Hot filter kernel: float64 predicate column without validity, output = the compacted column itself
-// (BASELINE configs[1]).  Three-stage software pipeline per workgroup so that neither the HBM reads nor
-// the successors of our tiles ever wait on a look-back:
-//     C = loads in flight (ticket just taken)   B = loaded -> counted -> AGGREGATE PUBLISHED
-//     A = counted one iteration ago -> look-back -> stores
-// A tile's aggregate is published as soon as its loads land (it depends on nothing else), and its
-// look-back runs one iteration later, when most predecessors have already published.
-// =======================================================================================================
-// Decoupled look-back over a 256-tile window (four status words per lane requested together).  sw[] holds
-// the window starting at tile - 1 prefetched by the caller.  Returns the exclusive prefix of `tile`.
-__device__ __forceinline__ int64_t lookback(unsigned long long* status, int64_t tile, int lane, uint64_t* sw) {
-    int64_t excl = 0;
-    int64_t look = tile - 1;
-    bool fresh = true;
-    for (;;) {
-        if (!fresh) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                int64_t idx = look - (q * 64 + lane);
-                sw[q] = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ST_INC;
-            }
-        }
-        fresh = false;
-        bool done = false, retry = false;
-        int64_t acc = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (done || retry) continue;
-            uint64_t flag = sw[q] >> 62;
-            uint64_t incl_mask = __ballot(flag == 2);
-            uint64_t zero_mask = __ballot(flag == 0);
-            uint64_t val = sw[q] & ST_VAL;
-            if (incl_mask) {
-                // only the predecessors up to the nearest inclusive prefix matter
-                int first = __ffsll((unsigned long long)incl_mask) - 1;
-                uint64_t need = first == 0 ? 0ULL : (~0ULL >> (64 - first));
-                if (zero_mask & need) { retry = true; continue; }
-                if (lane > first) val = 0;
-                done = true;
-            } else if (zero_mask) {
-                retry = true;
-                continue;
-            }
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) val += __shfl_xor(val, d);
-            acc += (int64_t)val;
-        }
-        if (retry) { __builtin_amdgcn_s_sleep(1); continue; }
-        excl += acc;
-        if (done) return excl;
-        look -= 256;
-    }
-}
-
-constexpr int FH_THREADS = 512;
-constexpr int FH_CHUNKS = 8;
-constexpr int FH_TILE = FH_THREADS * 2 * FH_CHUNKS;  // 8192 rows
-constexpr int FH_NW = FH_THREADS / 64;
-constexpr int FH_NSEG = FH_CHUNKS * FH_NW;           // 64: one segment per lane of wave 0
-
-__global__ __launch_bounds__(FH_THREADS) void filter_hot_kernel(FilterArgs a) {
-    __shared__ int64_t s_next[2];
-    __shared__ uint32_t s_cnt[FH_NSEG];
-    __shared__ uint32_t s_excl[2][FH_NSEG];
-    __shared__ int64_t s_base;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const uint64_t lt = lanemask_lt();
-    const double* vals = (const double*)a.pred.values;
-    const int op = a.p.op;
-    const double thr = a.p.dval;
-
-    // three register sets that ROTATE ROLES (A -> C -> B -> A) instead of being copied: a register copy of
-    // a set whose loads are still in flight would force an s_waitcnt on them and serialise the pipeline
-    double s0v0[FH_CHUNKS], s0v1[FH_CHUNKS], s1v0[FH_CHUNKS], s1v1[FH_CHUNKS], s2v0[FH_CHUNKS], s2v1[FH_CHUNKS];
-    uint32_t s0rank[FH_CHUNKS], s1rank[FH_CHUNKS], s2rank[FH_CHUNKS];
-    uint32_t s0flags = 0, s1flags = 0, s2flags = 0;
-    uint32_t a_total = 0;  // wave 0: total of tile A
-
-#define VNM_LOAD(T, V0, V1)                                                                       \
-    do {                                                                                          \
-        const int64_t pb_ = a.phys_base + (T) * FH_TILE + 2 * tid;                                \
-        const int64_t first_ = a.phys_base + (T) * FH_TILE - a.pred.offset;                       \
-        if (first_ >= 0 && first_ + FH_TILE <= a.length) {                                        \
-            const double2* src_ = (const double2*)(vals + pb_);                                   \
-            _Pragma("unroll") for (int j = 0; j < FH_CHUNKS; j++) {                               \
-                double2 t_ = src_[j * FH_THREADS];                                                \
-                V0[j] = t_.x; V1[j] = t_.y;                                                       \
-            }                                                                                     \
-        } else {                                                                                  \
-            _Pragma("unroll") for (int j = 0; j < FH_CHUNKS; j++) {                               \
-                int64_t p0 = pb_ + (int64_t)j * (2 * FH_THREADS);                                 \
-                int64_t r0 = p0 - a.pred.offset;                                                  \
-                V0[j] = (r0 >= 0 && r0 < a.length) ? vals[p0] : __builtin_nan("");                \
-                V1[j] = (r0 + 1 >= 0 && r0 + 1 < a.length) ? vals[p0 + 1] : __builtin_nan("");    \
-            }                                                                                     \
-        }                                                                                         \
-    } while (0)
-
-    // out-of-range elements of a ragged tile must not survive whatever the operator is
-#define VNM_COUNT(T, V0, V1, FLAGS, RANK)                                                         \
-    do {                                                                                          \
-        const int64_t rb_ = a.phys_base + (T) * FH_TILE + 2 * tid - a.pred.offset;                \
-        FLAGS = 0;                                                                                \
-        _Pragma("unroll") for (int j = 0; j < FH_CHUNKS; j++) {                                   \
-            int64_t r0 = rb_ + (int64_t)j * (2 * FH_THREADS);                                     \
-            bool f0 = r0 >= 0 && r0 < a.length && cmp_apply<double>(op, V0[j], thr);              \
-            bool f1 = r0 + 1 >= 0 && r0 + 1 < a.length && cmp_apply<double>(op, V1[j], thr);      \
-            uint64_t b0 = __ballot(f0), b1 = __ballot(f1);                                        \
-            RANK[j] = __popcll(b0 & lt) + __popcll(b1 & lt);                                      \
-            FLAGS |= (f0 ? 1u : 0u) << (2 * j) | (f1 ? 1u : 0u) << (2 * j + 1);                   \
-            if (lane == 0) s_cnt[j * FH_NW + wave] = __popcll(b0) + __popcll(b1);                 \
-        }                                                                                         \
-    } while (0)
-
-    // Tickets are requested one iteration before they are needed (a returning atomic on the shared ticket
-    // word takes 1-3 us under streaming load); `pending` lives in thread 0 only.  This file is built with
-    // -amdgpu-atomic-optimizer-strategy=None: the optimizer's wave-aggregation epilogue reads the result
-    // back immediately (s_waitcnt vmcnt(0)), which would drain the whole load pipeline every iteration.
-    unsigned long long pending = 0;
-    if (tid == 0) {
-        s_next[1] = (int64_t)__hip_atomic_fetch_add(a.ctl, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pending = __hip_atomic_fetch_add(a.ctl, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    int64_t tile_a = -1;
-    int64_t tile_b = s_next[1];
-    int64_t tile_c = 0;
-    if (tile_b < a.ntiles) VNM_LOAD(tile_b, s1v0, s1v1);
-    int it = 0;
-
-    // one pipeline step with register sets in roles A (store), B (count + publish), C (load)
-#define VNM_STEP(A, B, C)                                                                                   \
-    {                                                                                                       \
-        const int par = it & 1;                                                                             \
-        it++;                                                                                               \
-        /* (0) wave 0 requests A's 256-tile look-back window FIRST: under streaming load a status read */   \
-        /* queues behind every HBM request this CU already issued, so it goes out before the bulk loads */  \
-        uint64_t sw[4];                                                                                     \
-        if (wave == 0 && tile_a > 0) {                                                                      \
-            _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                 \
-                int64_t idx = tile_a - 1 - (q * 64 + lane);                                                 \
-                sw[q] = idx >= 0 ? __hip_atomic_load(&a.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ST_INC; \
-            }                                                                                               \
-        }                                                                                                   \
-        /* (1) hand out the ticket requested one step ago, request the next one */                          \
-        if (tid == 0) {                                                                                     \
-            s_next[par] = (int64_t)pending;                                                                 \
-            pending = __hip_atomic_fetch_add(a.ctl, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      \
-        }                                                                                                   \
-        /* (2) count B (its loads were issued one step ago) */                                              \
-        if (tile_b < a.ntiles) VNM_COUNT(tile_b, B##v0, B##v1, B##flags, B##rank);                          \
-        __syncthreads(); /* #1: s_cnt(B) and the ticket are visible */                                      \
-        tile_c = s_next[par];                                                                               \
-        if (wave != 0 && tile_c < a.ntiles) VNM_LOAD(tile_c, C##v0, C##v1);                                 \
-        if (wave == 0) {                                                                                    \
-            /* (3) publish B's aggregate right away: it depends on nothing but B's loads */                 \
-            uint32_t b_total = 0;                                                                           \
-            if (tile_b < a.ntiles) {                                                                        \
-                uint32_t c = s_cnt[lane];                                                                   \
-                uint32_t inc = c;                                                                           \
-                _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) {                                        \
-                    uint32_t o = __shfl_up(inc, d);                                                         \
-                    if (lane >= d) inc += o;                                                                \
-                }                                                                                           \
-                s_excl[par][lane] = inc - c;                                                                \
-                b_total = __shfl(inc, 63);                                                                  \
-                if (lane == 0)                                                                              \
-                    __hip_atomic_store(&a.status[tile_b], (tile_b > 0 ? ST_AGG : ST_INC) | (uint64_t)b_total, \
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                         \
-            }                                                                                               \
-            /* (4) look-back for A (its aggregate was published one step ago) */                            \
-            if (tile_a >= 0) {                                                                              \
-                int64_t excl = 0;                                                                           \
-                if (tile_a > 0 && (a.debug & 1)) excl = tile_a * (FH_TILE / 2);                             \
-                else if (tile_a > 0) {                                                                      \
-                    excl = lookback(a.status, tile_a, lane, sw);                                            \
-                    if (lane == 0)                                                                          \
-                        __hip_atomic_store(&a.status[tile_a], ST_INC | (uint64_t)(excl + a_total),          \
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                     \
-                }                                                                                           \
-                if (lane == 0) {                                                                            \
-                    s_base = excl;                                                                          \
-                    if (tile_a == a.ntiles - 1) a.ctl[1] = (unsigned long long)(excl + a_total);            \
-                }                                                                                           \
-            }                                                                                               \
-            a_total = b_total;                                                                              \
-            if (tile_c < a.ntiles) VNM_LOAD(tile_c, C##v0, C##v1);                                          \
-        }                                                                                                   \
-        __syncthreads(); /* #2: base(A) and s_excl(B) are visible */                                        \
-        /* (5) stores of A: per wave and chunk the survivors land on a contiguous range */                  \
-        if (tile_a >= 0 && a.n_payload && !(a.debug & 4)) {                                                 \
-            uint64_t* out = (uint64_t*)a.out_values[0] + s_base;                                            \
-            _Pragma("unroll") for (int j = 0; j < FH_CHUNKS; j++) {                                         \
-                uint32_t fj = (A##flags >> (2 * j)) & 3u;                                                   \
-                uint32_t pos = s_excl[par ^ 1][j * FH_NW + wave] + A##rank[j];                              \
-                if (fj & 1u) out[pos++] = (uint64_t)__double_as_longlong(A##v0[j]);                         \
-                if (fj & 2u) out[pos] = (uint64_t)__double_as_longlong(A##v1[j]);                           \
-            }                                                                                               \
-        }                                                                                                   \
-        tile_a = tile_b < a.ntiles ? tile_b : -1;                                                           \
-        tile_b = tile_c;                                                                                    \
+    if (a.debug & 4) return;
+    const int64_t base = s_base;
+    if (HOT) {
+        // the only payload is the predicate column itself: values are still in registers
+        if (a.n_payload) {
+            uint64_t* out = (uint64_t*)a.out_values[0] + base;
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                uint32_t fj = (flags >> (2 * j)) & 3u;
+                uint32_t pos = s_excl[j * NW + wave] + ((rank[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                if (fj & 1u) out[pos++] = (uint64_t)__double_as_longlong(v0[j]);
+                if (fj & 2u) out[pos] = (uint64_t)__double_as_longlong(v1[j]);
+            }
+        }
+        return;
     }
-
-    for (;;) {
-        VNM_STEP(s0, s1, s2)
-        if (!(tile_a >= 0 || tile_b < a.ntiles)) break;
-        VNM_STEP(s1, s2, s0)
-        if (!(tile_a >= 0 || tile_b < a.ntiles)) break;
-        VNM_STEP(s2, s0, s1)
-        if (!(tile_a >= 0 || tile_b < a.ntiles)) break;
+    for (int k = 0; k < a.n_payload; k++) {
+        const vnm_dcol& c = a.payload[k];
+        const int w = type_width(c.type);
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            uint32_t fj = (flags >> (2 * j)) & 3u;
+            if (!fj) continue;
+            int64_t r0 = pb - a.pred.offset + (int64_t)j * (2 * FB);
+            int64_t pos = base + s_excl[j * NW + wave] + ((rank[j >> 2] >> (8 * (j & 3))) & 0xffu);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                if (!(fj & (1u << e))) continue;
+                uint64_t bits = col_raw_bits(c, r0 + e);
+                switch (w) {
+                    case 8: ((uint64_t*)a.out_values[k])[pos] = bits; break;
+                    case 4: ((uint32_t*)a.out_values[k])[pos] = (uint32_t)bits; break;
+                    case 2: ((uint16_t*)a.out_values[k])[pos] = (uint16_t)bits; break;
+                    default: ((uint8_t*)a.out_values[k])[pos] = (uint8_t)bits; break;
+                }
+                if (a.out_valid[k])
+                    a.out_valid[k][pos] = col_valid(c, r0 + e) && !(MODE == MODE_MASK && a.mask_valid && !a.mask_valid[r0 + e]);
+                pos++;
+            }
+        }
     }
-#undef VNM_STEP
-#undef VNM_LOAD
-#undef VNM_COUNT
 }
 
 // byte-per-row validity -> Arrow bitmap (LSB first), 8 rows per lane
@@ -471,32 +292,19 @@ __global__ void pack_validity_kernel(const uint8_t* bytes, int64_t n, uint8_t* b
     }
 }
 
-template <int MODE, int FB>
-static void launch_variant(const FilterArgs& a, int grid, hipStream_t s) {
-    const bool hot = MODE == CMP_F64 && a.pred.type == VNM_F64 && !a.pred.validity &&
-                     (a.n_payload == 0 || (a.n_payload == 1 && a.reuse_pred && !a.out_valid[0]));
-    if (hot) filter_kernel<MODE, FB, true><<<grid, FB, 0, s>>>(a);
-    else filter_kernel<MODE, FB, false><<<grid, FB, 0, s>>>(a);
-}
-
-// tuning knobs (defaults chosen by measurement, profiles/): VNM_FILTER_THREADS in {256,512,1024},
-// VNM_FILTER_WGS_PER_CU
+// tuning knobs (defaults chosen by measurement, profiles/filter_tuning_r01.md)
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
 
 static int launch_filter(FilterArgs& a, int mode, int64_t* out_count, hipStream_t s) {
-    DeviceInfo& d = device_info();
     const bool hot = mode == CMP_F64 && a.pred.type == VNM_F64 && !a.pred.validity &&
-                     (a.n_payload == 0 || (a.n_payload == 1 && a.reuse_pred && !a.out_valid[0])) &&
-                     env_int("VNM_FILTER_PIPE3", 0) != 0;  // 3-stage variant: measured slower (profiles/filter_tuning_r01.md)
-    const bool hot2 = mode == CMP_F64 && a.pred.type == VNM_F64 && !a.pred.validity &&
-                      (a.n_payload == 0 || (a.n_payload == 1 && a.reuse_pred && !a.out_valid[0]));
-    int fb = hot ? FH_THREADS : env_int("VNM_FILTER_THREADS", hot2 ? 1024 : 512);
-    fb = fb >= 1024 ? 1024 : (fb >= 512 ? 512 : 256);
-    const int chunks = 8;
-    const int tile_rows = hot ? FH_TILE : fb * 2 * chunks;
+                     (a.n_payload == 0 || (a.n_payload == 1 && a.reuse_pred && !a.out_valid[0]));
+    // hot: 1024 threads x 8 rows (43 VGPRs, two workgroups per CU); generic: 512 threads x 16 rows
+    const int fb = hot ? (env_int("VNM_FILTER_THREADS", 1024) >= 1024 ? 1024 : 512) : 512;
+    const int ch = hot && fb == 1024 ? 4 : 8;
+    const int tile_rows = fb * 2 * ch;
     a.phys_base = a.pred.values ? (a.pred.offset & ~1LL) : 0;
     int64_t span = (a.pred.values ? a.pred.offset : 0) + a.length - a.phys_base;
     a.ntiles = (span + tile_rows - 1) / tile_rows;
@@ -504,39 +312,40 @@ static int launch_filter(FilterArgs& a, int mode, int64_t* out_count, hipStream_
         *out_count = 0;
         return 0;
     }
-    size_t sbytes = (size_t)(a.ntiles + 8) * 8;
+    if (a.ntiles > 0x7fffffffLL) return set_error("filter: batch too large");
+    const int64_t ngroups = (a.ntiles >> 6) + 1;
+    size_t sbytes = (size_t)(a.ntiles + ngroups + 8) * 8;
     unsigned long long* scratch = (unsigned long long*)pool_alloc(sbytes);
     if (!scratch) return 1;
     VNM_HIP(hipMemsetAsync(scratch, 0, sbytes, s));
     a.ctl = scratch;
     a.status = scratch + 8;
+    a.gstatus = scratch + 8 + a.ntiles;
     a.debug = env_int("VNM_FILTER_DEBUG", 0);
-    int64_t grid = (int64_t)d.num_cus * env_int("VNM_FILTER_WGS_PER_CU", 2048 / fb);
-    if (grid > a.ntiles) grid = a.ntiles;
+    a.lb_sleep = env_int("VNM_FILTER_SLEEP", 16);
     {
     KernelTimer timer("filter_kernel", s);
-#define VNM_LAUNCH(M)                                                    \
-    do {                                                                 \
-        if (fb == 1024) launch_variant<M, 1024>(a, (int)grid, s);        \
-        else if (fb == 512) launch_variant<M, 512>(a, (int)grid, s);     \
-        else launch_variant<M, 256>(a, (int)grid, s);                    \
-    } while (0)
+    const int grid = (int)a.ntiles;
     if (hot) {
-        int64_t g2 = (int64_t)d.num_cus * env_int("VNM_FILTER_WGS_PER_CU", 1);
-        if (g2 > a.ntiles) g2 = a.ntiles;
-        filter_hot_kernel<<<(int)g2, FH_THREADS, 0, s>>>(a);
-    } else
-    switch (mode) {
-        case CMP_F64: VNM_LAUNCH(CMP_F64); break;
-        case MODE_MASK: VNM_LAUNCH(MODE_MASK); break;
-        default: VNM_LAUNCH(CMP_I64); break;  // generic pred_eval path
+        if (fb == 1024 && (a.debug & 8)) filter_tile_kernel<CMP_F64, 1024, 4, true, true><<<grid, 1024, 0, s>>>(a);
+        else if (fb == 1024) filter_tile_kernel<CMP_F64, 1024, 4, true, false><<<grid, 1024, 0, s>>>(a);
+        else filter_tile_kernel<CMP_F64, 512, 8, true, false><<<grid, 512, 0, s>>>(a);
+    } else if (mode == MODE_MASK) {
+        filter_tile_kernel<MODE_MASK, 512, 8, false, false><<<grid, 512, 0, s>>>(a);
+    } else {
+        filter_tile_kernel<CMP_I64, 512, 8, false, false><<<grid, 512, 0, s>>>(a);  // generic pred_eval path
     }
-#undef VNM_LAUNCH
     }
     VNM_HIP(hipGetLastError());
     unsigned long long total = 0;
     VNM_HIP(hipMemcpyAsync(&total, scratch + 1, 8, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
+    if (a.debug & 8) {
+        unsigned long long st[3] = {0, 0, 0};
+        VNM_HIP(hipMemcpy(st, scratch + 2, 24, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[vnm filter] look-back: tiles %llu rounds/tile %.2f cycles/tile %.0f\n", st[2],
+                st[2] ? (double)st[0] / st[2] : 0.0, st[2] ? (double)st[1] / st[2] : 0.0);
+    }
     pool_free(scratch);
     *out_count = (int64_t)total;
     return 0;
