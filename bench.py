@@ -191,8 +191,8 @@ def main():
             return
         if args.workload == "project":
             cols = {"v": vcol, "a": acol, "b": bcol}
-            state["outs"] = [ops.project(e, cols, length=n, stream=stream)
-                             for e in (("add", ("mul", "v", 2), 1), ("sub", "v", "a"), ("mul", "a", "b"))]
+            state["outs"] = ops.project_many([("add", ("mul", "v", 2), 1), ("sub", "v", "a"), ("mul", "a", "b")],
+                                             cols, length=n, stream=stream)
             state["out_rows"] = n
             return
         agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],

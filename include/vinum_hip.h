@@ -69,7 +69,8 @@ enum vnm_expr_op {
     /* predicates (vinum/core/expressions.py:27-48): the result is a boolean mask */
     VNM_EX_EQ, VNM_EX_NE, VNM_EX_GT, VNM_EX_GE, VNM_EX_LT, VNM_EX_LE, /* NumPy comparison lambdas :30-36 */
     VNM_EX_AND, VNM_EX_OR, VNM_EX_NOT,                             /* pc.and_ / pc.or_ / pc.invert :27-29 */
-    VNM_EX_IS_NULL, VNM_EX_IS_NOT_NULL                             /* pc.is_null / pc.is_valid :37-38 (arg = column) */
+    VNM_EX_IS_NULL, VNM_EX_IS_NOT_NULL,                            /* pc.is_null / pc.is_valid :37-38 (arg = column) */
+    VNM_EX_STORE      /* pop the top of the stack into output `arg` (vnm_project_multi: one SELECT list, one pass) */
 };
 /* out_type of vnm_project when the expression is a predicate: out_values is a byte mask (1 byte per row) */
 #define VNM_MASK_U8 100
@@ -239,6 +240,12 @@ typedef struct vnm_expr_ins {
  * out_values = length bytes (BETWEEN / IN are compiled to AND / OR chains by the caller). */
 int vnm_project(int n_ins, const vnm_expr_ins* program, int n_cols, const vnm_dcol* cols, int64_t length,
                 void* out_values, int* out_type, void* stream);
+/* A whole SELECT list in one pass (ProjectOperator._kernel evaluates every expression of the list over the same
+ * batch, vinum/core/algebra.py:52-64): the program holds n_out expressions, each terminated by
+ * VNM_EX_STORE(arg = output index); every input column is read from HBM once.  out_values[k] must hold
+ * length*8 bytes (length bytes suffice for a predicate output); out_types[k] is returned per output. */
+int vnm_project_multi(int n_ins, const vnm_expr_ins* program, int n_cols, const vnm_dcol* cols, int64_t length,
+                      int n_out, void** out_values, int* out_types, void* stream);
 
 /* ---- TableBatchReader -----------------------------------------------------------------------------
  * replaces vinum/core/vinum_lib.cpp:144-165 / vinum_cpp/src/operators/table_batch_reader.cpp:5-16.

@@ -102,3 +102,38 @@ def test_projection_nulls_and_scalars():
             assert np.array_equal(got.view(np.uint64), np.asarray(ref, dtype=np.float64).view(np.uint64)), expr
     got = ops.project(("add", ("mul", 2, 3), 1), {}, length=5).to_numpy()   # scalar-only: np.repeat (algebra.py:77-87)
     assert got.tolist() == [7] * 5
+
+
+def test_project_many_equals_single_expression_kernels():
+    """A whole SELECT list in one kernel (vnm_project_multi) == one kernel per expression, bit for bit; ragged
+    lengths exercise the four-rows-per-lane tail; > 16 outputs exercise the host-side program packing."""
+    from vinum_amd.device import DeviceColumn
+    from vinum_amd import ops
+    case = MAN["project"][0]
+    table = util.read_ipc(case["input"]).combine_chunks()
+    expected = util.read_ipc(case["expected"]).combine_chunks()
+
+    def conv(e):
+        return tuple(conv(x) for x in e) if isinstance(e, list) else e
+
+    names = list(case["exprs"])
+    exprs = [conv(case["exprs"][n]) for n in names]
+    for length in (table.num_rows, 1, 255, 1025):
+        t = table.slice(0, length)
+        dev = {n: DeviceColumn.from_arrow(t.column(n)) for n in t.schema.names}
+        outs = ops.project_many(exprs, dev, length=length)
+        assert len(outs) == len(exprs)
+        for name, col in zip(names, outs):
+            util.assert_col_equal(col.to_arrow(), expected.column(name).slice(0, length), f"project_many {name} n={length}")
+    # predicates and arithmetic in the same program, more outputs than one program holds
+    rng = np.random.default_rng(4)
+    n = 3000
+    a = rng.integers(-50, 50, n).astype(np.int64)
+    v = rng.normal(size=n)
+    dev = {"a": DeviceColumn.from_numpy(a), "v": DeviceColumn.from_numpy(v)}
+    exprs = [("add", "a", k) for k in range(20)] + [("gt", "v", 0.0), ("mul", "v", "a")]
+    outs = ops.project_many(exprs, dev, length=n)
+    for k in range(20):
+        assert np.array_equal(outs[k].to_numpy(), a + k)
+    assert np.array_equal(outs[20].to_numpy().astype(bool), v > 0.0)
+    assert np.array_equal(outs[21].to_numpy().view(np.uint64), (v * a).view(np.uint64))

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Regenerates the rocprofv3 summaries kept under profiles/ (run on the GPU box: gpurun -- 'bash tools/profile.sh r01').
+# Kernel trace and each PMC counter are collected in SEPARATE runs (MI355X_MICROARCH.md, HBM section).
+R=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+prof() {  # name, rocprof args..., -- bench args
+    local name=$1; shift
+    local pargs=(); while [ "$1" != "--" ]; do pargs+=("$1"); shift; done; shift
+    rm -rf /tmp/rp_$name
+    timeout 600 rocprofv3 "${pargs[@]}" -d /tmp/rp_$name -- python $ROOT/bench.py --no-cpu-baseline "$@" > /tmp/rp_$name.log 2>&1
+    local db=$(find /tmp/rp_$name -name '*.db' | head -1)
+    echo "# rocprofv3 ${pargs[*]} -- python bench.py --no-cpu-baseline $*"
+    python $ROOT/tools/rocpd_summary.py "$db" vnm
+    echo
+}
+for wl in "groupby --groups 1e8" "groupby --groups 7" "groupby --groups 1e6" "filter" "topk" "project"; do
+    tag=$(echo $wl | tr -d ' -' ); 
+    prof ks_$tag --kernel-trace -- --workload $wl --steps 5 --warmup 2 > $OUT/${R}_rocprofv3_kernel_stats_$tag.txt
+done
+for wl in "groupby --groups 1e8" "filter"; do
+    tag=$(echo $wl | tr -d ' -' )
+    { prof pf_$tag --pmc FETCH_SIZE --kernel-trace -- --workload $wl --steps 2 --warmup 1
+      prof pw_$tag --pmc WRITE_SIZE --kernel-trace -- --workload $wl --steps 2 --warmup 1; } > $OUT/${R}_rocprofv3_pmc_$tag.txt
+done
+ls -la $OUT

@@ -35,7 +35,8 @@ ONE_GROUP, SINGLE_NUMERICAL, MULTI_NUMERICAL = range(3)
 ASC, DESC = 0, 1
 EQ, NE, GT, GE, LT, LE = range(6)
 (EX_COL, EX_CONST_F, EX_CONST_I, EX_ADD, EX_SUB, EX_MUL, EX_DIV, EX_MOD, EX_NEG, EX_BAND, EX_BOR, EX_BXOR,
- EX_BNOT, EX_EQ, EX_NE, EX_GT, EX_GE, EX_LT, EX_LE, EX_AND, EX_OR, EX_NOT, EX_IS_NULL, EX_IS_NOT_NULL) = range(24)
+ EX_BNOT, EX_EQ, EX_NE, EX_GT, EX_GE, EX_LT, EX_LE, EX_AND, EX_OR, EX_NOT, EX_IS_NULL, EX_IS_NOT_NULL,
+ EX_STORE) = range(25)
 MASK_U8 = 100
 OUT_U64, OUT_I64, OUT_F64, OUT_F32, OUT_DEC128, OUT_I32 = range(6)
 FLAG_SUM32 = 1
@@ -83,6 +84,7 @@ PROTOTYPES = {
     "vnm_sort_op_sorted": (c_int, [c_void, c_i64, c_void, c_void]),
     "vnm_sort_op_destroy": (None, [c_void]),
     "vnm_project": (c_int, [c_int, c_void, c_int, c_void, c_i64, c_void, c_void, c_void]),
+    "vnm_project_multi": (c_int, [c_int, c_void, c_int, c_void, c_i64, c_int, c_void, c_void, c_void]),
     "vnm_stage_column": (c_int, [c_void, c_void, c_i64, c_i64, ctypes.c_int32, c_void, c_void]),
     "vnm_free_column": (c_int, [c_void]),
     "vnm_malloc": (c_void, [c_i64]),

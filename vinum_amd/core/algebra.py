@@ -83,12 +83,20 @@ class ProjectOperator(Operator):
     def _kernel(self, batch: DeviceRecordBatch) -> DeviceRecordBatch:
         out = dict(batch.columns) if self._keep else {}
         n = batch.num_rows
+        # every computed expression of the SELECT list goes into one fused kernel
+        exprs, used = [], {}
         for name, arg in zip(self._col_names, self._arguments):
-            if isinstance(arg, str):
-                out[name] = batch.column(arg)
-            else:
-                used = {c: batch.columns[c] for c in _columns_of(arg)}
-                out[name] = ops.project(arg, used, length=n if used else max(n, 1))   # scalars repeat (:77-87)
+            if not isinstance(arg, str):
+                exprs.append((name, arg))
+                for c in _columns_of(arg):
+                    used[c] = batch.columns[c]
+        computed = {}
+        if exprs:
+            # column-free expressions repeat their scalar once per row (:77-87)
+            res = ops.project_many([e for _, e in exprs], used, length=n if used else max(n, 1))
+            computed = {name: col for (name, _), col in zip(exprs, res)}
+        for name, arg in zip(self._col_names, self._arguments):
+            out[name] = batch.column(arg) if isinstance(arg, str) else computed[name]
         return DeviceRecordBatch(out, n if out and any(not isinstance(a, (int, float)) for a in self._arguments) else n)
 
 

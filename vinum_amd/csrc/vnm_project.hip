@@ -15,8 +15,14 @@ namespace vnm {
 
 constexpr int PJ_MAX_INS = 64;
 constexpr int PJ_MAX_COLS = 16;
+constexpr int PJ_MAX_OUT = 16;
 constexpr int PJ_STACK = 12;
 constexpr int PJ_BLOCK = 256;
+#ifndef VNM_PJ_R
+#define VNM_PJ_R 4
+#endif
+constexpr int PJ_R = VNM_PJ_R;                 // rows per lane per tile: one opcode decode serves PJ_R rows
+constexpr int PJ_TILE = PJ_BLOCK * PJ_R;
 
 struct PIns {
     int op;
@@ -34,8 +40,8 @@ struct ProjArgs {
     PIns ins[PJ_MAX_INS];
     vnm_dcol cols[PJ_MAX_COLS];
     int64_t length;
-    uint64_t* out;
-    uint8_t* out_mask;  // predicate programs write a byte mask instead
+    void* out[PJ_MAX_OUT];
+    uint8_t out_is_mask[PJ_MAX_OUT];  // predicate outputs are byte masks
 };
 
 __device__ __forceinline__ double np_fmod(double a, double b) {
@@ -57,108 +63,160 @@ __device__ __forceinline__ int64_t np_imod(int64_t a, int64_t b) {
     return m;
 }
 
+// Postfix interpreter.  The program is uniform, so opcode fetch and dispatch are scalar; the top of the stack
+// lives in registers (tos), deeper values in LDS (sized by the host to the program's real depth), and every
+// decoded opcode is applied to PJ_R rows of the lane.
 __global__ __launch_bounds__(PJ_BLOCK) void project_kernel(ProjArgs a) {
-    __shared__ uint64_t stack[PJ_STACK][PJ_BLOCK];
+    extern __shared__ uint64_t stk[];  // [depth - 1][PJ_R][PJ_BLOCK]
     const int tid = threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * PJ_BLOCK;
-    for (int64_t row = (int64_t)blockIdx.x * PJ_BLOCK + tid; row < a.length; row += stride) {
-        int sp = 0;
+    const int64_t ntiles = (a.length + PJ_TILE - 1) / PJ_TILE;
+#define STK(level, r) stk[((level) * PJ_R + (r)) * PJ_BLOCK + tid]
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = tile * PJ_TILE + tid;
+        uint64_t tos[PJ_R];
+#pragma unroll
+        for (int r = 0; r < PJ_R; r++) tos[r] = 0;
+        int sp = 0;  // values on the stack, tos included
         for (int i = 0; i < a.n_ins; i++) {
             const PIns& in = a.ins[i];
-            switch (in.op) {
-                case VNM_EX_COL: {
+            const int op = in.op;
+            if (op == VNM_EX_COL || op == VNM_EX_CONST_F || op == VNM_EX_CONST_I || op == VNM_EX_IS_NULL ||
+                op == VNM_EX_IS_NOT_NULL) {
+                // ---- push ----
+                if (sp > 0) {
+#pragma unroll
+                    for (int r = 0; r < PJ_R; r++) STK(sp - 1, r) = tos[r];
+                }
+                sp++;
+                if (op == VNM_EX_COL) {
                     const vnm_dcol& c = a.cols[in.arg];
-                    uint64_t v;
-                    if (in.is_f) {
-                        double d = col_valid(c, row) ? col_f64(c, row) : __builtin_nan("");
-                        v = (uint64_t)__double_as_longlong(d);
-                    } else {
-                        v = (uint64_t)col_i64(c, row);
+#pragma unroll
+                    for (int r = 0; r < PJ_R; r++) {
+                        const int64_t row = base + r * PJ_BLOCK;
+                        uint64_t v = 0;
+                        if (row < a.length) {
+                            if (in.is_f) {
+                                double d = col_valid(c, row) ? col_f64(c, row) : __builtin_nan("");
+                                v = (uint64_t)__double_as_longlong(d);
+                            } else {
+                                v = (uint64_t)col_i64(c, row);
+                            }
+                        }
+                        tos[r] = v;
                     }
-                    stack[sp++][tid] = v;
-                    break;
+                } else if (op == VNM_EX_CONST_F) {
+#pragma unroll
+                    for (int r = 0; r < PJ_R; r++) tos[r] = (uint64_t)__double_as_longlong(in.imm_f);
+                } else if (op == VNM_EX_CONST_I) {
+#pragma unroll
+                    for (int r = 0; r < PJ_R; r++) tos[r] = (uint64_t)in.imm_i;
+                } else {
+                    const vnm_dcol& c = a.cols[in.arg];
+                    const bool want_null = op == VNM_EX_IS_NULL;
+#pragma unroll
+                    for (int r = 0; r < PJ_R; r++) {
+                        const int64_t row = base + r * PJ_BLOCK;
+                        bool valid = row < a.length ? col_valid(c, row) : true;
+                        tos[r] = (valid != want_null) ? 1ULL : 0ULL;
+                    }
                 }
-                case VNM_EX_CONST_F: stack[sp++][tid] = (uint64_t)__double_as_longlong(in.imm_f); break;
-                case VNM_EX_CONST_I: stack[sp++][tid] = (uint64_t)in.imm_i; break;
-                case VNM_EX_NEG: {
-                    uint64_t x = stack[sp - 1][tid];
-                    stack[sp - 1][tid] = in.is_f ? (uint64_t)__double_as_longlong(-__longlong_as_double((long long)x)) : (uint64_t)0 - x;
-                    break;
+            } else if (op == VNM_EX_NEG || op == VNM_EX_BNOT || op == VNM_EX_NOT) {
+                // ---- unary ----
+#pragma unroll
+                for (int r = 0; r < PJ_R; r++) {
+                    uint64_t x = tos[r];
+                    if (op == VNM_EX_NEG)
+                        x = in.is_f ? (uint64_t)__double_as_longlong(-__longlong_as_double((long long)x)) : (uint64_t)0 - x;
+                    else if (op == VNM_EX_BNOT) x = ~x;
+                    else x ^= 1ULL;
+                    tos[r] = x;
                 }
-                case VNM_EX_BNOT: stack[sp - 1][tid] = ~stack[sp - 1][tid]; break;
-                case VNM_EX_NOT: stack[sp - 1][tid] = stack[sp - 1][tid] ^ 1ULL; break;
-                case VNM_EX_IS_NULL: stack[sp++][tid] = col_valid(a.cols[in.arg], row) ? 0ULL : 1ULL; break;
-                case VNM_EX_IS_NOT_NULL: stack[sp++][tid] = col_valid(a.cols[in.arg], row) ? 1ULL : 0ULL; break;
-                case VNM_EX_AND: { uint64_t xb = stack[--sp][tid]; stack[sp - 1][tid] &= xb; break; }
-                case VNM_EX_OR: { uint64_t xb = stack[--sp][tid]; stack[sp - 1][tid] |= xb; break; }
-                case VNM_EX_EQ: case VNM_EX_NE: case VNM_EX_GT: case VNM_EX_GE: case VNM_EX_LT: case VNM_EX_LE: {
-                    uint64_t xb = stack[--sp][tid];
-                    uint64_t xa = stack[sp - 1][tid];
-                    const int cop = in.op - VNM_EX_EQ;  // same order as enum vnm_cmp_op
-                    bool r;
-                    if (in.cvt_a || in.cvt_b || in.arg) {  // float comparison (arg = 1: both operands already float)
+            } else if (op == VNM_EX_STORE) {
+                // ---- pop into an output column ----
+                if (a.out_is_mask[in.arg]) {
+                    uint8_t* o = (uint8_t*)a.out[in.arg];
+#pragma unroll
+                    for (int r = 0; r < PJ_R; r++) {
+                        const int64_t row = base + r * PJ_BLOCK;
+                        if (row < a.length) o[row] = (uint8_t)tos[r];
+                    }
+                } else {
+                    uint64_t* o = (uint64_t*)a.out[in.arg];
+#pragma unroll
+                    for (int r = 0; r < PJ_R; r++) {
+                        const int64_t row = base + r * PJ_BLOCK;
+                        if (row < a.length) o[row] = tos[r];
+                    }
+                }
+                sp--;
+                if (sp > 0) {
+#pragma unroll
+                    for (int r = 0; r < PJ_R; r++) tos[r] = STK(sp - 1, r);
+                }
+            } else {
+                // ---- binary: a = value below the top (LDS), b = top (registers) ----
+                sp--;
+                const bool cmp = op >= VNM_EX_EQ && op <= VNM_EX_LE;
+                const bool as_f = cmp ? (in.cvt_a || in.cvt_b || in.arg) : in.is_f != 0;
+#pragma unroll
+                for (int r = 0; r < PJ_R; r++) {
+                    const uint64_t xa = STK(sp - 1, r);
+                    const uint64_t xb = tos[r];
+                    uint64_t res;
+                    if (op == VNM_EX_AND) res = xa & xb;
+                    else if (op == VNM_EX_OR) res = xa | xb;
+                    else if (as_f) {
                         double da = in.cvt_a ? (double)(int64_t)xa : __longlong_as_double((long long)xa);
                         double db = in.cvt_b ? (double)(int64_t)xb : __longlong_as_double((long long)xb);
-                        r = cmp_apply<double>(cop, da, db);
-                    } else {
-                        r = cmp_apply<int64_t>(cop, (int64_t)xa, (int64_t)xb);
-                    }
-                    stack[sp - 1][tid] = r ? 1ULL : 0ULL;
-                    break;
-                }
-                default: {
-                    uint64_t xb = stack[--sp][tid];
-                    uint64_t xa = stack[sp - 1][tid];
-                    uint64_t r;
-                    if (in.is_f) {
-                        double da = in.cvt_a ? (double)(int64_t)xa : __longlong_as_double((long long)xa);
-                        double db = in.cvt_b ? (double)(int64_t)xb : __longlong_as_double((long long)xb);
-                        double d;
-                        switch (in.op) {
-                            case VNM_EX_ADD: d = da + db; break;
-                            case VNM_EX_SUB: d = da - db; break;
-                            case VNM_EX_MUL: d = da * db; break;
-                            case VNM_EX_DIV: d = da / db; break;
-                            default: d = np_fmod(da, db); break;
+                        if (cmp) res = cmp_apply<double>(op - VNM_EX_EQ, da, db) ? 1ULL : 0ULL;  // same order as enum vnm_cmp_op
+                        else {
+                            double d;
+                            switch (op) {
+                                case VNM_EX_ADD: d = da + db; break;
+                                case VNM_EX_SUB: d = da - db; break;
+                                case VNM_EX_MUL: d = da * db; break;
+                                case VNM_EX_DIV: d = da / db; break;
+                                default: d = np_fmod(da, db); break;
+                            }
+                            res = (uint64_t)__double_as_longlong(d);
                         }
-                        r = (uint64_t)__double_as_longlong(d);
+                    } else if (cmp) {
+                        res = cmp_apply<int64_t>(op - VNM_EX_EQ, (int64_t)xa, (int64_t)xb) ? 1ULL : 0ULL;
                     } else {
-                        switch (in.op) {
-                            case VNM_EX_ADD: r = xa + xb; break;
-                            case VNM_EX_SUB: r = xa - xb; break;
-                            case VNM_EX_MUL: r = xa * xb; break;
-                            case VNM_EX_MOD: r = (uint64_t)np_imod((int64_t)xa, (int64_t)xb); break;
-                            case VNM_EX_BAND: r = xa & xb; break;
-                            case VNM_EX_BOR: r = xa | xb; break;
-                            default: r = xa ^ xb; break;
+                        switch (op) {
+                            case VNM_EX_ADD: res = xa + xb; break;
+                            case VNM_EX_SUB: res = xa - xb; break;
+                            case VNM_EX_MUL: res = xa * xb; break;
+                            case VNM_EX_MOD: res = (uint64_t)np_imod((int64_t)xa, (int64_t)xb); break;
+                            case VNM_EX_BAND: res = xa & xb; break;
+                            case VNM_EX_BOR: res = xa | xb; break;
+                            default: res = xa ^ xb; break;
                         }
                     }
-                    stack[sp - 1][tid] = r;
-                    break;
+                    tos[r] = res;
                 }
             }
         }
-        if (a.out_mask) a.out_mask[row] = (uint8_t)stack[0][tid];
-        else a.out[row] = stack[0][tid];
     }
+#undef STK
 }
 
 }  // namespace vnm
 
 using namespace vnm;
 
-extern "C" {
-
-int vnm_project(int n_ins, const vnm_expr_ins* program, int n_cols, const vnm_dcol* cols, int64_t length,
-                void* out_values, int* out_type, void* stream) {
+// Abstract interpretation of the program (types per stack slot: NumPy result_type over {int64, float64}; bool
+// masks), launch.  `single`: the program is one expression without a STORE; out index 0 is implied.
+static int project_impl(int n_ins, const vnm_expr_ins* program, int n_cols, const vnm_dcol* cols, int64_t length,
+                        int n_out, void** out_values, int* out_types, bool single, void* stream) {
     VNM_TRY(ensure_init());
-    if (n_ins <= 0 || n_ins > PJ_MAX_INS) return set_error("vnm_project: program must have 1..%d instructions", PJ_MAX_INS);
+    if (n_ins <= 0 || n_ins + (single ? 1 : 0) > PJ_MAX_INS)
+        return set_error("vnm_project: program must have 1..%d instructions", PJ_MAX_INS - (single ? 1 : 0));
     if (n_cols < 0 || n_cols > PJ_MAX_COLS) return set_error("vnm_project: at most %d input columns", PJ_MAX_COLS);
+    if (n_out < 1 || n_out > PJ_MAX_OUT) return set_error("vnm_project: 1..%d outputs per call", PJ_MAX_OUT);
     ProjArgs a{};
-    a.n_ins = n_ins;
     a.n_cols = n_cols;
     a.length = length;
-    a.out = (uint64_t*)out_values;
     for (int c = 0; c < n_cols; c++) {
         if (cols[c].type != VNM_I64 && cols[c].type != VNM_F64)
             return set_error("vnm_project: column %d: only int64 / float64 columns are supported (NumPy's narrower "
@@ -166,12 +224,15 @@ int vnm_project(int n_ins, const vnm_expr_ins* program, int n_cols, const vnm_dc
         if (cols[c].length != length) return set_error("Select expressions have unequal sizes. This is not permitted.");
         a.cols[c] = cols[c];
     }
-    // abstract interpretation: type of every stack slot (NumPy result_type over {int64, float64}; bool masks)
     enum { T_I = 0, T_F = 1, T_B = 2 };
     int ty[PJ_STACK];
-    int sp = 0;
-    for (int i = 0; i < n_ins; i++) {
-        const vnm_expr_ins& in = program[i];
+    int sp = 0, depth = 1;
+    bool stored[PJ_MAX_OUT] = {};
+    const int total = n_ins + (single ? 1 : 0);
+    for (int i = 0; i < total; i++) {
+        vnm_expr_ins in;
+        if (i < n_ins) in = program[i];
+        else { in = vnm_expr_ins{}; in.op = VNM_EX_STORE; in.arg = 0; }
         PIns& o = a.ins[i];
         o.op = in.op;
         o.arg = in.arg;
@@ -242,22 +303,52 @@ int vnm_project(int n_ins, const vnm_expr_ins* program, int n_cols, const vnm_dc
                 ty[sp - 1] = rf ? T_F : T_I;
                 break;
             }
+            case VNM_EX_STORE: {
+                if (single && i < n_ins) return set_error("vnm_project: VNM_EX_STORE belongs to vnm_project_multi programs");
+                if (sp < 1) return set_error("vnm_project: malformed program (stack underflow)");
+                if (in.arg < 0 || in.arg >= n_out) return set_error("vnm_project: output index %d out of range", in.arg);
+                if (stored[in.arg]) return set_error("vnm_project: output %d stored twice", in.arg);
+                stored[in.arg] = true;
+                const int t = ty[sp - 1];
+                a.out[in.arg] = out_values[in.arg];
+                a.out_is_mask[in.arg] = t == T_B;
+                if (out_types) out_types[in.arg] = t == T_B ? VNM_MASK_U8 : (t == T_F ? VNM_F64 : VNM_I64);
+                sp--;
+                break;
+            }
             default: return set_error("vnm_project: unknown opcode %d", in.op);
         }
+        if (sp > depth) depth = sp;
     }
-    if (sp != 1) return set_error("vnm_project: malformed program (final stack depth %d)", sp);
-    if (out_type) *out_type = ty[0] == T_B ? VNM_MASK_U8 : (ty[0] == T_F ? VNM_F64 : VNM_I64);
-    if (ty[0] == T_B) { a.out_mask = (uint8_t*)out_values; a.out = nullptr; }
+    if (sp != 0) return set_error("vnm_project: malformed program (final stack depth %d)", sp + (single ? 1 : 0));
+    for (int k = 0; k < n_out; k++)
+        if (!stored[k]) return set_error("vnm_project: output %d is never stored", k);
+    a.n_ins = total;
     if (length <= 0) return 0;
+    const size_t lds = (size_t)(depth > 1 ? depth - 1 : 1) * PJ_R * PJ_BLOCK * 8;
     int grid = device_info().num_cus * 8;
-    int64_t need = (length + PJ_BLOCK - 1) / PJ_BLOCK;
+    int64_t need = (length + PJ_TILE - 1) / PJ_TILE;
     if (grid > need) grid = (int)need;
     {
         KernelTimer timer("project_kernel", as_stream(stream));
-        project_kernel<<<grid, PJ_BLOCK, 0, as_stream(stream)>>>(a);
+        project_kernel<<<grid, PJ_BLOCK, lds, as_stream(stream)>>>(a);
     }
     VNM_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" {
+
+int vnm_project(int n_ins, const vnm_expr_ins* program, int n_cols, const vnm_dcol* cols, int64_t length,
+                void* out_values, int* out_type, void* stream) {
+    void* outs[1] = {out_values};
+    return project_impl(n_ins, program, n_cols, cols, length, 1, outs, out_type, true, stream);
+}
+
+int vnm_project_multi(int n_ins, const vnm_expr_ins* program, int n_cols, const vnm_dcol* cols, int64_t length,
+                      int n_out, void** out_values, int* out_types, void* stream) {
+    if (!out_values) return set_error("vnm_project_multi: null argument");
+    return project_impl(n_ins, program, n_cols, cols, length, n_out, out_values, out_types, false, stream);
 }
 
 }  // extern "C"

@@ -224,31 +224,65 @@ __global__ void topk_sample_kernel(vnm_dcol c, int desc, int64_t n, int64_t m, u
     }
 }
 
-// keep rows whose (class, code) <= (t_cls, t_code); unordered wave-aggregated append of (code, class, row)
-__global__ void topk_select_kernel(vnm_dcol c, int desc, int64_t n, uint32_t t_cls, uint64_t t_code, int64_t cap,
-                                   unsigned long long* count, uint64_t* code, uint8_t* cls, uint32_t* rows) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+// keep rows whose (class, code) <= (t_cls, t_code); unordered append of (code, class, row).
+// Candidates are collected in a per-wave LDS buffer and appended with ONE atomic per 256 candidates: a
+// returning atomic per wave-with-survivors saturates the shared counter (~90/us) once K reaches ~1e6.
+// Four independent rows per lane keep the column reads in flight.
+constexpr int TK_U = 4;
+constexpr int TK_BUF = 256;
+__global__ __launch_bounds__(256) void topk_select_kernel(vnm_dcol c, int desc, int64_t n, uint32_t t_cls, uint64_t t_code, int64_t cap,
+                                                          unsigned long long* count, uint64_t* code, uint8_t* cls, uint32_t* rows) {
+    __shared__ uint64_t b_code[4][TK_BUF];
+    __shared__ uint32_t b_row[4][TK_BUF];
+    __shared__ uint8_t b_cls[4][TK_BUF];
     const int lane = threadIdx.x & 63;
-    const int64_t iters = (n + stride - 1) / stride;
-    for (int64_t it = 0; it < iters; it++) {
-        int64_t i = it * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        bool keep = false;
-        uint64_t e = 0; uint32_t k = 0;
-        if (i < n) {
-            encode_key(c, i, desc, &e, &k);
-            keep = k < t_cls || (k == t_cls && e <= t_code);
-        }
-        uint64_t b = __ballot(keep);
-        if (!b) continue;
+    const int wave = threadIdx.x >> 6;
+    const uint64_t lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+    uint32_t fill = 0;  // wave-uniform
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(b));
+        if (lane == 0) base = atomicAdd(count, (unsigned long long)fill);
         base = __shfl(base, 0);
-        if (keep) {
-            uint64_t lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
-            int64_t pos = (int64_t)base + __popcll(b & lt);
-            if (pos < cap) { code[pos] = e; cls[pos] = (uint8_t)k; rows[pos] = (uint32_t)i; }
+        for (uint32_t j = lane; j < fill; j += 64) {
+            int64_t pos = (int64_t)base + j;
+            if (pos < cap) { code[pos] = b_code[wave][j]; cls[pos] = b_cls[wave][j]; rows[pos] = b_row[wave][j]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        fill = 0;
+    };
+    const int64_t tile_rows = 256 * TK_U;
+    const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        uint64_t e[TK_U];
+        uint32_t k[TK_U];
+        bool keep[TK_U];
+#pragma unroll
+        for (int u = 0; u < TK_U; u++) {
+            int64_t i = t * tile_rows + u * 256 + threadIdx.x;
+            e[u] = 0; k[u] = 0; keep[u] = false;
+            if (i < n) {
+                encode_key(c, i, desc, &e[u], &k[u]);
+                keep[u] = k[u] < t_cls || (k[u] == t_cls && e[u] <= t_code);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TK_U; u++) {
+            uint64_t b = __ballot(keep[u]);
+            if (!b) continue;
+            uint32_t cnt = (uint32_t)__popcll(b);
+            if (fill + cnt > TK_BUF) flush();
+            if (keep[u]) {
+                uint32_t slot = fill + (uint32_t)__popcll(b & lt);
+                b_code[wave][slot] = e[u];
+                b_cls[wave][slot] = (uint8_t)k[u];
+                b_row[wave][slot] = (uint32_t)(t * tile_rows + u * 256 + threadIdx.x);
+            }
+            fill += cnt;
         }
     }
+    if (fill) flush();
 }
 
 __global__ void gather_u8_kernel(const uint8_t* src, const uint32_t* idx, int64_t n, uint64_t* out) {

@@ -294,11 +294,8 @@ def _desugar(e):
     return (op,) + tuple(args)
 
 
-def compile_expr(expr, col_index):
-    """Nested prefix expression -> postfix vnm_expr_ins list.
-    expr := column name | int | float | (op, expr[, expr...]); n-ary chains fold left like
-    VectorizedExpression._apply_binary_args_function (vinum/core/base.py:145-151)."""
-    out = []
+def _emit_expr(expr, col_index, out):
+    """Append the postfix form of one nested prefix expression to `out` (tuples op, arg, imm_f, imm_i)."""
 
     def emit(e):
         if isinstance(e, str):
@@ -323,10 +320,22 @@ def compile_expr(expr, col_index):
                     emit(a)
                     out.append((op, 0, 0.0, 0))
     emit(_desugar(expr))
-    prog = (L.ExprIns * len(out))()
-    for i, (op, arg, f, k) in enumerate(out):
+
+
+def _program(ins):
+    prog = (L.ExprIns * len(ins))()
+    for i, (op, arg, f, k) in enumerate(ins):
         prog[i].op, prog[i].arg, prog[i].imm_f, prog[i].imm_i = op, arg, f, k
     return prog
+
+
+def compile_expr(expr, col_index):
+    """Nested prefix expression -> postfix vnm_expr_ins list.
+    expr := column name | int | float | (op, expr[, expr...]); n-ary chains fold left like
+    VectorizedExpression._apply_binary_args_function (vinum/core/base.py:145-151)."""
+    out = []
+    _emit_expr(expr, col_index, out)
+    return _program(out)
 
 
 def project(expr, columns: dict, length=None, stream=None) -> DeviceColumn:
@@ -345,6 +354,49 @@ def project(expr, columns: dict, length=None, stream=None) -> DeviceColumn:
         return DeviceColumn(out, None, 0, length, pa.uint8())   # byte mask (predicate program)
     t = pa.float64() if ot.value == L.F64 else pa.int64()
     return DeviceColumn(out, None, 0, length, t)
+
+
+def project_many(exprs, columns: dict, length=None, stream=None):
+    """A whole SELECT list in ONE kernel (vnm_project_multi): every input column is read from HBM once, every
+    output written once -- ProjectOperator._kernel's loop over expressions (vinum/core/algebra.py:52-64) without
+    its per-node temporaries.  Returns one DeviceColumn per expression."""
+    exprs = list(exprs)
+    if not exprs:
+        return []
+    if length is None:
+        length = next(iter(columns.values())).length if columns else 1
+    # pack expressions into programs that respect the kernel limits (64 instructions, 16 columns, 16 outputs)
+    chunks, cur, cur_cols, cur_ins = [], [], [], 0
+    for k, e in enumerate(exprs):
+        tmp = []
+        ecols = columns_of(e)
+        _emit_expr(e, {n: 0 for n in ecols}, tmp)
+        n_ins = len(tmp) + 1
+        merged = cur_cols + [c for c in ecols if c not in cur_cols]
+        if cur and (cur_ins + n_ins > 64 or len(merged) > 16 or len(cur) >= 16):
+            chunks.append((cur, cur_cols))
+            cur, cur_ins, merged = [], 0, list(ecols)
+        cur.append(k)
+        cur_cols, cur_ins = merged, cur_ins + n_ins
+    chunks.append((cur, cur_cols))
+    result = [None] * len(exprs)
+    for ks, names in chunks:
+        cols = [columns[n] for n in names]
+        index = {n: i for i, n in enumerate(names)}
+        ins = []
+        for j, k in enumerate(ks):
+            _emit_expr(exprs[k], index, ins)
+            ins.append((L.EX_STORE, j, 0.0, 0))
+        prog = _program(ins)
+        bufs = [DeviceBuffer(max(length, 1) * 8) for _ in ks]
+        ptrs = (ctypes.c_void_p * len(ks))(*[b.ptr for b in bufs])
+        types = (ctypes.c_int * len(ks))()
+        L.check(L.lib().vnm_project_multi(len(prog), prog, len(cols), dcol_array(cols), length, len(ks), ptrs, types,
+                                          _stream_ptr(stream)))
+        for k, b, t in zip(ks, bufs, types):
+            at = pa.uint8() if t == L.MASK_U8 else (pa.float64() if t == L.F64 else pa.int64())
+            result[k] = DeviceColumn(b, None, 0, length, at)
+    return result
 
 
 def columns_of(expr):
