@@ -693,6 +693,7 @@ struct PartArgs {
     int nparts;          // 256 or 512
     int shift;           // partition = (hash >> shift) & (nparts - 1)
     unsigned long long* flags;  // [0] overflow
+    int debug;  // timing experiments (VNM_PART_DEBUG): 1 = no copy-out stores, 2 = no staging / copy-out at all
 };
 
 template <bool FROM_ROWS>
@@ -742,6 +743,11 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
         }
         prefetch_next();
         __syncthreads();
+        if (a.debug & 2) {
+            if (tid < np) { cursor[tid] += cnt[tid]; cnt[tid] = 0; }
+            __syncthreads();
+            return;
+        }
         // B: exclusive scan of cnt[0..np): wave scans, then the totals of the preceding waves are added
         if (tid < npad) {
             uint32_t c = cnt[tid], inc = c;
@@ -769,7 +775,7 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
         }
         __syncthreads();
         // D: copy out: consecutive lanes write consecutive 16-byte entries of one partition's run
-        const uint32_t total = s_total;
+        const uint32_t total = (a.debug & 1) ? 0 : s_total;
         for (uint32_t i = tid; i < total; i += PT_BLOCK) {
             uint32_t p = part_of[i];
             uint32_t j = cursor[p] + (i - off[p]);
@@ -837,13 +843,20 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
         __syncthreads();
         const uint32_t total_in = rstart[per];
         ulonglong2 eb[PT_ITEMS];
+        // region of item k of the current tile: v grows by PT_TILE per tile, so the region index only ever moves
+        // forward by a step or two -- a per-item cursor replaces a binary search over rstart (8 dependent LDS
+        // reads per item, which made this pass load-latency bound: 3.9 of its 4.5 ms)
+        int reg[PT_ITEMS];
+#pragma unroll
+        for (int k = 0; k < PT_ITEMS; k++) reg[k] = 0;
         auto load_entries = [&](uint32_t t0) {
 #pragma unroll
             for (int k = 0; k < PT_ITEMS; k++) {
                 uint32_t v = t0 + (uint32_t)k * PT_BLOCK + tid;
                 if (v < total_in) {
-                    int lo = 0, hi = per;  // largest rj with rstart[rj] <= v
-                    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (rstart[mid] <= v) lo = mid; else hi = mid; }
+                    int lo = reg[k];  // largest rj with rstart[rj] <= v (rstart[per] = total_in > v)
+                    while (rstart[lo + 1] <= v) lo++;
+                    reg[k] = lo;
                     eb[k] = a.in_entries[(region0 + lo) * a.in_cap + (v - rstart[lo])];
                 }
             }
@@ -933,7 +946,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
                             if (expected == key) { slot = (int)h; break; }
                         }
                         h = (h + 1) & smask;
-                        if (s_fail) break;
+                        if ((probe & 15) == 15 && s_fail) break;
                     }
                 }
                 if (slot >= 0) {
@@ -1248,7 +1261,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_merge_kernel(PartMergeArgs a) {
                             if (expected == key) { slot = (int)h; break; }
                         }
                         h = (h + 1) & smask;
-                        if (s_fail) break;
+                        if ((probe & 15) == 15 && s_fail) break;
                     }
                 }
                 if (slot >= 0)
@@ -1547,6 +1560,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     int lg1 = 0;
     while ((1 << lg1) < np1) lg1++;
     p1.nparts = np1; p1.shift = 32 - lg1; p1.flags = flags;
+    p1.debug = (int)env_i64("VNM_PART_DEBUG", 0);
     {
         KernelTimer timer("agg_part_scatter1", s);
         part_scatter_kernel<true><<<grid1, PT_BLOCK, 0, s>>>(p1);
@@ -1570,6 +1584,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         p2.in_entries = e1; p2.in_counts = c1; p2.in_cap = cap1; p2.in_regions = grid1; p2.in_split = split2;
         p2.out_entries = e2; p2.out_counts = c2; p2.out_cap = cap2;
         p2.nparts = np2; p2.shift = 15; p2.flags = flags;  // hash bits [23:15] (pass 1 used [31:24])
+        p2.debug = p1.debug;
         {
             KernelTimer timer("agg_part_scatter2", s);
             part_scatter_kernel<false><<<np1 * p2.in_split, PT_BLOCK, 0, s>>>(p2);
