@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="groupby", choices=["groupby", "filter", "topk", "project"])
+    ap.add_argument("--no-also", action="store_true", help="skip the side measurements (configs[1] filter, G=7 group-by)")
     ap.add_argument("--limit", type=int, default=10)
     ap.add_argument("--rows", type=float, default=1e9)
     ap.add_argument("--groups", type=float, default=1e8)
@@ -118,6 +119,83 @@ class CudaArrayView:
 
     def __init__(self, ptr, n, typestr="<i8"):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def _spans(lib, ctypes, names, steps):
+    out = {}
+    for nm in names:
+        tot_ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+        lib.vnm_profile_query(nm, ctypes.byref(tot_ms), ctypes.byref(cnt))
+        if cnt.value:
+            out[nm.decode()] = tot_ms.value / steps
+    return out
+
+
+def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream, args, steps=5, warmup=2):
+    """configs[1] (WHERE v > X -> compacted column) and the small-cardinality group-by (G = 7, the shape of
+    configs[0]'s query) over the headline run's resident columns.  Same timing method: HIP events per kernel."""
+    out = {}
+    # ---- configs[1]
+    dst = torch.empty(n, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+    cnt = ctypes.c_int64(0)
+
+    def filt():
+        ov = (ctypes.c_void_p * 1)(dst.data_ptr())
+        ob = (ctypes.c_void_p * 1)(None)
+        d = vcol.dcol()
+        L.check(lib.vnm_filter_cmp(ctypes.byref(d), L.GT, 1, x_thr, 0, 1, ctypes.byref(d), ov, ob, ctypes.byref(cnt),
+                                   ctypes.c_void_p(stream)))
+    for _ in range(warmup):
+        filt()
+    torch.cuda.synchronize()
+    lib.vnm_set_profiling(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        filt()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    sp = _spans(lib, ctypes, [b"filter_kernel"], steps)
+    lib.vnm_set_profiling(0)
+    kms = sum(sp.values())
+    alg = 8.0 * n + 8.0 * cnt.value
+    out["configs[1] filter"] = {"workload": f"WHERE v > {x_thr} over {n:.3g}-row fp64 column -> compacted column",
+                                "rows_per_s": n * steps / el, "ms_per_step": el / steps * 1e3, "result_rows": int(cnt.value),
+                                "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9 if kms else 0.0,
+                                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": (alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms else 0.0,
+                                             "kernels_ms": {k: round(v, 4) for k, v in sp.items()}, "algorithmic_bytes": alg}}
+    del dst
+    # ---- group-by with 7 groups: keys folded onto [0, 7) by a fused projection (k % 7), then the same query
+    k7 = ops.project(("mod", "k", 7), {"k": kcol}, length=n, stream=stream)
+    ng = 0
+
+    def gb():
+        nonlocal ng
+        agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
+                                  expected_groups=0 if args.no_hint else 7)
+        agg.set_predicate(">", x_thr)
+        agg.next([k7], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
+        ng = agg.finish(stream=stream)
+    for _ in range(warmup):
+        gb()
+    torch.cuda.synchronize()
+    lib.vnm_set_profiling(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gb()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    sp = _spans(lib, ctypes, [b"agg_estimate", b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final"], steps)
+    lib.vnm_set_profiling(0)
+    kms = sum(sp.values())
+    alg = 16.0 * n + 24.0 * ng
+    out["group-by G=7"] = {"workload": f"SELECT k,sum(v),avg(v) WHERE v>{x_thr} GROUP BY k; N={n:.3g}, 7 groups",
+                           "rows_per_s": n * steps / el, "ms_per_step": el / steps * 1e3, "result_rows": int(ng),
+                           "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9 if kms else 0.0,
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": (alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms else 0.0,
+                                        "kernels_ms": {k: round(v, 4) for k, v in sp.items()}, "algorithmic_bytes": alg}}
+    return out
 
 
 def main():
@@ -341,6 +419,13 @@ def main():
             "exchange_ms_per_step": ({k2: round(v2 / max(args.steps, 1), 3) for k2, v2 in state["phases"].items()}
                                      if "phases" in state else None),
         }
+        if world == 1 and not force_exchange and args.workload == "groupby" and not args.no_also:
+            # the other single-GPU configurations of BASELINE.json on the same resident column, a few steps each
+            # (reported beside the headline; not part of `value`)
+            try:
+                result["also"] = side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream, args)
+            except Exception as e:
+                result["also"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline and args.workload in ("groupby", "filter"):
             try:
                 result["cpu_baseline"] = cpu_baseline(args, x_thr)

@@ -10,7 +10,7 @@ prof() {  # name, rocprof args..., -- bench args
     local name=$1; shift
     local pargs=(); while [ "$1" != "--" ]; do pargs+=("$1"); shift; done; shift
     rm -rf /tmp/rp_$name
-    timeout 600 rocprofv3 "${pargs[@]}" -d /tmp/rp_$name -- python $ROOT/bench.py --no-cpu-baseline "$@" > /tmp/rp_$name.log 2>&1
+    timeout 600 rocprofv3 "${pargs[@]}" -d /tmp/rp_$name -- python $ROOT/bench.py --no-cpu-baseline --no-also "$@" > /tmp/rp_$name.log 2>&1
     local db=$(find /tmp/rp_$name -name '*.db' | head -1)
     echo "# rocprofv3 ${pargs[*]} -- python bench.py --no-cpu-baseline $*"
     python $ROOT/tools/rocpd_summary.py "$db" vnm

@@ -46,6 +46,11 @@ struct FilterArgs {
     int debug;  // timing experiments only: 1 = skip look-back (outputs are wrong)
 };
 
+// number of set bits of `m` in lanes below this one (v_mbcnt: no lane mask to keep in registers)
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 __device__ __forceinline__ uint64_t lanemask_lt() {
     uint32_t lane = __lane_id();
     return lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
@@ -124,11 +129,9 @@ __device__ __forceinline__ int64_t lookback2(unsigned long long* status, unsigne
 }
 
 // =======================================================================================================
-// Filter kernel: one tile per workgroup, tile = blockIdx.x, several workgroups per CU — while one waits for
-// its look-back the others stream.  No ticket atomics (a single ticket word saturates at ~90 returning
-// atomics/us).  Deadlock freedom rests on the dispatcher handing out the workgroups of a 1-D grid in
-// increasing index order within each XCD (round-robin across XCDs): the lowest unfinished tile is always
-// running or next in line on its XCD, so it never waits on a tile that cannot start.
+// Filter: tiles of FB x 2 x CH rows, several workgroups per CU -- while one waits for its look-back the others
+// stream.  No ticket atomics (a single ticket word saturates at ~90 returning atomics/us, and see
+// filter_tile_kernel for what tickets do to the look-back chain).
 //   HOT: float64 predicate column without validity whose survivors are the only output (BASELINE
 //   configs[1]): 16-byte loads, values stay in registers.  Otherwise predicates go through the generic
 //   per-element evaluator and payload columns are gathered after the tile base is known.
@@ -136,11 +139,12 @@ __device__ __forceinline__ int64_t lookback2(unsigned long long* status, unsigne
 // a chunk together cover whole cache lines.
 // =======================================================================================================
 template <int MODE, int FB, int CH, bool HOT, bool STATS>
-__global__ __launch_bounds__(FB) void filter_tile_kernel(FilterArgs a) {
+__device__ __forceinline__ void filter_tile(const FilterArgs& a, const int64_t tile) {
     constexpr int TILE = FB * 2 * CH;
     constexpr int NW = FB / 64;
     constexpr int NSEG = CH * NW;  // (chunk, wave) segments
     static_assert(NSEG <= 64 && CH <= 8, "one segment per lane of wave 0; ranks are packed 8 bits per chunk");
+    // declared here, not passed in: a generic pointer would turn every LDS access into a flat_ instruction
     __shared__ uint32_t s_cnt[NSEG];
     __shared__ uint32_t s_excl[NSEG];
     __shared__ int64_t s_base;
@@ -148,8 +152,6 @@ __global__ __launch_bounds__(FB) void filter_tile_kernel(FilterArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const uint64_t lt = lanemask_lt();
-    const int64_t tile = blockIdx.x;
     // physical element index of this lane's first element in chunk 0; logical row = phys - pred.offset
     const int64_t pb = a.phys_base + tile * TILE + 2 * tid;
     const int64_t first = a.phys_base + tile * TILE - a.pred.offset;
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(FB) void filter_tile_kernel(FilterArgs a) {
             f1 = in1 && pred_eval(a.p, a.pred, r1);
         }
         uint64_t b0 = __ballot(f0), b1 = __ballot(f1);
-        rank[j >> 2] |= (uint32_t)(__popcll(b0 & lt) + __popcll(b1 & lt)) << (8 * (j & 3));
+        rank[j >> 2] |= (lanes_below(b0) + lanes_below(b1)) << (8 * (j & 3));
         flags |= (f0 ? 1u : 0u) << (2 * j) | (f1 ? 1u : 0u) << (2 * j + 1);
         if (lane == 0) s_cnt[j * NW + wave] = __popcll(b0) + __popcll(b1);
     }
@@ -278,6 +280,22 @@ __global__ __launch_bounds__(FB) void filter_tile_kernel(FilterArgs a) {
     }
 }
 
+// Persistent workgroups: tile = blockIdx.x, blockIdx.x + gridDim.x, ..., launched COOPERATIVELY, i.e. the runtime
+// only accepts the grid if every workgroup is co-resident.  A look-back therefore never waits on a workgroup that
+// has not started, whatever the dispatch order (HIP promises none), and the workgroups advance in lockstep rounds:
+// the predecessors of a tile are in flight at the same time as the tile.  Handing tiles out by an atomic ticket
+// instead was measured at 5.8-6.7 ms: a ticket taken ahead of time reserves a tile whose owner is still busy, and
+// every later tile's look-back waits for it; a ticket taken just in time exposes a ~2 us returning atomic per tile.
+// (occupancy target: two 1024-thread workgroups per CU need <= 64 VGPRs AND <= 100 SGPRs on gfx9-family parts)
+template <int MODE, int FB, int CH, bool HOT, bool STATS>
+__global__ __launch_bounds__(FB) __attribute__((amdgpu_waves_per_eu(CH == 4 ? 8 : 5, 8)))
+void filter_tile_kernel(FilterArgs a) {
+    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        filter_tile<MODE, FB, CH, HOT, STATS>(a, tile);
+        __syncthreads();
+    }
+}
+
 // byte-per-row validity -> Arrow bitmap (LSB first), 8 rows per lane
 __global__ void pack_validity_kernel(const uint8_t* bytes, int64_t n, uint8_t* bits) {
     const int64_t nb = (n + 7) >> 3;
@@ -323,18 +341,37 @@ static int launch_filter(FilterArgs& a, int mode, int64_t* out_count, hipStream_
     a.gstatus = scratch + 8 + a.ntiles;
     a.debug = env_int("VNM_FILTER_DEBUG", 0);
     a.lb_sleep = env_int("VNM_FILTER_SLEEP", 16);
+    // persistent workgroups, grid = what is co-resident; see filter_tile_kernel for the two tile hand-out schemes
+    // VNM_FILTER_PERSIST=0 (measurement only): one workgroup per tile, plain launch -- 5-8 % faster, but its
+    // forward progress relies on workgroups being dispatched in index order, which HIP does not promise
+    const bool persist = env_int("VNM_FILTER_PERSIST", 1) != 0;
+    auto launch = [&](auto kernel, int threads) -> int {
+        if (!persist) {
+            kernel<<<(int)a.ntiles, threads, 0, s>>>(a);
+            return 0;
+        }
+        int per_cu = 0;
+        VNM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0));
+        if (per_cu < 1) return set_error("filter: kernel does not fit a CU");
+        int64_t grid = (int64_t)per_cu * device_info().num_cus;
+        if (grid > a.ntiles) grid = a.ntiles;
+        void* params[] = {(void*)&a};
+        VNM_HIP(hipLaunchCooperativeKernel((const void*)kernel, dim3((int)grid), dim3(threads), params, 0, s));
+        return 0;
+    };
     {
     KernelTimer timer("filter_kernel", s);
-    const int grid = (int)a.ntiles;
+    int rc;
     if (hot) {
-        if (fb == 1024 && (a.debug & 8)) filter_tile_kernel<CMP_F64, 1024, 4, true, true><<<grid, 1024, 0, s>>>(a);
-        else if (fb == 1024) filter_tile_kernel<CMP_F64, 1024, 4, true, false><<<grid, 1024, 0, s>>>(a);
-        else filter_tile_kernel<CMP_F64, 512, 8, true, false><<<grid, 512, 0, s>>>(a);
+        if (fb == 1024 && (a.debug & 8)) rc = launch(filter_tile_kernel<CMP_F64, 1024, 4, true, true>, 1024);
+        else if (fb == 1024) rc = launch(filter_tile_kernel<CMP_F64, 1024, 4, true, false>, 1024);
+        else rc = launch(filter_tile_kernel<CMP_F64, 512, 8, true, false>, 512);
     } else if (mode == MODE_MASK) {
-        filter_tile_kernel<MODE_MASK, 512, 8, false, false><<<grid, 512, 0, s>>>(a);
+        rc = launch(filter_tile_kernel<MODE_MASK, 512, 8, false, false>, 512);
     } else {
-        filter_tile_kernel<CMP_I64, 512, 8, false, false><<<grid, 512, 0, s>>>(a);  // generic pred_eval path
+        rc = launch(filter_tile_kernel<CMP_I64, 512, 8, false, false>, 512);  // generic pred_eval path
     }
+    if (rc) { pool_free(scratch); return rc; }
     }
     VNM_HIP(hipGetLastError());
     unsigned long long total = 0;
