@@ -310,7 +310,7 @@ __global__ void pack_validity_kernel(const uint8_t* bytes, int64_t n, uint8_t* b
     }
 }
 
-// tuning knobs (defaults chosen by measurement, profiles/filter_tuning_r01.md)
+// tuning knobs (defaults chosen by measurement, profiles/tuning_log_r01.md)
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
