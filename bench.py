@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="groupby", choices=["groupby", "filter", "topk", "project"])
+    ap.add_argument("--shape", default="hot", choices=["hot", "count_star", "minmax"],
+                    help="group-by function mix: hot = sum,avg (configs[2]); count_star = configs[0]'s query shape "
+                         "(no predicate); minmax = min,max -- the latter two run the generic accumulator kernel")
     ap.add_argument("--no-also", action="store_true", help="skip the side measurements (configs[1] filter, G=7 group-by)")
     ap.add_argument("--limit", type=int, default=10)
     ap.add_argument("--rows", type=float, default=1e9)
@@ -273,11 +276,22 @@ def main():
                                              cols, length=n, stream=stream)
             state["out_rows"] = n
             return
-        agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
-                                  [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
-                                  expected_groups=0 if args.no_hint else groups)
-        agg.set_predicate(">", x_thr)
-        agg.next([kcol], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
+        if args.shape == "count_star":
+            agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.COUNT_STAR, 0, None)],
+                                      expected_groups=0 if args.no_hint else groups)
+            agg.next([kcol], [None], nrows=n, stream=stream)
+        elif args.shape == "minmax":
+            agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
+                                      [(L.MIN, 1, pa.float64()), (L.MAX, 1, pa.float64())],
+                                      expected_groups=0 if args.no_hint else groups)
+            agg.set_predicate(">", x_thr)
+            agg.next([kcol], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
+        else:
+            agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
+                                      [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
+                                      expected_groups=0 if args.no_hint else groups)
+            agg.set_predicate(">", x_thr)
+            agg.next([kcol], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
         ng = agg.finish(stream=stream)
         if world > 1 or force_exchange:
             ng = exchange_and_merge(agg, ng)
@@ -378,6 +392,12 @@ def main():
         alg_bytes = 16.0 * n + 24.0 * out_rows        # read key+value once, write key,sum,avg per group
         workload = (f"configs[2]: SELECT k,sum(v),avg(v) WHERE v>{x_thr} GROUP BY k; N={n:.3g} rows/GPU, "
                     f"G={groups:.3g} int64 keys, s={args.selectivity}")
+        if args.shape == "count_star":
+            alg_bytes = 8.0 * n + 16.0 * out_rows
+            workload = f"SELECT k,count(*) GROUP BY k (configs[0]'s query shape); N={n:.3g} rows/GPU, G={groups:.3g}"
+        elif args.shape == "minmax":
+            workload = (f"SELECT k,min(v),max(v) WHERE v>{x_thr} GROUP BY k; N={n:.3g} rows/GPU, G={groups:.3g}, "
+                        f"s={args.selectivity}")
         pass
     if args.workload not in ("filter",):
         dom = " + ".join(spans) + f" (dominant: {dom_name})" if len(spans) > 1 else dom_name
@@ -421,14 +441,14 @@ def main():
             "exchange_ms_per_step": ({k2: round(v2 / max(args.steps, 1), 3) for k2, v2 in state["phases"].items()}
                                      if "phases" in state else None),
         }
-        if world == 1 and not force_exchange and args.workload == "groupby" and not args.no_also:
+        if world == 1 and not force_exchange and args.workload == "groupby" and args.shape == "hot" and not args.no_also:
             # the other single-GPU configurations of BASELINE.json on the same resident column, a few steps each
             # (reported beside the headline; not part of `value`)
             try:
                 result["also"] = side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream, args)
             except Exception as e:
                 result["also"] = {"error": str(e)}
-        if world == 1 and not args.no_cpu_baseline and args.workload in ("groupby", "filter"):
+        if world == 1 and not args.no_cpu_baseline and args.workload in ("groupby", "filter") and args.shape == "hot":
             try:
                 result["cpu_baseline"] = cpu_baseline(args, x_thr)
             except Exception as e:  # the baseline is reporting only; never fail the bench line on it

@@ -151,6 +151,57 @@ def test_partitioned_path_vs_oracle(groups, levels, with_pred, monkeypatch):
         util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"partitioned G={groups} L={levels} pred={with_pred}")
 
 
+@pytest.mark.parametrize("shape", ["count_star", "minmax_f64", "int64_mix", "uint64_mix", "pred_on_other_column"])
+@pytest.mark.parametrize("levels", [1, 2])
+def test_partitioned_path_generic_programs(shape, levels, monkeypatch):
+    """The partitioned path with a GENERIC accumulator program (anything over at most one 8-byte input column):
+    entries carry (key, raw value bits), the final pass interprets them.  COUNT(*) alone (configs[0]'s query
+    shape), MIN/MAX on the order-preserving encodings, int64 / uint64 SUM and AVG through the 128-bit lanes
+    (values near the int64 range so the decimal128 promotion triggers).  Bit-exact against the oracle."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_PART_L1_MAX", "4" if levels == 2 else "256")
+    rng = np.random.default_rng(len(shape) * 7 + levels)
+    n = 500_003
+    groups = 60_000
+    k = rng.integers(0, groups, n).astype(np.int64) * 1_000_003 - 77
+    k[rng.integers(0, n, 5)] = -1
+    cols = {"k": pa.array(k)}
+    pred = None
+    if shape == "count_star":
+        funcs = [(O.COUNT_STAR, "", "n")]
+    elif shape == "minmax_f64":
+        v = rng.normal(size=n) * 1e3
+        v[rng.integers(0, n, 50)] = np.nan
+        v[rng.integers(0, n, 50)] = -0.0
+        cols["v"] = pa.array(v)
+        funcs = [(O.MIN, "v", "mn"), (O.MAX, "v", "mx"), (O.COUNT, "v", "c")]
+        pred = ("v", "<", 500.0)
+    elif shape == "int64_mix":
+        v = rng.integers(-2**62, 2**62, n).astype(np.int64)
+        cols["v"] = pa.array(v)
+        funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.MIN, "v", "mn"), (O.MAX, "v", "mx"), (O.COUNT_STAR, "", "n")]
+    elif shape == "uint64_mix":
+        v = rng.integers(0, 2**63, n).astype(np.uint64) * np.uint64(2)
+        cols["v"] = pa.array(v)
+        funcs = [(O.SUM, "v", "s"), (O.MAX, "v", "mx"), (O.MIN, "v", "mn")]
+    else:
+        cols["v"] = pa.array(rng.integers(-1000, 1000, n).astype(np.int64))
+        cols["p"] = pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0)
+        funcs = [(O.SUM, "v", "s"), (O.COUNT_STAR, "", "n")]
+        pred = ("p", ">", 64.0)
+    t = pa.table(cols)
+    names = t.schema.names
+    for batches in (t.to_batches(), util.sliced_batches(t, 300_000)):
+        got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=pred, expected_groups=groups)
+        o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+        for b in batches:
+            if pred:
+                op = {"<": O.LT, ">": O.GT}[pred[1]]
+                b = O.filter_batch(b, O.cmp_mask(b.column(names.index(pred[0])), op, pred[2]))
+            o.next(b)
+        util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"partitioned generic {shape} L={levels}")
+
+
 def test_partitioned_path_wrong_hint_falls_back():
     """A hint far below the real group count overflows the per-partition LDS tables; the operator must
     notice and produce the right answer through the general path."""

@@ -58,6 +58,8 @@ struct AggArgs {
     // hot-shape kernel (single 8-byte key, one float64 input column, no validity bitmaps)
     int hot_w_rows, hot_w_valid, hot_w_sum;
     int hot_pred_is_v;
+    int part_generic;  // partitioned path with a generic accumulator program over one 8-byte column (or none)
+    int part_vtype;
 };
 
 // ---- global table primitives ------------------------------------------------------------------------
@@ -892,6 +894,10 @@ struct PartAggArgs {
     GTable g;
     int64_t table_limit;
     unsigned long long* dir;  // [2 * nfinal]: (first dense row, row count) of every final partition, or NULL
+    // generic accumulator program over the entry's value bits (part_agg_generic_kernel)
+    int n_ops, vtype;
+    AccOp ops[AGG_MAX_OPS];
+    int merge[AGG_MAX_WORDS];
 };
 
 __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
@@ -1014,6 +1020,155 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
                 if (a.w_rows >= 0) a.dacc[(int64_t)a.w_rows * a.dstride + pos] = lcnt[i];
                 if (a.w_valid >= 0) a.dacc[(int64_t)a.w_valid * a.dstride + pos] = lcnt[i];
                 if (a.w_sum >= 0) a.dacc[(int64_t)a.w_sum * a.dstride + pos] = lsum[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// value an op contributes for an entry whose input value has the raw bits `vb` (type `vtype`, never NULL here)
+__device__ __forceinline__ uint64_t op_value_bits(int kind, int vtype, uint64_t vb) {
+    switch (kind) {
+        case A_COUNT_ROWS:
+        case A_COUNT_VALID: return 1;
+        case A_SUM_F64: return vtype == VNM_F64 ? vb : (uint64_t)__double_as_longlong((double)(int64_t)vb);
+        case A_SUM_I64: return vb;
+        case A_SUM_LO32: return vb & 0xFFFFFFFFULL;
+        case A_SUM_HI32S: return (uint64_t)((int64_t)vb >> 32);
+        case A_SUM_HI32U: return vb >> 32;
+        default:  // A_MIN / A_MAX on the order-preserving encoding
+            if (vtype == VNM_F64) return enc_f64(__longlong_as_double((long long)vb));
+            if (vtype == VNM_U64) return vb;
+            return enc_i64((int64_t)vb);
+    }
+}
+
+// Final pass of the partitioned path for ANY accumulator program over one 8-byte input column (or none):
+// same protocol as part_agg_kernel, W accumulator words per LDS slot.  LDS: lkey[S + 1], lw[W][S + 1].
+__global__ __launch_bounds__(PA_BLOCK) void part_agg_generic_kernel(PartAggArgs a) {
+    extern __shared__ uint64_t pa_lds[];
+    __shared__ uint32_t s_n, s_fail;
+    __shared__ unsigned s_new;
+    __shared__ unsigned long long s_base;
+    constexpr int ST = PA_SLOTS + 1;
+    uint64_t* lkey = pa_lds;
+    uint64_t* lw = pa_lds + ST;
+    const int W = a.n_words;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t smask = PA_SLOTS - 1;
+    if (tid == 0) s_new = 0;
+    for (int64_t unit = blockIdx.x; unit < a.nfinal * a.splits; unit += gridDim.x) {
+        const int64_t f = unit / a.splits;
+        const int part = (int)(unit % a.splits);
+        for (int i = tid; i < ST; i += PA_BLOCK) lkey[i] = EMPTY;
+        for (int w = 0; w < W; w++) {
+            const uint64_t init = merge_init(a.merge[w]);
+            for (int i = tid; i < ST; i += PA_BLOCK) lw[w * ST + i] = init;
+        }
+        if (tid == 0) { s_n = 0; s_fail = 0; }
+        __syncthreads();
+        for (int rj = part; rj < a.regions; rj += a.splits) {
+            const int64_t region = f * a.regions + rj;
+            const uint32_t n = a.counts[region];
+            const ulonglong2* src = a.entries + region * a.cap;
+            for (uint32_t i0 = 0; i0 < n; i0 += PA_BLOCK * 4) {
+                ulonglong2 eb[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    uint32_t i = i0 + (uint32_t)u * PA_BLOCK + tid;
+                    if (i < n) eb[u] = src[i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    uint32_t i = i0 + (uint32_t)u * PA_BLOCK + tid;
+                    if (i >= n) continue;
+                    const uint64_t key = eb[u].x;
+                    int slot = -1;
+                    if (key == EMPTY) { slot = PA_SLOTS; lkey[slot] = 0; }
+                    else {
+                        uint32_t h = hash_u64(key) & smask;
+                        for (int probe = 0; probe < PA_SLOTS; probe++) {
+                            uint64_t k = *(volatile uint64_t*)&lkey[h];
+                            if (k == key) { slot = (int)h; break; }
+                            if (k == EMPTY) {
+                                uint64_t expected = EMPTY;
+                                if (__hip_atomic_compare_exchange_strong(&lkey[h], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                         __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                                    if (atomicAdd(&s_n, 1u) >= (uint32_t)(PA_SLOTS * 9 / 10)) s_fail = 1;
+                                    slot = (int)h;
+                                    break;
+                                }
+                                if (expected == key) { slot = (int)h; break; }
+                            }
+                            h = (h + 1) & smask;
+                            if ((probe & 15) == 15 && s_fail) break;
+                        }
+                    }
+                    if (slot >= 0) {
+                        for (int o = 0; o < a.n_ops; o++) {
+                            const int w = a.ops[o].word;
+                            l_merge(&lw[w * ST + slot], a.merge[w], op_value_bits(a.ops[o].kind, a.vtype, eb[u].y));
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (s_fail) {  // more groups than the LDS table holds: tell the host to use the general path
+            if (tid == 0) __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (a.to_table) {
+            if (tid == 0) {
+                fold_new(a.g, &s_new);
+                unsigned long long fill = __hip_atomic_load(&a.g.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int64_t)(fill + s_n) > a.table_limit) s_fail = 1;
+            }
+            __syncthreads();
+            if (s_fail) {
+                if (tid == 0) __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            for (int i = tid; i < ST; i += PA_BLOCK) {
+                uint64_t k = lkey[i];
+                if (k == EMPTY) continue;
+                uint64_t slot;
+                if (i < PA_SLOTS) slot = gt_find_single(a.g, k, &s_new);
+                else { slot = a.g.cap; if (ld_agent(&a.g.tag[slot]) == EMPTY) st_agent(&a.g.tag[slot], 0); }
+                for (int w = 0; w < W; w++) {
+                    uint64_t v = lw[w * ST + i];
+                    if (v != merge_init(a.merge[w])) g_merge(&a.g.acc[(uint64_t)w * a.g.stride + slot], a.merge[w], v);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) fold_new(a.g, &s_new);
+            continue;
+        }
+        const uint32_t ngroups = s_n + (lkey[PA_SLOTS] != EMPTY ? 1u : 0u);
+        __syncthreads();
+        if (tid == 0) {
+            s_base = atomicAdd(&a.flags[1], (unsigned long long)ngroups);
+            s_n = 0;
+            if (a.dir) { a.dir[2 * f] = s_base; a.dir[2 * f + 1] = ngroups; }
+        }
+        __syncthreads();
+        if ((int64_t)(s_base + ngroups) > a.dstride) {
+            if (tid == 0) __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        for (int i0 = 0; i0 < ST; i0 += PA_BLOCK) {
+            int i = i0 + tid;
+            bool occ = i < ST && lkey[i] != EMPTY;
+            uint64_t b = __ballot(occ);
+            uint32_t wbase = 0;
+            if (lane == 0 && b) wbase = atomicAdd(&s_n, (uint32_t)__popcll(b));
+            wbase = __shfl(wbase, 0);
+            if (occ) {
+                uint64_t lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+                int64_t pos = (int64_t)s_base + wbase + __popcll(b & lt);
+                a.dkey[pos] = i == PA_SLOTS ? EMPTY : lkey[i];
+                a.dkey[a.dstride + pos] = 0;
+                for (int w = 0; w < W; w++) a.dacc[(int64_t)w * a.dstride + pos] = lw[w * ST + i];
             }
         }
         __syncthreads();
@@ -1552,7 +1707,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
     PartArgs p1{};
     p1.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
-    p1.vp = (const double*)a.cols[0].values + a.cols[0].offset;
+    p1.vp = h->plan.n_cols ? (const double*)a.cols[0].values + a.cols[0].offset : (const double*)p1.kp;
     p1.pp = h->pred_set ? (const double*)a.pred.values + a.pred.offset : nullptr;
     p1.has_pred = h->pred_set; p1.pred_is_v = a.hot_pred_is_v; p1.op = a.p.op; p1.thr = a.p.dval;
     p1.nrows = nrows;
@@ -1634,7 +1789,17 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     {
         KernelTimer timer("agg_part_final", s);
         int g3 = (int)std::min<int64_t>(nfinal * splits, (int64_t)cus * 4);
-        part_agg_kernel<<<g3, PA_BLOCK, 0, s>>>(pa);
+        if (a.part_generic) {
+            pa.n_ops = h->plan.n_ops;
+            pa.vtype = a.part_vtype;
+            for (int o = 0; o < h->plan.n_ops; o++) pa.ops[o] = h->plan.ops[o];
+            for (int w = 0; w < h->plan.n_words; w++) pa.merge[w] = h->plan.merge[w];
+            const size_t lds_bytes = (size_t)(PA_SLOTS + 1) * 8 * (1 + h->plan.n_words);
+            VNM_HIP(hipFuncSetAttribute((const void*)part_agg_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            part_agg_generic_kernel<<<g3, PA_BLOCK, lds_bytes, s>>>(pa);
+        } else {
+            part_agg_kernel<<<g3, PA_BLOCK, 0, s>>>(pa);
+        }
     }
     VNM_HIP(hipGetLastError());
     unsigned long long fl[2];
@@ -1784,8 +1949,26 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         hot = a.pred.type == VNM_F64 && !a.pred.validity && (a.pred.offset & 1) == 0 && a.p.mode == CMP_F64;
         a.hot_pred_is_v = a.pred.values == a.cols[0].values && a.pred.offset == a.cols[0].offset;
     }
+    // the partitioned path also takes ANY accumulator program over at most one 8-byte input column: its entries
+    // carry (key, raw value bits) and only the final pass interprets them
+    bool part_ok = hot;
+    if (!hot && h->single && h->plan.n_cols <= 1 && type_width(keys[0].type) == 8 && !keys[0].validity &&
+        (keys[0].offset & 1) == 0 && getenv("VNM_AGG_NO_PART_GENERIC") == nullptr &&
+        (size_t)(PA_SLOTS + 1) * 8 * (1 + h->plan.n_words) <= 150 * 1024) {
+        part_ok = true;
+        if (h->plan.n_cols == 1) {
+            const vnm_dcol& c = a.cols[0];
+            part_ok = (c.type == VNM_I64 || c.type == VNM_U64 || c.type == VNM_F64) && !c.validity && (c.offset & 1) == 0;
+            a.part_vtype = c.type;
+        }
+        if (part_ok && h->pred_set) {
+            part_ok = a.pred.type == VNM_F64 && !a.pred.validity && (a.pred.offset & 1) == 0 && a.p.mode == CMP_F64;
+            a.hot_pred_is_v = h->plan.n_cols == 1 && a.pred.values == a.cols[0].values && a.pred.offset == a.cols[0].offset;
+        }
+        a.part_generic = part_ok;
+    }
     // no hint from the caller: estimate the group count once from a sample of the first large batch
-    if (hot && h->hint == 0 && !h->estimated && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
+    if (part_ok && h->hint == 0 && !h->estimated && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
         getenv("VNM_AGG_NO_ESTIMATE") == nullptr) {
         int64_t est = 0;
         {
@@ -1796,7 +1979,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         h->estimated = true;
     }
     // many groups: radix-partitioned path (no per-row HBM atomics); falls through when it does not apply
-    if (hot && h->hint > env_i64("VNM_AGG_PART_MIN_GROUPS", 2400) && getenv("VNM_AGG_NO_PART") == nullptr) {
+    if (part_ok && h->hint > env_i64("VNM_AGG_PART_MIN_GROUPS", 2400) && getenv("VNM_AGG_NO_PART") == nullptr) {
         if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
         int prc = partitioned_aggregate(h, a, nrows, s);
         if (prc == 0) { h->rows_seen += nrows; return 0; }
