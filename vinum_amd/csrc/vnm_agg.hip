@@ -22,7 +22,10 @@ namespace vnm {
 constexpr uint64_t EMPTY = ~0ULL;
 constexpr uint64_t LOCKED = ~0ULL - 1;
 constexpr int AGG_BLOCK = 1024;        // LDS kernel: 16 waves, one workgroup per CU
-constexpr int AGG_ROWS_PER_THREAD = 8;
+#ifndef VNM_AGG_R
+#define VNM_AGG_R 8
+#endif
+constexpr int AGG_ROWS_PER_THREAD = VNM_AGG_R;
 constexpr int AGG_TILE = AGG_BLOCK * AGG_ROWS_PER_THREAD;
 constexpr int AGG_LDS_BUDGET = 128 * 1024;
 constexpr int AGG_MAX_PROBES = 48;
@@ -60,6 +63,7 @@ struct AggArgs {
     int hot_pred_is_v;
     int part_generic;  // partitioned path with a generic accumulator program over one 8-byte column (or none)
     int part_vtype;
+    int debug;  // timing experiments (VNM_AGG_DEBUG): 1 = no accumulator ops, 2 = no probes either, 4 = no room check
 };
 
 // ---- global table primitives ------------------------------------------------------------------------
@@ -222,7 +226,121 @@ __device__ __forceinline__ void lds_flush(const AggArgs& a, uint64_t* lkey, uint
     }
 }
 
-__global__ __launch_bounds__(AGG_BLOCK) void agg_lds_kernel(AggArgs a) {
+// Row-major slow path: rows (row0 + r * step for the bits r of `rows`) whose key is known to be valid, not NULL
+// and not the EMPTY sentinel are merged straight into the HBM table.  One ROLLED loop that re-reads what it needs
+// from memory, so it adds a few hundred bytes of code instead of a copy per unrolled row and op.
+__device__ __forceinline__ void agg_rows_to_table(const AggArgs& a, int64_t row0, int step, uint32_t rows, unsigned* s_new) {
+#pragma unroll 1
+    for (int r = 0; rows; r++, rows >>= 1) {
+        if (!(rows & 1u)) continue;
+        const int64_t row = row0 + (int64_t)r * step;
+        const uint64_t gs = gt_find_single(a.g, col_key_bits(a.keys[0], row), s_new);
+#pragma unroll 1
+        for (int o = 0; o < a.plan.n_ops; o++) {
+            const AccOp& op = a.plan.ops[o];
+            uint64_t v;
+            if (op_value(op, a.cols, row, &v)) g_merge(&a.g.acc[(uint64_t)op.word * a.g.stride + gs], a.plan.merge[op.word], v);
+        }
+    }
+}
+
+// raw column bits (as col_raw_bits returns them: zero-extended) -> typed values
+__device__ __forceinline__ int64_t raw_to_i64(int type, uint64_t raw) {
+    switch (type) {
+        case VNM_I8: return (int8_t)raw;
+        case VNM_I16: return (int16_t)raw;
+        case VNM_I32: return (int32_t)raw;
+        default: return (int64_t)raw;  // unsigned types are zero-extended already
+    }
+}
+__device__ __forceinline__ double raw_to_f64(int type, uint64_t raw) {
+    if (type == VNM_F64) return __longlong_as_double((long long)raw);
+    if (type == VNM_F32) return (double)__uint_as_float((uint32_t)raw);
+    return (double)raw_to_i64(type, raw);
+}
+// what op `kind` contributes for a non-NULL input value (same table as op_value)
+__device__ __forceinline__ uint64_t op_value_raw(int kind, int type, uint64_t raw) {
+    switch (kind) {
+        case A_COUNT_ROWS:
+        case A_COUNT_VALID: return 1;
+        case A_SUM_F64: return (uint64_t)__double_as_longlong(raw_to_f64(type, raw));
+        case A_SUM_I64: return (uint64_t)raw_to_i64(type, raw);
+        case A_SUM_LO32: return (uint64_t)raw_to_i64(type, raw) & 0xFFFFFFFFULL;
+        case A_SUM_HI32S: return (uint64_t)(raw_to_i64(type, raw) >> 32);
+        case A_SUM_HI32U: return (uint64_t)raw_to_i64(type, raw) >> 32;
+        default:  // A_MIN / A_MAX on the order-preserving encoding
+            if (type_is_float(type)) return enc_f64(raw_to_f64(type, raw));
+            if (type_is_unsigned(type)) return (uint64_t)raw_to_i64(type, raw);
+            return enc_i64(raw_to_i64(type, raw));
+    }
+}
+
+// raw bits of R rows of a column, all loads issued back to back: the width switch is outside the row loop and
+// nothing branches on loaded data (a load behind a data-dependent branch -- "read the key only if the predicate
+// passed" -- serialises the rows: 16 dependent latencies per tile made the load phase alone cost 5.7 ms)
+template <int R>
+__device__ __forceinline__ void load_raw_rows(const vnm_dcol& c, const int64_t* rowc, uint64_t* raw) {
+    const int64_t off = c.offset;
+    switch (type_width(c.type)) {
+        case 8: {
+            const uint64_t* p = (const uint64_t*)c.values + off;
+#pragma unroll
+            for (int r = 0; r < R; r++) raw[r] = p[rowc[r]];
+            break;
+        }
+        case 4: {
+            const uint32_t* p = (const uint32_t*)c.values + off;
+#pragma unroll
+            for (int r = 0; r < R; r++) raw[r] = p[rowc[r]];
+            break;
+        }
+        case 2: {
+            const uint16_t* p = (const uint16_t*)c.values + off;
+#pragma unroll
+            for (int r = 0; r < R; r++) raw[r] = p[rowc[r]];
+            break;
+        }
+        default: {
+            const uint8_t* p = (const uint8_t*)c.values + off;
+#pragma unroll
+            for (int r = 0; r < R; r++) raw[r] = p[rowc[r]];
+            break;
+        }
+    }
+}
+// validity bits of R rows as a mask (all ones without a bitmap)
+template <int R>
+__device__ __forceinline__ uint32_t load_valid_rows(const vnm_dcol& c, const int64_t* rowc) {
+    if (!c.validity) return (1u << R) - 1u;
+    uint8_t by[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) by[r] = c.validity[(c.offset + rowc[r]) >> 3];
+    uint32_t m = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) m |= (uint32_t)((by[r] >> ((c.offset + rowc[r]) & 7)) & 1) << r;
+    return m;
+}
+// pred_eval on already loaded bits
+__device__ __forceinline__ bool pred_eval_raw(const Predicate& p, int type, uint64_t raw, bool valid) {
+    switch (p.mode) {
+        case CMP_F64: return cmp_apply<double>(p.op, valid ? raw_to_f64(type, raw) : __builtin_nan(""), p.dval);
+        case CMP_F32: return cmp_apply<float>(p.op, __uint_as_float((uint32_t)raw), (float)p.dval);
+        case CMP_I64: return cmp_apply<int64_t>(p.op, raw_to_i64(type, raw), p.ival);
+        case CMP_U64: return cmp_apply<uint64_t>(p.op, (uint64_t)raw_to_i64(type, raw), (uint64_t)p.ival);
+        default: return p.const_result != 0;
+    }
+}
+
+// The tile is processed in phases so that every decode serves AGG_ROWS_PER_THREAD rows and loads of the same
+// kind are in flight together: (A0) predicate + key loads, (A1) LDS probes -> one slot per row, (B) for each
+// accumulator op: load its column for all rows, then merge.  (Row-major interpretation -- one op decode, one
+// dependent load and one type switch per row and op -- ran at 12.7 ms per 1e9 rows for MIN+MAX.)
+// BLK = 1024: one workgroup per CU with the largest LDS table (unknown or larger group counts);
+// BLK = 512: two workgroups per CU with half-size tables, for small known group counts -- the phases of one
+// workgroup (loads / probes / merges, each latency bound on its own) then overlap with the other's.
+template <int BLK>
+__global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
+    constexpr int R = AGG_ROWS_PER_THREAD;
     extern __shared__ uint64_t lds[];
     __shared__ unsigned s_fill, s_new;
     __shared__ int64_t s_tile;
@@ -233,10 +351,10 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_lds_kernel(AggArgs a) {
     uint64_t* lacc = lds + stride;
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < stride; i += AGG_BLOCK) lkey[i] = EMPTY;
+    for (int i = tid; i < stride; i += BLK) lkey[i] = EMPTY;
     for (int w = 0; w < W; w++) {
         uint64_t init = merge_init(a.plan.merge[w]);
-        for (int i = tid; i < stride; i += AGG_BLOCK) lacc[w * stride + i] = init;
+        for (int i = tid; i < stride; i += BLK) lacc[w * stride + i] = init;
     }
     if (tid == 0) { s_fill = 0; s_new = 0; }
     __syncthreads();
@@ -244,71 +362,168 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_lds_kernel(AggArgs a) {
     const unsigned flush_at = (unsigned)(S * 7 / 10);
     const uint32_t smask = (uint32_t)S - 1;
     const vnm_dcol& kc = a.keys[0];
+    const bool key8 = type_width(kc.type) == 8;
     unsigned it = a.progress[blockIdx.x];
     for (;; it++) {
         const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
         if (tile >= a.ntiles) break;
-        if (tid == 0) s_tile = table_has_room(a, &s_new) ? 1 : 0;
-        __syncthreads();
-        if (!s_tile) break;
+        const int64_t row0 = tile * (BLK * AGG_ROWS_PER_THREAD) + tid;
+        // ---- A0: predicate and key of every row (st: 0 = no row, 1 = key, 2 = key equal to the EMPTY sentinel,
+        // 3 = NULL key); the room check's agent-scope read overlaps these loads
+        uint64_t key[R];
+        int st[R];
+        int64_t rowc[R];  // row index clamped into the batch, so every load below is unconditional
+        uint32_t inr = 0;
 #pragma unroll
-        for (int r = 0; r < AGG_ROWS_PER_THREAD; r++) {
-            const int64_t row = tile * AGG_TILE + (int64_t)r * AGG_BLOCK + tid;
-            if (row >= a.nrows) continue;
-            if (a.p.enabled && !pred_eval(a.p, a.pred, row)) continue;
-            int slot = -1;
-            uint64_t key = 0;
-            if (!col_valid(kc, row)) {
-                slot = S + 1;
-                lkey[slot] = 0;
-            } else {
-                key = col_key_bits(kc, row);
-                if (key == EMPTY) {
-                    slot = S;
-                    lkey[slot] = 0;
-                } else {
-                    uint32_t h = hash_u64(key) & smask;
-                    for (int probe = 0; probe < AGG_MAX_PROBES; probe++) {
-                        uint64_t k = *(volatile uint64_t*)&lkey[h];
-                        if (k == key) { slot = (int)h; break; }
-                        if (k == EMPTY) {
-                            uint64_t expected = EMPTY;
-                            if (__hip_atomic_compare_exchange_strong(&lkey[h], &expected, key, __ATOMIC_RELAXED,
-                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                                atomicAdd(&s_fill, 1u);
-                                slot = (int)h;
-                                break;
-                            }
-                            if (expected == key) { slot = (int)h; break; }
-                        }
-                        h = (h + 1) & smask;
+        for (int r = 0; r < R; r++) {
+            const int64_t row = row0 + (int64_t)r * BLK;
+            if (row < a.nrows) inr |= 1u << r;
+            rowc[r] = row < a.nrows ? row : a.nrows - 1;
+        }
+        uint32_t pass = inr;
+        {
+            uint64_t praw[R];
+            uint32_t pvalid = 0;
+            if (a.p.enabled) {
+                load_raw_rows<R>(a.pred, rowc, praw);
+                pvalid = load_valid_rows<R>(a.pred, rowc);
+            }
+            load_raw_rows<R>(kc, rowc, key);
+            const uint32_t kvalid = load_valid_rows<R>(kc, rowc);
+            if (a.p.enabled) {
+                // one uniform switch per tile, straight-line code per row
+                const int pt = a.pred.type;
+#define VNM_PRED_LOOP(EXPR)                                                                   \
+    _Pragma("unroll") for (int r = 0; r < R; r++) { if (!(EXPR)) pass &= ~(1u << r); }
+                switch (a.p.mode) {
+                    case CMP_F64:
+                        if (pt == VNM_F64) { VNM_PRED_LOOP(cmp_apply<double>(a.p.op, ((pvalid >> r) & 1u) ? __longlong_as_double((long long)praw[r]) : __builtin_nan(""), a.p.dval)) }
+                        else { VNM_PRED_LOOP(cmp_apply<double>(a.p.op, ((pvalid >> r) & 1u) ? raw_to_f64(pt, praw[r]) : __builtin_nan(""), a.p.dval)) }
+                        break;
+                    case CMP_F32: VNM_PRED_LOOP(cmp_apply<float>(a.p.op, __uint_as_float((uint32_t)praw[r]), (float)a.p.dval)) break;
+                    case CMP_I64: VNM_PRED_LOOP(cmp_apply<int64_t>(a.p.op, raw_to_i64(pt, praw[r]), a.p.ival)) break;
+                    case CMP_U64: VNM_PRED_LOOP(cmp_apply<uint64_t>(a.p.op, (uint64_t)raw_to_i64(pt, praw[r]), (uint64_t)a.p.ival)) break;
+                    default: if (!a.p.const_result) pass = 0; break;
+                }
+#undef VNM_PRED_LOOP
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                st[r] = 0;
+                if ((pass >> r) & 1u) {
+                    if (!((kvalid >> r) & 1u)) st[r] = 3;
+                    else {
+                        // raw bits -> key bits (array_iterators.h:215-217: ints sign-extended, floats by bit pattern)
+                        if (!key8) key[r] = type_is_float(kc.type) ? key[r] : (uint64_t)raw_to_i64(kc.type, key[r]);
+                        st[r] = key[r] == EMPTY ? 2 : 1;
                     }
                 }
             }
-            if (slot >= 0) {
-                for (int o = 0; o < a.plan.n_ops; o++) {
-                    const AccOp& op = a.plan.ops[o];
-                    uint64_t v;
-                    if (op_value(op, a.cols, row, &v)) l_merge(&lacc[op.word * stride + slot], a.plan.merge[op.word], v);
-                }
-            } else {
-                // LDS table saturated for this key: go straight to the HBM table
-                uint64_t gs = gt_find_single(a.g, key, &s_new);
-                for (int o = 0; o < a.plan.n_ops; o++) {
-                    const AccOp& op = a.plan.ops[o];
-                    uint64_t v;
-                    if (op_value(op, a.cols, row, &v)) g_merge(&a.g.acc[(uint64_t)op.word * a.g.stride + gs], a.plan.merge[op.word], v);
+        }
+        if (!(a.debug & 4)) {
+        if (tid == 0) s_tile = table_has_room(a, &s_new) ? 1 : 0;
+        __syncthreads();
+        if (!s_tile) break;
+        }
+        // ---- A1: one LDS slot per row (-1 = no row, -2 = LDS table saturated for this key: straight to HBM)
+        int slot[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            slot[r] = -1;
+            if (st[r] == 3) { slot[r] = S + 1; lkey[S + 1] = 0; }
+            else if (st[r] == 2) { slot[r] = S; lkey[S] = 0; }
+            else if (st[r] == 1 && !(a.debug & 2)) {
+                slot[r] = -2;
+                uint32_t h = hash_u64(key[r]) & smask;
+                for (int probe = 0; probe < AGG_MAX_PROBES; probe++) {
+                    uint64_t k = *(volatile uint64_t*)&lkey[h];
+                    if (k == key[r]) { slot[r] = (int)h; break; }
+                    if (k == EMPTY) {
+                        uint64_t expected = EMPTY;
+                        if (__hip_atomic_compare_exchange_strong(&lkey[h], &expected, key[r], __ATOMIC_RELAXED,
+                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                            atomicAdd(&s_fill, 1u);
+                            slot[r] = (int)h;
+                            break;
+                        }
+                        if (expected == key[r]) { slot[r] = (int)h; break; }
+                    }
+                    h = (h + 1) & smask;
                 }
             }
         }
+        // keys the LDS table could not take go straight to the HBM table, out of line (this code must not be
+        // replicated per row and op: at 69 KB the kernel overflowed the 64 KB instruction cache)
+        {
+            uint32_t sat = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) if (slot[r] == -2) sat |= 1u << r;
+            if (sat) agg_rows_to_table(a, row0, BLK, sat, &s_new);
+        }
+        // ---- B: one accumulator op at a time over all rows of the lane
+        for (int o = 0; o < ((a.debug & 1) ? 0 : a.plan.n_ops); o++) {
+            const AccOp op = a.plan.ops[o];
+            const int mk = a.plan.merge[op.word];
+            uint64_t raw[R];
+            uint32_t have = 0;  // rows that contribute to this op
+            if (op.kind == A_COUNT_ROWS) {
+#pragma unroll
+                for (int r = 0; r < R; r++) { raw[r] = 0; if (slot[r] != -1) have |= 1u << r; }
+            } else {
+                const vnm_dcol& c = a.cols[op.col];
+                load_raw_rows<R>(c, rowc, raw);
+                const uint32_t cvalid = load_valid_rows<R>(c, rowc);
+#pragma unroll
+                for (int r = 0; r < R; r++) if (slot[r] != -1 && ((cvalid >> r) & 1u)) have |= 1u << r;
+            }
+            const int vtype = op.kind == A_COUNT_ROWS ? VNM_U64 : a.cols[op.col].type;
+            uint64_t* const wl = lacc + op.word * stride;
+            // sign / zero extension of narrow integers without a per-row type switch: (x << sh) >> sh
+            const int sh = 64 - 8 * type_width(vtype);
+            const bool is_f = type_is_float(vtype), is_f32 = vtype == VNM_F32, is_u = type_is_unsigned(vtype);
+#define VNM_I64(RAW) (is_u ? (int64_t)(RAW) : (int64_t)((RAW) << sh) >> sh)
+#define VNM_F64V(RAW) (is_f ? (is_f32 ? (double)__uint_as_float((uint32_t)(RAW)) : __longlong_as_double((long long)(RAW))) : (double)VNM_I64(RAW))
+            // LDS atomic for slot >= 0; saturated keys (slot -2, rare) are redone row-major by agg_rows_to_table
+#define VNM_MERGE_LOOP(MK, VAL, LDSOP)                                                                      \
+    _Pragma("unroll") for (int r = 0; r < R; r++) {                                                         \
+        if (!((have >> r) & 1u) || slot[r] < 0) continue;                                                   \
+        const uint64_t v = (VAL);                                                                           \
+        LDSOP;                                                                                              \
+    }
+#define VNM_LADD(V) __hip_atomic_fetch_add(&wl[slot[r]], (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+            switch (op.kind) {
+                case A_COUNT_ROWS:
+                case A_COUNT_VALID: VNM_MERGE_LOOP(M_ADD_U64, 1ULL, VNM_LADD(v)) break;
+                case A_SUM_F64:
+                    VNM_MERGE_LOOP(M_ADD_F64, (uint64_t)__double_as_longlong(VNM_F64V(raw[r])),
+                                   __hip_atomic_fetch_add((double*)&wl[slot[r]], __longlong_as_double((long long)v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                    break;
+                case A_SUM_I64: VNM_MERGE_LOOP(M_ADD_U64, (uint64_t)VNM_I64(raw[r]), VNM_LADD(v)) break;
+                case A_SUM_LO32: VNM_MERGE_LOOP(M_ADD_U64, (uint64_t)VNM_I64(raw[r]) & 0xFFFFFFFFULL, VNM_LADD(v)) break;
+                case A_SUM_HI32S: VNM_MERGE_LOOP(M_ADD_U64, (uint64_t)(VNM_I64(raw[r]) >> 32), VNM_LADD(v)) break;
+                case A_SUM_HI32U: VNM_MERGE_LOOP(M_ADD_U64, (uint64_t)VNM_I64(raw[r]) >> 32, VNM_LADD(v)) break;
+                case A_MIN:
+                    VNM_MERGE_LOOP(M_MIN_U64, is_f ? enc_f64(VNM_F64V(raw[r])) : (is_u ? raw[r] : enc_i64(VNM_I64(raw[r]))),
+                                   __hip_atomic_fetch_min(&wl[slot[r]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                    break;
+                default:  // A_MAX
+                    VNM_MERGE_LOOP(M_MAX_U64, is_f ? enc_f64(VNM_F64V(raw[r])) : (is_u ? raw[r] : enc_i64(VNM_I64(raw[r]))),
+                                   __hip_atomic_fetch_max(&wl[slot[r]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                    break;
+            }
+#undef VNM_LADD
+#undef VNM_MERGE_LOOP
+#undef VNM_F64V
+#undef VNM_I64
+        }
         __syncthreads();
         if (s_fill > flush_at) {
-            lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK, &s_new);
+            lds_flush(a, lkey, lacc, S, tid, BLK, &s_new);
             __syncthreads();
             if (tid == 0) s_fill = 0;
         }
     }
-    lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK, &s_new);
+    lds_flush(a, lkey, lacc, S, tid, BLK, &s_new);
     __syncthreads();
     if (tid == 0) { fold_new(a.g, &s_new); a.progress[blockIdx.x] = it; }
 }
@@ -1537,10 +1752,10 @@ uint64_t pow2_at_least(uint64_t x) {
     return p;
 }
 
-int lds_slots_for(const AggPlan& p) {
+int lds_slots_for(const AggPlan& p, int budget = AGG_LDS_BUDGET) {
     int per_slot = 8 * (1 + p.n_words);
     int s = 1;
-    while ((s * 2 + 2) * per_slot <= AGG_LDS_BUDGET) s *= 2;
+    while ((s * 2 + 2) * per_slot <= budget) s *= 2;
     if (s > 8192) s = 8192;
     return s;
 }
@@ -1913,6 +2128,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     }
     a.nrows = nrows;
     a.ntiles = (nrows + AGG_TILE - 1) / AGG_TILE;
+    a.debug = (int)env_i64("VNM_AGG_DEBUG", 0);
     const int cus = device_info().num_cus;
 
     if (h->plan.n_keys == 0) {
@@ -1987,9 +2203,14 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     }
     VNM_TRY(ensure_table(h, nrows, s));
     if (hot) a.ntiles = (nrows + HOT_TILE - 1) / HOT_TILE;
-    int grid = h->single ? cus : cus * 4;
+    // generic single-key kernel, small known group count: two 512-thread workgroups per CU with 64 KB tables
+    const int S2 = lds_slots_for(h->plan, 64 * 1024);
+    const bool twin = !hot && h->single && h->hint > 0 && h->hint <= (int64_t)S2 * 6 / 10 && getenv("VNM_AGG_TWIN") != nullptr;  // measured slower (9.9-13.8 vs 9.9 ms): off
+    const int lds_tile = twin ? 512 * AGG_ROWS_PER_THREAD : AGG_TILE;
+    if (twin) { a.lds_slots = S2; a.ntiles = (nrows + lds_tile - 1) / lds_tile; }
+    int grid = h->single ? (twin ? cus * 2 : cus) : cus * 4;
     if (grid > a.ntiles) grid = (int)a.ntiles;
-    a.margin = (int64_t)grid * (h->single ? (S + 2 + (hot ? HOT_TILE : AGG_TILE)) : AGG_TILE);
+    a.margin = (int64_t)grid * (h->single ? (a.lds_slots + 2 + (hot ? HOT_TILE : lds_tile)) : AGG_TILE);
     unsigned int* progress = (unsigned int*)pool_alloc((size_t)grid * 4);
     if (!progress) return 1;
     VNM_HIP(hipMemsetAsync(progress, 0, (size_t)grid * 4, s));
@@ -2014,9 +2235,14 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
             else VNM_HOT(true, false);
 #undef VNM_HOT
         } else if (h->single) {
-            size_t lds_bytes = (size_t)(S + 2) * 8 * (1 + h->plan.n_words);
-            VNM_HIP(hipFuncSetAttribute((const void*)agg_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            agg_lds_kernel<<<grid, AGG_BLOCK, lds_bytes, s>>>(a);
+            size_t lds_bytes = (size_t)(a.lds_slots + 2) * 8 * (1 + h->plan.n_words);
+            if (twin) {
+                VNM_HIP(hipFuncSetAttribute((const void*)agg_lds_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                agg_lds_kernel<512><<<grid, 512, lds_bytes, s>>>(a);
+            } else {
+                VNM_HIP(hipFuncSetAttribute((const void*)agg_lds_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                agg_lds_kernel<1024><<<grid, 1024, lds_bytes, s>>>(a);
+            }
         } else {
             agg_wide_kernel<<<grid, 256, 0, s>>>(a);
         }
