@@ -1,5 +1,8 @@
 // Runtime plumbing of libvinum_hip.so: init, errors, caching device allocator, staging, memcpy helpers.
+#include <condition_variable>
+#include <cstring>
 #include <map>
+#include <thread>
 #include <unordered_map>
 
 #include "vnm_common.hpp"
@@ -162,6 +165,71 @@ struct Stager {
 };
 Stager& stager() { static Stager s; return s; }
 std::mutex g_stage_mu;
+
+// One thread fills a pinned buffer at ~13 GB/s, the DMA engine drains it at ~50: a few helper threads copy
+// slices of every chunk so the PCIe link, not memcpy, bounds the staging (VNM_STAGE_THREADS, default 4).
+class CopyPool {
+public:
+    explicit CopyPool(int helpers) {
+        for (int i = 0; i < helpers; i++) workers_.emplace_back([this, i] { run(i); });
+    }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; gen_++; }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void copy(void* dst, const void* src, size_t n) {
+        const int parts = (int)workers_.size() + 1;
+        if (parts == 1 || n < (4u << 20)) { memcpy(dst, src, n); return; }
+        const size_t slice = ((n + parts - 1) / parts + 4095) & ~(size_t)4095;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            dst_ = (uint8_t*)dst; src_ = (const uint8_t*)src; n_ = n; slice_ = slice;
+            pending_ = (int)workers_.size();
+            gen_++;
+        }
+        cv_.notify_all();
+        memcpy(dst, src, slice < n ? slice : n);  // slice 0 on the calling thread
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [this] { return pending_ == 0; });
+    }
+private:
+    void run(int idx) {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> g(mu_);
+            cv_.wait(g, [&] { return gen_ != seen; });
+            seen = gen_;
+            if (stop_) return;
+            const size_t lo = slice_ * (size_t)(idx + 1);
+            uint8_t* d = dst_; const uint8_t* s = src_;
+            const size_t n = n_, sl = slice_;
+            g.unlock();
+            if (lo < n) memcpy(d + lo, s + lo, lo + sl < n ? sl : n - lo);
+            g.lock();
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    uint8_t* dst_ = nullptr; const uint8_t* src_ = nullptr;
+    size_t n_ = 0, slice_ = 0;
+    int pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+CopyPool& copy_pool() {
+    static CopyPool* p = [] {
+        const char* e = getenv("VNM_STAGE_THREADS");
+        int t = e ? atoi(e) : 4;
+        unsigned hw = std::thread::hardware_concurrency();
+        if (hw && (unsigned)t > hw) t = (int)hw;
+        if (t < 1) t = 1;
+        return new CopyPool(t - 1);  // leaked on purpose: joining threads from a static destructor is fragile
+    }();
+    return *p;
+}
 }  // namespace
 
 // host (pageable) -> device, through the pinned ring; returns when the last DMA has been enqueued AND completed
@@ -180,7 +248,7 @@ static int staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t stre
     while (off < bytes) {
         size_t n = bytes - off < STAGE_BYTES ? bytes - off : STAGE_BYTES;
         if (used[slot]) VNM_HIP(hipEventSynchronize(st.done[slot]));  // the DMA that read this buffer is finished
-        memcpy(st.pin[slot], (const uint8_t*)src + off, n);
+        copy_pool().copy(st.pin[slot], (const uint8_t*)src + off, n);
         VNM_HIP(hipMemcpyAsync((uint8_t*)dst + off, st.pin[slot], n, hipMemcpyHostToDevice, st.copy));
         VNM_HIP(hipEventRecord(st.done[slot], st.copy));
         used[slot] = true;
@@ -293,12 +361,17 @@ int vnm_stage_column(const void* host_values, const uint8_t* host_validity, int6
     out->type = type;
     out->length = length;
     size_t vbytes = (size_t)length * w;
-    void* dv = pool_alloc(vbytes ? vbytes : 1);
+    // With a validity bitmap the values are staged with (offset & 7) elements of left padding: the bitmap is
+    // copied from its first BYTE, so bit (offset & 7) of the device bitmap belongs to logical element 0, and one
+    // offset then serves both buffers.
+    const int shift = host_validity ? (int)(offset & 7) : 0;
+    size_t pbytes = ((size_t)length + shift) * w;
+    void* dv = pool_alloc(pbytes ? pbytes : 1);
     if (!dv) return 1;
     if (vbytes)
-        VNM_TRY(staged_h2d(dv, (const uint8_t*)host_values + (size_t)offset * w, vbytes, s));
+        VNM_TRY(staged_h2d((uint8_t*)dv + (size_t)shift * w, (const uint8_t*)host_values + (size_t)offset * w, vbytes, s));
     out->values = dv;
-    out->offset = 0;
+    out->offset = shift;
     if (host_validity) {
         int64_t first_byte = offset >> 3;
         int64_t last_byte = (offset + length + 7) >> 3;
@@ -307,21 +380,6 @@ int vnm_stage_column(const void* host_values, const uint8_t* host_validity, int6
         if (!db) return 1;
         if (nb) VNM_TRY(staged_h2d(db, host_validity + first_byte, nb, s));
         out->validity = (const uint8_t*)db;
-        // values were copied from element `offset` on (device element 0), the bitmap from byte
-        // `first_byte` on, so bit (offset & 7) of the device bitmap belongs to device element 0.
-        // Encode that by shifting the VALUES view: element i lives at values[(i + shift) - shift].
-        int shift = (int)(offset & 7);
-        if (shift) {
-            // re-stage values with `shift` elements of left padding so one offset serves both buffers
-            pool_free(dv);
-            size_t pbytes = ((size_t)length + shift) * w;
-            dv = pool_alloc(pbytes ? pbytes : 1);
-            if (!dv) return 1;
-            if (vbytes)
-                VNM_TRY(staged_h2d((uint8_t*)dv + (size_t)shift * w, (const uint8_t*)host_values + (size_t)offset * w, vbytes, s));
-            out->values = dv;
-            out->offset = shift;
-        }
     }
     return 0;
 }
