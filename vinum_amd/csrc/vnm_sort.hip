@@ -44,14 +44,19 @@ __device__ __forceinline__ void encode_key(const vnm_dcol& c, int64_t row, int d
 }
 
 // code[i], cls[i] for row idx[i] (idx == NULL: identity)
-__global__ void sort_encode_kernel(vnm_dcol c, int desc, const uint32_t* idx, int64_t n, uint64_t* code, uint8_t* cls) {
+// any_cls (optional): set to 1 when some row is NaN or NULL (class != 0) -- lets the caller skip the class pass
+__global__ void sort_encode_kernel(vnm_dcol c, int desc, const uint32_t* idx, int64_t n, uint64_t* code, uint8_t* cls,
+                                   unsigned long long* any_cls) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool special = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         uint64_t e; uint32_t k;
         encode_key(c, idx ? (int64_t)idx[i] : i, desc, &e, &k);
         code[i] = e;
         cls[i] = (uint8_t)k;
+        special = special || k != 0;
     }
+    if (any_cls && __ballot(special) && (threadIdx.x & 63) == 0) atomicOr(any_cls, 1ULL);
 }
 
 __global__ void sort_iota_kernel(uint32_t* idx, int64_t n) {
@@ -108,51 +113,106 @@ __global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* counts, int n
     }
 }
 
-// stable scatter: sub-tiles of RS_BLOCK consecutive elements; rank among equal digits = (elements of earlier
-// waves) + (earlier lanes of the own wave, via eight ballots)
+// Stable scatter of one radix pass.  Tiles of RS_TILE consecutive elements; wave w owns elements
+// [w * 512, (w + 1) * 512) of the tile and ranks them on its own (eight 64-element sub-rounds: same-digit lanes found
+// with eight ballots, a wave-private digit counter in LDS carries the running count), so ranking needs no
+// workgroup barrier.  The tile is then laid out by digit in LDS (digit offsets + per-wave bases keep it stable) and
+// copied out in runs: consecutive lanes write consecutive elements of one digit (~32 per digit and tile), instead
+// of one isolated 8 + 4 byte store per element (the first version: 18.7 ms per pass over 1e9 elements).
+constexpr int RS_SUB = 8;                     // sub-rounds per wave and tile
+constexpr int RS_TILE = RS_BLOCK * RS_SUB;    // 8192 elements
 __global__ __launch_bounds__(RS_BLOCK) void radix_scatter_kernel(const uint64_t* code, const uint32_t* val, int64_t n, int64_t per,
                                                                  int shift, const unsigned long long* offsets, int nb,
                                                                  uint64_t* code_out, uint32_t* val_out) {
+    extern __shared__ uint64_t rs_lds[];
+    uint64_t* scode = rs_lds;                                  // [RS_TILE]
+    uint32_t* sval = (uint32_t*)(rs_lds + RS_TILE);            // [RS_TILE]
+    uint32_t* wcnt = sval + RS_TILE;                           // [RS_WAVES][256] per-wave digit counts -> bases
+    uint32_t* off = wcnt + RS_WAVES * 256;                     // [256] start of each digit inside the staged tile
+    uint32_t* tot = off + 256;                                 // [256] elements of each digit in this tile
     __shared__ unsigned long long run[256];
-    __shared__ uint32_t wcount[RS_WAVES][256];
+    __shared__ uint32_t wtot[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 256) run[tid] = offsets[(int64_t)tid * nb + blockIdx.x];
-    for (int i = tid; i < RS_WAVES * 256; i += RS_BLOCK) (&wcount[0][0])[i] = 0;
+    for (int i = tid; i < RS_WAVES * 256; i += RS_BLOCK) wcnt[i] = 0;
     __syncthreads();
-    const uint64_t lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
-    int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
-    for (int64_t base = lo; base < hi; base += RS_BLOCK) {
-        int64_t i = base + tid;
-        bool in = i < hi;
-        uint64_t c = in ? code[i] : 0;
-        uint32_t v = in ? val[i] : 0;
-        uint32_t dg = (uint32_t)(c >> shift) & 255u;
-        // lanes of this wave with the same digit
-        uint64_t m = __ballot(in);
+    uint32_t* mycnt = wcnt + wave * 256;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (int64_t base = lo; base < hi; base += RS_TILE) {
+        // ---- load + rank inside the wave
+        uint64_t c[RS_SUB];
+        uint32_t v[RS_SUB], lpos[RS_SUB];
+        const int64_t wbase = base + (int64_t)wave * (64 * RS_SUB) + lane;
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
-            uint64_t bb = __ballot((dg >> b) & 1u);
-            m &= ((dg >> b) & 1u) ? bb : ~bb;
+        for (int k = 0; k < RS_SUB; k++) {
+            const int64_t i = wbase + k * 64;
+            c[k] = i < hi ? code[i] : 0;
+            v[k] = i < hi ? val[i] : 0;
         }
-        uint32_t rank_in_wave = __popcll(m & lt);
-        if (in && rank_in_wave == 0) wcount[wave][dg] = __popcll(m);
-        __syncthreads();
-        if (in) {
-            unsigned long long pos = run[dg] + rank_in_wave;
-            for (int w = 0; w < wave; w++) pos += wcount[w][dg];
-            code_out[pos] = c;
-            val_out[pos] = v;
+#pragma unroll
+        for (int k = 0; k < RS_SUB; k++) {
+            const bool in = wbase + k * 64 < hi;
+            const uint32_t dg = (uint32_t)(c[k] >> shift) & 255u;
+            uint64_t m = __ballot(in);
+#pragma unroll
+            for (int bit = 0; bit < 8; bit++) {
+                const uint64_t bb = __ballot((dg >> bit) & 1u);
+                m &= ((dg >> bit) & 1u) ? bb : ~bb;
+            }
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            lpos[k] = 0;
+            if (in) {
+                lpos[k] = mycnt[dg] + before;                 // LDS ops of one wave execute in order
+                if (before == 0) mycnt[dg] += (uint32_t)__popcll(m);
+            }
         }
         __syncthreads();
+        // ---- per digit: wave counts -> exclusive bases over the waves, tile total; then digit offsets
         if (tid < 256) {
             uint32_t s = 0;
 #pragma unroll
-            for (int w = 0; w < RS_WAVES; w++) { s += wcount[w][tid]; wcount[w][tid] = 0; }
-            run[tid] += s;
+            for (int w = 0; w < RS_WAVES; w++) { uint32_t t = wcnt[w * 256 + tid]; wcnt[w * 256 + tid] = s; s += t; }
+            tot[tid] = s;
+            uint32_t inc = s;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+            off[tid] = inc - s;
+            if (lane == 63) wtot[wave] = inc;
         }
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t add = 0;
+            for (int w = 0; w < wave; w++) add += wtot[w];
+            off[tid] += add;
+        }
+        __syncthreads();
+        // ---- stage by digit
+#pragma unroll
+        for (int k = 0; k < RS_SUB; k++) {
+            if (wbase + k * 64 < hi) {
+                const uint32_t dg = (uint32_t)(c[k] >> shift) & 255u;
+                const uint32_t pos = off[dg] + mycnt[dg] + lpos[k];
+                scode[pos] = c[k];
+                sval[pos] = v[k];
+            }
+        }
+        __syncthreads();
+        // ---- copy out in runs
+        const uint32_t total = (uint32_t)((hi - base) < RS_TILE ? (hi - base) : RS_TILE);
+        for (uint32_t i = tid; i < total; i += RS_BLOCK) {
+            const uint64_t cc = scode[i];
+            const uint32_t dg = (uint32_t)(cc >> shift) & 255u;
+            const unsigned long long pos = run[dg] + (i - off[dg]);
+            code_out[pos] = cc;
+            val_out[pos] = sval[i];
+        }
+        __syncthreads();
+        if (tid < 256) run[tid] += tot[tid];
+        for (int i = tid; i < RS_WAVES * 256; i += RS_BLOCK) wcnt[i] = 0;
         __syncthreads();
     }
 }
+constexpr size_t RS_LDS_BYTES = (size_t)RS_TILE * 12 + (size_t)RS_WAVES * 256 * 4 + 2 * 256 * 4;
 
 struct RadixBufs {
     uint64_t* code[2];
@@ -187,16 +247,24 @@ static void radix_free(RadixBufs* r) {
 }
 
 // sort (code[cur], val[cur]) stably by the bytes of code that are not constant
-static int radix_sort_codes(RadixBufs* r, int64_t n, hipStream_t s) {
-    if (n <= 1) return 0;
-    unsigned long long init[2] = {0ULL, ~0ULL}, red[2];
+// extra (optional): receives r->red[4], a flag word the caller's previous kernel may have set (read back with the
+// same synchronisation as the digit masks)
+static int radix_sort_codes(RadixBufs* r, int64_t n, hipStream_t s, unsigned long long* extra = nullptr) {
+    if (n <= 1) { if (extra) { VNM_HIP(hipMemcpyAsync(extra, r->red + 4, 8, hipMemcpyDeviceToHost, s)); VNM_HIP(hipStreamSynchronize(s)); } return 0; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        VNM_HIP(hipFuncSetAttribute((const void*)radix_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS_LDS_BYTES));
+        attr_set = true;
+    }
+    unsigned long long init[2] = {0ULL, ~0ULL}, red[5];
     VNM_HIP(hipMemcpyAsync(r->red, init, 16, hipMemcpyHostToDevice, s));
     int g = device_info().num_cus * 4;
     int64_t need = (n + 255) / 256;
     if (g > need) g = (int)need;
     sort_orand_kernel<<<g, 256, 0, s>>>(r->code[r->cur], n, r->red);
-    VNM_HIP(hipMemcpyAsync(red, r->red, 16, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipMemcpyAsync(red, r->red, 40, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
+    if (extra) *extra = red[4];
     uint64_t differ = red[0] ^ red[1];
     for (int byte = 0; byte < 8; byte++) {
         if (!((differ >> (8 * byte)) & 0xFF)) continue;
@@ -204,8 +272,8 @@ static int radix_sort_codes(RadixBufs* r, int64_t n, hipStream_t s) {
         int shift = 8 * byte;
         radix_hist_kernel<<<r->nb, 256, 0, s>>>(r->code[r->cur], n, r->per, shift, r->counts);
         radix_scan_kernel<<<1, 256, 0, s>>>(r->counts, r->nb, r->offsets);
-        radix_scatter_kernel<<<r->nb, RS_BLOCK, 0, s>>>(r->code[r->cur], r->val[r->cur], n, r->per, shift, r->offsets, r->nb,
-                                                        r->code[r->cur ^ 1], r->val[r->cur ^ 1]);
+        radix_scatter_kernel<<<r->nb, RS_BLOCK, RS_LDS_BYTES, s>>>(r->code[r->cur], r->val[r->cur], n, r->per, shift, r->offsets,
+                                                                   r->nb, r->code[r->cur ^ 1], r->val[r->cur ^ 1]);
         r->cur ^= 1;
     }
     VNM_HIP(hipGetLastError());
@@ -332,13 +400,15 @@ static int full_sort(int n_keys, const vnm_dcol* keys, const int* orders, int64_
     sort_iota_kernel<<<grid_for(n), 256, 0, s>>>(r->val[r->cur], n);
     for (int k = n_keys - 1; k >= 0; k--) {
         // codes of key k in the current row order
-        sort_encode_kernel<<<grid_for(n), 256, 0, s>>>(keys[k], orders[k] == VNM_DESC, r->val[r->cur], n, r->code[r->cur], cls);
-        VNM_TRY(radix_sort_codes(r, n, s));
+        VNM_HIP(hipMemsetAsync(r->red + 4, 0, 8, s));
+        sort_encode_kernel<<<grid_for(n), 256, 0, s>>>(keys[k], orders[k] == VNM_DESC, r->val[r->cur], n, r->code[r->cur], cls, r->red + 4);
+        unsigned long long any_special = 0;
+        VNM_TRY(radix_sort_codes(r, n, s, &any_special));
         // class pass (values < NaN < NULL), more significant than the code: cls was computed in the order BEFORE
         // the code passes, so recompute it in the current order
-        bool has_cls = keys[k].validity != nullptr || type_is_float(keys[k].type);
+        bool has_cls = (keys[k].validity != nullptr || type_is_float(keys[k].type)) && any_special != 0;  // no NaN / NULL at all: nothing to do
         if (has_cls) {
-            sort_encode_kernel<<<grid_for(n), 256, 0, s>>>(keys[k], orders[k] == VNM_DESC, r->val[r->cur], n, r->code[r->cur ^ 1], cls);
+            sort_encode_kernel<<<grid_for(n), 256, 0, s>>>(keys[k], orders[k] == VNM_DESC, r->val[r->cur], n, r->code[r->cur ^ 1], cls, nullptr);
             sort_cls_to_code_kernel<<<grid_for(n), 256, 0, s>>>(cls, n, r->code[r->cur]);
             VNM_TRY(radix_sort_codes(r, n, s));
         }
