@@ -363,6 +363,10 @@ __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
     const uint32_t smask = (uint32_t)S - 1;
     const vnm_dcol& kc = a.keys[0];
     const bool key8 = type_width(kc.type) == 8;
+    // The HBM table only grows when this workgroup flushes or when its LDS table is too full to take a key, so the
+    // room check (an agent-scope read + a barrier per tile) is only repeated after a flush or above half load;
+    // the margin the host reserves per workgroup (one LDS table + one tile) covers everything in between.
+    bool need_check = true;
     unsigned it = a.progress[blockIdx.x];
     for (;; it++) {
         const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
@@ -420,10 +424,10 @@ __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
                 }
             }
         }
-        if (!(a.debug & 4)) {
-        if (tid == 0) s_tile = table_has_room(a, &s_new) ? 1 : 0;
-        __syncthreads();
-        if (!s_tile) break;
+        if (need_check) {
+            if (tid == 0) s_tile = table_has_room(a, &s_new) ? 1 : 0;
+            __syncthreads();
+            if (!s_tile) break;
         }
         // ---- A1: one LDS slot per row (-1 = no row, -2 = LDS table saturated for this key: straight to HBM)
         int slot[R];
@@ -517,7 +521,9 @@ __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
 #undef VNM_I64
         }
         __syncthreads();
-        if (s_fill > flush_at) {
+        const unsigned fill_now = s_fill;
+        need_check = fill_now > (unsigned)S / 2;
+        if (fill_now > flush_at) {
             lds_flush(a, lkey, lacc, S, tid, BLK, &s_new);
             __syncthreads();
             if (tid == 0) s_fill = 0;
@@ -603,13 +609,16 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
     const int op = a.p.op;
     const double thr = a.p.dval;
 
+    bool need_check = true;
     unsigned it = a.progress[blockIdx.x];
     for (;; it++) {
         const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
         if (tile >= a.ntiles) break;
-        if (tid == 0) s_go = table_has_room(a, &s_new) ? 1 : 0;
-        __syncthreads();
-        if (!s_go) break;
+        if (need_check) {  // see agg_lds_kernel
+            if (tid == 0) s_go = table_has_room(a, &s_new) ? 1 : 0;
+            __syncthreads();
+            if (!s_go) break;
+        }
         const int64_t base = tile * HOT_TILE + 2 * tid;
         ulonglong2 kk[HOT_UNROLL];
         double2 vv[HOT_UNROLL], pv[HOT_UNROLL];
@@ -637,7 +646,9 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                 }
         }
         __syncthreads();
-        if (s_fill > flush_at) {
+        const unsigned fill_now = s_fill;
+        need_check = fill_now > (unsigned)S / 2;
+        if (fill_now > flush_at) {
             lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK, &s_new);
             __syncthreads();
             if (tid == 0) s_fill = 0;
@@ -2195,7 +2206,10 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         h->estimated = true;
     }
     // many groups: radix-partitioned path (no per-row HBM atomics); falls through when it does not apply
-    if (part_ok && h->hint > env_i64("VNM_AGG_PART_MIN_GROUPS", 2400) && getenv("VNM_AGG_NO_PART") == nullptr) {
+    // ... from the point where the groups stop fitting the LDS table of the scan kernel (flush storms otherwise:
+    // MIN+MAX with 2000 groups and a 2048-slot table ran at 38 ms)
+    const int64_t part_min = env_i64("VNM_AGG_PART_MIN_GROUPS", std::min<int64_t>(2400, (int64_t)S * 6 / 10));
+    if (part_ok && h->hint > part_min && getenv("VNM_AGG_NO_PART") == nullptr) {
         if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
         int prc = partitioned_aggregate(h, a, nrows, s);
         if (prc == 0) { h->rows_seen += nrows; return 0; }
