@@ -61,6 +61,10 @@ struct AggArgs {
     // hot-shape kernel (single 8-byte key, one float64 input column, no validity bitmaps)
     int hot_w_rows, hot_w_valid, hot_w_sum;
     int hot_pred_is_v;
+    // extended hot shape: every accumulator kind over ONE 8-byte input column without NULLs (or no input at all)
+    int hot_w[9];      // word of each AccKind, -1 = absent
+    int hot_vtype;     // VNM_F64 / VNM_I64 / VNM_U64
+    int hot_has_val;
     int part_generic;  // partitioned path with a generic accumulator program over one 8-byte column (or none)
     int part_vtype;
     int debug;  // timing experiments (VNM_AGG_DEBUG): 1 = no accumulator ops, 2 = no probes either, 4 = no room check
@@ -537,7 +541,9 @@ __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
 // =======================================================================================================
 // Kernel 1h: the hot shape of the north-star query
 //     SELECT k, {sum|avg|count}(v), count(*) [WHERE p > X] GROUP BY k
-// with an 8-byte key, a float64 input, no validity bitmaps and even Arrow offsets.  Same LDS table and
+// with an 8-byte key, a float64 input, no validity bitmaps and even Arrow offsets -- and, with the same code,
+// every other accumulator kind (MIN / MAX, int64 / uint64 sums and 128-bit sums) over ONE 8-byte input column
+// without NULLs, or no input column at all (COUNT(*): configs[0]'s query shape).  Same LDS table and
 // flush protocol as agg_lds_kernel, but every lane issues 16-byte loads (two rows), four requests per
 // column in flight, the predicate / hash / accumulate sequence is straight-line code, and the block only
 // synchronises once per 8192 rows (to decide about flushing).
@@ -545,43 +551,58 @@ __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
 constexpr int HOT_UNROLL = 4;
 constexpr int HOT_TILE = AGG_BLOCK * 2 * HOT_UNROLL;  // 8192 rows per block iteration
 
-__device__ __forceinline__ void hot_row(const AggArgs& a, uint64_t* lkey, uint64_t* lacc, int S, int stride, uint32_t smask,
-                                        unsigned* s_fill, unsigned* s_new, uint64_t key, double v) {
-    int slot = -1;
-    if (key == EMPTY) {
-        slot = S;
-        lkey[slot] = 0;
-    } else {
-        uint32_t h = hash_u64(key) & smask;
-        for (int probe = 0; probe < AGG_MAX_PROBES; probe++) {
-            uint64_t k = *(volatile uint64_t*)&lkey[h];
-            if (k == key) { slot = (int)h; break; }
-            if (k == EMPTY) {
-                uint64_t expected = EMPTY;
-                if (__hip_atomic_compare_exchange_strong(&lkey[h], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                    atomicAdd(s_fill, 1u);
-                    slot = (int)h;
-                    break;
-                }
-                if (expected == key) { slot = (int)h; break; }
+// probe / claim the LDS slot of `key`; -1 = the table is saturated for this key
+__device__ __forceinline__ int hot_slot(uint64_t* lkey, int S, uint32_t smask, unsigned* s_fill, uint64_t key) {
+    if (key == EMPTY) { lkey[S] = 0; return S; }
+    uint32_t h = hash_u64(key) & smask;
+    for (int probe = 0; probe < AGG_MAX_PROBES; probe++) {
+        uint64_t k = *(volatile uint64_t*)&lkey[h];
+        if (k == key) return (int)h;
+        if (k == EMPTY) {
+            uint64_t expected = EMPTY;
+            if (__hip_atomic_compare_exchange_strong(&lkey[h], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                atomicAdd(s_fill, 1u);
+                return (int)h;
             }
-            h = (h + 1) & smask;
+            if (expected == key) return (int)h;
         }
+        h = (h + 1) & smask;
     }
-    if (slot >= 0) {
-        if (a.hot_w_rows >= 0) __hip_atomic_fetch_add(&lacc[a.hot_w_rows * stride + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (a.hot_w_valid >= 0) __hip_atomic_fetch_add(&lacc[a.hot_w_valid * stride + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (a.hot_w_sum >= 0) __hip_atomic_fetch_add((double*)&lacc[a.hot_w_sum * stride + slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
-        uint64_t gs = gt_find_single(a.g, key, s_new);
-        if (a.hot_w_rows >= 0) g_merge(&a.g.acc[(uint64_t)a.hot_w_rows * a.g.stride + gs], M_ADD_U64, 1);
-        if (a.hot_w_valid >= 0) g_merge(&a.g.acc[(uint64_t)a.hot_w_valid * a.g.stride + gs], M_ADD_U64, 1);
-        if (a.hot_w_sum >= 0) g_merge(&a.g.acc[(uint64_t)a.hot_w_sum * a.g.stride + gs], M_ADD_F64, (uint64_t)__double_as_longlong(v));
-    }
+    return -1;
 }
 
-template <bool HAS_PRED, bool PRED_IS_V>
+// every accumulator word this query has, updated for a row whose input value has the raw bits vb
+// (SIMPLE: only COUNT(*), COUNT and the float64 sum can be present -- the north-star shape keeps its short path)
+template <bool SIMPLE>
+__device__ __forceinline__ void hot_accumulate(const AggArgs& a, uint64_t* lacc, int stride, int slot, uint64_t vb) {
+    if (SIMPLE) {
+        if (a.hot_w_rows >= 0) __hip_atomic_fetch_add(&lacc[a.hot_w_rows * stride + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (a.hot_w_valid >= 0) __hip_atomic_fetch_add(&lacc[a.hot_w_valid * stride + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (a.hot_w_sum >= 0) __hip_atomic_fetch_add((double*)&lacc[a.hot_w_sum * stride + slot], __longlong_as_double((long long)vb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+#define VNM_W(K) (lacc + a.hot_w[K] * stride + slot)
+#define VNM_ADD(K, V) if (a.hot_w[K] >= 0) __hip_atomic_fetch_add(VNM_W(K), (uint64_t)(V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+    VNM_ADD(A_COUNT_ROWS, 1ULL);
+    VNM_ADD(A_COUNT_VALID, 1ULL);
+    if (a.hot_w[A_SUM_F64] >= 0)
+        __hip_atomic_fetch_add((double*)VNM_W(A_SUM_F64), __longlong_as_double((long long)vb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    VNM_ADD(A_SUM_I64, vb);
+    VNM_ADD(A_SUM_LO32, vb & 0xFFFFFFFFULL);
+    VNM_ADD(A_SUM_HI32S, (int64_t)vb >> 32);
+    VNM_ADD(A_SUM_HI32U, vb >> 32);
+    if (a.hot_w[A_MIN] >= 0 || a.hot_w[A_MAX] >= 0) {
+        const uint64_t e = a.hot_vtype == VNM_F64 ? enc_f64(__longlong_as_double((long long)vb))
+                                                  : (a.hot_vtype == VNM_U64 ? vb : enc_i64((int64_t)vb));
+        if (a.hot_w[A_MIN] >= 0) __hip_atomic_fetch_min(VNM_W(A_MIN), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (a.hot_w[A_MAX] >= 0) __hip_atomic_fetch_max(VNM_W(A_MAX), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#undef VNM_ADD
+#undef VNM_W
+}
+
+template <bool HAS_PRED, bool PRED_IS_V, bool HAS_VAL, bool SIMPLE>
 __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
     extern __shared__ uint64_t lds[];
     __shared__ unsigned s_fill, s_new;
@@ -604,7 +625,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
     const unsigned flush_at = (unsigned)(S * 6 / 10);
     const uint32_t smask = (uint32_t)S - 1;
     const uint64_t* kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
-    const double* vp = (const double*)a.cols[0].values + a.cols[0].offset;
+    const uint64_t* vp = HAS_VAL ? (const uint64_t*)a.cols[0].values + a.cols[0].offset : kp;
     const double* pp = (const double*)a.pred.values + a.pred.offset;
     const int op = a.p.op;
     const double thr = a.p.dval;
@@ -620,31 +641,48 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
             if (!s_go) break;
         }
         const int64_t base = tile * HOT_TILE + 2 * tid;
-        ulonglong2 kk[HOT_UNROLL];
-        double2 vv[HOT_UNROLL], pv[HOT_UNROLL];
+        uint32_t sat0 = 0, sat1 = 0;  // rows (even / odd element of chunk u) whose key the LDS table could not take
         if (base + (int64_t)(HOT_UNROLL - 1) * 2 * AGG_BLOCK + 1 < a.nrows) {
+            ulonglong2 kk[HOT_UNROLL], vv[HOT_UNROLL];
+            double2 pv[HOT_UNROLL];
 #pragma unroll
             for (int u = 0; u < HOT_UNROLL; u++) {
                 int64_t r = base + (int64_t)u * 2 * AGG_BLOCK;
                 kk[u] = *(const ulonglong2*)(kp + r);
-                vv[u] = *(const double2*)(vp + r);
+                if (HAS_VAL) vv[u] = *(const ulonglong2*)(vp + r);
                 if (HAS_PRED && !PRED_IS_V) pv[u] = *(const double2*)(pp + r);
             }
 #pragma unroll
             for (int u = 0; u < HOT_UNROLL; u++) {
-                double p0 = PRED_IS_V ? vv[u].x : pv[u].x, p1 = PRED_IS_V ? vv[u].y : pv[u].y;
-                if (!HAS_PRED || cmp_apply<double>(op, p0, thr)) hot_row(a, lkey, lacc, S, stride, smask, &s_fill, &s_new, kk[u].x, vv[u].x);
-                if (!HAS_PRED || cmp_apply<double>(op, p1, thr)) hot_row(a, lkey, lacc, S, stride, smask, &s_fill, &s_new, kk[u].y, vv[u].y);
+                const uint64_t v0 = HAS_VAL ? vv[u].x : 0, v1 = HAS_VAL ? vv[u].y : 0;
+                const double p0 = PRED_IS_V ? __longlong_as_double((long long)v0) : pv[u].x;
+                const double p1 = PRED_IS_V ? __longlong_as_double((long long)v1) : pv[u].y;
+                if (!HAS_PRED || cmp_apply<double>(op, p0, thr)) {
+                    int slot = hot_slot(lkey, S, smask, &s_fill, kk[u].x);
+                    if (slot >= 0) hot_accumulate<SIMPLE>(a, lacc, stride, slot, v0); else sat0 |= 1u << u;
+                }
+                if (!HAS_PRED || cmp_apply<double>(op, p1, thr)) {
+                    int slot = hot_slot(lkey, S, smask, &s_fill, kk[u].y);
+                    if (slot >= 0) hot_accumulate<SIMPLE>(a, lacc, stride, slot, v1); else sat1 |= 1u << u;
+                }
             }
         } else {
             for (int u = 0; u < HOT_UNROLL; u++)
                 for (int e = 0; e < 2; e++) {
                     int64_t r = base + (int64_t)u * 2 * AGG_BLOCK + e;
                     if (r >= a.nrows) continue;
-                    double p = PRED_IS_V ? vp[r] : (HAS_PRED ? pp[r] : 0.0);
-                    if (!HAS_PRED || cmp_apply<double>(op, p, thr)) hot_row(a, lkey, lacc, S, stride, smask, &s_fill, &s_new, kp[r], vp[r]);
+                    const uint64_t vb = HAS_VAL ? vp[r] : 0;
+                    const double p = PRED_IS_V ? __longlong_as_double((long long)vb) : (HAS_PRED ? pp[r] : 0.0);
+                    if (HAS_PRED && !cmp_apply<double>(op, p, thr)) continue;
+                    int slot = hot_slot(lkey, S, smask, &s_fill, kp[r]);
+                    if (slot >= 0) hot_accumulate<SIMPLE>(a, lacc, stride, slot, vb);
+                    else if (e == 0) sat0 |= 1u << u;
+                    else sat1 |= 1u << u;
                 }
         }
+        // saturated keys: straight to the HBM table, out of line (rows base + e + u * 2 * AGG_BLOCK)
+        if (sat0) agg_rows_to_table(a, base, 2 * AGG_BLOCK, sat0, &s_new);
+        if (sat1) agg_rows_to_table(a, base + 1, 2 * AGG_BLOCK, sat1, &s_new);
         __syncthreads();
         const unsigned fill_now = s_fill;
         need_check = fill_now > (unsigned)S / 2;
@@ -2159,22 +2197,37 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     a.lds_slots = S;
     // hot shape: one 8-byte key, every function in {COUNT(*), COUNT, SUM, AVG} over ONE float64 column,
     // float64 predicate column (or none), no validity bitmaps, even offsets (16-byte aligned pairs)
-    bool hot = h->single && h->plan.n_cols == 1 && type_width(keys[0].type) == 8 && !keys[0].validity &&
-               (keys[0].offset & 1) == 0 && a.cols[0].type == VNM_F64 && !a.cols[0].validity && (a.cols[0].offset & 1) == 0 &&
-               getenv("VNM_AGG_NO_HOT") == nullptr;
+    // hot_scan: what agg_hot_kernel takes (any accumulator kind over at most one 8-byte column without NULLs);
+    // hot: the subset {COUNT(*), COUNT, SUM, AVG} of a float64 column that part_agg_kernel is specialised for
+    bool hot_scan = h->single && h->plan.n_cols <= 1 && type_width(keys[0].type) == 8 && !keys[0].validity &&
+                    (keys[0].offset & 1) == 0 && getenv("VNM_AGG_NO_HOT") == nullptr;
+    a.hot_has_val = h->plan.n_cols == 1;
+    a.hot_vtype = VNM_U64;
+    if (hot_scan && a.hot_has_val) {
+        const vnm_dcol& c = a.cols[0];
+        hot_scan = (c.type == VNM_F64 || c.type == VNM_I64 || c.type == VNM_U64) && !c.validity && (c.offset & 1) == 0;
+        a.hot_vtype = c.type;
+    }
     a.hot_w_rows = a.hot_w_valid = a.hot_w_sum = -1;
-    if (hot) {
-        for (int o = 0; o < h->plan.n_ops && hot; o++) {
+    for (int k = 0; k < 9; k++) a.hot_w[k] = -1;
+    bool hot = hot_scan && a.hot_has_val && a.hot_vtype == VNM_F64;
+    if (hot_scan) {
+        for (int o = 0; o < h->plan.n_ops; o++) {
             const AccOp& op = h->plan.ops[o];
+            if (op.kind < 0 || op.kind > A_MAX || a.hot_w[op.kind] >= 0) { hot_scan = false; break; }  // one word per kind
+            if (op.kind == A_SUM_F64 && a.hot_vtype != VNM_F64) { hot_scan = false; break; }
+            a.hot_w[op.kind] = op.word;
             if (op.kind == A_COUNT_ROWS) a.hot_w_rows = op.word;
             else if (op.kind == A_COUNT_VALID) a.hot_w_valid = op.word;
             else if (op.kind == A_SUM_F64) a.hot_w_sum = op.word;
             else hot = false;
         }
     }
-    if (hot && h->pred_set) {
-        hot = a.pred.type == VNM_F64 && !a.pred.validity && (a.pred.offset & 1) == 0 && a.p.mode == CMP_F64;
-        a.hot_pred_is_v = a.pred.values == a.cols[0].values && a.pred.offset == a.cols[0].offset;
+    hot = hot && hot_scan;
+    if (hot_scan && h->pred_set) {
+        hot_scan = a.pred.type == VNM_F64 && !a.pred.validity && (a.pred.offset & 1) == 0 && a.p.mode == CMP_F64;
+        hot = hot && hot_scan;
+        a.hot_pred_is_v = a.hot_has_val && a.hot_vtype == VNM_F64 && a.pred.values == a.cols[0].values && a.pred.offset == a.cols[0].offset;
     }
     // the partitioned path also takes ANY accumulator program over at most one 8-byte input column: its entries
     // carry (key, raw value bits) and only the final pass interprets them
@@ -2216,15 +2269,15 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         if (prc == 1) return 1;
     }
     VNM_TRY(ensure_table(h, nrows, s));
-    if (hot) a.ntiles = (nrows + HOT_TILE - 1) / HOT_TILE;
+    if (hot_scan) a.ntiles = (nrows + HOT_TILE - 1) / HOT_TILE;
     // generic single-key kernel, small known group count: two 512-thread workgroups per CU with 64 KB tables
     const int S2 = lds_slots_for(h->plan, 64 * 1024);
-    const bool twin = !hot && h->single && h->hint > 0 && h->hint <= (int64_t)S2 * 6 / 10 && getenv("VNM_AGG_TWIN") != nullptr;  // measured slower (9.9-13.8 vs 9.9 ms): off
+    const bool twin = !hot_scan && h->single && h->hint > 0 && h->hint <= (int64_t)S2 * 6 / 10 && getenv("VNM_AGG_TWIN") != nullptr;  // measured slower (9.9-13.8 vs 9.9 ms): off
     const int lds_tile = twin ? 512 * AGG_ROWS_PER_THREAD : AGG_TILE;
     if (twin) { a.lds_slots = S2; a.ntiles = (nrows + lds_tile - 1) / lds_tile; }
     int grid = h->single ? (twin ? cus * 2 : cus) : cus * 4;
     if (grid > a.ntiles) grid = (int)a.ntiles;
-    a.margin = (int64_t)grid * (h->single ? (a.lds_slots + 2 + (hot ? HOT_TILE : lds_tile)) : AGG_TILE);
+    a.margin = (int64_t)grid * (h->single ? (a.lds_slots + 2 + (hot_scan ? HOT_TILE : lds_tile)) : AGG_TILE);
     unsigned int* progress = (unsigned int*)pool_alloc((size_t)grid * 4);
     if (!progress) return 1;
     VNM_HIP(hipMemsetAsync(progress, 0, (size_t)grid * 4, s));
@@ -2237,16 +2290,21 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         a.fill_limit = (int64_t)(h->g.cap * 7 / 10);
         {
         KernelTimer timer("agg_scan", s);
-        if (hot) {
+        if (hot_scan) {
             size_t lds_bytes = (size_t)(S + 2) * 8 * (1 + h->plan.n_words);
-#define VNM_HOT(P, V)                                                                                          \
+#define VNM_HOT(P, V, HV, SI)                                                                                  \
     do {                                                                                                       \
-        VNM_HIP(hipFuncSetAttribute((const void*)agg_hot_kernel<P, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-        agg_hot_kernel<P, V><<<grid, AGG_BLOCK, lds_bytes, s>>>(a);                                            \
+        VNM_HIP(hipFuncSetAttribute((const void*)agg_hot_kernel<P, V, HV, SI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        agg_hot_kernel<P, V, HV, SI><<<grid, AGG_BLOCK, lds_bytes, s>>>(a);                                    \
     } while (0)
-            if (!h->pred_set) VNM_HOT(false, false);
-            else if (a.hot_pred_is_v) VNM_HOT(true, true);
-            else VNM_HOT(true, false);
+            if (hot) {  // the north-star shape
+                if (!h->pred_set) VNM_HOT(false, false, true, true);
+                else if (a.hot_pred_is_v) VNM_HOT(true, true, true, true);
+                else VNM_HOT(true, false, true, true);
+            } else if (!a.hot_has_val) { if (h->pred_set) VNM_HOT(true, false, false, false); else VNM_HOT(false, false, false, false); }
+            else if (!h->pred_set) VNM_HOT(false, false, true, false);
+            else if (a.hot_pred_is_v) VNM_HOT(true, true, true, false);
+            else VNM_HOT(true, false, true, false);
 #undef VNM_HOT
         } else if (h->single) {
             size_t lds_bytes = (size_t)(a.lds_slots + 2) * 8 * (1 + h->plan.n_words);
