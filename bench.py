@@ -198,6 +198,32 @@ def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": (alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms else 0.0,
                                         "kernels_ms": {k: round(v, 4) for k, v in sp.items()}, "algorithmic_bytes": alg}}
+    # ---- configs[0]'s query shape at scale: SELECT k, count(*) GROUP BY k (no predicate, key column only)
+    def gc():
+        nonlocal ng
+        agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.COUNT_STAR, None, None)],
+                                  expected_groups=0 if args.no_hint else 7)
+        agg.next([k7], [None], nrows=n, stream=stream)
+        ng = agg.finish(stream=stream)
+    for _ in range(warmup):
+        gc()
+    torch.cuda.synchronize()
+    lib.vnm_set_profiling(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gc()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    sp = _spans(lib, ctypes, [b"agg_estimate", b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final"], steps)
+    lib.vnm_set_profiling(0)
+    kms = sum(sp.values())
+    alg = 8.0 * n + 16.0 * ng
+    out["configs[0] query shape"] = {"workload": f"SELECT k,count(*) GROUP BY k; N={n:.3g}, 7 groups (the 1M-row CSV query of configs[0], at scale)",
+                                     "rows_per_s": n * steps / el, "ms_per_step": el / steps * 1e3, "result_rows": int(ng),
+                                     "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9 if kms else 0.0,
+                                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                  "frac": (alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms else 0.0,
+                                                  "kernels_ms": {k: round(v, 4) for k, v in sp.items()}, "algorithmic_bytes": alg}}
     return out
 
 
