@@ -17,6 +17,9 @@
 
 #include "vnm_common.hpp"
 
+#ifndef VNM_F16W
+#define VNM_F16W 4
+#endif
 namespace vnm {
 
 constexpr int F_MAX_PAYLOAD = 8;
@@ -143,7 +146,7 @@ __device__ __forceinline__ void filter_tile(const FilterArgs& a, const int64_t t
     constexpr int TILE = FB * 2 * CH;
     constexpr int NW = FB / 64;
     constexpr int NSEG = CH * NW;  // (chunk, wave) segments
-    static_assert(NSEG <= 64 && CH <= 8, "one segment per lane of wave 0; ranks are packed 8 bits per chunk");
+    static_assert(NSEG <= 64 && CH <= 16, "one segment per lane of wave 0; ranks are packed 8 bits per chunk");
     // declared here, not passed in: a generic pointer would turn every LDS access into a flat_ instruction
     __shared__ uint32_t s_cnt[NSEG];
     __shared__ uint32_t s_excl[NSEG];
@@ -177,7 +180,7 @@ __device__ __forceinline__ void filter_tile(const FilterArgs& a, const int64_t t
             }
         }
     }
-    uint32_t flags = 0, rank[2] = {0, 0};  // 2 flag bits and an 8-bit in-wave rank per chunk
+    uint32_t flags = 0, rank[(CH + 3) / 4] = {};  // 2 flag bits and an 8-bit in-wave rank per chunk
 #pragma unroll
     for (int j = 0; j < CH; j++) {
         const int64_t r0 = pb - a.pred.offset + (int64_t)j * (2 * FB), r1 = r0 + 1;
@@ -288,7 +291,7 @@ __device__ __forceinline__ void filter_tile(const FilterArgs& a, const int64_t t
 // every later tile's look-back waits for it; a ticket taken just in time exposes a ~2 us returning atomic per tile.
 // (occupancy target: two 1024-thread workgroups per CU need <= 64 VGPRs AND <= 100 SGPRs on gfx9-family parts)
 template <int MODE, int FB, int CH, bool HOT, bool STATS>
-__global__ __launch_bounds__(FB) __attribute__((amdgpu_waves_per_eu(CH == 4 ? 8 : 5, 8)))
+__global__ __launch_bounds__(FB) __attribute__((amdgpu_waves_per_eu(CH == 4 ? 8 : (CH == 16 ? VNM_F16W : 5), 8)))
 void filter_tile_kernel(FilterArgs a) {
     for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         filter_tile<MODE, FB, CH, HOT, STATS>(a, tile);
@@ -319,9 +322,11 @@ static int env_int(const char* name, int dflt) {
 static int launch_filter(FilterArgs& a, int mode, int64_t* out_count, hipStream_t s) {
     const bool hot = mode == CMP_F64 && a.pred.type == VNM_F64 && !a.pred.validity &&
                      (a.n_payload == 0 || (a.n_payload == 1 && a.reuse_pred && !a.out_valid[0]));
-    // hot: 1024 threads x 8 rows (43 VGPRs, two workgroups per CU); generic: 512 threads x 16 rows
-    const int fb = hot ? (env_int("VNM_FILTER_THREADS", 1024) >= 1024 ? 1024 : 512) : 512;
-    const int ch = hot && fb == 1024 ? 4 : 8;
+    // hot: 256 threads x 32 rows (8192-row tiles, four workgroups = four tiles in flight per CU: 2.71 ms; 1024 x 8
+    // rows, two per CU: 2.94); generic: 512 threads x 16 rows
+    const int fbe = env_int("VNM_FILTER_THREADS", 256);
+    const int fb = hot ? (fbe >= 1024 ? 1024 : (fbe >= 512 ? 512 : 256)) : 512;
+    const int ch = hot && fb == 1024 ? 4 : (hot && fb == 256 ? 16 : 8);
     const int tile_rows = fb * 2 * ch;
     a.phys_base = a.pred.values ? (a.pred.offset & ~1LL) : 0;
     int64_t span = (a.pred.values ? a.pred.offset : 0) + a.length - a.phys_base;
@@ -365,6 +370,7 @@ static int launch_filter(FilterArgs& a, int mode, int64_t* out_count, hipStream_
     if (hot) {
         if (fb == 1024 && (a.debug & 8)) rc = launch(filter_tile_kernel<CMP_F64, 1024, 4, true, true>, 1024);
         else if (fb == 1024) rc = launch(filter_tile_kernel<CMP_F64, 1024, 4, true, false>, 1024);
+        else if (fb == 256) rc = launch(filter_tile_kernel<CMP_F64, 256, 16, true, false>, 256);
         else rc = launch(filter_tile_kernel<CMP_F64, 512, 8, true, false>, 512);
     } else if (mode == MODE_MASK) {
         rc = launch(filter_tile_kernel<MODE_MASK, 512, 8, false, false>, 512);
