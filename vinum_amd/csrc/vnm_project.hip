@@ -23,6 +23,7 @@ constexpr int PJ_BLOCK = 256;
 #endif
 constexpr int PJ_R = VNM_PJ_R;                 // rows per lane per tile: one opcode decode serves PJ_R rows
 constexpr int PJ_TILE = PJ_BLOCK * PJ_R;
+static_assert(PJ_R % 2 == 0, "a lane owns pairs of adjacent rows");
 
 struct PIns {
     int op;
@@ -72,7 +73,10 @@ __global__ __launch_bounds__(PJ_BLOCK) void project_kernel(ProjArgs a) {
     const int64_t ntiles = (a.length + PJ_TILE - 1) / PJ_TILE;
 #define STK(level, r) stk[((level) * PJ_R + (r)) * PJ_BLOCK + tid]
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t base = tile * PJ_TILE + tid;
+        // a lane owns PAIRS of adjacent rows (2 tid, 2 tid + 1) + k * 2 * PJ_BLOCK, so 8-byte columns move 16 bytes per
+        // request whenever the Arrow offset is even
+        const int64_t base = tile * PJ_TILE + 2 * tid;
+        const bool full_tile = (tile + 1) * PJ_TILE <= a.length;
         uint64_t tos[PJ_R];
 #pragma unroll
         for (int r = 0; r < PJ_R; r++) tos[r] = 0;
@@ -88,11 +92,21 @@ __global__ __launch_bounds__(PJ_BLOCK) void project_kernel(ProjArgs a) {
                     for (int r = 0; r < PJ_R; r++) STK(sp - 1, r) = tos[r];
                 }
                 sp++;
-                if (op == VNM_EX_COL) {
+                if (op == VNM_EX_COL && full_tile && !a.cols[in.arg].validity && (a.cols[in.arg].offset & 1) == 0 &&
+                    (a.cols[in.arg].type == VNM_F64 || (!in.is_f && type_width(a.cols[in.arg].type) == 8))) {
+                    // 8-byte column pushed with its own type: raw bits, 16 bytes per request
+                    const uint64_t* p = (const uint64_t*)a.cols[in.arg].values + a.cols[in.arg].offset + base;
+#pragma unroll
+                    for (int k = 0; k < PJ_R / 2; k++) {
+                        const ulonglong2 t = *(const ulonglong2*)(p + k * (2 * PJ_BLOCK));
+                        tos[2 * k] = t.x;
+                        tos[2 * k + 1] = t.y;
+                    }
+                } else if (op == VNM_EX_COL) {
                     const vnm_dcol& c = a.cols[in.arg];
 #pragma unroll
                     for (int r = 0; r < PJ_R; r++) {
-                        const int64_t row = base + r * PJ_BLOCK;
+                        const int64_t row = base + (r >> 1) * (2 * PJ_BLOCK) + (r & 1);
                         uint64_t v = 0;
                         if (row < a.length) {
                             if (in.is_f) {
@@ -115,7 +129,7 @@ __global__ __launch_bounds__(PJ_BLOCK) void project_kernel(ProjArgs a) {
                     const bool want_null = op == VNM_EX_IS_NULL;
 #pragma unroll
                     for (int r = 0; r < PJ_R; r++) {
-                        const int64_t row = base + r * PJ_BLOCK;
+                        const int64_t row = base + (r >> 1) * (2 * PJ_BLOCK) + (r & 1);
                         bool valid = row < a.length ? col_valid(c, row) : true;
                         tos[r] = (valid != want_null) ? 1ULL : 0ULL;
                     }
@@ -137,14 +151,23 @@ __global__ __launch_bounds__(PJ_BLOCK) void project_kernel(ProjArgs a) {
                     uint8_t* o = (uint8_t*)a.out[in.arg];
 #pragma unroll
                     for (int r = 0; r < PJ_R; r++) {
-                        const int64_t row = base + r * PJ_BLOCK;
+                        const int64_t row = base + (r >> 1) * (2 * PJ_BLOCK) + (r & 1);
                         if (row < a.length) o[row] = (uint8_t)tos[r];
+                    }
+                } else if (full_tile) {
+                    uint64_t* o = (uint64_t*)a.out[in.arg] + base;
+#pragma unroll
+                    for (int k = 0; k < PJ_R / 2; k++) {
+                        ulonglong2 t;
+                        t.x = tos[2 * k];
+                        t.y = tos[2 * k + 1];
+                        *(ulonglong2*)(o + k * (2 * PJ_BLOCK)) = t;
                     }
                 } else {
                     uint64_t* o = (uint64_t*)a.out[in.arg];
 #pragma unroll
                     for (int r = 0; r < PJ_R; r++) {
-                        const int64_t row = base + r * PJ_BLOCK;
+                        const int64_t row = base + (r >> 1) * (2 * PJ_BLOCK) + (r & 1);
                         if (row < a.length) o[row] = tos[r];
                     }
                 }
