@@ -35,7 +35,8 @@ struct FilterArgs {
     const uint8_t* mask;
     const uint8_t* mask_valid;
     int n_payload;
-    int reuse_pred;  // payload[0] is the predicate column itself (values stay in registers)
+    int reuse_idx;   // 0 when payload column 0 IS the predicate column (its values stay in registers; the host moves
+                     // such a column to the front), else -1
     vnm_dcol payload[F_MAX_PAYLOAD];
     void* out_values[F_MAX_PAYLOAD];
     uint8_t* out_valid[F_MAX_PAYLOAD];
@@ -141,7 +142,9 @@ __device__ __forceinline__ int64_t lookback2(unsigned long long* status, unsigne
 // Within a wave the survivors of one chunk land on a contiguous output range, so the store instructions of
 // a chunk together cover whole cache lines.
 // =======================================================================================================
-template <int MODE, int FB, int CH, bool HOT, bool STATS>
+// PAYLOOP: further payload columns are gathered after the tile base is known (not compiled into the configs[1]
+// shape, whose register budget is tight)
+template <int MODE, int FB, int CH, bool HOT, bool STATS, bool PAYLOOP>
 __device__ __forceinline__ void filter_tile(const FilterArgs& a, const int64_t tile) {
     constexpr int TILE = FB * 2 * CH;
     constexpr int NW = FB / 64;
@@ -243,8 +246,8 @@ __device__ __forceinline__ void filter_tile(const FilterArgs& a, const int64_t t
     if (a.debug & 4) return;
     const int64_t base = s_base;
     if (HOT) {
-        // the only payload is the predicate column itself: values are still in registers
-        if (a.n_payload) {
+        // one payload column is the predicate column itself: its values are still in registers
+        if (a.reuse_idx == 0) {
             uint64_t* out = (uint64_t*)a.out_values[0] + base;
 #pragma unroll
             for (int j = 0; j < CH; j++) {
@@ -254,11 +257,28 @@ __device__ __forceinline__ void filter_tile(const FilterArgs& a, const int64_t t
                 if (fj & 2u) out[pos] = (uint64_t)__double_as_longlong(v1[j]);
             }
         }
-        return;
+        if (!PAYLOOP || a.n_payload <= (a.reuse_idx == 0 ? 1 : 0)) return;
     }
-    for (int k = 0; k < a.n_payload; k++) {
+    for (int k = (HOT && a.reuse_idx == 0) ? 1 : 0; k < a.n_payload; k++) {
         const vnm_dcol& c = a.payload[k];
         const int w = type_width(c.type);
+        if (w == 8 && !c.validity && !a.out_valid[k] && full && ((c.offset + (pb - a.pred.offset)) & 1) == 0) {
+            // 8-byte column without NULLs: the whole tile is read with unconditional 16-byte requests (all of them
+            // in flight together), only the stores are conditional
+            const uint64_t* p = (const uint64_t*)c.values + c.offset + (pb - a.pred.offset);
+            uint64_t* out = (uint64_t*)a.out_values[k] + base;
+            ulonglong2 t[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) t[j] = *(const ulonglong2*)(p + (int64_t)j * (2 * FB));
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                uint32_t fj = (flags >> (2 * j)) & 3u;
+                uint32_t pos = s_excl[j * NW + wave] + ((rank[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                if (fj & 1u) out[pos++] = t[j].x;
+                if (fj & 2u) out[pos] = t[j].y;
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < CH; j++) {
             uint32_t fj = (flags >> (2 * j)) & 3u;
@@ -290,11 +310,11 @@ __device__ __forceinline__ void filter_tile(const FilterArgs& a, const int64_t t
 // instead was measured at 5.8-6.7 ms: a ticket taken ahead of time reserves a tile whose owner is still busy, and
 // every later tile's look-back waits for it; a ticket taken just in time exposes a ~2 us returning atomic per tile.
 // (occupancy target: two 1024-thread workgroups per CU need <= 64 VGPRs AND <= 100 SGPRs on gfx9-family parts)
-template <int MODE, int FB, int CH, bool HOT, bool STATS>
+template <int MODE, int FB, int CH, bool HOT, bool STATS, bool PAYLOOP>
 __global__ __launch_bounds__(FB) __attribute__((amdgpu_waves_per_eu(CH == 4 ? 8 : (CH == 16 ? VNM_F16W : 5), 8)))
 void filter_tile_kernel(FilterArgs a) {
     for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        filter_tile<MODE, FB, CH, HOT, STATS>(a, tile);
+        filter_tile<MODE, FB, CH, HOT, STATS, PAYLOOP>(a, tile);
         __syncthreads();
     }
 }
@@ -320,10 +340,13 @@ static int env_int(const char* name, int dflt) {
 }
 
 static int launch_filter(FilterArgs& a, int mode, int64_t* out_count, hipStream_t s) {
-    const bool hot = mode == CMP_F64 && a.pred.type == VNM_F64 && !a.pred.validity &&
-                     (a.n_payload == 0 || (a.n_payload == 1 && a.reuse_pred && !a.out_valid[0]));
+    // hot_pred: float64 predicate column without NULLs (16-byte loads, values kept in registers);
+    // hot: ... and its survivors are the only output (BASELINE configs[1])
+    const bool hot_pred = mode == CMP_F64 && a.pred.type == VNM_F64 && !a.pred.validity &&
+                          !(a.reuse_idx == 0 && a.out_valid[0]);
+    const bool hot = hot_pred && (a.n_payload == 0 || (a.n_payload == 1 && a.reuse_idx == 0));
     // hot: 256 threads x 32 rows (8192-row tiles, four workgroups = four tiles in flight per CU: 2.71 ms; 1024 x 8
-    // rows, two per CU: 2.94); generic: 512 threads x 16 rows
+    // rows, two per CU: 2.94); other shapes: 512 threads x 16 rows
     const int fbe = env_int("VNM_FILTER_THREADS", 256);
     const int fb = hot ? (fbe >= 1024 ? 1024 : (fbe >= 512 ? 512 : 256)) : 512;
     const int ch = hot && fb == 1024 ? 4 : (hot && fb == 256 ? 16 : 8);
@@ -368,14 +391,16 @@ static int launch_filter(FilterArgs& a, int mode, int64_t* out_count, hipStream_
     KernelTimer timer("filter_kernel", s);
     int rc;
     if (hot) {
-        if (fb == 1024 && (a.debug & 8)) rc = launch(filter_tile_kernel<CMP_F64, 1024, 4, true, true>, 1024);
-        else if (fb == 1024) rc = launch(filter_tile_kernel<CMP_F64, 1024, 4, true, false>, 1024);
-        else if (fb == 256) rc = launch(filter_tile_kernel<CMP_F64, 256, 16, true, false>, 256);
-        else rc = launch(filter_tile_kernel<CMP_F64, 512, 8, true, false>, 512);
+        if (fb == 1024 && (a.debug & 8)) rc = launch(filter_tile_kernel<CMP_F64, 1024, 4, true, true, false>, 1024);
+        else if (fb == 1024) rc = launch(filter_tile_kernel<CMP_F64, 1024, 4, true, false, false>, 1024);
+        else if (fb == 256) rc = launch(filter_tile_kernel<CMP_F64, 256, 16, true, false, false>, 256);
+        else rc = launch(filter_tile_kernel<CMP_F64, 512, 8, true, false, false>, 512);
+    } else if (hot_pred) {
+        rc = launch(filter_tile_kernel<CMP_F64, 512, 8, true, false, true>, 512);  // float64 predicate, several payload columns
     } else if (mode == MODE_MASK) {
-        rc = launch(filter_tile_kernel<MODE_MASK, 512, 8, false, false>, 512);
+        rc = launch(filter_tile_kernel<MODE_MASK, 512, 8, false, false, true>, 512);
     } else {
-        rc = launch(filter_tile_kernel<CMP_I64, 512, 8, false, false>, 512);  // generic pred_eval path
+        rc = launch(filter_tile_kernel<CMP_I64, 512, 8, false, false, true>, 512);  // generic pred_eval path
     }
     if (rc) { pool_free(scratch); return rc; }
     }
@@ -431,8 +456,17 @@ int vnm_filter_cmp(const vnm_dcol* pred, int op, int scalar_is_float, double dva
         a.out_valid[k] = out_valid ? out_valid[k] : nullptr;
         if (payload[k].validity && !a.out_valid[k]) return set_error("vnm_filter_cmp: payload %d has nulls but no out_valid buffer", k);
     }
-    a.reuse_pred = n_payload > 0 && payload[0].values == pred->values && payload[0].offset == pred->offset &&
-                   payload[0].type == pred->type;
+    a.reuse_idx = -1;
+    for (int k = 0; k < n_payload && a.reuse_idx < 0; k++)
+        if (payload[k].values == pred->values && payload[k].offset == pred->offset && payload[k].type == pred->type &&
+            payload[k].validity == pred->validity)
+            a.reuse_idx = k;
+    if (a.reuse_idx > 0) {  // the kernel only knows "payload 0 is the predicate column": the order of the outputs is free
+        std::swap(a.payload[0], a.payload[a.reuse_idx]);
+        std::swap(a.out_values[0], a.out_values[a.reuse_idx]);
+        std::swap(a.out_valid[0], a.out_valid[a.reuse_idx]);
+        a.reuse_idx = 0;
+    }
     int mode = (a.p.mode == CMP_F64) ? CMP_F64 : CMP_I64;
     return launch_filter(a, mode, out_count, as_stream(stream));
 }
@@ -446,6 +480,7 @@ int vnm_filter_mask(const uint8_t* mask, const uint8_t* mask_valid, int64_t leng
     FilterArgs a{};
     a.mask = mask;
     a.mask_valid = mask_valid;
+    a.reuse_idx = -1;
     a.length = length;
     a.n_payload = n_payload;
     for (int k = 0; k < n_payload; k++) {
