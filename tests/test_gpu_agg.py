@@ -333,3 +333,48 @@ def test_partition_aligned_exchange_simulated(world):
         for b in t.to_batches():
             o_.next(b)
     util.assert_agg_equal(got, o_.result(), funcs, ["k"], what=f"partition-aligned world={world}")
+
+
+@pytest.mark.parametrize("scenario", ["dims", "nulls_and_negatives", "float_key", "demote_on_later_batch", "unpackable"])
+def test_multi_key_packed_composite_keys(scenario):
+    """Multi-column GROUP BY: key columns whose observed ranges fit 63 bits are packed into one word per row and run
+    through the single-key machinery, result keys unpacked at the end; a later batch outside the ranges demotes the
+    operator to the wide-key table; ranges that do not fit never pack.  All bit-exact against the oracle, NULL keys
+    (null == null, multi_numerical_hash_aggregate.h:11-18) included."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(len(scenario))
+    n = 400_000
+    v = pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0)
+    if scenario == "dims":
+        a = pa.array(rng.integers(0, 1000, n).astype(np.int64))
+        b = pa.array(rng.integers(0, 12, n).astype(np.int32))
+        c = pa.array(rng.integers(0, 3, n).astype(np.uint8))
+        keys = {"a": a, "b": b, "c": c}
+    elif scenario == "nulls_and_negatives":
+        a = pa.array(rng.integers(-500, 500, n).astype(np.int64), mask=rng.random(n) < 0.05)
+        b = pa.array(rng.integers(-3, 4, n).astype(np.int16), mask=rng.random(n) < 0.2)
+        keys = {"a": a, "b": b}
+    elif scenario == "float_key":
+        a = pa.array(rng.integers(0, 50, n).astype(np.float64) * 0.25 - 3.0)   # 50 distinct bit patterns, wide span
+        b = pa.array(rng.integers(0, 40, n).astype(np.int64))
+        keys = {"a": a, "b": b}
+    elif scenario == "demote_on_later_batch":
+        a = np.concatenate([rng.integers(0, 100, n // 2), rng.integers(10**12, 10**12 + 100, n - n // 2)]).astype(np.int64)
+        b = pa.array(rng.integers(0, 7, n).astype(np.int64))
+        keys = {"a": pa.array(a), "b": b}
+    else:
+        a = pa.array(rng.integers(-2**62, 2**62, n).astype(np.int64))
+        b = pa.array(rng.integers(-2**62, 2**62, n).astype(np.int64))
+        keys = {"a": a, "b": b}
+    t = pa.table({**keys, "v": v})
+    names = list(keys)
+    funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "m"), (O.COUNT_STAR, "", "n"), (O.MIN, "v", "lo")]
+    batches = util.sliced_batches(t, n // 2)
+    for pred in (None, ("v", ">", 64.0)):
+        got = gpu_aggregate(O.MULTI, names, names, funcs, batches, predicate=pred)
+        o = O.OracleAggregate(O.MULTI, names, names, funcs)
+        for bt in batches:
+            if pred:
+                bt = O.filter_batch(bt, O.cmp_mask(bt.column(len(names)), O.GT, 64.0))
+            o.next(bt)
+        util.assert_agg_equal(got, o.result(), funcs, names, what=f"packed multi-key {scenario} pred={pred}")

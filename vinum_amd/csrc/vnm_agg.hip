@@ -1723,6 +1723,85 @@ __global__ void fill_u64_kernel(uint64_t* p, uint64_t v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
+// =======================================================================================================
+// Packed composite keys.  GROUP BY a, b, ... with keys whose values span few bits (dimension columns) is the
+// common multi-column case.  The key columns of a batch are packed into ONE 64-bit word per row
+//     word = sum_j code_j << shift_j,   code_j = value_j - lo_j  (or the all-ones code of the field for NULL)
+// which is a bijection on the observed ranges, so the single-key machinery (LDS pre-aggregation, partitioned
+// path) applies unchanged and the result keys are unpacked at the end.  The top bit stays clear, so a packed
+// word never equals the EMPTY sentinel.  A later batch outside the ranges demotes the operator to the wide-key
+// table (the groups so far are unpacked and merged there).
+// =======================================================================================================
+struct PackParams {
+    int n;
+    int shift[AGG_MAX_KEYS];
+    int bits[AGG_MAX_KEYS];
+    uint64_t lo[AGG_MAX_KEYS];   // value bits of code 0
+    vnm_dcol cols[AGG_MAX_KEYS];
+};
+
+// per key column: min / max of the key bits as int64 (order-preserving encoding for the unsigned atomics)
+__global__ __launch_bounds__(256) void key_range_kernel(PackParams p, int64_t nrows, unsigned long long* out /* [n][2] */) {
+    __shared__ unsigned long long smin[AGG_MAX_KEYS], smax[AGG_MAX_KEYS];
+    if (threadIdx.x < AGG_MAX_KEYS) { smin[threadIdx.x] = ~0ULL; smax[threadIdx.x] = 0; }
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int j = 0; j < p.n; j++) {
+        uint64_t mn = ~0ULL, mx = 0;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nrows; i += stride) {
+            if (!col_valid(p.cols[j], i)) continue;
+            const uint64_t e = enc_i64((int64_t)col_key_bits(p.cols[j], i));
+            mn = e < mn ? e : mn;
+            mx = e > mx ? e : mx;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            uint64_t a = __shfl_xor(mn, d), b = __shfl_xor(mx, d);
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&smin[j], (unsigned long long)mn); atomicMax(&smax[j], (unsigned long long)mx); }
+    }
+    __syncthreads();
+    if (threadIdx.x < p.n) { atomicMin(&out[2 * threadIdx.x], smin[threadIdx.x]); atomicMax(&out[2 * threadIdx.x + 1], smax[threadIdx.x]); }
+}
+
+__global__ __launch_bounds__(256) void key_pack_kernel(PackParams p, int64_t nrows, uint64_t* packed, unsigned long long* out_of_range) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nrows; i += stride) {
+        uint64_t w = 0;
+        for (int j = 0; j < p.n; j++) {
+            const uint64_t cap = (1ULL << p.bits[j]) - 1;  // values use codes [0, cap), NULL is cap
+            uint64_t code = cap;
+            if (col_valid(p.cols[j], i)) {
+                code = col_key_bits(p.cols[j], i) - p.lo[j];
+                bad = bad || code >= cap;
+            }
+            w |= (code & cap) << p.shift[j];
+        }
+        packed[i] = w;
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(out_of_range, 1ULL);
+}
+
+// packed[i] -> key words [n + 1][stride] (values, NULL -> 0, then the null mask) as agg_wide_kernel builds them
+__global__ __launch_bounds__(256) void key_unpack_kernel(PackParams p, const uint64_t* packed, int64_t n, uint64_t* dkey, int64_t stride) {
+    const int64_t gstride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += gstride) {
+        const uint64_t w = packed[i];
+        uint64_t nullmask = 0;
+        for (int j = 0; j < p.n; j++) {
+            const uint64_t cap = (1ULL << p.bits[j]) - 1;
+            const uint64_t code = (w >> p.shift[j]) & cap;
+            const bool isnull = code == cap;
+            dkey[(int64_t)j * stride + i] = isnull ? 0 : p.lo[j] + code;
+            if (isnull) nullmask |= 1ULL << j;
+        }
+        dkey[(int64_t)p.n * stride + i] = nullmask;
+    }
+}
+
 }  // namespace vnm
 
 // ==========================================================================================================
@@ -1763,6 +1842,12 @@ struct vnm_agg {
     int64_t merge_stride = 0;  // set by vnm_agg_merge_rows around vnm_agg_merge_device
     unsigned long long* run_dir = nullptr;  // partition directory of the run (partitioned path, one workgroup per partition)
     int64_t run_nfin = 0;
+    // packed composite keys (multi-column GROUP BY through the single-key machinery)
+    vnm_agg* inner = nullptr;
+    bool pack_tried = false;
+    PackParams pack{};
+    int c_funcs[AGG_MAX_FUNCS], c_in_types[AGG_MAX_FUNCS], c_in_flags[AGG_MAX_FUNCS], c_in_col_ids[AGG_MAX_FUNCS];
+    bool c_has_ids = false;
 };
 
 namespace {
@@ -2102,6 +2187,95 @@ static int merge_run_into_table(vnm_agg* h, hipStream_t s) {
     return rc;
 }
 
+// ---- packed composite keys: host side ----------------------------------------------------------------------
+extern "C" int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream);
+extern "C" int vnm_agg_merge_device(vnm_agg* h, int64_t n, uint64_t* const* key_words, uint64_t* const* acc_words, void* stream);
+extern "C" int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs, const vnm_dcol* pred, void* stream);
+extern "C" vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
+                                   const int* in_types, const int* in_flags, const int* in_col_ids);
+extern "C" void vnm_agg_destroy(vnm_agg* h);
+
+namespace {
+
+// Decide the packing from the key ranges of the first batch: field j holds value codes [0, cap_j) + the NULL code.
+// Spare bits are spread over the fields and the observed range is centred in its field, so later batches may
+// drift in both directions.  Returns true and fills h->pack when the keys fit 63 bits.
+bool plan_packing(vnm_agg* h, const vnm_dcol* keys, int64_t nrows, hipStream_t s, int* err) {
+    *err = 0;
+    const int n = h->plan.n_keys;
+    PackParams& p = h->pack;
+    p.n = n;
+    for (int j = 0; j < n; j++) p.cols[j] = keys[j];
+    unsigned long long* d = (unsigned long long*)pool_alloc(16 * AGG_MAX_KEYS);
+    if (!d) { *err = 1; return false; }
+    unsigned long long init[2 * AGG_MAX_KEYS], got[2 * AGG_MAX_KEYS];
+    for (int j = 0; j < AGG_MAX_KEYS; j++) { init[2 * j] = ~0ULL; init[2 * j + 1] = 0; }
+    bool ok = hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, s) == hipSuccess;
+    int grid = (int)std::min<int64_t>((nrows + 255) / 256, (int64_t)device_info().num_cus * 8);
+    if (ok) key_range_kernel<<<grid, 256, 0, s>>>(p, nrows, d);
+    ok = ok && hipMemcpyAsync(got, d, sizeof(got), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    pool_free(d);
+    if (!ok) { *err = set_error("aggregate: key range kernel failed"); return false; }
+    int need_bits[AGG_MAX_KEYS];
+    uint64_t span[AGG_MAX_KEYS];
+    int64_t mn[AGG_MAX_KEYS];
+    int total = 0;
+    for (int j = 0; j < n; j++) {
+        const bool any = got[2 * j] <= got[2 * j + 1];
+        mn[j] = any ? (int64_t)(got[2 * j] ^ 0x8000000000000000ULL) : 0;
+        const int64_t mx = any ? (int64_t)(got[2 * j + 1] ^ 0x8000000000000000ULL) : 0;
+        span[j] = (uint64_t)mx - (uint64_t)mn[j];
+        if (span[j] >= (1ULL << 61)) return false;
+        const uint64_t need = span[j] + 2;  // values + the NULL code
+        int b = 1;
+        while ((1ULL << b) < need) b++;
+        need_bits[j] = b;
+        total += b;
+    }
+    if (total > 63) return false;
+    const int extra = (63 - total) / n;
+    int shift = 0;
+    for (int j = 0; j < n; j++) {
+        int b = need_bits[j] + extra;
+        if (b > 62) b = 62;
+        p.bits[j] = b;
+        p.shift[j] = shift;
+        shift += b;
+        const uint64_t cap = (1ULL << b) - 1;
+        const uint64_t slack = cap - (span[j] + 1);
+        p.lo[j] = (uint64_t)mn[j] - slack / 2;
+    }
+    return true;
+}
+
+// leave packed mode: the groups aggregated so far are unpacked and merged into h's own (wide-key) table
+int demote_packed(vnm_agg* h, hipStream_t s) {
+    vnm_agg* in = h->inner;
+    h->inner = nullptr;
+    int64_t n = 0;
+    int rc = vnm_agg_finish(in, &n, (void*)s);
+    if (!rc && n > 0) {
+        const int kw = h->plan.kw;
+        uint64_t* keys = (uint64_t*)pool_alloc((size_t)kw * n * 8);
+        if (!keys) rc = 1;
+        if (!rc) {
+            int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_info().num_cus * 8);
+            key_unpack_kernel<<<grid, 256, 0, s>>>(h->pack, in->dkey, n, keys, n);
+            uint64_t* kp[AGG_MAX_KEYS + 1];
+            uint64_t* ap[AGG_MAX_WORDS];
+            for (int j = 0; j < kw; j++) kp[j] = keys + (size_t)j * n;
+            for (int w = 0; w < h->plan.n_words; w++) ap[w] = in->dacc + (size_t)w * in->dstride;
+            rc = vnm_agg_merge_device(h, n, kp, ap, (void*)s);
+            if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = set_error("aggregate: demotion failed");
+        }
+        pool_free(keys);
+    }
+    vnm_agg_destroy(in);
+    return rc;
+}
+
+}  // namespace
+
 extern "C" {
 
 vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
@@ -2123,11 +2297,19 @@ vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs,
         if (h->func_col[i] < 0) { ids[nc] = id; h->col_first_func[nc] = i; h->func_col[i] = nc++; }
     }
     h->single = (kind == VNM_SINGLE_NUMERICAL) || (kind == VNM_MULTI_NUMERICAL && n_keys == 1);
+    for (int i = 0; i < n_funcs; i++) {
+        h->c_funcs[i] = funcs[i];
+        h->c_in_types[i] = in_types ? in_types[i] : 0;
+        h->c_in_flags[i] = in_flags ? in_flags[i] : 0;
+        h->c_in_col_ids[i] = in_col_ids ? in_col_ids[i] : 0;
+    }
+    h->c_has_ids = in_col_ids != nullptr;
     return h;
 }
 
 void vnm_agg_destroy(vnm_agg* h) {
     if (!h) return;
+    if (h->inner) { vnm_agg_destroy(h->inner); h->inner = nullptr; }
     if (h->have_table) table_free(&h->g);
     invalidate_result(h);
     drop_run(h);
@@ -2163,6 +2345,52 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         return 0;
     }
     if (nrows >= (1LL << 31)) return set_error("vnm_agg_next_device: batches must be < 2^31 rows (as in the reference, agg_funcs.h:45)");
+
+    // multi-column keys: try the packed single-word form first (see PackParams)
+    if (!h->single && h->plan.n_keys >= 2) {
+        for (int j = 0; j < h->plan.n_keys; j++)
+            if (keys[j].type != h->plan.key_types[j]) return set_error("vnm_agg_next_device: key %d changed type between batches", j);
+        if (!h->pack_tried && !h->have_table && getenv("VNM_AGG_NO_PACK") == nullptr) {
+            h->pack_tried = true;
+            int err = 0;
+            if (plan_packing(h, keys, nrows, s, &err)) {
+                const int kt = VNM_U64;
+                h->inner = vnm_agg_create(VNM_SINGLE_NUMERICAL, 1, &kt, h->n_funcs, h->c_funcs, h->c_in_types, h->c_in_flags,
+                                          h->c_has_ids ? h->c_in_col_ids : nullptr);
+                if (!h->inner) return 1;
+                h->inner->hint = h->hint;
+            } else if (err) return err;
+        }
+        if (h->inner) {
+            for (int j = 0; j < h->plan.n_keys; j++) h->pack.cols[j] = keys[j];
+            uint64_t* packed = (uint64_t*)pool_alloc((size_t)nrows * 8);
+            unsigned long long* flag = (unsigned long long*)pool_alloc(64);
+            if (!packed || !flag) return 1;
+            VNM_HIP(hipMemsetAsync(flag, 0, 8, s));
+            {
+                KernelTimer timer("agg_pack_keys", s);
+                int grid = (int)std::min<int64_t>((nrows + 255) / 256, (int64_t)device_info().num_cus * 8);
+                key_pack_kernel<<<grid, 256, 0, s>>>(h->pack, nrows, packed, flag);
+            }
+            unsigned long long bad = 0;
+            VNM_HIP(hipMemcpyAsync(&bad, flag, 8, hipMemcpyDeviceToHost, s));
+            VNM_HIP(hipStreamSynchronize(s));
+            pool_free(flag);
+            int rc = 0;
+            if (!bad) {
+                vnm_dcol pk{};
+                pk.values = packed; pk.type = VNM_U64; pk.length = nrows;
+                if (h->pred_set) rc = vnm_agg_set_predicate(h->inner, 1, h->pred_op, h->pred_is_float, h->pred_dval, h->pred_ival);
+                if (!rc) rc = vnm_agg_next_device(h->inner, nrows, &pk, inputs, pred, stream);
+                if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = set_error("aggregate: packed batch failed");
+                pool_free(packed);
+                if (!rc) h->rows_seen += nrows;
+                return rc;
+            }
+            pool_free(packed);
+            VNM_TRY(demote_packed(h, s));  // keys outside the packed ranges: continue with the wide-key table
+        }
+    }
 
     AggArgs a{};
     a.plan = h->plan;
@@ -2339,6 +2567,7 @@ int vnm_agg_merge_device(vnm_agg* h, int64_t n, uint64_t* const* key_words, uint
     VNM_TRY(ensure_init());
     if (!h) return set_error("vnm_agg_merge_device: null handle");
     hipStream_t s = as_stream(stream);
+    if (h->inner) VNM_TRY(demote_packed(h, s));
     invalidate_result(h);
     VNM_TRY(ensure_table(h, n, s));
     if (n <= 0) return 0;
@@ -2385,6 +2614,26 @@ int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream) {
     hipStream_t s = as_stream(stream);
     if (h->n_groups >= 0) {
         if (n_groups) *n_groups = h->n_groups;
+        return 0;
+    }
+    if (h->inner) {  // packed composite keys: finish the single-key operator, unpack its keys into the wide layout
+        int64_t n = 0;
+        VNM_TRY(vnm_agg_finish(h->inner, &n, stream));
+        h->dstride = n + 2;
+        h->dkey = (uint64_t*)pool_alloc((size_t)h->dstride * 8 * h->plan.kw);
+        h->dacc = (uint64_t*)pool_alloc((size_t)h->dstride * 8 * h->plan.n_words);
+        if (!h->dkey || !h->dacc) return 1;
+        if (n > 0) {
+            int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_info().num_cus * 8);
+            key_unpack_kernel<<<grid, 256, 0, s>>>(h->pack, h->inner->dkey, n, h->dkey, h->dstride);
+            for (int w = 0; w < h->plan.n_words; w++)
+                VNM_HIP(hipMemcpyAsync(h->dacc + (size_t)w * h->dstride, h->inner->dacc + (size_t)w * h->inner->dstride, (size_t)n * 8,
+                                       hipMemcpyDeviceToDevice, s));
+            VNM_HIP(hipGetLastError());
+            VNM_HIP(hipStreamSynchronize(s));
+        }
+        h->n_groups = n;
+        if (n_groups) *n_groups = n;
         return 0;
     }
     if (h->have_run && !h->have_table) {  // the partitioned path already produced the dense result
