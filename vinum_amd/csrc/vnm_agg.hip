@@ -469,20 +469,23 @@ __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
             if (sat) agg_rows_to_table(a, row0, BLK, sat, &s_new);
         }
         // ---- B: one accumulator op at a time over all rows of the lane
+        uint64_t raw[R];
+        uint32_t cvalid = 0, rows = 0;
+        int loaded_col = -1;  // consecutive ops on one column share its loads
+#pragma unroll
+        for (int r = 0; r < R; r++) { raw[r] = 0; if (slot[r] != -1) rows |= 1u << r; }
         for (int o = 0; o < ((a.debug & 1) ? 0 : a.plan.n_ops); o++) {
             const AccOp op = a.plan.ops[o];
             const int mk = a.plan.merge[op.word];
-            uint64_t raw[R];
-            uint32_t have = 0;  // rows that contribute to this op
-            if (op.kind == A_COUNT_ROWS) {
-#pragma unroll
-                for (int r = 0; r < R; r++) { raw[r] = 0; if (slot[r] != -1) have |= 1u << r; }
-            } else {
-                const vnm_dcol& c = a.cols[op.col];
-                load_raw_rows<R>(c, rowc, raw);
-                const uint32_t cvalid = load_valid_rows<R>(c, rowc);
-#pragma unroll
-                for (int r = 0; r < R; r++) if (slot[r] != -1 && ((cvalid >> r) & 1u)) have |= 1u << r;
+            uint32_t have = rows;  // rows that contribute to this op
+            if (op.kind != A_COUNT_ROWS) {
+                if (op.col != loaded_col) {
+                    const vnm_dcol& c = a.cols[op.col];
+                    load_raw_rows<R>(c, rowc, raw);
+                    cvalid = load_valid_rows<R>(c, rowc);
+                    loaded_col = op.col;
+                }
+                have &= cvalid;
             }
             const int vtype = op.kind == A_COUNT_ROWS ? VNM_U64 : a.cols[op.col].type;
             uint64_t* const wl = lacc + op.word * stride;
@@ -756,21 +759,54 @@ __device__ __forceinline__ uint64_t merge_vals(int mk, uint64_t x, uint64_t y) {
     }
 }
 
+constexpr int OG_R = 8;  // rows per lane and tile: loads of one column are issued together, one op decode serves all
 __global__ __launch_bounds__(OG_BLOCK) void agg_onegroup_kernel(AggArgs a) {
-    extern __shared__ uint64_t lds[];  // [W][OG_BLOCK]
+    extern __shared__ uint64_t lds[];  // [W][OG_BLOCK]: per-lane partial accumulators
     const int tid = threadIdx.x;
     const int W = a.plan.n_words;
     for (int w = 0; w < W; w++) lds[w * OG_BLOCK + tid] = merge_init(a.plan.merge[w]);
-    const int64_t stride = (int64_t)gridDim.x * OG_BLOCK;
-    for (int64_t row = (int64_t)blockIdx.x * OG_BLOCK + tid; row < a.nrows; row += stride) {
-        if (a.p.enabled && !pred_eval(a.p, a.pred, row)) continue;
+    const int64_t ntiles = (a.nrows + (int64_t)OG_BLOCK * OG_R - 1) / ((int64_t)OG_BLOCK * OG_R);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * OG_BLOCK * OG_R + tid;
+        int64_t rowc[OG_R];
+        uint32_t pass = 0;
+#pragma unroll
+        for (int r = 0; r < OG_R; r++) {
+            const int64_t row = row0 + (int64_t)r * OG_BLOCK;
+            if (row < a.nrows) pass |= 1u << r;
+            rowc[r] = row < a.nrows ? row : a.nrows - 1;
+        }
+        if (a.p.enabled) {
+            uint64_t praw[OG_R];
+            load_raw_rows<OG_R>(a.pred, rowc, praw);
+            const uint32_t pvalid = load_valid_rows<OG_R>(a.pred, rowc);
+#pragma unroll
+            for (int r = 0; r < OG_R; r++)
+                if (!pred_eval_raw(a.p, a.pred.type, praw[r], (pvalid >> r) & 1u)) pass &= ~(1u << r);
+        }
+        uint64_t raw[OG_R];
+        uint32_t cvalid = 0;
+        int loaded_col = -1;  // consecutive ops on one column share its loads
         for (int o = 0; o < a.plan.n_ops; o++) {
-            const AccOp& op = a.plan.ops[o];
-            uint64_t v;
-            if (op_value(op, a.cols, row, &v)) {
-                uint64_t* p = &lds[op.word * OG_BLOCK + tid];
-                *p = merge_vals(a.plan.merge[op.word], *p, v);
+            const AccOp op = a.plan.ops[o];
+            const int mk = a.plan.merge[op.word];
+            uint32_t have = pass;
+            int vtype = VNM_U64;
+            if (op.kind != A_COUNT_ROWS) {
+                const vnm_dcol& c = a.cols[op.col];
+                vtype = c.type;
+                if (op.col != loaded_col) {
+                    load_raw_rows<OG_R>(c, rowc, raw);
+                    cvalid = load_valid_rows<OG_R>(c, rowc);
+                    loaded_col = op.col;
+                }
+                have &= cvalid;
             }
+            uint64_t acc = lds[op.word * OG_BLOCK + tid];
+#pragma unroll
+            for (int r = 0; r < OG_R; r++)
+                if ((have >> r) & 1u) acc = merge_vals(mk, acc, op_value_raw(op.kind, vtype, op.kind == A_COUNT_ROWS ? 0 : raw[r]));
+            lds[op.word * OG_BLOCK + tid] = acc;
         }
     }
     __syncthreads();
