@@ -218,6 +218,27 @@ def test_partitioned_path_wrong_hint_falls_back():
     util.assert_agg_equal(got, o.result(), funcs, ["k"], what="wrong hint")
 
 
+def test_partitioned_path_skewed_keys_fall_back_early():
+    """Power-law keys: a few keys own most rows, so their partition regions overflow in the first scatter pass.
+    The operator must notice right there (not after aggregating doomed partitions -- one workgroup would chew
+    through the heavy key's partition alone) and give the exact answer through the scan kernel."""
+    import time
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    n = 900_000
+    groups = 80_000
+    k = np.floor(groups * rng.random(n) ** 8).astype(np.int64)
+    t = pa.table({"k": pa.array(k), "v": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0)})
+    funcs = [(O.SUM, "v", "sum_v"), (O.AVG, "v", "avg_v"), (O.COUNT_STAR, "", "n")]
+    t0 = time.perf_counter()
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, t.to_batches(), expected_groups=groups)
+    assert time.perf_counter() - t0 < 20.0
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in t.to_batches():
+        o.next(b)
+    util.assert_agg_equal(got, o.result(), funcs, ["k"], what="skewed keys")
+
+
 @pytest.mark.parametrize("groups", [50, 20_000, 400_000])
 def test_hintless_operator_estimates_cardinality(groups, monkeypatch):
     """No expected_groups: the operator samples the first batch (scratch table, then HyperLogLog), picks the LDS
