@@ -65,6 +65,7 @@ struct AggArgs {
     int hot_w[9];      // word of each AccKind, -1 = absent
     int hot_vtype;     // VNM_F64 / VNM_I64 / VNM_U64
     int hot_has_val;
+    const ulonglong2* ent;  // agg_hot_kernel<FROM_ENT>: (key, value bits) entries spilled by the partitioned path
     int part_generic;  // partitioned path with a generic accumulator program over one 8-byte column (or none)
     int part_vtype;
     int debug;  // timing experiments (VNM_AGG_DEBUG): 1 = no accumulator ops, 2 = no probes either, 4 = no room check
@@ -605,7 +606,22 @@ __device__ __forceinline__ void hot_accumulate(const AggArgs& a, uint64_t* lacc,
 #undef VNM_W
 }
 
-template <bool HAS_PRED, bool PRED_IS_V, bool HAS_VAL, bool SIMPLE>
+// one entry (key, value bits) straight into the HBM table: the saturated-key path of agg_hot_kernel<FROM_ENT>
+__device__ __forceinline__ void hot_entry_to_table(const AggArgs& a, uint64_t key, uint64_t vb, unsigned* s_new) {
+    uint64_t gs;
+    if (key == EMPTY) { gs = a.g.cap; if (ld_agent(&a.g.tag[gs]) == EMPTY) st_agent(&a.g.tag[gs], 0); }
+    else gs = gt_find_single(a.g, key, s_new);
+#pragma unroll 1
+    for (int k = 0; k <= A_MAX; k++) {
+        const int w = a.hot_w[k];
+        if (w < 0) continue;
+        g_merge(&a.g.acc[(uint64_t)w * a.g.stride + gs], a.plan.merge[w], op_value_raw(k, a.hot_vtype, vb));
+    }
+}
+
+// FROM_ENT: the rows are (key, value bits) entries (a.ent) instead of columns -- what the partitioned path spills when a
+// region is full (heavy keys); no predicate (already applied).
+template <bool HAS_PRED, bool PRED_IS_V, bool HAS_VAL, bool SIMPLE, bool FROM_ENT = false>
 __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
     extern __shared__ uint64_t lds[];
     __shared__ unsigned s_fill, s_new;
@@ -651,9 +667,15 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
 #pragma unroll
             for (int u = 0; u < HOT_UNROLL; u++) {
                 int64_t r = base + (int64_t)u * 2 * AGG_BLOCK;
-                kk[u] = *(const ulonglong2*)(kp + r);
-                if (HAS_VAL) vv[u] = *(const ulonglong2*)(vp + r);
-                if (HAS_PRED && !PRED_IS_V) pv[u] = *(const double2*)(pp + r);
+                if (FROM_ENT) {
+                    const ulonglong2 e0 = a.ent[r], e1 = a.ent[r + 1];
+                    kk[u].x = e0.x; kk[u].y = e1.x;
+                    vv[u].x = e0.y; vv[u].y = e1.y;
+                } else {
+                    kk[u] = *(const ulonglong2*)(kp + r);
+                    if (HAS_VAL) vv[u] = *(const ulonglong2*)(vp + r);
+                    if (HAS_PRED && !PRED_IS_V) pv[u] = *(const double2*)(pp + r);
+                }
             }
 #pragma unroll
             for (int u = 0; u < HOT_UNROLL; u++) {
@@ -668,24 +690,30 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                     int slot = hot_slot(lkey, S, smask, &s_fill, kk[u].y);
                     if (slot >= 0) hot_accumulate<SIMPLE>(a, lacc, stride, slot, v1); else sat1 |= 1u << u;
                 }
+                if (FROM_ENT && ((sat0 | sat1) >> u) & 1u) {  // no columns to re-read: merge the entry right here
+                    if ((sat0 >> u) & 1u) hot_entry_to_table(a, kk[u].x, v0, &s_new);
+                    if ((sat1 >> u) & 1u) hot_entry_to_table(a, kk[u].y, v1, &s_new);
+                }
             }
         } else {
             for (int u = 0; u < HOT_UNROLL; u++)
                 for (int e = 0; e < 2; e++) {
                     int64_t r = base + (int64_t)u * 2 * AGG_BLOCK + e;
                     if (r >= a.nrows) continue;
-                    const uint64_t vb = HAS_VAL ? vp[r] : 0;
+                    const uint64_t vb = FROM_ENT ? a.ent[r].y : (HAS_VAL ? vp[r] : 0);
+                    const uint64_t kb = FROM_ENT ? a.ent[r].x : kp[r];
                     const double p = PRED_IS_V ? __longlong_as_double((long long)vb) : (HAS_PRED ? pp[r] : 0.0);
                     if (HAS_PRED && !cmp_apply<double>(op, p, thr)) continue;
-                    int slot = hot_slot(lkey, S, smask, &s_fill, kp[r]);
+                    int slot = hot_slot(lkey, S, smask, &s_fill, kb);
                     if (slot >= 0) hot_accumulate<SIMPLE>(a, lacc, stride, slot, vb);
+                    else if (FROM_ENT) hot_entry_to_table(a, kb, vb, &s_new);
                     else if (e == 0) sat0 |= 1u << u;
                     else sat1 |= 1u << u;
                 }
         }
         // saturated keys: straight to the HBM table, out of line (rows base + e + u * 2 * AGG_BLOCK)
-        if (sat0) agg_rows_to_table(a, base, 2 * AGG_BLOCK, sat0, &s_new);
-        if (sat1) agg_rows_to_table(a, base + 1, 2 * AGG_BLOCK, sat1, &s_new);
+        if (!FROM_ENT && sat0) agg_rows_to_table(a, base, 2 * AGG_BLOCK, sat0, &s_new);
+        if (!FROM_ENT && sat1) agg_rows_to_table(a, base + 1, 2 * AGG_BLOCK, sat1, &s_new);
         __syncthreads();
         const unsigned fill_now = s_fill;
         need_check = fill_now > (unsigned)S / 2;
@@ -994,7 +1022,10 @@ struct PartArgs {
     int64_t out_cap;
     int nparts;          // 256 or 512
     int shift;           // partition = (hash >> shift) & (nparts - 1)
-    unsigned long long* flags;  // [0] overflow
+    unsigned long long* flags;  // [0] failure (spill buffer full)  [2] entries in the spill buffer
+    // entries that do not fit their region (skewed keys) are appended here and aggregated by agg_entries_kernel
+    ulonglong2* spill;
+    int64_t spill_cap;
     int debug;  // timing experiments (VNM_PART_DEBUG): 1 = no copy-out stores, 2 = no staging / copy-out at all
 };
 
@@ -1003,7 +1034,8 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
     __shared__ ulonglong2 stage[PT_TILE];
     __shared__ uint16_t part_of[PT_TILE];
     __shared__ uint32_t cnt[PT_MAXP], off[PT_MAXP], cursor[PT_MAXP];
-    __shared__ uint32_t s_total;
+    __shared__ uint32_t s_total, s_spill;
+    __shared__ unsigned long long s_spill_base;
     __shared__ uint32_t wtot[PT_MAXP / 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1011,6 +1043,7 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
     const uint32_t pmask = (uint32_t)np - 1;
     const int npad = np < 64 ? 64 : np;  // scan width: whole waves (counts beyond np stay zero)
     for (int i = tid; i < PT_MAXP; i += PT_BLOCK) { cnt[i] = 0; cursor[i] = 0; }
+    if (tid == 0) s_spill = 0;
     __syncthreads();
 
     // output region of partition p for this producer
@@ -1078,13 +1111,35 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
         __syncthreads();
         // D: copy out: consecutive lanes write consecutive 16-byte entries of one partition's run
         const uint32_t total = (a.debug & 1) ? 0 : s_total;
-        for (uint32_t i = tid; i < total; i += PT_BLOCK) {
-            uint32_t p = part_of[i];
-            uint32_t j = cursor[p] + (i - off[p]);
-            if (j < (uint32_t)a.out_cap) a.out_entries[(out_base + (int64_t)p * out_stride) * a.out_cap + j] = stage[i];
-            else __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t spilled = 0;  // bit q: this lane's q-th entry of the tile did not fit its region
+        uint32_t srank[PT_ITEMS];
+#pragma unroll
+        for (int q = 0; q < PT_ITEMS; q++) {
+            const uint32_t i = (uint32_t)q * PT_BLOCK + tid;
+            srank[q] = 0;
+            if (i < total) {
+                uint32_t p = part_of[i];
+                uint32_t j = cursor[p] + (i - off[p]);
+                if (j < (uint32_t)a.out_cap) a.out_entries[(out_base + (int64_t)p * out_stride) * a.out_cap + j] = stage[i];
+                else { spilled |= 1u << q; srank[q] = atomicAdd(&s_spill, 1u); }
+            }
         }
         __syncthreads();
+        // D2: regions that are full (a heavy key, an uneven split) spill into one global buffer: one atomic per tile
+        if (s_spill) {
+            if (tid == 0) s_spill_base = atomicAdd(&a.flags[2], (unsigned long long)s_spill);
+            __syncthreads();
+            const unsigned long long sb = s_spill_base;
+#pragma unroll
+            for (int q = 0; q < PT_ITEMS; q++) {
+                if (!((spilled >> q) & 1u)) continue;
+                const unsigned long long pos = sb + srank[q];
+                if ((int64_t)pos < a.spill_cap) a.spill[pos] = stage[(uint32_t)q * PT_BLOCK + tid];
+                else __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            if (tid == 0) s_spill = 0;
+        }
         // E: advance cursors
         if (tid < np) { cursor[tid] += cnt[tid]; cnt[tid] = 0; }
         __syncthreads();
@@ -1173,7 +1228,7 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
             }, [&]() { load_entries(t0 + PT_TILE); });
         }
     }
-    if (tid < np) a.out_counts[out_base + (int64_t)tid * out_stride] = cursor[tid];
+    if (tid < np) a.out_counts[out_base + (int64_t)tid * out_stride] = cursor[tid] < (uint32_t)a.out_cap ? cursor[tid] : (uint32_t)a.out_cap;
 }
 
 struct PartAggArgs {
@@ -2063,7 +2118,10 @@ int estimate_groups(vnm_agg* h, const vnm_dcol& key, int64_t nrows, int64_t* est
 }
 
 // returns 0 = done (run stored), 2 = not applicable / overflowed (caller uses the general path), 1 = error
-int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s) {
+// spill_out / n_spill_out (optional): entries that did not fit their partition region (heavy keys); the caller
+// aggregates them with agg_hot_kernel<FROM_ENT> and owns the buffer.  Without them a full region fails the attempt.
+int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s, ulonglong2** spill_out = nullptr,
+                          int64_t* n_spill_out = nullptr) {
     const int cus = device_info().num_cus;
     // final partitions sized for ~900 groups each: enough keys per partition that their sizes concentrate
     // (few keys per partition -> Poisson imbalance overflows the fixed-capacity regions), few enough for
@@ -2090,6 +2148,9 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     uint32_t* c1 = (uint32_t*)pool_alloc((size_t)np1 * grid1 * 4);
     if (!flags || !e1 || !c1) return 1;
     VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
+    const int64_t spill_cap = spill_out ? nrows / 2 + (1 << 20) : 0;
+    ulonglong2* spill = spill_out ? (ulonglong2*)pool_alloc((size_t)spill_cap * 16) : nullptr;
+    if (spill_out && !spill) return 1;
     PartArgs p1{};
     p1.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
     p1.vp = h->plan.n_cols ? (const double*)a.cols[0].values + a.cols[0].offset : (const double*)p1.kp;
@@ -2101,6 +2162,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     while ((1 << lg1) < np1) lg1++;
     p1.nparts = np1; p1.shift = 32 - lg1; p1.flags = flags;
     p1.debug = (int)env_i64("VNM_PART_DEBUG", 0);
+    p1.spill = spill; p1.spill_cap = spill_cap;
     {
         KernelTimer timer("agg_part_scatter1", s);
         part_scatter_kernel<true><<<grid1, PT_BLOCK, 0, s>>>(p1);
@@ -2117,7 +2179,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     {
         int ov = overflowed();
         if (ov) {
-            pool_free(e1); pool_free(c1); pool_free(flags);
+            pool_free(e1); pool_free(c1); pool_free(flags); pool_free(spill);
             return ov < 0 ? set_error("aggregate: partition pass failed") : 2;
         }
     }
@@ -2140,6 +2202,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         p2.out_entries = e2; p2.out_counts = c2; p2.out_cap = cap2;
         p2.nparts = np2; p2.shift = 15; p2.flags = flags;  // hash bits [23:15] (pass 1 used [31:24])
         p2.debug = p1.debug;
+        p2.spill = spill; p2.spill_cap = spill_cap;
         {
             KernelTimer timer("agg_part_scatter2", s);
             part_scatter_kernel<false><<<np1 * p2.in_split, PT_BLOCK, 0, s>>>(p2);
@@ -2148,7 +2211,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         {
             int ov = overflowed();
             if (ov) {
-                pool_free(e1); pool_free(c1); pool_free(e2); pool_free(c2); pool_free(flags);
+                pool_free(e1); pool_free(c1); pool_free(e2); pool_free(c2); pool_free(flags); pool_free(spill);
                 return ov < 0 ? set_error("aggregate: partition pass failed") : 2;
             }
         }
@@ -2164,7 +2227,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     }
     const bool to_table = splits > 1;
     if (to_table && (h->have_table || h->have_run)) {
-        pool_free(e1); pool_free(c1); pool_free(e2); pool_free(c2); pool_free(flags);
+        pool_free(e1); pool_free(c1); pool_free(e2); pool_free(c2); pool_free(flags); pool_free(spill);
         return 2;
     }
     // dense output sized from the hint (guarded in the kernel)
@@ -2209,14 +2272,18 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         }
     }
     VNM_HIP(hipGetLastError());
-    unsigned long long fl[2];
-    VNM_HIP(hipMemcpyAsync(fl, flags, 16, hipMemcpyDeviceToHost, s));
+    unsigned long long fl[3];
+    VNM_HIP(hipMemcpyAsync(fl, flags, 24, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
     pool_free(e1); pool_free(c1); pool_free(e2); pool_free(c2); pool_free(flags);
-    if (fl[0]) {  // skewed partitions / more groups than hinted: use the general path for this batch
-        pool_free(rk); pool_free(ra); pool_free(dir);
+    if (fl[0]) {  // more groups than hinted / spill buffer full: use the general path for this batch
+        pool_free(rk); pool_free(ra); pool_free(dir); pool_free(spill);
         if (to_table) { table_free(&h->g); h->have_table = false; }  // drop the partial merge
         return 2;
+    }
+    if (spill_out) {
+        if (fl[2]) { *spill_out = spill; *n_spill_out = (int64_t)fl[2]; }
+        else { pool_free(spill); *spill_out = nullptr; *n_spill_out = 0; }
     }
     if (to_table) {  // the groups already live in the HBM table
         pool_free(rk); pool_free(ra);
@@ -2548,14 +2615,23 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     // ... from the point where the groups stop fitting the LDS table of the scan kernel (flush storms otherwise:
     // MIN+MAX with 2000 groups and a 2048-slot table ran at 38 ms)
     const int64_t part_min = env_i64("VNM_AGG_PART_MIN_GROUPS", std::min<int64_t>(2400, (int64_t)S * 6 / 10));
+    ulonglong2* spill = nullptr;  // entries the partitioned path could not place (heavy keys): aggregated below
+    int64_t n_spill = 0;
     if (part_ok && h->hint > part_min && getenv("VNM_AGG_NO_PART") == nullptr) {
         if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
-        int prc = partitioned_aggregate(h, a, nrows, s);
-        if (prc == 0) { h->rows_seen += nrows; return 0; }
+        const bool can_spill = hot_scan && getenv("VNM_AGG_NO_SPILL") == nullptr;
+        int prc = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
+        if (prc == 0 && !spill) { h->rows_seen += nrows; return 0; }
         if (prc == 1) return 1;
+        if (prc == 0) {  // the scan below runs over the spilled entries only (predicate already applied)
+            a.ent = spill;
+            a.nrows = n_spill;
+            a.p.enabled = 0;
+        }
     }
-    VNM_TRY(ensure_table(h, nrows, s));
-    if (hot_scan) a.ntiles = (nrows + HOT_TILE - 1) / HOT_TILE;
+    const int64_t scan_n = a.nrows;
+    VNM_TRY(ensure_table(h, scan_n, s));
+    if (hot_scan) a.ntiles = (scan_n + HOT_TILE - 1) / HOT_TILE;
     // generic single-key kernel, small known group count: two 512-thread workgroups per CU with 64 KB tables
     const int S2 = lds_slots_for(h->plan, 64 * 1024);
     const bool twin = !hot_scan && h->single && h->hint > 0 && h->hint <= (int64_t)S2 * 6 / 10 && getenv("VNM_AGG_TWIN") != nullptr;  // measured slower (9.9-13.8 vs 9.9 ms): off
@@ -2583,7 +2659,15 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         VNM_HIP(hipFuncSetAttribute((const void*)agg_hot_kernel<P, V, HV, SI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
         agg_hot_kernel<P, V, HV, SI><<<grid, AGG_BLOCK, lds_bytes, s>>>(a);                                    \
     } while (0)
-            if (hot) {  // the north-star shape
+            if (a.ent) {  // spilled entries of the partitioned path
+                if (hot) {
+                    VNM_HIP(hipFuncSetAttribute((const void*)agg_hot_kernel<false, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                    agg_hot_kernel<false, false, true, true, true><<<grid, AGG_BLOCK, lds_bytes, s>>>(a);
+                } else {
+                    VNM_HIP(hipFuncSetAttribute((const void*)agg_hot_kernel<false, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                    agg_hot_kernel<false, false, true, false, true><<<grid, AGG_BLOCK, lds_bytes, s>>>(a);
+                }
+            } else if (hot) {  // the north-star shape
                 if (!h->pred_set) VNM_HOT(false, false, true, true);
                 else if (a.hot_pred_is_v) VNM_HOT(true, true, true, true);
                 else VNM_HOT(true, false, true, true);
@@ -2617,6 +2701,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         VNM_TRY(table_grow(h, new_cap, s));
     }
     pool_free(progress);
+    pool_free(spill);
     h->rows_seen += nrows;
     return 0;
 }
