@@ -218,25 +218,36 @@ def test_partitioned_path_wrong_hint_falls_back():
     util.assert_agg_equal(got, o.result(), funcs, ["k"], what="wrong hint")
 
 
-def test_partitioned_path_skewed_keys_fall_back_early():
-    """Power-law keys: a few keys own most rows, so their partition regions overflow in the first scatter pass.
-    The operator must notice right there (not after aggregating doomed partitions -- one workgroup would chew
-    through the heavy key's partition alone) and give the exact answer through the scan kernel."""
+@pytest.mark.parametrize("shape", ["sum_avg", "min_max_int"])
+@pytest.mark.parametrize("spill", [True, False])
+def test_partitioned_path_skewed_keys(shape, spill, monkeypatch):
+    """Power-law keys: a few keys own most rows, so their partition regions fill up in the first scatter pass.
+    Entries that do not fit spill to the scan kernel (whose LDS table absorbs exactly the heavy keys); the result is
+    a run + a table, merged at finish.  With spilling disabled the operator must notice the overflow right after the
+    pass (not after aggregating doomed partitions) and fall back.  Two batches also exercise run + table + run."""
     import time
     from oracle import oracle as O
+    if not spill:
+        monkeypatch.setenv("VNM_AGG_NO_SPILL", "1")
     rng = np.random.default_rng(11)
     n = 900_000
     groups = 80_000
     k = np.floor(groups * rng.random(n) ** 8).astype(np.int64)
-    t = pa.table({"k": pa.array(k), "v": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0)})
-    funcs = [(O.SUM, "v", "sum_v"), (O.AVG, "v", "avg_v"), (O.COUNT_STAR, "", "n")]
-    t0 = time.perf_counter()
-    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, t.to_batches(), expected_groups=groups)
-    assert time.perf_counter() - t0 < 20.0
-    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
-    for b in t.to_batches():
-        o.next(b)
-    util.assert_agg_equal(got, o.result(), funcs, ["k"], what="skewed keys")
+    k[rng.integers(0, n, 3)] = -1   # the EMPTY-sentinel key among them
+    if shape == "sum_avg":
+        t = pa.table({"k": pa.array(k), "v": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0)})
+        funcs = [(O.SUM, "v", "sum_v"), (O.AVG, "v", "avg_v"), (O.COUNT_STAR, "", "n")]
+    else:
+        t = pa.table({"k": pa.array(k), "v": pa.array(rng.integers(-2**40, 2**40, n).astype(np.int64))})
+        funcs = [(O.MIN, "v", "lo"), (O.MAX, "v", "hi"), (O.SUM, "v", "s"), (O.COUNT, "v", "c")]
+    for batches in (t.to_batches(), util.sliced_batches(t, 500_000)):
+        t0 = time.perf_counter()
+        got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, expected_groups=groups)
+        assert time.perf_counter() - t0 < 20.0
+        o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+        for b in batches:
+            o.next(b)
+        util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"skewed keys {shape} spill={spill}")
 
 
 @pytest.mark.parametrize("groups", [50, 20_000, 400_000])
