@@ -218,6 +218,42 @@ def test_partitioned_path_wrong_hint_falls_back():
     util.assert_agg_equal(got, o.result(), funcs, ["k"], what="wrong hint")
 
 
+@pytest.mark.parametrize("ncols", [2, 3])
+@pytest.mark.parametrize("levels", [1, 2])
+@pytest.mark.parametrize("with_pred", ["none", "on_input", "on_other"])
+def test_partitioned_path_several_input_columns(ncols, levels, with_pred, monkeypatch):
+    """Aggregates over two or three 8-byte input columns take the partitioned path with wide entries
+    (key + one raw value per column); every accumulator kind, a predicate on one of the inputs or on a
+    fourth column.  Bit-exact against the oracle (quantised floats, integers)."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_PART_L1_MAX", "4" if levels == 2 else "256")
+    rng = np.random.default_rng(ncols * 10 + levels)
+    n = 450_007
+    groups = 50_000
+    k = rng.integers(0, groups, n).astype(np.int64) * 977 - 5
+    k[rng.integers(0, n, 4)] = -1
+    cols = {"k": pa.array(k),
+            "a": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0),
+            "b": pa.array(rng.integers(-2**40, 2**40, n).astype(np.int64)),
+            "c": pa.array(rng.integers(0, 2**63, n).astype(np.uint64)),
+            "p": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0)}
+    funcs = [(O.SUM, "a", "sa"), (O.AVG, "a", "ma"), (O.MAX, "b", "xb"), (O.SUM, "b", "sb"), (O.COUNT_STAR, "", "n")]
+    if ncols == 3:
+        funcs += [(O.MIN, "c", "nc"), (O.AVG, "c", "mc")]
+    pred = {"none": None, "on_input": ("a", ">", 64.0), "on_other": ("p", "<=", 100.0)}[with_pred]
+    t = pa.table(cols)
+    names = t.schema.names
+    for batches in (t.to_batches(), util.sliced_batches(t, 250_000)):
+        got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=pred, expected_groups=groups)
+        o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+        for b in batches:
+            if pred:
+                op = {">": O.GT, "<=": O.LE}[pred[1]]
+                b = O.filter_batch(b, O.cmp_mask(b.column(names.index(pred[0])), op, pred[2]))
+            o.next(b)
+        util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"wide entries ncols={ncols} L={levels} pred={with_pred}")
+
+
 @pytest.mark.parametrize("shape", ["sum_avg", "min_max_int"])
 @pytest.mark.parametrize("spill", [True, False])
 def test_partitioned_path_skewed_keys(shape, spill, monkeypatch):

@@ -68,6 +68,7 @@ struct AggArgs {
     const ulonglong2* ent;  // agg_hot_kernel<FROM_ENT>: (key, value bits) entries spilled by the partitioned path
     int part_generic;  // partitioned path with a generic accumulator program over one 8-byte column (or none)
     int part_vtype;
+    int part_vtypes[3];  // wide entries: type of each input column
     int debug;  // timing experiments (VNM_AGG_DEBUG): 1 = no accumulator ops, 2 = no probes either, 4 = no room check
 };
 
@@ -1026,7 +1027,11 @@ struct PartArgs {
     // entries that do not fit their region (skewed keys) are appended here and aggregated by agg_entries_kernel
     ulonglong2* spill;
     int64_t spill_cap;
-    int debug;  // timing experiments (VNM_PART_DEBUG): 1 = no copy-out stores, 2 = no staging / copy-out at all
+    int debug;
+    // wide entries (part_scatter_wide_kernel): key + nval raw values per entry
+    const uint64_t* vcol[3];
+    int nval;
+    int pred_col;  // value column that is also the predicate column, or -1 (predicate read from pp)  // timing experiments (VNM_PART_DEBUG): 1 = no copy-out stores, 2 = no staging / copy-out at all
 };
 
 template <bool FROM_ROWS>
@@ -1231,6 +1236,153 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
     if (tid < np) a.out_counts[out_base + (int64_t)tid * out_stride] = cursor[tid] < (uint32_t)a.out_cap ? cursor[tid] : (uint32_t)a.out_cap;
 }
 
+// -------------------------------------------------------------------------------------------------------
+// Wide entries: aggregates over 2-3 input columns carry (key, v1, v2[, v3]) = E 8-byte words per entry.  Same
+// passes and region bookkeeping as part_scatter_kernel, 4096-entry tiles (the LDS stage holds E words per entry),
+// 8-byte column loads, no prefetch and no spill buffer: a straightforward version -- it only has to beat the HBM
+// atomics of the general path (two input columns, G >= 1e5: 217-250 ms per 1e9 rows).
+// -------------------------------------------------------------------------------------------------------
+constexpr int PW_ITEMS = 4;
+constexpr int PW_TILE = PT_BLOCK * PW_ITEMS;
+template <bool FROM_ROWS, int E>
+__global__ __launch_bounds__(PT_BLOCK) void part_scatter_wide_kernel(PartArgs a) {
+    extern __shared__ uint64_t wstage[];  // [PW_TILE][E]
+    __shared__ uint16_t part_of[PW_TILE];
+    __shared__ uint32_t cnt[PT_MAXP], off[PT_MAXP], cursor[PT_MAXP];
+    __shared__ uint32_t s_total;
+    __shared__ uint32_t wtot[PT_MAXP / 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int np = a.nparts;
+    const uint32_t pmask = (uint32_t)np - 1;
+    const int npad = np < 64 ? 64 : np;
+    for (int i = tid; i < PT_MAXP; i += PT_BLOCK) { cnt[i] = 0; cursor[i] = 0; }
+    __syncthreads();
+    uint64_t* const oute = (uint64_t*)a.out_entries;
+    const uint64_t* const ine = (const uint64_t*)a.in_entries;
+    int64_t out_base, out_stride;
+    if (FROM_ROWS) { out_base = blockIdx.x; out_stride = gridDim.x; }
+    else {
+        const int pin = blockIdx.x / a.in_split, g = blockIdx.x % a.in_split;
+        out_base = (int64_t)pin * np * a.in_split + g; out_stride = a.in_split;
+    }
+    uint64_t ent[PW_ITEMS][E];
+    auto process_tile = [&](uint32_t valid) {
+        uint32_t myp[PW_ITEMS], myr[PW_ITEMS];
+#pragma unroll
+        for (int k = 0; k < PW_ITEMS; k++) {
+            myp[k] = 0xFFFFFFFFu;
+            if ((valid >> k) & 1u) {
+                uint32_t p = (hash_u64(ent[k][0]) >> a.shift) & pmask;
+                myp[k] = p;
+                myr[k] = atomicAdd(&cnt[p], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < npad) {
+            uint32_t c = cnt[tid], inc = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+            off[tid] = inc - c;
+            if (lane == 63) wtot[tid >> 6] = inc;
+        }
+        __syncthreads();
+        if (tid < npad) {
+            uint32_t add = 0;
+            for (int w = 0; w < (tid >> 6); w++) add += wtot[w];
+            off[tid] += add;
+            if (tid == npad - 1) s_total = off[tid] + cnt[tid];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PW_ITEMS; k++) {
+            if (myp[k] != 0xFFFFFFFFu) {
+                uint32_t pos = off[myp[k]] + myr[k];
+#pragma unroll
+                for (int e = 0; e < E; e++) wstage[pos * E + e] = ent[k][e];
+                part_of[pos] = (uint16_t)myp[k];
+            }
+        }
+        __syncthreads();
+        const uint32_t total = s_total;
+        for (uint32_t i = tid; i < total; i += PT_BLOCK) {
+            uint32_t p = part_of[i];
+            uint32_t j = cursor[p] + (i - off[p]);
+            if (j < (uint32_t)a.out_cap) {
+                uint64_t* dst = oute + (((out_base + (int64_t)p * out_stride) * a.out_cap + j) * E);
+#pragma unroll
+                for (int e = 0; e < E; e++) dst[e] = wstage[i * E + e];
+            } else __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (tid < np) { cursor[tid] += cnt[tid]; cnt[tid] = 0; }
+        __syncthreads();
+    };
+    if (FROM_ROWS) {
+        const int64_t ntiles = (a.nrows + PW_TILE - 1) / PW_TILE;
+        for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            uint32_t valid = 0;
+            double pv[PW_ITEMS];
+#pragma unroll
+            for (int k = 0; k < PW_ITEMS; k++) {
+                const int64_t row = tile * PW_TILE + (int64_t)k * PT_BLOCK + tid;
+                const int64_t rc = row < a.nrows ? row : a.nrows - 1;
+                if (row < a.nrows) valid |= 1u << k;
+                ent[k][0] = a.kp[rc];
+#pragma unroll
+                for (int c = 0; c < E - 1; c++) ent[k][1 + c] = a.vcol[c][rc];
+                pv[k] = (a.has_pred && a.pred_col < 0) ? a.pp[rc] : 0.0;
+            }
+            if (a.has_pred) {
+#pragma unroll
+                for (int k = 0; k < PW_ITEMS; k++) {
+                    double p = pv[k];
+#pragma unroll
+                    for (int c = 0; c < E - 1; c++) if (a.pred_col == c) p = __longlong_as_double((long long)ent[k][1 + c]);
+                    if (!cmp_apply<double>(a.op, p, a.thr)) valid &= ~(1u << k);
+                }
+            }
+            process_tile(valid);
+        }
+    } else {
+        __shared__ uint32_t rstart[PT_MAX_REGIONS + 1];
+        const int pin = blockIdx.x / a.in_split;
+        const int per_max = (a.in_regions + a.in_split - 1) / a.in_split;
+        const int g = blockIdx.x % a.in_split;
+        const int first = g * per_max;
+        const int per = first + per_max <= a.in_regions ? per_max : (a.in_regions > first ? a.in_regions - first : 0);
+        const int64_t region0 = (int64_t)pin * a.in_regions + first;
+        if (tid == 0) {
+            uint32_t run = 0;
+            for (int rj = 0; rj < per; rj++) { rstart[rj] = run; run += a.in_counts[region0 + rj]; }
+            rstart[per] = run;
+        }
+        __syncthreads();
+        const uint32_t total_in = rstart[per];
+        int reg[PW_ITEMS];
+#pragma unroll
+        for (int k = 0; k < PW_ITEMS; k++) reg[k] = 0;
+        for (uint32_t t0 = 0; t0 < total_in; t0 += PW_TILE) {
+            uint32_t valid = 0;
+#pragma unroll
+            for (int k = 0; k < PW_ITEMS; k++) {
+                uint32_t v = t0 + (uint32_t)k * PT_BLOCK + tid;
+                if (v < total_in) {
+                    int lo = reg[k];
+                    while (rstart[lo + 1] <= v) lo++;
+                    reg[k] = lo;
+                    const uint64_t* src = ine + (((region0 + lo) * a.in_cap + (v - rstart[lo])) * E);
+#pragma unroll
+                    for (int e = 0; e < E; e++) ent[k][e] = src[e];
+                    valid |= 1u << k;
+                }
+            }
+            process_tile(valid);
+        }
+    }
+    if (tid < np) a.out_counts[out_base + (int64_t)tid * out_stride] = cursor[tid] < (uint32_t)a.out_cap ? cursor[tid] : (uint32_t)a.out_cap;
+}
+
 struct PartAggArgs {
     const ulonglong2* entries;
     const uint32_t* counts;
@@ -1251,6 +1403,8 @@ struct PartAggArgs {
     unsigned long long* dir;  // [2 * nfinal]: (first dense row, row count) of every final partition, or NULL
     // generic accumulator program over the entry's value bits (part_agg_generic_kernel)
     int n_ops, vtype;
+    int ent_words;   // 2 = (key, value); 3 / 4 = key + 2 / 3 values (wide entries)
+    int vtypes[3];
     AccOp ops[AGG_MAX_OPS];
     int merge[AGG_MAX_WORDS];
 };
@@ -1400,6 +1554,7 @@ __device__ __forceinline__ uint64_t op_value_bits(int kind, int vtype, uint64_t 
 
 // Final pass of the partitioned path for ANY accumulator program over one 8-byte input column (or none):
 // same protocol as part_agg_kernel, W accumulator words per LDS slot.  LDS: lkey[S + 1], lw[W][S + 1].
+template <int E>
 __global__ __launch_bounds__(PA_BLOCK) void part_agg_generic_kernel(PartAggArgs a) {
     extern __shared__ uint64_t pa_lds[];
     __shared__ uint32_t s_n, s_fail;
@@ -1425,19 +1580,25 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_generic_kernel(PartAggArgs 
         for (int rj = part; rj < a.regions; rj += a.splits) {
             const int64_t region = f * a.regions + rj;
             const uint32_t n = a.counts[region];
-            const ulonglong2* src = a.entries + region * a.cap;
+            const uint64_t* src = (const uint64_t*)a.entries + region * a.cap * E;
             for (uint32_t i0 = 0; i0 < n; i0 += PA_BLOCK * 4) {
-                ulonglong2 eb[4];
+                uint64_t eb[4][E];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     uint32_t i = i0 + (uint32_t)u * PA_BLOCK + tid;
-                    if (i < n) eb[u] = src[i];
+                    if (i < n) {
+                        if (E == 2) { const ulonglong2 t = ((const ulonglong2*)src)[i]; eb[u][0] = t.x; eb[u][1] = t.y; }
+                        else {
+#pragma unroll
+                            for (int e = 0; e < E; e++) eb[u][e] = src[(size_t)i * E + e];
+                        }
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     uint32_t i = i0 + (uint32_t)u * PA_BLOCK + tid;
                     if (i >= n) continue;
-                    const uint64_t key = eb[u].x;
+                    const uint64_t key = eb[u][0];
                     int slot = -1;
                     if (key == EMPTY) { slot = PA_SLOTS; lkey[slot] = 0; }
                     else {
@@ -1462,7 +1623,11 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_generic_kernel(PartAggArgs 
                     if (slot >= 0) {
                         for (int o = 0; o < a.n_ops; o++) {
                             const int w = a.ops[o].word;
-                            l_merge(&lw[w * ST + slot], a.merge[w], op_value_bits(a.ops[o].kind, a.vtype, eb[u].y));
+                            const int c = E == 2 ? 0 : (a.ops[o].col < 0 ? 0 : a.ops[o].col);
+                            uint64_t vb = eb[u][1];
+#pragma unroll
+                            for (int e = 2; e < E; e++) if (c == e - 1) vb = eb[u][e];
+                            l_merge(&lw[w * ST + slot], a.merge[w], op_value_bits(a.ops[o].kind, E == 2 ? a.vtype : a.vtypes[c], vb));
                         }
                     }
                 }
@@ -2135,16 +2300,21 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         if (h->hint / (l1_max * 512) > 1600) return 2;  // would need a third level
         nfin = l1_max * 512;
     }
+    // entry = key + one value (16 bytes, tuned kernels) or key + 2-3 values (wide entries)
+    const int E = (a.part_generic && h->plan.n_cols >= 2) ? 1 + h->plan.n_cols : 2;
+    const int64_t tile1 = E == 2 ? PT_TILE : PW_TILE;
+    const size_t ebytes = (size_t)E * 8;
+    if (E > 2) { spill_out = nullptr; n_spill_out = nullptr; }
     const int levels = nfin > l1_max ? 2 : 1;
     const int np1 = levels == 2 ? (int)l1_max : (int)nfin;
     const int np2 = levels == 2 ? (int)(nfin / l1_max) : 0;
-    const int grid1 = (int)std::min<int64_t>((int64_t)cus * 2, (nrows + PT_TILE - 1) / PT_TILE);
+    const int grid1 = (int)std::min<int64_t>((int64_t)cus * 2, (nrows + tile1 - 1) / tile1);
     const int split2 = std::max(2, (grid1 + PT_MAX_REGIONS - 1) / PT_MAX_REGIONS);  // pass-2 workgroups per partition
-    const int64_t tiles_per_wg = ((nrows + PT_TILE - 1) / PT_TILE + grid1 - 1) / grid1;
-    const int64_t rows_per_wg = tiles_per_wg * PT_TILE;
+    const int64_t tiles_per_wg = ((nrows + tile1 - 1) / tile1 + grid1 - 1) / grid1;
+    const int64_t rows_per_wg = tiles_per_wg * tile1;
     const int64_t cap1 = rows_per_wg / np1 + rows_per_wg / np1 / 5 + 512;
     unsigned long long* flags = (unsigned long long*)pool_alloc(64);
-    ulonglong2* e1 = (ulonglong2*)pool_alloc((size_t)np1 * grid1 * cap1 * 16);
+    ulonglong2* e1 = (ulonglong2*)pool_alloc((size_t)np1 * grid1 * cap1 * ebytes);
     uint32_t* c1 = (uint32_t*)pool_alloc((size_t)np1 * grid1 * 4);
     if (!flags || !e1 || !c1) return 1;
     VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
@@ -2163,9 +2333,27 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     p1.nparts = np1; p1.shift = 32 - lg1; p1.flags = flags;
     p1.debug = (int)env_i64("VNM_PART_DEBUG", 0);
     p1.spill = spill; p1.spill_cap = spill_cap;
+    p1.nval = E - 1;
+    p1.pred_col = -1;
+    if (E > 2) {
+        for (int c = 0; c < E - 1; c++) {
+            p1.vcol[c] = (const uint64_t*)a.cols[c].values + a.cols[c].offset;
+            if (h->pred_set && a.pred.values == a.cols[c].values && a.pred.offset == a.cols[c].offset && a.cols[c].type == VNM_F64) p1.pred_col = c;
+        }
+    }
     {
         KernelTimer timer("agg_part_scatter1", s);
-        part_scatter_kernel<true><<<grid1, PT_BLOCK, 0, s>>>(p1);
+        if (E == 2) part_scatter_kernel<true><<<grid1, PT_BLOCK, 0, s>>>(p1);
+        else {
+            const size_t lds = (size_t)PW_TILE * ebytes;
+            if (E == 3) {
+                VNM_HIP(hipFuncSetAttribute((const void*)part_scatter_wide_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                part_scatter_wide_kernel<true, 3><<<grid1, PT_BLOCK, lds, s>>>(p1);
+            } else {
+                VNM_HIP(hipFuncSetAttribute((const void*)part_scatter_wide_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                part_scatter_wide_kernel<true, 4><<<grid1, PT_BLOCK, lds, s>>>(p1);
+            }
+        }
     }
     VNM_HIP(hipGetLastError());
     // A region overflowed (skewed keys, or more rows per partition than the hint implied): stop here.  Carrying on
@@ -2194,7 +2382,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         // worst case: every row survived and spread evenly; 25 % slack + constant
         const int64_t per_pg = (int64_t)grid1 * rows_per_wg / np1 / split2;
         const int64_t cap2 = per_pg / np2 + per_pg / np2 / 4 + 256;
-        e2 = (ulonglong2*)pool_alloc((size_t)np1 * np2 * split2 * cap2 * 16);
+        e2 = (ulonglong2*)pool_alloc((size_t)np1 * np2 * split2 * cap2 * ebytes);
         c2 = (uint32_t*)pool_alloc((size_t)np1 * np2 * split2 * 4);
         if (!e2 || !c2) return 1;
         PartArgs p2{};
@@ -2203,9 +2391,20 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         p2.nparts = np2; p2.shift = 15; p2.flags = flags;  // hash bits [23:15] (pass 1 used [31:24])
         p2.debug = p1.debug;
         p2.spill = spill; p2.spill_cap = spill_cap;
+        p2.nval = E - 1;
         {
             KernelTimer timer("agg_part_scatter2", s);
-            part_scatter_kernel<false><<<np1 * p2.in_split, PT_BLOCK, 0, s>>>(p2);
+            if (E == 2) part_scatter_kernel<false><<<np1 * p2.in_split, PT_BLOCK, 0, s>>>(p2);
+            else {
+                const size_t lds = (size_t)PW_TILE * ebytes;
+                if (E == 3) {
+                    VNM_HIP(hipFuncSetAttribute((const void*)part_scatter_wide_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    part_scatter_wide_kernel<false, 3><<<np1 * p2.in_split, PT_BLOCK, lds, s>>>(p2);
+                } else {
+                    VNM_HIP(hipFuncSetAttribute((const void*)part_scatter_wide_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    part_scatter_wide_kernel<false, 4><<<np1 * p2.in_split, PT_BLOCK, lds, s>>>(p2);
+                }
+            }
         }
         VNM_HIP(hipGetLastError());
         {
@@ -2265,8 +2464,15 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
             for (int o = 0; o < h->plan.n_ops; o++) pa.ops[o] = h->plan.ops[o];
             for (int w = 0; w < h->plan.n_words; w++) pa.merge[w] = h->plan.merge[w];
             const size_t lds_bytes = (size_t)(PA_SLOTS + 1) * 8 * (1 + h->plan.n_words);
-            VNM_HIP(hipFuncSetAttribute((const void*)part_agg_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            part_agg_generic_kernel<<<g3, PA_BLOCK, lds_bytes, s>>>(pa);
+            pa.ent_words = E;
+            for (int c = 0; c < 3; c++) pa.vtypes[c] = a.part_vtypes[c];
+#define VNM_PAG(E_)                                                                                                  \
+    do {                                                                                                             \
+        VNM_HIP(hipFuncSetAttribute((const void*)part_agg_generic_kernel<E_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        part_agg_generic_kernel<E_><<<g3, PA_BLOCK, lds_bytes, s>>>(pa);                                             \
+    } while (0)
+            if (E == 2) VNM_PAG(2); else if (E == 3) VNM_PAG(3); else VNM_PAG(4);
+#undef VNM_PAG
         } else {
             part_agg_kernel<<<g3, PA_BLOCK, 0, s>>>(pa);
         }
@@ -2585,15 +2791,16 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     // the partitioned path also takes ANY accumulator program over at most one 8-byte input column: its entries
     // carry (key, raw value bits) and only the final pass interprets them
     bool part_ok = hot;
-    if (!hot && h->single && h->plan.n_cols <= 1 && type_width(keys[0].type) == 8 && !keys[0].validity &&
+    if (!hot && h->single && h->plan.n_cols <= 3 && type_width(keys[0].type) == 8 && !keys[0].validity &&
         (keys[0].offset & 1) == 0 && getenv("VNM_AGG_NO_PART_GENERIC") == nullptr &&
         (size_t)(PA_SLOTS + 1) * 8 * (1 + h->plan.n_words) <= 150 * 1024) {
         part_ok = true;
-        if (h->plan.n_cols == 1) {
-            const vnm_dcol& c = a.cols[0];
-            part_ok = (c.type == VNM_I64 || c.type == VNM_U64 || c.type == VNM_F64) && !c.validity && (c.offset & 1) == 0;
-            a.part_vtype = c.type;
+        for (int c = 0; c < h->plan.n_cols && part_ok; c++) {
+            const vnm_dcol& col = a.cols[c];
+            part_ok = (col.type == VNM_I64 || col.type == VNM_U64 || col.type == VNM_F64) && !col.validity && (col.offset & 1) == 0;
+            a.part_vtypes[c] = col.type;
         }
+        if (h->plan.n_cols >= 1) a.part_vtype = a.cols[0].type;
         if (part_ok && h->pred_set) {
             part_ok = a.pred.type == VNM_F64 && !a.pred.validity && (a.pred.offset & 1) == 0 && a.p.mode == CMP_F64;
             a.hot_pred_is_v = h->plan.n_cols == 1 && a.pred.values == a.cols[0].values && a.pred.offset == a.cols[0].offset;
