@@ -254,6 +254,50 @@ def test_partitioned_path_several_input_columns(ncols, levels, with_pred, monkey
         util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"wide entries ncols={ncols} L={levels} pred={with_pred}")
 
 
+@pytest.mark.parametrize("case", ["nullable_f64", "int32_and_nullable_i64", "float32_uint16", "int_predicate"])
+@pytest.mark.parametrize("levels", [1, 2])
+def test_partitioned_path_nulls_and_narrow_types(case, levels, monkeypatch):
+    """Wide entries also carry a validity word and raw bits of any numeric width, and the first pass evaluates any
+    predicate column: NULL inputs (skipped, all-NULL groups give NULL), int32 / float32 / uint16 inputs (AVG of
+    16-bit ints is float32, agg_func_factory.cpp:179-196), an integer predicate."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_PART_L1_MAX", "4" if levels == 2 else "256")
+    rng = np.random.default_rng(len(case) + levels)
+    n = 400_003
+    groups = 40_000
+    k = rng.integers(0, groups, n).astype(np.int64) * 31 - 9
+    cols = {"k": pa.array(k)}
+    pred = None
+    if case == "nullable_f64":
+        cols["a"] = pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0, mask=rng.random(n) < 0.3)
+        funcs = [(O.SUM, "a", "s"), (O.AVG, "a", "m"), (O.COUNT, "a", "c"), (O.COUNT_STAR, "", "n"), (O.MIN, "a", "lo")]
+        pred = ("a", ">", 10.0)   # NULL compares False (NaN), record_batch.py:112-118
+    elif case == "int32_and_nullable_i64":
+        cols["a"] = pa.array(rng.integers(-2**31, 2**31 - 1, n).astype(np.int32))
+        cols["b"] = pa.array(rng.integers(-2**50, 2**50, n).astype(np.int64), mask=rng.random(n) < 0.5)
+        funcs = [(O.SUM, "a", "sa"), (O.AVG, "a", "ma"), (O.MAX, "a", "xa"), (O.SUM, "b", "sb"), (O.MIN, "b", "nb"), (O.COUNT, "b", "cb")]
+    elif case == "float32_uint16":
+        cols["a"] = pa.array((rng.integers(0, 2**10, n) / 8.0).astype(np.float32))
+        cols["b"] = pa.array(rng.integers(0, 2**16, n).astype(np.uint16))
+        funcs = [(O.SUM, "a", "sa"), (O.MAX, "a", "xa"), (O.AVG, "b", "mb"), (O.SUM, "b", "sb"), (O.MIN, "b", "nb")]
+    else:
+        cols["a"] = pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0)
+        cols["p"] = pa.array(rng.integers(-100, 100, n).astype(np.int64))
+        funcs = [(O.SUM, "a", "s"), (O.COUNT_STAR, "", "n")]
+        pred = ("p", ">=", 0)
+    t = pa.table(cols)
+    names = t.schema.names
+    for batches in (t.to_batches(), util.sliced_batches(t, 250_000)):
+        got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=pred, expected_groups=groups)
+        o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+        for b in batches:
+            if pred:
+                op = {">": O.GT, ">=": O.GE}[pred[1]]
+                b = O.filter_batch(b, O.cmp_mask(b.column(names.index(pred[0])), op, pred[2]))
+            o.next(b)
+        util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"wide entries {case} L={levels}")
+
+
 @pytest.mark.parametrize("shape", ["sum_avg", "min_max_int"])
 @pytest.mark.parametrize("spill", [True, False])
 def test_partitioned_path_skewed_keys(shape, spill, monkeypatch):

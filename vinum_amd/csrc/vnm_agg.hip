@@ -69,6 +69,8 @@ struct AggArgs {
     int part_generic;  // partitioned path with a generic accumulator program over one 8-byte column (or none)
     int part_vtype;
     int part_vtypes[3];  // wide entries: type of each input column
+    int part_wide;       // wide entries (several input columns, NULLs, narrow types, any predicate column)
+    int part_vmask;      // ... with a validity word
     int debug;  // timing experiments (VNM_AGG_DEBUG): 1 = no accumulator ops, 2 = no probes either, 4 = no room check
 };
 
@@ -1029,9 +1031,11 @@ struct PartArgs {
     int64_t spill_cap;
     int debug;
     // wide entries (part_scatter_wide_kernel): key + nval raw values per entry
-    const uint64_t* vcol[3];
+    vnm_dcol vcols[3];   // input columns (any numeric type, NULLs allowed)
     int nval;
-    int pred_col;  // value column that is also the predicate column, or -1 (predicate read from pp)  // timing experiments (VNM_PART_DEBUG): 1 = no copy-out stores, 2 = no staging / copy-out at all
+    int has_vmask;       // last entry word = validity bits of the input columns (some column has a bitmap)
+    Predicate wp;        // generic predicate over wpred (any type)
+    vnm_dcol wpred;  // timing experiments (VNM_PART_DEBUG): 1 = no copy-out stores, 2 = no staging / copy-out at all
 };
 
 template <bool FROM_ROWS>
@@ -1322,25 +1326,21 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_wide_kernel(PartArgs a)
         const int64_t ntiles = (a.nrows + PW_TILE - 1) / PW_TILE;
         for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             uint32_t valid = 0;
-            double pv[PW_ITEMS];
 #pragma unroll
             for (int k = 0; k < PW_ITEMS; k++) {
                 const int64_t row = tile * PW_TILE + (int64_t)k * PT_BLOCK + tid;
                 const int64_t rc = row < a.nrows ? row : a.nrows - 1;
-                if (row < a.nrows) valid |= 1u << k;
+                if (row < a.nrows && (!a.wp.enabled || pred_eval(a.wp, a.wpred, rc))) valid |= 1u << k;
                 ent[k][0] = a.kp[rc];
+                uint64_t vmask = 0;
 #pragma unroll
-                for (int c = 0; c < E - 1; c++) ent[k][1 + c] = a.vcol[c][rc];
-                pv[k] = (a.has_pred && a.pred_col < 0) ? a.pp[rc] : 0.0;
-            }
-            if (a.has_pred) {
-#pragma unroll
-                for (int k = 0; k < PW_ITEMS; k++) {
-                    double p = pv[k];
-#pragma unroll
-                    for (int c = 0; c < E - 1; c++) if (a.pred_col == c) p = __longlong_as_double((long long)ent[k][1 + c]);
-                    if (!cmp_apply<double>(a.op, p, a.thr)) valid &= ~(1u << k);
+                for (int c = 0; c < E - 1; c++) {
+                    if (c < a.nval) {
+                        ent[k][1 + c] = col_raw_bits(a.vcols[c], rc);
+                        if (col_valid(a.vcols[c], rc)) vmask |= 1ULL << c;
+                    }
                 }
+                if (a.has_vmask) ent[k][E - 1] = vmask;
             }
             process_tile(valid);
         }
@@ -1403,7 +1403,8 @@ struct PartAggArgs {
     unsigned long long* dir;  // [2 * nfinal]: (first dense row, row count) of every final partition, or NULL
     // generic accumulator program over the entry's value bits (part_agg_generic_kernel)
     int n_ops, vtype;
-    int ent_words;   // 2 = (key, value); 3 / 4 = key + 2 / 3 values (wide entries)
+    int ent_words;   // 2 = (key, value); 3 / 4 = key + values [+ validity word] (wide entries)
+    int has_vmask;   // wide entries: last word = validity bits of the input columns
     int vtypes[3];
     AccOp ops[AGG_MAX_OPS];
     int merge[AGG_MAX_WORDS];
@@ -1621,13 +1622,17 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_generic_kernel(PartAggArgs 
                         }
                     }
                     if (slot >= 0) {
+                        const uint64_t vmask = (E > 2 && a.has_vmask) ? eb[u][E - 1] : ~0ULL;
                         for (int o = 0; o < a.n_ops; o++) {
                             const int w = a.ops[o].word;
                             const int c = E == 2 ? 0 : (a.ops[o].col < 0 ? 0 : a.ops[o].col);
+                            if (E > 2 && a.ops[o].kind != A_COUNT_ROWS && !((vmask >> c) & 1ULL)) continue;  // NULL input
                             uint64_t vb = eb[u][1];
 #pragma unroll
                             for (int e = 2; e < E; e++) if (c == e - 1) vb = eb[u][e];
-                            l_merge(&lw[w * ST + slot], a.merge[w], op_value_bits(a.ops[o].kind, E == 2 ? a.vtype : a.vtypes[c], vb));
+                            const uint64_t v = E == 2 ? op_value_bits(a.ops[o].kind, a.vtype, vb)
+                                                      : op_value_raw(a.ops[o].kind, a.vtypes[c], vb);  // any numeric type
+                            l_merge(&lw[w * ST + slot], a.merge[w], v);
                         }
                     }
                 }
@@ -2301,7 +2306,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         nfin = l1_max * 512;
     }
     // entry = key + one value (16 bytes, tuned kernels) or key + 2-3 values (wide entries)
-    const int E = (a.part_generic && h->plan.n_cols >= 2) ? 1 + h->plan.n_cols : 2;
+    const int E = a.part_wide ? 1 + h->plan.n_cols + (a.part_vmask ? 1 : 0) : 2;
     const int64_t tile1 = E == 2 ? PT_TILE : PW_TILE;
     const size_t ebytes = (size_t)E * 8;
     if (E > 2) { spill_out = nullptr; n_spill_out = nullptr; }
@@ -2333,13 +2338,12 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     p1.nparts = np1; p1.shift = 32 - lg1; p1.flags = flags;
     p1.debug = (int)env_i64("VNM_PART_DEBUG", 0);
     p1.spill = spill; p1.spill_cap = spill_cap;
-    p1.nval = E - 1;
-    p1.pred_col = -1;
+    p1.nval = h->plan.n_cols;
+    p1.has_vmask = a.part_vmask;
     if (E > 2) {
-        for (int c = 0; c < E - 1; c++) {
-            p1.vcol[c] = (const uint64_t*)a.cols[c].values + a.cols[c].offset;
-            if (h->pred_set && a.pred.values == a.cols[c].values && a.pred.offset == a.cols[c].offset && a.cols[c].type == VNM_F64) p1.pred_col = c;
-        }
+        for (int c = 0; c < h->plan.n_cols; c++) p1.vcols[c] = a.cols[c];
+        p1.wp = a.p;
+        p1.wpred = a.pred;
     }
     {
         KernelTimer timer("agg_part_scatter1", s);
@@ -2391,7 +2395,8 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         p2.nparts = np2; p2.shift = 15; p2.flags = flags;  // hash bits [23:15] (pass 1 used [31:24])
         p2.debug = p1.debug;
         p2.spill = spill; p2.spill_cap = spill_cap;
-        p2.nval = E - 1;
+        p2.nval = h->plan.n_cols;
+        p2.has_vmask = a.part_vmask;
         {
             KernelTimer timer("agg_part_scatter2", s);
             if (E == 2) part_scatter_kernel<false><<<np1 * p2.in_split, PT_BLOCK, 0, s>>>(p2);
@@ -2465,6 +2470,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
             for (int w = 0; w < h->plan.n_words; w++) pa.merge[w] = h->plan.merge[w];
             const size_t lds_bytes = (size_t)(PA_SLOTS + 1) * 8 * (1 + h->plan.n_words);
             pa.ent_words = E;
+            pa.has_vmask = a.part_vmask;
             for (int c = 0; c < 3; c++) pa.vtypes[c] = a.part_vtypes[c];
 #define VNM_PAG(E_)                                                                                                  \
     do {                                                                                                             \
@@ -2794,18 +2800,28 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     if (!hot && h->single && h->plan.n_cols <= 3 && type_width(keys[0].type) == 8 && !keys[0].validity &&
         (keys[0].offset & 1) == 0 && getenv("VNM_AGG_NO_PART_GENERIC") == nullptr &&
         (size_t)(PA_SLOTS + 1) * 8 * (1 + h->plan.n_words) <= 150 * 1024) {
-        part_ok = true;
-        for (int c = 0; c < h->plan.n_cols && part_ok; c++) {
+        // narrow entries (key, value): at most one 8-byte input column without NULLs, float64 predicate column
+        bool narrow = h->plan.n_cols <= 1;
+        bool any_null = false;
+        for (int c = 0; c < h->plan.n_cols; c++) {
             const vnm_dcol& col = a.cols[c];
-            part_ok = (col.type == VNM_I64 || col.type == VNM_U64 || col.type == VNM_F64) && !col.validity && (col.offset & 1) == 0;
             a.part_vtypes[c] = col.type;
+            if (col.validity) any_null = true;
+            if (!((col.type == VNM_I64 || col.type == VNM_U64 || col.type == VNM_F64) && !col.validity && (col.offset & 1) == 0)) narrow = false;
         }
         if (h->plan.n_cols >= 1) a.part_vtype = a.cols[0].type;
-        if (part_ok && h->pred_set) {
-            part_ok = a.pred.type == VNM_F64 && !a.pred.validity && (a.pred.offset & 1) == 0 && a.p.mode == CMP_F64;
+        if (narrow && h->pred_set) {
+            narrow = a.pred.type == VNM_F64 && !a.pred.validity && (a.pred.offset & 1) == 0 && a.p.mode == CMP_F64;
             a.hot_pred_is_v = h->plan.n_cols == 1 && a.pred.values == a.cols[0].values && a.pred.offset == a.cols[0].offset;
         }
+        // wide entries take the rest: several columns, NULLs, narrow types, any predicate -- while key + values
+        // (+ validity word) fit four words
+        const bool wide = !narrow && h->plan.n_cols >= 1 && h->plan.n_cols + (any_null ? 1 : 0) <= 3 &&
+                          getenv("VNM_AGG_NO_PART_WIDE") == nullptr;
+        part_ok = narrow || wide;
         a.part_generic = part_ok;
+        a.part_wide = wide;
+        a.part_vmask = wide && any_null;
     }
     // no hint from the caller: estimate the group count once from a sample of the first large batch
     if (part_ok && h->hint == 0 && !h->estimated && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
