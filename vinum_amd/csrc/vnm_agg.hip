@@ -343,9 +343,8 @@ __device__ __forceinline__ bool pred_eval_raw(const Predicate& p, int type, uint
 // kind are in flight together: (A0) predicate + key loads, (A1) LDS probes -> one slot per row, (B) for each
 // accumulator op: load its column for all rows, then merge.  (Row-major interpretation -- one op decode, one
 // dependent load and one type switch per row and op -- ran at 12.7 ms per 1e9 rows for MIN+MAX.)
-// BLK = 1024: one workgroup per CU with the largest LDS table (unknown or larger group counts);
-// BLK = 512: two workgroups per CU with half-size tables, for small known group counts -- the phases of one
-// workgroup (loads / probes / merges, each latency bound on its own) then overlap with the other's.
+// BLK = 1024: one workgroup per CU with the largest LDS table (two 512-thread workgroups per CU with half-size
+// tables were measured slower: 9.9-13.8 vs 9.9 ms).
 template <int BLK>
 __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
     constexpr int R = AGG_ROWS_PER_THREAD;
@@ -2855,12 +2854,8 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     const int64_t scan_n = a.nrows;
     VNM_TRY(ensure_table(h, scan_n, s));
     if (hot_scan) a.ntiles = (scan_n + HOT_TILE - 1) / HOT_TILE;
-    // generic single-key kernel, small known group count: two 512-thread workgroups per CU with 64 KB tables
-    const int S2 = lds_slots_for(h->plan, 64 * 1024);
-    const bool twin = !hot_scan && h->single && h->hint > 0 && h->hint <= (int64_t)S2 * 6 / 10 && getenv("VNM_AGG_TWIN") != nullptr;  // measured slower (9.9-13.8 vs 9.9 ms): off
-    const int lds_tile = twin ? 512 * AGG_ROWS_PER_THREAD : AGG_TILE;
-    if (twin) { a.lds_slots = S2; a.ntiles = (nrows + lds_tile - 1) / lds_tile; }
-    int grid = h->single ? (twin ? cus * 2 : cus) : cus * 4;
+    const int lds_tile = AGG_TILE;
+    int grid = h->single ? cus : cus * 4;
     if (grid > a.ntiles) grid = (int)a.ntiles;
     a.margin = (int64_t)grid * (h->single ? (a.lds_slots + 2 + (hot_scan ? HOT_TILE : lds_tile)) : AGG_TILE);
     unsigned int* progress = (unsigned int*)pool_alloc((size_t)grid * 4);
@@ -2901,13 +2896,8 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
 #undef VNM_HOT
         } else if (h->single) {
             size_t lds_bytes = (size_t)(a.lds_slots + 2) * 8 * (1 + h->plan.n_words);
-            if (twin) {
-                VNM_HIP(hipFuncSetAttribute((const void*)agg_lds_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-                agg_lds_kernel<512><<<grid, 512, lds_bytes, s>>>(a);
-            } else {
-                VNM_HIP(hipFuncSetAttribute((const void*)agg_lds_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-                agg_lds_kernel<1024><<<grid, 1024, lds_bytes, s>>>(a);
-            }
+            VNM_HIP(hipFuncSetAttribute((const void*)agg_lds_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            agg_lds_kernel<1024><<<grid, 1024, lds_bytes, s>>>(a);
         } else {
             agg_wide_kernel<<<grid, 256, 0, s>>>(a);
         }
