@@ -1119,34 +1119,37 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
         __syncthreads();
         // D: copy out: consecutive lanes write consecutive 16-byte entries of one partition's run
         const uint32_t total = (a.debug & 1) ? 0 : s_total;
-        uint32_t spilled = 0;  // bit q: this lane's q-th entry of the tile did not fit its region
-        uint32_t srank[PT_ITEMS];
 #pragma unroll
         for (int q = 0; q < PT_ITEMS; q++) {
             const uint32_t i = (uint32_t)q * PT_BLOCK + tid;
-            srank[q] = 0;
             if (i < total) {
                 uint32_t p = part_of[i];
                 uint32_t j = cursor[p] + (i - off[p]);
                 if (j < (uint32_t)a.out_cap) a.out_entries[(out_base + (int64_t)p * out_stride) * a.out_cap + j] = stage[i];
-                else { spilled |= 1u << q; srank[q] = atomicAdd(&s_spill, 1u); }
+                else atomicAdd(&s_spill, 1u);
             }
         }
         __syncthreads();
-        // D2: regions that are full (a heavy key, an uneven split) spill into one global buffer: one atomic per tile
-        if (s_spill) {
-            if (tid == 0) s_spill_base = atomicAdd(&a.flags[2], (unsigned long long)s_spill);
+        // D2: regions that are full (a heavy key, an uneven split) spill into one global buffer: one global atomic per
+        // tile.  The entries are found again here instead of being remembered above (that cost the common path 24
+        // bytes of scratch per lane and 0.5 ms).
+        const uint32_t nspill = s_spill;  // uniform: read by everyone before thread 0 resets it
+        if (nspill) {
+            __syncthreads();
+            if (tid == 0) { s_spill_base = atomicAdd(&a.flags[2], (unsigned long long)nspill); s_spill = 0; }
             __syncthreads();
             const unsigned long long sb = s_spill_base;
-#pragma unroll
-            for (int q = 0; q < PT_ITEMS; q++) {
-                if (!((spilled >> q) & 1u)) continue;
-                const unsigned long long pos = sb + srank[q];
-                if ((int64_t)pos < a.spill_cap) a.spill[pos] = stage[(uint32_t)q * PT_BLOCK + tid];
+            for (uint32_t i = tid; i < total; i += PT_BLOCK) {
+                uint32_t p = part_of[i];
+                uint32_t j = cursor[p] + (i - off[p]);
+                if (j < (uint32_t)a.out_cap) continue;
+                const unsigned long long pos = sb + atomicAdd(&s_spill, 1u);
+                if ((int64_t)pos < a.spill_cap) a.spill[pos] = stage[i];
                 else __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
             if (tid == 0) s_spill = 0;
+            __syncthreads();
         }
         // E: advance cursors
         if (tid < np) { cursor[tid] += cnt[tid]; cnt[tid] = 0; }
