@@ -322,17 +322,43 @@ __global__ __launch_bounds__(256) void topk_select_kernel(vnm_dcol c, int desc, 
     };
     const int64_t tile_rows = 256 * TK_U;
     const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
+    const bool fast = c.type == VNM_F64 && !c.validity && (c.offset & 1) == 0;
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         uint64_t e[TK_U];
         uint32_t k[TK_U];
         bool keep[TK_U];
+        int64_t rowi[TK_U];
+        if (fast && (t + 1) * tile_rows <= n) {
+            // float64 without NULLs: a lane owns pairs of adjacent rows, 16 bytes per request
+            const double* p = (const double*)c.values + c.offset + t * tile_rows + 2 * threadIdx.x;
 #pragma unroll
-        for (int u = 0; u < TK_U; u++) {
-            int64_t i = t * tile_rows + u * 256 + threadIdx.x;
-            e[u] = 0; k[u] = 0; keep[u] = false;
-            if (i < n) {
-                encode_key(c, i, desc, &e[u], &k[u]);
-                keep[u] = k[u] < t_cls || (k[u] == t_cls && e[u] <= t_code);
+            for (int u = 0; u < TK_U / 2; u++) {
+                const double2 d = *(const double2*)(p + u * 512);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    double x = h ? d.y : d.x;
+                    const int q = 2 * u + h;
+                    rowi[q] = t * tile_rows + u * 512 + 2 * threadIdx.x + h;
+                    if (x != x) { e[q] = 0; k[q] = 1; }
+                    else {
+                        if (x == 0.0) x = 0.0;  // -0.0 and +0.0 tie (see encode_key)
+                        const uint64_t enc = enc_f64(x);
+                        e[q] = desc ? ~enc : enc;
+                        k[q] = 0;
+                    }
+                    keep[q] = k[q] < t_cls || (k[q] == t_cls && e[q] <= t_code);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < TK_U; u++) {
+                int64_t i = t * tile_rows + u * 256 + threadIdx.x;
+                rowi[u] = i;
+                e[u] = 0; k[u] = 0; keep[u] = false;
+                if (i < n) {
+                    encode_key(c, i, desc, &e[u], &k[u]);
+                    keep[u] = k[u] < t_cls || (k[u] == t_cls && e[u] <= t_code);
+                }
             }
         }
 #pragma unroll
@@ -345,7 +371,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(vnm_dcol c, int desc, 
                 uint32_t slot = fill + (uint32_t)__popcll(b & lt);
                 b_code[wave][slot] = e[u];
                 b_cls[wave][slot] = (uint8_t)k[u];
-                b_row[wave][slot] = (uint32_t)(t * tile_rows + u * 256 + threadIdx.x);
+                b_row[wave][slot] = (uint32_t)rowi[u];
             }
             fill += cnt;
         }
