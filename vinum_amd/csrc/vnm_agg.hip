@@ -445,7 +445,9 @@ __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
             else if (st[r] == 2) { slot[r] = S; lkey[S] = 0; }
             else if (st[r] == 1 && !(a.debug & 2)) {
                 slot[r] = -2;
-                uint32_t h = hash_u64(key[r]) & smask;
+                const uint32_t hv = hash_u64(key[r]);
+                uint32_t h = hv & smask;
+                const uint32_t step = ((hv >> 20) & 31u) * 2u + 1u;  // double hashing
                 for (int probe = 0; probe < AGG_MAX_PROBES; probe++) {
                     uint64_t k = *(volatile uint64_t*)&lkey[h];
                     if (k == key[r]) { slot[r] = (int)h; break; }
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
                         }
                         if (expected == key[r]) { slot[r] = (int)h; break; }
                     }
-                    h = (h + 1) & smask;
+                    h = (h + step) & smask;
                 }
             }
         }
@@ -560,7 +562,9 @@ constexpr int HOT_TILE = AGG_BLOCK * 2 * HOT_UNROLL;  // 8192 rows per block ite
 // probe / claim the LDS slot of `key`; -1 = the table is saturated for this key
 __device__ __forceinline__ int hot_slot(uint64_t* lkey, int S, uint32_t smask, unsigned* s_fill, uint64_t key) {
     if (key == EMPTY) { lkey[S] = 0; return S; }
-    uint32_t h = hash_u64(key) & smask;
+    const uint32_t hv = hash_u64(key);
+    uint32_t h = hv & smask;
+    const uint32_t step = ((hv >> 20) & 31u) * 2u + 1u;  // double hashing: shorter worst chains than linear probing
     for (int probe = 0; probe < AGG_MAX_PROBES; probe++) {
         uint64_t k = *(volatile uint64_t*)&lkey[h];
         if (k == key) return (int)h;
@@ -573,7 +577,7 @@ __device__ __forceinline__ int hot_slot(uint64_t* lkey, int S, uint32_t smask, u
             }
             if (expected == key) return (int)h;
         }
-        h = (h + 1) & smask;
+        h = (h + step) & smask;
     }
     return -1;
 }
@@ -1449,7 +1453,11 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
                 int slot = -1;
                 if (key == EMPTY) { slot = PA_SLOTS; lkey[slot] = 0; }
                 else {
-                    uint32_t h = hash_u64(key) & smask;
+                    const uint32_t hv = hash_u64(key);
+                    uint32_t h = hv & smask;
+                    // double hashing: an odd step from hash bits the partitioning did not use ([14:11]).  A wave runs as
+                    // long as its unluckiest lane, and linear probing's clusters make that lane's chain long.
+                    const uint32_t step = ((hv >> 11) & 15u) * 2u + 1u;
                     for (int probe = 0; probe < PA_SLOTS; probe++) {
                         uint64_t k = *(volatile uint64_t*)&lkey[h];
                         if (k == key) { slot = (int)h; break; }
@@ -1463,7 +1471,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
                             }
                             if (expected == key) { slot = (int)h; break; }
                         }
-                        h = (h + 1) & smask;
+                        h = (h + step) & smask;
                         if ((probe & 15) == 15 && s_fail) break;
                     }
                 }
@@ -1605,7 +1613,9 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_generic_kernel(PartAggArgs 
                     int slot = -1;
                     if (key == EMPTY) { slot = PA_SLOTS; lkey[slot] = 0; }
                     else {
-                        uint32_t h = hash_u64(key) & smask;
+                        const uint32_t hv = hash_u64(key);
+                        uint32_t h = hv & smask;
+                        const uint32_t step = ((hv >> 11) & 15u) * 2u + 1u;  // double hashing, see part_agg_kernel
                         for (int probe = 0; probe < PA_SLOTS; probe++) {
                             uint64_t k = *(volatile uint64_t*)&lkey[h];
                             if (k == key) { slot = (int)h; break; }
@@ -1619,7 +1629,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_generic_kernel(PartAggArgs 
                                 }
                                 if (expected == key) { slot = (int)h; break; }
                             }
-                            h = (h + 1) & smask;
+                            h = (h + step) & smask;
                             if ((probe & 15) == 15 && s_fail) break;
                         }
                     }
