@@ -264,6 +264,7 @@ __device__ __forceinline__ int64_t raw_to_i64(int type, uint64_t raw) {
 __device__ __forceinline__ double raw_to_f64(int type, uint64_t raw) {
     if (type == VNM_F64) return __longlong_as_double((long long)raw);
     if (type == VNM_F32) return (double)__uint_as_float((uint32_t)raw);
+    if (type == VNM_U64) return (double)raw;  // not through int64: values >= 2^63 would turn negative
     return (double)raw_to_i64(type, raw);
 }
 // what op `kind` contributes for a non-NULL input value (same table as op_value)
@@ -1411,6 +1412,7 @@ struct PartAggArgs {
     int n_ops, vtype;
     int ent_words;   // 2 = (key, value); 3 / 4 = key + values [+ validity word] (wide entries)
     int has_vmask;   // wide entries: last word = validity bits of the input columns
+    int wide;        // values are raw bits of any numeric width (vtypes[]), not 8-byte values of type vtype
     int vtypes[3];
     AccOp ops[AGG_MAX_OPS];
     int merge[AGG_MAX_WORDS];
@@ -1642,8 +1644,8 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_generic_kernel(PartAggArgs 
                             uint64_t vb = eb[u][1];
 #pragma unroll
                             for (int e = 2; e < E; e++) if (c == e - 1) vb = eb[u][e];
-                            const uint64_t v = E == 2 ? op_value_bits(a.ops[o].kind, a.vtype, vb)
-                                                      : op_value_raw(a.ops[o].kind, a.vtypes[c], vb);  // any numeric type
+                            const uint64_t v = a.wide ? op_value_raw(a.ops[o].kind, a.vtypes[c], vb)  // any numeric type
+                                                      : op_value_bits(a.ops[o].kind, a.vtype, vb);
                             l_merge(&lw[w * ST + slot], a.merge[w], v);
                         }
                     }
@@ -2319,9 +2321,10 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     }
     // entry = key + one value (16 bytes, tuned kernels) or key + 2-3 values (wide entries)
     const int E = a.part_wide ? 1 + h->plan.n_cols + (a.part_vmask ? 1 : 0) : 2;
-    const int64_t tile1 = E == 2 ? PT_TILE : PW_TILE;
+    const bool wide = a.part_wide != 0;  // generic column accessors (any width, NULLs, any predicate column)
+    const int64_t tile1 = wide ? PW_TILE : PT_TILE;
     const size_t ebytes = (size_t)E * 8;
-    if (E > 2) { spill_out = nullptr; n_spill_out = nullptr; }
+    if (wide) { spill_out = nullptr; n_spill_out = nullptr; }
     const int levels = nfin > l1_max ? 2 : 1;
     const int np1 = levels == 2 ? (int)l1_max : (int)nfin;
     const int np2 = levels == 2 ? (int)(nfin / l1_max) : 0;
@@ -2352,23 +2355,22 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     p1.spill = spill; p1.spill_cap = spill_cap;
     p1.nval = h->plan.n_cols;
     p1.has_vmask = a.part_vmask;
-    if (E > 2) {
+    if (wide) {
         for (int c = 0; c < h->plan.n_cols; c++) p1.vcols[c] = a.cols[c];
         p1.wp = a.p;
         p1.wpred = a.pred;
     }
     {
         KernelTimer timer("agg_part_scatter1", s);
-        if (E == 2) part_scatter_kernel<true><<<grid1, PT_BLOCK, 0, s>>>(p1);
+        if (!wide) part_scatter_kernel<true><<<grid1, PT_BLOCK, 0, s>>>(p1);
         else {
             const size_t lds = (size_t)PW_TILE * ebytes;
-            if (E == 3) {
-                VNM_HIP(hipFuncSetAttribute((const void*)part_scatter_wide_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                part_scatter_wide_kernel<true, 3><<<grid1, PT_BLOCK, lds, s>>>(p1);
-            } else {
-                VNM_HIP(hipFuncSetAttribute((const void*)part_scatter_wide_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                part_scatter_wide_kernel<true, 4><<<grid1, PT_BLOCK, lds, s>>>(p1);
-            }
+#define VNM_PSW(FR, E_, GRID, ARGS)                                                                                  \
+    do {                                                                                                             \
+        VNM_HIP(hipFuncSetAttribute((const void*)part_scatter_wide_kernel<FR, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        part_scatter_wide_kernel<FR, E_><<<GRID, PT_BLOCK, lds, s>>>(ARGS);                                          \
+    } while (0)
+            if (E == 2) VNM_PSW(true, 2, grid1, p1); else if (E == 3) VNM_PSW(true, 3, grid1, p1); else VNM_PSW(true, 4, grid1, p1);
         }
     }
     VNM_HIP(hipGetLastError());
@@ -2411,18 +2413,14 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         p2.has_vmask = a.part_vmask;
         {
             KernelTimer timer("agg_part_scatter2", s);
-            if (E == 2) part_scatter_kernel<false><<<np1 * p2.in_split, PT_BLOCK, 0, s>>>(p2);
+            if (!wide) part_scatter_kernel<false><<<np1 * p2.in_split, PT_BLOCK, 0, s>>>(p2);
             else {
                 const size_t lds = (size_t)PW_TILE * ebytes;
-                if (E == 3) {
-                    VNM_HIP(hipFuncSetAttribute((const void*)part_scatter_wide_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    part_scatter_wide_kernel<false, 3><<<np1 * p2.in_split, PT_BLOCK, lds, s>>>(p2);
-                } else {
-                    VNM_HIP(hipFuncSetAttribute((const void*)part_scatter_wide_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    part_scatter_wide_kernel<false, 4><<<np1 * p2.in_split, PT_BLOCK, lds, s>>>(p2);
-                }
+                const int g2 = np1 * p2.in_split;
+                if (E == 2) VNM_PSW(false, 2, g2, p2); else if (E == 3) VNM_PSW(false, 3, g2, p2); else VNM_PSW(false, 4, g2, p2);
             }
         }
+#undef VNM_PSW
         VNM_HIP(hipGetLastError());
         {
             int ov = overflowed();
@@ -2482,6 +2480,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
             for (int w = 0; w < h->plan.n_words; w++) pa.merge[w] = h->plan.merge[w];
             const size_t lds_bytes = (size_t)(PA_SLOTS + 1) * 8 * (1 + h->plan.n_words);
             pa.ent_words = E;
+            pa.wide = wide;
             pa.has_vmask = a.part_vmask;
             for (int c = 0; c < 3; c++) pa.vtypes[c] = a.part_vtypes[c];
 #define VNM_PAG(E_)                                                                                                  \

@@ -128,6 +128,8 @@ std::vector<TimedSpan> g_spans;
 }  // namespace
 
 KernelTimer::KernelTimer(const char* name, hipStream_t s) : on(g_profiling), slot(-1), stream(s) {
+    static const bool trace = getenv("VNM_TRACE") != nullptr;  // debugging aid: name every timed launch on stderr
+    if (trace) { fprintf(stderr, "[vnm] launch %s\n", name); fflush(stderr); (void)hipStreamSynchronize(s); }
     if (!on) return;
     TimedSpan sp;
     sp.name = name;
