@@ -137,3 +137,58 @@ def test_project_many_equals_single_expression_kernels():
         assert np.array_equal(outs[k].to_numpy(), a + k)
     assert np.array_equal(outs[20].to_numpy().astype(bool), v > 0.0)
     assert np.array_equal(outs[21].to_numpy().view(np.uint64), (v * a).view(np.uint64))
+
+
+def _rand_col(rng, n, kind, null_p, card):
+    """A column of `kind` with about `card` distinct values (ties matter for stability) and NULLs / NaNs."""
+    base = rng.integers(0, max(card, 1), n)
+    mask = (rng.random(n) < null_p) if null_p else None
+    if kind == "f64":
+        a = base.astype(np.float64) * 0.37 - card * 0.1
+        a[rng.random(n) < 0.01] = np.nan
+        a[rng.random(n) < 0.01] = -0.0
+        a[rng.random(n) < 0.005] = np.inf
+    elif kind == "f32":
+        a = (base.astype(np.float32) * np.float32(0.5)) - np.float32(3)
+    elif kind == "i64":
+        a = (base.astype(np.int64) - card // 2) * 1_000_003
+    elif kind == "i32":
+        a = (base - card // 2).astype(np.int32)
+    elif kind == "u16":
+        a = (base % 65536).astype(np.uint16)
+    else:
+        a = (base.astype(np.uint64) * np.uint64(9_007_199_254_740_993)) % np.uint64(2**64 - 1)
+    return pa.array(a, mask=mask)
+
+
+import os
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS", "40")))))
+def test_random_sorts_vs_oracle(seed):
+    """Seeded differential test: 1-3 sort keys of random types (floats with NaN / -0.0 / inf, NULLs, narrow ints,
+    uint64 beyond 2^63), random directions, many ties (stability), optional LIMIT, a payload column taken along."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([1, 2, 63, 1000, 70_000, 150_000, 260_000]))
+    nk = int(rng.choice([1, 1, 2, 3]))
+    cols, names, orders = {}, [], []
+    for j in range(nk):
+        kind = str(rng.choice(["f64", "f32", "i64", "i32", "u16", "u64"]))
+        card = int(rng.choice([1, 3, 50, 5000, 10**6]))
+        cols[f"s{j}"] = _rand_col(rng, n, kind, 0.03 if rng.random() < 0.4 else 0.0, card)
+        names.append(f"s{j}")
+        orders.append(int(rng.integers(0, 2)))
+    cols["rowid"] = pa.array(np.arange(n, dtype=np.int64))
+    t = pa.table(cols)
+    limit = int(rng.choice([0, 0, 1, 10, 5000])) if n > 100 else 0
+    limit = min(limit, n)
+    got = gpu_sort(t, names, orders, limit=limit)
+    s = O.OracleSort(names, orders)
+    for b in t.to_batches():
+        s.next(b)
+    exp = s.sorted()
+    if limit:
+        exp = exp.slice(0, limit)
+    util.assert_batches_equal(got, exp, what=f"seed {seed}: n={n} keys {[str(t.schema.field(c).type) for c in names]} "
+                                             f"orders {orders} limit {limit}")
