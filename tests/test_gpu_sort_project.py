@@ -192,3 +192,64 @@ def test_random_sorts_vs_oracle(seed):
         exp = exp.slice(0, limit)
     util.assert_batches_equal(got, exp, what=f"seed {seed}: n={n} keys {[str(t.schema.field(c).type) for c in names]} "
                                              f"orders {orders} limit {limit}")
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS", "40")))))
+def test_random_expressions_vs_numpy(seed):
+    """Seeded differential test of the fused projection: random arithmetic trees over int64 / float64 columns (one
+    of them with NULLs, which reach NumPy as float64 NaN, record_batch.py:112-118) and int / float literals,
+    evaluated the way the reference does it -- one NumPy ufunc per node (expressions.py:13-24)."""
+    from vinum_amd.device import DeviceColumn
+    from vinum_amd import ops
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([1, 255, 1024, 1025, 5000, 70_001]))
+    a = rng.integers(-1000, 1000, n).astype(np.int64)
+    b = rng.integers(0, 2**12, n).astype(np.float64) / 16.0 - 50.0
+    cvals = rng.integers(-50, 50, n).astype(np.int64)
+    cmask = rng.random(n) < 0.1
+    arrow = {"a": pa.array(a), "b": pa.array(b), "c": pa.array(cvals, mask=cmask)}
+    dev = {k: DeviceColumn.from_arrow(v) for k, v in arrow.items()}
+    # only a column that really has NULLs is converted (null_count > 0, record_batch.py:112-118)
+    npv = {"a": a, "b": b, "c": np.where(cmask, np.nan, cvals.astype(np.float64)) if cmask.any() else cvals}
+    ufunc = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "mod": np.mod}
+
+    def gen(depth):
+        r = rng.random()
+        if depth == 0 or r < 0.25:
+            return str(rng.choice(["a", "b", "c"])) if rng.random() < 0.75 else (
+                int(rng.integers(-5, 6)) if rng.random() < 0.5 else float(rng.choice([0.5, -2.25, 3.0])))
+        if r < 0.35:
+            return ("neg", gen(depth - 1))
+        return (str(rng.choice(list(ufunc))), gen(depth - 1), gen(depth - 1))
+
+    def has_col(e):
+        return isinstance(e, str) or (isinstance(e, tuple) and any(has_col(x) for x in e[1:]))
+
+    def ev(e):
+        if isinstance(e, str):
+            return npv[e]
+        if isinstance(e, (int, float)):
+            return e
+        if e[0] == "neg":
+            return np.negative(ev(e[1]))
+        return ufunc[e[0]](ev(e[1]), ev(e[2]))
+
+    exprs = []
+    while len(exprs) < 4:
+        e = gen(3)
+        if isinstance(e, tuple) and has_col(e):
+            exprs.append(e)
+    with np.errstate(all="ignore"):
+        refs = [np.asarray(ev(e)) for e in exprs]
+    used = {k: dev[k] for k in ("a", "b", "c")}
+    outs = ops.project_many(exprs, used, length=n)
+    for e, ref, out in zip(exprs, refs, outs):
+        got = out.to_numpy()
+        ref = np.broadcast_to(ref, (n,))
+        assert got.dtype == ref.dtype, (seed, e, got.dtype, ref.dtype)
+        if ref.dtype.kind == "f":
+            both_nan = np.isnan(got) & np.isnan(ref)
+            same = (got.view(np.uint64) == np.ascontiguousarray(ref).view(np.uint64)) | both_nan
+        else:
+            same = got == ref
+        assert same.all(), f"seed {seed}: {e}: row {int(np.argmin(same))}: {got[np.argmin(same)]!r} vs {ref[np.argmin(same)]!r}"
