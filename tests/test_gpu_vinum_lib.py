@@ -115,3 +115,30 @@ def test_large_batches_through_pinned_staging():
     for b in t.to_batches():
         o.next(b)
     util.assert_agg_equal(agg.result(), o.result(), funcs2, ["k"], what="large batches generic")
+
+
+import os
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS", "30")))))
+def test_random_aggregates_through_vinum_lib(seed):
+    """Seeded differential test at the Arrow boundary: random aggregates (see util.random_agg_case) fed through the
+    vinum_lib classes as record batches cut at random places, with non-zero Arrow offsets, vs the oracle."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(3000 + seed)
+    cols, key_names, in_names, funcs, n, groups, skew = util.random_agg_case(rng)
+    t = pa.table(cols)
+    off = int(rng.choice([0, 1, 7, 64, 1001]))
+    t = t.slice(off)                                    # every column now carries an Arrow offset
+    cuts = sorted(set(int(x) for x in rng.integers(1, max(t.num_rows - 1, 2), int(rng.integers(0, 4)))))
+    bounds = [0] + cuts + [t.num_rows]
+    batches = [t.slice(a, b - a).combine_chunks().to_batches()[0] for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+    kind = O.SINGLE if len(key_names) == 1 else O.MULTI
+    agg = _agg(kind, key_names, key_names, funcs)
+    o = O.OracleAggregate(kind, key_names, key_names, funcs)
+    for b in batches:
+        agg.next(b)
+        o.next(b)
+    util.assert_agg_equal(agg.result(), o.result(), funcs, key_names,
+                          what=f"seed {seed}: keys {[str(cols[k].type) for k in key_names]} inputs "
+                               f"{[str(cols[v].type) for v in in_names]} G~{groups} off={off} cuts={cuts}")
