@@ -529,3 +529,53 @@ def test_random_plans_vs_oracle(seed, monkeypatch):
     util.assert_agg_equal(got, o.result(), funcs, key_names,
                           what=f"seed {seed}: keys {[str(cols[k].type) for k in key_names]} inputs "
                                f"{[str(cols[v].type) for v in in_names]} G~{groups} skew={skew} hint={hint} pred={pred}")
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS", "24")))))
+def test_random_plans_sharded_exchange_simulated(seed):
+    """The N-GPU path with random queries, on one GPU: the rows are dealt to `world` operators (the ranks), every rank
+    buckets its partial groups by owner (vnm_agg_bucket_by_owner), owner o merges bucket o of every rank
+    (vnm_agg_merge_rows) -- what exchange_bucketed does over RCCL -- and the union of the owners' results must be
+    the oracle's answer over all rows.  Any key layout (packed composite keys included), any accumulator program."""
+    import torch
+    from oracle import oracle as O
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    rng = np.random.default_rng(11000 + seed)
+    cols, key_names, in_names, funcs, n, groups, skew = util.random_agg_case(rng)
+    world = int(rng.choice([2, 3, 8]))
+    t = pa.table(cols)
+    names = t.schema.names
+    kind = O.SINGLE if len(key_names) == 1 else O.MULTI
+    key_types = [t.schema.field(c).type for c in key_names]
+    fspec = [(f, names.index(col) if col else None, t.schema.field(col).type if col else None) for f, col, _ in funcs]
+    bounds = np.linspace(0, n, world + 1).astype(int)
+    ranks = []
+    for r in range(world):
+        b = t.slice(int(bounds[r]), int(bounds[r + 1] - bounds[r])).combine_chunks().to_batches()
+        agg = ops.DeviceAggregate(kind, key_types, fspec, expected_groups=groups if rng.random() < 0.5 else 0)
+        for bb in b:
+            dev = {c: DeviceColumn.from_arrow(bb.column(names.index(c))) for c in set(key_names) | set(in_names)}
+            agg.next([dev[c] for c in key_names], [dev[col] if col else None for _, col, _ in funcs], nrows=bb.num_rows)
+        ng = agg.finish()
+        kw, aw = agg.layout()
+        rows = torch.empty((max(ng, 1), kw + aw), dtype=torch.int64, device="cuda")
+        counts = agg.bucket_by_owner(world, rows.data_ptr())
+        assert sum(counts) == ng
+        ranks.append((rows, counts))
+    parts = []
+    for o in range(world):
+        m = ops.DeviceAggregate(kind, key_types, fspec)
+        for rows, counts in ranks:
+            start = sum(counts[:o])
+            part = rows[start:start + counts[o]].contiguous()
+            if part.shape[0]:
+                m.merge_rows(part.shape[0], part.data_ptr())
+        parts.append(m.result_arrays(list(range(len(key_names))), key_names, [f[2] for f in funcs]))
+    got = pa.Table.from_batches([p for p in parts if p.num_rows] or parts[:1]).combine_chunks()
+    got = got.to_batches()[0] if got.num_rows else parts[0]
+    o = O.OracleAggregate(kind, key_names, key_names, funcs)
+    for b in t.to_batches():
+        o.next(b)
+    util.assert_agg_equal(got, o.result(), funcs, key_names,
+                          what=f"seed {seed}: world {world} keys {[str(c) for c in key_types]} G~{groups}")
