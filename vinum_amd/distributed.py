@@ -115,7 +115,8 @@ def exchange_partition_aligned(agg, make_merged, device, group=None):
     the owner-bucketed exchange)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    nfin = agg.run_partitions()
+    kw0, aw0 = agg.layout()
+    nfin = agg.run_partitions() if aw0 <= 3 else 0   # the LDS merge kernel holds at most 3 accumulator words per group
     t = torch.tensor([nfin, -nfin], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     if int(t[0]) <= 0 or int(t[0]) != -int(t[1]) or nfin < world:
