@@ -63,6 +63,8 @@ struct AggArgs {
     int hot_pred_is_v;
     // extended hot shape: every accumulator kind over ONE 8-byte input column without NULLs (or no input at all)
     int hot_w[9];      // word of each AccKind, -1 = absent
+    int hot_w2[9];     // ... for a second input column (agg_hot_kernel<TWO>)
+    int hot_vtype2;
     int hot_vtype;     // VNM_F64 / VNM_I64 / VNM_U64
     int hot_has_val;
     const ulonglong2* ent;  // agg_hot_kernel<FROM_ENT>: (key, value bits) entries spilled by the partitioned path
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
                 uint32_t h = hv & smask;
                 const uint32_t step = ((hv >> 20) & 31u) * 2u + 1u;  // double hashing
                 for (int probe = 0; probe < AGG_MAX_PROBES; probe++) {
-                    uint64_t k = *(volatile uint64_t*)&lkey[h];
+                    uint64_t k = __hip_atomic_load(&lkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (k == key[r]) { slot[r] = (int)h; break; }
                     if (k == EMPTY) {
                         uint64_t expected = EMPTY;
@@ -567,7 +569,7 @@ __device__ __forceinline__ int hot_slot(uint64_t* lkey, int S, uint32_t smask, u
     uint32_t h = hv & smask;
     const uint32_t step = ((hv >> 20) & 31u) * 2u + 1u;  // double hashing: shorter worst chains than linear probing
     for (int probe = 0; probe < AGG_MAX_PROBES; probe++) {
-        uint64_t k = *(volatile uint64_t*)&lkey[h];
+        uint64_t k = __hip_atomic_load(&lkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (k == key) return (int)h;
         if (k == EMPTY) {
             uint64_t expected = EMPTY;
@@ -583,6 +585,27 @@ __device__ __forceinline__ int hot_slot(uint64_t* lkey, int S, uint32_t smask, u
     return -1;
 }
 
+// the accumulator words of ONE input column (word table hw[kind], -1 = absent), for a value with raw bits vb
+__device__ __forceinline__ void hot_accumulate_col(const int* hw, int vtype, uint64_t* lacc, int stride, int slot, uint64_t vb) {
+#define VNM_W(K) (lacc + hw[K] * stride + slot)
+#define VNM_ADD(K, V) if (hw[K] >= 0) __hip_atomic_fetch_add(VNM_W(K), (uint64_t)(V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+    VNM_ADD(A_COUNT_ROWS, 1ULL);
+    VNM_ADD(A_COUNT_VALID, 1ULL);
+    if (hw[A_SUM_F64] >= 0)
+        __hip_atomic_fetch_add((double*)VNM_W(A_SUM_F64), __longlong_as_double((long long)vb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    VNM_ADD(A_SUM_I64, vb);
+    VNM_ADD(A_SUM_LO32, vb & 0xFFFFFFFFULL);
+    VNM_ADD(A_SUM_HI32S, (int64_t)vb >> 32);
+    VNM_ADD(A_SUM_HI32U, vb >> 32);
+    if (hw[A_MIN] >= 0 || hw[A_MAX] >= 0) {
+        const uint64_t e = vtype == VNM_F64 ? enc_f64(__longlong_as_double((long long)vb)) : (vtype == VNM_U64 ? vb : enc_i64((int64_t)vb));
+        if (hw[A_MIN] >= 0) __hip_atomic_fetch_min(VNM_W(A_MIN), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (hw[A_MAX] >= 0) __hip_atomic_fetch_max(VNM_W(A_MAX), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#undef VNM_ADD
+#undef VNM_W
+}
+
 // every accumulator word this query has, updated for a row whose input value has the raw bits vb
 // (SIMPLE: only COUNT(*), COUNT and the float64 sum can be present -- the north-star shape keeps its short path)
 template <bool SIMPLE>
@@ -593,24 +616,7 @@ __device__ __forceinline__ void hot_accumulate(const AggArgs& a, uint64_t* lacc,
         if (a.hot_w_sum >= 0) __hip_atomic_fetch_add((double*)&lacc[a.hot_w_sum * stride + slot], __longlong_as_double((long long)vb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return;
     }
-#define VNM_W(K) (lacc + a.hot_w[K] * stride + slot)
-#define VNM_ADD(K, V) if (a.hot_w[K] >= 0) __hip_atomic_fetch_add(VNM_W(K), (uint64_t)(V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-    VNM_ADD(A_COUNT_ROWS, 1ULL);
-    VNM_ADD(A_COUNT_VALID, 1ULL);
-    if (a.hot_w[A_SUM_F64] >= 0)
-        __hip_atomic_fetch_add((double*)VNM_W(A_SUM_F64), __longlong_as_double((long long)vb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    VNM_ADD(A_SUM_I64, vb);
-    VNM_ADD(A_SUM_LO32, vb & 0xFFFFFFFFULL);
-    VNM_ADD(A_SUM_HI32S, (int64_t)vb >> 32);
-    VNM_ADD(A_SUM_HI32U, vb >> 32);
-    if (a.hot_w[A_MIN] >= 0 || a.hot_w[A_MAX] >= 0) {
-        const uint64_t e = a.hot_vtype == VNM_F64 ? enc_f64(__longlong_as_double((long long)vb))
-                                                  : (a.hot_vtype == VNM_U64 ? vb : enc_i64((int64_t)vb));
-        if (a.hot_w[A_MIN] >= 0) __hip_atomic_fetch_min(VNM_W(A_MIN), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (a.hot_w[A_MAX] >= 0) __hip_atomic_fetch_max(VNM_W(A_MAX), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-#undef VNM_ADD
-#undef VNM_W
+    hot_accumulate_col(a.hot_w, a.hot_vtype, lacc, stride, slot, vb);
 }
 
 // one entry (key, value bits) straight into the HBM table: the saturated-key path of agg_hot_kernel<FROM_ENT>
@@ -628,7 +634,8 @@ __device__ __forceinline__ void hot_entry_to_table(const AggArgs& a, uint64_t ke
 
 // FROM_ENT: the rows are (key, value bits) entries (a.ent) instead of columns -- what the partitioned path spills when a
 // region is full (heavy keys); no predicate (already applied).
-template <bool HAS_PRED, bool PRED_IS_V, bool HAS_VAL, bool SIMPLE, bool FROM_ENT = false>
+// TWO: a second 8-byte input column (its accumulator words in hot_w2).
+template <bool HAS_PRED, bool PRED_IS_V, bool HAS_VAL, bool SIMPLE, bool FROM_ENT = false, bool TWO = false>
 __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
     extern __shared__ uint64_t lds[];
     __shared__ unsigned s_fill, s_new;
@@ -652,10 +659,14 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
     const uint32_t smask = (uint32_t)S - 1;
     const uint64_t* kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
     const uint64_t* vp = HAS_VAL ? (const uint64_t*)a.cols[0].values + a.cols[0].offset : kp;
+    const uint64_t* vp2 = TWO ? (const uint64_t*)a.cols[1].values + a.cols[1].offset : kp;
     const double* pp = (const double*)a.pred.values + a.pred.offset;
     const int op = a.p.op;
     const double thr = a.p.dval;
 
+    ulonglong2 kk[HOT_UNROLL], vv[HOT_UNROLL], vw[HOT_UNROLL];  // this block's current (then next) tile, see below
+    double2 pv[HOT_UNROLL];
+    bool have = false;
     bool need_check = true;
     unsigned it = a.progress[blockIdx.x];
     for (;; it++) {
@@ -669,40 +680,59 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
         const int64_t base = tile * HOT_TILE + 2 * tid;
         uint32_t sat0 = 0, sat1 = 0;  // rows (even / odd element of chunk u) whose key the LDS table could not take
         if (base + (int64_t)(HOT_UNROLL - 1) * 2 * AGG_BLOCK + 1 < a.nrows) {
-            ulonglong2 kk[HOT_UNROLL], vv[HOT_UNROLL];
-            double2 pv[HOT_UNROLL];
+            // Register rotation: as soon as chunk u of this tile has been copied out, chunk u of the block's NEXT
+            // tile is requested into the same registers, so HBM loads are in flight while the LDS work of this tile
+            // runs (one 1024-thread block per CU: without this the block alternates between a load phase and an
+            // LDS phase -- G=1000 ran at 4.2 ms against 3.1 ms for G=7).
+#define VNM_HOT_LOAD(u, b)                                                                                      \
+    do {                                                                                                       \
+        const int64_t r_ = (b) + (int64_t)(u) * 2 * AGG_BLOCK;                                                 \
+        if (FROM_ENT) {                                                                                        \
+            const ulonglong2 e0 = a.ent[r_], e1 = a.ent[r_ + 1];                                               \
+            kk[u].x = e0.x; kk[u].y = e1.x;                                                                    \
+            vv[u].x = e0.y; vv[u].y = e1.y;                                                                    \
+        } else {                                                                                               \
+            kk[u] = *(const ulonglong2*)(kp + r_);                                                             \
+            if (HAS_VAL) vv[u] = *(const ulonglong2*)(vp + r_);                                                \
+            if (TWO) vw[u] = *(const ulonglong2*)(vp2 + r_);                                                   \
+            if (HAS_PRED && !PRED_IS_V) pv[u] = *(const double2*)(pp + r_);                                    \
+        }                                                                                                      \
+    } while (0)
+            if (!have) {
 #pragma unroll
-            for (int u = 0; u < HOT_UNROLL; u++) {
-                int64_t r = base + (int64_t)u * 2 * AGG_BLOCK;
-                if (FROM_ENT) {
-                    const ulonglong2 e0 = a.ent[r], e1 = a.ent[r + 1];
-                    kk[u].x = e0.x; kk[u].y = e1.x;
-                    vv[u].x = e0.y; vv[u].y = e1.y;
-                } else {
-                    kk[u] = *(const ulonglong2*)(kp + r);
-                    if (HAS_VAL) vv[u] = *(const ulonglong2*)(vp + r);
-                    if (HAS_PRED && !PRED_IS_V) pv[u] = *(const double2*)(pp + r);
-                }
+                for (int u = 0; u < HOT_UNROLL; u++) VNM_HOT_LOAD(u, base);
             }
+            const int64_t nbase = base + (int64_t)gridDim.x * HOT_TILE;
+            const bool nfull = tile + gridDim.x < a.ntiles && nbase + (int64_t)(HOT_UNROLL - 1) * 2 * AGG_BLOCK + 1 < a.nrows;
 #pragma unroll
             for (int u = 0; u < HOT_UNROLL; u++) {
+                const ulonglong2 k = kk[u];
                 const uint64_t v0 = HAS_VAL ? vv[u].x : 0, v1 = HAS_VAL ? vv[u].y : 0;
+                const uint64_t w0 = TWO ? vw[u].x : 0, w1 = TWO ? vw[u].y : 0;
                 const double p0 = PRED_IS_V ? __longlong_as_double((long long)v0) : pv[u].x;
                 const double p1 = PRED_IS_V ? __longlong_as_double((long long)v1) : pv[u].y;
+                if (nfull) VNM_HOT_LOAD(u, nbase);
                 if (!HAS_PRED || cmp_apply<double>(op, p0, thr)) {
-                    int slot = hot_slot(lkey, S, smask, &s_fill, kk[u].x);
-                    if (slot >= 0) hot_accumulate<SIMPLE>(a, lacc, stride, slot, v0); else sat0 |= 1u << u;
+                    int slot = hot_slot(lkey, S, smask, &s_fill, k.x);
+                    if (slot >= 0) {
+                        hot_accumulate<SIMPLE>(a, lacc, stride, slot, v0);
+                        if (TWO) hot_accumulate_col(a.hot_w2, a.hot_vtype2, lacc, stride, slot, w0);
+                    } else if (FROM_ENT) hot_entry_to_table(a, k.x, v0, &s_new);  // no columns to re-read: merge right here
+                    else sat0 |= 1u << u;
                 }
                 if (!HAS_PRED || cmp_apply<double>(op, p1, thr)) {
-                    int slot = hot_slot(lkey, S, smask, &s_fill, kk[u].y);
-                    if (slot >= 0) hot_accumulate<SIMPLE>(a, lacc, stride, slot, v1); else sat1 |= 1u << u;
-                }
-                if (FROM_ENT && ((sat0 | sat1) >> u) & 1u) {  // no columns to re-read: merge the entry right here
-                    if ((sat0 >> u) & 1u) hot_entry_to_table(a, kk[u].x, v0, &s_new);
-                    if ((sat1 >> u) & 1u) hot_entry_to_table(a, kk[u].y, v1, &s_new);
+                    int slot = hot_slot(lkey, S, smask, &s_fill, k.y);
+                    if (slot >= 0) {
+                        hot_accumulate<SIMPLE>(a, lacc, stride, slot, v1);
+                        if (TWO) hot_accumulate_col(a.hot_w2, a.hot_vtype2, lacc, stride, slot, w1);
+                    } else if (FROM_ENT) hot_entry_to_table(a, k.y, v1, &s_new);
+                    else sat1 |= 1u << u;
                 }
             }
+            have = nfull;
+#undef VNM_HOT_LOAD
         } else {
+            have = false;
             for (int u = 0; u < HOT_UNROLL; u++)
                 for (int e = 0; e < 2; e++) {
                     int64_t r = base + (int64_t)u * 2 * AGG_BLOCK + e;
@@ -712,7 +742,10 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                     const double p = PRED_IS_V ? __longlong_as_double((long long)vb) : (HAS_PRED ? pp[r] : 0.0);
                     if (HAS_PRED && !cmp_apply<double>(op, p, thr)) continue;
                     int slot = hot_slot(lkey, S, smask, &s_fill, kb);
-                    if (slot >= 0) hot_accumulate<SIMPLE>(a, lacc, stride, slot, vb);
+                    if (slot >= 0) {
+                        hot_accumulate<SIMPLE>(a, lacc, stride, slot, vb);
+                        if (TWO) hot_accumulate_col(a.hot_w2, a.hot_vtype2, lacc, stride, slot, vp2[r]);
+                    }
                     else if (FROM_ENT) hot_entry_to_table(a, kb, vb, &s_new);
                     else if (e == 0) sat0 |= 1u << u;
                     else sat1 |= 1u << u;
@@ -1461,7 +1494,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
                     // long as its unluckiest lane, and linear probing's clusters make that lane's chain long.
                     const uint32_t step = ((hv >> 11) & 15u) * 2u + 1u;
                     for (int probe = 0; probe < PA_SLOTS; probe++) {
-                        uint64_t k = *(volatile uint64_t*)&lkey[h];
+                        uint64_t k = __hip_atomic_load(&lkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (k == key) { slot = (int)h; break; }
                         if (k == EMPTY) {
                             uint64_t expected = EMPTY;
@@ -1619,7 +1652,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_generic_kernel(PartAggArgs 
                         uint32_t h = hv & smask;
                         const uint32_t step = ((hv >> 11) & 15u) * 2u + 1u;  // double hashing, see part_agg_kernel
                         for (int probe = 0; probe < PA_SLOTS; probe++) {
-                            uint64_t k = *(volatile uint64_t*)&lkey[h];
+                            uint64_t k = __hip_atomic_load(&lkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             if (k == key) { slot = (int)h; break; }
                             if (k == EMPTY) {
                                 uint64_t expected = EMPTY;
@@ -1942,7 +1975,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_merge_kernel(PartMergeArgs a) {
                 else {
                     uint32_t h = hash_u64(key) & smask;
                     for (int probe = 0; probe < PA_SLOTS; probe++) {
-                        uint64_t k = *(volatile uint64_t*)&lkey[h];
+                        uint64_t k = __hip_atomic_load(&lkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (k == key) { slot = (int)h; break; }
                         if (k == EMPTY) {
                             uint64_t expected = EMPTY;
@@ -2773,26 +2806,30 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     a.lds_slots = S;
     // hot shape: one 8-byte key, every function in {COUNT(*), COUNT, SUM, AVG} over ONE float64 column,
     // float64 predicate column (or none), no validity bitmaps, even offsets (16-byte aligned pairs)
-    // hot_scan: what agg_hot_kernel takes (any accumulator kind over at most one 8-byte column without NULLs);
+    // hot_scan: what agg_hot_kernel takes (any accumulator kind over at most TWO 8-byte columns without NULLs);
     // hot: the subset {COUNT(*), COUNT, SUM, AVG} of a float64 column that part_agg_kernel is specialised for
-    bool hot_scan = h->single && h->plan.n_cols <= 1 && type_width(keys[0].type) == 8 && !keys[0].validity &&
+    bool hot_scan = h->single && h->plan.n_cols <= 2 && type_width(keys[0].type) == 8 && !keys[0].validity &&
                     (keys[0].offset & 1) == 0 && getenv("VNM_AGG_NO_HOT") == nullptr;
-    a.hot_has_val = h->plan.n_cols == 1;
-    a.hot_vtype = VNM_U64;
-    if (hot_scan && a.hot_has_val) {
-        const vnm_dcol& c = a.cols[0];
-        hot_scan = (c.type == VNM_F64 || c.type == VNM_I64 || c.type == VNM_U64) && !c.validity && (c.offset & 1) == 0;
-        a.hot_vtype = c.type;
+    a.hot_has_val = h->plan.n_cols >= 1;
+    a.hot_vtype = a.hot_vtype2 = VNM_U64;
+    for (int c = 0; c < h->plan.n_cols && hot_scan; c++) {
+        const vnm_dcol& col = a.cols[c];
+        hot_scan = (col.type == VNM_F64 || col.type == VNM_I64 || col.type == VNM_U64) && !col.validity && (col.offset & 1) == 0;
+        (c == 0 ? a.hot_vtype : a.hot_vtype2) = col.type;
     }
+    const bool hot_two = hot_scan && h->plan.n_cols == 2;
     a.hot_w_rows = a.hot_w_valid = a.hot_w_sum = -1;
-    for (int k = 0; k < 9; k++) a.hot_w[k] = -1;
-    bool hot = hot_scan && a.hot_has_val && a.hot_vtype == VNM_F64;
+    for (int k = 0; k < 9; k++) a.hot_w[k] = a.hot_w2[k] = -1;
+    bool hot = hot_scan && h->plan.n_cols == 1 && a.hot_vtype == VNM_F64;
     if (hot_scan) {
         for (int o = 0; o < h->plan.n_ops; o++) {
             const AccOp& op = h->plan.ops[o];
-            if (op.kind < 0 || op.kind > A_MAX || a.hot_w[op.kind] >= 0) { hot_scan = false; break; }  // one word per kind
-            if (op.kind == A_SUM_F64 && a.hot_vtype != VNM_F64) { hot_scan = false; break; }
-            a.hot_w[op.kind] = op.word;
+            int* hw = op.col == 1 ? a.hot_w2 : a.hot_w;
+            const int vt = op.col == 1 ? a.hot_vtype2 : a.hot_vtype;
+            if (op.kind < 0 || op.kind > A_MAX || hw[op.kind] >= 0) { hot_scan = false; break; }  // one word per kind and column
+            if (op.kind == A_SUM_F64 && vt != VNM_F64) { hot_scan = false; break; }
+            hw[op.kind] = op.word;
+            if (op.col == 1) { hot = false; continue; }
             if (op.kind == A_COUNT_ROWS) a.hot_w_rows = op.word;
             else if (op.kind == A_COUNT_VALID) a.hot_w_valid = op.word;
             else if (op.kind == A_SUM_F64) a.hot_w_sum = op.word;
@@ -2853,7 +2890,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     int64_t n_spill = 0;
     if (part_ok && h->hint > part_min && getenv("VNM_AGG_NO_PART") == nullptr) {
         if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
-        const bool can_spill = hot_scan && getenv("VNM_AGG_NO_SPILL") == nullptr;
+        const bool can_spill = hot_scan && !hot_two && getenv("VNM_AGG_NO_SPILL") == nullptr;
         int prc = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
         if (prc == 0 && !spill) { h->rows_seen += nrows; return 0; }
         if (prc == 1) return 1;
@@ -2901,6 +2938,16 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
                 if (!h->pred_set) VNM_HOT(false, false, true, true);
                 else if (a.hot_pred_is_v) VNM_HOT(true, true, true, true);
                 else VNM_HOT(true, false, true, true);
+            } else if (hot_two && hot_scan) {
+#define VNM_HOT2(P, V)                                                                                          \
+    do {                                                                                                       \
+        VNM_HIP(hipFuncSetAttribute((const void*)agg_hot_kernel<P, V, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        agg_hot_kernel<P, V, true, false, false, true><<<grid, AGG_BLOCK, lds_bytes, s>>>(a);                  \
+    } while (0)
+                if (!h->pred_set) VNM_HOT2(false, false);
+                else if (a.hot_pred_is_v) VNM_HOT2(true, true);
+                else VNM_HOT2(true, false);
+#undef VNM_HOT2
             } else if (!a.hot_has_val) { if (h->pred_set) VNM_HOT(true, false, false, false); else VNM_HOT(false, false, false, false); }
             else if (!h->pred_set) VNM_HOT(false, false, true, false);
             else if (a.hot_pred_is_v) VNM_HOT(true, true, true, false);
