@@ -579,3 +579,41 @@ def test_random_plans_sharded_exchange_simulated(seed):
         o.next(b)
     util.assert_agg_equal(got, o.result(), funcs, key_names,
                           what=f"seed {seed}: world {world} keys {[str(c) for c in key_types]} G~{groups}")
+
+
+@pytest.mark.parametrize("scenario", ["g1", "g3", "g16", "g40", "few_then_many", "two_columns_g5"])
+def test_few_groups_many_rows_key_copies(scenario):
+    """Low-cardinality keys over many tiles per workgroup: the scan kernel gives every key up to eight copies in its
+    LDS table (lane-spread slots) once the first tile showed a handful of groups, and drops the copies again when
+    the table fills up (few_then_many).  Quantised values: every partial sum is exact, so the float columns are
+    compared bit for bit (util.assert_agg_equal)."""
+    import pandas as pd
+    from oracle import oracle as O
+    rng = np.random.default_rng(len(scenario))
+    n = 7_000_000
+    if scenario == "few_then_many":
+        k = np.concatenate([rng.integers(0, 3, n // 2), rng.integers(0, 1800, n - n // 2)]).astype(np.int64)
+    else:
+        g = {"g1": 1, "g3": 3, "g16": 16, "g40": 40, "two_columns_g5": 5}[scenario]
+        k = rng.integers(0, g, n).astype(np.int64) * 1_000_003 - 7
+    a = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
+    b = rng.integers(-2**40, 2**40, n).astype(np.int64)
+    t = pa.table({"k": pa.array(k), "a": pa.array(a), "b": pa.array(b)})
+    if scenario == "two_columns_g5":
+        funcs = [(O.SUM, "a", "sa"), (O.MAX, "b", "mb"), (O.MIN, "b", "nb"), (O.COUNT_STAR, "", "n"), (O.AVG, "a", "aa")]
+    else:
+        funcs = [(O.SUM, "a", "sa"), (O.MIN, "a", "na"), (O.MAX, "a", "ma"), (O.COUNT_STAR, "", "n"), (O.AVG, "a", "aa")]
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, t.to_batches(max_chunksize=n))
+    df = pd.DataFrame({"k": k, "a": a, "b": b}).groupby("k", sort=True)
+    exp = {"k": None}
+    ref = df.agg(sa=("a", "sum"), na=("a", "min"), ma=("a", "max"), n=("a", "size"), aa=("a", "mean"),
+                 mb=("b", "max"), nb=("b", "min")).reset_index()
+    order = np.argsort(got.column(0).to_numpy(zero_copy_only=False), kind="stable")
+    assert got.num_rows == len(ref)
+    np.testing.assert_array_equal(got.column(0).to_numpy(zero_copy_only=False)[order], ref["k"].to_numpy())
+    for i, (_, _, out) in enumerate(funcs):
+        col = got.column(1 + i).to_numpy(zero_copy_only=False)[order]
+        want = ref[out].to_numpy()
+        if out == "aa":   # sum / count in float64, as the reference computes it
+            want = ref["sa"].to_numpy() / ref["n"].to_numpy()
+        np.testing.assert_array_equal(col, want.astype(col.dtype), err_msg=f"{scenario}: {out}")

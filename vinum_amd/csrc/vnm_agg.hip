@@ -563,23 +563,25 @@ constexpr int HOT_UNROLL = 4;
 constexpr int HOT_TILE = AGG_BLOCK * 2 * HOT_UNROLL;  // 8192 rows per block iteration
 
 // probe / claim the LDS slot of `key`; -1 = the table is saturated for this key
-__device__ __forceinline__ int hot_slot(uint64_t* lkey, int S, uint32_t smask, unsigned* s_fill, uint64_t key) {
+// spread (0..7, per lane): with very few groups the lanes of a wave that hold the same key would all hit ONE accumulator
+// address (LDS atomics on one address are serial); xor-ing the lane's low bits into the home slot gives every key up to
+// eight copies in adjacent banks, which the flush merges by key like any other slot.
+__device__ __forceinline__ int hot_slot(uint64_t* lkey, int S, uint32_t smask, unsigned* s_fill, uint64_t key, uint32_t spread) {
     if (key == EMPTY) { lkey[S] = 0; return S; }
     const uint32_t hv = hash_u64(key);
-    uint32_t h = hv & smask;
+    uint32_t h = (hv ^ spread) & smask;
     const uint32_t step = ((hv >> 20) & 31u) * 2u + 1u;  // double hashing: shorter worst chains than linear probing
+    // one divergent region (the claim) and one exit per iteration: the scan issues fewer scalar exec-mask instructions
     for (int probe = 0; probe < AGG_MAX_PROBES; probe++) {
         uint64_t k = __hip_atomic_load(&lkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (k == key) return (int)h;
         if (k == EMPTY) {
             uint64_t expected = EMPTY;
-            if (__hip_atomic_compare_exchange_strong(&lkey[h], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                atomicAdd(s_fill, 1u);
-                return (int)h;
-            }
-            if (expected == key) return (int)h;
+            const bool won = __hip_atomic_compare_exchange_strong(&lkey[h], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (won) atomicAdd(s_fill, 1u);
+            k = won ? key : expected;
         }
+        if (k == key) return (int)h;
         h = (h + step) & smask;
     }
     return -1;
@@ -667,6 +669,8 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
     ulonglong2 kk[HOT_UNROLL], vv[HOT_UNROLL], vw[HOT_UNROLL];  // this block's current (then next) tile, see below
     double2 pv[HOT_UNROLL];
     bool have = false;
+    uint32_t spread = 0;
+    int spread_state = (a.debug & 4) ? 2 : 0;  // VNM_AGG_DEBUG & 4: no key copies (measurement)
     bool need_check = true;
     unsigned it = a.progress[blockIdx.x];
     for (;; it++) {
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                 const double p1 = PRED_IS_V ? __longlong_as_double((long long)v1) : pv[u].y;
                 if (nfull) VNM_HOT_LOAD(u, nbase);
                 if (!HAS_PRED || cmp_apply<double>(op, p0, thr)) {
-                    int slot = hot_slot(lkey, S, smask, &s_fill, k.x);
+                    int slot = hot_slot(lkey, S, smask, &s_fill, k.x, spread);
                     if (slot >= 0) {
                         hot_accumulate<SIMPLE>(a, lacc, stride, slot, v0);
                         if (TWO) hot_accumulate_col(a.hot_w2, a.hot_vtype2, lacc, stride, slot, w0);
@@ -721,7 +725,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                     else sat0 |= 1u << u;
                 }
                 if (!HAS_PRED || cmp_apply<double>(op, p1, thr)) {
-                    int slot = hot_slot(lkey, S, smask, &s_fill, k.y);
+                    int slot = hot_slot(lkey, S, smask, &s_fill, k.y, spread);
                     if (slot >= 0) {
                         hot_accumulate<SIMPLE>(a, lacc, stride, slot, v1);
                         if (TWO) hot_accumulate_col(a.hot_w2, a.hot_vtype2, lacc, stride, slot, w1);
@@ -741,7 +745,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                     const uint64_t kb = FROM_ENT ? a.ent[r].x : kp[r];
                     const double p = PRED_IS_V ? __longlong_as_double((long long)vb) : (HAS_PRED ? pp[r] : 0.0);
                     if (HAS_PRED && !cmp_apply<double>(op, p, thr)) continue;
-                    int slot = hot_slot(lkey, S, smask, &s_fill, kb);
+                    int slot = hot_slot(lkey, S, smask, &s_fill, kb, spread);
                     if (slot >= 0) {
                         hot_accumulate<SIMPLE>(a, lacc, stride, slot, vb);
                         if (TWO) hot_accumulate_col(a.hot_w2, a.hot_vtype2, lacc, stride, slot, vp2[r]);
@@ -757,6 +761,10 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
         __syncthreads();
         const unsigned fill_now = s_fill;
         need_check = fill_now > (unsigned)S / 2;
+        // key copies (see hot_slot): on after the first tile when it found a handful of groups, off for good once the
+        // table holds more than that would explain
+        if (spread_state == 0) { spread_state = fill_now <= (unsigned)S / 128 ? 1 : 2; if (spread_state == 1) spread = tid & 7u; }
+        else if (spread_state == 1 && fill_now > (unsigned)S / 8) { spread_state = 2; spread = 0; }
         if (fill_now > flush_at) {
             lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK, &s_new);
             __syncthreads();
@@ -1451,6 +1459,40 @@ struct PartAggArgs {
     int merge[AGG_MAX_WORDS];
 };
 
+// Find-or-claim the slot of `key` in a final-pass LDS table (PA_SLOTS keys).  The pass is bound by the number of
+// instructions a wave issues per entry (PMC: ~250, half of them scalar exec-mask bookkeeping, at one instruction per
+// ~4 cycles and SIMD), so the loop has ONE divergent region (the claim) and one exit; the number of claimed slots is
+// counted per lane (*ins) and summed once per partition instead of one LDS atomic per claim.  -1 = no room.
+constexpr int PA_MAX_PROBES = 256;
+__device__ __forceinline__ int pa_find_slot(uint64_t* lkey, uint32_t smask, uint64_t key, uint32_t* ins, uint32_t* s_fail) {
+    const uint32_t hv = hash_u64(key);
+    uint32_t h = hv & smask;
+    // double hashing: an odd step from hash bits the partitioning did not use ([14:11]).  A wave runs as long as its
+    // unluckiest lane, and linear probing's clusters make that lane's chain long.
+    const uint32_t step = ((hv >> 11) & 15u) * 2u + 1u;
+    for (int probe = 0; probe < PA_MAX_PROBES; probe++) {
+        uint64_t k = __hip_atomic_load(&lkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k == EMPTY) {
+            uint64_t expected = EMPTY;
+            const bool won = __hip_atomic_compare_exchange_strong(&lkey[h], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+            *ins += won ? 1u : 0u;
+            k = won ? key : expected;
+        }
+        if (k == key) return (int)h;
+        h = (h + step) & smask;
+        if ((probe & 31) == 31 && __hip_atomic_load(s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;  // the partition is lost anyway
+    }
+    return -1;
+}
+
+// sum of v over the block's lanes that call it (all of them), added to *dst by one lane per wave
+__device__ __forceinline__ void pa_block_add(uint32_t* dst, uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+}
+
 __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
     __shared__ uint64_t lkey[PA_SLOTS + 1];
     __shared__ uint64_t lsum[PA_SLOTS + 1];
@@ -1467,6 +1509,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
         for (int i = tid; i <= PA_SLOTS; i += PA_BLOCK) { lkey[i] = EMPTY; lsum[i] = 0; lcnt[i] = 0; }
         if (tid == 0) { s_n = 0; s_fail = 0; }
         __syncthreads();
+        uint32_t ins = 0;  // slots this lane claimed in this partition's table
         for (int rj = part; rj < a.regions; rj += a.splits) {
             const int64_t region = f * a.regions + rj;
             const uint32_t n = a.counts[region];
@@ -1485,30 +1528,11 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
                 if (i >= n) continue;
                 ulonglong2 e = eb[u];
                 const uint64_t key = e.x;
-                int slot = -1;
+                int slot;
                 if (key == EMPTY) { slot = PA_SLOTS; lkey[slot] = 0; }
                 else {
-                    const uint32_t hv = hash_u64(key);
-                    uint32_t h = hv & smask;
-                    // double hashing: an odd step from hash bits the partitioning did not use ([14:11]).  A wave runs as
-                    // long as its unluckiest lane, and linear probing's clusters make that lane's chain long.
-                    const uint32_t step = ((hv >> 11) & 15u) * 2u + 1u;
-                    for (int probe = 0; probe < PA_SLOTS; probe++) {
-                        uint64_t k = __hip_atomic_load(&lkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (k == key) { slot = (int)h; break; }
-                        if (k == EMPTY) {
-                            uint64_t expected = EMPTY;
-                            if (__hip_atomic_compare_exchange_strong(&lkey[h], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                                if (atomicAdd(&s_n, 1u) >= (uint32_t)(PA_SLOTS * 9 / 10)) s_fail = 1;
-                                slot = (int)h;
-                                break;
-                            }
-                            if (expected == key) { slot = (int)h; break; }
-                        }
-                        h = (h + step) & smask;
-                        if ((probe & 15) == 15 && s_fail) break;
-                    }
+                    slot = pa_find_slot(lkey, smask, key, &ins, &s_fail);
+                    if (slot < 0) s_fail = 1;
                 }
                 if (slot >= 0) {
                     __hip_atomic_fetch_add((double*)&lsum[slot], __longlong_as_double((long long)e.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1517,6 +1541,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
               }
             }
         }
+        pa_block_add(&s_n, ins);
         __syncthreads();
         if (s_fail) {  // more groups than the LDS table holds: tell the host to use the general path
             if (tid == 0) __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1550,6 +1575,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
         }
         // compact: reserve a dense range for this partition's groups, then write them
         const uint32_t ngroups = s_n + (lkey[PA_SLOTS] != EMPTY ? 1u : 0u);
+        __syncthreads();
         if (tid == 0) {
             s_base = atomicAdd(&a.flags[1], (unsigned long long)ngroups);
             s_n = 0;
@@ -1623,6 +1649,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_generic_kernel(PartAggArgs 
         }
         if (tid == 0) { s_n = 0; s_fail = 0; }
         __syncthreads();
+        uint32_t ins = 0;  // slots this lane claimed in this partition's table
         for (int rj = part; rj < a.regions; rj += a.splits) {
             const int64_t region = f * a.regions + rj;
             const uint32_t n = a.counts[region];
@@ -1645,28 +1672,11 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_generic_kernel(PartAggArgs 
                     uint32_t i = i0 + (uint32_t)u * PA_BLOCK + tid;
                     if (i >= n) continue;
                     const uint64_t key = eb[u][0];
-                    int slot = -1;
+                    int slot;
                     if (key == EMPTY) { slot = PA_SLOTS; lkey[slot] = 0; }
                     else {
-                        const uint32_t hv = hash_u64(key);
-                        uint32_t h = hv & smask;
-                        const uint32_t step = ((hv >> 11) & 15u) * 2u + 1u;  // double hashing, see part_agg_kernel
-                        for (int probe = 0; probe < PA_SLOTS; probe++) {
-                            uint64_t k = __hip_atomic_load(&lkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (k == key) { slot = (int)h; break; }
-                            if (k == EMPTY) {
-                                uint64_t expected = EMPTY;
-                                if (__hip_atomic_compare_exchange_strong(&lkey[h], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                                         __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                                    if (atomicAdd(&s_n, 1u) >= (uint32_t)(PA_SLOTS * 9 / 10)) s_fail = 1;
-                                    slot = (int)h;
-                                    break;
-                                }
-                                if (expected == key) { slot = (int)h; break; }
-                            }
-                            h = (h + step) & smask;
-                            if ((probe & 15) == 15 && s_fail) break;
-                        }
+                        slot = pa_find_slot(lkey, smask, key, &ins, &s_fail);
+                        if (slot < 0) s_fail = 1;
                     }
                     if (slot >= 0) {
                         const uint64_t vmask = (E > 2 && a.has_vmask) ? eb[u][E - 1] : ~0ULL;
@@ -1685,6 +1695,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_generic_kernel(PartAggArgs 
                 }
             }
         }
+        pa_block_add(&s_n, ins);
         __syncthreads();
         if (s_fail) {  // more groups than the LDS table holds: tell the host to use the general path
             if (tid == 0) __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2505,7 +2516,14 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     pa.dkey = rk; pa.dacc = ra; pa.dstride = dstride; pa.flags = flags;
     {
         KernelTimer timer("agg_part_final", s);
+        // one resident set of workgroups (they loop over the partitions): a grid larger than what fits leaves a
+        // second, partly filled round
         int g3 = (int)std::min<int64_t>(nfinal * splits, (int64_t)cus * 4);
+        auto fit_grid = [&](const void* fn, size_t lds) {
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, PA_BLOCK, lds) == hipSuccess && occ > 0)
+                g3 = (int)std::min<int64_t>(nfinal * splits, (int64_t)cus * std::min(occ, (int)env_i64("VNM_PA_OCC", 8)));
+        };
         if (a.part_generic) {
             pa.n_ops = h->plan.n_ops;
             pa.vtype = a.part_vtype;
@@ -2519,11 +2537,13 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
 #define VNM_PAG(E_)                                                                                                  \
     do {                                                                                                             \
         VNM_HIP(hipFuncSetAttribute((const void*)part_agg_generic_kernel<E_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        fit_grid((const void*)part_agg_generic_kernel<E_>, lds_bytes);                                               \
         part_agg_generic_kernel<E_><<<g3, PA_BLOCK, lds_bytes, s>>>(pa);                                             \
     } while (0)
             if (E == 2) VNM_PAG(2); else if (E == 3) VNM_PAG(3); else VNM_PAG(4);
 #undef VNM_PAG
         } else {
+            fit_grid((const void*)part_agg_kernel, 0);
             part_agg_kernel<<<g3, PA_BLOCK, 0, s>>>(pa);
         }
     }
