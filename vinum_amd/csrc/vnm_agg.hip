@@ -1457,6 +1457,11 @@ struct PartAggArgs {
     int vtypes[3];
     AccOp ops[AGG_MAX_OPS];
     int merge[AGG_MAX_WORDS];
+    // the same program as a table (part_agg_generic_kernel, when every (kind, column) occurs once): 6 bits per
+    // AccKind = accumulator word, 63 = absent; COUNT(*) separately.  Two scalar registers per column instead of
+    // kernel-argument loads (and their lgkmcnt waits) inside the entry loop.
+    unsigned long long wpack[3];
+    int w_rows_g, use_table, nval;
 };
 
 // Find-or-claim the slot of `key` in a final-pass LDS table (PA_SLOTS keys).  The pass is bound by the number of
@@ -1624,6 +1629,33 @@ __device__ __forceinline__ uint64_t op_value_bits(int kind, int vtype, uint64_t 
     }
 }
 
+// every accumulator word of ONE input column (packed word table, see PartAggArgs::wpack) for a non-NULL value with
+// the raw bits `raw` of type `type`
+__device__ __forceinline__ void pa_accumulate_col(unsigned long long pack, int type, uint64_t* lw, int ST, int slot, uint64_t raw) {
+#define VNM_WI(K) ((int)((pack >> (6 * (K))) & 63ULL))
+#define VNM_W(K) (lw + VNM_WI(K) * ST + slot)
+#define VNM_ADD(K, V) if (VNM_WI(K) != 63) __hip_atomic_fetch_add(VNM_W(K), (uint64_t)(V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+    VNM_ADD(A_COUNT_VALID, 1ULL);
+    if (VNM_WI(A_SUM_F64) != 63)
+        __hip_atomic_fetch_add((double*)VNM_W(A_SUM_F64), raw_to_f64(type, raw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (((pack >> (6 * A_SUM_I64)) & 0xFFFFFFULL) != 0xFFFFFFULL) {  // any of the four integer-sum kinds (consecutive AccKinds)
+        const uint64_t iv = (uint64_t)raw_to_i64(type, raw);
+        VNM_ADD(A_SUM_I64, iv);
+        VNM_ADD(A_SUM_LO32, iv & 0xFFFFFFFFULL);
+        VNM_ADD(A_SUM_HI32S, (int64_t)iv >> 32);
+        VNM_ADD(A_SUM_HI32U, iv >> 32);
+    }
+    if (VNM_WI(A_MIN) != 63 || VNM_WI(A_MAX) != 63) {
+        const uint64_t e = type_is_float(type) ? enc_f64(raw_to_f64(type, raw))
+                                               : (type_is_unsigned(type) ? (uint64_t)raw_to_i64(type, raw) : enc_i64(raw_to_i64(type, raw)));
+        if (VNM_WI(A_MIN) != 63) __hip_atomic_fetch_min(VNM_W(A_MIN), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (VNM_WI(A_MAX) != 63) __hip_atomic_fetch_max(VNM_W(A_MAX), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#undef VNM_ADD
+#undef VNM_W
+#undef VNM_WI
+}
+
 // Final pass of the partitioned path for ANY accumulator program over one 8-byte input column (or none):
 // same protocol as part_agg_kernel, W accumulator words per LDS slot.  LDS: lkey[S + 1], lw[W][S + 1].
 template <int E>
@@ -1678,7 +1710,15 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_generic_kernel(PartAggArgs 
                         slot = pa_find_slot(lkey, smask, key, &ins, &s_fail);
                         if (slot < 0) s_fail = 1;
                     }
-                    if (slot >= 0) {
+                    if (slot >= 0 && a.use_table) {
+                        const uint64_t vmask = (E > 2 && a.has_vmask) ? eb[u][E - 1] : ~0ULL;
+                        if (a.w_rows_g >= 0) __hip_atomic_fetch_add(&lw[a.w_rows_g * ST + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                        for (int c = 0; c < E - 1; c++) {
+                            if (c < a.nval && (E == 2 || ((vmask >> c) & 1ULL)))  // a NULL input updates nothing of its column
+                                pa_accumulate_col(a.wpack[c], a.vtypes[c], lw, ST, slot, eb[u][1 + c]);
+                        }
+                    } else if (slot >= 0) {
                         const uint64_t vmask = (E > 2 && a.has_vmask) ? eb[u][E - 1] : ~0ULL;
                         for (int o = 0; o < a.n_ops; o++) {
                             const int w = a.ops[o].word;
@@ -2534,6 +2574,17 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
             pa.wide = wide;
             pa.has_vmask = a.part_vmask;
             for (int c = 0; c < 3; c++) pa.vtypes[c] = a.part_vtypes[c];
+            pa.nval = h->plan.n_cols;
+            pa.w_rows_g = -1;
+            pa.use_table = getenv("VNM_AGG_NO_PART_TABLE") == nullptr;
+            for (int c = 0; c < 3; c++) pa.wpack[c] = ~0ULL;
+            for (int o = 0; o < h->plan.n_ops && pa.use_table; o++) {
+                const AccOp& op = h->plan.ops[o];
+                if (op.kind == A_COUNT_ROWS) { if (pa.w_rows_g >= 0) pa.use_table = 0; pa.w_rows_g = op.word; continue; }
+                const int c = op.col < 0 ? 0 : op.col;
+                if (c > 2 || op.kind < 0 || op.kind > A_MAX || op.word >= 63 || ((pa.wpack[c] >> (6 * op.kind)) & 63ULL) != 63) { pa.use_table = 0; break; }
+                pa.wpack[c] = (pa.wpack[c] & ~(63ULL << (6 * op.kind))) | ((unsigned long long)op.word << (6 * op.kind));
+            }
 #define VNM_PAG(E_)                                                                                                  \
     do {                                                                                                             \
         VNM_HIP(hipFuncSetAttribute((const void*)part_agg_generic_kernel<E_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
