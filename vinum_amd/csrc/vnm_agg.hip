@@ -348,6 +348,8 @@ __device__ __forceinline__ bool pred_eval_raw(const Predicate& p, int type, uint
 // dependent load and one type switch per row and op -- ran at 12.7 ms per 1e9 rows for MIN+MAX.)
 // BLK = 1024: one workgroup per CU with the largest LDS table (two 512-thread workgroups per CU with half-size
 // tables were measured slower: 9.9-13.8 vs 9.9 ms).
+__device__ __forceinline__ int hot_slot(uint64_t* lkey, int S, uint32_t smask, unsigned* s_fill, uint64_t key, uint32_t spread);
+
 template <int BLK>
 __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
     constexpr int R = AGG_ROWS_PER_THREAD;
@@ -377,6 +379,8 @@ __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
     // room check (an agent-scope read + a barrier per tile) is only repeated after a flush or above half load;
     // the margin the host reserves per workgroup (one LDS table + one tile) covers everything in between.
     bool need_check = true;
+    uint32_t spread = 0;
+    int spread_state = (a.debug & 4) ? 2 : 0;
     unsigned it = a.progress[blockIdx.x];
     for (;; it++) {
         const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
@@ -447,25 +451,8 @@ __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
             if (st[r] == 3) { slot[r] = S + 1; lkey[S + 1] = 0; }
             else if (st[r] == 2) { slot[r] = S; lkey[S] = 0; }
             else if (st[r] == 1 && !(a.debug & 2)) {
-                slot[r] = -2;
-                const uint32_t hv = hash_u64(key[r]);
-                uint32_t h = hv & smask;
-                const uint32_t step = ((hv >> 20) & 31u) * 2u + 1u;  // double hashing
-                for (int probe = 0; probe < AGG_MAX_PROBES; probe++) {
-                    uint64_t k = __hip_atomic_load(&lkey[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (k == key[r]) { slot[r] = (int)h; break; }
-                    if (k == EMPTY) {
-                        uint64_t expected = EMPTY;
-                        if (__hip_atomic_compare_exchange_strong(&lkey[h], &expected, key[r], __ATOMIC_RELAXED,
-                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                            atomicAdd(&s_fill, 1u);
-                            slot[r] = (int)h;
-                            break;
-                        }
-                        if (expected == key[r]) { slot[r] = (int)h; break; }
-                    }
-                    h = (h + step) & smask;
-                }
+                const int hs = hot_slot(lkey, S, smask, &s_fill, key[r], spread);
+                slot[r] = hs < 0 ? -2 : hs;
             }
         }
         // keys the LDS table could not take go straight to the HBM table, out of line (this code must not be
@@ -538,6 +525,8 @@ __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
         __syncthreads();
         const unsigned fill_now = s_fill;
         need_check = fill_now > (unsigned)S / 2;
+        if (spread_state == 0) { spread_state = fill_now <= (unsigned)S / 128 ? 1 : 2; if (spread_state == 1) spread = tid & 7u; }  // see agg_hot_kernel
+        else if (spread_state == 1 && fill_now > (unsigned)S / 8) { spread_state = 2; spread = 0; }
         if (fill_now > flush_at) {
             lds_flush(a, lkey, lacc, S, tid, BLK, &s_new);
             __syncthreads();
