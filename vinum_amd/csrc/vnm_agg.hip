@@ -1487,11 +1487,17 @@ __device__ __forceinline__ void pa_block_add(uint32_t* dst, uint32_t v) {
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
 }
 
-__global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
-    __shared__ uint64_t lkey[PA_SLOTS + 1];
-    __shared__ uint64_t lsum[PA_SLOTS + 1];
-    __shared__ uint32_t lcnt[PA_SLOTS + 1];
-    __shared__ uint32_t s_n, s_fail;
+__global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void part_agg_kernel(PartAggArgs a) {
+    // 40 KB per workgroup, so that FOUR fit a CU (the pass is latency-bound: 1 / 2 / 3 resident workgroups ran at
+    // 5.6 / 3.3 / 2.6 ms).  The last PA_DEAD slots of the key table are never used (they hold a reserved marker that
+    // probes step over), which pays for the scalars below and for the accumulators of the two keys that cannot live in
+    // the table: EMPTY (the free marker) and PA_RESERVED itself, at lsum / lcnt [PA_LIVE] and [PA_LIVE + 1].
+    constexpr int PA_DEAD = 8, PA_LIVE = PA_SLOTS - PA_DEAD;
+    constexpr uint64_t PA_RESERVED = EMPTY - 1;
+    __shared__ uint64_t lkey[PA_SLOTS];
+    __shared__ uint64_t lsum[PA_LIVE + 2];
+    __shared__ uint32_t lcnt[PA_LIVE + 2];
+    __shared__ uint32_t s_n, s_fail, s_sp[2];
     __shared__ unsigned s_new;
     __shared__ unsigned long long s_base;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1500,8 +1506,11 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
     for (int64_t unit = blockIdx.x; unit < a.nfinal * a.splits; unit += gridDim.x) {
         const int64_t f = unit / a.splits;
         const int part = (int)(unit % a.splits);
-        for (int i = tid; i <= PA_SLOTS; i += PA_BLOCK) { lkey[i] = EMPTY; lsum[i] = 0; lcnt[i] = 0; }
-        if (tid == 0) { s_n = 0; s_fail = 0; }
+        for (int i = tid; i < PA_SLOTS; i += PA_BLOCK) {
+            lkey[i] = i < PA_LIVE ? EMPTY : PA_RESERVED;
+            if (i < PA_LIVE + 2) { lsum[i] = 0; lcnt[i] = 0; }
+        }
+        if (tid == 0) { s_n = 0; s_fail = 0; s_sp[0] = 0; s_sp[1] = 0; }
         __syncthreads();
         uint32_t ins = 0;  // slots this lane claimed in this partition's table
         for (int rj = part; rj < a.regions; rj += a.splits) {
@@ -1523,7 +1532,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
                 ulonglong2 e = eb[u];
                 const uint64_t key = e.x;
                 int slot;
-                if (key == EMPTY) { slot = PA_SLOTS; lkey[slot] = 0; }
+                if (key >= PA_RESERVED) { const int sp = key == EMPTY ? 0 : 1; slot = PA_LIVE + sp; s_sp[sp] = 1; }
                 else {
                     slot = pa_find_slot(lkey, smask, key, &ins, &s_fail);
                     if (slot < 0) s_fail = 1;
@@ -1553,11 +1562,11 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
                 if (tid == 0) __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return;
             }
-            for (int i = tid; i <= PA_SLOTS; i += PA_BLOCK) {
-                uint64_t k = lkey[i];
+            for (int i = tid; i < PA_LIVE + 2; i += PA_BLOCK) {
+                uint64_t k = i < PA_LIVE ? lkey[i] : (s_sp[i - PA_LIVE] ? (i == PA_LIVE ? 0 : PA_RESERVED) : EMPTY);
                 if (k == EMPTY) continue;
                 uint64_t slot;
-                if (i < PA_SLOTS) slot = gt_find_single(a.g, k, &s_new);
+                if (i != PA_LIVE) slot = gt_find_single(a.g, k, &s_new);
                 else { slot = a.g.cap; if (ld_agent(&a.g.tag[slot]) == EMPTY) st_agent(&a.g.tag[slot], 0); }
                 if (a.w_rows >= 0) g_merge(&a.g.acc[(uint64_t)a.w_rows * a.g.stride + slot], M_ADD_U64, lcnt[i]);
                 if (a.w_valid >= 0) g_merge(&a.g.acc[(uint64_t)a.w_valid * a.g.stride + slot], M_ADD_U64, lcnt[i]);
@@ -1568,7 +1577,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
             continue;
         }
         // compact: reserve a dense range for this partition's groups, then write them
-        const uint32_t ngroups = s_n + (lkey[PA_SLOTS] != EMPTY ? 1u : 0u);
+        const uint32_t ngroups = s_n + s_sp[0] + s_sp[1];
         __syncthreads();
         if (tid == 0) {
             s_base = atomicAdd(&a.flags[1], (unsigned long long)ngroups);
@@ -1580,9 +1589,9 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
             if (tid == 0) __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
-        for (int i0 = 0; i0 <= PA_SLOTS; i0 += PA_BLOCK) {
+        for (int i0 = 0; i0 < PA_LIVE + 2; i0 += PA_BLOCK) {
             int i = i0 + tid;
-            bool occ = i <= PA_SLOTS && lkey[i] != EMPTY;
+            bool occ = i < PA_LIVE ? lkey[i] != EMPTY : (i < PA_LIVE + 2 && s_sp[i - PA_LIVE] != 0);
             uint64_t b = __ballot(occ);
             uint32_t wbase = 0;
             if (lane == 0 && b) wbase = atomicAdd(&s_n, (uint32_t)__popcll(b));
@@ -1590,7 +1599,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_kernel(PartAggArgs a) {
             if (occ) {
                 uint64_t lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
                 int64_t pos = (int64_t)s_base + wbase + __popcll(b & lt);
-                a.dkey[pos] = i == PA_SLOTS ? EMPTY : lkey[i];
+                a.dkey[pos] = i < PA_LIVE ? lkey[i] : (i == PA_LIVE ? EMPTY : PA_RESERVED);
                 a.dkey[a.dstride + pos] = 0;
                 if (a.w_rows >= 0) a.dacc[(int64_t)a.w_rows * a.dstride + pos] = lcnt[i];
                 if (a.w_valid >= 0) a.dacc[(int64_t)a.w_valid * a.dstride + pos] = lcnt[i];
@@ -1647,8 +1656,10 @@ __device__ __forceinline__ void pa_accumulate_col(unsigned long long pack, int t
 
 // Final pass of the partitioned path for ANY accumulator program over one 8-byte input column (or none):
 // same protocol as part_agg_kernel, W accumulator words per LDS slot.  LDS: lkey[S + 1], lw[W][S + 1].
-template <int E>
-__global__ __launch_bounds__(PA_BLOCK) void part_agg_generic_kernel(PartAggArgs a) {
+// TABLE: the accumulator program as packed word tables (PartAggArgs::wpack) -- the normal case; the op loop is only
+// compiled into the <E, false> instances (it costs registers: 89+ VGPRs and scratch left two workgroups per CU).
+template <int E, bool TABLE>
+__global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void part_agg_generic_kernel(PartAggArgs a) {
     extern __shared__ uint64_t pa_lds[];
     __shared__ uint32_t s_n, s_fail;
     __shared__ unsigned s_new;
@@ -1699,7 +1710,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_generic_kernel(PartAggArgs 
                         slot = pa_find_slot(lkey, smask, key, &ins, &s_fail);
                         if (slot < 0) s_fail = 1;
                     }
-                    if (slot >= 0 && a.use_table) {
+                    if (slot >= 0 && TABLE) {
                         const uint64_t vmask = (E > 2 && a.has_vmask) ? eb[u][E - 1] : ~0ULL;
                         if (a.w_rows_g >= 0) __hip_atomic_fetch_add(&lw[a.w_rows_g * ST + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
@@ -1707,7 +1718,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_agg_generic_kernel(PartAggArgs 
                             if (c < a.nval && (E == 2 || ((vmask >> c) & 1ULL)))  // a NULL input updates nothing of its column
                                 pa_accumulate_col(a.wpack[c], a.vtypes[c], lw, ST, slot, eb[u][1 + c]);
                         }
-                    } else if (slot >= 0) {
+                    } else if (slot >= 0 && !TABLE) {
                         const uint64_t vmask = (E > 2 && a.has_vmask) ? eb[u][E - 1] : ~0ULL;
                         for (int o = 0; o < a.n_ops; o++) {
                             const int w = a.ops[o].word;
@@ -2574,13 +2585,14 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
                 if (c > 2 || op.kind < 0 || op.kind > A_MAX || op.word >= 63 || ((pa.wpack[c] >> (6 * op.kind)) & 63ULL) != 63) { pa.use_table = 0; break; }
                 pa.wpack[c] = (pa.wpack[c] & ~(63ULL << (6 * op.kind))) | ((unsigned long long)op.word << (6 * op.kind));
             }
-#define VNM_PAG(E_)                                                                                                  \
+#define VNM_PAG(E_, T_)                                                                                              \
     do {                                                                                                             \
-        VNM_HIP(hipFuncSetAttribute((const void*)part_agg_generic_kernel<E_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-        fit_grid((const void*)part_agg_generic_kernel<E_>, lds_bytes);                                               \
-        part_agg_generic_kernel<E_><<<g3, PA_BLOCK, lds_bytes, s>>>(pa);                                             \
+        VNM_HIP(hipFuncSetAttribute((const void*)part_agg_generic_kernel<E_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        fit_grid((const void*)part_agg_generic_kernel<E_, T_>, lds_bytes);                                           \
+        part_agg_generic_kernel<E_, T_><<<g3, PA_BLOCK, lds_bytes, s>>>(pa);                                         \
     } while (0)
-            if (E == 2) VNM_PAG(2); else if (E == 3) VNM_PAG(3); else VNM_PAG(4);
+            if (pa.use_table) { if (E == 2) VNM_PAG(2, true); else if (E == 3) VNM_PAG(3, true); else VNM_PAG(4, true); }
+            else { if (E == 2) VNM_PAG(2, false); else if (E == 3) VNM_PAG(3, false); else VNM_PAG(4, false); }
 #undef VNM_PAG
         } else {
             fit_grid((const void*)part_agg_kernel, 0);
@@ -3285,7 +3297,9 @@ int vnm_agg_merge_partitioned(vnm_agg* h, int world, int64_t nlocal, const uint6
     m.dkey = rk; m.dacc = ra; m.dstride = dstride; m.flags = flags;
     {
         KernelTimer timer("agg_part_merge", s);
-        part_merge_kernel<<<(int)std::min<int64_t>(nlocal, (int64_t)device_info().num_cus * 4), PA_BLOCK, 0, s>>>(m);
+        int occ = 0;  // one resident set of workgroups, as in the final pass
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)part_merge_kernel, PA_BLOCK, 0) != hipSuccess || occ < 1) occ = 2;
+        part_merge_kernel<<<(int)std::min<int64_t>(nlocal, (int64_t)device_info().num_cus * occ), PA_BLOCK, 0, s>>>(m);
     }
     VNM_HIP(hipGetLastError());
     unsigned long long fl[2];
