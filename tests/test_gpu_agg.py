@@ -617,3 +617,53 @@ def test_few_groups_many_rows_key_copies(scenario):
         if out == "aa":   # sum / count in float64, as the reference computes it
             want = ref["sa"].to_numpy() / ref["n"].to_numpy()
         np.testing.assert_array_equal(col, want.astype(col.dtype), err_msg=f"{scenario}: {out}")
+
+
+@pytest.mark.parametrize("scenario", ["int32", "nullable_int64", "int16_nulls", "float32", "uint32_pred", "demote_on_later_batch",
+                                      "sliced_odd_offset", "unpackable_range", "hintless_large_batch"])
+def test_single_key_packed_for_the_partitioned_path(scenario):
+    """A single key that the fast paths do not take as it is (narrow type, NULLs, odd Arrow offset) is packed into a
+    plain 64-bit word when the group count is large or unknown, runs through the single-key machinery and is unpacked
+    at the end (the same PackParams as the multi-column case); identity rules as in the reference (NULL is a group)."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(len(scenario) * 7)
+    n, G = 500_000, 60_000
+    hint = G
+    pred = None
+    v = pa.array(rng.integers(0, 2**12, n).astype(np.float64) / 64.0)
+    x = pa.array(rng.integers(-5000, 5000, n).astype(np.int64), mask=rng.random(n) < 0.05)
+    if scenario == "int32":
+        k = pa.array(rng.integers(-G // 2, G // 2, n).astype(np.int32))
+    elif scenario == "nullable_int64":
+        k = pa.array(rng.integers(0, G, n).astype(np.int64) * 1_000_003, mask=rng.random(n) < 0.02)
+    elif scenario == "int16_nulls":
+        k = pa.array(rng.integers(-30000, 30000, n).astype(np.int16), mask=rng.random(n) < 0.01)
+    elif scenario == "float32":
+        k = pa.array((rng.integers(0, G, n) / 8.0).astype(np.float32))
+    elif scenario == "uint32_pred":
+        k = pa.array(rng.integers(0, G, n).astype(np.uint32) + np.uint32(4_000_000_000))
+        pred = ("v", ">", 20.0)
+    elif scenario == "demote_on_later_batch":   # the second batch leaves the range planned on the first
+        k = pa.array(np.concatenate([rng.integers(0, G, n // 2), rng.integers(0, G, n - n // 2) * 2**40]).astype(np.int64),
+                     mask=rng.random(n) < 0.02)
+    elif scenario == "sliced_odd_offset":
+        k = pa.array(rng.integers(0, G, n + 3).astype(np.int64)).slice(3)
+    elif scenario == "unpackable_range":        # spans the whole int64 range: stays on the general path
+        k = pa.array(rng.integers(-2**62, 2**62, n).astype(np.int64) * 2, mask=rng.random(n) < 0.02)
+    else:                                       # no hint, batch above the estimator threshold
+        n = 5_000_000
+        hint = 0
+        v = pa.array(rng.integers(0, 2**12, n).astype(np.float64) / 64.0)
+        x = pa.array(rng.integers(-5000, 5000, n).astype(np.int64), mask=rng.random(n) < 0.05)
+        k = pa.array(rng.integers(0, 300_000, n).astype(np.int32), mask=rng.random(n) < 0.02)
+    t = pa.table({"k": k, "v": v, "x": x})
+    funcs = [(O.SUM, "v", "sv"), (O.AVG, "v", "av"), (O.COUNT_STAR, "", "n"), (O.MIN, "x", "mn"), (O.MAX, "x", "mx"),
+             (O.COUNT, "x", "cx"), (O.SUM, "x", "sx")]
+    batches = util.sliced_batches(t, (n + 1) // 2) if scenario != "hintless_large_batch" else t.to_batches(max_chunksize=n)
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=pred, expected_groups=hint)
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in batches:
+        if pred:
+            b = O.filter_batch(b, O.cmp_mask(b.column(1), O.GT, 20.0))
+        o.next(b)
+    util.assert_agg_equal(got, o.result(), funcs, ["k"], what=scenario)

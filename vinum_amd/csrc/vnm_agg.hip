@@ -2799,8 +2799,14 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     }
     if (nrows >= (1LL << 31)) return set_error("vnm_agg_next_device: batches must be < 2^31 rows (as in the reference, agg_funcs.h:45)");
 
-    // multi-column keys: try the packed single-word form first (see PackParams)
-    if (!h->single && h->plan.n_keys >= 2) {
+    // multi-column keys: try the packed single-word form first (see PackParams).  A SINGLE key that the fast paths do
+    // not take as it is (int32 / int16 / float32 ..., NULLs, an odd Arrow offset) is packed the same way when the
+    // group count is large or unknown: one extra pass over the key column (12 B/row) buys the partitioned path instead
+    // of per-row HBM atomics (G = 1e6 int32 keys: 20x).
+    const bool key_plain = h->plan.n_keys == 1 && type_width(keys[0].type) == 8 && !keys[0].validity && (keys[0].offset & 1) == 0;
+    const bool pack_single = h->single && h->plan.n_keys == 1 && !key_plain &&
+                             (h->hint > 2400 || (h->hint == 0 && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22)));
+    if ((!h->single && h->plan.n_keys >= 2) || pack_single || (h->single && h->inner)) {
         for (int j = 0; j < h->plan.n_keys; j++)
             if (keys[j].type != h->plan.key_types[j]) return set_error("vnm_agg_next_device: key %d changed type between batches", j);
         if (!h->pack_tried && !h->have_table && getenv("VNM_AGG_NO_PACK") == nullptr) {
