@@ -2607,7 +2607,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     if (fl[0]) {  // more groups than hinted / spill buffer full: use the general path for this batch
         pool_free(rk); pool_free(ra); pool_free(dir); pool_free(spill);
         if (to_table) { table_free(&h->g); h->have_table = false; }  // drop the partial merge
-        return 2;
+        return 3;  // only the final pass fails this way: the hint was too small, more partitions would do
     }
     if (spill_out) {
         if (fl[2]) { *spill_out = spill; *n_spill_out = (int64_t)fl[2]; }
@@ -2970,6 +2970,18 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
         const bool can_spill = hot_scan && !hot_two && getenv("VNM_AGG_NO_SPILL") == nullptr;
         int prc = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
+        // more groups than hinted (a partition overflowed its LDS table, or the dense output its allocation): estimate
+        // the group count from the keys (< 1 ms) and partition again (~12 ms per attempt) before giving in to the HBM
+        // table (~300 ms per 1e9 rows)
+        for (int retry = 0; prc == 3 && retry < 2; retry++) {
+            int64_t est = 0;
+            if (retry == 0 && !h->estimated) {
+                VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s));
+                h->estimated = true;
+            }
+            h->hint = std::min<int64_t>(std::max<int64_t>(h->hint * 4, est + est / 4), (int64_t)1600 * env_i64("VNM_AGG_PART_L1_MAX", 256) * 512);
+            prc = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
+        }
         if (prc == 0 && !spill) { h->rows_seen += nrows; return 0; }
         if (prc == 1) return 1;
         if (prc == 0) {  // the scan below runs over the spilled entries only (predicate already applied)
