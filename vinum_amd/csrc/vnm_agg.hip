@@ -65,6 +65,7 @@ struct AggArgs {
     int hot_w[9];      // word of each AccKind, -1 = absent
     int hot_w2[9];     // ... for a second input column (agg_hot_kernel<TWO>)
     int hot_vtype2;
+    unsigned long long hot_wpack, hot_wpack2;  // the same tables, 6 bits per kind (63 = absent, COUNT(*) excluded): scalar registers
     int hot_vtype;     // VNM_F64 / VNM_I64 / VNM_U64
     int hot_has_val;
     const ulonglong2* ent;  // agg_hot_kernel<FROM_ENT>: (key, value bits) entries spilled by the partitioned path
@@ -576,26 +577,7 @@ __device__ __forceinline__ int hot_slot(uint64_t* lkey, int S, uint32_t smask, u
     return -1;
 }
 
-// the accumulator words of ONE input column (word table hw[kind], -1 = absent), for a value with raw bits vb
-__device__ __forceinline__ void hot_accumulate_col(const int* hw, int vtype, uint64_t* lacc, int stride, int slot, uint64_t vb) {
-#define VNM_W(K) (lacc + hw[K] * stride + slot)
-#define VNM_ADD(K, V) if (hw[K] >= 0) __hip_atomic_fetch_add(VNM_W(K), (uint64_t)(V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-    VNM_ADD(A_COUNT_ROWS, 1ULL);
-    VNM_ADD(A_COUNT_VALID, 1ULL);
-    if (hw[A_SUM_F64] >= 0)
-        __hip_atomic_fetch_add((double*)VNM_W(A_SUM_F64), __longlong_as_double((long long)vb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    VNM_ADD(A_SUM_I64, vb);
-    VNM_ADD(A_SUM_LO32, vb & 0xFFFFFFFFULL);
-    VNM_ADD(A_SUM_HI32S, (int64_t)vb >> 32);
-    VNM_ADD(A_SUM_HI32U, vb >> 32);
-    if (hw[A_MIN] >= 0 || hw[A_MAX] >= 0) {
-        const uint64_t e = vtype == VNM_F64 ? enc_f64(__longlong_as_double((long long)vb)) : (vtype == VNM_U64 ? vb : enc_i64((int64_t)vb));
-        if (hw[A_MIN] >= 0) __hip_atomic_fetch_min(VNM_W(A_MIN), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (hw[A_MAX] >= 0) __hip_atomic_fetch_max(VNM_W(A_MAX), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-#undef VNM_ADD
-#undef VNM_W
-}
+__device__ __forceinline__ void pa_accumulate_col(unsigned long long pack, int type, uint64_t* lw, int ST, int slot, uint64_t raw);
 
 // every accumulator word this query has, updated for a row whose input value has the raw bits vb
 // (SIMPLE: only COUNT(*), COUNT and the float64 sum can be present -- the north-star shape keeps its short path)
@@ -607,7 +589,8 @@ __device__ __forceinline__ void hot_accumulate(const AggArgs& a, uint64_t* lacc,
         if (a.hot_w_sum >= 0) __hip_atomic_fetch_add((double*)&lacc[a.hot_w_sum * stride + slot], __longlong_as_double((long long)vb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return;
     }
-    hot_accumulate_col(a.hot_w, a.hot_vtype, lacc, stride, slot, vb);
+    if (a.hot_w[A_COUNT_ROWS] >= 0) __hip_atomic_fetch_add(&lacc[a.hot_w[A_COUNT_ROWS] * stride + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    pa_accumulate_col(a.hot_wpack, a.hot_vtype, lacc, stride, slot, vb);
 }
 
 // one entry (key, value bits) straight into the HBM table: the saturated-key path of agg_hot_kernel<FROM_ENT>
@@ -709,7 +692,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                     int slot = hot_slot(lkey, S, smask, &s_fill, k.x, spread);
                     if (slot >= 0) {
                         hot_accumulate<SIMPLE>(a, lacc, stride, slot, v0);
-                        if (TWO) hot_accumulate_col(a.hot_w2, a.hot_vtype2, lacc, stride, slot, w0);
+                        if (TWO) pa_accumulate_col(a.hot_wpack2, a.hot_vtype2, lacc, stride, slot, w0);
                     } else if (FROM_ENT) hot_entry_to_table(a, k.x, v0, &s_new);  // no columns to re-read: merge right here
                     else sat0 |= 1u << u;
                 }
@@ -717,7 +700,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                     int slot = hot_slot(lkey, S, smask, &s_fill, k.y, spread);
                     if (slot >= 0) {
                         hot_accumulate<SIMPLE>(a, lacc, stride, slot, v1);
-                        if (TWO) hot_accumulate_col(a.hot_w2, a.hot_vtype2, lacc, stride, slot, w1);
+                        if (TWO) pa_accumulate_col(a.hot_wpack2, a.hot_vtype2, lacc, stride, slot, w1);
                     } else if (FROM_ENT) hot_entry_to_table(a, k.y, v1, &s_new);
                     else sat1 |= 1u << u;
                 }
@@ -737,7 +720,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                     int slot = hot_slot(lkey, S, smask, &s_fill, kb, spread);
                     if (slot >= 0) {
                         hot_accumulate<SIMPLE>(a, lacc, stride, slot, vb);
-                        if (TWO) hot_accumulate_col(a.hot_w2, a.hot_vtype2, lacc, stride, slot, vp2[r]);
+                        if (TWO) pa_accumulate_col(a.hot_wpack2, a.hot_vtype2, lacc, stride, slot, vp2[r]);
                     }
                     else if (FROM_ENT) hot_entry_to_table(a, kb, vb, &s_new);
                     else if (e == 0) sat0 |= 1u << u;
@@ -2913,6 +2896,11 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
             else if (op.kind == A_SUM_F64) a.hot_w_sum = op.word;
             else hot = false;
         }
+    }
+    a.hot_wpack = a.hot_wpack2 = ~0ULL;
+    for (int k = A_COUNT_VALID; k <= A_MAX; k++) {
+        if (a.hot_w[k] >= 0) a.hot_wpack = (a.hot_wpack & ~(63ULL << (6 * k))) | ((unsigned long long)a.hot_w[k] << (6 * k));
+        if (a.hot_w2[k] >= 0) a.hot_wpack2 = (a.hot_wpack2 & ~(63ULL << (6 * k))) | ((unsigned long long)a.hot_w2[k] << (6 * k));
     }
     hot = hot && hot_scan;
     if (hot_scan && h->pred_set) {
