@@ -667,3 +667,40 @@ def test_single_key_packed_for_the_partitioned_path(scenario):
             b = O.filter_batch(b, O.cmp_mask(b.column(1), O.GT, 20.0))
         o.next(b)
     util.assert_agg_equal(got, o.result(), funcs, ["k"], what=scenario)
+
+
+@pytest.mark.parametrize("vtype", ["float64", "int64", "uint64", "count_only", "nullable_falls_back"])
+@pytest.mark.parametrize("pred", ["none", "on_input", "on_other"])
+def test_one_group_register_kernel(vtype, pred):
+    """No GROUP BY (OneGroupAggregate, one_group_aggregate.cpp): every accumulator kind in registers over one plain
+    8-byte column (agg_onegroup_hot_kernel), odd row counts, predicate on the input or on another float64 column;
+    a nullable input takes the generic kernel.  Quantised floats: sums are exact, so everything is bit-exact."""
+    from oracle import oracle as O
+    if pred == "on_input" and vtype != "float64":
+        pytest.skip("the fused predicate is a float64 comparison")
+    rng = np.random.default_rng(len(vtype) * 3 + len(pred))
+    n = 3_000_001
+    p = pa.array(rng.integers(0, 2**12, n).astype(np.float64) / 64.0)
+    if vtype == "float64":
+        v = pa.array(rng.integers(-2**13, 2**13, n).astype(np.float64) / 128.0)
+    elif vtype == "uint64":
+        v = pa.array(rng.integers(0, 2**64 - 1, n, dtype=np.uint64))          # sums need the 128-bit lanes
+    elif vtype == "nullable_falls_back":
+        v = pa.array(rng.integers(-2**40, 2**40, n).astype(np.int64), mask=rng.random(n) < 0.1)
+    else:
+        v = pa.array(rng.integers(-2**62, 2**62, n).astype(np.int64))
+    t = pa.table({"v": v, "p": p})
+    if vtype == "count_only":
+        funcs = [(O.COUNT_STAR, "", "n")]
+    else:
+        funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.MIN, "v", "lo"), (O.MAX, "v", "hi"), (O.COUNT, "v", "c"), (O.COUNT_STAR, "", "n")]
+    pcol = {"none": None, "on_input": "v", "on_other": "p"}[pred]
+    thr = 0.0 if pred == "on_input" else 20.0
+    batches = util.sliced_batches(t, 2_000_000)
+    got = gpu_aggregate(O.ONE_GROUP, [], [], funcs, batches, predicate=(pcol, ">", thr) if pcol else None)
+    o = O.OracleAggregate(O.ONE_GROUP, [], [], funcs)
+    for b in batches:
+        if pcol:
+            b = O.filter_batch(b, O.cmp_mask(b.column(t.schema.names.index(pcol)), O.GT, thr))
+        o.next(b)
+    util.assert_agg_equal(got, o.result(), funcs, [], what=f"one group {vtype} pred={pred}")

@@ -871,6 +871,96 @@ __global__ __launch_bounds__(OG_BLOCK) void agg_onegroup_kernel(AggArgs a) {
     }
 }
 
+// No GROUP BY over at most one 8-byte column without NULLs (float64 predicate column or none): every accumulator kind
+// is kept in registers for every row (a few VALU ops each, far below the load time) and the plan only decides which of
+// them are written at the end -- no per-op dispatch, 16-byte loads, four pairs in flight per lane.
+// VT: VNM_F64 / VNM_I64 / VNM_U64, or -1 = no input column (COUNT(*) only).  PM: 0 no predicate, 1 the predicate column
+// is the input column, 2 a separate float64 predicate column.
+template <int VT, int PM>
+__global__ __launch_bounds__(OG_BLOCK) void agg_onegroup_hot_kernel(AggArgs a) {
+    __shared__ uint64_t part[OG_BLOCK / 64][8];
+    const int tid = threadIdx.x;
+    const ulonglong2* vp = VT >= 0 ? (const ulonglong2*)((const uint64_t*)a.cols[0].values + a.cols[0].offset) : nullptr;
+    const double2* pp = PM == 2 ? (const double2*)((const double*)a.pred.values + a.pred.offset) : nullptr;
+    const int op = a.p.op;
+    const double thr = a.p.dval;
+    double sf = 0.0;
+    uint64_t si = 0, slo = 0, shis = 0, shiu = 0, cnt = 0, mn = ~0ULL, mx = 0;
+    auto take = [&](uint64_t vb, double pv) {
+        const double f = VT == VNM_F64 ? __longlong_as_double((long long)vb) : (VT == VNM_U64 ? (double)vb : (double)(int64_t)vb);
+        if (PM != 0 && !cmp_apply<double>(op, PM == 1 ? f : pv, thr)) return;
+        cnt++;
+        if (VT < 0) return;
+        sf += f;
+        if (VT != VNM_F64) {
+            si += vb;
+            slo += vb & 0xFFFFFFFFULL;
+            shis += (uint64_t)((int64_t)vb >> 32);
+            shiu += vb >> 32;
+        }
+        const uint64_t e = VT == VNM_F64 ? enc_f64(f) : (VT == VNM_U64 ? vb : enc_i64((int64_t)vb));
+        mn = e < mn ? e : mn;
+        mx = e > mx ? e : mx;
+    };
+    constexpr int U = 4;
+    const int64_t npairs = a.nrows >> 1;
+    const int64_t stride = (int64_t)gridDim.x * OG_BLOCK;
+    for (int64_t base = (int64_t)blockIdx.x * OG_BLOCK + tid; base < npairs; base += stride * U) {
+        ulonglong2 v[U];
+        double2 p[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t i = base + (int64_t)u * stride;
+            v[u] = make_ulonglong2(0, 0);
+            p[u] = make_double2(0.0, 0.0);
+            if (i < npairs) {
+                if (VT >= 0) v[u] = vp[i];
+                if (PM == 2) p[u] = pp[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (base + (int64_t)u * stride < npairs) { take(v[u].x, p[u].x); take(v[u].y, p[u].y); }
+        }
+    }
+    if ((a.nrows & 1) && blockIdx.x == 0 && tid == 0) {  // the odd last row
+        const int64_t r = a.nrows - 1;
+        take(VT >= 0 ? ((const uint64_t*)vp)[r] : 0, PM == 2 ? ((const double*)pp)[r] : 0.0);
+    }
+    // wave reduction, then one merge per needed word and workgroup
+    uint64_t w8[8] = {(uint64_t)__double_as_longlong(sf), si, slo, shis, shiu, cnt, mn, mx};
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double of = __shfl_xor(__longlong_as_double((long long)w8[0]), o);
+        w8[0] = (uint64_t)__double_as_longlong(__longlong_as_double((long long)w8[0]) + of);
+#pragma unroll
+        for (int k = 1; k < 6; k++) w8[k] += __shfl_xor(w8[k], o);
+        const uint64_t omn = __shfl_xor(w8[6], o), omx = __shfl_xor(w8[7], o);
+        w8[6] = omn < w8[6] ? omn : w8[6];
+        w8[7] = omx > w8[7] ? omx : w8[7];
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) part[tid >> 6][k] = w8[k];
+    }
+    __syncthreads();
+    if (tid <= A_MAX && a.hot_w[tid] >= 0) {
+        // AccKind -> register: COUNT(*) and COUNT both see `cnt` (no NULLs on this path)
+        const int src = tid == A_COUNT_ROWS || tid == A_COUNT_VALID ? 5 : (tid == A_SUM_F64 ? 0 : (tid == A_MIN ? 6 : (tid == A_MAX ? 7 : tid - A_SUM_I64 + 1)));
+        uint64_t v = part[0][src];
+        for (int wv = 1; wv < OG_BLOCK / 64; wv++) {
+            const uint64_t o = part[wv][src];
+            if (src == 0) v = (uint64_t)__double_as_longlong(__longlong_as_double((long long)v) + __longlong_as_double((long long)o));
+            else if (src == 6) v = o < v ? o : v;
+            else if (src == 7) v = o > v ? o : v;
+            else v += o;
+        }
+        const int w = a.hot_w[tid];
+        const int mk = a.plan.merge[w];
+        if (v != merge_init(mk) || mk == M_ADD_F64) g_merge(&a.g.acc[(uint64_t)w * a.g.stride], mk, v);
+    }
+}
+
 // =======================================================================================================
 // Merge dense partial groups (another rank's run, or the old table during growth) into the table.
 // src_tag != NULL: source is a table (skip EMPTY / use tag as key).  Otherwise dense run: key words
@@ -2857,6 +2947,36 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         int64_t need = (nrows + OG_BLOCK - 1) / OG_BLOCK;
         if (grid > need) grid = (int)need;
         KernelTimer timer("agg_scan", s);
+        // every kind at most once over at most one plain 8-byte column, float64 predicate or none: the register kernel
+        bool og_hot = h->plan.n_cols <= 1 && getenv("VNM_AGG_NO_HOT") == nullptr;
+        int vt = -1;
+        if (og_hot && h->plan.n_cols == 1) {
+            const vnm_dcol& c = a.cols[0];
+            og_hot = (c.type == VNM_F64 || c.type == VNM_I64 || c.type == VNM_U64) && !c.validity && (c.offset & 1) == 0;
+            vt = c.type;
+        }
+        for (int k = 0; k < 9; k++) a.hot_w[k] = -1;
+        for (int o = 0; o < h->plan.n_ops && og_hot; o++) {
+            const AccOp& op = h->plan.ops[o];
+            if (op.kind < 0 || op.kind > A_MAX || a.hot_w[op.kind] >= 0 || (op.kind != A_COUNT_ROWS && vt < 0)) og_hot = false;
+            else a.hot_w[op.kind] = op.word;
+        }
+        int pm = 0;
+        if (og_hot && h->pred_set) {
+            og_hot = a.pred.type == VNM_F64 && !a.pred.validity && (a.pred.offset & 1) == 0 && a.p.mode == CMP_F64;
+            pm = og_hot && vt == VNM_F64 && a.pred.values == a.cols[0].values && a.pred.offset == a.cols[0].offset ? 1 : 2;
+        }
+        if (og_hot) {
+            const int g2 = (int)std::min<int64_t>((int64_t)cus * 8, std::max<int64_t>(1, (nrows / 2 + OG_BLOCK - 1) / OG_BLOCK));
+#define VNM_OG(VT_)                                                                                                 \
+    do {                                                                                                            \
+        if (pm == 0) agg_onegroup_hot_kernel<VT_, 0><<<g2, OG_BLOCK, 0, s>>>(a);                                    \
+        else if (pm == 1) agg_onegroup_hot_kernel<VT_, 1><<<g2, OG_BLOCK, 0, s>>>(a);                               \
+        else agg_onegroup_hot_kernel<VT_, 2><<<g2, OG_BLOCK, 0, s>>>(a);                                            \
+    } while (0)
+            if (vt == VNM_F64) VNM_OG(VNM_F64); else if (vt == VNM_I64) VNM_OG(VNM_I64); else if (vt == VNM_U64) VNM_OG(VNM_U64); else VNM_OG(-1);
+#undef VNM_OG
+        } else
         agg_onegroup_kernel<<<grid, OG_BLOCK, (size_t)h->plan.n_words * OG_BLOCK * 8, s>>>(a);
         VNM_HIP(hipGetLastError());
         h->rows_seen += nrows;
