@@ -1524,6 +1524,7 @@ struct PartAggArgs {
     // kernel-argument loads (and their lgkmcnt waits) inside the entry loop.
     unsigned long long wpack[3];
     int w_rows_g, use_table, nval;
+    int slots;  // LDS table size of part_agg_generic_kernel
 };
 
 // Find-or-claim the slot of `key` in a final-pass LDS table (PA_SLOTS keys).  The pass is bound by the number of
@@ -1737,12 +1738,13 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
     __shared__ uint32_t s_n, s_fail;
     __shared__ unsigned s_new;
     __shared__ unsigned long long s_base;
-    constexpr int ST = PA_SLOTS + 1;
+    const int SL = a.slots;  // 2048, or 1024 for programs with many accumulator words (LDS per workgroup decides how many are resident)
+    const int ST = SL + 1;
     uint64_t* lkey = pa_lds;
     uint64_t* lw = pa_lds + ST;
     const int W = a.n_words;
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t smask = PA_SLOTS - 1;
+    const uint32_t smask = (uint32_t)SL - 1;
     if (tid == 0) s_new = 0;
     for (int64_t unit = blockIdx.x; unit < a.nfinal * a.splits; unit += gridDim.x) {
         const int64_t f = unit / a.splits;
@@ -1778,7 +1780,7 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
                     if (i >= n) continue;
                     const uint64_t key = eb[u][0];
                     int slot;
-                    if (key == EMPTY) { slot = PA_SLOTS; lkey[slot] = 0; }
+                    if (key == EMPTY) { slot = SL; lkey[slot] = 0; }
                     else {
                         slot = pa_find_slot(lkey, smask, key, &ins, &s_fail);
                         if (slot < 0) s_fail = 1;
@@ -1829,7 +1831,7 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
                 uint64_t k = lkey[i];
                 if (k == EMPTY) continue;
                 uint64_t slot;
-                if (i < PA_SLOTS) slot = gt_find_single(a.g, k, &s_new);
+                if (i < SL) slot = gt_find_single(a.g, k, &s_new);
                 else { slot = a.g.cap; if (ld_agent(&a.g.tag[slot]) == EMPTY) st_agent(&a.g.tag[slot], 0); }
                 for (int w = 0; w < W; w++) {
                     uint64_t v = lw[w * ST + i];
@@ -1840,7 +1842,7 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
             if (tid == 0) fold_new(a.g, &s_new);
             continue;
         }
-        const uint32_t ngroups = s_n + (lkey[PA_SLOTS] != EMPTY ? 1u : 0u);
+        const uint32_t ngroups = s_n + (lkey[SL] != EMPTY ? 1u : 0u);
         __syncthreads();
         if (tid == 0) {
             s_base = atomicAdd(&a.flags[1], (unsigned long long)ngroups);
@@ -1862,7 +1864,7 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
             if (occ) {
                 uint64_t lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
                 int64_t pos = (int64_t)s_base + wbase + __popcll(b & lt);
-                a.dkey[pos] = i == PA_SLOTS ? EMPTY : lkey[i];
+                a.dkey[pos] = i == SL ? EMPTY : lkey[i];
                 a.dkey[a.dstride + pos] = 0;
                 for (int w = 0; w < W; w++) a.dacc[(int64_t)w * a.dstride + pos] = lw[w * ST + i];
             }
@@ -2467,7 +2469,14 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     // final partitions sized for ~900 groups each: enough keys per partition that their sizes concentrate
     // (few keys per partition -> Poisson imbalance overflows the fixed-capacity regions), few enough for
     // the 2048-slot LDS table of pass 3
-    const int64_t per_final = env_i64("VNM_AGG_PART_GROUPS", 900);
+    // Generic programs with three or more accumulator words: a 2048-slot table is 65+ KB, i.e. one or two resident
+    // workgroups per CU in a latency-bound pass (5 words, G=1e5: 10 ms).  They get 1024-slot tables and half the groups
+    // per partition while two levels still provide enough partitions.
+    const int64_t l1_cap = env_i64("VNM_AGG_PART_L1_MAX", 256) * 512;
+    const bool small_tables = a.part_generic && (size_t)(PA_SLOTS + 1) * 8 * (1 + h->plan.n_words) > 54 * 1024 &&
+                              h->hint / 450 < l1_cap && getenv("VNM_AGG_NO_SMALL_TABLES") == nullptr;
+    const int pa_slots = small_tables ? PA_SLOTS / 2 : PA_SLOTS;
+    const int64_t per_final = env_i64("VNM_AGG_PART_GROUPS", small_tables ? 450 : 900);
     int64_t nfin = 2;
     while (nfin * per_final < h->hint) nfin *= 2;
     const int64_t l1_max = env_i64("VNM_AGG_PART_L1_MAX", 256);
@@ -2642,7 +2651,8 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
             pa.vtype = a.part_vtype;
             for (int o = 0; o < h->plan.n_ops; o++) pa.ops[o] = h->plan.ops[o];
             for (int w = 0; w < h->plan.n_words; w++) pa.merge[w] = h->plan.merge[w];
-            const size_t lds_bytes = (size_t)(PA_SLOTS + 1) * 8 * (1 + h->plan.n_words);
+            const size_t lds_bytes = (size_t)(pa_slots + 1) * 8 * (1 + h->plan.n_words);
+            pa.slots = pa_slots;
             pa.ent_words = E;
             pa.wide = wide;
             pa.has_vmask = a.part_vmask;
