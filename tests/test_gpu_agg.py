@@ -704,3 +704,35 @@ def test_one_group_register_kernel(vtype, pred):
             b = O.filter_batch(b, O.cmp_mask(b.column(t.schema.names.index(pcol)), O.GT, thr))
         o.next(b)
     util.assert_agg_equal(got, o.result(), funcs, [], what=f"one group {vtype} pred={pred}")
+
+
+@pytest.mark.parametrize("vtype", ["float64", "int64"])
+@pytest.mark.parametrize("pred", ["none", "gt_on_input", "ne_on_input", "gt_on_other"])
+@pytest.mark.parametrize("groups", [3, 900])
+def test_scan_kernel_nullable_input(vtype, pred, groups):
+    """One nullable 8-byte input column through agg_hot_kernel<VNULL>: a NULL input only counts for COUNT(*); a NULL in
+    the predicate column compares like NaN (`!=` is true, everything else false), as the reference's NumPy
+    comparison sees it.  Several tiles per workgroup (register rotation, key copies for 3 groups)."""
+    from oracle import oracle as O
+    if pred.endswith("on_input") and vtype != "float64":
+        pytest.skip("the fused predicate is a float64 comparison")
+    rng = np.random.default_rng(groups + len(pred) + len(vtype))
+    n = 5_000_001
+    k = pa.array(rng.integers(0, groups, n).astype(np.int64) * 977 - 5)
+    mask = rng.random(n) < 0.15
+    if vtype == "float64":
+        v = pa.array(rng.integers(-2**13, 2**13, n).astype(np.float64) / 128.0, mask=mask)
+    else:
+        v = pa.array(rng.integers(-2**50, 2**50, n).astype(np.int64), mask=mask)
+    p = pa.array(rng.integers(0, 2**12, n).astype(np.float64) / 64.0)
+    t = pa.table({"k": k, "v": v, "p": p})
+    funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.MIN, "v", "lo"), (O.MAX, "v", "hi"), (O.COUNT, "v", "c"), (O.COUNT_STAR, "", "n")]
+    spec = {"none": None, "gt_on_input": ("v", ">", 1.5, O.GT), "ne_on_input": ("v", "!=", 1.5, O.NE), "gt_on_other": ("p", ">", 20.0, O.GT)}[pred]
+    batches = util.sliced_batches(t, 3_000_000)   # even batch offsets: the 16-byte pair loads apply
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=spec[:3] if spec else None, expected_groups=groups)
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in batches:
+        if spec:
+            b = O.filter_batch(b, O.cmp_mask(b.column(t.schema.names.index(spec[0])), spec[3], spec[2]))
+        o.next(b)
+    util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"nullable {vtype} pred={pred} G={groups}")

@@ -582,7 +582,7 @@ __device__ __forceinline__ void pa_accumulate_col(unsigned long long pack, int t
 // every accumulator word this query has, updated for a row whose input value has the raw bits vb
 // (SIMPLE: only COUNT(*), COUNT and the float64 sum can be present -- the north-star shape keeps its short path)
 template <bool SIMPLE>
-__device__ __forceinline__ void hot_accumulate(const AggArgs& a, uint64_t* lacc, int stride, int slot, uint64_t vb) {
+__device__ __forceinline__ void hot_accumulate(const AggArgs& a, uint64_t* lacc, int stride, int slot, uint64_t vb, bool valid = true) {
     if (SIMPLE) {
         if (a.hot_w_rows >= 0) __hip_atomic_fetch_add(&lacc[a.hot_w_rows * stride + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (a.hot_w_valid >= 0) __hip_atomic_fetch_add(&lacc[a.hot_w_valid * stride + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -590,7 +590,7 @@ __device__ __forceinline__ void hot_accumulate(const AggArgs& a, uint64_t* lacc,
         return;
     }
     if (a.hot_w[A_COUNT_ROWS] >= 0) __hip_atomic_fetch_add(&lacc[a.hot_w[A_COUNT_ROWS] * stride + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    pa_accumulate_col(a.hot_wpack, a.hot_vtype, lacc, stride, slot, vb);
+    if (valid) pa_accumulate_col(a.hot_wpack, a.hot_vtype, lacc, stride, slot, vb);  // a NULL input only counts for COUNT(*)
 }
 
 // one entry (key, value bits) straight into the HBM table: the saturated-key path of agg_hot_kernel<FROM_ENT>
@@ -609,7 +609,9 @@ __device__ __forceinline__ void hot_entry_to_table(const AggArgs& a, uint64_t ke
 // FROM_ENT: the rows are (key, value bits) entries (a.ent) instead of columns -- what the partitioned path spills when a
 // region is full (heavy keys); no predicate (already applied).
 // TWO: a second 8-byte input column (its accumulator words in hot_w2).
-template <bool HAS_PRED, bool PRED_IS_V, bool HAS_VAL, bool SIMPLE, bool FROM_ENT = false, bool TWO = false>
+// VNULL: the input column has a validity bitmap (one byte per lane and chunk: both rows of a pair share it); a NULL
+// fails a predicate on that column and otherwise only counts for COUNT(*).
+template <bool HAS_PRED, bool PRED_IS_V, bool HAS_VAL, bool SIMPLE, bool FROM_ENT = false, bool TWO = false, bool VNULL = false>
 __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
     extern __shared__ uint64_t lds[];
     __shared__ unsigned s_fill, s_new;
@@ -639,6 +641,9 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
     const double thr = a.p.dval;
 
     ulonglong2 kk[HOT_UNROLL], vv[HOT_UNROLL], vw[HOT_UNROLL];  // this block's current (then next) tile, see below
+    uint32_t vm[HOT_UNROLL];  // VNULL: validity bits of the pair (bit 0 / 1)
+    const uint8_t* vbm = VNULL ? a.cols[0].validity : nullptr;
+    const int64_t voff = VNULL ? a.cols[0].offset : 0;
     double2 pv[HOT_UNROLL];
     bool have = false;
     uint32_t spread = 0;
@@ -670,6 +675,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
         } else {                                                                                               \
             kk[u] = *(const ulonglong2*)(kp + r_);                                                             \
             if (HAS_VAL) vv[u] = *(const ulonglong2*)(vp + r_);                                                \
+            if (VNULL) vm[u] = (uint32_t)vbm[(voff + r_) >> 3] >> ((voff + r_) & 7);                           \
             if (TWO) vw[u] = *(const ulonglong2*)(vp2 + r_);                                                   \
             if (HAS_PRED && !PRED_IS_V) pv[u] = *(const double2*)(pp + r_);                                    \
         }                                                                                                      \
@@ -685,13 +691,15 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                 const ulonglong2 k = kk[u];
                 const uint64_t v0 = HAS_VAL ? vv[u].x : 0, v1 = HAS_VAL ? vv[u].y : 0;
                 const uint64_t w0 = TWO ? vw[u].x : 0, w1 = TWO ? vw[u].y : 0;
-                const double p0 = PRED_IS_V ? __longlong_as_double((long long)v0) : pv[u].x;
-                const double p1 = PRED_IS_V ? __longlong_as_double((long long)v1) : pv[u].y;
+                const bool ok0 = !VNULL || (vm[u] & 1u), ok1 = !VNULL || (vm[u] & 2u);
+                // a NULL predicate value compares like NaN (pred_eval: the reference sees NumPy NaNs there)
+                const double p0 = PRED_IS_V ? (ok0 ? __longlong_as_double((long long)v0) : __builtin_nan("")) : pv[u].x;
+                const double p1 = PRED_IS_V ? (ok1 ? __longlong_as_double((long long)v1) : __builtin_nan("")) : pv[u].y;
                 if (nfull) VNM_HOT_LOAD(u, nbase);
                 if (!HAS_PRED || cmp_apply<double>(op, p0, thr)) {
                     int slot = hot_slot(lkey, S, smask, &s_fill, k.x, spread);
                     if (slot >= 0) {
-                        hot_accumulate<SIMPLE>(a, lacc, stride, slot, v0);
+                        hot_accumulate<SIMPLE>(a, lacc, stride, slot, v0, ok0);
                         if (TWO) pa_accumulate_col(a.hot_wpack2, a.hot_vtype2, lacc, stride, slot, w0);
                     } else if (FROM_ENT) hot_entry_to_table(a, k.x, v0, &s_new);  // no columns to re-read: merge right here
                     else sat0 |= 1u << u;
@@ -699,7 +707,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                 if (!HAS_PRED || cmp_apply<double>(op, p1, thr)) {
                     int slot = hot_slot(lkey, S, smask, &s_fill, k.y, spread);
                     if (slot >= 0) {
-                        hot_accumulate<SIMPLE>(a, lacc, stride, slot, v1);
+                        hot_accumulate<SIMPLE>(a, lacc, stride, slot, v1, ok1);
                         if (TWO) pa_accumulate_col(a.hot_wpack2, a.hot_vtype2, lacc, stride, slot, w1);
                     } else if (FROM_ENT) hot_entry_to_table(a, k.y, v1, &s_new);
                     else sat1 |= 1u << u;
@@ -715,11 +723,12 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                     if (r >= a.nrows) continue;
                     const uint64_t vb = FROM_ENT ? a.ent[r].y : (HAS_VAL ? vp[r] : 0);
                     const uint64_t kb = FROM_ENT ? a.ent[r].x : kp[r];
-                    const double p = PRED_IS_V ? __longlong_as_double((long long)vb) : (HAS_PRED ? pp[r] : 0.0);
+                    const bool ok = !VNULL || ((vbm[(voff + r) >> 3] >> ((voff + r) & 7)) & 1);
+                    const double p = PRED_IS_V ? (ok ? __longlong_as_double((long long)vb) : __builtin_nan("")) : (HAS_PRED ? pp[r] : 0.0);
                     if (HAS_PRED && !cmp_apply<double>(op, p, thr)) continue;
                     int slot = hot_slot(lkey, S, smask, &s_fill, kb, spread);
                     if (slot >= 0) {
-                        hot_accumulate<SIMPLE>(a, lacc, stride, slot, vb);
+                        hot_accumulate<SIMPLE>(a, lacc, stride, slot, vb, ok);
                         if (TWO) pa_accumulate_col(a.hot_wpack2, a.hot_vtype2, lacc, stride, slot, vp2[r]);
                     }
                     else if (FROM_ENT) hot_entry_to_table(a, kb, vb, &s_new);
@@ -3003,15 +3012,17 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
                     (keys[0].offset & 1) == 0 && getenv("VNM_AGG_NO_HOT") == nullptr;
     a.hot_has_val = h->plan.n_cols >= 1;
     a.hot_vtype = a.hot_vtype2 = VNM_U64;
+    bool hot_vnull = false;  // ONE nullable input column: agg_hot_kernel<VNULL>
     for (int c = 0; c < h->plan.n_cols && hot_scan; c++) {
         const vnm_dcol& col = a.cols[c];
-        hot_scan = (col.type == VNM_F64 || col.type == VNM_I64 || col.type == VNM_U64) && !col.validity && (col.offset & 1) == 0;
+        if (col.validity && h->plan.n_cols == 1) hot_vnull = true;
+        hot_scan = (col.type == VNM_F64 || col.type == VNM_I64 || col.type == VNM_U64) && (!col.validity || hot_vnull) && (col.offset & 1) == 0;
         (c == 0 ? a.hot_vtype : a.hot_vtype2) = col.type;
     }
     const bool hot_two = hot_scan && h->plan.n_cols == 2;
     a.hot_w_rows = a.hot_w_valid = a.hot_w_sum = -1;
     for (int k = 0; k < 9; k++) a.hot_w[k] = a.hot_w2[k] = -1;
-    bool hot = hot_scan && h->plan.n_cols == 1 && a.hot_vtype == VNM_F64;
+    bool hot = hot_scan && h->plan.n_cols == 1 && a.hot_vtype == VNM_F64 && !hot_vnull;
     if (hot_scan) {
         for (int o = 0; o < h->plan.n_ops; o++) {
             const AccOp& op = h->plan.ops[o];
@@ -3034,9 +3045,10 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     }
     hot = hot && hot_scan;
     if (hot_scan && h->pred_set) {
-        hot_scan = a.pred.type == VNM_F64 && !a.pred.validity && (a.pred.offset & 1) == 0 && a.p.mode == CMP_F64;
-        hot = hot && hot_scan;
         a.hot_pred_is_v = a.hot_has_val && a.hot_vtype == VNM_F64 && a.pred.values == a.cols[0].values && a.pred.offset == a.cols[0].offset;
+        // a nullable predicate column only as the (nullable) input column itself
+        hot_scan = a.pred.type == VNM_F64 && (!a.pred.validity || (hot_vnull && a.hot_pred_is_v)) && (a.pred.offset & 1) == 0 && a.p.mode == CMP_F64;
+        hot = hot && hot_scan;
     }
     // the partitioned path also takes ANY accumulator program over at most one 8-byte input column: its entries
     // carry (key, raw value bits) and only the final pass interprets them
@@ -3086,7 +3098,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     int64_t n_spill = 0;
     if (part_ok && h->hint > part_min && getenv("VNM_AGG_NO_PART") == nullptr) {
         if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
-        const bool can_spill = hot_scan && !hot_two && getenv("VNM_AGG_NO_SPILL") == nullptr;
+        const bool can_spill = hot_scan && !hot_two && !hot_vnull && getenv("VNM_AGG_NO_SPILL") == nullptr;
         int prc = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
         // more groups than hinted (a partition overflowed its LDS table, or the dense output its allocation): estimate
         // the group count from the keys (< 1 ms) and partition again (~12 ms per attempt) before giving in to the HBM
@@ -3146,6 +3158,16 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
                 if (!h->pred_set) VNM_HOT(false, false, true, true);
                 else if (a.hot_pred_is_v) VNM_HOT(true, true, true, true);
                 else VNM_HOT(true, false, true, true);
+            } else if (hot_vnull) {
+#define VNM_HOTN(P, V)                                                                                          \
+    do {                                                                                                       \
+        VNM_HIP(hipFuncSetAttribute((const void*)agg_hot_kernel<P, V, true, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        agg_hot_kernel<P, V, true, false, false, false, true><<<grid, AGG_BLOCK, lds_bytes, s>>>(a);           \
+    } while (0)
+                if (!h->pred_set) VNM_HOTN(false, false);
+                else if (a.hot_pred_is_v) VNM_HOTN(true, true);
+                else VNM_HOTN(true, false);
+#undef VNM_HOTN
             } else if (hot_two && hot_scan) {
 #define VNM_HOT2(P, V)                                                                                          \
     do {                                                                                                       \
