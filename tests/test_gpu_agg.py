@@ -300,7 +300,7 @@ def test_partitioned_path_nulls_and_narrow_types(case, levels, monkeypatch):
         util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"wide entries {case} L={levels}")
 
 
-@pytest.mark.parametrize("shape", ["sum_avg", "min_max_int"])
+@pytest.mark.parametrize("shape", ["sum_avg", "min_max_int", "count_only"])
 @pytest.mark.parametrize("spill", [True, False])
 def test_partitioned_path_skewed_keys(shape, spill, monkeypatch):
     """Power-law keys: a few keys own most rows, so their partition regions fill up in the first scatter pass.
@@ -319,6 +319,9 @@ def test_partitioned_path_skewed_keys(shape, spill, monkeypatch):
     if shape == "sum_avg":
         t = pa.table({"k": pa.array(k), "v": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0)})
         funcs = [(O.SUM, "v", "sum_v"), (O.AVG, "v", "avg_v"), (O.COUNT_STAR, "", "n")]
+    elif shape == "count_only":   # key-only (8-byte) entries overflow a region, the operator goes back to 16-byte entries + spill
+        t = pa.table({"k": pa.array(k)})
+        funcs = [(O.COUNT_STAR, "", "n")]
     else:
         t = pa.table({"k": pa.array(k), "v": pa.array(rng.integers(-2**40, 2**40, n).astype(np.int64))})
         funcs = [(O.MIN, "v", "lo"), (O.MAX, "v", "hi"), (O.SUM, "v", "s"), (O.COUNT, "v", "c")]

@@ -1808,7 +1808,7 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
                             const int w = a.ops[o].word;
                             const int c = E == 2 ? 0 : (a.ops[o].col < 0 ? 0 : a.ops[o].col);
                             if (E > 2 && a.ops[o].kind != A_COUNT_ROWS && !((vmask >> c) & 1ULL)) continue;  // NULL input
-                            uint64_t vb = eb[u][1];
+                            uint64_t vb = E >= 2 ? eb[u][E >= 2 ? 1 : 0] : 0;
 #pragma unroll
                             for (int e = 2; e < E; e++) if (c == e - 1) vb = eb[u][e];
                             const uint64_t v = a.wide ? op_value_raw(a.ops[o].kind, a.vtypes[c], vb)  // any numeric type
@@ -2288,6 +2288,7 @@ struct vnm_agg {
     // packed composite keys (multi-column GROUP BY through the single-key machinery)
     vnm_agg* inner = nullptr;
     bool pack_tried = false;
+    bool key_only_failed = false;  // COUNT(*)-only programs: 8-byte entries overflowed a region once (skewed keys)
     PackParams pack{};
     int c_funcs[AGG_MAX_FUNCS], c_in_types[AGG_MAX_FUNCS], c_in_flags[AGG_MAX_FUNCS], c_in_col_ids[AGG_MAX_FUNCS];
     bool c_has_ids = false;
@@ -2545,7 +2546,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         VNM_HIP(hipFuncSetAttribute((const void*)part_scatter_wide_kernel<FR, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         part_scatter_wide_kernel<FR, E_><<<GRID, PT_BLOCK, lds, s>>>(ARGS);                                          \
     } while (0)
-            if (E == 2) VNM_PSW(true, 2, grid1, p1); else if (E == 3) VNM_PSW(true, 3, grid1, p1); else VNM_PSW(true, 4, grid1, p1);
+            if (E == 1) VNM_PSW(true, 1, grid1, p1); else if (E == 2) VNM_PSW(true, 2, grid1, p1); else if (E == 3) VNM_PSW(true, 3, grid1, p1); else VNM_PSW(true, 4, grid1, p1);
         }
     }
     VNM_HIP(hipGetLastError());
@@ -2592,7 +2593,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
             else {
                 const size_t lds = (size_t)PW_TILE * ebytes;
                 const int g2 = np1 * p2.in_split;
-                if (E == 2) VNM_PSW(false, 2, g2, p2); else if (E == 3) VNM_PSW(false, 3, g2, p2); else VNM_PSW(false, 4, g2, p2);
+                if (E == 1) VNM_PSW(false, 1, g2, p2); else if (E == 2) VNM_PSW(false, 2, g2, p2); else if (E == 3) VNM_PSW(false, 3, g2, p2); else VNM_PSW(false, 4, g2, p2);
             }
         }
 #undef VNM_PSW
@@ -2683,8 +2684,8 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         fit_grid((const void*)part_agg_generic_kernel<E_, T_>, lds_bytes);                                           \
         part_agg_generic_kernel<E_, T_><<<g3, PA_BLOCK, lds_bytes, s>>>(pa);                                         \
     } while (0)
-            if (pa.use_table) { if (E == 2) VNM_PAG(2, true); else if (E == 3) VNM_PAG(3, true); else VNM_PAG(4, true); }
-            else { if (E == 2) VNM_PAG(2, false); else if (E == 3) VNM_PAG(3, false); else VNM_PAG(4, false); }
+            if (pa.use_table) { if (E == 1) VNM_PAG(1, true); else if (E == 2) VNM_PAG(2, true); else if (E == 3) VNM_PAG(3, true); else VNM_PAG(4, true); }
+            else { if (E == 1) VNM_PAG(1, false); else if (E == 2) VNM_PAG(2, false); else if (E == 3) VNM_PAG(3, false); else VNM_PAG(4, false); }
 #undef VNM_PAG
         } else {
             fit_grid((const void*)part_agg_kernel, 0);
@@ -3078,6 +3079,10 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         a.part_generic = part_ok;
         a.part_wide = wide;
         a.part_vmask = wide && any_null;
+        // no input column at all (COUNT(*) only): the entries are the keys alone -- 8 bytes instead of 16 through every
+        // pass, via the wide kernels with E = 1.  Those cannot spill heavy keys; if a region overflows the operator goes
+        // back to (key, unused word) entries with the spill buffer for good.
+        if (narrow && h->plan.n_cols == 0 && !h->key_only_failed && getenv("VNM_AGG_NO_KEY_ONLY") == nullptr) a.part_wide = 1;
     }
     // no hint from the caller: estimate the group count once from a sample of the first large batch
     if (part_ok && h->hint == 0 && !h->estimated && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
@@ -3100,6 +3105,11 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
         const bool can_spill = hot_scan && !hot_two && !hot_vnull && getenv("VNM_AGG_NO_SPILL") == nullptr;
         int prc = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
+        if (prc == 2 && a.part_wide && h->plan.n_cols == 0) {  // key-only entries and a region overflowed: see above
+            h->key_only_failed = true;
+            a.part_wide = 0;
+            prc = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
+        }
         // more groups than hinted (a partition overflowed its LDS table, or the dense output its allocation): estimate
         // the group count from the keys (< 1 ms) and partition again (~12 ms per attempt) before giving in to the HBM
         // table (~300 ms per 1e9 rows)
