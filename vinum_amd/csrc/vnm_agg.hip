@@ -1365,10 +1365,14 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
 // 8-byte column loads, no prefetch and no spill buffer: a straightforward version -- it only has to beat the HBM
 // atomics of the general path (two input columns, G >= 1e5: 217-250 ms per 1e9 rows).
 // -------------------------------------------------------------------------------------------------------
-constexpr int PW_ITEMS = 4;
-constexpr int PW_TILE = PT_BLOCK * PW_ITEMS;
-template <bool FROM_ROWS, int E>
+// items per lane and tile: one- and two-word entries get 8192-entry tiles (twice the run length), wider ones 4096
+constexpr int pw_items(int E) { return E <= 2 ? 8 : 4; }
+constexpr int pw_tile(int E) { return PT_BLOCK * pw_items(E); }
+// IT: items per lane and tile (8 only for one- and two-word entries; pass 2 keeps 4 when it has few sub-partitions:
+// its runs are long anyway and three resident workgroups beat one)
+template <bool FROM_ROWS, int E, int IT>
 __global__ __launch_bounds__(PT_BLOCK) void part_scatter_wide_kernel(PartArgs a) {
+    constexpr int PW_ITEMS = IT, PW_TILE = PT_BLOCK * IT;
     extern __shared__ uint64_t wstage[];  // [PW_TILE][E]
     __shared__ uint16_t part_of[PW_TILE];
     __shared__ uint32_t cnt[PT_MAXP], off[PT_MAXP], cursor[PT_MAXP];
@@ -2498,7 +2502,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     // entry = key + one value (16 bytes, tuned kernels) or key + 2-3 values (wide entries)
     const int E = a.part_wide ? 1 + h->plan.n_cols + (a.part_vmask ? 1 : 0) : 2;
     const bool wide = a.part_wide != 0;  // generic column accessors (any width, NULLs, any predicate column)
-    const int64_t tile1 = wide ? PW_TILE : PT_TILE;
+    const int64_t tile1 = wide ? pw_tile(E) : PT_TILE;
     const size_t ebytes = (size_t)E * 8;
     if (wide) { spill_out = nullptr; n_spill_out = nullptr; }
     const int levels = nfin > l1_max ? 2 : 1;
@@ -2540,13 +2544,13 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         KernelTimer timer("agg_part_scatter1", s);
         if (!wide) part_scatter_kernel<true><<<grid1, PT_BLOCK, 0, s>>>(p1);
         else {
-            const size_t lds = (size_t)PW_TILE * ebytes;
-#define VNM_PSW(FR, E_, GRID, ARGS)                                                                                  \
+            const size_t lds = (size_t)pw_tile(E) * ebytes;
+#define VNM_PSW(FR, E_, IT_, GRID, ARGS)                                                                             \
     do {                                                                                                             \
-        VNM_HIP(hipFuncSetAttribute((const void*)part_scatter_wide_kernel<FR, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        part_scatter_wide_kernel<FR, E_><<<GRID, PT_BLOCK, lds, s>>>(ARGS);                                          \
+        VNM_HIP(hipFuncSetAttribute((const void*)part_scatter_wide_kernel<FR, E_, IT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        part_scatter_wide_kernel<FR, E_, IT_><<<GRID, PT_BLOCK, lds, s>>>(ARGS);                                     \
     } while (0)
-            if (E == 1) VNM_PSW(true, 1, grid1, p1); else if (E == 2) VNM_PSW(true, 2, grid1, p1); else if (E == 3) VNM_PSW(true, 3, grid1, p1); else VNM_PSW(true, 4, grid1, p1);
+            if (E == 1) VNM_PSW(true, 1, 8, grid1, p1); else if (E == 2) VNM_PSW(true, 2, 8, grid1, p1); else if (E == 3) VNM_PSW(true, 3, 4, grid1, p1); else VNM_PSW(true, 4, 4, grid1, p1);
         }
     }
     VNM_HIP(hipGetLastError());
@@ -2591,9 +2595,12 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
             KernelTimer timer("agg_part_scatter2", s);
             if (!wide) part_scatter_kernel<false><<<np1 * p2.in_split, PT_BLOCK, 0, s>>>(p2);
             else {
-                const size_t lds = (size_t)PW_TILE * ebytes;
+                const bool big2 = E <= 2 && np2 >= 128;
+                const size_t lds = (size_t)PT_BLOCK * (big2 ? 8 : 4) * ebytes;
                 const int g2 = np1 * p2.in_split;
-                if (E == 1) VNM_PSW(false, 1, g2, p2); else if (E == 2) VNM_PSW(false, 2, g2, p2); else if (E == 3) VNM_PSW(false, 3, g2, p2); else VNM_PSW(false, 4, g2, p2);
+                if (E == 1) { if (big2) VNM_PSW(false, 1, 8, g2, p2); else VNM_PSW(false, 1, 4, g2, p2); }
+                else if (E == 2) { if (big2) VNM_PSW(false, 2, 8, g2, p2); else VNM_PSW(false, 2, 4, g2, p2); }
+                else if (E == 3) VNM_PSW(false, 3, 4, g2, p2); else VNM_PSW(false, 4, 4, g2, p2);
             }
         }
 #undef VNM_PSW
