@@ -78,7 +78,16 @@ __global__ void sort_orand_kernel(const uint64_t* code, int64_t n, unsigned long
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { o |= code[i]; a &= code[i]; }
     for (int d = 32; d > 0; d >>= 1) { o |= __shfl_xor(o, d); a &= __shfl_xor(a, d); }
-    if ((threadIdx.x & 63) == 0) { atomicOr(&red[0], (unsigned long long)o); atomicAnd(&red[1], (unsigned long long)a); }
+    // one atomic pair per workgroup: 8192 same-address atomics (one pair per wave of a 4-per-CU grid) cost ~95 us,
+    // five times per top-K query
+    __shared__ unsigned long long so[4], sa[4];
+    if ((threadIdx.x & 63) == 0) { so[threadIdx.x >> 6] = o; sa[threadIdx.x >> 6] = a; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) { o |= so[w]; a &= sa[w]; }
+        atomicOr(&red[0], (unsigned long long)o);
+        atomicAnd(&red[1], (unsigned long long)a);
+    }
 }
 
 // ---- one stable radix pass ------------------------------------------------------------------------------
@@ -258,7 +267,7 @@ static int radix_sort_codes(RadixBufs* r, int64_t n, hipStream_t s, unsigned lon
     }
     unsigned long long init[2] = {0ULL, ~0ULL}, red[5];
     VNM_HIP(hipMemcpyAsync(r->red, init, 16, hipMemcpyHostToDevice, s));
-    int g = device_info().num_cus * 4;
+    int g = device_info().num_cus * (n >= (1 << 24) ? 4 : 1);
     int64_t need = (n + 255) / 256;
     if (g > need) g = (int)need;
     sort_orand_kernel<<<g, 256, 0, s>>>(r->code[r->cur], n, r->red);
