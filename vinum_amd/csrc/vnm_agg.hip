@@ -3213,6 +3213,10 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         VNM_HIP(hipMemcpyAsync(ctl, h->g.ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
         VNM_HIP(hipStreamSynchronize(s));
         if (ctl[1] == 2) return set_error("aggregate: HBM hash table overflow (internal error)");
+        // a hint below the partitioning threshold with far more actual groups ran this scan into flush storms (77 ms per
+        // 1e9 rows at G = 1e7): the table's fill is the lesson for the batches that follow (checking small hints up
+        // front would cost every correctly hinted query ~0.3 ms)
+        if (h->single && nrows >= (1 << 22) && (int64_t)ctl[2] > 2 * 2400 && (int64_t)ctl[2] > h->hint) h->hint = (int64_t)(ctl[2] + ctl[2] / 4);
         if (!ctl[1]) break;  // no block ran out of room: every tile was processed
         // grow (x4, or to the projected final size) and relaunch; blocks resume from progress[]
         uint64_t new_cap = h->g.cap * 4;
