@@ -1102,7 +1102,7 @@ __global__ void agg_compact_special_kernel(CompactArgs c) {
 // When the groups do not fit an LDS table, per-row updates would have to go to the HBM table, and agent
 // scope atomics cap at ~24 G/s (profiles/microbench_r01.txt) -- 285 ms for the 1e9-row / 1e8-group query.
 // Instead the surviving (key, value) pairs are radix partitioned by hash bits, streaming and atomic-free:
-//   pass 1  rows -> 256 partitions           (filter fused; LDS counting sort per 4096-row tile, runs of
+//   pass 1  rows -> 256 partitions           (filter fused; LDS counting sort per 8192-row tile, runs of
 //                                              consecutive 16-byte entries written per partition)
 //   pass 2  each partition -> 512 sub-parts   (same kernel, next hash bits; only when G > ~280k)
 //   pass 3  one workgroup per final partition aggregates it in an LDS table and appends dense groups.
@@ -1115,7 +1115,7 @@ constexpr int PT_BLOCK = 1024;
 #endif
 constexpr int PT_ITEMS = VNM_PT_ITEMS;
 constexpr int PT_PAIRS = PT_ITEMS / 2;
-constexpr int PT_TILE = PT_BLOCK * PT_ITEMS;  // 4096 rows or entries per tile
+constexpr int PT_TILE = PT_BLOCK * PT_ITEMS;  // 8192 rows or entries per tile
 constexpr int PT_MAXP = 512;
 constexpr int PT_MAX_REGIONS = 256;  // input regions per pass-2 workgroup (keeps two workgroups per CU in LDS)
 constexpr int PA_BLOCK = 512;
