@@ -721,8 +721,9 @@ def test_scan_kernel_nullable_input(vtype, pred, groups):
         pytest.skip("the fused predicate is a float64 comparison")
     rng = np.random.default_rng(groups + len(pred) + len(vtype))
     n = 5_000_001
-    k = pa.array(rng.integers(0, groups, n).astype(np.int64) * 977 - 5)
-    mask = rng.random(n) < 0.15
+    kidx = rng.integers(0, groups, n)
+    k = pa.array(kidx.astype(np.int64) * 977 - 5)
+    mask = (rng.random(n) < 0.15) | (kidx == 1)   # every input of one group is NULL: the group must still come out
     if vtype == "float64":
         v = pa.array(rng.integers(-2**13, 2**13, n).astype(np.float64) / 128.0, mask=mask)
     else:
