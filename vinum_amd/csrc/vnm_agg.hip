@@ -472,7 +472,6 @@ __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
         for (int r = 0; r < R; r++) { raw[r] = 0; if (slot[r] != -1) rows |= 1u << r; }
         for (int o = 0; o < ((a.debug & 1) ? 0 : a.plan.n_ops); o++) {
             const AccOp op = a.plan.ops[o];
-            const int mk = a.plan.merge[op.word];
             uint32_t have = rows;  // rows that contribute to this op
             if (op.kind != A_COUNT_ROWS) {
                 if (op.col != loaded_col) {
