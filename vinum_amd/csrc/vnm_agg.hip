@@ -2194,11 +2194,15 @@ __global__ __launch_bounds__(256) void key_range_kernel(PackParams p, int64_t nr
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int j = 0; j < p.n; j++) {
         uint64_t mn = ~0ULL, mx = 0;
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nrows; i += stride) {
-            if (!col_valid(p.cols[j], i)) continue;
-            const uint64_t e = enc_i64((int64_t)col_key_bits(p.cols[j], i));
-            mn = e < mn ? e : mn;
-            mx = e > mx ? e : mx;
+        for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < nrows; i0 += stride * 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {  // four independent rows per lane
+                const int64_t i = i0 + (int64_t)u * stride;
+                const int64_t ic = i < nrows ? i : nrows - 1;
+                const bool ok = col_valid(p.cols[j], ic);
+                const uint64_t e = enc_i64((int64_t)col_key_bits(p.cols[j], ic));
+                if (ok && i < nrows) { mn = e < mn ? e : mn; mx = e > mx ? e : mx; }
+            }
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
@@ -2215,18 +2219,30 @@ __global__ __launch_bounds__(256) void key_range_kernel(PackParams p, int64_t nr
 __global__ __launch_bounds__(256) void key_pack_kernel(PackParams p, int64_t nrows, uint64_t* packed, unsigned long long* out_of_range) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     bool bad = false;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nrows; i += stride) {
-        uint64_t w = 0;
+    constexpr int U = 4;  // independent rows per lane: their column loads overlap
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < nrows; i0 += stride * U) {
+        uint64_t w[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) w[u] = 0;
         for (int j = 0; j < p.n; j++) {
             const uint64_t cap = (1ULL << p.bits[j]) - 1;  // values use codes [0, cap), NULL is cap
-            uint64_t code = cap;
-            if (col_valid(p.cols[j], i)) {
-                code = col_key_bits(p.cols[j], i) - p.lo[j];
-                bad = bad || code >= cap;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t i = i0 + (int64_t)u * stride;
+                const int64_t ic = i < nrows ? i : nrows - 1;
+                uint64_t code = cap;
+                if (col_valid(p.cols[j], ic)) {
+                    code = col_key_bits(p.cols[j], ic) - p.lo[j];
+                    bad = bad || (i < nrows && code >= cap);
+                }
+                w[u] |= (code & cap) << p.shift[j];
             }
-            w |= (code & cap) << p.shift[j];
         }
-        packed[i] = w;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t i = i0 + (int64_t)u * stride;
+            if (i < nrows) packed[i] = w[u];
+        }
     }
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(out_of_range, 1ULL);
 }
