@@ -183,10 +183,25 @@ enum vnm_out_kind { VNM_OUT_U64 = 0, VNM_OUT_I64, VNM_OUT_F64, VNM_OUT_F32, VNM_
 int vnm_agg_result_key(vnm_agg* h, int key_idx, uint64_t* vals, uint8_t* valid);
 int vnm_agg_result_func(vnm_agg* h, int func_idx, void* cells16, uint8_t* valid, int* out_kind);
 
+/* BaseAggregate::Result part 2 ON THE DEVICE: the result column of group key `key_idx` / function `func_idx` as Arrow
+ * buffers in HBM (what base_aggregate.cpp:47-68 assembles from the functions' Summarize methods, agg_funcs.h:72-80,
+ * 482-491, 519-540 incl. the 128-bit AVG): out_values = n_groups values of the column's OUTPUT type (keys and MIN / MAX:
+ * the input type; COUNT: uint64; SUM: int64 / uint64 / float64, int32 for time32; AVG: float64, float32 for 8 / 16-bit
+ * integers -- *out_kind as in vnm_agg_result_func), out_bitmap = Arrow validity bitmap of ((n_groups + 63) / 64) * 8
+ * bytes, *null_count = NULL results.  Returns 2 (and leaves the buffers undefined) when an int64 / uint64 SUM overflowed
+ * 64 bits in some group: the reference then promotes the whole column to decimal128 (agg_funcs.h:366-389), which
+ * vnm_agg_result_func does on the host. */
+int vnm_agg_result_key_device(vnm_agg* h, int key_idx, void* out_values, uint8_t* out_bitmap, int64_t* null_count, void* stream);
+int vnm_agg_result_func_device(vnm_agg* h, int func_idx, void* out_values, uint8_t* out_bitmap, int* out_kind,
+                               int64_t* null_count, void* stream);
+
 /* Host-only helpers (no GPU touched): how (functions, input types) lower onto 64-bit accumulator words
- * with commutative merge kinds (0 add-u64, 1 add-f64, 2 min-u64, 3 max-u64), and the finalisation of one
- * result column from dense accumulator words in HOST memory.  Used by the multi-GPU merge and unit-tested
- * on CPU. */
+ * with commutative merge kinds (0 add-u64, 1 add-f64, 2 min-u64, 3 max-u64, 4 compensated add-f64: the high
+ * word of a (hi, lo) pair -- every add into it is a returning atomic whose exact rounding error (TwoSum) is
+ * added to the NEXT word, an ordinary add-f64 word; the float64 SUM / AVG of a group is hi + lo, i.e. the
+ * correctly rounded exact sum up to second-order terms, whatever order the rows arrived in), and the
+ * finalisation of one result column from dense accumulator words in HOST memory.  Used by the multi-GPU merge
+ * and unit-tested on CPU. */
 int vnm_agg_plan_host(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
                       const int* in_types, const int* in_flags, const int* in_col_ids, int* n_key_words,
                       int* n_acc_words, int* merge_kinds /* >= 40 ints */, int* n_ops,

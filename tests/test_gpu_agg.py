@@ -36,6 +36,13 @@ def gpu_aggregate(kind, groupby, agg_cols, funcs, batches, predicate=None, expec
         pred = dev(predicate[0]) if predicate else None
         agg.next(keys, inputs, pred=pred, nrows=b.num_rows)
     res = agg.result_arrays([groupby.index(c) for c in agg_cols], agg_cols, [f[2] for f in funcs])
+    # the same result finalised ON THE DEVICE (vnm_agg_result_*_device) must equal the host finaliser bit for bit
+    try:
+        dcols = agg.result_device([groupby.index(c) for c in agg_cols])
+        dev = pa.RecordBatch.from_arrays([c.to_arrow() for c in dcols], names=res.schema.names)
+        util.assert_batches_equal(dev, res, what="device finalisation vs host finalisation")
+    except ops.NeedsHostFinalize:
+        assert any(pa.types.is_decimal(f.type) for f in res.schema), "only a decimal128 promotion may need the host"
     agg.close()
     return res
 

@@ -101,3 +101,21 @@ def test_oracle_matches_live_reference(seed):
             o.next(b)
             r.next(b)
         util.assert_batches_equal(o.result(), r.result(), key_names=gb, what=f"live kind={kind}")
+
+
+def test_oracle_float_sum_order_and_minmax_rule_match_the_reference():
+    """Sequential float64 `sum += x` in row order (agg_funcs.h:294-305) and `(row < last) ^ is_max` (agg_funcs.h:198)
+    on NaNs / mixed zeros: the oracle must reproduce the real reference bit for bit on the seeded float cases
+    (tests/golden/fsum_ref.arrow, minmax_ref.arrow: outputs of oracle/_ref, inputs regenerated from the seeds)."""
+    import json
+    import os
+    from tests.golden import float_cases as C
+    with open(os.path.join(util.GOLDEN, "float_cases.json")) as f:
+        sums = json.load(f)
+    for table, funcs, chunk, digest, out in ((C.fsum_table(), C.FSUM_FUNCS, C.FSUM_CHUNK, sums["fsum_sha256"], "fsum_ref.arrow"),
+                                             (C.minmax_table(), C.MINMAX_FUNCS, C.MINMAX_CHUNK, sums["minmax_sha256"], "minmax_ref.arrow")):
+        assert C.table_digest(table) == digest
+        o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+        for b in util.sliced_batches(table, chunk):
+            o.next(b)
+        util.assert_batches_equal(o.result(), util.read_ipc(out), key_names=["k"], what=out)

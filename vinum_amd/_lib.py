@@ -40,6 +40,8 @@ EQ, NE, GT, GE, LT, LE = range(6)
 MASK_U8 = 100
 OUT_U64, OUT_I64, OUT_F64, OUT_F32, OUT_DEC128, OUT_I32 = range(6)
 FLAG_SUM32 = 1
+# accumulator-word merge kinds (vnm_agg_plan_host)
+M_ADD_U64, M_ADD_F64, M_MIN_U64, M_MAX_U64, M_ADD_F64C = range(5)
 
 # name -> (restype, argtypes); mirrors include/vinum_hip.h one to one
 PROTOTYPES = {
@@ -69,6 +71,8 @@ PROTOTYPES = {
     "vnm_agg_merge_rows": (c_int, [c_void, c_i64, c_void, c_void]),
     "vnm_agg_result_key": (c_int, [c_void, c_int, c_void, c_void]),
     "vnm_agg_result_func": (c_int, [c_void, c_int, c_void, c_void, c_void]),
+    "vnm_agg_result_key_device": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void]),
+    "vnm_agg_result_func_device": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_void]),
     "vnm_agg_plan_host": (c_int, [c_int, c_int, c_void, c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_void,
                                   c_void, c_void]),
     "vnm_agg_finalize_host": (c_int, [c_int, c_int, c_void, c_int, c_void, c_void, c_void, c_void, c_int, c_i64,

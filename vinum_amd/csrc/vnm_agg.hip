@@ -60,6 +60,7 @@ struct AggArgs {
     unsigned int* progress;  // per-block loop index to resume from
     // hot-shape kernel (single 8-byte key, one float64 input column, no validity bitmaps)
     int hot_w_rows, hot_w_valid, hot_w_sum;
+    int hot_comp;      // float64 sums are compensated (hi, lo) pairs: M_ADD_F64C
     int hot_pred_is_v;
     // extended hot shape: every accumulator kind over ONE 8-byte input column without NULLs (or no input at all)
     int hot_w[9];      // word of each AccKind, -1 = absent
@@ -85,18 +86,42 @@ __device__ __forceinline__ void st_agent(uint64_t* p, uint64_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void g_merge(uint64_t* p, int mk, uint64_t v) {
+// Exact rounding error of s = fl(a + b) (Knuth's TwoSum: a + b == s + e in real arithmetic).  Zero when the sum
+// overflowed or an operand was not finite, so that inf / NaN results are what a plain sum gives.
+__device__ __forceinline__ double two_sum_err(double a, double b, double s) {
+    const double bb = s - a;
+    const double e = (a - (s - bb)) + (b - bb);
+    return (s - s == 0.0) ? e : 0.0;
+}
+// Compensated add into the (hi, lo) word pair of an M_ADD_F64C accumulator: hi = fl(hi + x) with a RETURNING atomic,
+// the exact error of that add goes to lo (the word `ws` elements further on).  Exact adds (the benchmark's quantised
+// data) never touch lo.
+__device__ __forceinline__ void g_add_f64c(uint64_t* p, int64_t ws, double x) {
+    const double old = __hip_atomic_fetch_add((double*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double e = two_sum_err(old, x, old + x);
+    if (e != 0.0) __hip_atomic_fetch_add((double*)(p + ws), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void l_add_f64c(uint64_t* p, int ws, double x) {
+    const double old = __hip_atomic_fetch_add((double*)p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const double e = two_sum_err(old, x, old + x);
+    if (e != 0.0) __hip_atomic_fetch_add((double*)(p + ws), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ws: distance (in elements) between consecutive accumulator words of one group (M_ADD_F64C updates word + 1 too)
+__device__ __forceinline__ void g_merge(uint64_t* p, int mk, uint64_t v, int64_t ws) {
     switch (mk) {
         case M_ADD_U64: __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
         case M_ADD_F64: __hip_atomic_fetch_add((double*)p, __longlong_as_double((long long)v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
+        case M_ADD_F64C: g_add_f64c(p, ws, __longlong_as_double((long long)v)); break;
         case M_MIN_U64: __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
         default: __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
     }
 }
-__device__ __forceinline__ void l_merge(uint64_t* p, int mk, uint64_t v) {
+__device__ __forceinline__ void l_merge(uint64_t* p, int mk, uint64_t v, int ws) {
     switch (mk) {
         case M_ADD_U64: __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break;
         case M_ADD_F64: __hip_atomic_fetch_add((double*)p, __longlong_as_double((long long)v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break;
+        case M_ADD_F64C: l_add_f64c(p, ws, __longlong_as_double((long long)v)); break;
         case M_MIN_U64: __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break;
         default: __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break;
     }
@@ -230,7 +255,7 @@ __device__ __forceinline__ void lds_flush(const AggArgs& a, uint64_t* lkey, uint
         for (int w = 0; w < W; w++) {
             uint64_t v = lacc[w * stride + i];
             int mk = a.plan.merge[w];
-            if (v != merge_init(mk)) g_merge(&a.g.acc[(uint64_t)w * a.g.stride + slot], mk, v);
+            if (v != merge_init(mk)) g_merge(&a.g.acc[(uint64_t)w * a.g.stride + slot], mk, v, (int64_t)a.g.stride);
             lacc[w * stride + i] = merge_init(mk);
         }
         lkey[i] = EMPTY;
@@ -250,7 +275,7 @@ __device__ __forceinline__ void agg_rows_to_table(const AggArgs& a, int64_t row0
         for (int o = 0; o < a.plan.n_ops; o++) {
             const AccOp& op = a.plan.ops[o];
             uint64_t v;
-            if (op_value(op, a.cols, row, &v)) g_merge(&a.g.acc[(uint64_t)op.word * a.g.stride + gs], a.plan.merge[op.word], v);
+            if (op_value(op, a.cols, row, &v)) g_merge(&a.g.acc[(uint64_t)op.word * a.g.stride + gs], a.plan.merge[op.word], v, (int64_t)a.g.stride);
         }
     }
 }
@@ -501,8 +526,13 @@ __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
                 case A_COUNT_ROWS:
                 case A_COUNT_VALID: VNM_MERGE_LOOP(M_ADD_U64, 1ULL, VNM_LADD(v)) break;
                 case A_SUM_F64:
-                    VNM_MERGE_LOOP(M_ADD_F64, (uint64_t)__double_as_longlong(VNM_F64V(raw[r])),
-                                   __hip_atomic_fetch_add((double*)&wl[slot[r]], __longlong_as_double((long long)v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                    if (a.plan.merge[op.word] == M_ADD_F64C) {
+                        VNM_MERGE_LOOP(M_ADD_F64C, (uint64_t)__double_as_longlong(VNM_F64V(raw[r])),
+                                       l_add_f64c(&wl[slot[r]], stride, __longlong_as_double((long long)v)))
+                    } else {
+                        VNM_MERGE_LOOP(M_ADD_F64, (uint64_t)__double_as_longlong(VNM_F64V(raw[r])),
+                                       __hip_atomic_fetch_add((double*)&wl[slot[r]], __longlong_as_double((long long)v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                    }
                     break;
                 case A_SUM_I64: VNM_MERGE_LOOP(M_ADD_U64, (uint64_t)VNM_I64(raw[r]), VNM_LADD(v)) break;
                 case A_SUM_LO32: VNM_MERGE_LOOP(M_ADD_U64, (uint64_t)VNM_I64(raw[r]) & 0xFFFFFFFFULL, VNM_LADD(v)) break;
@@ -576,7 +606,7 @@ __device__ __forceinline__ int hot_slot(uint64_t* lkey, int S, uint32_t smask, u
     return -1;
 }
 
-__device__ __forceinline__ void pa_accumulate_col(unsigned long long pack, int type, uint64_t* lw, int ST, int slot, uint64_t raw);
+__device__ __forceinline__ void pa_accumulate_col(unsigned long long pack, int type, uint64_t* lw, int ST, int slot, uint64_t raw, int comp);
 
 // every accumulator word this query has, updated for a row whose input value has the raw bits vb
 // (SIMPLE: only COUNT(*), COUNT and the float64 sum can be present -- the north-star shape keeps its short path)
@@ -585,11 +615,14 @@ __device__ __forceinline__ void hot_accumulate(const AggArgs& a, uint64_t* lacc,
     if (SIMPLE) {
         if (a.hot_w_rows >= 0) __hip_atomic_fetch_add(&lacc[a.hot_w_rows * stride + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (a.hot_w_valid >= 0) __hip_atomic_fetch_add(&lacc[a.hot_w_valid * stride + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (a.hot_w_sum >= 0) __hip_atomic_fetch_add((double*)&lacc[a.hot_w_sum * stride + slot], __longlong_as_double((long long)vb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (a.hot_w_sum >= 0) {
+            if (a.hot_comp) l_add_f64c(&lacc[a.hot_w_sum * stride + slot], stride, __longlong_as_double((long long)vb));
+            else __hip_atomic_fetch_add((double*)&lacc[a.hot_w_sum * stride + slot], __longlong_as_double((long long)vb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         return;
     }
     if (a.hot_w[A_COUNT_ROWS] >= 0) __hip_atomic_fetch_add(&lacc[a.hot_w[A_COUNT_ROWS] * stride + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (valid) pa_accumulate_col(a.hot_wpack, a.hot_vtype, lacc, stride, slot, vb);  // a NULL input only counts for COUNT(*)
+    if (valid) pa_accumulate_col(a.hot_wpack, a.hot_vtype, lacc, stride, slot, vb, a.hot_comp);  // a NULL input only counts for COUNT(*)
 }
 
 // one entry (key, value bits) straight into the HBM table: the saturated-key path of agg_hot_kernel<FROM_ENT>
@@ -601,7 +634,7 @@ __device__ __forceinline__ void hot_entry_to_table(const AggArgs& a, uint64_t ke
     for (int k = 0; k <= A_MAX; k++) {
         const int w = a.hot_w[k];
         if (w < 0) continue;
-        g_merge(&a.g.acc[(uint64_t)w * a.g.stride + gs], a.plan.merge[w], op_value_raw(k, a.hot_vtype, vb));
+        g_merge(&a.g.acc[(uint64_t)w * a.g.stride + gs], a.plan.merge[w], op_value_raw(k, a.hot_vtype, vb), (int64_t)a.g.stride);
     }
 }
 
@@ -699,7 +732,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                     int slot = hot_slot(lkey, S, smask, &s_fill, k.x, spread);
                     if (slot >= 0) {
                         hot_accumulate<SIMPLE>(a, lacc, stride, slot, v0, ok0);
-                        if (TWO) pa_accumulate_col(a.hot_wpack2, a.hot_vtype2, lacc, stride, slot, w0);
+                        if (TWO) pa_accumulate_col(a.hot_wpack2, a.hot_vtype2, lacc, stride, slot, w0, a.hot_comp);
                     } else if (FROM_ENT) hot_entry_to_table(a, k.x, v0, &s_new);  // no columns to re-read: merge right here
                     else sat0 |= 1u << u;
                 }
@@ -707,7 +740,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                     int slot = hot_slot(lkey, S, smask, &s_fill, k.y, spread);
                     if (slot >= 0) {
                         hot_accumulate<SIMPLE>(a, lacc, stride, slot, v1, ok1);
-                        if (TWO) pa_accumulate_col(a.hot_wpack2, a.hot_vtype2, lacc, stride, slot, w1);
+                        if (TWO) pa_accumulate_col(a.hot_wpack2, a.hot_vtype2, lacc, stride, slot, w1, a.hot_comp);
                     } else if (FROM_ENT) hot_entry_to_table(a, k.y, v1, &s_new);
                     else sat1 |= 1u << u;
                 }
@@ -728,7 +761,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                     int slot = hot_slot(lkey, S, smask, &s_fill, kb, spread);
                     if (slot >= 0) {
                         hot_accumulate<SIMPLE>(a, lacc, stride, slot, vb, ok);
-                        if (TWO) pa_accumulate_col(a.hot_wpack2, a.hot_vtype2, lacc, stride, slot, vp2[r]);
+                        if (TWO) pa_accumulate_col(a.hot_wpack2, a.hot_vtype2, lacc, stride, slot, vp2[r], a.hot_comp);
                     }
                     else if (FROM_ENT) hot_entry_to_table(a, kb, vb, &s_new);
                     else if (e == 0) sat0 |= 1u << u;
@@ -794,7 +827,7 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggArgs a) {
             for (int o = 0; o < a.plan.n_ops; o++) {
                 const AccOp& op = a.plan.ops[o];
                 uint64_t v;
-                if (op_value(op, a.cols, row, &v)) g_merge(&a.g.acc[(uint64_t)op.word * a.g.stride + gs], a.plan.merge[op.word], v);
+                if (op_value(op, a.cols, row, &v)) g_merge(&a.g.acc[(uint64_t)op.word * a.g.stride + gs], a.plan.merge[op.word], v, (int64_t)a.g.stride);
             }
         }
     }
@@ -809,7 +842,8 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggArgs a) {
 __device__ __forceinline__ uint64_t merge_vals(int mk, uint64_t x, uint64_t y) {
     switch (mk) {
         case M_ADD_U64: return x + y;
-        case M_ADD_F64: return (uint64_t)__double_as_longlong(__longlong_as_double((long long)x) + __longlong_as_double((long long)y));
+        case M_ADD_F64:
+        case M_ADD_F64C: return (uint64_t)__double_as_longlong(__longlong_as_double((long long)x) + __longlong_as_double((long long)y));
         case M_MIN_U64: return x < y ? x : y;
         default: return x > y ? x : y;
     }
@@ -859,6 +893,20 @@ __global__ __launch_bounds__(OG_BLOCK) void agg_onegroup_kernel(AggArgs a) {
                 have &= cvalid;
             }
             uint64_t acc = lds[op.word * OG_BLOCK + tid];
+            if (mk == M_ADD_F64C) {  // compensated float64 sum: this lane's (hi, lo) pair
+                double hi = __longlong_as_double((long long)acc), lo = __longlong_as_double((long long)lds[(op.word + 1) * OG_BLOCK + tid]);
+#pragma unroll
+                for (int r = 0; r < OG_R; r++)
+                    if ((have >> r) & 1u) {
+                        const double x = __longlong_as_double((long long)op_value_raw(op.kind, vtype, raw[r]));
+                        const double sm = hi + x;
+                        lo += two_sum_err(hi, x, sm);
+                        hi = sm;
+                    }
+                lds[op.word * OG_BLOCK + tid] = (uint64_t)__double_as_longlong(hi);
+                lds[(op.word + 1) * OG_BLOCK + tid] = (uint64_t)__double_as_longlong(lo);
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < OG_R; r++)
                 if ((have >> r) & 1u) acc = merge_vals(mk, acc, op_value_raw(op.kind, vtype, op.kind == A_COUNT_ROWS ? 0 : raw[r]));
@@ -868,14 +916,22 @@ __global__ __launch_bounds__(OG_BLOCK) void agg_onegroup_kernel(AggArgs a) {
     __syncthreads();
     for (int half = OG_BLOCK / 2; half > 0; half >>= 1) {
         if (tid < half)
-            for (int w = 0; w < W; w++)
+            for (int w = 0; w < W; w++) {
+                if (a.plan.merge[w] == M_ADD_F64C) {  // (hi, lo) + (hi, lo): the error of hi + hi joins lo (word w + 1, merged next)
+                    const double x = __longlong_as_double((long long)lds[w * OG_BLOCK + tid]), y = __longlong_as_double((long long)lds[w * OG_BLOCK + tid + half]);
+                    const double sm = x + y;
+                    lds[w * OG_BLOCK + tid] = (uint64_t)__double_as_longlong(sm);
+                    lds[(w + 1) * OG_BLOCK + tid] = (uint64_t)__double_as_longlong(__longlong_as_double((long long)lds[(w + 1) * OG_BLOCK + tid]) + two_sum_err(x, y, sm));
+                    continue;
+                }
                 lds[w * OG_BLOCK + tid] = merge_vals(a.plan.merge[w], lds[w * OG_BLOCK + tid], lds[w * OG_BLOCK + tid + half]);
+            }
         __syncthreads();
     }
     if (tid < W) {
         int mk = a.plan.merge[tid];
         uint64_t v = lds[tid * OG_BLOCK];
-        if (v != merge_init(mk)) g_merge(&a.g.acc[(uint64_t)tid * a.g.stride], mk, v);
+        if (v != merge_init(mk)) g_merge(&a.g.acc[(uint64_t)tid * a.g.stride], mk, v, (int64_t)a.g.stride);
     }
 }
 
@@ -886,20 +942,20 @@ __global__ __launch_bounds__(OG_BLOCK) void agg_onegroup_kernel(AggArgs a) {
 // is the input column, 2 a separate float64 predicate column.
 template <int VT, int PM>
 __global__ __launch_bounds__(OG_BLOCK) void agg_onegroup_hot_kernel(AggArgs a) {
-    __shared__ uint64_t part[OG_BLOCK / 64][8];
+    __shared__ uint64_t part[OG_BLOCK / 64][9];
     const int tid = threadIdx.x;
     const ulonglong2* vp = VT >= 0 ? (const ulonglong2*)((const uint64_t*)a.cols[0].values + a.cols[0].offset) : nullptr;
     const double2* pp = PM == 2 ? (const double2*)((const double*)a.pred.values + a.pred.offset) : nullptr;
     const int op = a.p.op;
     const double thr = a.p.dval;
-    double sf = 0.0;
+    double sf = 0.0, sc = 0.0;  // float64 sum and the accumulated rounding errors of its adds (see M_ADD_F64C)
     uint64_t si = 0, slo = 0, shis = 0, shiu = 0, cnt = 0, mn = ~0ULL, mx = 0;
     auto take = [&](uint64_t vb, double pv) {
         const double f = VT == VNM_F64 ? __longlong_as_double((long long)vb) : (VT == VNM_U64 ? (double)vb : (double)(int64_t)vb);
         if (PM != 0 && !cmp_apply<double>(op, PM == 1 ? f : pv, thr)) return;
         cnt++;
         if (VT < 0) return;
-        sf += f;
+        { const double sm = sf + f; sc += two_sum_err(sf, f, sm); sf = sm; }
         if (VT != VNM_F64) {
             si += vb;
             slo += vb & 0xFFFFFFFFULL;
@@ -936,11 +992,14 @@ __global__ __launch_bounds__(OG_BLOCK) void agg_onegroup_hot_kernel(AggArgs a) {
         take(VT >= 0 ? ((const uint64_t*)vp)[r] : 0, PM == 2 ? ((const double*)pp)[r] : 0.0);
     }
     // wave reduction, then one merge per needed word and workgroup
-    uint64_t w8[8] = {(uint64_t)__double_as_longlong(sf), si, slo, shis, shiu, cnt, mn, mx};
+    uint64_t w8[9] = {(uint64_t)__double_as_longlong(sf), si, slo, shis, shiu, cnt, mn, mx, (uint64_t)__double_as_longlong(sc)};
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const double of = __shfl_xor(__longlong_as_double((long long)w8[0]), o);
-        w8[0] = (uint64_t)__double_as_longlong(__longlong_as_double((long long)w8[0]) + of);
+        const double mine = __longlong_as_double((long long)w8[0]);
+        const double of = __shfl_xor(mine, o), oc = __shfl_xor(__longlong_as_double((long long)w8[8]), o);
+        const double sm = mine + of;
+        w8[0] = (uint64_t)__double_as_longlong(sm);
+        w8[8] = (uint64_t)__double_as_longlong(__longlong_as_double((long long)w8[8]) + oc + two_sum_err(mine, of, sm));
 #pragma unroll
         for (int k = 1; k < 6; k++) w8[k] += __shfl_xor(w8[k], o);
         const uint64_t omn = __shfl_xor(w8[6], o), omx = __shfl_xor(w8[7], o);
@@ -949,23 +1008,31 @@ __global__ __launch_bounds__(OG_BLOCK) void agg_onegroup_hot_kernel(AggArgs a) {
     }
     if ((tid & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) part[tid >> 6][k] = w8[k];
+        for (int k = 0; k < 9; k++) part[tid >> 6][k] = w8[k];
     }
     __syncthreads();
     if (tid <= A_MAX && a.hot_w[tid] >= 0) {
         // AccKind -> register: COUNT(*) and COUNT both see `cnt` (no NULLs on this path)
         const int src = tid == A_COUNT_ROWS || tid == A_COUNT_VALID ? 5 : (tid == A_SUM_F64 ? 0 : (tid == A_MIN ? 6 : (tid == A_MAX ? 7 : tid - A_SUM_I64 + 1)));
         uint64_t v = part[0][src];
+        double comp = __longlong_as_double((long long)part[0][8]);
         for (int wv = 1; wv < OG_BLOCK / 64; wv++) {
             const uint64_t o = part[wv][src];
-            if (src == 0) v = (uint64_t)__double_as_longlong(__longlong_as_double((long long)v) + __longlong_as_double((long long)o));
+            if (src == 0) {
+                const double x = __longlong_as_double((long long)v), y = __longlong_as_double((long long)o), sm = x + y;
+                comp += __longlong_as_double((long long)part[wv][8]) + two_sum_err(x, y, sm);
+                v = (uint64_t)__double_as_longlong(sm);
+            }
             else if (src == 6) v = o < v ? o : v;
             else if (src == 7) v = o > v ? o : v;
             else v += o;
         }
         const int w = a.hot_w[tid];
         const int mk = a.plan.merge[w];
-        if (v != merge_init(mk) || mk == M_ADD_F64) g_merge(&a.g.acc[(uint64_t)w * a.g.stride], mk, v);
+        if (src == 0 && mk == M_ADD_F64) v = (uint64_t)__double_as_longlong(__longlong_as_double((long long)v) + comp);
+        if (v != merge_init(mk) || mk == M_ADD_F64 || mk == M_ADD_F64C) g_merge(&a.g.acc[(uint64_t)w * a.g.stride], mk, v, (int64_t)a.g.stride);
+        if (src == 0 && mk == M_ADD_F64C && comp != 0.0)
+            __hip_atomic_fetch_add((double*)&a.g.acc[(uint64_t)(w + 1) * a.g.stride], comp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1025,7 +1092,7 @@ __global__ __launch_bounds__(256) void agg_merge_kernel(MergeArgs m) {
         for (int w = 0; w < m.plan.n_words; w++) {
             uint64_t v = m.src_acc[w][i * (m.src_is_table ? 1 : m.src_stride)];
             int mk = m.plan.merge[w];
-            if (v != merge_init(mk)) g_merge(&m.g.acc[(uint64_t)w * m.g.stride + slot], mk, v);
+            if (v != merge_init(mk)) g_merge(&m.g.acc[(uint64_t)w * m.g.stride + slot], mk, v, (int64_t)m.g.stride);
         }
     }
     __syncthreads();
@@ -1512,6 +1579,7 @@ struct PartAggArgs {
     int regions;          // regions per final partition
     int64_t nfinal;       // number of final partitions
     int w_rows, w_valid, w_sum, n_words;
+    int w_lo;             // compensation word of the float64 sum (w_sum + 1), -1 = plain sum
     uint64_t* dkey;       // [2][dstride]
     uint64_t* dacc;       // [W][dstride]
     int64_t dstride;
@@ -1537,6 +1605,7 @@ struct PartAggArgs {
     unsigned long long wpack[3];
     int w_rows_g, use_table, nval;
     int slots;  // LDS table size of part_agg_generic_kernel
+    int comp;   // float64 sums are compensated (hi, lo) pairs
 };
 
 // Find-or-claim the slot of `key` in a final-pass LDS table (PA_SLOTS keys).  The pass is bound by the number of
@@ -1582,6 +1651,10 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     constexpr uint64_t PA_RESERVED = EMPTY - 1;
     __shared__ uint64_t lkey[PA_SLOTS];
     __shared__ uint64_t lsum[PA_LIVE + 2];
+    // compensation terms of the float64 sums (M_ADD_F64C) in SINGLE precision: they are ~2^-53 of the sum, so 24 bits of
+    // them keep hi + lo within 2^-77; a float64 array would cost the fourth resident workgroup.  An error term beyond
+    // float range (|sum| > ~1e54) fails the partition over to the general path; one below it (|sum| < ~1e-22) is dropped.
+    __shared__ float llo[PA_LIVE + 2];
     __shared__ uint32_t lcnt[PA_LIVE + 2];
     __shared__ uint32_t s_n, s_fail, s_sp[2];
     __shared__ unsigned s_new;
@@ -1594,7 +1667,7 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
         const int part = (int)(unit % a.splits);
         for (int i = tid; i < PA_SLOTS; i += PA_BLOCK) {
             lkey[i] = i < PA_LIVE ? EMPTY : PA_RESERVED;
-            if (i < PA_LIVE + 2) { lsum[i] = 0; lcnt[i] = 0; }
+            if (i < PA_LIVE + 2) { lsum[i] = 0; lcnt[i] = 0; llo[i] = 0.0f; }
         }
         if (tid == 0) { s_n = 0; s_fail = 0; s_sp[0] = 0; s_sp[1] = 0; }
         __syncthreads();
@@ -1624,7 +1697,16 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                     if (slot < 0) s_fail = 1;
                 }
                 if (slot >= 0) {
-                    __hip_atomic_fetch_add((double*)&lsum[slot], __longlong_as_double((long long)e.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const double x = __longlong_as_double((long long)e.y);
+                    if (a.w_lo >= 0) {
+                        const double old = __hip_atomic_fetch_add((double*)&lsum[slot], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const double er = two_sum_err(old, x, old + x);
+                        if (er != 0.0) {
+                            const float ef = (float)er;
+                            if (ef - ef != 0.0f) s_fail = 1;
+                            __hip_atomic_fetch_add(&llo[slot], ef, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    } else __hip_atomic_fetch_add((double*)&lsum[slot], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     atomicAdd(&lcnt[slot], 1u);
                 }
               }
@@ -1654,9 +1736,11 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                 uint64_t slot;
                 if (i != PA_LIVE) slot = gt_find_single(a.g, k, &s_new);
                 else { slot = a.g.cap; if (ld_agent(&a.g.tag[slot]) == EMPTY) st_agent(&a.g.tag[slot], 0); }
-                if (a.w_rows >= 0) g_merge(&a.g.acc[(uint64_t)a.w_rows * a.g.stride + slot], M_ADD_U64, lcnt[i]);
-                if (a.w_valid >= 0) g_merge(&a.g.acc[(uint64_t)a.w_valid * a.g.stride + slot], M_ADD_U64, lcnt[i]);
-                if (a.w_sum >= 0) g_merge(&a.g.acc[(uint64_t)a.w_sum * a.g.stride + slot], M_ADD_F64, lsum[i]);
+                if (a.w_rows >= 0) g_merge(&a.g.acc[(uint64_t)a.w_rows * a.g.stride + slot], M_ADD_U64, lcnt[i], 0);
+                if (a.w_valid >= 0) g_merge(&a.g.acc[(uint64_t)a.w_valid * a.g.stride + slot], M_ADD_U64, lcnt[i], 0);
+                if (a.w_sum >= 0) g_merge(&a.g.acc[(uint64_t)a.w_sum * a.g.stride + slot], a.w_lo >= 0 ? M_ADD_F64C : M_ADD_F64, lsum[i], (int64_t)a.g.stride);
+                if (a.w_lo >= 0 && llo[i] != 0.0f)
+                    g_merge(&a.g.acc[(uint64_t)a.w_lo * a.g.stride + slot], M_ADD_F64, (uint64_t)__double_as_longlong((double)llo[i]), 0);
             }
             __syncthreads();
             if (tid == 0) fold_new(a.g, &s_new);
@@ -1690,6 +1774,7 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                 if (a.w_rows >= 0) a.dacc[(int64_t)a.w_rows * a.dstride + pos] = lcnt[i];
                 if (a.w_valid >= 0) a.dacc[(int64_t)a.w_valid * a.dstride + pos] = lcnt[i];
                 if (a.w_sum >= 0) a.dacc[(int64_t)a.w_sum * a.dstride + pos] = lsum[i];
+                if (a.w_lo >= 0) a.dacc[(int64_t)a.w_lo * a.dstride + pos] = (uint64_t)__double_as_longlong((double)llo[i]);
             }
         }
         __syncthreads();
@@ -1715,13 +1800,15 @@ __device__ __forceinline__ uint64_t op_value_bits(int kind, int vtype, uint64_t 
 
 // every accumulator word of ONE input column (packed word table, see PartAggArgs::wpack) for a non-NULL value with
 // the raw bits `raw` of type `type`
-__device__ __forceinline__ void pa_accumulate_col(unsigned long long pack, int type, uint64_t* lw, int ST, int slot, uint64_t raw) {
+__device__ __forceinline__ void pa_accumulate_col(unsigned long long pack, int type, uint64_t* lw, int ST, int slot, uint64_t raw, int comp) {
 #define VNM_WI(K) ((int)((pack >> (6 * (K))) & 63ULL))
 #define VNM_W(K) (lw + VNM_WI(K) * ST + slot)
 #define VNM_ADD(K, V) if (VNM_WI(K) != 63) __hip_atomic_fetch_add(VNM_W(K), (uint64_t)(V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
     VNM_ADD(A_COUNT_VALID, 1ULL);
-    if (VNM_WI(A_SUM_F64) != 63)
-        __hip_atomic_fetch_add((double*)VNM_W(A_SUM_F64), raw_to_f64(type, raw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (VNM_WI(A_SUM_F64) != 63) {
+        if (comp) l_add_f64c(VNM_W(A_SUM_F64), ST, raw_to_f64(type, raw));  // (hi, lo) pair: lo is the next word
+        else __hip_atomic_fetch_add((double*)VNM_W(A_SUM_F64), raw_to_f64(type, raw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     if (((pack >> (6 * A_SUM_I64)) & 0xFFFFFFULL) != 0xFFFFFFULL) {  // any of the four integer-sum kinds (consecutive AccKinds)
         const uint64_t iv = (uint64_t)raw_to_i64(type, raw);
         VNM_ADD(A_SUM_I64, iv);
@@ -1803,7 +1890,7 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
 #pragma unroll
                         for (int c = 0; c < E - 1; c++) {
                             if (c < a.nval && (E == 2 || ((vmask >> c) & 1ULL)))  // a NULL input updates nothing of its column
-                                pa_accumulate_col(a.wpack[c], a.vtypes[c], lw, ST, slot, eb[u][1 + c]);
+                                pa_accumulate_col(a.wpack[c], a.vtypes[c], lw, ST, slot, eb[u][1 + c], a.comp);
                         }
                     } else if (slot >= 0 && !TABLE) {
                         const uint64_t vmask = (E > 2 && a.has_vmask) ? eb[u][E - 1] : ~0ULL;
@@ -1816,7 +1903,7 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
                             for (int e = 2; e < E; e++) if (c == e - 1) vb = eb[u][e];
                             const uint64_t v = a.wide ? op_value_raw(a.ops[o].kind, a.vtypes[c], vb)  // any numeric type
                                                       : op_value_bits(a.ops[o].kind, a.vtype, vb);
-                            l_merge(&lw[w * ST + slot], a.merge[w], v);
+                            l_merge(&lw[w * ST + slot], a.merge[w], v, ST);
                         }
                     }
                 }
@@ -1847,7 +1934,7 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
                 else { slot = a.g.cap; if (ld_agent(&a.g.tag[slot]) == EMPTY) st_agent(&a.g.tag[slot], 0); }
                 for (int w = 0; w < W; w++) {
                     uint64_t v = lw[w * ST + i];
-                    if (v != merge_init(a.merge[w])) g_merge(&a.g.acc[(uint64_t)w * a.g.stride + slot], a.merge[w], v);
+                    if (v != merge_init(a.merge[w])) g_merge(&a.g.acc[(uint64_t)w * a.g.stride + slot], a.merge[w], v, (int64_t)a.g.stride);
                 }
             }
             __syncthreads();
@@ -2130,7 +2217,7 @@ __global__ __launch_bounds__(PA_BLOCK) void part_merge_kernel(PartMergeArgs a) {
                     }
                 }
                 if (slot >= 0)
-                    for (int w = 0; w < a.n_words; w++) l_merge(&lw[w][slot], a.merge[w], row[2 + w]);
+                    for (int w = 0; w < a.n_words; w++) l_merge(&lw[w][slot], a.merge[w], row[2 + w], PA_SLOTS + 1);
             }
         }
         __syncthreads();
@@ -2262,6 +2349,132 @@ __global__ __launch_bounds__(256) void key_unpack_kernel(PackParams p, const uin
         }
         dkey[(int64_t)p.n * stride + i] = nullmask;
     }
+}
+
+
+// =======================================================================================================
+// Device-side finalisation: BaseAggregate::Result / SummarizeGroups (base_aggregate.cpp:47-68) and the Summarize
+// methods of the aggregate functions (agg_funcs.h:72-80 generic, :358-397 int64 sum, :482-491 + :519-540 AVG incl.
+// the 128-bit divmod) evaluated per group ON THE DEVICE from the dense accumulator words, written as Arrow-layout
+// buffers (typed values + validity bitmap).  The host finaliser (vnm_finalize.cpp) stays the authority for the one
+// case that changes the column TYPE: an int64 / uint64 SUM that overflows 64 bits in some group promotes the whole
+// column to decimal128 (:366-389) -- the kernel raises a flag for it and the caller uses vnm_agg_result_func.
+// =======================================================================================================
+struct FinArgs {
+    FuncOut fo;
+    const uint64_t* words[3];  // w_valid, w_a, w_b (nullptr when absent)
+    int is_key, key_bit;       // key column: words[1] = key bits, words[0] = NULL-mask word
+    int out_width;             // bytes per output value
+    int out_f32;               // float32 output (AVG of 8 / 16-bit integers)
+    int64_t n;
+    void* out;
+    unsigned long long* bitmap;   // (n + 63) / 64 words
+    unsigned long long* ctl;      // [0] null count  [1] a 64-bit SUM overflowed
+};
+
+__device__ __forceinline__ void fin_store(void* out, int width, int64_t i, uint64_t bits) {
+    switch (width) {
+        case 1: ((uint8_t*)out)[i] = (uint8_t)bits; break;
+        case 2: ((uint16_t*)out)[i] = (uint16_t)bits; break;
+        case 4: ((uint32_t*)out)[i] = (uint32_t)bits; break;
+        default: ((uint64_t*)out)[i] = bits; break;
+    }
+}
+// Hugeint::TryCast<double>, huge_int.cpp:395-406 (including its 2^64-for-UINT64_MAX rounding)
+__device__ __forceinline__ double fin_huge_to_double(uint64_t lower, int64_t upper) {
+    if (upper == -1) return -(double)(0xFFFFFFFFFFFFFFFFULL - lower) - 1;
+    return (double)lower + (double)upper * 18446744073709551615.0;
+}
+
+__global__ __launch_bounds__(256) void agg_finalize_kernel(FinArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int t = a.fo.in_type;
+    const int64_t nround = (a.n + 63) & ~63LL;
+    unsigned long long nulls = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += stride) {
+        bool valid = false;
+        uint64_t bits = 0;
+        if (i < a.n) {
+            if (a.is_key) {
+                valid = !((a.words[0][i] >> a.key_bit) & 1ULL);
+                bits = a.words[1][i];
+            } else {
+                const uint64_t cnt = a.words[0] ? a.words[0][i] : 1;
+                const uint64_t wa = a.words[1][i];
+                const uint64_t wb = a.words[2] ? a.words[2][i] : 0;
+                valid = cnt > 0;
+                switch (a.fo.func) {
+                    case VNM_COUNT_STAR:
+                    case VNM_COUNT: valid = true; bits = wa; break;
+                    case VNM_MIN:
+                    case VNM_MAX:
+                        if (t == VNM_F64) bits = (uint64_t)__double_as_longlong(dec_f64(wa));
+                        else if (t == VNM_F32) bits = (uint64_t)__float_as_uint((float)dec_f64(wa));
+                        else if (type_is_unsigned(t)) bits = wa;
+                        else bits = (uint64_t)dec_i64(wa);
+                        break;
+                    case VNM_SUM:
+                        if (t == VNM_I64 || t == VNM_U64) {
+                            // 128-bit two's complement sum = hi * 2^32 + lo (A_SUM_LO32 / A_SUM_HI32S|U lanes)
+                            const uint64_t slo = wa + (wb << 32);
+                            const int64_t shi = (t == VNM_I64 ? ((int64_t)wb >> 32) : (int64_t)(wb >> 32)) + (slo < wa ? 1 : 0);
+                            bool fits;
+                            if (t == VNM_I64) fits = (shi == 0 && slo <= 0x7FFFFFFFFFFFFFFFULL) || (shi == -1 && slo > 0x8000000000000000ULL);  // huge_int.cpp:334-355
+                            else fits = shi == 0;
+                            if (valid && !fits) __hip_atomic_store(&a.ctl[1], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            bits = slo;
+                        } else if (type_is_float(t)) {
+                            bits = (uint64_t)__double_as_longlong(__longlong_as_double((long long)wa) + (a.words[2] ? __longlong_as_double((long long)wb) : 0.0));
+                        } else bits = wa;  // int64 / uint64 accumulators of the narrow integers; time32 keeps its low 32 bits
+                        break;
+                    default: {  // VNM_AVG
+                        double avg = 0.0;
+                        if (valid) {
+                            if (t == VNM_I64 || t == VNM_U64) {
+                                uint64_t slo = wa + (wb << 32);
+                                int64_t shi = (t == VNM_I64 ? ((int64_t)wb >> 32) : (int64_t)(wb >> 32)) + (slo < wa ? 1 : 0);
+                                const bool neg = shi < 0;
+                                if (neg) { slo = ~slo + 1; shi = ~shi + (slo == 0 ? 1 : 0); }  // magnitude
+                                // (shi, slo) / cnt by 32-bit limbs; cnt < 2^32 rows per group by construction of the lanes
+                                const uint32_t limb[4] = {(uint32_t)((uint64_t)shi >> 32), (uint32_t)shi, (uint32_t)(slo >> 32), (uint32_t)slo};
+                                uint32_t ql[4];
+                                uint64_t r = 0;
+#pragma unroll
+                                for (int k = 0; k < 4; k++) {
+                                    const uint64_t cur = (r << 32) | limb[k];
+                                    ql[k] = (uint32_t)(cur / cnt);
+                                    r = cur % cnt;
+                                }
+                                uint64_t qlo = ((uint64_t)ql[2] << 32) | ql[3];
+                                int64_t qhi = (int64_t)(((uint64_t)ql[0] << 32) | ql[1]);
+                                uint64_t rlo = r;
+                                int64_t rhi = 0;
+                                if (neg) {  // C truncation: quotient and remainder take the sign of the dividend
+                                    qlo = ~qlo + 1; qhi = ~qhi + (qlo == 0 ? 1 : 0);
+                                    rlo = ~rlo + 1; rhi = ~rhi + (rlo == 0 ? 1 : 0);
+                                }
+                                avg = fin_huge_to_double(qlo, qhi) + fin_huge_to_double(rlo, rhi) / (double)cnt;  // agg_funcs.h:524-540
+                            } else if (type_is_float(t)) {
+                                avg = (__longlong_as_double((long long)wa) + (a.words[2] ? __longlong_as_double((long long)wb) : 0.0)) / (double)cnt;
+                            } else if (type_is_unsigned(t)) avg = (double)wa / (double)cnt;
+                            else avg = (double)(int64_t)wa / (double)cnt;
+                        }
+                        bits = a.out_f32 ? (uint64_t)__float_as_uint((float)avg) : (uint64_t)__double_as_longlong(avg);
+                        break;
+                    }
+                }
+            }
+            fin_store(a.out, a.out_width, i, valid ? bits : 0);
+        }
+        const unsigned long long b = __ballot(valid);
+        if (lane == 0) {
+            a.bitmap[i >> 6] = b;
+            const int64_t live = a.n - i >= 64 ? 64 : a.n - i;
+            nulls += (unsigned long long)(live - __popcll(b));
+        }
+    }
+    if (lane == 0 && nulls) atomicAdd(&a.ctl[0], nulls);
 }
 
 }  // namespace vnm
@@ -2667,6 +2880,8 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     }
     pa.entries = fin_e; pa.counts = fin_c; pa.cap = fin_cap; pa.regions = fin_regions; pa.nfinal = nfinal;
     pa.w_rows = a.hot_w_rows; pa.w_valid = a.hot_w_valid; pa.w_sum = a.hot_w_sum; pa.n_words = h->plan.n_words;
+    pa.w_lo = a.hot_comp && a.hot_w_sum >= 0 ? a.hot_w_sum + 1 : -1;
+    pa.comp = a.hot_comp;
     pa.dkey = rk; pa.dacc = ra; pa.dstride = dstride; pa.flags = flags;
     {
         KernelTimer timer("agg_part_final", s);
@@ -3044,6 +3259,8 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     }
     const bool hot_two = hot_scan && h->plan.n_cols == 2;
     a.hot_w_rows = a.hot_w_valid = a.hot_w_sum = -1;
+    a.hot_comp = 0;
+    for (int w = 0; w < h->plan.n_words; w++) if (h->plan.merge[w] == M_ADD_F64C) a.hot_comp = 1;
     for (int k = 0; k < 9; k++) a.hot_w[k] = a.hot_w2[k] = -1;
     bool hot = hot_scan && h->plan.n_cols == 1 && a.hot_vtype == VNM_F64 && !hot_vnull;
     if (hot_scan) {
@@ -3413,7 +3630,13 @@ int64_t vnm_agg_run_partitions(vnm_agg* h) {
     if (!h) return 0;
     int64_t n = 0;
     if (vnm_agg_finish(h, &n, nullptr) != 0) return 0;
-    return (h->result_is_run && h->run_dir) ? h->run_nfin : 0;
+    if (!(h->result_is_run && h->run_dir)) return 0;
+    // only what vnm_agg_merge_partitioned can merge: add-merge words (MIN / MAX programs and anything wider than the
+    // LDS merge table go through the owner-bucketed exchange)
+    if (h->plan.n_words > PM_MAX_WORDS) return 0;
+    for (int w = 0; w < h->plan.n_words; w++)
+        if (h->plan.merge[w] != M_ADD_U64 && h->plan.merge[w] != M_ADD_F64 && h->plan.merge[w] != M_ADD_F64C) return 0;
+    return h->run_nfin;
 }
 
 // Rows of the run in partition order, row-major [n][2 + n_acc_words]; per-partition row counts (device,
@@ -3460,7 +3683,7 @@ int vnm_agg_merge_partitioned(vnm_agg* h, int world, int64_t nlocal, const uint6
     if (h->have_table || h->have_run) return set_error("vnm_agg_merge_partitioned: the handle must be empty");
     if (h->plan.n_words > PM_MAX_WORDS) return set_error("vnm_agg_merge_partitioned: at most %d accumulator words", PM_MAX_WORDS);
     for (int w = 0; w < h->plan.n_words; w++)
-        if (h->plan.merge[w] != M_ADD_U64 && h->plan.merge[w] != M_ADD_F64) return set_error("vnm_agg_merge_partitioned: add-merge words only");
+        if (h->plan.merge[w] != M_ADD_U64 && h->plan.merge[w] != M_ADD_F64 && h->plan.merge[w] != M_ADD_F64C) return set_error("vnm_agg_merge_partitioned: add-merge words only");
     hipStream_t s = as_stream(stream);
     invalidate_result(h);
     // per-source exclusive prefix over the owned partitions -> absolute row offsets
@@ -3502,7 +3725,8 @@ int vnm_agg_merge_partitioned(vnm_agg* h, int world, int64_t nlocal, const uint6
     pool_free(dpre); pool_free(flags);
     if (fl[0]) {
         pool_free(rk); pool_free(ra);
-        return set_error("vnm_agg_merge_partitioned: a partition holds more groups than the LDS table (use vnm_agg_merge_rows)");
+        set_error("vnm_agg_merge_partitioned: a partition holds more groups than the LDS table (use vnm_agg_merge_rows)");
+        return 2;  // capacity, not an error of the data: the handle is still empty and the caller falls back
     }
     h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
     h->have_run = true;
@@ -3562,6 +3786,85 @@ int vnm_agg_result_func(vnm_agg* h, int func_idx, void* cells16, uint8_t* valid,
     const uint64_t* words[AGG_MAX_WORDS];
     for (int w = 0; w < h->plan.n_words; w++) words[w] = h->h_acc.data() + (size_t)w * n;
     return finalize_func(h->outs[func_idx], n, words, cells16, valid, out_kind);
+}
+
+// ---- device-side result columns ---------------------------------------------------------------------------
+static int finalize_on_device(vnm_agg* h, FinArgs& f, void* out_values, uint8_t* out_bitmap, int64_t* null_count, hipStream_t s) {
+    const int64_t n = h->n_groups;
+    f.n = n;
+    f.out = out_values;
+    f.bitmap = (unsigned long long*)out_bitmap;
+    if (null_count) *null_count = 0;
+    if (n == 0) return 0;
+    unsigned long long* ctl = (unsigned long long*)pool_alloc(64);
+    if (!ctl) return 1;
+    VNM_HIP(hipMemsetAsync(ctl, 0, 16, s));
+    f.ctl = ctl;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_info().num_cus * 16);
+    {
+        KernelTimer timer("agg_finalize", s);
+        agg_finalize_kernel<<<grid, 256, 0, s>>>(f);
+    }
+    VNM_HIP(hipGetLastError());
+    unsigned long long c[2] = {0, 0};
+    VNM_HIP(hipMemcpyAsync(c, ctl, 16, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    pool_free(ctl);
+    if (null_count) *null_count = (int64_t)c[0];
+    return c[1] ? 2 : 0;
+}
+
+int vnm_agg_result_key_device(vnm_agg* h, int key_idx, void* out_values, uint8_t* out_bitmap, int64_t* null_count, void* stream) {
+    if (!h) return set_error("vnm_agg_result_key_device: null handle");
+    if (key_idx < 0 || key_idx >= h->plan.n_keys) return set_error("vnm_agg_result_key_device: key index out of range");
+    VNM_TRY(vnm_agg_finish(h, nullptr, stream));
+    FinArgs f{};
+    f.is_key = 1;
+    f.key_bit = key_idx;
+    f.out_width = type_width(h->plan.key_types[key_idx]);
+    if (h->n_groups > 0) {
+        f.words[1] = h->dkey + (size_t)key_idx * h->dstride;
+        f.words[0] = h->dkey + (size_t)h->plan.n_keys * h->dstride;
+    }
+    return finalize_on_device(h, f, out_values, out_bitmap, null_count, as_stream(stream));
+}
+
+int vnm_agg_result_func_device(vnm_agg* h, int func_idx, void* out_values, uint8_t* out_bitmap, int* out_kind, int64_t* null_count,
+                               void* stream) {
+    if (!h) return set_error("vnm_agg_result_func_device: null handle");
+    if (func_idx < 0 || func_idx >= h->n_funcs) return set_error("vnm_agg_result_func_device: function index out of range");
+    VNM_TRY(vnm_agg_finish(h, nullptr, stream));
+    const FuncOut& fo = h->outs[func_idx];
+    const int t = fo.in_type;
+    FinArgs f{};
+    f.fo = fo;
+    int kind = VNM_OUT_U64, width = 8;
+    switch (fo.func) {
+        case VNM_COUNT_STAR: case VNM_COUNT: break;
+        case VNM_MIN: case VNM_MAX:  // type preserving (agg_func_factory.cpp:35-107)
+            kind = t == VNM_F64 ? VNM_OUT_F64 : (t == VNM_F32 ? VNM_OUT_F32 : (type_is_unsigned(t) ? VNM_OUT_U64 : VNM_OUT_I64));
+            width = type_width(t);
+            break;
+        case VNM_SUM:
+            if (type_is_float(t)) kind = VNM_OUT_F64;
+            else if (t == VNM_I32 && (fo.in_flags & VNM_FLAG_SUM32)) { kind = VNM_OUT_I32; width = 4; }
+            else kind = type_is_unsigned(t) ? VNM_OUT_U64 : VNM_OUT_I64;
+            break;
+        default:
+            f.out_f32 = (t == VNM_I8 || t == VNM_I16 || t == VNM_U8 || t == VNM_U16);
+            kind = f.out_f32 ? VNM_OUT_F32 : VNM_OUT_F64;
+            width = f.out_f32 ? 4 : 8;
+            break;
+    }
+    f.out_width = width;
+    if (out_kind) *out_kind = kind;
+    if (h->n_groups > 0) {
+        auto word = [&](int w) -> const uint64_t* { return w >= 0 ? h->dacc + (size_t)w * h->dstride : nullptr; };
+        f.words[0] = word(fo.w_valid);
+        f.words[1] = word(fo.w_a);
+        f.words[2] = word(fo.w_b);
+    }
+    return finalize_on_device(h, f, out_values, out_bitmap, null_count, as_stream(stream));
 }
 
 // host-only helpers: plan lowering and finalisation from accumulator words (no GPU needed)

@@ -18,6 +18,7 @@ enum AccKind : int {
     A_COUNT_ROWS = 0,  // word += 1                                   CountStarFunc  agg_funcs.h:97-127
     A_COUNT_VALID,     // word += valid                               CountFunc      :129-161
     A_SUM_F64,         // valid: (double)word += (double)x            SumFunc/AvgFunc double path :294-305,455-467
+                       //        (compensated: the rounding error of every add goes to word + 1, see M_ADD_F64C)
     A_SUM_I64,         // valid: word += (int64)x  (wraparound)       SumFunc int64_t/uint64_t accumulators
     A_SUM_LO32,        // valid: word += (uint64)(x & 0xffffffff)     } 128-bit sum of int64/uint64 inputs
     A_SUM_HI32S,       // valid: word += (int64)x >> 32 (arithmetic)  } (SumOverflowFunc :319-435, hugeint AVG)
@@ -25,7 +26,13 @@ enum AccKind : int {
     A_MIN,             // valid: word = min(word, enc(x))             MinMaxFunc :164-216 (total-order encoding)
     A_MAX,             // valid: word = max(word, enc(x))
 };
-enum MergeKind : int { M_ADD_U64 = 0, M_ADD_F64, M_MIN_U64, M_MAX_U64 };
+// M_ADD_F64C: high word of a COMPENSATED float64 sum.  Every add into it (per row, LDS table -> HBM table, rank -> rank)
+// is a returning atomic add; the exact rounding error of that add (Knuth's TwoSum, an error-free transformation) is added
+// to the word that follows it (an ordinary M_ADD_F64 word).  hi + lo then equals the exact sum up to second-order terms
+// (~n * 2^-106 relative to sum |x|) whatever the order of the adds was, so the finalised double is the correctly rounded
+// exact sum except within ~2^-50 of a rounding tie -- where a sequential float64 loop (the reference, agg_funcs.h:294-305)
+// is off by up to n/2 ULP and a plain atomic sum differs from run to run.
+enum MergeKind : int { M_ADD_U64 = 0, M_ADD_F64, M_MIN_U64, M_MAX_U64, M_ADD_F64C };
 
 struct AccOp {
     int kind;  // AccKind

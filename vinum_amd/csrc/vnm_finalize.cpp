@@ -1,5 +1,7 @@
 // Host side of the aggregate: lowering of (function, input type) onto accumulator words, and the
 // finalisation of result columns from those words.  Pure host code (unit-tested without a GPU).
+#include <cstdlib>
+
 #include "vnm_agg.hpp"
 
 namespace vnm {
@@ -84,8 +86,11 @@ int build_plan(int kind, int n_keys, const int* key_types, int n_funcs, const in
         } else if (f == VNM_SUM || f == VNM_AVG) {
             if (w_sum[c] < 0) {
                 if (type_is_float(t)) {
-                    w_sum[c] = new_word(M_ADD_F64);
-                    if (w_sum[c] < 0 || !add_op(A_SUM_F64, c, w_sum[c])) return set_error(too_many);
+                    // compensated sum: (hi, lo) word pair, see M_ADD_F64C.  VNM_AGG_PLAIN_FSUM=1 keeps the single
+                    // float64 word (order-dependent rounding; measurement aid only)
+                    static const bool plain = getenv("VNM_AGG_PLAIN_FSUM") != nullptr;
+                    w_sum[c] = new_word(plain ? M_ADD_F64 : M_ADD_F64C);
+                    if (w_sum[c] < 0 || (!plain && new_word(M_ADD_F64) < 0) || !add_op(A_SUM_F64, c, w_sum[c])) return set_error(too_many);
                 } else if (t == VNM_I64 || t == VNM_U64) {
                     w_sum[c] = new_word(M_ADD_U64);
                     w_hi[c] = new_word(M_ADD_U64);
@@ -99,6 +104,7 @@ int build_plan(int kind, int n_keys, const int* key_types, int n_funcs, const in
             }
             o.w_a = w_sum[c];
             o.w_b = w_hi[c];
+            if (type_is_float(t) && plan->merge[w_sum[c]] == M_ADD_F64C) o.w_b = w_sum[c] + 1;
         } else if (f == VNM_MIN) {
             if (w_min[c] < 0) {
                 w_min[c] = new_word(M_MIN_U64);
@@ -141,6 +147,14 @@ static bool fits_i64(i128 x) {
     return false;
 }
 static bool fits_u64(i128 x) { return (int64_t)(x >> 64) == 0; }
+
+// float64 sum of a group: hi (+ lo of the compensated pair, see M_ADD_F64C)
+static inline double fsum_word(const FuncOut& fo, const uint64_t* const* words, int64_t r) {
+    double hi, lo = 0.0;
+    memcpy(&hi, &words[fo.w_a][r], 8);
+    if (fo.w_b >= 0) memcpy(&lo, &words[fo.w_b][r], 8);
+    return hi + lo;
+}
 
 static inline i128 sum128(const FuncOut& fo, const uint64_t* const* words, int64_t r) {
     uint64_t lo = words[fo.w_a][r];
@@ -197,6 +211,7 @@ int finalize_func(const FuncOut& fo, int64_t n, const uint64_t* const* words, vo
                 valid[r] = words[fo.w_valid][r] > 0;
                 if (!valid[r]) continue;
                 uint64_t w = words[fo.w_a][r];
+                if (type_is_float(t)) { const double d = fsum_word(fo, words, r); memcpy(&w, &d, 8); }
                 if (t == VNM_I32 && (fo.in_flags & VNM_FLAG_SUM32)) w = (uint64_t)(int64_t)(int32_t)(uint32_t)w;
                 put8(r, &w);
             }
@@ -221,9 +236,7 @@ int finalize_func(const FuncOut& fo, int64_t n, const uint64_t* const* words, vo
                     avg = hugeint_to_double(q);
                     avg += hugeint_to_double(rem) / (double)cnt;
                 } else if (type_is_float(t)) {
-                    double s;
-                    memcpy(&s, &words[fo.w_a][r], 8);
-                    avg = s / (double)cnt;
+                    avg = fsum_word(fo, words, r) / (double)cnt;
                 } else if (type_is_unsigned(t)) {
                     avg = (double)words[fo.w_a][r] / (double)cnt;
                 } else {

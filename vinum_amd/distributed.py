@@ -116,7 +116,7 @@ def exchange_partition_aligned(agg, make_merged, device, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     kw0, aw0 = agg.layout()
-    nfin = agg.run_partitions() if aw0 <= 3 else 0   # the LDS merge kernel holds at most 3 accumulator words per group
+    nfin = agg.run_partitions()   # 0 unless every word add-merges and the group fits the LDS merge table
     t = torch.tensor([nfin, -nfin], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     if int(t[0]) <= 0 or int(t[0]) != -int(t[1]) or nfin < world:
@@ -140,6 +140,11 @@ def exchange_partition_aligned(agg, make_merged, device, group=None):
     for c in rc.tolist():
         offs.append(offs[-1] + c)
     merged = make_merged()
-    merged.merge_partitioned(world, nlocal, recv.data_ptr(), offs, pc_recv.data_ptr())
+    ok = merged.merge_partitioned(world, nlocal, recv.data_ptr(), offs, pc_recv.data_ptr())
+    # A merged partition that outgrows the LDS table (ranks with disjoint key sets) is a per-rank event, but what
+    # follows must stay collective-free AND consistent: the rows are already here, so the rank that could not merge
+    # them partition by partition merges the same rows through its HBM table instead -- no second exchange.
+    if not ok:
+        merged.merge_rows(int(recv.shape[0]), recv.data_ptr())
     merged._keep = (recv, pc_recv)
     return merged

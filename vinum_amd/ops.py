@@ -100,6 +100,7 @@ class DeviceAggregate:
             else:
                 p, g = physical_type(t)
                 it.append(p); fl.append(g); ids.append(col if col is not None else -1)
+        self._spec = (kind, kt, ft, it, fl, ids)
         self._h = L.lib().vnm_agg_create(kind, len(kt), _ints(kt), len(ft), _ints(ft), _ints(it), _ints(fl), _ints(ids))
         if not self._h:
             raise RuntimeError(L.last_error())
@@ -131,6 +132,18 @@ class DeviceAggregate:
         L.check(L.lib().vnm_agg_layout(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
+    def word_layout(self):
+        """How this operator's functions lower onto accumulator words (vnm_agg_plan_host): {'n_key_words', 'merge':
+        merge kind per word, 'ops': [(update kind, distinct input column, word)]}."""
+        kind, kt, ft, it, fl, ids = self._spec
+        nkw, nw, nops = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        mk = (ctypes.c_int * 40)()
+        op3 = (ctypes.c_int * (3 * 48))()
+        L.check(L.load().vnm_agg_plan_host(kind, len(kt), _ints(kt), len(ft), _ints(ft), _ints(it), _ints(fl), _ints(ids),
+                                           ctypes.byref(nkw), ctypes.byref(nw), mk, ctypes.byref(nops), op3))
+        return {"n_key_words": nkw.value, "merge": [mk[w] for w in range(nw.value)],
+                "ops": [(op3[3 * o], op3[3 * o + 1], op3[3 * o + 2]) for o in range(nops.value)]}
+
     def dense_ptrs(self):
         kw, aw = self.layout()
         K = (ctypes.c_void_p * max(kw, 1))()
@@ -159,8 +172,14 @@ class DeviceAggregate:
         return list(counts)
 
     def merge_partitioned(self, world, nlocal, rows_ptr, src_row_offsets, part_counts_ptr, stream=None):
+        """False when a merged partition does not fit the LDS merge table (ranks holding disjoint key sets): the
+        handle is still empty and the caller falls back to merge_rows on the same rows."""
         offs = (ctypes.c_int64 * (world + 1))(*src_row_offsets)
-        L.check(L.lib().vnm_agg_merge_partitioned(self._h, world, nlocal, rows_ptr, offs, part_counts_ptr, _stream_ptr(stream)))
+        rc = L.lib().vnm_agg_merge_partitioned(self._h, world, nlocal, rows_ptr, offs, part_counts_ptr, _stream_ptr(stream))
+        if rc == 2:
+            return False
+        L.check(rc)
+        return True
 
     def merge_rows(self, n, rows_ptr, stream=None):
         L.check(L.lib().vnm_agg_merge_rows(self._h, n, rows_ptr, _stream_ptr(stream)))
@@ -193,6 +212,39 @@ class DeviceAggregate:
             arrays.append(_func_array(f, in_t, kind.value, cells, valid))
         return pa.RecordBatch.from_arrays(arrays, names=names)
 
+    def result_device(self, key_indices=None, stream=None):
+        """BaseAggregate::Result with the columns LEFT IN HBM: selected group keys first, then the functions
+        (base_aggregate.cpp:47-68), finalised by a device kernel straight into Arrow-layout buffers (typed values +
+        validity bitmap) -- no accumulator words cross PCIe.  Returns DeviceColumns.  An int64 / uint64 SUM that
+        overflows 64 bits (-> decimal128, agg_funcs.h:366-389) raises NeedsHostFinalize: use result_arrays()."""
+        lib = L.lib()
+        n = self.finish(stream=stream)
+        if key_indices is None:
+            key_indices = range(len(self.key_arrow))
+        cols = []
+        nb = ((n + 63) // 64) * 8
+
+        def column(call, arrow_type_of):
+            vals = DeviceBuffer(max(n, 1) * 8)
+            bitmap = DeviceBuffer(max(nb, 8))
+            nulls = ctypes.c_int64(0)
+            kind = ctypes.c_int(-1)
+            rc = call(vals, bitmap, kind, nulls)
+            if rc == 2:
+                raise NeedsHostFinalize(L.last_error() or "a 64-bit SUM overflowed: decimal128 result")
+            L.check(rc)
+            return DeviceColumn(vals, bitmap if nulls.value else None, 0, n, arrow_type_of(kind.value))
+
+        for j in key_indices:
+            cols.append(column(lambda v, b, k, nl, j=j: lib.vnm_agg_result_key_device(self._h, j, v.ptr, b.ptr, ctypes.byref(nl),
+                                                                                       _stream_ptr(stream)),
+                               lambda kind, j=j: self.key_arrow[j]))
+        for i, (f, col, in_t) in enumerate(self.funcs):
+            cols.append(column(lambda v, b, k, nl, i=i: lib.vnm_agg_result_func_device(self._h, i, v.ptr, b.ptr, ctypes.byref(k),
+                                                                                        ctypes.byref(nl), _stream_ptr(stream)),
+                               lambda kind, f=f, in_t=in_t: _func_arrow_type(f, in_t, kind)))
+        return cols
+
     def close(self):
         if getattr(self, "_h", None):
             L.lib().vnm_agg_destroy(self._h)
@@ -203,6 +255,30 @@ class DeviceAggregate:
             self.close()
         except Exception:
             pass
+
+
+class NeedsHostFinalize(RuntimeError):
+    """The result column changes type on the host (int64 SUM -> decimal128): use DeviceAggregate.result_arrays()."""
+
+
+def _func_arrow_type(f, in_t, kind) -> pa.DataType:
+    """Output type of one aggregate function (agg_func_factory.cpp: COUNT -> uint64 :31-34; MIN/MAX type-preserving
+    :35-107; SUM :108-176; AVG :177-247)."""
+    if f in (L.MIN, L.MAX):
+        return in_t
+    if kind == L.OUT_U64:
+        return pa.uint64()
+    if kind == L.OUT_I64:
+        if f == L.SUM and in_t is not None and (pa.types.is_time64(in_t) or pa.types.is_duration(in_t)):
+            return in_t
+        return pa.int64()
+    if kind == L.OUT_I32:
+        return in_t
+    if kind == L.OUT_F64:
+        return pa.float64()
+    if kind == L.OUT_F32:
+        return pa.float32()
+    return pa.decimal128(38, 0)
 
 
 def _func_array(f, in_t, kind, cells, valid) -> pa.Array:
