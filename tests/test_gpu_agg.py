@@ -747,3 +747,58 @@ def test_scan_kernel_nullable_input(vtype, pred, groups):
             b = O.filter_batch(b, O.cmp_mask(b.column(t.schema.names.index(spec[0])), spec[3], spec[2]))
         o.next(b)
     util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"nullable {vtype} pred={pred} G={groups}")
+
+
+@pytest.mark.parametrize("case", ["uniform", "negative_sorted", "uint64_high", "sample_misses", "second_batch_shifted", "heavy_key", "p1_7", "nonquantised"])
+@pytest.mark.parametrize("hint", [0, 600_000])
+def test_dense_key_partitioned_path(case, hint, monkeypatch):
+    """Dense-key path (vnm_agg_dense.inc): int64 / uint64 keys whose sampled range fits 29 bits travel as scrambled
+    codes, the final pass direct-addresses its LDS accumulators.  Checked bit-exact against the oracle: negative and
+    sorted keys (the scrambling must spread them), keys above 2^63, keys the sample never saw (they spill to the scan
+    kernel), a later batch outside the code range, one key holding a third of the rows (region overflow -> spill)."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    if case == "p1_7":
+        monkeypatch.setenv("VNM_DENSE_P1", "3")
+    rng = np.random.default_rng(len(case) + hint)
+    n = 1_500_000
+    groups = 900_000
+    base = rng.integers(0, groups, n).astype(np.int64)
+    v = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
+    kt = np.int64
+    if case == "negative_sorted":
+        k = np.sort(base) - 450_000
+    elif case == "uint64_high":
+        k = base.astype(np.uint64) + np.uint64(2**63 + 12345)
+        kt = np.uint64
+    elif case == "sample_misses":
+        k = base.copy()
+        k[7::200_003] = 50_000_000          # far outside the sampled range, never on a sampled row stride
+        k[11::190_001] = -3
+    elif case == "heavy_key":
+        k = base.copy()
+        k[rng.random(n) < 0.33] = 4242
+    else:
+        k = base
+    if case == "nonquantised":
+        v = rng.lognormal(2.0, 1.0, n)
+    cols = {"k": pa.array(k.astype(kt)), "v": pa.array(v)}
+    t = pa.table(cols)
+    batches = util.sliced_batches(t, 1_000_000)
+    if case == "second_batch_shifted":
+        k2 = (rng.integers(0, groups, 600_000) + 5_000_000).astype(np.int64)
+        t2 = pa.table({"k": pa.array(k2), "v": pa.array(rng.integers(0, 2**14, 600_000).astype(np.float64) / 128.0)})
+        batches = t.to_batches() + t2.to_batches()
+    funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.COUNT_STAR, "", "n")]
+    for pred in (("v", ">", 64.0), None):
+        got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=pred, expected_groups=hint)
+        o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+        for b in batches:
+            if pred:
+                b = O.filter_batch(b, O.cmp_mask(b.column(1), O.GT, 64.0))
+            o.next(b)
+        exp = o.result()
+        if case == "nonquantised":   # float sums: exactly rounded here, sequential in the oracle -> compare keys / counts bitwise
+            util.assert_batches_equal(got.select(["k", "n"]), exp.select(["k", "n"]), key_names=["k"], what=f"dense {case}")
+        else:
+            util.assert_agg_equal(got, exp, funcs, ["k"], what=f"dense {case} hint={hint} pred={pred}")

@@ -1642,9 +1642,9 @@ __device__ __forceinline__ void pa_block_add(uint32_t* dst, uint32_t v) {
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
 }
 
-__global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void part_agg_kernel(PartAggArgs a) {
-    // 40 KB per workgroup, so that FOUR fit a CU (the pass is latency-bound: 1 / 2 / 3 resident workgroups ran at
-    // 5.6 / 3.3 / 2.6 ms).  The last PA_DEAD slots of the key table are never used (they hold a reserved marker that
+__global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void part_agg_kernel(PartAggArgs a) {
+    // 48 KB per workgroup (40 KB before the compensation terms of the float64 sums: FOUR fitted a CU then, three now;
+    // the pass is latency-bound: 1 / 2 / 3 / 4 resident workgroups ran at 5.6 / 3.3 / 2.6 / 2.4 ms).  The last PA_DEAD slots of the key table are never used (they hold a reserved marker that
     // probes step over), which pays for the scalars below and for the accumulators of the two keys that cannot live in
     // the table: EMPTY (the free marker) and PA_RESERVED itself, at lsum / lcnt [PA_LIVE] and [PA_LIVE + 1].
     constexpr int PA_DEAD = 8, PA_LIVE = PA_SLOTS - PA_DEAD;
@@ -2352,6 +2352,8 @@ __global__ __launch_bounds__(256) void key_unpack_kernel(PackParams p, const uin
 }
 
 
+#include "vnm_agg_dense.inc"
+
 // =======================================================================================================
 // Device-side finalisation: BaseAggregate::Result / SummarizeGroups (base_aggregate.cpp:47-68) and the Summarize
 // methods of the aggregate functions (agg_funcs.h:72-80 generic, :358-397 int64 sum, :482-491 + :519-540 AVG incl.
@@ -2521,6 +2523,10 @@ struct vnm_agg {
     vnm_agg* inner = nullptr;
     bool pack_tried = false;
     bool key_only_failed = false;  // COUNT(*)-only programs: 8-byte entries overflowed a region once (skewed keys)
+    // dense-key partitioned path (vnm_agg_dense.inc): 0 = range not sampled yet, 1 = code map valid, -1 = not applicable
+    int dense_state = 0;
+    DenseMap dmap{};
+    int64_t dense_span = 0;  // 2^bits: upper bound of the groups a dense run can hold
     PackParams pack{};
     int c_funcs[AGG_MAX_FUNCS], c_in_types[AGG_MAX_FUNCS], c_in_flags[AGG_MAX_FUNCS], c_in_col_ids[AGG_MAX_FUNCS];
     bool c_has_ids = false;
@@ -2636,7 +2642,9 @@ void drop_run(vnm_agg* h) {
 }
 
 // distinct-key estimate from a strided sample (tiered: a small sample settles small G cheaply)
-int estimate_groups(vnm_agg* h, const vnm_dcol& key, int64_t nrows, int64_t* est, hipStream_t s) {
+// tier0_lb (optional): when the small sample cannot settle G (most sampled keys distinct) return right there with
+// *est = 0 and a LOWER bound of G from the uniform model -- the dense-key path only needs to know that G is large.
+int estimate_groups(vnm_agg* h, const vnm_dcol& key, int64_t nrows, int64_t* est, hipStream_t s, int64_t* tier0_lb = nullptr) {
     const uint64_t* kp = (const uint64_t*)key.values + key.offset;
     int64_t sizes[2] = {std::min<int64_t>(nrows, 1 << 18), std::min<int64_t>(nrows, 1 << 24)};
     *est = 0;
@@ -2662,6 +2670,16 @@ int estimate_groups(vnm_agg* h, const vnm_dcol& key, int64_t nrows, int64_t* est
         if (d == 0) d = 1;
         if ((double)d / (double)m < 0.125 || m == nrows) {  // the sample saw (nearly) every group
             *est = (int64_t)((double)d * (m == nrows ? 1.0 : 1.15)) + 1;
+            return 0;
+        }
+        if (tier0_lb) {
+            const double frac = std::min(0.97, (double)d / (double)m);  // beyond 0.97 the sample has no resolution: G >= ~16 m
+            double lo = 1e-9, hi = 64.0;
+            for (int it = 0; it < 80; it++) {
+                const double x = 0.5 * (lo + hi);
+                if ((1.0 - exp(-x)) / x > frac) lo = x; else hi = x;
+            }
+            *tier0_lb = (int64_t)((double)m / (0.5 * (lo + hi)));
             return 0;
         }
     }
@@ -2949,6 +2967,160 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     }
     h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
     h->run_dir = dir; h->run_nfin = nfinal;
+    h->have_run = true;
+    return 0;
+}
+
+
+// ---- dense-key partitioned path: host side (kernels in vnm_agg_dense.inc) ------------------------------------
+// Sample the key range of the first large batch and derive the code map.  dense_state = 1 when the (widened) range fits
+// DP_MAX_BITS bits and is large enough to fill the chip with final partitions.
+int plan_dense(vnm_agg* h, const vnm_dcol& key, int64_t nrows, hipStream_t s) {
+    h->dense_state = -1;
+    if (key.type != VNM_I64 && key.type != VNM_U64) return 0;
+    const uint64_t sign = key.type == VNM_I64 ? 0x8000000000000000ULL : 0ULL;
+    const uint64_t* kp = (const uint64_t*)key.values + key.offset;
+    unsigned long long* d = (unsigned long long*)pool_alloc(64);
+    if (!d) return 1;
+    const unsigned long long init[2] = {~0ULL, 0ULL};
+    unsigned long long got[2];
+    VNM_HIP(hipMemcpyAsync(d, init, 16, hipMemcpyHostToDevice, s));
+    const int64_t m = std::min<int64_t>(nrows, 1 << 18);
+    const int grid = (int)std::min<int64_t>((m + 255) / 256, (int64_t)device_info().num_cus * 4);
+    dense_sample_range_kernel<<<grid, 256, 0, s>>>(kp, nrows, m, sign, d);
+    VNM_HIP(hipGetLastError());
+    VNM_HIP(hipMemcpyAsync(got, d, 16, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    pool_free(d);
+    if (got[0] > got[1]) return 0;
+    // widen by 1/8 of the sampled span on both sides (the sample misses the true extremes), then centre the range in
+    // the next power of two
+    const uint64_t span_s = got[1] - got[0];
+    if (span_s >= (1ULL << DP_MAX_BITS)) return 0;
+    const uint64_t margin = span_s / 8 + 4096;
+    uint64_t lo = got[0] > margin ? got[0] - margin : 0;
+    uint64_t hi = got[1] < ~0ULL - margin ? got[1] + margin : ~0ULL;
+    int bits = 1;
+    while (bits < 64 && ((hi - lo) >> bits) != 0) bits++;
+    if (bits > DP_MAX_BITS) return 0;
+    if (bits < DP_TBITS + 9) return 0;  // fewer than 512 final partitions: the LDS scan / hash paths serve small ranges
+    const uint64_t extra = ((1ULL << bits) - 1) - (hi - lo);
+    lo = lo > extra / 2 ? lo - extra / 2 : 0;
+    DenseMap& mp = h->dmap;
+    mp.lo_u = lo;
+    mp.sign = sign;
+    mp.bits = bits;
+    mp.mask = (uint32_t)((1ULL << bits) - 1);
+    mp.mul = (uint32_t)((double)(1ULL << bits) * 0.6180339887498949) | 1u;  // Fibonacci hashing on `bits` bits
+    uint32_t inv = mp.mul;                                                     // Newton: inverse modulo 2^32
+    for (int it = 0; it < 5; it++) inv *= 2u - mp.mul * inv;
+    mp.mul_inv = inv;
+    h->dense_span = (int64_t)1 << bits;
+    h->dense_state = 1;
+    return 0;
+}
+
+// returns 0 = done (run stored), 2 = not applicable / failed (caller continues with the hash-partitioned path), 1 = error
+int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s, ulonglong2** spill_out, int64_t* n_spill_out) {
+    const int cus = device_info().num_cus;
+    const DenseMap& mp = h->dmap;
+    const int pbits = mp.bits - DP_TBITS;
+    const int levels = pbits > 9 ? 2 : 1;
+    int p1 = levels == 2 ? (int)env_i64("VNM_DENSE_P1", (pbits + 1) / 2) : pbits;
+    if (levels == 2) { if (p1 > 9) p1 = 9; if (pbits - p1 > 9) p1 = pbits - 9; }
+    const int p2 = pbits - p1;
+    const int np1 = 1 << p1, np2 = levels == 2 ? 1 << p2 : 0;
+    const int64_t tile1 = PT_TILE;
+    const int grid1 = (int)std::min<int64_t>((int64_t)cus * 2, (nrows + tile1 - 1) / tile1);
+    int split2 = std::max(2, (grid1 + PT_MAX_REGIONS - 1) / PT_MAX_REGIONS);
+    split2 = std::max(split2, std::min(grid1, (cus * 2 + np1 - 1) / np1));
+    const int64_t tiles_per_wg = ((nrows + tile1 - 1) / tile1 + grid1 - 1) / grid1;
+    const int64_t rows_per_wg = tiles_per_wg * tile1;
+    const int64_t cap1 = ((rows_per_wg / np1 + rows_per_wg / np1 / 5 + 512) + 7) & ~7LL;
+    const bool c16_1 = levels == 1;  // pass-1 remainders fit 16 bits when they are the final slots
+    unsigned long long* flags = (unsigned long long*)pool_alloc(64);
+    double* v1 = (double*)pool_alloc((size_t)np1 * grid1 * cap1 * 8);
+    void* c1 = pool_alloc((size_t)np1 * grid1 * cap1 * (c16_1 ? 2 : 4));
+    uint32_t* n1 = (uint32_t*)pool_alloc((size_t)np1 * grid1 * 4);
+    const int64_t spill_cap = nrows / 2 + (1 << 20);
+    ulonglong2* spill = (ulonglong2*)pool_alloc((size_t)spill_cap * 16);
+    double* v2 = nullptr; void* c2 = nullptr; uint32_t* n2 = nullptr;
+    uint64_t* rk = nullptr; uint64_t* ra = nullptr;
+    auto release = [&]() { pool_free(flags); pool_free(v1); pool_free(c1); pool_free(n1); pool_free(v2); pool_free(c2); pool_free(n2); };
+    if (!flags || !v1 || !c1 || !n1 || !spill) { release(); pool_free(spill); return 1;}
+    VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
+    DPartArgs d1{};
+    d1.map = mp;
+    d1.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
+    d1.vp = (const double*)a.cols[0].values + a.cols[0].offset;
+    d1.pp = h->pred_set ? (const double*)a.pred.values + a.pred.offset : nullptr;
+    d1.has_pred = h->pred_set; d1.pred_is_v = a.hot_pred_is_v; d1.op = a.p.op; d1.thr = a.p.dval;
+    d1.nrows = nrows;
+    d1.out_vals = v1; d1.out_codes = c1; d1.out_counts = n1; d1.out_cap = cap1;
+    d1.nparts = np1; d1.out_bits = mp.bits - p1;
+    d1.flags = flags; d1.spill = spill; d1.spill_cap = spill_cap;
+    {
+        KernelTimer timer("agg_part_scatter1", s);
+        if (c16_1) dpart_scatter_kernel<true, uint16_t><<<grid1, PT_BLOCK, 0, s>>>(d1);
+        else dpart_scatter_kernel<true, uint32_t><<<grid1, PT_BLOCK, 0, s>>>(d1);
+    }
+    VNM_HIP(hipGetLastError());
+    const double* fin_v = v1; const void* fin_c = c1; const uint32_t* fin_n = n1;
+    int64_t fin_cap = cap1;
+    int fin_regions = grid1;
+    if (levels == 2) {
+        const int64_t per_pg = (int64_t)grid1 * rows_per_wg / np1 / split2;
+        const int64_t cap2 = ((per_pg / np2 + per_pg / np2 / 4 + 256) + 7) & ~7LL;
+        v2 = (double*)pool_alloc((size_t)np1 * np2 * split2 * cap2 * 8);
+        c2 = pool_alloc((size_t)np1 * np2 * split2 * cap2 * 2);
+        n2 = (uint32_t*)pool_alloc((size_t)np1 * np2 * split2 * 4);
+        if (!v2 || !c2 || !n2) { release(); pool_free(spill); return 1; }
+        DPartArgs d2{};
+        d2.map = mp;
+        d2.in_vals = v1; d2.in_codes = (const uint32_t*)c1; d2.in_counts = n1; d2.in_cap = cap1;
+        d2.in_regions = grid1; d2.in_split = split2; d2.in_bits = mp.bits - p1;
+        d2.out_vals = v2; d2.out_codes = c2; d2.out_counts = n2; d2.out_cap = cap2;
+        d2.nparts = np2; d2.out_bits = DP_TBITS;
+        d2.flags = flags; d2.spill = spill; d2.spill_cap = spill_cap;
+        {
+            KernelTimer timer("agg_part_scatter2", s);
+            dpart_scatter_kernel<false, uint16_t><<<np1 * split2, PT_BLOCK, 0, s>>>(d2);
+        }
+        VNM_HIP(hipGetLastError());
+        fin_v = v2; fin_c = c2; fin_n = n2; fin_cap = cap2; fin_regions = split2;
+    }
+    const int64_t nfinal = (int64_t)1 << pbits;
+    const int64_t dstride = std::min<int64_t>(h->dense_span, nrows) + 2;
+    rk = (uint64_t*)pool_alloc((size_t)dstride * 8 * 2);
+    ra = (uint64_t*)pool_alloc((size_t)dstride * 8 * h->plan.n_words);
+    if (!rk || !ra) { release(); pool_free(spill); pool_free(rk); pool_free(ra); return 1; }
+    DFinalArgs df{};
+    df.map = mp;
+    df.vals = fin_v; df.codes = fin_c; df.counts = fin_n; df.cap = fin_cap; df.regions = fin_regions; df.nfinal = nfinal;
+    df.w_rows = a.hot_w_rows; df.w_valid = a.hot_w_valid; df.w_sum = a.hot_w_sum;
+    df.w_lo = a.hot_comp && a.hot_w_sum >= 0 ? a.hot_w_sum + 1 : -1;
+    df.dkey = rk; df.dacc = ra; df.dstride = dstride; df.flags = flags;
+    {
+        KernelTimer timer("agg_part_final", s);
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)dpart_final_kernel<uint16_t>, DF_BLOCK, 0) != hipSuccess || occ < 1) occ = 4;
+        const int g3 = (int)std::min<int64_t>(nfinal, (int64_t)cus * std::min(occ, (int)env_i64("VNM_PA_OCC", 8)));
+        dpart_final_kernel<uint16_t><<<g3, DF_BLOCK, 0, s>>>(df);
+    }
+    VNM_HIP(hipGetLastError());
+    unsigned long long fl[3];
+    VNM_HIP(hipMemcpyAsync(fl, flags, 24, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    release();
+    if (fl[0]) {  // spill buffer full, dense output too small, or a compensation term beyond float range
+        pool_free(rk); pool_free(ra); pool_free(spill);
+        return 2;
+    }
+    if (fl[2]) { *spill_out = spill; *n_spill_out = (int64_t)fl[2]; }
+    else { pool_free(spill); *spill_out = nullptr; *n_spill_out = 0; }
+    if ((int64_t)fl[2] > nrows / 16) h->dense_state = -1;  // the sampled range does not describe the data: stop trying
+    h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
+    h->run_dir = nullptr; h->run_nfin = 0;
     h->have_run = true;
     return 0;
 }
@@ -3324,26 +3496,53 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         if (narrow && h->plan.n_cols == 0 && !h->key_only_failed && getenv("VNM_AGG_NO_KEY_ONLY") == nullptr) a.part_wide = 1;
     }
     // no hint from the caller: estimate the group count once from a sample of the first large batch
+    // Dense-key path (vnm_agg_dense.inc): the north-star shape over an int64 / uint64 key whose (sampled) range fits 29
+    // bits.  It needs to know that G is LARGE, not how large: when the small sample of the estimator cannot settle G, its
+    // lower bound is enough (span <= 32 G: the direct-addressed slots are reasonably filled) and the HyperLogLog pass
+    // (0.85 ms) is skipped; the hash-partitioned path below still estimates properly if the dense attempt fails.
+    const bool dense_shape = hot && part_ok && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) && getenv("VNM_AGG_NO_DENSE") == nullptr;
+    if (dense_shape && h->dense_state == 0) {
+        KernelTimer timer("agg_estimate", s);
+        VNM_TRY(plan_dense(h, keys[0], nrows, s));
+    }
+    bool dense_go = false;
+    int64_t dense_lb = 0;
     if (part_ok && h->hint == 0 && !h->estimated && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
         getenv("VNM_AGG_NO_ESTIMATE") == nullptr) {
         int64_t est = 0;
+        const bool want_lb = dense_shape && h->dense_state == 1;
         {
             KernelTimer timer("agg_estimate", s);
-            VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s));
+            VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s, want_lb ? &dense_lb : nullptr));
+            if (est == 0 && !(h->dense_span <= 32 * dense_lb && h->dense_span <= 4 * nrows)) {
+                dense_lb = 0;
+                VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s));  // too sparse for the dense path: full estimate
+            }
         }
-        h->hint = est;
-        h->estimated = true;
+        if (est) { h->hint = est; h->estimated = true; }
+        else dense_go = true;
     }
+    if (dense_shape && h->dense_state == 1 && h->hint > 0 && h->dense_span <= 32 * h->hint && h->dense_span <= 4 * nrows) dense_go = true;
     // many groups: radix-partitioned path (no per-row HBM atomics); falls through when it does not apply
     // ... from the point where the groups stop fitting the LDS table of the scan kernel (flush storms otherwise:
     // MIN+MAX with 2000 groups and a 2048-slot table ran at 38 ms)
     const int64_t part_min = env_i64("VNM_AGG_PART_MIN_GROUPS", std::min<int64_t>(2400, (int64_t)S * 6 / 10));
     ulonglong2* spill = nullptr;  // entries the partitioned path could not place (heavy keys): aggregated below
     int64_t n_spill = 0;
-    if (part_ok && h->hint > part_min && getenv("VNM_AGG_NO_PART") == nullptr) {
+    if (part_ok && (h->hint > part_min || dense_go) && getenv("VNM_AGG_NO_PART") == nullptr) {
         if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
         const bool can_spill = hot_scan && !hot_two && !hot_vnull && getenv("VNM_AGG_NO_SPILL") == nullptr;
-        int prc = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
+        int prc = 2;
+        if (dense_go && (h->hint > part_min || h->hint == 0)) {
+            prc = dense_partitioned_aggregate(h, a, nrows, s, &spill, &n_spill);
+            if (prc == 2 && h->hint == 0) {  // the dense attempt failed before G was ever estimated
+                int64_t est = 0;
+                VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s));
+                h->hint = est;
+                h->estimated = true;
+            }
+        }
+        if (prc == 2 && h->hint > part_min) prc = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
         if (prc == 2 && a.part_wide && h->plan.n_cols == 0) {  // key-only entries and a region overflowed: see above
             h->key_only_failed = true;
             a.part_wide = 0;
