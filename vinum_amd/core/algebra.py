@@ -130,29 +130,27 @@ class SortOperator(Operator):
 
 
 class SliceOperator(Operator):
-    """algebra.py:204-247: LIMIT / OFFSET over the batch stream."""
+    """LIMIT / OFFSET over the batch stream (algebra.py:204-247).  Rows are counted across batches; a batch that is only
+    partly wanted is narrowed to a VIEW of the same HBM buffers (Arrow offset + length, as pa.RecordBatch.slice does on
+    the host) -- nothing is copied and nothing leaves the device."""
 
     def __init__(self, limit: int, offset: int, parent_operator: Operator):
         super().__init__(parent_operator)
-        self._limit, self._offset = limit, offset
+        self._limit, self._offset = int(limit), int(offset)
 
     def next(self):
-        returned, cur = 0, 0
+        skip, want = self._offset, self._limit
         for batch in self._parent_operator.next():
-            if returned >= self._limit:
+            if want <= 0:
                 break
-            if self._offset >= cur + batch.num_rows:
-                cur += batch.num_rows
+            n = batch.num_rows
+            if skip >= n:
+                skip -= n
                 continue
-            off = max(self._offset - cur, 0)
-            size = min(self._limit - returned, batch.num_rows - off)
-            if size < batch.num_rows:
-                ab = batch.to_arrow().slice(off, size)
-                yield DeviceRecordBatch.from_arrow(ab)
-            else:
-                yield batch
-            returned += size
-            cur += off + size
+            take = min(want, n - skip)
+            yield batch if (skip == 0 and take == n) else batch.slice(skip, take)
+            want -= take
+            skip = 0
 
 
 class MaterializeTableOperator(Operator):

@@ -28,6 +28,10 @@ class DeviceRecordBatch:
             raise ValueError(f'Column "{name}" is not found.')   # record_batch.py:74-75
         return self.columns[name]
 
+    def slice(self, offset: int, length: int) -> "DeviceRecordBatch":
+        """Zero-copy row range (vinum/arrow/record_batch.py:92-95): every column becomes a view with a larger Arrow offset."""
+        return DeviceRecordBatch({n: c.slice(offset, length) for n, c in self.columns.items()}, length)
+
     def to_arrow(self) -> pa.RecordBatch:
         return pa.RecordBatch.from_arrays([c.to_arrow() for c in self.columns.values()], names=list(self.columns))
 

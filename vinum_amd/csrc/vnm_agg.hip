@@ -3003,7 +3003,7 @@ int plan_dense(vnm_agg* h, const vnm_dcol& key, int64_t nrows, hipStream_t s) {
     int bits = 1;
     while (bits < 64 && ((hi - lo) >> bits) != 0) bits++;
     if (bits > DP_MAX_BITS) return 0;
-    if (bits < DP_TBITS + 9) return 0;  // fewer than 512 final partitions: the LDS scan / hash paths serve small ranges
+    if (bits < DP_TBITS_MIN + 9) return 0;  // fewer than 512 final partitions: the LDS scan / hash paths serve small ranges
     const uint64_t extra = ((1ULL << bits) - 1) - (hi - lo);
     lo = lo > extra / 2 ? lo - extra / 2 : 0;
     DenseMap& mp = h->dmap;
@@ -3024,9 +3024,16 @@ int plan_dense(vnm_agg* h, const vnm_dcol& key, int64_t nrows, hipStream_t s) {
 int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s, ulonglong2** spill_out, int64_t* n_spill_out) {
     const int cus = device_info().num_cus;
     const DenseMap& mp = h->dmap;
-    const int pbits = mp.bits - DP_TBITS;
+    // slots per final partition: the largest table that still leaves >= 2048 final partitions (8 per CU)
+    int tb = (int)env_i64("VNM_DENSE_TBITS", 12);
+    tb = std::max(DP_TBITS_MIN, std::min(DP_TBITS_MAX, tb));
+    while (tb > DP_TBITS_MIN && mp.bits - tb < 11) tb--;
+    while (tb < DP_TBITS_MAX && mp.bits - tb > 18) tb++;
+    const int pbits = mp.bits - tb;
     const int levels = pbits > 9 ? 2 : 1;
-    int p1 = levels == 2 ? (int)env_i64("VNM_DENSE_P1", (pbits + 1) / 2) : pbits;
+    // pass 1 moves 12-byte entries out of 16-byte rows, pass 2 moves 10-byte entries out of 12: the SMALLER fan-out goes
+    // to pass 1, whose write runs are the shorter ones (measured at b = 27: p1 = 7 / 8 -> 4.9 / 5.6 ms for pass 1)
+    int p1 = levels == 2 ? (int)env_i64("VNM_DENSE_P1", pbits / 2) : pbits;
     if (levels == 2) { if (p1 > 9) p1 = 9; if (pbits - p1 > 9) p1 = pbits - 9; }
     const int p2 = pbits - p1;
     const int np1 = 1 << p1, np2 = levels == 2 ? 1 << p2 : 0;
@@ -3080,7 +3087,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         d2.in_vals = v1; d2.in_codes = (const uint32_t*)c1; d2.in_counts = n1; d2.in_cap = cap1;
         d2.in_regions = grid1; d2.in_split = split2; d2.in_bits = mp.bits - p1;
         d2.out_vals = v2; d2.out_codes = c2; d2.out_counts = n2; d2.out_cap = cap2;
-        d2.nparts = np2; d2.out_bits = DP_TBITS;
+        d2.nparts = np2; d2.out_bits = tb;
         d2.flags = flags; d2.spill = spill; d2.spill_cap = spill_cap;
         {
             KernelTimer timer("agg_part_scatter2", s);
@@ -3102,10 +3109,16 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     df.dkey = rk; df.dacc = ra; df.dstride = dstride; df.flags = flags;
     {
         KernelTimer timer("agg_part_final", s);
-        int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)dpart_final_kernel<uint16_t>, DF_BLOCK, 0) != hipSuccess || occ < 1) occ = 4;
-        const int g3 = (int)std::min<int64_t>(nfinal, (int64_t)cus * std::min(occ, (int)env_i64("VNM_PA_OCC", 8)));
-        dpart_final_kernel<uint16_t><<<g3, DF_BLOCK, 0, s>>>(df);
+#define VNM_DFIN(TB_)                                                                                                  \
+    do {                                                                                                              \
+        const int blk = TB_ >= 13 ? 1024 : 512;                                                                       \
+        int occ = 0;                                                                                                  \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)dpart_final_kernel<uint16_t, TB_>, blk, 0) != hipSuccess || occ < 1) occ = 1; \
+        const int g3 = (int)std::min<int64_t>(nfinal, (int64_t)cus * std::min(occ, (int)env_i64("VNM_PA_OCC", 8)));   \
+        dpart_final_kernel<uint16_t, TB_><<<g3, blk, 0, s>>>(df);                                                     \
+    } while (0)
+        if (tb == 11) VNM_DFIN(11); else if (tb == 12) VNM_DFIN(12); else VNM_DFIN(13);
+#undef VNM_DFIN
     }
     VNM_HIP(hipGetLastError());
     unsigned long long fl[3];

@@ -158,6 +158,12 @@ class DeviceColumn:
     def __len__(self):
         return self.length
 
+    def slice(self, offset: int, length: int) -> "DeviceColumn":
+        """View of rows [offset, offset + length): same HBM buffers, Arrow offset moved (no copy)."""
+        offset = max(0, min(int(offset), self.length))
+        length = max(0, min(int(length), self.length - offset))
+        return DeviceColumn(self._values, self._validity, self.offset + offset, length, self.arrow_type, keep=(self, self._keep))
+
     def to_numpy(self) -> np.ndarray:
         w = _WIDTH[self.vnm_type]
         raw = np.empty((self.offset + self.length) * w, np.uint8)
