@@ -172,7 +172,7 @@ def vectorize(expr, registry=None, classes=None):
         else:
             built = [build(a) for a in args]
         return VE(built, function=fn, is_numpy_func=(ftype == FT.NUMPY), is_binary_func=(member in BIN))
-    return build(e)
+    return build(expr)
 
 
 # ---- the adapter ---------------------------------------------------------------------------------------------------
