@@ -243,16 +243,21 @@ void vnm_sort_op_destroy(vnm_sort_op* h);
  * replaces the NumPy ufunc dispatch vinum/core/expressions.py:13-24 as evaluated by
  * VectorizedExpression.evaluate (vinum/core/base.py:105-125,145-151) and ProjectOperator._kernel
  * (vinum/core/algebra.py:52-64): one fused kernel per output expression, no temporaries.
- * Program = postfix opcode stream.  NumPy promotion: int op int -> int64 (wraparound), `/` -> float64,
- * int op float -> float64, `%` = floor-mod (sign of divisor). */
+ * Program = postfix opcode stream over columns of ANY numeric width (int8..uint64, float32, float64).  NumPy
+ * promotion (2.x / NEP 50): floats win (float32 only survives 8 / 16-bit integers), same-signedness integers widen,
+ * unsigned + signed -> the next wider signed type (uint64 + signed -> float64), integer results wrap in the result
+ * width, `/` -> float64 (float32 for float32 with narrow integers), `%` = floor-mod (sign of the divisor); a literal
+ * (VNM_EX_CONST_*) is "weak" and takes the column's type (arg = 1 makes it a strong int64 / float64 value, what an IN
+ * list is); a column with NULLs is evaluated as float64 with NaN (float32 stays float32). */
 typedef struct vnm_expr_ins {
     int32_t op;  /* enum vnm_expr_op */
     int32_t arg; /* column index for VNM_EX_COL */
     double imm_f;
     int64_t imm_i;
 } vnm_expr_ins;
-/* out_type (returned): VNM_F64 / VNM_I64 with out_values = length*8 bytes, or VNM_MASK_U8 (predicate) with
- * out_values = length bytes (BETWEEN / IN are compiled to AND / OR chains by the caller). */
+/* out_type (returned): the vnm_type of the result, values stored with that type's width (a buffer of length*8 bytes
+ * always suffices), or VNM_MASK_U8 (predicate) with out_values = length bytes (BETWEEN / IN are compiled to AND / OR
+ * chains by the caller). */
 int vnm_project(int n_ins, const vnm_expr_ins* program, int n_cols, const vnm_dcol* cols, int64_t length,
                 void* out_values, int* out_type, void* stream);
 /* A whole SELECT list in one pass (ProjectOperator._kernel evaluates every expression of the list over the same

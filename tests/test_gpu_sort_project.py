@@ -3,6 +3,7 @@ real reference (Sort) and from NumPy ufuncs exactly as the reference dispatches 
 import numpy as np
 import pyarrow as pa
 import pytest
+import warnings
 
 from tests import util
 
@@ -250,6 +251,104 @@ def test_random_expressions_vs_numpy(seed):
         if ref.dtype.kind == "f":
             both_nan = np.isnan(got) & np.isnan(ref)
             same = (got.view(np.uint64) == np.ascontiguousarray(ref).view(np.uint64)) | both_nan
+        else:
+            same = got == ref
+        assert same.all(), f"seed {seed}: {e}: row {int(np.argmin(same))}: {got[np.argmin(same)]!r} vs {ref[np.argmin(same)]!r}"
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS", "40")))))
+def test_random_expressions_narrow_types_vs_numpy(seed):
+    """The same differential test over EVERY numeric Arrow width (int8..uint64, float32, float64; some columns with
+    NULLs): result types, wraparound of narrow integers, float32 arithmetic, weak Python literals, comparisons
+    (int64 vs uint64 exactly, float32 against a literal in float32), IN lists (np.isin: strong int64 / float64) must be
+    what NumPy (vinum/core/expressions.py:13-48 dispatches to it node by node) produces, bit for bit."""
+    from vinum_amd.device import DeviceColumn
+    from vinum_amd import ops
+    rng = np.random.default_rng(91000 + seed)
+    n = int(rng.choice([1, 257, 4096, 4097, 30_001]))
+    makers = {
+        "i8": lambda: rng.integers(-128, 128, n).astype(np.int8), "i16": lambda: rng.integers(-2**15, 2**15, n).astype(np.int16),
+        "i32": lambda: rng.integers(-2**31, 2**31, n).astype(np.int32), "i64": lambda: rng.integers(-2**40, 2**40, n).astype(np.int64),
+        "u8": lambda: rng.integers(0, 256, n).astype(np.uint8), "u16": lambda: rng.integers(0, 2**16, n).astype(np.uint16),
+        "u32": lambda: rng.integers(0, 2**32, n).astype(np.uint32), "u64": lambda: rng.integers(0, 2**63, n).astype(np.uint64) * np.uint64(2) + np.uint64(1),
+        "f32": lambda: (rng.normal(0, 50, n)).astype(np.float32), "f64": lambda: rng.normal(0, 50, n),
+    }
+    names = list(rng.choice(list(makers), size=4, replace=False))
+    arrow, npv = {}, {}
+    for nm in names:
+        vals = makers[nm]()
+        mask = (rng.random(n) < 0.1) if rng.random() < 0.25 else None
+        arr = pa.array(vals, mask=mask)
+        arrow[nm] = arr
+        # what the reference hands to NumPy: to_numpy, NULL -> NaN (ints become float64, float32 stays float32)
+        npv[nm] = arr.to_numpy(zero_copy_only=False) if arr.null_count else vals
+    dev = {k: DeviceColumn.from_arrow(v) for k, v in arrow.items()}
+    arith = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "mod": np.mod}
+    bits = {"band": np.bitwise_and, "bor": np.bitwise_or, "bxor": np.bitwise_xor}
+    cmps = {"eq": lambda x, y: x == y, "ne": lambda x, y: x != y, "gt": lambda x, y: x > y, "ge": lambda x, y: x >= y,
+            "lt": lambda x, y: x < y, "le": lambda x, y: x <= y}
+
+    def lit():
+        return int(rng.integers(0, 100)) if rng.random() < 0.6 else float(rng.choice([0.5, -2.25, 0.1, 3.0]))
+
+    def gen(depth):
+        r = rng.random()
+        if depth == 0 or r < 0.3:
+            return str(rng.choice(names)) if rng.random() < 0.7 else lit()
+        if r < 0.38:
+            return (str(rng.choice(["neg", "bnot"])), gen(depth - 1))
+        pool = list(arith) * 3 + list(bits)
+        return (str(rng.choice(pool)), gen(depth - 1), gen(depth - 1))
+
+    def has_col(e):
+        return isinstance(e, str) or (isinstance(e, tuple) and any(has_col(x) for x in e[1:]))
+
+    def ev(e):
+        if isinstance(e, str):
+            return npv[e]
+        if isinstance(e, (int, float)):
+            return e
+        if e[0] == "neg":
+            return np.negative(ev(e[1]))
+        if e[0] == "bnot":
+            return ~ev(e[1])
+        if e[0] in ("in", "not_in"):
+            return np.isin(ev(e[1]), list(e[2]), invert=e[0] == "not_in")
+        f = arith.get(e[0]) or bits.get(e[0]) or cmps[e[0]]
+        return f(ev(e[1]), ev(e[2]))
+
+    cases = []
+    tries = 0
+    while len(cases) < 6 and tries < 400:
+        tries += 1
+        e = gen(3)
+        if not (isinstance(e, tuple) and has_col(e)):
+            continue
+        kind = rng.random()
+        if kind < 0.3:
+            e = (str(rng.choice(list(cmps))), e, gen(1))
+        elif kind < 0.4:
+            e = (str(rng.choice(["in", "not_in"])), str(rng.choice(names)), tuple(lit() for _ in range(3)))
+        try:
+            with np.errstate(all="ignore"), warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ref = np.asarray(ev(e))
+        except (TypeError, OverflowError):
+            # NumPy refuses (bitwise on floats, uint64 with a signed type, a literal out of range): so must we
+            with pytest.raises(Exception):
+                ops.project_many([e], dev, length=n)
+            continue
+        cases.append((e, np.broadcast_to(ref, (n,))))
+    outs = ops.project_many([e for e, _ in cases], dev, length=n)
+    for (e, ref), out in zip(cases, outs):
+        got = out.to_numpy()
+        if ref.dtype == np.bool_:
+            assert out.arrow_type == pa.uint8() and (got.astype(bool) == ref).all(), (seed, e)
+            continue
+        assert got.dtype == ref.dtype, (seed, e, got.dtype, ref.dtype)
+        if ref.dtype.kind == "f":
+            it = np.uint64 if ref.dtype == np.float64 else np.uint32
+            same = (got.view(it) == np.ascontiguousarray(ref).view(it)) | (np.isnan(got) & np.isnan(ref))
         else:
             same = got == ref
         assert same.all(), f"seed {seed}: {e}: row {int(np.argmin(same))}: {got[np.argmin(same)]!r} vs {ref[np.argmin(same)]!r}"

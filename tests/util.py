@@ -48,6 +48,13 @@ def _bits(arr: pa.Array):
     raw = arr.view(view_t) if t != view_t else arr
     vals = raw.fill_null(0).to_numpy(zero_copy_only=False).astype(np.uint64)
     vals = np.where(valid, vals, 0)
+    if pa.types.is_floating(t):
+        # NaN sign / payload bits are not part of the comparison: the reference's own NaN bits depend on the CPU it runs on
+        # (x86 SUBSD hands back the NaN operand, 0/0 is the NEGATIVE "real indefinite"; gfx950 negates the NaN of `a - b`
+        # and generates positive NaNs).  Every NaN compares as the canonical quiet NaN.
+        f = arr.fill_null(0).to_numpy(zero_copy_only=False)
+        canon_nan = {2: 0x7E00, 4: 0x7FC00000, 8: 0x7FF8000000000000}[width]
+        vals = np.where(np.isnan(f) & valid, np.uint64(canon_nan), vals)
     return valid, vals
 
 

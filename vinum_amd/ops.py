@@ -349,11 +349,17 @@ _EX = {"add": L.EX_ADD, "sub": L.EX_SUB, "mul": L.EX_MUL, "div": L.EX_DIV, "mod"
        "and": L.EX_AND, "or": L.EX_OR, "not": L.EX_NOT}
 
 
+_ARROW_OF = {L.I8: pa.int8(), L.I16: pa.int16(), L.I32: pa.int32(), L.I64: pa.int64(), L.U8: pa.uint8(), L.U16: pa.uint16(),
+             L.U32: pa.uint32(), L.U64: pa.uint64(), L.F32: pa.float32(), L.F64: pa.float64()}
+
+
 def _desugar(e):
     """BETWEEN / IN rewrite onto the primitive predicates, exactly what the reference's callables compute:
     between -> logical_and(x >= low, x <= high), not_between -> logical_or(x < low, x > high)
     (vinum/core/expressions.py:43-48); in / not_in -> np.isin(x, values[, invert]) (:39-40)."""
     if not isinstance(e, tuple):
+        return e
+    if e[0] == "strong":
         return e
     op, args = e[0], [_desugar(x) for x in e[1:]]
     if op == "between":
@@ -364,6 +370,10 @@ def _desugar(e):
         vals = list(e[2])
         if not vals:
             raise ValueError("IN with an empty list")
+        # np.isin turns the list into an ARRAY (int64 / float64: strong types), unlike a bare literal operand
+        if any(isinstance(v, float) for v in vals):
+            vals = [float(v) for v in vals]
+        vals = [("strong", v) for v in vals]
         if op == "in":
             return ("or",) + tuple(("eq", args[0], v) for v in vals) if len(vals) > 1 else ("eq", args[0], vals[0])
         return ("and",) + tuple(("ne", args[0], v) for v in vals) if len(vals) > 1 else ("ne", args[0], vals[0])
@@ -382,6 +392,8 @@ def _emit_expr(expr, col_index, out):
             out.append((L.EX_CONST_I, 0, 0.0, int(e)))
         elif isinstance(e, float):
             out.append((L.EX_CONST_F, 0, float(e), 0))
+        elif e[0] == "strong":
+            out.append((L.EX_CONST_F, 1, float(e[1]), 0) if isinstance(e[1], float) else (L.EX_CONST_I, 1, 0.0, int(e[1])))
         elif e[0] in ("is_null", "is_not_null"):
             out.append((L.EX_IS_NULL if e[0] == "is_null" else L.EX_IS_NOT_NULL, col_index[e[1]], 0.0, 0))
         else:
@@ -428,8 +440,7 @@ def project(expr, columns: dict, length=None, stream=None) -> DeviceColumn:
                                 _stream_ptr(stream)))
     if ot.value == L.MASK_U8:
         return DeviceColumn(out, None, 0, length, pa.uint8())   # byte mask (predicate program)
-    t = pa.float64() if ot.value == L.F64 else pa.int64()
-    return DeviceColumn(out, None, 0, length, t)
+    return DeviceColumn(out, None, 0, length, _ARROW_OF[ot.value])
 
 
 def project_many(exprs, columns: dict, length=None, stream=None):
@@ -470,7 +481,7 @@ def project_many(exprs, columns: dict, length=None, stream=None):
         L.check(L.lib().vnm_project_multi(len(prog), prog, len(cols), dcol_array(cols), length, len(ks), ptrs, types,
                                           _stream_ptr(stream)))
         for k, b, t in zip(ks, bufs, types):
-            at = pa.uint8() if t == L.MASK_U8 else (pa.float64() if t == L.F64 else pa.int64())
+            at = pa.uint8() if t == L.MASK_U8 else _ARROW_OF[t]
             result[k] = DeviceColumn(b, None, 0, length, at)
     return result
 
