@@ -48,7 +48,10 @@ def parse():
     ap.add_argument("--selectivity", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-hint", action="store_true", help="do not tell the operator the group count (it estimates it)")
+    ap.add_argument("--hint", action="store_true",
+                    help="tell the operator the group count (vnm_agg_set_hint).  The reference's operator boundary has no such "
+                         "argument, so the headline is the HINT-LESS run: the operator samples the keys itself")
+    ap.add_argument("--no-hint", action="store_true", help=argparse.SUPPRESS)  # r01 spelling of what is now the default
     return ap.parse_args()
 
 
@@ -109,12 +112,69 @@ def cpu_baseline(args, x_thr):
     batches = [make(chunk) for _ in range(n_batches)]
     t = run(batches)
     kind = "reference" if (use_ref or args.workload == "filter") else "port"
-    return {"value": n_batches * chunk / t, "unit": "rows/s", "cores": 1, "kind": kind,
+    all_cores = None
+    try:
+        all_cores = cpu_baseline_all_cores(args, x_thr, use_ref)
+    except Exception as e:  # reporting only
+        all_cores = {"value": None, "error": str(e)}
+    return {"value": n_batches * chunk / t, "unit": "rows/s", "cores": 1, "kind": kind, "all_cores": all_cores,
             "sample": f"{n_batches} batches x {chunk} rows of the same synthetic workload "
                       f"(G={groups}, s={args.selectivity}), single-threaded like the reference executor; "
                       + ("NumPy compare + pyarrow filter" if args.workload == "filter" else
                          ("NumPy compare + pyarrow filter + reference SingleNumericalHashAggregate (oracle/_ref)"
                           if use_ref else "NumPy compare + pyarrow filter + oracle port of the aggregate"))}
+
+
+def _cpu_worker(q, workload, groups, x_thr, use_ref, seconds, seed):
+    """One host core: the reference's CPU path over its own stream of batches for ~`seconds` (the all-cores
+    upper bound is a simple range partition -- every core aggregates its own rows, no merge is timed)."""
+    import pyarrow as pa
+    from oracle import oracle as O
+    from oracle import ref as R
+    rng = np.random.default_rng(seed)
+    chunk = 1_000_000
+    funcs = [(O.SUM, "v", "sum_v"), (O.AVG, "v", "avg_v")]
+    batches = []
+    for _ in range(3):
+        k = rng.integers(0, groups, chunk).astype(np.int64)
+        v = rng.integers(0, 1 << 14, chunk).astype(np.float64) / 128.0
+        batches.append(pa.RecordBatch.from_arrays([pa.array(k), pa.array(v)], names=["k", "v"]))
+    agg = None
+    if workload != "filter":
+        agg = R.RefAggregate(R.SINGLE, ["k"], ["k"], funcs) if use_ref else O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    rows, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        b = batches[(rows // chunk) % len(batches)]
+        x = b.column(1).to_numpy(zero_copy_only=True)
+        fb = b.filter(pa.array(x > x_thr), null_selection_behavior="emit_null")
+        if agg is not None:
+            agg.next(fb)
+        rows += chunk
+    if agg is not None:
+        agg.result()
+    q.put((rows, time.perf_counter() - t0))
+
+
+def cpu_baseline_all_cores(args, x_thr, use_ref):
+    import multiprocessing as mp
+    cores = min(os.cpu_count() or 1, 64)
+    ctx = mp.get_context("spawn")   # the parent holds a HIP context: never fork it
+    q = ctx.Queue()
+    seconds = max(4.0, min(args.cpu_seconds, 10.0))
+    procs = [ctx.Process(target=_cpu_worker, args=(q, args.workload, int(args.groups), x_thr, use_ref, seconds, 1000 + i))
+             for i in range(cores)]
+    t0 = time.perf_counter()
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=seconds * 6 + 120) for _ in procs]
+    for p in procs:
+        p.join()
+    wall = time.perf_counter() - t0
+    rows = sum(r for r, _ in got)
+    busy = max(t for _, t in got)
+    return {"value": rows / busy, "unit": "rows/s", "cores": cores,
+            "sample": f"{cores} processes x ~{seconds:.0f} s of the same single-threaded reference path, each over its own rows "
+                      f"(range partition, merge not timed); wall {wall:.1f} s incl. process start"}
 
 
 class CudaArrayView:
@@ -134,12 +194,72 @@ def _spans(lib, ctypes, names, steps):
     return out
 
 
-def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream, args, steps=5, warmup=2):
-    """configs[1] (WHERE v > X -> compacted column) and the small-cardinality group-by (G = 7, the shape of
-    configs[0]'s query) over the headline run's resident columns.  Same timing method: HIP events per kernel."""
+AGG_SPANS = [b"agg_estimate", b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final", b"agg_finalize"]
+
+
+def _measure(torch, lib, ctypes, fn, span_names, steps, warmup):
+    """`steps` timed calls of fn after `warmup` untimed ones: wall time per step and HIP-event time per kernel span."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    lib.vnm_set_profiling(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    sp = _spans(lib, ctypes, span_names, steps)
+    lib.vnm_set_profiling(0)
+    return el / steps * 1e3, sp
+
+
+def _entry(workload, n, ms, sp, alg, result_rows, extra=None):
+    kms = sum(sp.values())
+    ach = alg / (kms * 1e-3) / 1e9 if kms else 0.0
+    e = {"workload": workload, "rows_per_s": n / (ms * 1e-3), "ms_per_step": ms, "result_rows": int(result_rows),
+         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                      "kernels_ms": {k: round(v, 4) for k, v in sp.items()}, "algorithmic_bytes": alg}}
+    if extra:
+        e.update(extra)
+    return e
+
+
+def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream, args, steps=3, warmup=1):
+    """The other single-GPU configurations of BASELINE.json over the headline run's resident columns, a few steps each,
+    same timing method (HIP events per kernel): the HINTED headline query, configs[1] (WHERE v > X -> compacted column),
+    the small-cardinality group-by (G = 7) and configs[0]'s query shape at scale, configs[4] (ORDER BY v DESC LIMIT 10
+    and the three-expression projection), and the headline query END TO END including its result columns
+    (BaseAggregate::Result: key, sum, avg finalised on the device into Arrow buffers)."""
+    from vinum_amd.device import DeviceColumn
     out = {}
+    device = torch.device("cuda", torch.cuda.current_device())
+    groups = int(args.groups)
+    state = {}
+
+    def headline(hint, finalize=False):
+        def run():
+            agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
+                                      expected_groups=hint)
+            agg.set_predicate(">", x_thr)
+            agg.next([kcol], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
+            state["ng"] = agg.finish(stream=stream)
+            if finalize:
+                state["cols"] = agg.result_device(stream=stream)   # key, sum(v), avg(v) as Arrow-layout HBM buffers
+            state["agg"] = agg
+        return run
+
+    # ---- the headline query with the group count given (vnm_agg_set_hint): not reachable through the reference boundary
+    ms, sp = _measure(torch, lib, ctypes, headline(groups), AGG_SPANS, steps, warmup)
+    out["configs[2] hinted"] = _entry(f"the headline query with expected_groups={groups:.3g} passed to the operator", n, ms, sp,
+                                      16.0 * n + 24.0 * state["ng"], state["ng"])
+    # ---- the headline query end to end: next + finish + the three result columns finalised on the device
+    ms, sp = _measure(torch, lib, ctypes, headline(0, finalize=True), AGG_SPANS, steps, warmup)
+    out["end_to_end"] = _entry("configs[2] hint-less incl. BaseAggregate::Result: key, sum(v), avg(v) finalised by a device kernel "
+                               "into Arrow-layout buffers in HBM (vnm_agg_result_*_device); input resident in HBM", n, ms, sp,
+                               16.0 * n + 24.0 * state["ng"], state["ng"])
+    state.clear()
     # ---- configs[1]
-    dst = torch.empty(n, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+    dst = torch.empty(n, dtype=torch.float64, device=device)
     cnt = ctypes.c_int64(0)
 
     def filt():
@@ -148,82 +268,50 @@ def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream,
         d = vcol.dcol()
         L.check(lib.vnm_filter_cmp(ctypes.byref(d), L.GT, 1, x_thr, 0, 1, ctypes.byref(d), ov, ob, ctypes.byref(cnt),
                                    ctypes.c_void_p(stream)))
-    for _ in range(warmup):
-        filt()
-    torch.cuda.synchronize()
-    lib.vnm_set_profiling(1)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        filt()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    sp = _spans(lib, ctypes, [b"filter_kernel"], steps)
-    lib.vnm_set_profiling(0)
-    kms = sum(sp.values())
-    alg = 8.0 * n + 8.0 * cnt.value
-    out["configs[1] filter"] = {"workload": f"WHERE v > {x_thr} over {n:.3g}-row fp64 column -> compacted column",
-                                "rows_per_s": n * steps / el, "ms_per_step": el / steps * 1e3, "result_rows": int(cnt.value),
-                                "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9 if kms else 0.0,
-                                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": (alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms else 0.0,
-                                             "kernels_ms": {k: round(v, 4) for k, v in sp.items()}, "algorithmic_bytes": alg}}
+    ms, sp = _measure(torch, lib, ctypes, filt, [b"filter_kernel"], steps + 2, warmup + 1)
+    out["configs[1] filter"] = _entry(f"WHERE v > {x_thr} over {n:.3g}-row fp64 column -> compacted column", n, ms, sp,
+                                      8.0 * n + 8.0 * cnt.value, cnt.value)
     del dst
     # ---- group-by with 7 groups: keys folded onto [0, 7) by a fused projection (k % 7), then the same query
     k7 = ops.project(("mod", "k", 7), {"k": kcol}, length=n, stream=stream)
-    ng = 0
 
     def gb():
-        nonlocal ng
         agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
-                                  expected_groups=0 if args.no_hint else 7)
+                                  expected_groups=7 if args.hint else 0)
         agg.set_predicate(">", x_thr)
         agg.next([k7], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
-        ng = agg.finish(stream=stream)
-    for _ in range(warmup):
-        gb()
-    torch.cuda.synchronize()
-    lib.vnm_set_profiling(1)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        gb()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    sp = _spans(lib, ctypes, [b"agg_estimate", b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final"], steps)
-    lib.vnm_set_profiling(0)
-    kms = sum(sp.values())
-    alg = 16.0 * n + 24.0 * ng
-    out["group-by G=7"] = {"workload": f"SELECT k,sum(v),avg(v) WHERE v>{x_thr} GROUP BY k; N={n:.3g}, 7 groups",
-                           "rows_per_s": n * steps / el, "ms_per_step": el / steps * 1e3, "result_rows": int(ng),
-                           "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9 if kms else 0.0,
-                                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": (alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms else 0.0,
-                                        "kernels_ms": {k: round(v, 4) for k, v in sp.items()}, "algorithmic_bytes": alg}}
+        state["ng"] = agg.finish(stream=stream)
+    ms, sp = _measure(torch, lib, ctypes, gb, AGG_SPANS, steps + 2, warmup + 1)
+    out["group-by G=7"] = _entry(f"SELECT k,sum(v),avg(v) WHERE v>{x_thr} GROUP BY k; N={n:.3g}, 7 groups", n, ms, sp,
+                                 16.0 * n + 24.0 * state["ng"], state["ng"])
+
     # ---- configs[0]'s query shape at scale: SELECT k, count(*) GROUP BY k (no predicate, key column only)
     def gc():
-        nonlocal ng
-        agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.COUNT_STAR, None, None)],
-                                  expected_groups=0 if args.no_hint else 7)
+        agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.COUNT_STAR, None, None)], expected_groups=7 if args.hint else 0)
         agg.next([k7], [None], nrows=n, stream=stream)
-        ng = agg.finish(stream=stream)
-    for _ in range(warmup):
-        gc()
-    torch.cuda.synchronize()
-    lib.vnm_set_profiling(1)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        gc()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    sp = _spans(lib, ctypes, [b"agg_estimate", b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final"], steps)
-    lib.vnm_set_profiling(0)
-    kms = sum(sp.values())
-    alg = 8.0 * n + 16.0 * ng
-    out["configs[0] query shape"] = {"workload": f"SELECT k,count(*) GROUP BY k; N={n:.3g}, 7 groups (the 1M-row CSV query of configs[0], at scale)",
-                                     "rows_per_s": n * steps / el, "ms_per_step": el / steps * 1e3, "result_rows": int(ng),
-                                     "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9 if kms else 0.0,
-                                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                  "frac": (alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms else 0.0,
-                                                  "kernels_ms": {k: round(v, 4) for k, v in sp.items()}, "algorithmic_bytes": alg}}
+        state["ng"] = agg.finish(stream=stream)
+    ms, sp = _measure(torch, lib, ctypes, gc, AGG_SPANS, steps + 2, warmup + 1)
+    out["configs[0] query shape"] = _entry(f"SELECT k,count(*) GROUP BY k; N={n:.3g}, 7 groups (the 1M-row CSV query of configs[0], at scale)",
+                                           n, ms, sp, 8.0 * n + 16.0 * state["ng"], state["ng"])
+    del k7
+    # ---- configs[4]: ORDER BY v DESC LIMIT 10 and `v*2+1, v-a, a*b` over 1e9 rows (v ~ N(11, 9) seed 2)
+    gg = torch.Generator(device=device); gg.manual_seed(2)
+    v4 = torch.randn(n, device=device, dtype=torch.float64, generator=gg) * 3.0 + 11.0
+    v4col = DeviceColumn.from_torch(v4)
+
+    def topk():
+        state["idx"] = ops.sort_indices([v4col], [L.DESC], limit=10, stream=stream)
+    ms, sp = _measure(torch, lib, ctypes, topk, [b"topk_select", b"radix_pass", b"topk_sample"], steps + 2, warmup + 1)
+    out["configs[4] top-K"] = _entry(f"ORDER BY v DESC LIMIT 10 over {n:.3g} fp64 rows (row ids out)", n, ms, sp, 8.0 * n + 80.0, 10)
+    ca = torch.randn(n, device=device, dtype=torch.float64, generator=gg)
+    cb = torch.rand(n, device=device, dtype=torch.float64, generator=gg)
+    cols = {"v": v4col, "a": DeviceColumn.from_torch(ca), "b": DeviceColumn.from_torch(cb)}
+
+    def proj():
+        state["outs"] = ops.project_many([("add", ("mul", "v", 2), 1), ("sub", "v", "a"), ("mul", "a", "b")], cols, length=n, stream=stream)
+    ms, sp = _measure(torch, lib, ctypes, proj, [b"project_kernel"], steps, warmup)
+    out["configs[4] projection"] = _entry(f"projection v*2+1, v-a, a*b over {n:.3g} fp64 rows (one fused kernel)", n, ms, sp, 48.0 * n, n)
+    state.clear()
     return out
 
 
@@ -304,18 +392,18 @@ def main():
             return
         if args.shape == "count_star":
             agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.COUNT_STAR, 0, None)],
-                                      expected_groups=0 if args.no_hint else groups)
+                                      expected_groups=groups if args.hint else 0)
             agg.next([kcol], [None], nrows=n, stream=stream)
         elif args.shape == "minmax":
             agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
                                       [(L.MIN, 1, pa.float64()), (L.MAX, 1, pa.float64())],
-                                      expected_groups=0 if args.no_hint else groups)
+                                      expected_groups=groups if args.hint else 0)
             agg.set_predicate(">", x_thr)
             agg.next([kcol], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
         else:
             agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
                                       [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
-                                      expected_groups=0 if args.no_hint else groups)
+                                      expected_groups=groups if args.hint else 0)
             agg.set_predicate(">", x_thr)
             agg.next([kcol], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
         ng = agg.finish(stream=stream)
@@ -388,7 +476,7 @@ def main():
         elapsed = float(t.item())
 
     names = {"filter": [b"filter_kernel"], "topk": [b"topk_select", b"radix_pass"], "project": [b"project_kernel"]}.get(
-        args.workload, [b"agg_estimate", b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final"])
+        args.workload, AGG_SPANS)
     spans = {}
     for nm in names:
         tot_ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
@@ -438,15 +526,20 @@ def main():
 
     traffic = None
     traffic_src = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            tj = json.load(f)
-        key = f"{args.workload}_N{n:.0e}_G{groups:.0e}_s{args.selectivity}"
-        if key in tj:
-            traffic = tj[key]["bytes_per_step"]
-            traffic_src = tj[key].get("source", "profiles/") + " (" + tj[key].get("how", "") + ")"
-    except Exception:
-        pass
+    # HBM bytes per step from the PMC passes of the SAME command (tools/profile.sh -> profiles/rNN_rocprofv3_pmc_*.txt),
+    # newest round first; hinted and hint-less runs take different paths, so they have different entries
+    key = f"{args.workload}_N{n:.0e}_G{groups:.0e}_s{args.selectivity}" + ("_hint" if args.hint else "")
+    for tf in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", tf)) as f:
+                tj = json.load(f)
+        except Exception:
+            continue
+        k2 = key if key in tj else (key[:-5] if tf == "r01_traffic.json" and args.hint and key[:-5] in tj else None)
+        if k2:
+            traffic = tj[k2]["bytes_per_step"]
+            traffic_src = tj[k2].get("source", "profiles/") + " (" + tj[k2].get("how", "") + ")"
+            break
     if rank == 0:
         result = {
             "metric": "rows/sec + achieved HBM GB/s, filter->group-by over 10^9-row Arrow batches",
@@ -458,6 +551,7 @@ def main():
             "dtype": "f64/int64", "data": "synthetic",
             "config": {"workload": workload, "rows_per_gpu": n, "groups": groups if args.workload == "groupby" else None,
                        "selectivity": args.selectivity, "result_rows": int(out_rows),
+                       "group_count_hint": "given (vnm_agg_set_hint)" if args.hint else "none: the operator samples the keys (what the reference boundary allows)",
                        "parallelism": f"batch-sharded x{world}" + (", RCCL all_to_all partial-aggregate exchange" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the rocprofv3 summaries kept under profiles/ (run on the GPU box: gpurun -- 'bash tools/profile.sh r01').
 # Kernel trace and each PMC counter are collected in SEPARATE runs (MI355X_MICROARCH.md, HBM section).
-R=${1:-r01}
+R=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
