@@ -41,8 +41,10 @@ class AggregateOperator(Operator):
 
     def _init(self, batch: DeviceRecordBatch):
         key_types = [batch.column(c).arrow_type for c in self._group_by]
-        if not all(_is_numeric(t) for t in key_types):
-            raise RuntimeError("GenericHashAggregate (non-numeric group keys) is not implemented on the MI355X path")
+        self._key_dicts = {c: batch.column(c).dictionary for c in self._group_by}
+        for f in self._funcs:
+            if f.column and batch.column(f.column).dictionary is not None and f.func != "COUNT":
+                raise RuntimeError(f"{f.func.lower()}() over the non-numeric column {f.column!r} is not on the GPU path")
         kind = L.ONE_GROUP if not self._group_by else (L.SINGLE_NUMERICAL if len(self._group_by) == 1 else L.MULTI_NUMERICAL)
         names = batch.column_names
         spec = []
@@ -68,4 +70,8 @@ class AggregateOperator(Operator):
                                           [f.out_name for f in self._funcs])
             self._agg.close()
             self._agg = None
-            yield DeviceRecordBatch.from_arrow(res)
+            out = DeviceRecordBatch.from_arrow(res)
+            for c in self._agg_cols:                       # dictionary-encoded keys (strings, bools ...): codes -> values later
+                if self._key_dicts.get(c) is not None:
+                    out.columns[c].dictionary = self._key_dicts[c]
+            yield out

@@ -17,10 +17,11 @@ class TableReaderOperator(Operator):
     def __init__(self, table: pa.Table, columns: Optional[Sequence[str]] = None):
         super().__init__(None)
         self._table = table.select(list(columns)) if columns is not None else table
+        self._dicts = {}     # running dictionaries of the non-numeric columns (shared by every batch of this scan)
 
     def next(self):
         for b in self._table.to_batches(max_chunksize=get_batch_size()):
-            yield DeviceRecordBatch.from_arrow(b)
+            yield DeviceRecordBatch.from_arrow(b, self._dicts)
 
 
 class FileReaderOperator(Operator):
@@ -30,6 +31,7 @@ class FileReaderOperator(Operator):
     def __init__(self, reader, columns: Optional[Sequence[str]] = None):
         super().__init__(None)
         self._reader, self._columns = reader, columns
+        self._dicts = {}
 
     def next(self):
         while True:
@@ -38,7 +40,7 @@ class FileReaderOperator(Operator):
             except StopIteration:
                 break
             names = self._columns if self._columns is not None else [f.name for f in batch.schema if is_supported(f.type)]
-            yield DeviceRecordBatch.from_arrow(batch.select(list(names)))
+            yield DeviceRecordBatch.from_arrow(batch.select(list(names)), self._dicts)
 
 
 class FilterOperator(Operator):
@@ -121,7 +123,12 @@ class SortOperator(Operator):
             if f.name in self._cols and pa.types.is_boolean(f.type):   # algebra.py:191-201
                 raise RuntimeError("Sorting by boolean column is not supported yet. "
                                    "Please use float(bool_column) as a workaround.")
-        dev = {n: DeviceColumn.from_arrow(table.column(n)) for n in table.schema.names}
+        for c in self._cols:
+            if not is_supported(table.schema.field(c).type):
+                raise RuntimeError(f"ORDER BY {c}: sorting by a non-numeric column is not on the GPU path")
+        dicts = {}
+        dev = DeviceRecordBatch.from_arrow(table.to_batches()[0] if table.num_rows else pa.RecordBatch.from_arrays(
+            [pa.array([], f.type) for f in table.schema], names=table.schema.names), dicts).columns
         n = table.num_rows
         k = self._limit if 0 < self._limit < n else 0
         idx = ops.sort_indices([dev[c] for c in self._cols], self._orders, limit=k)

@@ -15,9 +15,21 @@ class DeviceRecordBatch:
         self.num_rows = num_rows if num_rows is not None else (next(iter(columns.values())).length if columns else 0)
 
     @staticmethod
-    def from_arrow(batch: pa.RecordBatch) -> "DeviceRecordBatch":
-        return DeviceRecordBatch({n: DeviceColumn.from_arrow(batch.column(i)) for i, n in enumerate(batch.schema.names)},
-                                 batch.num_rows)
+    def from_arrow(batch: pa.RecordBatch, dictionaries: Dict = None) -> "DeviceRecordBatch":
+        """dictionaries (optional, name -> KeyDictionary, filled on demand): non-numeric columns (strings, bools, decimals)
+        are dictionary-encoded with the running dictionary of their name and staged as int32 codes."""
+        from ..device import is_supported
+        cols = {}
+        for i, n in enumerate(batch.schema.names):
+            arr = batch.column(i)
+            if dictionaries is not None and not is_supported(arr.type):
+                from ..vinum_lib import KeyDictionary
+                if n not in dictionaries:
+                    dictionaries[n] = KeyDictionary(arr.type)
+                cols[n] = DeviceColumn.from_arrow(arr, dictionary=dictionaries[n])
+            else:
+                cols[n] = DeviceColumn.from_arrow(arr)
+        return DeviceRecordBatch(cols, batch.num_rows)
 
     @property
     def column_names(self) -> List[str]:

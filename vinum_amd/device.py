@@ -79,18 +79,29 @@ class DeviceBuffer:
 
 
 class DeviceColumn:
-    def __init__(self, values, validity, offset, length, arrow_type, keep=None):
-        """values / validity: DeviceBuffer, raw int pointer, or None (validity)."""
+    def __init__(self, values, validity, offset, length, arrow_type, keep=None, dictionary=None):
+        """values / validity: DeviceBuffer, raw int pointer, or None (validity).
+        dictionary: a vinum_lib.KeyDictionary when the column holds the int32 CODES of a non-numeric column (strings,
+        bools, decimals: dictionary-encoded on ingest); to_arrow() then returns the decoded values."""
         self._values, self._validity = values, validity
         self.offset, self.length, self.arrow_type = int(offset), int(length), arrow_type
         self.vnm_type, self.flags = physical_type(arrow_type)
         self._keep = keep  # anything that must outlive the raw pointers (torch tensors)
+        self.dictionary = dictionary
+
+    def like(self, values, validity, offset, length) -> "DeviceColumn":
+        """A column of the same logical type over other buffers (filter / take / slice outputs keep the dictionary)."""
+        return DeviceColumn(values, validity, offset, length, self.arrow_type, dictionary=self.dictionary)
 
     # -- constructors -------------------------------------------------------------------------------
     @staticmethod
-    def from_arrow(arr) -> "DeviceColumn":
+    def from_arrow(arr, dictionary=None) -> "DeviceColumn":
         if isinstance(arr, pa.ChunkedArray):
             arr = arr.combine_chunks() if arr.num_chunks != 1 else arr.chunk(0)
+        if dictionary is not None:                    # non-numeric column: stage its int32 codes
+            col = DeviceColumn.from_arrow(dictionary.encode(arr))
+            col.dictionary = dictionary
+            return col
         vt, _ = physical_type(arr.type)
         w = _WIDTH[vt]
         bufs = arr.buffers()
@@ -162,7 +173,8 @@ class DeviceColumn:
         """View of rows [offset, offset + length): same HBM buffers, Arrow offset moved (no copy)."""
         offset = max(0, min(int(offset), self.length))
         length = max(0, min(int(length), self.length - offset))
-        return DeviceColumn(self._values, self._validity, self.offset + offset, length, self.arrow_type, keep=(self, self._keep))
+        return DeviceColumn(self._values, self._validity, self.offset + offset, length, self.arrow_type, keep=(self, self._keep),
+                            dictionary=self.dictionary)
 
     def to_numpy(self) -> np.ndarray:
         w = _WIDTH[self.vnm_type]
@@ -180,7 +192,8 @@ class DeviceColumn:
             L.check(L.lib().vnm_memcpy_d2h(bits.ctypes.data, self.validity_ptr, nb))
             valid = np.unpackbits(bits, bitorder="little")[self.offset:self.offset + self.length].astype(bool)
             mask = ~valid
-        return arrow_from_numpy(vals, mask, self.arrow_type)
+        out = arrow_from_numpy(vals, mask, self.arrow_type)
+        return self.dictionary.decode(out) if self.dictionary is not None else out
 
 
 def arrow_from_numpy(vals: np.ndarray, mask, t: pa.DataType) -> pa.Array:

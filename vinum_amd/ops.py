@@ -47,7 +47,7 @@ def filter_cmp(pred: DeviceColumn, op, literal, payload, stream=None):
                 bitmap = DeviceBuffer((k + 7) // 8)
                 L.check(lib.vnm_pack_validity(b.ptr, k, bitmap.ptr, _stream_ptr(stream)))
                 L.check(lib.vnm_device_synchronize())
-            outs.append(DeviceColumn(v, bitmap, 0, k, c.arrow_type))
+            outs.append(c.like(v, bitmap, 0, k))
         if not payload:
             return [], k
     return outs, (outs[0].length if outs else 0)
@@ -74,7 +74,7 @@ def filter_mask(mask: DeviceBuffer, mask_valid, length, payload, stream=None):
                 bitmap = DeviceBuffer((k + 7) // 8)
                 L.check(lib.vnm_pack_validity(b.ptr, k, bitmap.ptr, _stream_ptr(stream)))
                 L.check(lib.vnm_device_synchronize())
-            outs.append(DeviceColumn(v, bitmap, 0, k, c.arrow_type))
+            outs.append(c.like(v, bitmap, 0, k))
     return outs, (outs[0].length if outs else 0)
 
 
@@ -337,7 +337,7 @@ def take(col: DeviceColumn, indices: DeviceBuffer, n, stream=None) -> DeviceColu
         bitmap = DeviceBuffer((n + 7) // 8)
         L.check(lib.vnm_pack_validity(vb.ptr, n, bitmap.ptr, _stream_ptr(stream)))
         L.check(lib.vnm_device_synchronize())
-    return DeviceColumn(vals, bitmap, 0, n, col.arrow_type)
+    return col.like(vals, bitmap, 0, n)
 
 
 # ---- projection ------------------------------------------------------------------------------------------

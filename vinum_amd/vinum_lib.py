@@ -12,8 +12,8 @@ Same names, constructor arguments, methods and error behaviour as the reference:
     TableBatchReader(table)               .next() / .set_batch_size(n)                      :144-165
     import_pyarrow() -> 0                                                                   :22-23
 
-GenericHashAggregate (string / bool / decimal keys) is outside the GPU scope: constructing it
-raises, it never silently falls back to a CPU implementation.
+    GenericHashAggregate(groupby_cols, agg_cols, agg_funcs)    string / bool / decimal keys          :92-109
+        -- dictionary-encoded on ingest, grouped on the GPU by their int32 codes, decoded in result().
 """
 import ctypes
 import enum
@@ -140,10 +140,105 @@ class OneGroupAggregate(_HashAggregateBase):
         super().__init__([], [], agg_funcs)
 
 
+class KeyDictionary:
+    """Running dictionary of one non-numeric group-by column: value -> int32 code, in order of first appearance.
+
+    The reference keys its generic map on arrow::Scalar vectors (generic_hash_aggregate.h:10-45): hash + Equals per row.
+    Here every batch is dictionary-encoded once on ingest (Arrow's C++ `dictionary_encode`, one pass), the batch-local
+    codes are mapped onto the running dictionary, and the GPU groups by 4-byte codes with the numeric machinery
+    (NULL stays NULL: its own group, as in the reference where a NULL scalar equals a NULL scalar)."""
+
+    def __init__(self, arrow_type: pa.DataType):
+        self.type = arrow_type
+        self.values = pa.array([], type=arrow_type)
+
+    def encode(self, column) -> pa.Array:
+        import numpy as np
+        import pyarrow.compute as pc
+        if isinstance(column, pa.ChunkedArray):
+            column = column.combine_chunks()
+        enc = column.dictionary_encode()
+        local = enc.dictionary
+        pos = pc.index_in(local, value_set=self.values) if len(self.values) else pa.nulls(len(local), pa.int32())
+        known = pos.is_valid().to_numpy(zero_copy_only=False)
+        mapping = pos.fill_null(0).to_numpy(zero_copy_only=False).astype(np.int32)
+        n_new = int((~known).sum())
+        if n_new:
+            mapping[~known] = len(self.values) + np.arange(n_new, dtype=np.int32)
+            fresh = local.filter(pa.array(~known))
+            self.values = pa.concat_arrays([self.values, fresh]) if len(self.values) else fresh
+        idx = enc.indices
+        codes = mapping[idx.fill_null(0).to_numpy(zero_copy_only=False).astype(np.int64)] if len(local) else np.zeros(len(idx), np.int32)
+        mask = ~idx.is_valid().to_numpy(zero_copy_only=False) if idx.null_count else None
+        return pa.array(codes, type=pa.int32(), mask=mask)
+
+    def decode(self, codes: pa.Array) -> pa.Array:
+        return self.values.take(codes)
+
+
+def _is_numeric(t: pa.DataType) -> bool:        # vinum/core/aggregate.py:63-66
+    return pa.types.is_integer(t) or pa.types.is_floating(t) or pa.types.is_temporal(t)
+
+
 class GenericHashAggregate:
-    def __init__(self, *args, **kwargs):
-        raise RuntimeError("GenericHashAggregate (string/bool/decimal group keys) is not implemented on the MI355X path; "
-                           "there is deliberately no CPU fallback (SURVEY.md §2 #1, §8f #3)")
+    """GROUP BY over keys of ANY Arrow type -- strings, bools, decimals, mixed with numeric keys
+    (vinum/core/vinum_lib.cpp:92-109, vinum_cpp/src/operators/aggregate/generic_hash_aggregate.{h,cpp}).
+
+    Non-numeric key columns are dictionary-encoded on ingest (KeyDictionary) and the query runs through the numeric GPU
+    operators (single key: the whole single-key machinery incl. the partitioned paths; several keys: packed composite
+    keys); result() maps the codes back, so key columns keep their type.  Aggregate INPUT columns must be numeric --
+    COUNT(col) of a non-numeric column counts through an int8 stand-in with the same validity; MIN / MAX of strings
+    (agg_funcs.h:219-261) are not available on the GPU path and raise."""
+
+    def __init__(self, groupby_cols, agg_cols, agg_funcs):
+        self._groupby, self._agg_cols, self._funcs = list(groupby_cols), list(agg_cols), list(agg_funcs)
+        self._inner = None
+        self._dicts = {}
+        self._stand_in = set()
+
+    def _init(self, batch: pa.RecordBatch):
+        schema = batch.schema
+        for c in self._groupby:
+            if c not in schema.names:
+                raise RuntimeError(f"Column not found: {c}")       # base_aggregate.cpp:121-131
+            t = schema.field(c).type
+            if not _is_numeric(t):
+                self._dicts[c] = KeyDictionary(t)
+        for f in self._funcs:
+            if f.column_name and f.column_name in schema.names and not _is_numeric(schema.field(f.column_name).type):
+                if f.func != AggFuncType.COUNT:
+                    raise RuntimeError({AggFuncType.MIN: "Column data type is not supported by min()/max().",
+                                        AggFuncType.MAX: "Column data type is not supported by min()/max().",
+                                        AggFuncType.SUM: "Column data type is not supported by sum().",
+                                        AggFuncType.AVG: "Column data type is not supported by avg()."}[f.func]
+                                       + " (non-numeric aggregate inputs are CPU-only in the reference; not on the GPU path)")
+                self._stand_in.add(f.column_name)
+        cls = SingleNumericalHashAggregate if len(self._groupby) == 1 else MultiNumericalHashAggregate
+        self._inner = cls(self._groupby, self._agg_cols, self._funcs)
+
+    def next(self, batch: pa.RecordBatch) -> None:
+        import numpy as np
+        if self._inner is None:
+            self._init(batch)
+        arrays, names = [], []
+        for i, name in enumerate(batch.schema.names):
+            col = batch.column(i)
+            if name in self._dicts:
+                col = self._dicts[name].encode(col)
+            elif name in self._stand_in:
+                col = pa.array(np.zeros(len(col), np.int8), mask=(~col.is_valid().to_numpy(zero_copy_only=False)) if col.null_count else None)
+            elif not _is_numeric(col.type):
+                continue                                     # neither a key nor an input: never staged
+            arrays.append(col)
+            names.append(name)
+        self._inner.next(pa.RecordBatch.from_arrays(arrays, names=names))
+
+    def result(self) -> pa.RecordBatch:
+        if self._inner is None:
+            raise RuntimeError("GenericHashAggregate.result() before any batch")
+        res = self._inner.result()
+        arrays = [self._dicts[n].decode(res.column(i)) if n in self._dicts else res.column(i) for i, n in enumerate(res.schema.names)]
+        return pa.RecordBatch.from_arrays(arrays, names=res.schema.names)
 
 
 class Sort:
