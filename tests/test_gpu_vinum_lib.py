@@ -3,6 +3,7 @@
 import numpy as np
 import pyarrow as pa
 import pytest
+import pyarrow.compute as pc
 
 from tests import util
 from tests.golden import gtest_fixtures as G
@@ -142,3 +143,87 @@ def test_random_aggregates_through_vinum_lib(seed):
     util.assert_agg_equal(agg.result(), o.result(), funcs, key_names,
                           what=f"seed {seed}: keys {[str(cols[k].type) for k in key_names]} inputs "
                                f"{[str(cols[v].type) for v in in_names]} G~{groups} off={off} cuts={cuts}")
+
+
+# ---- GenericHashAggregate: non-numeric group keys (vinum/core/vinum_lib.cpp:92-109) ---------------------------------
+def _city_table(n=250_000, seed=5):
+    rng = np.random.default_rng(seed)
+    cities = np.array([f"city_{i:03d}" for i in range(180)] + ["", "Zürich", "São Paulo"])
+    city = cities[rng.integers(0, len(cities), n)]
+    return pa.table({
+        "city_from": pa.array(city, mask=rng.random(n) < 0.02),
+        "is_rush": pa.array(rng.random(n) < 0.3, mask=rng.random(n) < 0.01),
+        "vendor": pa.array(rng.integers(0, 4, n).astype(np.int32)),
+        "total": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0, mask=rng.random(n) < 0.03),
+        "passengers": pa.array(rng.integers(1, 7, n).astype(np.int64)),
+        "note": pa.array(np.array(["a", "bb", "ccc"])[rng.integers(0, 3, n)], mask=rng.random(n) < 0.5),
+    })
+
+
+def _pa_groupby(t, keys, aggs):
+    """pyarrow's hash aggregate as the independent answer (the reference's GenericHashAggregate does not compile
+    against this image's Arrow 25, oracle/ref_build/Makefile): aggs = [(column, pyarrow function, output name)]."""
+    res = t.group_by(keys, use_threads=False).aggregate([(c if c else [], f) for c, f, _ in aggs])
+    names = [f"{c}_{f}" if c else "count_all" for c, f, _ in aggs]
+    return res.select(keys + names).rename_columns(keys + [o for _, _, o in aggs])
+
+
+@pytest.mark.parametrize("keys", [["city_from"], ["is_rush"], ["city_from", "vendor"], ["is_rush", "city_from", "vendor"]],
+                         ids=lambda k: "+".join(k))
+def test_generic_hash_aggregate_non_numeric_keys(keys):
+    """`GROUP BY city_from` -- the query shape that dominates the reference's own tests
+    (vinum/tests/test_query_results.py:436-443): string / bool keys, alone and mixed with numeric keys, NULL keys as
+    their own group, key columns keep their Arrow type."""
+    from vinum_amd import vinum_lib as V
+    t = _city_table()
+    funcs = [V.AggFuncDef(V.AggFuncType.COUNT_STAR, "", "n"), V.AggFuncDef(V.AggFuncType.SUM, "total", "s"),
+             V.AggFuncDef(V.AggFuncType.AVG, "total", "m"), V.AggFuncDef(V.AggFuncType.MAX, "passengers", "mx"),
+             V.AggFuncDef(V.AggFuncType.COUNT, "note", "notes")]
+    agg = V.GenericHashAggregate(keys, keys, funcs)
+    for b in t.to_batches(max_chunksize=60_000):
+        agg.next(b)
+    got = agg.result()
+    exp = _pa_groupby(t, keys, [("", "count_all", "n"), ("total", "sum", "s"), ("total", "mean", "m"),
+                                ("passengers", "max", "mx"), ("note", "count", "notes")])
+    assert got.schema.names == exp.schema.names
+    for k in keys:
+        assert got.schema.field(k).type == t.schema.field(k).type
+    g = pa.Table.from_batches([got]).sort_by([(k, "ascending") for k in keys])
+    e = exp.sort_by([(k, "ascending") for k in keys])
+    assert g.num_rows == e.num_rows
+    for name in g.schema.names:
+        a, b = g.column(name).combine_chunks(), e.column(name).combine_chunks()
+        if name in ("n", "notes"):
+            assert a.cast(pa.int64()).to_pylist() == b.cast(pa.int64()).to_pylist(), name
+        elif name == "m":   # quantised inputs: sums exact, one division
+            assert np.array_equal(np.array(a.to_pylist(), dtype=object), np.array(b.to_pylist(), dtype=object)), name
+        else:
+            assert a.to_pylist() == b.to_pylist(), name
+
+
+def test_generic_hash_aggregate_rejects_string_min_max():
+    from vinum_amd import vinum_lib as V
+    t = _city_table(1000)
+    agg = V.GenericHashAggregate(["vendor"], ["vendor"], [V.AggFuncDef(V.AggFuncType.MIN, "city_from", "first_city")])
+    with pytest.raises(RuntimeError, match=r"not supported by min\(\)/max\(\)"):
+        agg.next(t.to_batches()[0])
+
+
+def test_string_keys_and_distinct_through_the_planner():
+    """SELECT city_from, count(*), avg(total) ... GROUP BY city_from and SELECT DISTINCT city_from, is_rush through
+    vinum_amd.planner: non-numeric columns are dictionary-encoded at the reader, filtered / grouped as int32 codes in
+    HBM and decoded when the result is materialised."""
+    from vinum_amd import planner
+    t = _city_table(120_000, seed=9)
+    q = dict(select=["city_from", ["fn", "count_star"], ["fn", "avg", "total"]], aliases=[None, "n", "m"],
+             where=["gt", "passengers", 2], group_by=["city_from"])
+    got = planner.execute(q, t).sort_by("city_from")
+    ft = t.filter(pc.greater(t.column("passengers"), 2))
+    exp = _pa_groupby(ft, ["city_from"], [("", "count_all", "n"), ("total", "mean", "m")]).sort_by("city_from")
+    assert got.column("city_from").to_pylist() == exp.column("city_from").to_pylist()
+    assert got.column("n").cast(pa.int64()).to_pylist() == exp.column("n").to_pylist()
+    assert got.column("m").to_pylist() == exp.column("m").to_pylist()
+    d = planner.execute(dict(select=["city_from", "is_rush"], distinct=True), t)
+    exp_d = t.select(["city_from", "is_rush"]).group_by(["city_from", "is_rush"], use_threads=False).aggregate([])
+    key = lambda r: (r["city_from"] is None, r["city_from"] or "", r["is_rush"] is None, bool(r["is_rush"]))
+    assert sorted(d.to_pylist(), key=key) == sorted(exp_d.to_pylist(), key=key)
