@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--groups", type=float, default=1e8)
     ap.add_argument("--selectivity", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true",
+                    help="after the timed region: property-check the (merged) group-by result of the last step on the device -- "
+                         "survivors and totals conserved across all ranks, every merged key owned by exactly one rank")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--hint", action="store_true",
                     help="tell the operator the group count (vnm_agg_set_hint).  The reference's operator boundary has no such "
@@ -175,6 +178,43 @@ def cpu_baseline_all_cores(args, x_thr, use_ref):
     return {"value": rows / busy, "unit": "rows/s", "cores": cores,
             "sample": f"{cores} processes x ~{seconds:.0f} s of the same single-threaded reference path, each over its own rows "
                       f"(range partition, merge not timed); wall {wall:.1f} s incl. process start"}
+
+
+def check_groupby(torch, dist, state, k, v, x_thr, world, rank, device, exchanged):
+    """Size-independent properties of the LAST step's result, evaluated on the device and reduced over all ranks
+    (the data is quantised, so the float sums are exact): survivors conserved, totals conserved, no key on two ranks."""
+    from vinum_amd import _lib as L
+    agg = state.get("merged") if (world > 1 or exchanged) and state.get("merged") is not None else state["agg"]
+    if isinstance(agg, tuple):
+        agg = agg[0]
+    replicated = bool(state.get("replicated"))
+    n = agg.finish()
+    lay = agg.word_layout()
+    w_cnt = next(w for kind, col, w in lay["ops"] if kind == 1)
+    w_sum = next(w for kind, col, w in lay["ops"] if kind == 2)
+    kp, ap_ = agg.dense_ptrs()
+    def view(ptr, typestr="<i8"):
+        return torch.as_tensor(CudaArrayView(ptr, n, typestr), device=device) if n else torch.zeros(0, dtype=torch.int64, device=device)
+    keys, cnt, sm = view(kp[0]), view(ap_[w_cnt]), view(ap_[w_sum], "<f8")
+    if lay["merge"][w_sum] == L.M_ADD_F64C and n:
+        sm = sm + view(ap_[w_sum + 1], "<f8")
+    keep = v > x_thr
+    mine = 1.0 if (not replicated or rank == 0) else 0.0     # a replicated result counts once
+    t = torch.tensor([float(keep.sum()), float((v[keep] * 128.0).sum()), mine * float(cnt.sum()) if n else 0.0,
+                      mine * float((sm * 128.0).sum()) if n else 0.0, mine * float(n)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t)
+    ok = {"world_size": world, "survivors_conserved": t[0].item() == t[2].item(), "totals_conserved": t[1].item() == t[3].item(),
+          "groups_all_ranks": int(t[4].item())}
+    ok["exchange"] = state.get("exchange_kind")
+    if world > 1 and state.get("exchange_kind") == "bucketed" and n:
+        from vinum_amd import distributed as D
+        own = D.owner_of([keys, torch.zeros_like(keys)], world)
+        bad = torch.tensor([float((own != rank).sum())], dtype=torch.float64, device=device)
+        dist.all_reduce(bad)
+        ok["every_key_on_its_owner"] = bad.item() == 0.0
+    assert all(val for key, val in ok.items() if isinstance(val, bool)), f"multi-GPU result check failed: {ok}"
+    return ok
 
 
 class CudaArrayView:
@@ -430,11 +470,29 @@ def main():
             ph = state.setdefault("phases", {"bucket": 0.0, "all_to_all": 0.0, "merge": 0.0, "partition_aligned": 0.0})
             ph["partition_aligned"] += (time.perf_counter() - t_a) * 1e3
             state["merged"] = merged
+            state["exchange_kind"] = "partition_aligned"
             return out
         send = torch.empty((max(ng, 1), kw + aw), dtype=torch.int64, device=device)
         counts = agg.bucket_by_owner(world, send.data_ptr(), stream=stream)
         torch.cuda.synchronize()
         t_b = time.perf_counter()
+        # small result sets: one all_gather, every rank merges all partial rows (no all_to_all); the merged result is
+        # replicated, so only rank 0's copy counts as output rows
+        def merge_all(allrows):
+            m = make()
+            m.merge_rows(int(allrows.shape[0]), allrows.data_ptr(), stream=stream)
+            m._keep = allrows
+            return m
+        small = D.exchange_allgather_small(send[:ng], merge_all)
+        if small is not None:
+            out = small.finish(stream=stream)
+            torch.cuda.synchronize()
+            ph = state.setdefault("phases", {"bucket": 0.0, "all_to_all": 0.0, "merge": 0.0, "partition_aligned": 0.0, "allgather_small": 0.0})
+            ph["allgather_small"] = ph.get("allgather_small", 0.0) + (time.perf_counter() - t_a) * 1e3
+            state["merged"] = small
+            state["replicated"] = True
+            state["exchange_kind"] = "allgather_small"
+            return out
 
         def merge(recv):
             torch.cuda.synchronize()
@@ -450,6 +508,7 @@ def main():
             ph["all_to_all"] += (t_c - t_b) * 1e3
             ph["merge"] += (time.perf_counter() - t_c) * 1e3
             state["merged"] = (merged, recv)
+            state["exchange_kind"] = "bucketed"
             return out
 
         return D.exchange_bucketed(send[:ng], counts, merge)
@@ -475,6 +534,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    check = None
+    if args.check and args.workload == "groupby" and args.shape == "hot":
+        check = check_groupby(torch, dist, state, k, v, x_thr, world, rank, device, force_exchange)
     names = {"filter": [b"filter_kernel"], "topk": [b"topk_select", b"radix_pass"], "project": [b"project_kernel"]}.get(
         args.workload, AGG_SPANS)
     spans = {}
@@ -564,6 +626,8 @@ def main():
             "exchange_ms_per_step": ({k2: round(v2 / max(args.steps, 1), 3) for k2, v2 in state["phases"].items()}
                                      if "phases" in state else None),
         }
+        if check is not None:
+            result["check"] = check
         if world == 1 and not force_exchange and args.workload == "groupby" and args.shape == "hot" and not args.no_also:
             # the other single-GPU configurations of BASELINE.json on the same resident column, a few steps each
             # (reported beside the headline; not part of `value`)

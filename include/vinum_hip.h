@@ -134,8 +134,9 @@ int64_t vnm_filter_scratch_bytes(int64_t length);
  * Device level: keys / inputs are vnm_dcol views of HBM-resident columns. */
 typedef struct vnm_agg vnm_agg;
 
-/* in_col_ids (may be NULL): functions with equal ids read the same input column (they then share loads
- * and accumulators, e.g. SUM(v) and AVG(v)); ignored for COUNT(*). */
+/* in_col_ids (may be NULL): functions with equal NON-NEGATIVE ids read the same input column (they then share loads
+ * and accumulators, e.g. SUM(v) and AVG(v)); a negative id means "a column of its own" (never shared); ignored for
+ * COUNT(*). */
 vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
                         const int* in_types, const int* in_flags, const int* in_col_ids);
 void vnm_agg_destroy(vnm_agg* h);

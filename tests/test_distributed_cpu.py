@@ -84,3 +84,63 @@ def test_bucket_by_owner_is_a_permutation():
         assert torch.equal(own, torch.repeat_interleave(torch.arange(world), counts))
         if world > 1:
             assert counts.float().std() < 0.2 * counts.float().mean() + 50   # balanced ownership
+
+
+def _worker_small(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vinum_amd import distributed as D
+    rng = np.random.default_rng(2000 + rank)
+    n = 20_000 + 3000 * rank                       # ragged: the ranks hold different numbers of rows and groups
+    keys = rng.integers(0, 40 + 10 * rank, n).astype(np.int64) - 7
+    vals = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
+    words = _partial(keys, vals)
+    rows = torch.stack(words, dim=1).contiguous()
+
+    def merge_rows(allrows):
+        k = allrows[:, 0].numpy()
+        uk, inv = np.unique(k, return_inverse=True)
+        cnt = np.zeros(len(uk), np.uint64)
+        np.add.at(cnt, inv, allrows[:, 2].numpy().view(np.uint64))
+        sm = np.zeros(len(uk), np.float64)
+        np.add.at(sm, inv, np.ascontiguousarray(allrows[:, 3].numpy()).view(np.float64))
+        return uk, cnt, sm
+
+    assert D.exchange_allgather_small(rows, merge_rows, limit=10) is None      # above the limit on every rank: agreed fallback
+    uk, cnt, sm = D.exchange_allgather_small(rows, merge_rows)
+    # distributed ORDER BY v DESC LIMIT k: local winners -> global winners
+    v = rng.normal(size=5000)
+    v[rng.integers(0, 5000, 40)] = np.nan
+    v[rng.integers(0, 5000, 40)] = 1.25                                          # ties across ranks
+    k = 64
+    gid = np.arange(5000, dtype=np.int64) + 5000 * rank
+    key = np.where(np.isnan(v), -np.inf, v)
+    local = np.lexsort((gid, -key, np.isnan(v)))[:k]
+    tv, tid = D.topk_exchange(torch.from_numpy(v[local]), torch.from_numpy(gid[local]), k, True)
+    np.savez(os.path.join(tmp, f"small_{rank}.npz"), k=uk, c=cnt, s=sm, in_k=keys, in_v=vals, v=v, tv=tv.numpy(), tid=tid.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_small_group_allgather_exchange_and_distributed_topk_gloo(tmp_path):
+    world = 2
+    port = 29500 + ((os.getpid() + 17) % 1000)
+    mp.spawn(_worker_small, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(tmp_path / f"small_{r}.npz") for r in range(world)]
+    all_k = np.concatenate([o["in_k"] for o in outs])
+    all_v = np.concatenate([o["in_v"] for o in outs])
+    uk, inv = np.unique(all_k, return_inverse=True)
+    for o in outs:                                   # the merged result is REPLICATED: every rank holds all of it
+        assert np.array_equal(o["k"], uk)
+        assert np.array_equal(o["c"], np.bincount(inv).astype(np.uint64))
+        assert np.array_equal(o["s"], np.bincount(inv, weights=all_v))
+    v = np.concatenate([o["v"] for o in outs])
+    gid = np.arange(len(v))
+    key = np.where(np.isnan(v), -np.inf, v)
+    want = np.lexsort((gid, -key, np.isnan(v)))[:64]   # values desc, NaN last, ties by global row id
+    for o in outs:
+        assert np.array_equal(o["tid"], want)
+        assert np.array_equal(o["tv"].view(np.uint64), v[want].view(np.uint64))

@@ -3261,6 +3261,7 @@ vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs,
         h->func_col[i] = -1;
         if (funcs[i] == VNM_COUNT_STAR) continue;
         int id = in_col_ids ? in_col_ids[i] : (1000 + i);
+        if (id < 0) id = -1000 - i;   // as build_plan: negative = this function's own column
         for (int c = 0; c < nc; c++) if (ids[c] == id) h->func_col[i] = c;
         if (h->func_col[i] < 0) { ids[nc] = id; h->col_first_func[nc] = i; h->func_col[i] = nc++; }
     }

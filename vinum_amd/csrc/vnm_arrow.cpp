@@ -156,6 +156,9 @@ struct vnm_agg_op {
 };
 
 static int agg_op_init(vnm_agg_op* h, const struct ArrowSchema* sch) {
+    // a failed earlier attempt (unknown column, unsupported type) must not leave half-filled index vectors behind
+    h->key_idx.clear(); h->key_t.clear(); h->in_idx.clear(); h->in_t.clear(); h->aggcol_key.clear();
+    if (h->dev) { vnm_agg_destroy(h->dev); h->dev = nullptr; }
     // lookup_col_indices base_aggregate.cpp:121-131
     for (auto& c : h->groupby) {
         int i = find_child(sch, c);

@@ -32,6 +32,7 @@ int build_plan(int kind, int n_keys, const int* key_types, int n_funcs, const in
         col_of[i] = -1;
         if (funcs[i] == VNM_COUNT_STAR) continue;
         int id = func_col_id ? func_col_id[i] : (1000 + i);
+        if (id < 0) id = -1000 - i;   // a negative id means "no sharing": this function's column is its own
         for (int c = 0; c < ncols; c++)
             if (col_ids[c] == id) col_of[i] = c;
         if (col_of[i] < 0) {

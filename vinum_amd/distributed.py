@@ -148,3 +148,66 @@ def exchange_partition_aligned(agg, make_merged, device, group=None):
         merged.merge_rows(int(recv.shape[0]), recv.data_ptr())
     merged._keep = (recv, pc_recv)
     return merged
+
+
+# ---- small result sets: ONE all_gather, every rank merges everything ----------------------------------------------
+SMALL_G_ROWS = 1 << 20   # partial groups per rank up to which the all-gather path is used
+
+
+def gather_rows(rows: torch.Tensor, group=None):
+    """Variable-length all_gather of row blocks [n_r, ncol]: returns (all rows grouped by source rank, counts list).
+    One all_gather of the row counts + one padded all_gather of the rows."""
+    world = dist.get_world_size(group)
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    padded = torch.zeros((cap, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+    padded[: rows.shape[0]] = rows
+    out = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded, group=group)
+    return torch.cat([o[:c] for o, c in zip(out, counts)]).contiguous(), counts
+
+
+def exchange_allgather_small(rows: torch.Tensor, merge_rows, limit: int = SMALL_G_ROWS, group=None):
+    """Small-G exchange of SURVEY.md §8(e): when every rank holds at most `limit` partial groups, the runs are
+    all-gathered (a few MB) and EVERY rank merges all of them with the device merge kernel -- one collective, no
+    bucketing, no all_to_all, and the merged result is replicated instead of key-sharded.  (§8e sketches the same step
+    as all-gather of the keys + all_reduce of dense accumulator planes; an all_reduce would add the compensated float64
+    sums (hi, lo) in the transport's own order and precision, so the partial rows travel instead and are merged by the
+    library's exact merge, vnm_agg_merge_rows.)  rows: [n, n_key_words + n_acc_words] int64.
+    Returns merge_rows(all_rows) or None when some rank is above the limit (all ranks agree: one all_reduce)."""
+    t = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    if int(t.item()) > limit:
+        return None
+    allrows, _counts = gather_rows(rows, group)
+    return merge_rows(allrows)
+
+
+# ---- ORDER BY ... LIMIT K over batch-sharded rows --------------------------------------------------------------------
+def topk_exchange(values: torch.Tensor, row_ids: torch.Tensor, k: int, descending: bool, group=None):
+    """Distributed top-K: every rank passes its LOCAL first-K rows of `ORDER BY v [DESC] LIMIT k`
+    (values + GLOBAL row ids, e.g. from vnm_sort_indices with limit = k over its shard); one all_gather of K rows per
+    rank, then the same ordering rule selects the global first K on every rank: values first, NaN last in both
+    directions, ties in ascending global row id (the order Sort::Sorted gives over the concatenated table,
+    sort.cpp:22-37 -- stable).  Returns (values, row_ids) of the k winners, identical on all ranks."""
+    rows = torch.stack([values.view(torch.int64) if values.dtype == torch.float64 else values.to(torch.int64), row_ids.to(torch.int64)], dim=1)
+    allrows, _ = gather_rows(rows.contiguous(), group)
+    v = allrows[:, 0].view(torch.float64) if values.dtype == torch.float64 else allrows[:, 0]
+    ids = allrows[:, 1]
+    order = torch.argsort(ids, stable=True)                                    # ties: ascending global row id
+    v, ids = v[order], ids[order]
+    if v.dtype == torch.float64:
+        nan = torch.isnan(v)
+        key = torch.where(nan, torch.zeros_like(v), v)
+        key = torch.where(key == 0, torch.zeros_like(key), key)                # -0.0 == +0.0 (Arrow's comparison)
+        order = torch.argsort(key, descending=descending, stable=True)
+        v, ids, nan = v[order], ids[order], nan[order]
+        order = torch.argsort(nan.to(torch.int8), stable=True)                 # NaN after every number, both directions
+        v, ids = v[order], ids[order]
+    else:
+        order = torch.argsort(v, descending=descending, stable=True)
+        v, ids = v[order], ids[order]
+    return v[:k], ids[:k]
