@@ -443,7 +443,7 @@ def main():
         else:
             agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
                                       [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
-                                      expected_groups=groups if args.hint else 0)
+                                      expected_groups=groups if args.hint else 0, rank_aligned=(world > 1 or force_exchange))
             agg.set_predicate(">", x_thr)
             agg.next([kcol], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
         ng = agg.finish(stream=stream)

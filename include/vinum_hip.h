@@ -133,6 +133,7 @@ int64_t vnm_filter_scratch_bytes(int64_t length);
  *           (vinum/core/vinum_lib.cpp:54-124; vinum_cpp/src/operators/aggregate/).
  * Device level: keys / inputs are vnm_dcol views of HBM-resident columns. */
 typedef struct vnm_agg vnm_agg;
+struct vnm_expr_ins;   /* defined with the projection below */
 
 /* in_col_ids (may be NULL): functions with equal NON-NEGATIVE ids read the same input column (they then share loads
  * and accumulators, e.g. SUM(v) and AVG(v)); a negative id means "a column of its own" (never shared); ignored for
@@ -143,12 +144,29 @@ void vnm_agg_destroy(vnm_agg* h);
 /* optional fused WHERE `pred <op> literal` evaluated inside the aggregate scan (no materialised
  * filtered batch): Filter -> Aggregate of vinum/planner/planner.py:373-378,463-469 in one pass. */
 int vnm_agg_set_predicate(vnm_agg* h, int enabled, int op, int scalar_is_float, double dval, int64_t ival);
+/* Multi-GPU: the finished result of this handle will be exchanged with other ranks.  rank_aligned = 1 restricts the
+ * operator to run layouts that every rank derives identically from the keys alone (hash partitions: owner(f) = f * P / F,
+ * vnm_agg_run_partitions / _reorder / vnm_agg_merge_partitioned); the dense-key path, whose code range comes from a
+ * per-rank sample, is not used. */
+int vnm_agg_set_exchange_mode(vnm_agg* h, int rank_aligned);
 /* expected number of groups (0 = unknown): sizes the table and picks the kernel strategy */
 int vnm_agg_set_hint(vnm_agg* h, int64_t expected_groups);
 /* BaseAggregate::Next (base_aggregate.cpp:23-45).  inputs[i] is the input column of func i (ignored for
  * COUNT_STAR).  pred may be NULL when no predicate is set.  Asynchronous on `stream`. */
 int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs,
                         const vnm_dcol* pred, void* stream);
+/* Expressions inside aggregates -- `sum((1 - total) * (2 + tax) * (1 - tip))`, vinum/tests/test_query_results.py:436-443;
+ * the reference's planner projects the expression into a temporary column first (vinum/planner/planner.py:384-417).
+ * vnm_agg_set_input_expr: the input column of function `func_idx` (and of every function sharing its in_col_id; declare
+ * their input type as VNM_F64) is the value of `program` (postfix, as vnm_project; result float64) over the n_cols
+ * columns passed to vnm_agg_next_device_expr as expr_cols.  In the hot shape ({COUNT(*), COUNT, SUM, AVG} of the
+ * expression, plain 8-byte key or no GROUP BY, float64 columns without NULLs, program of + - * / negation within 16
+ * instructions / 4 columns / stack depth 4) the expression is evaluated IN REGISTERS inside the scan / partition
+ * kernels -- no materialised column; otherwise one fused vnm_project pass materialises it first.  inputs[i] of the
+ * functions reading the expression are ignored. */
+int vnm_agg_set_input_expr(vnm_agg* h, int func_idx, int n_ins, const struct vnm_expr_ins* program, int n_cols);
+int vnm_agg_next_device_expr(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs, const vnm_dcol* pred,
+                             int n_expr_cols, const vnm_dcol* expr_cols, void* stream);
 /* BaseAggregate::Result part 1: compact the table into dense device arrays; returns group count. */
 int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream);
 /* dense partial state (after finish), for the multi-GPU exchange: key words then accumulator words,

@@ -802,3 +802,71 @@ def test_dense_key_partitioned_path(case, hint, monkeypatch):
             util.assert_batches_equal(got.select(["k", "n"]), exp.select(["k", "n"]), key_names=["k"], what=f"dense {case}")
         else:
             util.assert_agg_equal(got, exp, funcs, ["k"], what=f"dense {case} hint={hint} pred={pred}")
+
+
+@pytest.mark.parametrize("shape", ["dense_large_g", "few_groups", "one_group", "with_pred", "hash_large_g", "nullable_materialised",
+                                   "int_columns_projected", "deep_materialised"])
+def test_expression_inside_aggregate(shape, monkeypatch):
+    """`SELECT k, sum(expr), avg(expr), count(*) ... GROUP BY k` with the expression handed to the aggregate
+    (vnm_agg_set_input_expr): in the hot shape it is evaluated in registers inside the dense / hash partition pass, the
+    LDS scan and the no-GROUP-BY kernel; otherwise the library materialises it with one fused projection pass.  Every
+    route must give what the reference computes -- NumPy evaluates the expression node by node into a temporary column
+    (planner.py:384-417), the aggregate sums it -- bit for bit (quantised inputs: exact products and sums)."""
+    from oracle import oracle as O
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    from vinum_amd import _lib as L
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(len(shape))
+    n = 1_300_001
+    groups = {"dense_large_g": 700_000, "hash_large_g": 300_000, "few_groups": 5, "with_pred": 2000}.get(shape, 1000)
+    k = rng.integers(0, groups, n).astype(np.int64)
+    if shape == "hash_large_g":
+        k = k * 1_000_003_337 - 99          # sparse 64-bit keys: not dense in their range -> hash-partitioned path
+    q = lambda hi: rng.integers(0, hi, n).astype(np.float64) / 128.0
+    total, tax, tip = q(128), q(64), q(32)
+    expr = ("mul", ("mul", ("sub", 1, "total"), ("add", 2, "tax")), ("sub", 1, "tip"))      # test_query_results.py:436-443
+    ref_expr = np.multiply(np.multiply(np.subtract(1, total), np.add(2, tax)), np.subtract(1, tip))
+    cols = {"total": pa.array(total), "tax": pa.array(tax), "tip": pa.array(tip)}
+    if shape == "nullable_materialised":
+        mask = rng.random(n) < 0.05
+        cols["tip"] = pa.array(tip, mask=mask)
+        ref_expr = np.multiply(np.multiply(np.subtract(1, total), np.add(2, tax)), np.subtract(1, np.where(mask, np.nan, tip)))
+    if shape == "int_columns_projected":
+        ia, ib = rng.integers(-50, 50, n).astype(np.int64), rng.integers(1, 9, n).astype(np.int64)
+        cols = {"ia": pa.array(ia), "ib": pa.array(ib)}
+        expr = ("div", ("mul", "ia", "ib"), 4)                  # int64 columns: true division -> float64
+        ref_expr = np.divide(np.multiply(ia, ib), 4)
+    if shape == "deep_materialised":
+        expr = ("add", "total", ("add", "tax", ("add", "tip", ("add", "total", ("mul", "tax", ("sub", "tip", ("neg", "total")))))))
+        ref_expr = total + (tax + (tip + (total + (tax * (tip - (-total))))))
+    names = list(cols)
+    dev = {c: DeviceColumn.from_arrow(a) for c, a in cols.items()}
+    kcol = DeviceColumn.from_numpy(k)
+    one = shape == "one_group"
+    agg = ops.DeviceAggregate(L.ONE_GROUP if one else L.SINGLE_NUMERICAL, [] if one else [pa.int64()],
+                              [(L.SUM, 77, pa.float64()), (L.AVG, 77, pa.float64()), (L.COUNT_STAR, None, None)],
+                              expected_groups=groups if shape == "hash_large_g" else 0)
+    agg.set_input_expr(0, expr, names)
+    pred = None
+    if shape == "with_pred":
+        agg.set_predicate(">", 0.25)
+        pred = dev["tax"]
+    half = 700_000
+    for lo, hi in ((0, half), (half, n)):         # two batches (the second through table / run merging)
+        sl = lambda c: c.slice(lo, hi - lo)
+        agg.next([] if one else [sl(kcol)], [None, None, None], pred=sl(pred) if pred is not None else None, nrows=hi - lo,
+                 expr_cols=[sl(dev[c]) for c in names])
+    got = agg.result_arrays([] if one else [0], [] if one else ["k"], ["s", "a", "n"])
+    agg.close()
+    keep = np.ones(n, bool) if shape != "with_pred" else tax > 0.25
+    t = pa.table({"k": pa.array(k[keep]), "e": pa.array(ref_expr[keep])})
+    funcs = [(O.SUM, "e", "s"), (O.AVG, "e", "a"), (O.COUNT_STAR, "", "n")]
+    o = O.OracleAggregate(O.ONE_GROUP if one else O.SINGLE, [] if one else ["k"], [] if one else ["k"], funcs)
+    for b in t.to_batches():
+        o.next(b)
+    exp = o.result()
+    if shape in ("nullable_materialised",):       # NaN inputs: sums are NaN on both sides; compare through the NaN-aware helper
+        util.assert_agg_equal(got, exp, funcs, [] if one else ["k"], exact_float_inputs=("e",), what=shape)
+    else:
+        util.assert_agg_equal(got, exp, funcs, [] if one else ["k"], exact_float_inputs=("e",), what=shape)

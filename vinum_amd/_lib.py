@@ -59,7 +59,10 @@ PROTOTYPES = {
     "vnm_agg_destroy": (None, [c_void]),
     "vnm_agg_set_predicate": (c_int, [c_void, c_int, c_int, c_int, c_dbl, c_i64]),
     "vnm_agg_set_hint": (c_int, [c_void, c_i64]),
+    "vnm_agg_set_exchange_mode": (c_int, [c_void, c_int]),
     "vnm_agg_next_device": (c_int, [c_void, c_i64, c_void, c_void, c_void, c_void]),
+    "vnm_agg_set_input_expr": (c_int, [c_void, c_int, c_int, c_void, c_int]),
+    "vnm_agg_next_device_expr": (c_int, [c_void, c_i64, c_void, c_void, c_void, c_int, c_void, c_void]),
     "vnm_agg_finish": (c_int, [c_void, c_void, c_void]),
     "vnm_agg_layout": (c_int, [c_void, c_void, c_void]),
     "vnm_agg_dense_ptrs": (c_int, [c_void, c_void, c_void]),

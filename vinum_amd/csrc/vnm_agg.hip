@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <vector>
 
 #include "vnm_agg.hpp"
 
@@ -45,8 +46,60 @@ struct GTable {
     int n_words;
 };
 
+// ---- expressions inside aggregates, evaluated in registers -------------------------------------------------------------
+// `SELECT k, sum((1 - total) * (2 + tax) * (1 - tip)) ... GROUP BY k` (vinum/tests/test_query_results.py:436-443): the
+// reference's planner projects the expression into a temporary column first (planner.py:384-417, one NumPy pass and one
+// n-row temporary per AST node) and the aggregate re-reads it.  Here the input of the hot-shape aggregate may BE an
+// expression: a postfix program over up to four float64 columns without NULLs, evaluated per row pair where the scan /
+// partition kernels used to load the value column -- no materialised column, no extra pass.  float64 +, -, *, /, negation
+// one IEEE operation per AST node (the interpreter's dispatch keeps the compiler from contracting a*b+c into an FMA), so the
+// values are bit-identical to the projection kernel's and to NumPy's.  Anything else (other types, NULLs, more columns,
+// deeper stacks, other aggregate shapes) is materialised by vnm_project first (vnm_agg_next_device_expr).
+constexpr int EXR_MAX_INS = 16, EXR_MAX_COLS = 4, EXR_MAX_DEPTH = 4;
+struct ExprIns { int op; int arg; double imm; };
+struct ExprProg {
+    int n;
+    const double* cols[EXR_MAX_COLS];
+    ExprIns ins[EXR_MAX_INS];
+};
+// the stack lives in four named registers (a dynamically indexed array would go to scratch memory)
+template <typename V, typename LOADER>
+__device__ __forceinline__ V expr_eval(const ExprProg& e, LOADER&& load_col, V splat_zero) {
+    V s0 = splat_zero, s1 = splat_zero, s2 = splat_zero, s3 = splat_zero;
+    for (int i = 0; i < e.n; i++) {
+        const int op = e.ins[i].op;
+        if (op == VNM_EX_COL || op == VNM_EX_CONST_F) {
+            s3 = s2; s2 = s1; s1 = s0;
+            s0 = op == VNM_EX_COL ? load_col(e.ins[i].arg) : splat_zero + e.ins[i].imm;
+        } else if (op == VNM_EX_NEG) {
+            s0 = -s0;
+        } else {
+            const V b = s0, a = s1;
+            s1 = s2; s2 = s3;
+            switch (op) {
+                case VNM_EX_ADD: s0 = a + b; break;
+                case VNM_EX_SUB: s0 = a - b; break;
+                case VNM_EX_MUL: s0 = a * b; break;
+                default: s0 = a / b; break;
+            }
+        }
+    }
+    return s0;
+}
+typedef double expr_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 expr_eval2(const ExprProg& e, int64_t r) {   // rows r, r + 1 (r even: 16-byte loads)
+    const expr_v2 z = {0.0, 0.0};
+    const expr_v2 v = expr_eval<expr_v2>(e, [&](int c) { return *(const expr_v2*)(e.cols[c] + r); }, z);
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ double expr_eval1(const ExprProg& e, int64_t r) {
+    return expr_eval<double>(e, [&](int c) { return e.cols[c][r]; }, 0.0);
+}
+
 struct AggArgs {
     AggPlan plan;
+    int has_expr;      // the (only) input column of this hot-shape plan is `expr`, not a.cols[0]
+    ExprProg expr;
     vnm_dcol keys[AGG_MAX_KEYS];
     vnm_dcol cols[AGG_MAX_COLS];
     vnm_dcol pred;
@@ -275,7 +328,12 @@ __device__ __forceinline__ void agg_rows_to_table(const AggArgs& a, int64_t row0
         for (int o = 0; o < a.plan.n_ops; o++) {
             const AccOp& op = a.plan.ops[o];
             uint64_t v;
-            if (op_value(op, a.cols, row, &v)) g_merge(&a.g.acc[(uint64_t)op.word * a.g.stride + gs], a.plan.merge[op.word], v, (int64_t)a.g.stride);
+            bool have;
+            if (a.has_expr && op.kind != A_COUNT_ROWS) {   // hot shape: COUNT / float64 SUM of the expression, never NULL
+                v = op.kind == A_COUNT_VALID ? 1ULL : (uint64_t)__double_as_longlong(expr_eval1(a.expr, row));
+                have = true;
+            } else have = op_value(op, a.cols, row, &v);
+            if (have) g_merge(&a.g.acc[(uint64_t)op.word * a.g.stride + gs], a.plan.merge[op.word], v, (int64_t)a.g.stride);
         }
     }
 }
@@ -706,7 +764,10 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
             vv[u].x = e0.y; vv[u].y = e1.y;                                                                    \
         } else {                                                                                               \
             kk[u] = *(const ulonglong2*)(kp + r_);                                                             \
-            if (HAS_VAL) vv[u] = *(const ulonglong2*)(vp + r_);                                                \
+            if (HAS_VAL) {                                                                                     \
+                if (a.has_expr) { const double2 ev_ = expr_eval2(a.expr, r_); vv[u].x = (unsigned long long)__double_as_longlong(ev_.x); vv[u].y = (unsigned long long)__double_as_longlong(ev_.y); } \
+                else vv[u] = *(const ulonglong2*)(vp + r_);                                                    \
+            }                                                                                                  \
             if (VNULL) vm[u] = (uint32_t)vbm[(voff + r_) >> 3] >> ((voff + r_) & 7);                           \
             if (TWO) vw[u] = *(const ulonglong2*)(vp2 + r_);                                                   \
             if (HAS_PRED && !PRED_IS_V) pv[u] = *(const double2*)(pp + r_);                                    \
@@ -753,7 +814,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                 for (int e = 0; e < 2; e++) {
                     int64_t r = base + (int64_t)u * 2 * AGG_BLOCK + e;
                     if (r >= a.nrows) continue;
-                    const uint64_t vb = FROM_ENT ? a.ent[r].y : (HAS_VAL ? vp[r] : 0);
+                    const uint64_t vb = FROM_ENT ? a.ent[r].y : (HAS_VAL ? (a.has_expr ? (uint64_t)__double_as_longlong(expr_eval1(a.expr, r)) : vp[r]) : 0);
                     const uint64_t kb = FROM_ENT ? a.ent[r].x : kp[r];
                     const bool ok = !VNULL || ((vbm[(voff + r) >> 3] >> ((voff + r) & 7)) & 1);
                     const double p = PRED_IS_V ? (ok ? __longlong_as_double((long long)vb) : __builtin_nan("")) : (HAS_PRED ? pp[r] : 0.0);
@@ -978,7 +1039,10 @@ __global__ __launch_bounds__(OG_BLOCK) void agg_onegroup_hot_kernel(AggArgs a) {
             v[u] = make_ulonglong2(0, 0);
             p[u] = make_double2(0.0, 0.0);
             if (i < npairs) {
-                if (VT >= 0) v[u] = vp[i];
+                if (VT >= 0) {
+                    if (a.has_expr) { const double2 ev_ = expr_eval2(a.expr, 2 * i); v[u].x = (unsigned long long)__double_as_longlong(ev_.x); v[u].y = (unsigned long long)__double_as_longlong(ev_.y); }
+                    else v[u] = vp[i];
+                }
                 if (PM == 2) p[u] = pp[i];
             }
         }
@@ -989,7 +1053,7 @@ __global__ __launch_bounds__(OG_BLOCK) void agg_onegroup_hot_kernel(AggArgs a) {
     }
     if ((a.nrows & 1) && blockIdx.x == 0 && tid == 0) {  // the odd last row
         const int64_t r = a.nrows - 1;
-        take(VT >= 0 ? ((const uint64_t*)vp)[r] : 0, PM == 2 ? ((const double*)pp)[r] : 0.0);
+        take(VT >= 0 ? (a.has_expr ? (uint64_t)__double_as_longlong(expr_eval1(a.expr, r)) : ((const uint64_t*)vp)[r]) : 0, PM == 2 ? ((const double*)pp)[r] : 0.0);
     }
     // wave reduction, then one merge per needed word and workgroup
     uint64_t w8[9] = {(uint64_t)__double_as_longlong(sf), si, slo, shis, shiu, cnt, mn, mx, (uint64_t)__double_as_longlong(sc)};
@@ -1195,6 +1259,8 @@ struct PartArgs {
     int has_pred, pred_is_v, op;
     double thr;
     int64_t nrows;
+    int has_expr;        // the value is `expr` evaluated per row pair instead of vp[row]
+    ExprProg expr;
     // source B: entry regions written by the previous level (pass 2)
     const ulonglong2* in_entries;
     const uint32_t* in_counts;
@@ -1350,7 +1416,7 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
                 for (int u = 0; u < PT_PAIRS; u++) {
                     int64_t r = base + (int64_t)u * 2 * PT_BLOCK + 2 * tid;
                     kk[u] = *(const ulonglong2*)(a.kp + r);
-                    vv[u] = *(const double2*)(a.vp + r);
+                    vv[u] = a.has_expr ? expr_eval2(a.expr, r) : *(const double2*)(a.vp + r);
                     if (a.has_pred && !a.pred_is_v) pv[u] = *(const double2*)(a.pp + r);
                 }
             }
@@ -1369,7 +1435,7 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
                     v = el ? vv[u].y : vv[u].x;
                     p = a.pred_is_v ? v : (el ? pv[u].y : pv[u].x);
                 } else {
-                    key = a.kp[r]; v = a.vp[r]; p = a.has_pred ? (a.pred_is_v ? v : a.pp[r]) : 0.0;
+                    key = a.kp[r]; v = a.has_expr ? expr_eval1(a.expr, r) : a.vp[r]; p = a.has_pred ? (a.pred_is_v ? v : a.pp[r]) : 0.0;
                 }
                 if (a.has_pred && !cmp_apply<double>(a.op, p, a.thr)) return false;
                 e->x = key;
@@ -2527,6 +2593,14 @@ struct vnm_agg {
     int dense_state = 0;
     DenseMap dmap{};
     int64_t dense_span = 0;  // 2^bits: upper bound of the groups a dense run can hold
+    bool rank_aligned = false;  // vnm_agg_set_exchange_mode: only run layouts every rank derives identically
+    // expression input (vnm_agg_set_input_expr): the functions reading plan column expr_col get an expression's value
+    int expr_col = -1;
+    std::vector<vnm_expr_ins> expr_prog;
+    int expr_ncols = 0;
+    bool expr_fusable = false;   // the program fits the in-register evaluator (float64 + - * / neg, <= 16 ins, depth <= 4)
+    bool expr_active = false;    // set around one vnm_agg_next_device call: evaluate expr_dev in the scan instead of a column
+    ExprProg expr_dev{};
     PackParams pack{};
     int c_funcs[AGG_MAX_FUNCS], c_in_types[AGG_MAX_FUNCS], c_in_flags[AGG_MAX_FUNCS], c_in_col_ids[AGG_MAX_FUNCS];
     bool c_has_ids = false;
@@ -2770,6 +2844,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     PartArgs p1{};
     p1.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
     p1.vp = h->plan.n_cols ? (const double*)a.cols[0].values + a.cols[0].offset : (const double*)p1.kp;
+    p1.has_expr = a.has_expr; p1.expr = a.expr;
     p1.pp = h->pred_set ? (const double*)a.pred.values + a.pred.offset : nullptr;
     p1.has_pred = h->pred_set; p1.pred_is_v = a.hot_pred_is_v; p1.op = a.p.op; p1.thr = a.p.dval;
     p1.nrows = nrows;
@@ -3060,6 +3135,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     d1.map = mp;
     d1.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
     d1.vp = (const double*)a.cols[0].values + a.cols[0].offset;
+    d1.has_expr = a.has_expr; d1.expr = a.expr;
     d1.pp = h->pred_set ? (const double*)a.pred.values + a.pred.offset : nullptr;
     d1.has_pred = h->pred_set; d1.pred_is_v = a.hot_pred_is_v; d1.op = a.p.op; d1.thr = a.p.dval;
     d1.nrows = nrows;
@@ -3296,6 +3372,12 @@ int vnm_agg_set_predicate(vnm_agg* h, int enabled, int op, int scalar_is_float, 
     return 0;
 }
 
+int vnm_agg_set_exchange_mode(vnm_agg* h, int rank_aligned) {
+    if (!h) return set_error("vnm_agg_set_exchange_mode: null handle");
+    h->rank_aligned = rank_aligned != 0;
+    return 0;
+}
+
 int vnm_agg_set_hint(vnm_agg* h, int64_t expected_groups) {
     if (!h) return set_error("vnm_agg_set_hint: null handle");
     h->hint = expected_groups;
@@ -3381,6 +3463,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     a.nrows = nrows;
     a.ntiles = (nrows + AGG_TILE - 1) / AGG_TILE;
     a.debug = (int)env_i64("VNM_AGG_DEBUG", 0);
+    if (h->expr_active) { a.has_expr = 1; a.expr = h->expr_dev; }
     const int cus = device_info().num_cus;
 
     if (h->plan.n_keys == 0) {
@@ -3514,7 +3597,8 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     // bits.  It needs to know that G is LARGE, not how large: when the small sample of the estimator cannot settle G, its
     // lower bound is enough (span <= 32 G: the direct-addressed slots are reasonably filled) and the HyperLogLog pass
     // (0.85 ms) is skipped; the hash-partitioned path below still estimates properly if the dense attempt fails.
-    const bool dense_shape = hot && part_ok && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) && getenv("VNM_AGG_NO_DENSE") == nullptr;
+    const bool dense_shape = hot && part_ok && !h->rank_aligned && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
+                             getenv("VNM_AGG_NO_DENSE") == nullptr;
     if (dense_shape && h->dense_state == 0) {
         KernelTimer timer("agg_estimate", s);
         VNM_TRY(plan_dense(h, keys[0], nrows, s));
@@ -3672,6 +3756,88 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     pool_free(spill);
     h->rows_seen += nrows;
     return 0;
+}
+
+// ---- expressions inside aggregates ---------------------------------------------------------------------------------------
+int vnm_agg_set_input_expr(vnm_agg* h, int func_idx, int n_ins, const vnm_expr_ins* program, int n_cols) {
+    if (!h || !program) return set_error("vnm_agg_set_input_expr: null argument");
+    if (func_idx < 0 || func_idx >= h->n_funcs || h->func_col[func_idx] < 0) return set_error("vnm_agg_set_input_expr: function %d has no input column", func_idx);
+    if (h->expr_col >= 0 && h->expr_col != h->func_col[func_idx]) return set_error("vnm_agg_set_input_expr: one expression input per operator (project the others first)");
+    if (n_ins < 1 || n_ins > 64 || n_cols < 1 || n_cols > 16) return set_error("vnm_agg_set_input_expr: bad program size");
+    if (h->c_in_types[func_idx] != VNM_F64) return set_error("vnm_agg_set_input_expr: declare the function's input type as float64 (the expression's result type)");
+    h->expr_col = h->func_col[func_idx];
+    h->expr_prog.assign(program, program + n_ins);
+    h->expr_ncols = n_cols;
+    // does it fit the in-register evaluator?
+    bool ok = n_ins <= EXR_MAX_INS && n_cols <= EXR_MAX_COLS;
+    int sp = 0;
+    for (int i = 0; ok && i < n_ins; i++) {
+        switch (program[i].op) {
+            case VNM_EX_COL: ok = program[i].arg >= 0 && program[i].arg < n_cols && ++sp <= EXR_MAX_DEPTH; break;
+            case VNM_EX_CONST_F: case VNM_EX_CONST_I: ok = ++sp <= EXR_MAX_DEPTH; break;
+            case VNM_EX_NEG: ok = sp >= 1; break;
+            case VNM_EX_ADD: case VNM_EX_SUB: case VNM_EX_MUL: case VNM_EX_DIV: ok = sp >= 2; sp--; break;
+            default: ok = false; break;
+        }
+    }
+    h->expr_fusable = ok && sp == 1;
+    return 0;
+}
+
+int vnm_agg_next_device_expr(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs, const vnm_dcol* pred,
+                             int n_expr_cols, const vnm_dcol* expr_cols, void* stream) {
+    VNM_TRY(ensure_init());
+    if (!h || !expr_cols) return set_error("vnm_agg_next_device_expr: null argument");
+    if (h->expr_col < 0) return set_error("vnm_agg_next_device_expr: call vnm_agg_set_input_expr first");
+    if (n_expr_cols != h->expr_ncols) return set_error("vnm_agg_next_device_expr: the expression reads %d columns, %d given", h->expr_ncols, n_expr_cols);
+    hipStream_t s = as_stream(stream);
+    std::vector<vnm_dcol> in(inputs, inputs + h->n_funcs);
+    // fused: the hot shape -- {COUNT(*), COUNT, SUM, AVG} of the expression alone, a plain 8-byte key (or no GROUP BY),
+    // float64 columns without NULLs at even offsets, float64 predicate column or none
+    bool fuse = h->expr_fusable && h->plan.n_cols == 1 && getenv("VNM_AGG_NO_HOT") == nullptr && getenv("VNM_AGG_NO_EXPR_FUSION") == nullptr &&
+                nrows > 0 && (h->plan.n_keys == 0 || (h->single && h->plan.n_keys == 1 && type_width(keys[0].type) == 8 && !keys[0].validity && (keys[0].offset & 1) == 0));
+    for (int o = 0; fuse && o < h->plan.n_ops; o++) {
+        const int k = h->plan.ops[o].kind;
+        fuse = k == A_COUNT_ROWS || k == A_COUNT_VALID || k == A_SUM_F64;
+    }
+    for (int c = 0; fuse && c < n_expr_cols; c++)
+        fuse = expr_cols[c].type == VNM_F64 && !expr_cols[c].validity && (expr_cols[c].offset & 1) == 0 && expr_cols[c].length >= nrows;
+    if (fuse && h->pred_set) fuse = pred && pred->type == VNM_F64 && !pred->validity && (pred->offset & 1) == 0;
+    if (fuse) {
+        ExprProg& e = h->expr_dev;
+        e.n = (int)h->expr_prog.size();
+        for (int c = 0; c < EXR_MAX_COLS; c++) e.cols[c] = c < n_expr_cols ? (const double*)expr_cols[c].values + expr_cols[c].offset : nullptr;
+        for (int i = 0; i < e.n; i++) {
+            const vnm_expr_ins& pi = h->expr_prog[i];
+            e.ins[i].op = pi.op == VNM_EX_CONST_I ? VNM_EX_CONST_F : pi.op;
+            e.ins[i].arg = pi.arg;
+            e.ins[i].imm = pi.op == VNM_EX_CONST_I ? (double)pi.imm_i : pi.imm_f;
+        }
+        // a stand-in column view for the functions that read the expression: float64, no NULLs; its address is never
+        // dereferenced (and equals no real column, so `predicate column == value column` cannot match by accident)
+        vnm_dcol stand{};
+        stand.values = (const void*)h; stand.type = VNM_F64; stand.length = nrows;
+        for (int i = 0; i < h->n_funcs; i++) if (h->func_col[i] == h->expr_col) in[i] = stand;
+        h->expr_active = true;
+        const int rc = vnm_agg_next_device(h, nrows, keys, in.data(), pred, stream);
+        h->expr_active = false;
+        return rc;
+    }
+    // general case: one fused projection pass materialises the expression, the aggregate reads it like any column
+    double* tmp = (double*)pool_alloc((size_t)(nrows > 0 ? nrows : 1) * 8);
+    if (!tmp) return 1;
+    int out_type = 0;
+    int rc = vnm_project((int)h->expr_prog.size(), h->expr_prog.data(), n_expr_cols, expr_cols, nrows, tmp, &out_type, stream);
+    if (!rc && out_type != VNM_F64) rc = set_error("vnm_agg_next_device_expr: the expression's result type is %d, float64 expected (cast in the projection)", out_type);
+    if (!rc) {
+        vnm_dcol col{};
+        col.values = tmp; col.type = VNM_F64; col.length = nrows;
+        for (int i = 0; i < h->n_funcs; i++) if (h->func_col[i] == h->expr_col) in[i] = col;
+        rc = vnm_agg_next_device(h, nrows, keys, in.data(), pred, stream);
+    }
+    if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = set_error("vnm_agg_next_device_expr: stream synchronisation failed");
+    pool_free(tmp);
+    return rc;
 }
 
 int vnm_agg_merge_device(vnm_agg* h, int64_t n, uint64_t* const* key_words, uint64_t* const* acc_words, void* stream) {

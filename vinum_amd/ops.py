@@ -87,7 +87,7 @@ class DeviceAggregate:
 
     funcs: list of (func_id, input_column_index or None, arrow_type of the input or None)."""
 
-    def __init__(self, kind, key_types, funcs, expected_groups=0):
+    def __init__(self, kind, key_types, funcs, expected_groups=0, rank_aligned=False):
         self.kind = kind
         self.key_arrow = list(key_types)
         self.funcs = list(funcs)
@@ -106,6 +106,8 @@ class DeviceAggregate:
             raise RuntimeError(L.last_error())
         if expected_groups:
             L.check(L.lib().vnm_agg_set_hint(self._h, int(expected_groups)))
+        if rank_aligned:     # the result will be exchanged between ranks (vinum_amd.distributed)
+            L.check(L.lib().vnm_agg_set_exchange_mode(self._h, 1))
         self._pred = False
 
     def set_predicate(self, op, literal):
@@ -114,12 +116,24 @@ class DeviceAggregate:
         L.check(L.lib().vnm_agg_set_predicate(self._h, 1, op, int(is_f), float(literal), 0 if is_f else int(literal)))
         self._pred = True
 
-    def next(self, keys, inputs, pred=None, nrows=None, stream=None):
-        """keys: list[DeviceColumn]; inputs: one DeviceColumn (or None for COUNT(*)) per function."""
+    def set_input_expr(self, func_idx, expr, col_names):
+        """The input of function `func_idx` (and of the functions sharing its column id) is `expr` -- a prefix expression
+        over `col_names` -- instead of a column: `sum((1 - total) * (2 + tax))`.  Evaluated in registers inside the scan in
+        the hot shape, otherwise materialised by one fused projection pass (vnm_agg_set_input_expr)."""
+        prog = compile_expr(expr, {n: i for i, n in enumerate(col_names)})
+        L.check(L.lib().vnm_agg_set_input_expr(self._h, int(func_idx), len(prog), prog, len(col_names)))
+
+    def next(self, keys, inputs, pred=None, nrows=None, stream=None, expr_cols=None):
+        """keys: list[DeviceColumn]; inputs: one DeviceColumn (or None for COUNT(*) / expression inputs) per function;
+        expr_cols: the columns of the expression set with set_input_expr, in its col_names order."""
         if nrows is None:
             nrows = keys[0].length if keys else next(c.length for c in inputs if c is not None) if any(
                 c is not None for c in inputs) else 0
         p = ctypes.byref(pred.dcol()) if pred is not None else None
+        if expr_cols is not None:
+            L.check(L.lib().vnm_agg_next_device_expr(self._h, nrows, dcol_array(keys), dcol_array(inputs), p, len(expr_cols),
+                                                     dcol_array(expr_cols), _stream_ptr(stream)))
+            return
         L.check(L.lib().vnm_agg_next_device(self._h, nrows, dcol_array(keys), dcol_array(inputs), p, _stream_ptr(stream)))
 
     def finish(self, stream=None) -> int:

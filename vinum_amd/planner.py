@@ -134,8 +134,11 @@ def plan_query(query: Dict, source, expected_groups: int = 0) -> Plan:
                 inner[e] = f"__inner_{len(inner)}"
             return inner[e]
 
-        # aggregate function nodes -> functions of the operator (one per distinct (function, input))
-        funcs: Dict[Tuple[str, str], str] = {}
+        # aggregate function nodes -> functions of the operator (one per distinct (function, input)).  An argument that is
+        # an EXPRESSION stays an expression: the aggregate operator hands it to the kernel (evaluated in registers in the
+        # hot shape) or projects it itself -- the reference plans a keep-input projection for it (planner.py:384-417)
+        funcs: Dict[Tuple[str, object], str] = {}
+        key_of_expr: Dict[Tuple, str] = {}
 
         def fn_col(node):
             if not _is_fn(node):
@@ -143,7 +146,9 @@ def plan_query(query: Dict, source, expected_groups: int = 0) -> Plan:
             name = node[1].lower()
             if name not in AGG_FUNCS:
                 raise ValueError(f"unknown aggregate function {node[1]!r}")
-            arg = inner_col(node[2]) if len(node) > 2 and not isinstance(node[2], (int, float)) else ""
+            arg = node[2] if len(node) > 2 and not isinstance(node[2], (int, float)) else ""
+            if isinstance(arg, tuple) and arg in key_of_expr:
+                arg = key_of_expr[arg]                    # the argument is a GROUP BY expression: already a column
             if name == "count" and not arg:
                 name = "count_star"
             key = (name, arg)
@@ -153,6 +158,7 @@ def plan_query(query: Dict, source, expected_groups: int = 0) -> Plan:
 
         key_cols = [inner_col(e) for e in group_by]
         key_of = dict(zip(group_by, key_cols))
+        key_of_expr.update({e: c for e, c in key_of.items() if isinstance(e, tuple)})
 
         def post(e):
             """an expression over the aggregate's OUTPUT: functions and group-by expressions become columns"""
@@ -166,7 +172,8 @@ def plan_query(query: Dict, source, expected_groups: int = 0) -> Plan:
         if inner:
             op = ProjectOperator(list(inner.keys()), op, col_names=list(inner.values()), keep_input_table=True)
             steps.append(("project_inner", tuple(inner.items())))
-        agg_funcs = [AggregateFunction(f, col or None, out) for (f, col), out in funcs.items()]
+        agg_funcs = [AggregateFunction(f, (arg or None) if isinstance(arg, str) else None, out, expr=arg if isinstance(arg, tuple) else None)
+                     for (f, arg), out in funcs.items()]
         op = AggregateOperator(op, key_cols, agg_funcs, key_cols, expected_groups=expected_groups)
         steps.append(("aggregate", tuple(key_cols), tuple(funcs.items())))
         select, having, order_by = select_post, having_post, order_post
