@@ -341,7 +341,7 @@ def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream,
 
     def topk():
         state["idx"] = ops.sort_indices([v4col], [L.DESC], limit=10, stream=stream)
-    ms, sp = _measure(torch, lib, ctypes, topk, [b"topk_select", b"radix_pass", b"topk_sample"], steps + 2, warmup + 1)
+    ms, sp = _measure(torch, lib, ctypes, topk, [b"topk_sample", b"topk_select", b"topk_small_sort", b"radix_pass"], steps + 2, warmup + 1)
     out["configs[4] top-K"] = _entry(f"ORDER BY v DESC LIMIT 10 over {n:.3g} fp64 rows (row ids out)", n, ms, sp, 8.0 * n + 80.0, 10)
     ca = torch.randn(n, device=device, dtype=torch.float64, generator=gg)
     cb = torch.rand(n, device=device, dtype=torch.float64, generator=gg)
@@ -537,7 +537,7 @@ def main():
     check = None
     if args.check and args.workload == "groupby" and args.shape == "hot":
         check = check_groupby(torch, dist, state, k, v, x_thr, world, rank, device, force_exchange)
-    names = {"filter": [b"filter_kernel"], "topk": [b"topk_select", b"radix_pass"], "project": [b"project_kernel"]}.get(
+    names = {"filter": [b"filter_kernel"], "topk": [b"topk_sample", b"topk_select", b"topk_small_sort", b"radix_pass"], "project": [b"project_kernel"]}.get(
         args.workload, AGG_SPANS)
     spans = {}
     for nm in names:

@@ -289,6 +289,90 @@ static int radix_sort_codes(RadixBufs* r, int64_t n, hipStream_t s, unsigned lon
     return 0;
 }
 
+
+// ---- LIMIT K without the launch-bound tail ------------------------------------------------------------------------------
+// r01's top-K query spent 1.35 ms in the selection scan and 1.5 ms in ~130 tiny radix launches (sorting the 2^18-key
+// sample to read ONE threshold off it, then sorting a few hundred candidates three times).  Both small problems fit one
+// workgroup each:
+//   * topk_blockbest_kernel + one workgroup sort: the threshold is the r-th best of 4096 block winners of a 2^22-key sample
+//     (a single-workgroup radix SELECT over the whole sample was tried first: 0.8 ms at 2^18 keys -- its LDS histogram
+//     atomics all hit the few bins the keys' top bytes share);
+//   * topk_small_sort_kernel: bitonic sort of up to 8192 candidates in LDS on the composite key (class, code, row id) --
+//     the row id makes it the stable order of the full sort -- and the first K row ids go straight to the output.
+// Block-best sampling: the m-key strided sample is cut into TB_BLOCKS blocks and only the BEST key of every block is kept.
+// The r-th best of those block winners is a threshold with AT LEAST r rows at or above it (the r winners themselves) and
+// about r * n / m in expectation while r << TB_BLOCKS -- the same statistic as the r-th order statistic of the sample,
+// found by sorting 4096 keys in one workgroup instead of the whole sample.
+constexpr int TB_BLOCKS = 4096;
+__global__ __launch_bounds__(256) void topk_blockbest_kernel(vnm_dcol c, int desc, int64_t n, int64_t m, uint64_t* best_code, uint8_t* best_cls) {
+    const int64_t per = (m + TB_BLOCKS - 1) / TB_BLOCKS;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < m ? lo + per : m;
+    uint64_t bc = ~0ULL;
+    uint32_t bk = 255;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const int64_t row = (int64_t)(((__int128)i * n) / m);
+        uint64_t e; uint32_t k;
+        encode_key(c, row, desc, &e, &k);
+        if (k < bk || (k == bk && e < bc)) { bk = k; bc = e; }
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint64_t oc = __shfl_xor(bc, d);
+        const uint32_t ok = __shfl_xor(bk, d);
+        if (ok < bk || (ok == bk && oc < bc)) { bk = ok; bc = oc; }
+    }
+    __shared__ uint64_t sc[4];
+    __shared__ uint32_t sk[4];
+    if ((threadIdx.x & 63) == 0) { sc[threadIdx.x >> 6] = bc; sk[threadIdx.x >> 6] = bk; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) if (sk[w] < bk || (sk[w] == bk && sc[w] < bc)) { bk = sk[w]; bc = sc[w]; }
+        best_code[blockIdx.x] = bc;
+        best_cls[blockIdx.x] = (uint8_t)bk;
+    }
+}
+
+constexpr int TS_MAX = 8192;
+// thr (optional): instead of row ids, write the (class, code) of the element at sorted position `limit` to thr[0], thr[1]
+__global__ __launch_bounds__(1024) void topk_small_sort_kernel(const uint64_t* code, const uint8_t* cls, const uint32_t* rows, int n, int np2,
+                                                              int64_t limit, int64_t* out, unsigned long long* thr) {
+    extern __shared__ uint64_t ts_lds[];
+    uint64_t* k_code = ts_lds;                         // [np2]
+    uint32_t* k_row = (uint32_t*)(ts_lds + np2);       // [np2]
+    uint8_t* k_cls = (uint8_t*)(k_row + np2);          // [np2]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < np2; i += 1024) {
+        const bool in = i < n;
+        k_code[i] = in ? code[i] : ~0ULL;
+        k_row[i] = in ? (rows ? rows[i] : (uint32_t)i) : 0xFFFFFFFFu;
+        k_cls[i] = in ? cls[i] : (uint8_t)255;         // padding sorts last
+    }
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < np2 / 2; t += 1024) {
+                const int lo = 2 * t - (t & (stride - 1));   // index with bit `stride` clear
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint8_t ca = k_cls[lo], cb = k_cls[hi];
+                const uint64_t xa = k_code[lo], xb = k_code[hi];
+                const uint32_t ra = k_row[lo], rb = k_row[hi];
+                const bool a_gt_b = ca != cb ? ca > cb : (xa != xb ? xa > xb : ra > rb);
+                if (a_gt_b == up) {
+                    k_cls[lo] = cb; k_cls[hi] = ca;
+                    k_code[lo] = xb; k_code[hi] = xa;
+                    k_row[lo] = rb; k_row[hi] = ra;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (thr) {
+        if (tid == 0) { thr[0] = k_cls[limit]; thr[1] = k_code[limit]; }
+        return;
+    }
+    for (int64_t i = tid; i < limit; i += 1024) out[i] = (int64_t)k_row[i];
+}
+
 // ---- top-K candidate selection ----------------------------------------------------------------------------
 __global__ void topk_sample_kernel(vnm_dcol c, int desc, int64_t n, int64_t m, uint64_t* code, uint8_t* cls) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -474,42 +558,70 @@ int vnm_sort_indices(int n_keys, const vnm_dcol* keys, const int* orders, int64_
     const bool try_topk = limit > 0 && n_keys == 1 && limit * 8 < n && n >= (1 << 16) && getenv("VNM_SORT_NO_TOPK") == nullptr;
     if (try_topk) {
         const int desc = orders[0] == VNM_DESC;
-        const int64_t m = std::min<int64_t>(n, 1 << 18);
-        RadixBufs sr{};
-        VNM_TRY(radix_alloc(&sr, m));
-        uint8_t* scls = (uint8_t*)pool_alloc((size_t)m);
-        if (!scls) return 1;
-        topk_sample_kernel<<<grid_for(m), 256, 0, s>>>(keys[0], desc, n, m, sr.code[0], scls);
-        sort_iota_kernel<<<grid_for(m), 256, 0, s>>>(sr.val[0], m);
-        // sort the sample by (cls, code): code passes then class pass
-        int rc = radix_sort_codes(&sr, m, s);
-        uint64_t* scode_sorted = (uint64_t*)pool_alloc((size_t)m * 8);
-        if (rc || !scode_sorted) return 1;
-        VNM_HIP(hipMemcpyAsync(scode_sorted, sr.code[sr.cur], (size_t)m * 8, hipMemcpyDeviceToDevice, s));
-        gather_u8_kernel<<<grid_for(m), 256, 0, s>>>(scls, sr.val[sr.cur], m, sr.code[sr.cur]);
-        // keep the code order as the stable secondary key: values = positions in the code-sorted sample
-        sort_iota_kernel<<<grid_for(m), 256, 0, s>>>(sr.val[sr.cur], m);
-        rc = radix_sort_codes(&sr, m, s);
-        if (rc) return 1;
-        // rank of the threshold in the sample: expected rank of the K-th row + safety margin
+        static bool ts_attr = false;
+        if (!ts_attr) {
+            VNM_HIP(hipFuncSetAttribute((const void*)topk_small_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TS_MAX * 13));
+            ts_attr = true;
+        }
+        const int64_t m = std::min<int64_t>(n, 1 << 22);
+        // threshold = the sample element at the expected rank of the K-th row + a safety margin, in (class, code) order
+        // (a threshold that keeps fewer than K rows is noticed below and answered by the full sort)
         double frac = (double)limit / (double)n;
-        int64_t rnk = (int64_t)(frac * (double)m * 1.5) + 64 + (int64_t)(6.0 * sqrt(frac * (double)m + 1.0));
+        int64_t rnk = (int64_t)(frac * (double)m * 1.5) + 8 + (int64_t)(6.0 * sqrt(frac * (double)m + 1.0));
         bool ok = rnk < m - 1;
         uint32_t t_cls = 0;
         uint64_t t_code = 0;
-        if (ok) {
-            uint32_t pos_in_code_sorted = 0;
-            uint64_t cls64 = 0;
-            VNM_HIP(hipMemcpyAsync(&pos_in_code_sorted, sr.val[sr.cur] + rnk, 4, hipMemcpyDeviceToHost, s));
-            VNM_HIP(hipMemcpyAsync(&cls64, sr.code[sr.cur] + rnk, 8, hipMemcpyDeviceToHost, s));
+        if (ok && rnk < TB_BLOCKS / 4 && m >= TB_BLOCKS * 64) {
+            // small ranks: the rnk-th best of the 4096 block winners (one scan of the sample, one workgroup sort)
+            uint64_t* bcode = (uint64_t*)pool_alloc(TB_BLOCKS * 8);
+            uint8_t* bcls = (uint8_t*)pool_alloc(TB_BLOCKS);
+            unsigned long long* thr = (unsigned long long*)pool_alloc(64);
+            if (!bcode || !bcls || !thr) return 1;
+            {
+                KernelTimer timer("topk_sample", s);
+                topk_blockbest_kernel<<<TB_BLOCKS, 256, 0, s>>>(keys[0], desc, n, m, bcode, bcls);
+                topk_small_sort_kernel<<<1, 1024, (size_t)TB_BLOCKS * 13, s>>>(bcode, bcls, nullptr, TB_BLOCKS, TB_BLOCKS, rnk, nullptr, thr);
+            }
+            unsigned long long th[2] = {0, 0};
+            VNM_HIP(hipMemcpyAsync(th, thr, 16, hipMemcpyDeviceToHost, s));
             VNM_HIP(hipStreamSynchronize(s));
-            VNM_HIP(hipMemcpyAsync(&t_code, scode_sorted + pos_in_code_sorted, 8, hipMemcpyDeviceToHost, s));
-            VNM_HIP(hipStreamSynchronize(s));
-            t_cls = (uint32_t)cls64;
+            t_cls = (uint32_t)th[0];
+            t_code = th[1];
+            pool_free(bcode); pool_free(bcls); pool_free(thr);
+        } else if (ok) {
+            // larger ranks: the r01 route -- sort a 2^18-key sample by (class, code) with the grid-wide radix sort and read
+            // the threshold off it (its ~130 small launches cost ~1.5 ms, which only matters for small K)
+            const int64_t ms_ = std::min<int64_t>(n, 1 << 18);
+            rnk = (int64_t)((double)limit / (double)n * (double)ms_ * 1.5) + 64 + (int64_t)(6.0 * sqrt((double)limit / (double)n * (double)ms_ + 1.0));
+            ok = rnk < ms_ - 1;
+            if (ok) {
+                RadixBufs sr{};
+                VNM_TRY(radix_alloc(&sr, ms_));
+                uint8_t* scls = (uint8_t*)pool_alloc((size_t)ms_);
+                if (!scls) return 1;
+                topk_sample_kernel<<<grid_for(ms_), 256, 0, s>>>(keys[0], desc, n, ms_, sr.code[0], scls);
+                sort_iota_kernel<<<grid_for(ms_), 256, 0, s>>>(sr.val[0], ms_);
+                int rc = radix_sort_codes(&sr, ms_, s);
+                uint64_t* scode_sorted = (uint64_t*)pool_alloc((size_t)ms_ * 8);
+                if (rc || !scode_sorted) return 1;
+                VNM_HIP(hipMemcpyAsync(scode_sorted, sr.code[sr.cur], (size_t)ms_ * 8, hipMemcpyDeviceToDevice, s));
+                gather_u8_kernel<<<grid_for(ms_), 256, 0, s>>>(scls, sr.val[sr.cur], ms_, sr.code[sr.cur]);
+                sort_iota_kernel<<<grid_for(ms_), 256, 0, s>>>(sr.val[sr.cur], ms_);   // stable secondary key: position in the code order
+                rc = radix_sort_codes(&sr, ms_, s);
+                if (rc) return 1;
+                uint32_t pos_in_code_sorted = 0;
+                uint64_t cls64 = 0;
+                VNM_HIP(hipMemcpyAsync(&pos_in_code_sorted, sr.val[sr.cur] + rnk, 4, hipMemcpyDeviceToHost, s));
+                VNM_HIP(hipMemcpyAsync(&cls64, sr.code[sr.cur] + rnk, 8, hipMemcpyDeviceToHost, s));
+                VNM_HIP(hipStreamSynchronize(s));
+                VNM_HIP(hipMemcpyAsync(&t_code, scode_sorted + pos_in_code_sorted, 8, hipMemcpyDeviceToHost, s));
+                VNM_HIP(hipStreamSynchronize(s));
+                t_cls = (uint32_t)cls64;
+                pool_free(scode_sorted);
+                pool_free(scls);
+                radix_free(&sr);
+            }
         }
-        pool_free(scode_sorted);
-        pool_free(scls);
-        radix_free(&sr);
         if (ok) {
             const int64_t cap = std::max<int64_t>(limit * 4 + 65536, 1 << 20);
             RadixBufs cr{};
@@ -528,7 +640,20 @@ int vnm_sort_indices(int n_keys, const vnm_dcol* keys, const int* orders, int64_
             VNM_HIP(hipStreamSynchronize(s));
             int rc2 = 0;
             bool done = false;
-            if ((int64_t)found >= limit && (int64_t)found <= cap) {
+            if ((int64_t)found >= limit && (int64_t)found <= TS_MAX && getenv("VNM_SORT_NO_SMALL") == nullptr) {
+                // few candidates: one workgroup sorts them in LDS and writes the first K row ids
+                const int c = (int)found;
+                int np2 = 64;
+                while (np2 < c) np2 <<= 1;
+                const size_t lds = (size_t)np2 * 13;
+                {
+                    KernelTimer timer("topk_small_sort", s);
+                    topk_small_sort_kernel<<<1, 1024, lds, s>>>(cr.code[0], ccls, crows, c, np2, limit, out_indices, nullptr);
+                }
+                VNM_HIP(hipGetLastError());
+                VNM_HIP(hipStreamSynchronize(s));
+                done = true;
+            } else if ((int64_t)found >= limit && (int64_t)found <= cap) {
                 const int64_t c = (int64_t)found;
                 // canonical order: by row id, then (stable) by code, then by class
                 cr.nb = (int)std::min<int64_t>((c + 16383) / 16384, RS_MAX_BLOCKS);
