@@ -3599,28 +3599,28 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     // (0.85 ms) is skipped; the hash-partitioned path below still estimates properly if the dense attempt fails.
     const bool dense_shape = hot && part_ok && !h->rank_aligned && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
                              getenv("VNM_AGG_NO_DENSE") == nullptr;
-    if (dense_shape && h->dense_state == 0) {
-        KernelTimer timer("agg_estimate", s);
-        VNM_TRY(plan_dense(h, keys[0], nrows, s));
-    }
     bool dense_go = false;
-    int64_t dense_lb = 0;
     if (part_ok && h->hint == 0 && !h->estimated && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
         getenv("VNM_AGG_NO_ESTIMATE") == nullptr) {
-        int64_t est = 0;
-        const bool want_lb = dense_shape && h->dense_state == 1;
-        {
-            KernelTimer timer("agg_estimate", s);
-            VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s, want_lb ? &dense_lb : nullptr));
-            if (est == 0 && !(h->dense_span <= 32 * dense_lb && h->dense_span <= 4 * nrows)) {
-                dense_lb = 0;
-                VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s));  // too sparse for the dense path: full estimate
-            }
+        int64_t est = 0, dense_lb = 0;
+        KernelTimer timer("agg_estimate", s);
+        // the small sample first: a conclusive (small) group count needs neither the key range nor HyperLogLog
+        VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s, dense_shape ? &dense_lb : nullptr));
+        if (est == 0) {
+            if (h->dense_state == 0) VNM_TRY(plan_dense(h, keys[0], nrows, s));
+            if (h->dense_state == 1 && h->dense_span <= 32 * dense_lb && h->dense_span <= 4 * nrows) dense_go = true;
+            else VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s));   // too sparse (or not a code-able key): full estimate
         }
         if (est) { h->hint = est; h->estimated = true; }
-        else dense_go = true;
     }
-    if (dense_shape && h->dense_state == 1 && h->hint > 0 && h->dense_span <= 32 * h->hint && h->dense_span <= 4 * nrows) dense_go = true;
+    const int64_t part_min0 = env_i64("VNM_AGG_PART_MIN_GROUPS", std::min<int64_t>(2400, (int64_t)S * 6 / 10));
+    if (dense_shape && !dense_go && h->hint > part_min0) {
+        if (h->dense_state == 0) {
+            KernelTimer timer("agg_estimate", s);
+            VNM_TRY(plan_dense(h, keys[0], nrows, s));
+        }
+        if (h->dense_state == 1 && h->dense_span <= 32 * h->hint && h->dense_span <= 4 * nrows) dense_go = true;
+    }
     // many groups: radix-partitioned path (no per-row HBM atomics); falls through when it does not apply
     // ... from the point where the groups stop fitting the LDS table of the scan kernel (flush storms otherwise:
     // MIN+MAX with 2000 groups and a 2048-slot table ran at 38 ms)
