@@ -870,3 +870,24 @@ def test_expression_inside_aggregate(shape, monkeypatch):
         util.assert_agg_equal(got, exp, funcs, [] if one else ["k"], exact_float_inputs=("e",), what=shape)
     else:
         util.assert_agg_equal(got, exp, funcs, [] if one else ["k"], exact_float_inputs=("e",), what=shape)
+
+
+@pytest.mark.parametrize("groups", [30_000, 150_000])
+def test_streamed_batches_mid_cardinality(groups):
+    """A stream of batches with a few 1e4 ... 1e5 groups (what TableReaderOperator makes of a big table): the final pass of
+    the partitioned path splits partitions over several workgroups; from the second batch on the table is not empty, so
+    the splits write partial groups (duplicate keys) into a run that is folded into the table -- ADVICE r01: those batches
+    used to fall back to the scan kernel's flush storms.  Six batches, bit-exact against the oracle."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(groups)
+    n = 2_400_000
+    k = rng.integers(0, groups, n).astype(np.int64) * 1_000_003 + 17
+    v = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
+    t = pa.table({"k": pa.array(k), "v": pa.array(v)})
+    funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.COUNT_STAR, "", "n")]
+    batches = util.sliced_batches(t, 400_000)
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=("v", ">", 20.0), expected_groups=groups)
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in batches:
+        o.next(O.filter_batch(b, O.cmp_mask(b.column(1), O.GT, 20.0)))
+    util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"streamed G={groups}")

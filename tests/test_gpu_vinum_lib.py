@@ -70,8 +70,9 @@ def test_error_behaviour_matches_reference():
     agg = vl.SingleNumericalHashAggregate(["k"], ["k"], [vl.AggFuncDef(vl.SUM, "s", "x")])
     with pytest.raises(RuntimeError, match=r"not supported by sum\(\)"):     # agg_func_factory.cpp:174
         agg.next(b)
-    with pytest.raises(RuntimeError):
-        vl.GenericHashAggregate(["s"], ["s"], [])
+    g = vl.GenericHashAggregate(["s"], ["s"], [vl.AggFuncDef(vl.COUNT_STAR, "", "n")])   # string keys: dictionary-encoded
+    g.next(b)
+    assert sorted(g.result().to_pylist(), key=lambda r: r["s"]) == [{"s": "a", "n": 1}, {"s": "b", "n": 1}]
     assert vl.import_pyarrow() == 0
     assert repr(vl.AggFuncDef(vl.SUM, "a", "b")) == "<AggFuncDef col_name: a, out_col_name: b>"
 

@@ -2794,6 +2794,10 @@ int estimate_groups(vnm_agg* h, const vnm_dcol& key, int64_t nrows, int64_t* est
     return 0;
 }
 
+}  // namespace
+static int merge_run_into_table(vnm_agg* h, hipStream_t s);
+namespace {
+
 // returns 0 = done (run stored), 2 = not applicable / overflowed (caller uses the general path), 1 = error
 // spill_out / n_spill_out (optional): entries that did not fit their partition region (heavy keys); the caller
 // aggregates them with agg_hot_kernel<FROM_ENT> and owns the buffer.  Without them a full region fails the attempt.
@@ -2943,18 +2947,19 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         splits = (int)std::min<int64_t>(256, ((int64_t)cus * 8 + nfinal - 1) / nfinal);
         if (splits > fin_regions) splits = fin_regions;
     }
-    const bool to_table = splits > 1;
-    if (to_table && (h->have_table || h->have_run)) {
-        pool_free(e1); pool_free(c1); pool_free(e2); pool_free(c2); pool_free(flags); pool_free(spill);
-        return 2;
-    }
+    // Merging straight into the HBM table is only legal while the table holds nothing else (a failed attempt is then
+    // simply dropped).  With groups already in the table -- every batch of a stream after the first -- the split
+    // workgroups write their PARTIAL groups (a key may appear once per split) into a dense run instead, which is folded
+    // into the table like any other run: no flush storms for streamed input with 2.4 K ... 900 K groups.
+    const bool to_table = splits > 1 && !(h->have_table || h->have_run);
+    const bool dup_run = splits > 1 && !to_table;
     // dense output sized from the hint (guarded in the kernel)
-    const int64_t dstride = to_table ? 2 : std::min<int64_t>(nrows, h->hint * 2 + (1 << 20)) + 2;
+    const int64_t dstride = to_table ? 2 : std::min<int64_t>(nrows, (h->hint * 2 + (1 << 20)) * (dup_run ? splits : 1)) + 2;
     uint64_t* rk = (uint64_t*)pool_alloc((size_t)dstride * 8 * 2);
     uint64_t* ra = (uint64_t*)pool_alloc((size_t)dstride * 8 * h->plan.n_words);
     if (!rk || !ra) return 1;
     unsigned long long* dir = nullptr;
-    if (!to_table) {
+    if (!to_table && !dup_run) {   // the partition directory only describes runs with ONE workgroup per partition
         dir = (unsigned long long*)pool_alloc((size_t)nfinal * 16);
         if (!dir) return 1;
     }
@@ -3041,8 +3046,11 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         return 0;
     }
     h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
-    h->run_dir = dir; h->run_nfin = nfinal;
+    h->run_dir = dir; h->run_nfin = dir ? nfinal : 0;
     h->have_run = true;
+    if (dup_run) {   // keys repeat inside this run: it must never be handed out as a result, fold it into the table now
+        if (merge_run_into_table(h, s)) return 1;
+    }
     return 0;
 }
 
@@ -3141,6 +3149,10 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     d1.nrows = nrows;
     d1.out_vals = v1; d1.out_codes = c1; d1.out_counts = n1; d1.out_cap = cap1;
     d1.nparts = np1; d1.out_bits = mp.bits - p1;
+    // producer-major regions (a workgroup's 128 output regions adjacent) were tried against TLB pressure: pass 1 unchanged,
+    // pass 2 and the final pass 15-20 % slower (their reads become 150 KB chunks 75 MB apart) -> partition-major stays
+    const int pmajor = (int)env_i64("VNM_DENSE_PRODUCER_MAJOR", 0);
+    d1.producer_major = pmajor;
     d1.flags = flags; d1.spill = spill; d1.spill_cap = spill_cap;
     {
         KernelTimer timer("agg_part_scatter1", s);
@@ -3162,6 +3174,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         d2.map = mp;
         d2.in_vals = v1; d2.in_codes = (const uint32_t*)c1; d2.in_counts = n1; d2.in_cap = cap1;
         d2.in_regions = grid1; d2.in_split = split2; d2.in_bits = mp.bits - p1;
+        d2.in_pstride = pmajor ? 1 : grid1; d2.in_rstride = pmajor ? np1 : 1;
         d2.out_vals = v2; d2.out_codes = c2; d2.out_counts = n2; d2.out_cap = cap2;
         d2.nparts = np2; d2.out_bits = tb;
         d2.flags = flags; d2.spill = spill; d2.spill_cap = spill_cap;
@@ -3180,6 +3193,8 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     DFinalArgs df{};
     df.map = mp;
     df.vals = fin_v; df.codes = fin_c; df.counts = fin_n; df.cap = fin_cap; df.regions = fin_regions; df.nfinal = nfinal;
+    df.pstride = fin_regions; df.rstride = 1;
+    if (levels == 1 && pmajor) { df.pstride = 1; df.rstride = np1; }
     df.w_rows = a.hot_w_rows; df.w_valid = a.hot_w_valid; df.w_sum = a.hot_w_sum;
     df.w_lo = a.hot_comp && a.hot_w_sum >= 0 ? a.hot_w_sum + 1 : -1;
     df.dkey = rk; df.dacc = ra; df.dstride = dstride; df.flags = flags;
