@@ -294,6 +294,20 @@ int vnm_stage_column(const void* host_values, const uint8_t* host_validity, int6
                      int32_t type, vnm_dcol* out, void* stream);
 int vnm_free_column(vnm_dcol* col);
 
+/* ---- CSV ingest ---------------------------------------------------------------------------------------
+ * replaces, for numeric columns, the pyarrow.csv reader behind stream_csv() / read_csv() (vinum/io/arrow.py:58-61,106;
+ * FileReaderOperator vinum/core/algebra.py:268-279): one block of CSV text (must end with '\n'; < 2 GiB) is staged once
+ * and tokenised + parsed on the device.  n_fields = fields per row (from the header); field_idx[c] (ascending) / types[c]
+ * (VNM_I64 | VNM_F64) select the columns; out_cols[c] receives an HBM column (values + validity bitmap; an empty field is
+ * NULL; free with vnm_free_column).  Decimal -> float64 is exact integer arithmetic (correctly rounded, as strtod /
+ * fast_float).  fallback[c] = 1: column c holds a field outside the device parser's domain (> 19 significant digits,
+ * |decimal exponent| > 19, "nan" / "inf", stray characters): parse that column of this block on the host;
+ * fallback[n_cols] = 1: a quote character (quoted fields are not tokenised here); fallback[n_cols + 1] = 1: a row whose
+ * field count differs from n_fields. */
+int vnm_csv_parse_block(const char* host_text, int64_t nbytes, int skip_header, int delimiter, int n_fields, int n_cols,
+                        const int* field_idx, const int* types, vnm_dcol* out_cols, int64_t* n_rows, int* fallback,
+                        void* stream);
+
 /* device memory helpers for hosts without a GPU allocator of their own (ctypes / cgo bindings) */
 void* vnm_malloc(int64_t bytes);
 int vnm_free(void* p);

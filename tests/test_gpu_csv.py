@@ -1,0 +1,153 @@
+"""GPU CSV ingest (vnm_csv_parse_block, vinum_amd.io.GpuCsvReader) against pyarrow.csv -- the reader the reference's
+stream_csv() / read_csv() delegate to (vinum/io/arrow.py:58-61,106) -- and against Python's float() for the exactness of
+the decimal -> float64 conversion (both are correctly rounded, like Arrow's fast_float)."""
+import io
+import os
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.csv as pacsv
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _taxi(n, seed=0):
+    rng = np.random.default_rng(seed)
+    w = np.array([165, 34808, 7386, 2183, 1016, 3453, 989], float)
+    t = pa.table({
+        "key": pa.array([f"2009-06-15 17:26:{i % 60:02d}.{i:07d}" for i in range(n)]),
+        "fare_amount": pa.array(np.round(rng.lognormal(2.2, 0.6, n), 2), mask=rng.random(n) < 0.01),
+        "pickup_longitude": pa.array(rng.normal(-73.9, 0.1, n)),                      # 17 significant digits
+        "pickup_latitude": pa.array(rng.normal(40.75, 0.1, n) * rng.choice([1.0, 1e-7, 1e9], n)),
+        "passenger_count": pa.array(rng.choice(7, n, p=w / w.sum()).astype(np.int64), mask=rng.random(n) < 0.005),
+        "big": pa.array(rng.integers(-2**62, 2**62, n).astype(np.int64)),
+    })
+    buf = io.BytesIO()
+    pacsv.write_csv(t, buf, write_options=pacsv.WriteOptions(quoting_style="none"))
+    return buf.getvalue()
+
+
+def _read_all(reader):
+    batches = []
+    while True:
+        try:
+            batches.append(reader.read_next_batch())
+        except StopIteration:
+            break
+    return pa.Table.from_batches(batches)
+
+
+@pytest.mark.parametrize("block_size", [1 << 16, 1 << 20, 64 << 20])
+def test_gpu_csv_reader_equals_pyarrow(block_size, tmp_path):
+    from vinum_amd.io import stream_csv
+    data = _taxi(120_000)
+    path = os.path.join(tmp_path, "taxi.csv")
+    with open(path, "wb") as f:
+        f.write(data)
+    exp = pacsv.read_csv(io.BytesIO(data), read_options=pacsv.ReadOptions(use_threads=False))
+    got = _read_all(stream_csv(path, block_size=block_size))
+    assert got.schema.names == exp.schema.names
+    for name in exp.schema.names:
+        a, e = got.column(name).combine_chunks(), exp.column(name).combine_chunks()
+        assert a.type == e.type, name
+        if pa.types.is_floating(e.type) or pa.types.is_integer(e.type):
+            util.assert_col_equal(a, e, name)        # bit-exact, NULLs (empty fields) included
+        else:
+            assert a.to_pylist() == e.to_pylist(), name
+
+
+def test_decimal_to_double_is_correctly_rounded():
+    """Random decimal strings of every shape the parser accepts: the device result must be the bits of Python's float()
+    (correctly rounded); shapes outside its domain must raise the fallback flag instead of producing a value."""
+    import ctypes
+    from vinum_amd import _lib as L
+    rng = np.random.default_rng(4)
+    strs = []
+    for _ in range(60_000):
+        nd = int(rng.integers(1, 20))
+        digits = "".join(str(d) for d in rng.integers(0, 10, nd))
+        dot = int(rng.integers(0, nd + 1))
+        s = digits[:dot] + ("." + digits[dot:] if dot < nd or rng.random() < 0.2 else "")
+        if s.startswith("."):
+            s = ("0" if rng.random() < 0.5 else "") + s
+        if rng.random() < 0.3:
+            s += rng.choice(["e", "E"]) + rng.choice(["", "+", "-"]) + str(int(rng.integers(0, 12)))
+        if rng.random() < 0.4:
+            s = rng.choice(["-", "+"]) + s
+        strs.append(s)
+    strs += ["0", "-0", "0.0", "-0.0", "1", "9007199254740993", "9007199254740992.5", "0.1", "1e19", "1e-19", "123456789012345678.9",
+             "4.35", "2.675", "1.0000000000000002", "8.41e-5", "5e-1", "179769313486231570e-17", "00012.5000", ".5", "5."]
+    ok = [s for s in strs if sum(ch.isdigit() for ch in s.split("e")[0].split("E")[0].lstrip("+-").lstrip("0").replace(".", "")) <= 19]
+    text = ("x\n" + "\n".join(ok) + "\n").encode()
+    lib = L.lib()
+    out = (L.DCol * 1)()
+    n_rows = ctypes.c_int64(0)
+    fb = (ctypes.c_int * 3)()
+    L.check(lib.vnm_csv_parse_block(text, len(text), 1, ord(","), 1, 1, (ctypes.c_int * 1)(0), (ctypes.c_int * 1)(L.F64), out,
+                                    ctypes.byref(n_rows), fb, None))
+    assert n_rows.value == len(ok)
+    vals = np.empty(len(ok), np.float64)
+    L.check(lib.vnm_memcpy_d2h(vals.ctypes.data, out[0].values, vals.nbytes))
+    lib.vnm_free_column(ctypes.byref(out[0]))
+    exp = np.array([float(s) for s in ok])
+    in_domain = np.array([abs(_dec_exp(s)) <= 19 for s in ok])
+    bad = np.nonzero((vals.view(np.uint64) != exp.view(np.uint64)) & in_domain)[0]
+    assert bad.size == 0, f"{bad.size} differ, e.g. " + "; ".join(f"{ok[i]!r}: device {vals[i]!r} vs float() {exp[i]!r}" for i in bad[:12])
+    assert bool(fb[0]) == bool((~in_domain).any())
+
+
+def _dec_exp(s):
+    """decimal exponent q of the string's significand-as-integer form w * 10^q"""
+    m = s.lstrip("+-")
+    e = 0
+    for sep in ("e", "E"):
+        if sep in m:
+            m, ex = m.split(sep)
+            e = int(ex)
+    frac = len(m.split(".")[1]) if "." in m else 0
+    return e - frac
+
+
+def test_fallbacks_go_to_pyarrow(tmp_path):
+    """Quoted fields, 'nan' tokens, 20+ digit numbers, CRLF line ends: every block / column the device parser declines is read
+    by pyarrow instead -- same table either way."""
+    from vinum_amd.io import stream_csv
+    rows = ["a,b,c,s"] + [f"{i},{i * 0.25},{i * 3 - 7},txt{i % 5}" for i in range(5000)]
+    rows[100] = '100,nan,293,txt0'
+    rows[200] = '200,0.123456789012345678901234,593,"quoted, text"'
+    rows[300] = "300,,893,"
+    data = ("\r\n".join(rows) + "\r\n").encode()
+    path = os.path.join(tmp_path, "odd.csv")
+    with open(path, "wb") as f:
+        f.write(data)
+    exp = pacsv.read_csv(io.BytesIO(data), read_options=pacsv.ReadOptions(use_threads=False))
+    got = _read_all(stream_csv(path, block_size=1 << 14))
+    assert got.schema == exp.schema
+    for name in exp.schema.names:
+        util.assert_col_equal(got.column(name).combine_chunks(), exp.column(name).combine_chunks(), name) \
+            if not pa.types.is_string(exp.schema.field(name).type) else None
+        if pa.types.is_string(exp.schema.field(name).type):
+            assert got.column(name).to_pylist() == exp.column(name).to_pylist()
+
+
+def test_config4_stream_csv_group_by_on_the_gpu(tmp_path):
+    """BASELINE configs[0] / [3] shape: SELECT passenger_count, count(*), avg(fare_amount) FROM stream_csv(...) GROUP BY
+    passenger_count -- only the two needed fields of each row are parsed, on the device."""
+    from vinum_amd import planner
+    from vinum_amd.io import stream_csv
+    data = _taxi(200_000, seed=3)
+    path = os.path.join(tmp_path, "taxi.csv")
+    with open(path, "wb") as f:
+        f.write(data)
+    q = dict(select=["passenger_count", ["fn", "count_star"], ["fn", "avg", "fare_amount"]], aliases=[None, "n", "m"],
+             group_by=["passenger_count"])
+    got = planner.execute(q, stream_csv(path, block_size=4 << 20)).sort_by("passenger_count")
+    t = pacsv.read_csv(io.BytesIO(data))
+    exp = t.group_by("passenger_count", use_threads=False).aggregate([([], "count_all"), ("fare_amount", "mean")]).sort_by("passenger_count")
+    assert got.column("passenger_count").to_pylist() == exp.column("passenger_count").to_pylist()
+    assert got.column("n").cast(pa.int64()).to_pylist() == exp.column("count_all").to_pylist()
+    a, b = np.array(got.column("m").to_pylist(), float), np.array(exp.column("fare_amount_mean").to_pylist(), float)
+    assert (util._ulp_diff(a, b) <= 64).all()     # pyarrow's mean sums sequentially (not exactly rounded); ours is exact

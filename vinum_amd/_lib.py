@@ -94,6 +94,7 @@ PROTOTYPES = {
     "vnm_project_multi": (c_int, [c_int, c_void, c_int, c_void, c_i64, c_int, c_void, c_void, c_void]),
     "vnm_stage_column": (c_int, [c_void, c_void, c_i64, c_i64, ctypes.c_int32, c_void, c_void]),
     "vnm_free_column": (c_int, [c_void]),
+    "vnm_csv_parse_block": (c_int, [c_void, c_i64, c_int, c_int, c_int, c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
     "vnm_malloc": (c_void, [c_i64]),
     "vnm_free": (c_int, [c_void]),
     "vnm_memcpy_h2d": (c_int, [c_void, c_void, c_i64]),

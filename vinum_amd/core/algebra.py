@@ -35,6 +35,12 @@ class FileReaderOperator(Operator):
 
     def next(self):
         while True:
+            if hasattr(self._reader, "read_next_device_batch"):     # vinum_amd.io.GpuCsvReader: columns are born in HBM
+                try:
+                    yield self._reader.read_next_device_batch()
+                except StopIteration:
+                    break
+                continue
             try:
                 batch = self._reader.read_next_batch()
             except StopIteration:

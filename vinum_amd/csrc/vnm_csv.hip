@@ -1,0 +1,392 @@
+// CSV ingest for gfx950: tokenise one block of CSV text and parse its numeric columns on the device.
+//
+// Replaces, for numeric columns, what stream_csv() / read_csv() delegate to pyarrow.csv (vinum/io/arrow.py:58-61,106 and
+// FileReaderOperator, vinum/core/algebra.py:268-279): the block's bytes cross PCIe ONCE as text (pinned double buffer) and
+// the Arrow columns are born in HBM -- instead of being parsed on one CPU core, materialised as Arrow arrays in host memory
+// and staged column by column.  Parity target: pyarrow.csv's defaults (third-party; Arrow's converters are fast_float /
+// from_chars: correctly rounded) -- comma delimiter, first line = header, empty field = NULL, int64 / float64 columns.
+//
+//   csv_count_kernel    newlines per 16 KB slab (+ a flag when a quote character is seen: quoted fields are not handled
+//                       here, the caller reads such a block with pyarrow)
+//   csv_scan_kernel     exclusive scan of the slab counts (one workgroup)
+//   csv_offsets_kernel  row start offsets (ballot ranks inside the slab)
+//   csv_parse_kernel    one lane per row: walk the fields, parse the selected ones
+//
+// Decimal -> float64 is EXACT integer arithmetic, not floating point: a field is (sign, w, q) with w < 2^64 the significant
+// digits (at most 19) and q the decimal exponent; q >= 0: the 128-bit product w * 10^q rounded to 53 bits (half to even);
+// q < 0: the 128-by-64-bit quotient (w << s) / 10^-q with its remainder as the sticky bit, rounded the same way.  Both are
+// the correctly rounded value of the decimal string -- what strtod / fast_float / Python's float() return.  Fields outside
+// that domain (more than 19 significant digits, |q| > 19, "inf", "nan", hex floats, thousands separators, whitespace) are
+// not guessed at: the lane raises the column's fallback flag and the caller has pyarrow parse that column of that block.
+#include <algorithm>
+
+#include "vnm_common.hpp"
+
+namespace vnm {
+
+constexpr int CSV_SLAB = 16384;      // bytes per workgroup in the newline passes
+constexpr int CSV_MAX_COLS = 16;
+
+struct CsvArgs {
+    const uint8_t* text;
+    int64_t nbytes;
+    int64_t first;                    // offset of the first data byte (after the header line, 0 without header)
+    uint32_t* slab_counts;            // newlines per slab, then their exclusive prefix
+    int64_t nslabs;
+    int64_t* row_start;               // [nrows + 1]
+    unsigned long long* flags;        // [0] quote seen  [1 + c] column c needs the host parser  [20] malformed row (field count)
+    uint8_t delim;
+    int n_fields;                     // fields per row (from the header)
+    int n_cols;
+    int field_of[CSV_MAX_COLS];       // ascending field indices of the parsed columns
+    int type_of[CSV_MAX_COLS];        // VNM_I64 / VNM_F64
+    void* out_values[CSV_MAX_COLS];
+    uint8_t* out_valid[CSV_MAX_COLS]; // byte per row (packed into bitmaps afterwards)
+    int64_t nrows;
+};
+
+__global__ __launch_bounds__(256) void csv_count_kernel(CsvArgs a) {
+    const int64_t base = (int64_t)blockIdx.x * CSV_SLAB;   // slabs are aligned in the buffer (16-byte loads); bytes before `first` are skipped
+    uint32_t c = 0;
+    bool quote = false;
+    for (int i = threadIdx.x * 16; i < CSV_SLAB; i += 256 * 16) {
+        const int64_t p = base + i;
+        if (p >= a.first && p + 16 <= a.nbytes) {
+            const uint4 v = *(const uint4*)(a.text + p);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const uint32_t ch = (w[k] >> (8 * b)) & 255u;
+                    c += ch == '\n';
+                    quote |= ch == '"';
+                }
+        } else {
+            for (int k = 0; k < 16 && p + k < a.nbytes; k++) {
+                if (p + k < a.first) continue;
+                const uint8_t ch = a.text[p + k];
+                c += ch == '\n';
+                quote |= ch == '"';
+            }
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+    __shared__ uint32_t sc[4];
+    if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = c;
+    if (__ballot(quote) && (threadIdx.x & 63) == 0) a.flags[0] = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) a.slab_counts[blockIdx.x] = sc[0] + sc[1] + sc[2] + sc[3];
+}
+
+// in place: counts -> exclusive prefix; total to slab_counts[nslabs]
+__global__ __launch_bounds__(1024) void csv_scan_kernel(uint32_t* counts, int64_t n) {
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t lo = tid * per, hi = lo + per < n ? lo + per : n;
+    uint32_t s = 0;
+    for (int64_t i = lo; i < hi; i++) s += counts[i];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int k = 0; k < 1024; k++) { const uint32_t t = part[k]; part[k] = run; run += t; }
+        counts[n] = run;
+    }
+    __syncthreads();
+    uint32_t run = part[tid];
+    for (int64_t i = lo; i < hi; i++) { const uint32_t t = counts[i]; counts[i] = run; run += t; }
+}
+
+// row r starts right after the r-th newline of the data (row 0 at a.first); one lane per byte of the slab, 64 bytes per
+// wave round, ranks from ballots
+__global__ __launch_bounds__(256) void csv_offsets_kernel(CsvArgs a) {
+    const int64_t base = (int64_t)blockIdx.x * CSV_SLAB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ uint32_t wcount[4];
+    uint32_t seen = a.slab_counts[blockIdx.x];   // newlines before this slab
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.row_start[0] = a.first;
+    for (int i0 = 0; i0 < CSV_SLAB; i0 += 256) {
+        const int64_t p = base + i0 + threadIdx.x;
+        const bool nl = p >= a.first && p < a.nbytes && a.text[p] == '\n';
+        const unsigned long long m = __ballot(nl);
+        if (lane == 0) wcount[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wave; w++) before += wcount[w];
+        const uint32_t total = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        if (nl) {
+            const unsigned long long lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+            const uint32_t r = seen + before + (uint32_t)__popcll(m & lt);
+            a.row_start[(int64_t)r + 1] = p + 1;
+        }
+        seen += total;
+        __syncthreads();
+    }
+}
+
+// ---- exact decimal -> binary64 ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int clz64(uint64_t x) { return __clzll((long long)x); }
+
+// (hi:lo) as an integer, plus a sticky flag for discarded lower-order information, scaled by 2^e2 -> nearest double, ties to even
+__device__ __forceinline__ double round_u128(uint64_t hi, uint64_t lo, bool sticky, int e2) {
+    if (hi == 0 && lo == 0) return 0.0;
+    int msb;   // index of the top set bit of (hi:lo)
+    if (hi) msb = 127 - clz64(hi); else msb = 63 - clz64(lo);
+    uint64_t mant;  // top 53 bits
+    bool half = false, rest = sticky;
+    if (msb <= 52) {
+        mant = lo;                      // exact
+        return ldexp((double)mant, e2);
+    }
+    const int sh = msb - 52;            // bits to drop
+    if (sh < 64) {
+        mant = (sh == 0) ? lo : ((lo >> sh) | (hi << (64 - sh)));
+        if (hi >> sh) {}                // cannot happen: msb bounds mant to 53 bits
+        const uint64_t dropped = lo & ((1ULL << sh) - 1ULL);
+        half = (dropped >> (sh - 1)) & 1ULL;
+        rest = rest || (dropped & ((1ULL << (sh - 1)) - 1ULL)) != 0;
+        mant &= (1ULL << 53) - 1ULL;
+    } else {
+        const int s2 = sh - 64;
+        mant = s2 == 0 ? hi : (hi >> s2);
+        mant &= (1ULL << 53) - 1ULL;
+        if (s2 == 0) { half = lo >> 63; rest = rest || (lo << 1) != 0; }
+        else {
+            const uint64_t dropped = hi & ((1ULL << s2) - 1ULL);
+            half = (dropped >> (s2 - 1)) & 1ULL;
+            rest = rest || (dropped & ((1ULL << (s2 - 1)) - 1ULL)) != 0 || lo != 0;
+        }
+    }
+    if (half && (rest || (mant & 1ULL))) mant++;      // may carry to 2^53: still exactly representable
+    return ldexp((double)mant, e2 + sh);
+}
+
+// quotient of (hi:lo) / d for hi < d (so the quotient fits 64 bits), remainder in *rem
+__device__ __forceinline__ uint64_t udiv128_64(uint64_t hi, uint64_t lo, uint64_t d, uint64_t* rem) {
+    uint64_t r = hi, q = 0;
+#pragma unroll 4
+    for (int i = 63; i >= 0; i--) {
+        const bool carry = r >> 63;
+        r = (r << 1) | ((lo >> i) & 1ULL);
+        q <<= 1;
+        if (carry || r >= d) { r -= d; q |= 1ULL; }
+    }
+    *rem = r;
+    return q;
+}
+
+__device__ __constant__ uint64_t CSV_POW10[20] = {
+    1ULL, 10ULL, 100ULL, 1000ULL, 10000ULL, 100000ULL, 1000000ULL, 10000000ULL, 100000000ULL, 1000000000ULL, 10000000000ULL,
+    100000000000ULL, 1000000000000ULL, 10000000000000ULL, 100000000000000ULL, 1000000000000000ULL, 10000000000000000ULL,
+    100000000000000000ULL, 1000000000000000000ULL, 10000000000000000000ULL};
+
+// w * 10^q, correctly rounded; false when outside the exact domain (|q| > 19)
+__device__ __forceinline__ bool decimal_to_double(uint64_t w, int q, double* out) {
+    if (w == 0) { *out = 0.0; return true; }
+    if (q >= 0) {
+        if (q > 19) return false;
+        const uint64_t p = CSV_POW10[q];
+        const uint64_t lo = w * p, hi = __umul64hi(w, p);
+        *out = round_u128(hi, lo, false, 0);
+        return true;
+    }
+    const int k = -q;
+    if (k > 19) return false;
+    const uint64_t d = CSV_POW10[k];
+    // numerator w << s with s chosen so that the quotient has 63 or 64 significant bits and hi < d
+    const int lw = 64 - clz64(w), ld = 64 - clz64(d);
+    const int s = 63 + ld - lw;                       // 0 < s <= 126
+    uint64_t hi, lo;
+    if (s >= 64) { hi = w << (s - 64); lo = 0; }
+    else { hi = s == 0 ? 0 : (w >> (64 - s)); lo = w << s; }
+    if (hi >= d) return false;                        // cannot happen by construction; never divide wrongly
+    uint64_t rem;
+    const uint64_t quo = udiv128_64(hi, lo, d, &rem);
+    *out = round_u128(0, quo, rem != 0, -s);
+    return true;
+}
+
+// one numeric field [p, p + len): 0 = ok, 1 = NULL (empty), 2 = needs the host parser.
+// A single pass with an explicit state (0 mantissa, 1 right after e / E, 2 exponent digits): [sign] digits [. digits] [e|E [sign] digits]
+__device__ __noinline__ int csv_parse_field(const uint8_t* p, int len, int type, uint64_t* bits) {
+    if (len == 0) return 1;
+    bool neg = false, eneg = false, seen_dot = false;
+    uint64_t w = 0;
+    int digits = 0, q = 0, any = 0, state = 0, ex = 0, exdigits = 0;
+    const bool is_f = type == VNM_F64;
+    for (int i = 0; i < len; i++) {
+        const uint32_t ch = p[i];
+        const bool dig = ch >= 48u && ch <= 57u;
+        if (state == 0) {
+            if (dig) {
+                any = 1;
+                if (digits == 0 && ch == 48u) { if (seen_dot) q--; }          // leading zeros carry no digits
+                else {
+                    if (digits >= 19) return 2;                                // beyond 64-bit significands: host parser
+                    w = w * 10 + (ch - 48u);
+                    digits++;
+                    if (seen_dot) q--;
+                }
+            } else if (i == 0 && (ch == 45u || ch == 43u)) {                   // '-' '+'
+                neg = ch == 45u;
+            } else if (ch == 46u && !seen_dot && is_f) {                       // '.'
+                seen_dot = true;
+            } else if ((ch == 101u || ch == 69u) && is_f && any) {             // 'e' 'E'
+                state = 1;
+            } else return 2;
+        } else if (state == 1) {
+            if (ch == 45u || ch == 43u) { eneg = ch == 45u; state = 2; }
+            else if (dig) { ex = (int)(ch - 48u); exdigits = 1; state = 2; }
+            else return 2;
+        } else {
+            if (!dig || ex > 9999) return 2;
+            ex = ex * 10 + (int)(ch - 48u);
+            exdigits++;
+        }
+    }
+    if (!any || (state != 0 && exdigits == 0)) return 2;
+    q += eneg ? -ex : ex;
+    if (!is_f) {
+        if (neg ? w > 0x8000000000000000ULL : w > 0x7FFFFFFFFFFFFFFFULL) return 2;
+        *bits = neg ? (uint64_t)0 - w : w;
+        return 0;
+    }
+    double d;
+    if (!decimal_to_double(w, q, &d)) return 2;
+    *bits = (uint64_t)__double_as_longlong(neg ? -d : d);
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void csv_parse_kernel(CsvArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.nrows; r += stride) {
+        const int64_t lo = a.row_start[r];
+        int64_t hi = a.row_start[r + 1] - 1;                  // the '\n'
+        if (hi > lo && a.text[hi - 1] == '\r') hi--;
+        const uint8_t* p = a.text + lo;
+        const int len = (int)(hi - lo);
+        int field = 0, fstart = 0, c = 0;
+        for (int i = 0; i <= len; i++) {
+            if (i == len || p[i] == a.delim) {
+                if (c < a.n_cols && field == a.field_of[c]) {
+                    uint64_t bits = 0;
+                    const int rc = csv_parse_field(p + fstart, i - fstart, a.type_of[c], &bits);
+                    if (rc == 2) a.flags[1 + c] = 1;
+                    ((uint64_t*)a.out_values[c])[r] = bits;
+                    a.out_valid[c][r] = rc == 0;
+                    c++;
+                }
+                field++;
+                fstart = i + 1;
+            }
+        }
+        if (field != a.n_fields) a.flags[20] = 1;            // ragged row: pyarrow raises on it, so does the caller
+        for (; c < a.n_cols; c++) { ((uint64_t*)a.out_values[c])[r] = 0; a.out_valid[c][r] = 0; }
+    }
+}
+
+}  // namespace vnm
+
+using namespace vnm;
+
+extern "C" {
+
+int vnm_pack_validity(const uint8_t* valid_bytes, int64_t n, uint8_t* bitmap, void* stream);
+
+int vnm_csv_parse_block(const char* host_text, int64_t nbytes, int skip_header, int delimiter, int n_fields, int n_cols,
+                        const int* field_idx, const int* types, vnm_dcol* out_cols, int64_t* n_rows, int* fallback /* [n_cols + 2] */,
+                        void* stream) {
+    VNM_TRY(ensure_init());
+    if (!host_text || !out_cols || !n_rows || !fallback) return set_error("vnm_csv_parse_block: null argument");
+    if (n_cols < 1 || n_cols > CSV_MAX_COLS) return set_error("vnm_csv_parse_block: 1..%d columns per call", CSV_MAX_COLS);
+    if (nbytes <= 0 || host_text[nbytes - 1] != '\n') return set_error("vnm_csv_parse_block: a block must end with a newline");
+    if (nbytes >= (1LL << 31)) return set_error("vnm_csv_parse_block: blocks must be < 2 GiB");
+    for (int c = 0; c < n_cols; c++) {
+        if (types[c] != VNM_I64 && types[c] != VNM_F64) return set_error("vnm_csv_parse_block: column %d: int64 / float64 only", c);
+        if (c && field_idx[c] <= field_idx[c - 1]) return set_error("vnm_csv_parse_block: field indices must ascend");
+        if (field_idx[c] < 0 || field_idx[c] >= n_fields) return set_error("vnm_csv_parse_block: field index out of range");
+    }
+    hipStream_t s = as_stream(stream);
+    int64_t first = 0;
+    if (skip_header) {
+        const char* nl = (const char*)memchr(host_text, '\n', (size_t)nbytes);
+        first = nl ? (nl - host_text) + 1 : nbytes;
+    }
+    for (int c = 0; c < n_cols + 2; c++) fallback[c] = 0;
+    for (int c = 0; c < n_cols; c++) memset(&out_cols[c], 0, sizeof(vnm_dcol));
+    *n_rows = 0;
+    if (first >= nbytes) return 0;
+    vnm_dcol text{};
+    VNM_TRY(vnm_stage_column(host_text, nullptr, 0, nbytes, VNM_U8, &text, stream));   // the text crosses PCIe once
+    CsvArgs a{};
+    a.text = (const uint8_t*)text.values;
+    a.nbytes = nbytes;
+    a.first = first;
+    a.nslabs = (nbytes + CSV_SLAB - 1) / CSV_SLAB;
+    a.delim = (uint8_t)delimiter;
+    a.n_fields = n_fields;
+    a.n_cols = n_cols;
+    for (int c = 0; c < n_cols; c++) { a.field_of[c] = field_idx[c]; a.type_of[c] = types[c]; }
+    a.slab_counts = (uint32_t*)pool_alloc((size_t)(a.nslabs + 1) * 4);
+    a.flags = (unsigned long long*)pool_alloc(256);
+    if (!a.slab_counts || !a.flags) return 1;
+    VNM_HIP(hipMemsetAsync(a.flags, 0, 256, s));
+    int rc = 0;
+    {
+        KernelTimer timer("csv_tokenize", s);
+        csv_count_kernel<<<(int)a.nslabs, 256, 0, s>>>(a);
+        csv_scan_kernel<<<1, 1024, 0, s>>>(a.slab_counts, a.nslabs);
+    }
+    uint32_t total = 0;
+    VNM_HIP(hipMemcpyAsync(&total, a.slab_counts + a.nslabs, 4, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    a.nrows = (int64_t)total;
+    *n_rows = a.nrows;
+    uint8_t* valid_bytes[CSV_MAX_COLS] = {};
+    if (a.nrows > 0) {
+        a.row_start = (int64_t*)pool_alloc((size_t)(a.nrows + 1) * 8);
+        if (!a.row_start) rc = 1;
+        for (int c = 0; !rc && c < n_cols; c++) {
+            a.out_values[c] = pool_alloc((size_t)a.nrows * 8);
+            valid_bytes[c] = (uint8_t*)pool_alloc((size_t)a.nrows);
+            a.out_valid[c] = valid_bytes[c];
+            if (!a.out_values[c] || !valid_bytes[c]) rc = 1;
+        }
+        if (!rc) {
+            KernelTimer timer("csv_parse", s);
+            csv_offsets_kernel<<<(int)a.nslabs, 256, 0, s>>>(a);
+            const int grid = (int)std::min<int64_t>((a.nrows + 255) / 256, (int64_t)device_info().num_cus * 16);
+            csv_parse_kernel<<<grid, 256, 0, s>>>(a);
+        }
+        if (!rc && hipGetLastError() != hipSuccess) rc = set_error("vnm_csv_parse_block: kernel launch failed");
+        // Arrow validity bitmaps
+        for (int c = 0; !rc && c < n_cols; c++) {
+            uint8_t* bm = (uint8_t*)pool_alloc((size_t)((a.nrows + 63) / 64) * 8);
+            if (!bm) { rc = 1; break; }
+            rc = vnm_pack_validity(valid_bytes[c], a.nrows, bm, stream);
+            out_cols[c].values = a.out_values[c];
+            out_cols[c].validity = bm;
+            out_cols[c].length = a.nrows;
+            out_cols[c].type = types[c];
+        }
+    }
+    unsigned long long fl[21] = {};
+    if (!rc) {
+        VNM_HIP(hipMemcpyAsync(fl, a.flags, sizeof(fl), hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipStreamSynchronize(s));
+        for (int c = 0; c < n_cols; c++) fallback[c] = fl[1 + c] != 0;
+        fallback[n_cols] = fl[0] != 0;        // a quote character: the whole block needs the host reader
+        fallback[n_cols + 1] = fl[20] != 0;   // a row with a different number of fields
+    }
+    for (int c = 0; c < n_cols; c++) pool_free(valid_bytes[c]);
+    pool_free(a.row_start);
+    pool_free(a.slab_counts);
+    pool_free(a.flags);
+    vnm_free_column(&text);
+    if (rc) for (int c = 0; c < n_cols; c++) vnm_free_column(&out_cols[c]);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+"""CSV ingest on the GPU: the device counterpart of stream_csv() / read_csv() (vinum/io/arrow.py:9-61, 64-110), which are
+thin wrappers around pyarrow.csv.open_csv / read_csv and parse on one CPU core.
+
+`GpuCsvReader` reads the file in blocks that end on a row boundary, hands each block's TEXT to the library
+(`vnm_csv_parse_block`: one H2D copy, newline scan, one lane per row, exact decimal -> float64) and yields
+`DeviceRecordBatch`es whose numeric columns were never Arrow arrays in host memory.  The schema (names, which columns are
+int64 / float64) comes from pyarrow's own type inference over the first block, as `pyarrow.csv.open_csv` does it.  Only the
+columns the query needs are parsed.  What the device parser does not handle is handed to pyarrow for that block: non-numeric
+columns (strings, timestamps: dictionary-encoded as usual afterwards), blocks containing quote characters, fields outside
+the exact parser's domain ("nan", > 19 significant digits, ...) -- per column and per block, never silently guessed.
+"""
+import ctypes
+import io
+from typing import List, Optional, Sequence
+
+import pyarrow as pa
+import pyarrow.csv as pacsv
+
+from . import _lib as L
+from .core.base import DeviceRecordBatch
+from .device import DeviceBuffer, DeviceColumn
+
+
+class _OwnedColumn(DeviceColumn):
+    """A column whose HBM buffers belong to the library's pool (vnm_csv_parse_block): freed with vnm_free_column."""
+
+    def __init__(self, dcol: L.DCol, arrow_type):
+        super().__init__(dcol.values, dcol.validity or None, int(dcol.offset), int(dcol.length), arrow_type)
+        self._dcol = dcol
+
+    def __del__(self):
+        try:
+            if self._dcol is not None:
+                L.lib().vnm_free_column(ctypes.byref(self._dcol))
+                self._dcol = None
+        except Exception:
+            pass
+
+
+class GpuCsvReader:
+    """Streaming CSV reader with the protocol FileReaderOperator expects (`read_next_batch`, StopIteration at the end),
+    plus `read_next_device_batch()` for the GPU operators.  columns: the column names the query touches (None = all)."""
+
+    def __init__(self, source, columns: Optional[Sequence[str]] = None, block_size: int = 64 << 20):
+        self._f = open(source, "rb") if isinstance(source, (str, bytes)) else source
+        self._block = int(block_size)
+        self._carry = b""
+        self._eof = False
+        first = self._read_block()
+        if not first:
+            raise pa.ArrowInvalid("CSV parse error: Empty CSV file")
+        nl = first.find(b"\n")
+        self._header = first[: nl + 1] if nl >= 0 else first + b"\n"
+        self._pending = first[nl + 1:] if nl >= 0 else b""
+        # pyarrow's own header parsing and type inference over the first block fix names and types for the stream (as open_csv does)
+        probe = pacsv.read_csv(io.BytesIO(self._header + self._pending), read_options=pacsv.ReadOptions(use_threads=False))
+        self.schema = probe.schema
+        self._names = list(probe.schema.names)
+        self._want = list(columns) if columns is not None else list(self._names)
+        for c in self._want:
+            if c not in self._names:
+                raise ValueError(f'Column "{c}" is not found.')
+        self._dicts = {}
+
+    # -- block reading: every block handed on ends with a newline ----------------------------------------------------
+    def _read_block(self) -> bytes:
+        if self._eof:
+            data, self._carry = self._carry, b""
+            return data
+        data = self._carry + self._f.read(self._block)
+        if len(data) < len(self._carry) + self._block:
+            self._eof = True
+            self._carry = b""
+            return data + (b"\n" if data and not data.endswith(b"\n") else b"")
+        cut = data.rfind(b"\n")
+        if cut < 0:
+            self._carry = data
+            return self._read_block()
+        self._carry = data[cut + 1:]
+        return data[: cut + 1]
+
+    def _next_text(self) -> bytes:
+        if self._pending is not None:
+            data, self._pending = self._pending, None
+            if data:
+                return data
+        data = self._read_block()
+        if not data:
+            raise StopIteration
+        return data
+
+    # -- parsing --------------------------------------------------------------------------------------------------------
+    def _host_parse(self, text: bytes, names: List[str]) -> pa.Table:
+        opts = pacsv.ConvertOptions(include_columns=names, column_types={n: self.schema.field(n).type for n in names})
+        return pacsv.read_csv(io.BytesIO(self._header + text), read_options=pacsv.ReadOptions(use_threads=False), convert_options=opts)
+
+    def read_next_device_batch(self) -> DeviceRecordBatch:
+        text = self._next_text()
+        lib = L.lib()
+        gpu_cols = [n for n in self._want if self.schema.field(n).type in (pa.int64(), pa.float64())]
+        gpu_cols.sort(key=self._names.index)
+        cols = {}
+        nrows = None
+        host_cols = [n for n in self._want if n not in gpu_cols]
+        if gpu_cols:
+            k = len(gpu_cols)
+            fidx = (ctypes.c_int * k)(*[self._names.index(n) for n in gpu_cols])
+            types = (ctypes.c_int * k)(*[L.I64 if self.schema.field(n).type == pa.int64() else L.F64 for n in gpu_cols])
+            out = (L.DCol * k)()
+            n_rows = ctypes.c_int64(0)
+            fb = (ctypes.c_int * (k + 2))()
+            L.check(lib.vnm_csv_parse_block(text, len(text), 0, ord(","), len(self._names), k, fidx, types, out, ctypes.byref(n_rows), fb, None))
+            nrows = n_rows.value
+            owned = [_OwnedColumn(out[i], self.schema.field(n).type) for i, n in enumerate(gpu_cols)]
+            if fb[k] or fb[k + 1]:          # quotes / ragged rows: the whole block goes through pyarrow (which raises on ragged rows)
+                host_cols, gpu_cols = list(self._want), []
+            else:
+                for i, n in enumerate(gpu_cols):
+                    if fb[i]:
+                        host_cols.append(n)    # a field the exact device parser does not cover
+                    else:
+                        cols[n] = owned[i]
+        if host_cols:
+            t = self._host_parse(text, host_cols)
+            nrows = t.num_rows if nrows is None else nrows
+            b = t.combine_chunks().to_batches()[0] if t.num_rows else None
+            staged = DeviceRecordBatch.from_arrow(b, self._dicts) if b is not None else None
+            for n in host_cols:
+                cols[n] = staged.columns[n] if staged is not None else DeviceColumn.from_arrow(pa.array([], self.schema.field(n).type))
+        return DeviceRecordBatch({n: cols[n] for n in self._want}, nrows or 0)
+
+    def read_next_batch(self) -> pa.RecordBatch:
+        return self.read_next_device_batch().to_arrow()
+
+    def close(self):
+        try:
+            self._f.close()
+        except Exception:
+            pass
+
+
+def stream_csv(input_file, columns: Optional[Sequence[str]] = None, block_size: int = 64 << 20) -> GpuCsvReader:
+    """vinum.stream_csv (vinum/io/arrow.py:9-61) with the numeric columns tokenised and parsed on the device."""
+    return GpuCsvReader(input_file, columns=columns, block_size=block_size)

@@ -113,6 +113,8 @@ def plan_query(query: Dict, source, expected_groups: int = 0) -> Plan:
             used = [source.schema.names[0]]          # count(*) only: keep one column for the row count (:354-355)
         op = TableReaderOperator(source, columns=used)
     else:
+        if hasattr(source, "read_next_device_batch") and used:
+            source._want = [c for c in used]          # column pruning reaches the CSV parser: only these fields are parsed
         op = FileReaderOperator(source, columns=used or None)
     steps.append(("read", tuple(used)))
 
