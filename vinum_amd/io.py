@@ -42,18 +42,26 @@ class GpuCsvReader:
     plus `read_next_device_batch()` for the GPU operators.  columns: the column names the query touches (None = all)."""
 
     def __init__(self, source, columns: Optional[Sequence[str]] = None, block_size: int = 64 << 20):
-        self._f = open(source, "rb") if isinstance(source, (str, bytes)) else source
+        self._f = open(source, "rb", buffering=0) if isinstance(source, (str, bytes)) else source
         self._block = int(block_size)
-        self._carry = b""
+        # one reusable buffer: [carry from the previous block | freshly read bytes]; blocks are handed to the library as
+        # (pointer, length) views of it -- the text is never copied on the host
+        self._buf = bytearray(self._block + (1 << 20))
+        self._have = 0            # valid bytes in the buffer
         self._eof = False
-        first = self._read_block()
-        if not first:
+        self._fill()
+        if self._have == 0:
             raise pa.ArrowInvalid("CSV parse error: Empty CSV file")
-        nl = first.find(b"\n")
-        self._header = first[: nl + 1] if nl >= 0 else first + b"\n"
-        self._pending = first[nl + 1:] if nl >= 0 else b""
-        # pyarrow's own header parsing and type inference over the first block fix names and types for the stream (as open_csv does)
-        probe = pacsv.read_csv(io.BytesIO(self._header + self._pending), read_options=pacsv.ReadOptions(use_threads=False))
+        nl = self._buf.find(b"\n", 0, self._have)
+        if nl < 0:
+            raise pa.ArrowInvalid("CSV parse error: no line end in the first block")
+        self._header = bytes(self._buf[: nl + 1])
+        self._start = nl + 1      # first unconsumed byte of the buffer
+        # pyarrow's own header parsing and type inference over the first rows fix names and types for the stream (open_csv
+        # infers from its first block too)
+        end = self._buf.rfind(b"\n", self._start, min(self._have, self._start + (1 << 20))) + 1
+        probe = pacsv.read_csv(io.BytesIO(self._header + bytes(self._buf[self._start:max(end, self._start)])),
+                               read_options=pacsv.ReadOptions(use_threads=False))
         self.schema = probe.schema
         self._names = list(probe.schema.names)
         self._want = list(columns) if columns is not None else list(self._names)
@@ -63,31 +71,47 @@ class GpuCsvReader:
         self._dicts = {}
 
     # -- block reading: every block handed on ends with a newline ----------------------------------------------------
-    def _read_block(self) -> bytes:
-        if self._eof:
-            data, self._carry = self._carry, b""
-            return data
-        data = self._carry + self._f.read(self._block)
-        if len(data) < len(self._carry) + self._block:
-            self._eof = True
-            self._carry = b""
-            return data + (b"\n" if data and not data.endswith(b"\n") else b"")
-        cut = data.rfind(b"\n")
-        if cut < 0:
-            self._carry = data
-            return self._read_block()
-        self._carry = data[cut + 1:]
-        return data[: cut + 1]
+    def _fill(self):
+        """read until the buffer is full or the file ends"""
+        mv = memoryview(self._buf)
+        while not self._eof and self._have < len(self._buf) - (1 << 16):
+            got = self._f.readinto(mv[self._have:])
+            if not got:
+                self._eof = True
+                if self._have and self._buf[self._have - 1] != 0x0A:      # a last line without a newline
+                    self._buf[self._have] = 0x0A
+                    self._have += 1
+                break
+            self._have += got
 
-    def _next_text(self) -> bytes:
-        if self._pending is not None:
-            data, self._pending = self._pending, None
-            if data:
-                return data
-        data = self._read_block()
-        if not data:
-            raise StopIteration
-        return data
+    def _next_text(self):
+        """(offset, length) of the next block inside the buffer: whole rows only"""
+        if self._start >= self._have:
+            if self._eof:
+                raise StopIteration
+            self._have, self._start = 0, 0
+            self._fill()
+            if self._have == 0:
+                raise StopIteration
+        cut = self._buf.rfind(b"\n", self._start, self._have)
+        if cut < 0:
+            if self._eof:
+                raise StopIteration
+            raise pa.ArrowInvalid("CSV parse error: a row longer than the block size")
+        off, length = self._start, cut + 1 - self._start
+        self._pending_tail = (cut + 1, self._have)
+        return off, length
+
+    def _advance(self):
+        """after a block was consumed: move the partial last row to the front and read on"""
+        lo, hi = self._pending_tail
+        tail = hi - lo
+        self._buf[:tail] = self._buf[lo:hi]
+        self._have, self._start = tail, 0
+        if not self._eof:
+            self._fill()
+        elif tail == 0:
+            self._start = self._have = 0
 
     # -- parsing --------------------------------------------------------------------------------------------------------
     def _host_parse(self, text: bytes, names: List[str]) -> pa.Table:
@@ -95,8 +119,15 @@ class GpuCsvReader:
         return pacsv.read_csv(io.BytesIO(self._header + text), read_options=pacsv.ReadOptions(use_threads=False), convert_options=opts)
 
     def read_next_device_batch(self) -> DeviceRecordBatch:
-        text = self._next_text()
+        off, length = self._next_text()
+        try:
+            return self._parse_block(off, length)
+        finally:
+            self._advance()
+
+    def _parse_block(self, off: int, length: int) -> DeviceRecordBatch:
         lib = L.lib()
+        text_ptr = ctypes.addressof((ctypes.c_char * length).from_buffer(self._buf, off))
         gpu_cols = [n for n in self._want if self.schema.field(n).type in (pa.int64(), pa.float64())]
         gpu_cols.sort(key=self._names.index)
         cols = {}
@@ -109,7 +140,7 @@ class GpuCsvReader:
             out = (L.DCol * k)()
             n_rows = ctypes.c_int64(0)
             fb = (ctypes.c_int * (k + 2))()
-            L.check(lib.vnm_csv_parse_block(text, len(text), 0, ord(","), len(self._names), k, fidx, types, out, ctypes.byref(n_rows), fb, None))
+            L.check(lib.vnm_csv_parse_block(text_ptr, length, 0, ord(","), len(self._names), k, fidx, types, out, ctypes.byref(n_rows), fb, None))
             nrows = n_rows.value
             owned = [_OwnedColumn(out[i], self.schema.field(n).type) for i, n in enumerate(gpu_cols)]
             if fb[k] or fb[k + 1]:          # quotes / ragged rows: the whole block goes through pyarrow (which raises on ragged rows)
@@ -121,7 +152,7 @@ class GpuCsvReader:
                     else:
                         cols[n] = owned[i]
         if host_cols:
-            t = self._host_parse(text, host_cols)
+            t = self._host_parse(bytes(self._buf[off:off + length]), host_cols)
             nrows = t.num_rows if nrows is None else nrows
             b = t.combine_chunks().to_batches()[0] if t.num_rows else None
             staged = DeviceRecordBatch.from_arrow(b, self._dicts) if b is not None else None
