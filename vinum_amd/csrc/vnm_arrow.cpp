@@ -100,6 +100,25 @@ void make_primitive(struct ArrowArray* a, int64_t n, int width, const void* valu
     a->release = release_array;
 }
 
+// primitive array whose buffers are filled by D2H copies of device-finalised Arrow buffers (values of `width` bytes + bitmap)
+int make_primitive_from_device(struct ArrowArray* a, int64_t n, int width, const void* dev_values, const uint8_t* dev_bitmap, int64_t null_count) {
+    memset(a, 0, sizeof(*a));
+    a->length = n;
+    a->n_buffers = 2;
+    a->buffers = (const void**)calloc(2, sizeof(void*));
+    a->null_count = null_count;
+    a->release = release_array;
+    void* data = malloc((size_t)(n ? n : 1) * width);
+    a->buffers[1] = data;
+    if (n && hipMemcpy(data, dev_values, (size_t)n * width, hipMemcpyDeviceToHost) != hipSuccess) return set_error("result: device to host copy failed");
+    if (null_count) {
+        uint8_t* bm = (uint8_t*)calloc((size_t)((n + 63) / 64) * 8, 1);
+        a->buffers[0] = bm;
+        if (hipMemcpy(bm, dev_bitmap, (size_t)((n + 7) / 8), hipMemcpyDeviceToHost) != hipSuccess) return set_error("result: device to host copy failed");
+    }
+    return 0;
+}
+
 void make_struct(struct ArrowArray* a, int64_t n, int64_t n_children) {
     memset(a, 0, sizeof(*a));
     a->length = n;
@@ -271,6 +290,50 @@ int vnm_agg_op_result(vnm_agg_op* h, struct ArrowArray* out, struct ArrowSchema*
     const int64_t ncols = (int64_t)h->agg_cols.size() + (int64_t)h->funcs.size();
     make_struct(out, n, ncols);
     make_schema(out_schema, "+s", "", ncols);
+    // BaseAggregate::Result on the DEVICE: every column is finalised by a kernel into Arrow-layout buffers and only those
+    // cross PCIe (8 bytes per group and column instead of all accumulator words + a serial host loop).  The one case that
+    // changes a column's TYPE -- an int64 / uint64 SUM overflowing 64 bits (-> decimal128, agg_funcs.h:366-389) -- makes
+    // the kernel return 2 and the whole result falls back to the host finaliser below.
+    if (getenv("VNM_AGG_HOST_FINALIZE") == nullptr) {
+        void* dv = pool_alloc((size_t)(n ? n : 1) * 8);
+        uint8_t* db = (uint8_t*)pool_alloc((size_t)((n + 63) / 64 + 1) * 8);
+        if (!dv || !db) return 1;
+        int rc = 0, col = 0;
+        for (size_t a = 0; !rc && a < h->agg_cols.size(); a++, col++) {
+            const int j = h->aggcol_key[a];
+            const ColType& t = h->key_t[j];
+            int64_t nulls = 0;
+            rc = vnm_agg_result_key_device(h->dev, j, dv, db, &nulls, nullptr);
+            if (!rc) rc = make_primitive_from_device(out->children[col], n, type_width(t.type), dv, db, nulls);
+            make_schema(out_schema->children[col], t.format, h->agg_cols[a], 0);
+        }
+        for (size_t i = 0; !rc && i < h->funcs.size(); i++, col++) {
+            int kind = 0;
+            int64_t nulls = 0;
+            rc = vnm_agg_result_func_device(h->dev, (int)i, dv, db, &kind, &nulls, nullptr);
+            if (rc) break;
+            const ColType& t = h->in_t[i];
+            const int f = h->funcs[i];
+            std::string fmt;
+            int w = 8;
+            if (f == VNM_MIN || f == VNM_MAX) { fmt = t.format; w = type_width(t.type); }
+            else if (kind == VNM_OUT_U64) fmt = "L";
+            else if (kind == VNM_OUT_I64) {
+                fmt = "l";
+                if (f == VNM_SUM && (t.format == "ttu" || t.format == "ttn" || t.format.rfind("tD", 0) == 0)) fmt = t.format;
+            } else if (kind == VNM_OUT_I32) { fmt = t.format; w = 4; }
+            else if (kind == VNM_OUT_F64) fmt = "g";
+            else { fmt = "f"; w = 4; }
+            rc = make_primitive_from_device(out->children[col], n, w, dv, db, nulls);
+            make_schema(out_schema->children[col], fmt, h->out_cols[i], 0);
+        }
+        pool_free(dv); pool_free(db);
+        if (rc == 0) return 0;
+        release_array(out); release_schema(out_schema);       // rebuilt below
+        if (rc != 2) return rc;
+        make_struct(out, n, ncols);
+        make_schema(out_schema, "+s", "", ncols);
+    }
     std::vector<uint64_t> vals((size_t)(n ? n : 1));
     std::vector<uint8_t> valid((size_t)(n ? n : 1));
     std::vector<uint8_t> cells((size_t)(n ? n : 1) * 16);
