@@ -211,6 +211,12 @@ int vnm_agg_result_func(vnm_agg* h, int func_idx, void* cells16, uint8_t* valid,
  * 64 bits in some group: the reference then promotes the whole column to decimal128 (agg_funcs.h:366-389), which
  * vnm_agg_result_func does on the host. */
 int vnm_agg_result_key_device(vnm_agg* h, int key_idx, void* out_values, uint8_t* out_bitmap, int64_t* null_count, void* stream);
+/* The same for n_cols result columns in ONE kernel launch (the accumulator words of a group are read once and
+ * the launch cost is paid once): which[c] >= 0 selects aggregate function which[c], which[c] < 0 selects key
+ * column ~which[c].  out_kinds[c] = VNM_OUT_* of a function column, -1 for a key column (it keeps its input
+ * type).  Returns 2 when any selected int64 / uint64 SUM overflowed (all other columns are still valid). */
+int vnm_agg_result_device(vnm_agg* h, int n_cols, const int* which, void* const* out_values,
+                          uint8_t* const* out_bitmaps, int* out_kinds, int64_t* null_counts, void* stream);
 int vnm_agg_result_func_device(vnm_agg* h, int func_idx, void* out_values, uint8_t* out_bitmap, int* out_kind,
                                int64_t* null_count, void* stream);
 

@@ -352,3 +352,22 @@ def test_random_expressions_narrow_types_vs_numpy(seed):
         else:
             same = got == ref
         assert same.all(), f"seed {seed}: {e}: row {int(np.argmin(same))}: {got[np.argmin(same)]!r} vs {ref[np.argmin(same)]!r}"
+
+
+def test_out_of_range_literal_true_division_vs_numpy():
+    """NumPy range-checks a Python integer against the column's type for + - * % (OverflowError) but not for true division,
+    which runs in float64 for every integer width (fuzz seed 73 of the 400-seed campaign: `~59 / uint64`)."""
+    from vinum_amd.device import DeviceColumn
+    from vinum_amd import ops
+    cols = {"u64": np.array([5, 7, 2**63 + 3], np.uint64), "i8": np.array([5, -7, 100], np.int8), "u8": np.array([1, 2, 255], np.uint8)}
+    dev = {k: DeviceColumn.from_arrow(pa.array(v)) for k, v in cols.items()}
+    good = [(("div", "u64", -60), np.divide(cols["u64"], -60)), (("div", -60, "u64"), np.divide(-60, cols["u64"])),
+            (("div", "i8", 300), np.divide(cols["i8"], 300)), (("div", ("bnot", 59), "u8"), np.divide(~59, cols["u8"])),
+            (("div", 300, "i8"), np.divide(300, cols["i8"]))]
+    outs = ops.project_many([e for e, _ in good], dev, length=3)
+    for (e, ref), out in zip(good, outs):
+        got = out.to_numpy()
+        assert got.dtype == np.float64 and (got.view(np.uint64) == ref.view(np.uint64)).all(), (e, got, ref)
+    for e in [("add", "u64", -60), ("mod", "i8", 300), ("mul", -1, "u8"), ("sub", 300, "i8")]:
+        with pytest.raises(Exception, match="out of bounds"):
+            ops.project_many([e], dev, length=3)

@@ -2437,7 +2437,7 @@ struct FinArgs {
     int64_t n;
     void* out;
     unsigned long long* bitmap;   // (n + 63) / 64 words
-    unsigned long long* ctl;      // [0] null count  [1] a 64-bit SUM overflowed
+    unsigned long long* ctl;      // [0] null count  [1] a 64-bit SUM overflowed  (this column's pair)
 };
 
 __device__ __forceinline__ void fin_store(void* out, int width, int64_t i, uint64_t bits) {
@@ -2454,16 +2454,11 @@ __device__ __forceinline__ double fin_huge_to_double(uint64_t lower, int64_t upp
     return (double)lower + (double)upper * 18446744073709551615.0;
 }
 
-__global__ __launch_bounds__(256) void agg_finalize_kernel(FinArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+// one result cell: group i of one output column
+__device__ __forceinline__ void fin_cell(const FinArgs& a, int64_t i, bool& valid, uint64_t& bits) {
     const int t = a.fo.in_type;
-    const int64_t nround = (a.n + 63) & ~63LL;
-    unsigned long long nulls = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += stride) {
-        bool valid = false;
-        uint64_t bits = 0;
-        if (i < a.n) {
+    {
+        {
             if (a.is_key) {
                 valid = !((a.words[0][i] >> a.key_bit) & 1ULL);
                 bits = a.words[1][i];
@@ -2533,16 +2528,40 @@ __global__ __launch_bounds__(256) void agg_finalize_kernel(FinArgs a) {
                     }
                 }
             }
-            fin_store(a.out, a.out_width, i, valid ? bits : 0);
-        }
-        const unsigned long long b = __ballot(valid);
-        if (lane == 0) {
-            a.bitmap[i >> 6] = b;
-            const int64_t live = a.n - i >= 64 ? 64 : a.n - i;
-            nulls += (unsigned long long)(live - __popcll(b));
         }
     }
-    if (lane == 0 && nulls) atomicAdd(&a.ctl[0], nulls);
+}
+
+// Every requested output column in ONE launch: a group's accumulator words are read once per column that uses them (the second
+// reader hits L2) and the launch / tail cost is paid once.  ctl[2c] = NULL count of column c, ctl[2c + 1] = its SUM overflowed.
+constexpr int FIN_MAX_COLS = 8;
+struct FinMulti {
+    FinArgs col[FIN_MAX_COLS];
+    int n_cols;
+    int64_t n;
+};
+
+__global__ __launch_bounds__(256) void agg_finalize_kernel(FinMulti m) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nround = (m.n + 63) & ~63LL;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += stride) {
+        for (int c = 0; c < m.n_cols; c++) {
+            const FinArgs& a = m.col[c];
+            bool valid = false;
+            uint64_t bits = 0;
+            if (i < m.n) {
+                fin_cell(a, i, valid, bits);
+                fin_store(a.out, a.out_width, i, valid ? bits : 0);
+            }
+            const unsigned long long b = __ballot(valid);
+            if (lane == 0) {
+                a.bitmap[i >> 6] = b;
+                const int64_t live = m.n - i >= 64 ? 64 : m.n - i;
+                if (live != __popcll(b)) atomicAdd(&a.ctl[0], (unsigned long long)(live - __popcll(b)));
+            }
+        }
+    }
 }
 
 }  // namespace vnm
@@ -4183,36 +4202,8 @@ int vnm_agg_result_func(vnm_agg* h, int func_idx, void* cells16, uint8_t* valid,
 }
 
 // ---- device-side result columns ---------------------------------------------------------------------------
-static int finalize_on_device(vnm_agg* h, FinArgs& f, void* out_values, uint8_t* out_bitmap, int64_t* null_count, hipStream_t s) {
-    const int64_t n = h->n_groups;
-    f.n = n;
-    f.out = out_values;
-    f.bitmap = (unsigned long long*)out_bitmap;
-    if (null_count) *null_count = 0;
-    if (n == 0) return 0;
-    unsigned long long* ctl = (unsigned long long*)pool_alloc(64);
-    if (!ctl) return 1;
-    VNM_HIP(hipMemsetAsync(ctl, 0, 16, s));
-    f.ctl = ctl;
-    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_info().num_cus * 16);
-    {
-        KernelTimer timer("agg_finalize", s);
-        agg_finalize_kernel<<<grid, 256, 0, s>>>(f);
-    }
-    VNM_HIP(hipGetLastError());
-    unsigned long long c[2] = {0, 0};
-    VNM_HIP(hipMemcpyAsync(c, ctl, 16, hipMemcpyDeviceToHost, s));
-    VNM_HIP(hipStreamSynchronize(s));
-    pool_free(ctl);
-    if (null_count) *null_count = (int64_t)c[0];
-    return c[1] ? 2 : 0;
-}
-
-int vnm_agg_result_key_device(vnm_agg* h, int key_idx, void* out_values, uint8_t* out_bitmap, int64_t* null_count, void* stream) {
-    if (!h) return set_error("vnm_agg_result_key_device: null handle");
-    if (key_idx < 0 || key_idx >= h->plan.n_keys) return set_error("vnm_agg_result_key_device: key index out of range");
-    VNM_TRY(vnm_agg_finish(h, nullptr, stream));
-    FinArgs f{};
+namespace {
+void fin_key_args(vnm_agg* h, int key_idx, FinArgs& f) {
     f.is_key = 1;
     f.key_bit = key_idx;
     f.out_width = type_width(h->plan.key_types[key_idx]);
@@ -4220,17 +4211,11 @@ int vnm_agg_result_key_device(vnm_agg* h, int key_idx, void* out_values, uint8_t
         f.words[1] = h->dkey + (size_t)key_idx * h->dstride;
         f.words[0] = h->dkey + (size_t)h->plan.n_keys * h->dstride;
     }
-    return finalize_on_device(h, f, out_values, out_bitmap, null_count, as_stream(stream));
 }
 
-int vnm_agg_result_func_device(vnm_agg* h, int func_idx, void* out_values, uint8_t* out_bitmap, int* out_kind, int64_t* null_count,
-                               void* stream) {
-    if (!h) return set_error("vnm_agg_result_func_device: null handle");
-    if (func_idx < 0 || func_idx >= h->n_funcs) return set_error("vnm_agg_result_func_device: function index out of range");
-    VNM_TRY(vnm_agg_finish(h, nullptr, stream));
+int fin_func_args(vnm_agg* h, int func_idx, FinArgs& f) {  // returns the VNM_OUT_* kind of the column
     const FuncOut& fo = h->outs[func_idx];
     const int t = fo.in_type;
-    FinArgs f{};
     f.fo = fo;
     int kind = VNM_OUT_U64, width = 8;
     switch (fo.func) {
@@ -4251,14 +4236,80 @@ int vnm_agg_result_func_device(vnm_agg* h, int func_idx, void* out_values, uint8
             break;
     }
     f.out_width = width;
-    if (out_kind) *out_kind = kind;
     if (h->n_groups > 0) {
         auto word = [&](int w) -> const uint64_t* { return w >= 0 ? h->dacc + (size_t)w * h->dstride : nullptr; };
         f.words[0] = word(fo.w_valid);
         f.words[1] = word(fo.w_a);
         f.words[2] = word(fo.w_b);
     }
-    return finalize_on_device(h, f, out_values, out_bitmap, null_count, as_stream(stream));
+    return kind;
+}
+}  // namespace
+
+int vnm_agg_result_device(vnm_agg* h, int n_cols, const int* which, void* const* out_values, uint8_t* const* out_bitmaps,
+                          int* out_kinds, int64_t* null_counts, void* stream) {
+    if (!h) return set_error("vnm_agg_result_device: null handle");
+    if (n_cols < 0 || (n_cols > 0 && (!which || !out_values || !out_bitmaps))) return set_error("vnm_agg_result_device: bad arguments");
+    for (int c = 0; c < n_cols; c++) {
+        const int w = which[c];
+        if (w >= 0 ? w >= h->n_funcs : ~w >= h->plan.n_keys) return set_error("vnm_agg_result_device: column index out of range");
+    }
+    VNM_TRY(vnm_agg_finish(h, nullptr, stream));
+    hipStream_t s = as_stream(stream);
+    const int64_t n = h->n_groups;
+    int rc = 0;
+    for (int base = 0; base < n_cols; base += FIN_MAX_COLS) {
+        const int nc = std::min(FIN_MAX_COLS, n_cols - base);
+        FinMulti m{};
+        m.n_cols = nc;
+        m.n = n;
+        unsigned long long* ctl = n > 0 ? (unsigned long long*)pool_alloc(16 * FIN_MAX_COLS) : nullptr;
+        if (n > 0 && !ctl) return 1;
+        for (int c = 0; c < nc; c++) {
+            FinArgs& f = m.col[c];
+            const int w = which[base + c];
+            int kind = -1;
+            if (w < 0) fin_key_args(h, ~w, f);
+            else kind = fin_func_args(h, w, f);
+            if (out_kinds) out_kinds[base + c] = kind;
+            if (null_counts) null_counts[base + c] = 0;
+            f.n = n;
+            f.out = out_values[base + c];
+            f.bitmap = (unsigned long long*)out_bitmaps[base + c];
+            f.ctl = ctl + 2 * c;
+        }
+        if (n == 0) continue;
+        VNM_HIP(hipMemsetAsync(ctl, 0, 16 * FIN_MAX_COLS, s));
+        const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_info().num_cus * 16);
+        {
+            KernelTimer timer("agg_finalize", s);
+            agg_finalize_kernel<<<grid, 256, 0, s>>>(m);
+        }
+        VNM_HIP(hipGetLastError());
+        unsigned long long c2[2 * FIN_MAX_COLS];
+        VNM_HIP(hipMemcpyAsync(c2, ctl, 16 * FIN_MAX_COLS, hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipStreamSynchronize(s));
+        pool_free(ctl);
+        for (int c = 0; c < nc; c++) {
+            if (null_counts) null_counts[base + c] = (int64_t)c2[2 * c];
+            if (c2[2 * c + 1]) rc = 2;
+        }
+    }
+    return rc;
+}
+
+int vnm_agg_result_key_device(vnm_agg* h, int key_idx, void* out_values, uint8_t* out_bitmap, int64_t* null_count, void* stream) {
+    if (!h) return set_error("vnm_agg_result_key_device: null handle");
+    if (key_idx < 0 || key_idx >= h->plan.n_keys) return set_error("vnm_agg_result_key_device: key index out of range");
+    const int which = ~key_idx;
+    return vnm_agg_result_device(h, 1, &which, &out_values, &out_bitmap, nullptr, null_count, stream);
+}
+
+int vnm_agg_result_func_device(vnm_agg* h, int func_idx, void* out_values, uint8_t* out_bitmap, int* out_kind, int64_t* null_count,
+                               void* stream) {
+    if (!h) return set_error("vnm_agg_result_func_device: null handle");
+    if (func_idx < 0 || func_idx >= h->n_funcs) return set_error("vnm_agg_result_func_device: function index out of range");
+    return vnm_agg_result_device(h, 1, &func_idx, &out_values, &out_bitmap, out_kind, null_count, stream);
 }
 
 // host-only helpers: plan lowering and finalisation from accumulator words (no GPU needed)

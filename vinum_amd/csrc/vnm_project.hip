@@ -467,7 +467,8 @@ static int project_impl(int n_ins, const vnm_expr_ins* program, int n_cols, cons
                     const int w = wa ? ta : tb, t = wa ? tb : ta, wslot = wa ? sp - 2 : sp - 1;
                     if (w == T_WI) {
                         rt = t;                                                               // the literal takes the column's type
-                        if (!type_is_float(t) && lit[wslot] >= 0 && !pj_int_fits(t, a.ins[lit[wslot]].imm_i))
+                        // true division runs in float64 whatever the integer width: NumPy converts the literal to double, no range check
+                        if (in.op != VNM_EX_DIV && !type_is_float(t) && lit[wslot] >= 0 && !pj_int_fits(t, a.ins[lit[wslot]].imm_i))
                             return set_error("OverflowError: Python integer %lld out of bounds for %s", (long long)a.ins[lit[wslot]].imm_i, pj_type_name(t));
                         if (t == VNM_F32) round_lit_f32(wslot);
                     } else {

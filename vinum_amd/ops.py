@@ -235,28 +235,24 @@ class DeviceAggregate:
         n = self.finish(stream=stream)
         if key_indices is None:
             key_indices = range(len(self.key_arrow))
-        cols = []
+        which = [~j for j in key_indices] + list(range(len(self.funcs)))
+        nc = len(which)
         nb = ((n + 63) // 64) * 8
-
-        def column(call, arrow_type_of):
-            vals = DeviceBuffer(max(n, 1) * 8)
-            bitmap = DeviceBuffer(max(nb, 8))
-            nulls = ctypes.c_int64(0)
-            kind = ctypes.c_int(-1)
-            rc = call(vals, bitmap, kind, nulls)
-            if rc == 2:
-                raise NeedsHostFinalize(L.last_error() or "a 64-bit SUM overflowed: decimal128 result")
-            L.check(rc)
-            return DeviceColumn(vals, bitmap if nulls.value else None, 0, n, arrow_type_of(kind.value))
-
-        for j in key_indices:
-            cols.append(column(lambda v, b, k, nl, j=j: lib.vnm_agg_result_key_device(self._h, j, v.ptr, b.ptr, ctypes.byref(nl),
-                                                                                       _stream_ptr(stream)),
-                               lambda kind, j=j: self.key_arrow[j]))
-        for i, (f, col, in_t) in enumerate(self.funcs):
-            cols.append(column(lambda v, b, k, nl, i=i: lib.vnm_agg_result_func_device(self._h, i, v.ptr, b.ptr, ctypes.byref(k),
-                                                                                        ctypes.byref(nl), _stream_ptr(stream)),
-                               lambda kind, f=f, in_t=in_t: _func_arrow_type(f, in_t, kind)))
+        vals = [DeviceBuffer(max(n, 1) * 8) for _ in which]
+        bitmaps = [DeviceBuffer(max(nb, 8)) for _ in which]
+        c_which = (ctypes.c_int * nc)(*which)
+        c_vals = (ctypes.c_void_p * nc)(*[v.ptr for v in vals])
+        c_bitmaps = (ctypes.c_void_p * nc)(*[b.ptr for b in bitmaps])
+        kinds = (ctypes.c_int * nc)()
+        nulls = (ctypes.c_int64 * nc)()
+        rc = lib.vnm_agg_result_device(self._h, nc, c_which, c_vals, c_bitmaps, kinds, nulls, _stream_ptr(stream))
+        if rc == 2:
+            raise NeedsHostFinalize(L.last_error() or "a 64-bit SUM overflowed: decimal128 result")
+        L.check(rc)
+        cols = []
+        for c, w in enumerate(which):
+            t = self.key_arrow[~w] if w < 0 else _func_arrow_type(self.funcs[w][0], self.funcs[w][2], kinds[c])
+            cols.append(DeviceColumn(vals[c], bitmaps[c] if nulls[c] else None, 0, n, t))
         return cols
 
     def close(self):
