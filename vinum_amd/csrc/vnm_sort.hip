@@ -7,12 +7,15 @@
 //
 //   * every key column is turned into an order-preserving unsigned 64-bit code (DESC = complemented code)
 //     plus a 2-bit class (0 value, 1 NaN, 2 NULL);
-//   * full sort: stable LSD radix sort of (code, row id), 8 bits per pass, key columns from last to first,
-//     passes whose digit is identical for every row are skipped (one OR/AND reduction finds them);
+//   * full sort: stable LSD radix sort of (code, row id), 8 bits per pass, key columns from last to first: the encode kernel
+//     also produces all eight digit histograms, each pass is ONE kernel (chained scan over the tiles, "onesweep"), passes
+//     whose digit is identical for every row are skipped, the first pass makes up the identity row ids and the last one
+//     writes int64 row ids straight into the caller's buffer;
 //   * LIMIT K on a single key: a threshold taken from a sorted sample selects ~K..4K candidates in one scan
 //     of the column (8 B/row), only the candidates are sorted -- identical first K rows (ties keep row
 //     order) as the reference's full sort + SliceOperator (vinum/core/algebra.py:229-247).
-// Roofline: HBM.  top-K: 8*N read; full sort: 12 B/row read + 12 B/row written per executed pass.
+// Roofline: HBM.  top-K: 8*N read; full sort: 8 B/row read + 8 written by the encode, 12 B/row read + 12 B/row written per
+// executed pass (8 + 12 for the first, 12 + 8 for the last).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -21,9 +24,6 @@
 
 namespace vnm {
 
-constexpr int RS_BLOCK = 1024;           // scatter block: 16 waves, 1024 elements per sub-tile
-constexpr int RS_WAVES = RS_BLOCK / 64;
-constexpr int RS_MAX_BLOCKS = 1024;
 
 // ---- key encoding ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void encode_key(const vnm_dcol& c, int64_t row, int desc, uint64_t* code, uint32_t* cls) {
@@ -43,20 +43,55 @@ __device__ __forceinline__ void encode_key(const vnm_dcol& c, int64_t row, int d
     *cls = 0;
 }
 
-// code[i], cls[i] for row idx[i] (idx == NULL: identity)
+// Digit histograms of one wave's codes into the workgroup's LDS table h[8][256] (all 64 lanes hold an element).
+// The upper bytes of real keys are often identical across a wave: one add of 64 instead of 64 same-address adds.
+__device__ __forceinline__ void hist8_wave(uint32_t* h, uint64_t c, int lane) {
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const uint32_t dg = (uint32_t)(c >> (8 * b)) & 255u;
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)dg);
+        if (__ballot(dg != first) == 0) { if (lane == 0) atomicAdd(&h[b * 256 + first], 64u); }
+        else atomicAdd(&h[b * 256 + dg], 1u);
+    }
+}
+
+// code[i] (and cls[i] when cls != NULL) for row idx[i] (idx == NULL: identity); class_codes: code[i] = the row's class
+// (0 value, 1 NaN, 2 NULL) instead -- the input of the class pass
 // any_cls (optional): set to 1 when some row is NaN or NULL (class != 0) -- lets the caller skip the class pass
-__global__ void sort_encode_kernel(vnm_dcol c, int desc, const uint32_t* idx, int64_t n, uint64_t* code, uint8_t* cls,
-                                   unsigned long long* any_cls) {
+// ghist (optional): the eight digit histograms of the codes are accumulated on the way (radix_sort_codes then needs no
+// histogram pass of its own: one read of the codes less)
+__global__ __launch_bounds__(256) void sort_encode_kernel(vnm_dcol c, int desc, const uint32_t* idx, int64_t n, uint64_t* code, uint8_t* cls,
+                                                          unsigned long long* any_cls, unsigned long long* ghist, int class_codes) {
+    __shared__ uint32_t h[8 * 256];
+    if (ghist) {
+        for (int i = threadIdx.x; i < 8 * 256; i += 256) h[i] = 0;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nfull = n & ~63LL;
     bool special = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         uint64_t e; uint32_t k;
         encode_key(c, idx ? (int64_t)idx[i] : i, desc, &e, &k);
+        if (class_codes) e = k;
         code[i] = e;
-        cls[i] = (uint8_t)k;
+        if (cls) cls[i] = (uint8_t)k;
         special = special || k != 0;
+        if (ghist) {
+            if (i < nfull) hist8_wave(h, e, lane);   // i < nfull is uniform across the wave (64-aligned chunks)
+            else {
+#pragma unroll
+                for (int b = 0; b < 8; b++) atomicAdd(&h[b * 256 + ((uint32_t)(e >> (8 * b)) & 255u)], 1u);
+            }
+        }
     }
-    if (any_cls && __ballot(special) && (threadIdx.x & 63) == 0) atomicOr(any_cls, 1ULL);
+    if (any_cls && __ballot(special) && lane == 0) atomicOr(any_cls, 1ULL);
+    if (ghist) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 8 * 256; i += 256)
+            if (h[i]) atomicAdd(&ghist[i], (unsigned long long)h[i]);
+    }
 }
 
 __global__ void sort_iota_kernel(uint32_t* idx, int64_t n) {
@@ -67,101 +102,109 @@ __global__ void sort_widen_kernel(const uint32_t* idx, int64_t n, int64_t* out) 
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (int64_t)idx[i];
 }
-__global__ void sort_cls_to_code_kernel(const uint8_t* cls, int64_t n, uint64_t* code) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) code[i] = cls[i];
-}
 
-// OR / AND over all codes: digits where they agree are constant and need no pass.  red[0]=OR, red[1]=AND
-__global__ void sort_orand_kernel(const uint64_t* code, int64_t n, unsigned long long* red) {
-    uint64_t o = 0, a = ~0ULL;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { o |= code[i]; a &= code[i]; }
-    for (int d = 32; d > 0; d >>= 1) { o |= __shfl_xor(o, d); a &= __shfl_xor(a, d); }
-    // one atomic pair per workgroup: 8192 same-address atomics (one pair per wave of a 4-per-CU grid) cost ~95 us,
-    // five times per top-K query
-    __shared__ unsigned long long so[4], sa[4];
-    if ((threadIdx.x & 63) == 0) { so[threadIdx.x >> 6] = o; sa[threadIdx.x >> 6] = a; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); w++) { o |= so[w]; a &= sa[w]; }
-        atomicOr(&red[0], (unsigned long long)o);
-        atomicAnd(&red[1], (unsigned long long)a);
-    }
-}
+// ---- onesweep: one histogram pre-pass for all eight digits, then ONE kernel per executed pass ------------------------
+// r01 ran three kernels per pass (per-block histogram: a full extra read of the codes, scan, scatter): 8 x 2.2 ms of the
+// 83 ms went into re-reading the keys for histograms.  The digit histograms of the WHOLE array do not depend on the order
+// of the elements, so a single pre-pass computes all eight (radix_hist_all_kernel), a 256-thread kernel turns them into
+// exclusive digit bases, and each scatter pass finds its tile's offset inside every digit with a chained scan over the
+// tiles that ran before it (decoupled look-back, one status word per tile and digit: tag | prefix-flag | count).  Tiles are
+// handed out by an atomic ticket, so tile t - 1 is always resident or finished when tile t looks back.
+constexpr int OS_BLOCK = 512;                    // 8 waves; two workgroups per CU (74 KB of LDS each)
+constexpr int OS_SUB = 16;                       // elements per lane and tile
+constexpr int OS_WAVES = OS_BLOCK / 64;
+constexpr int OS_TILE = OS_BLOCK * OS_SUB;       // 8192 elements: ~32 per digit -> 256-B code runs, 128-B row-id runs
+constexpr unsigned long long OS_PREFIX = 1ULL << 59;
+constexpr unsigned long long OS_VAL_MASK = OS_PREFIX - 1;
+constexpr unsigned long long OS_TAG_MASK = 0xFULL << 60;
+constexpr size_t OS_LDS_BYTES = (size_t)OS_TILE * 8 + (size_t)OS_WAVES * 256 * 4 + 2 * 256 * 4;
 
-// ---- one stable radix pass ------------------------------------------------------------------------------
-// Block b owns the contiguous element range [b*per, (b+1)*per).  counts are digit-major: counts[d*nb + b].
-__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* code, int64_t n, int64_t per, int shift, uint32_t* counts) {
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+__global__ __launch_bounds__(256) void radix_hist_all_kernel(const uint64_t* code, int64_t n, unsigned long long* ghist) {
+    __shared__ uint32_t h[8 * 256];
+    for (int i = threadIdx.x; i < 8 * 256; i += 256) h[i] = 0;
     __syncthreads();
-    int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&h[(code[i] >> shift) & 255], 1u);
-    __syncthreads();
-    counts[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
-}
-
-// exclusive scan of counts in (digit, block) order -> global output offsets; one block of 256 threads
-__global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* counts, int nb, unsigned long long* offsets) {
-    __shared__ unsigned long long tot[256];
-    const int d = threadIdx.x;
-    unsigned long long s = 0;
-    for (int b = 0; b < nb; b++) s += counts[(int64_t)d * nb + b];
-    tot[d] = s;
-    __syncthreads();
-    if (d == 0) {
-        unsigned long long run = 0;
-        for (int k = 0; k < 256; k++) { unsigned long long t = tot[k]; tot[k] = run; run += t; }
-    }
-    __syncthreads();
-    unsigned long long run = tot[d];
-    for (int b = 0; b < nb; b++) {
-        offsets[(int64_t)d * nb + b] = run;
-        run += counts[(int64_t)d * nb + b];
-    }
-}
-
-// Stable scatter of one radix pass.  Tiles of RS_TILE consecutive elements; wave w owns elements
-// [w * 512, (w + 1) * 512) of the tile and ranks them on its own (eight 64-element sub-rounds: same-digit lanes found
-// with eight ballots, a wave-private digit counter in LDS carries the running count), so ranking needs no
-// workgroup barrier.  The tile is then laid out by digit in LDS (digit offsets + per-wave bases keep it stable) and
-// copied out in runs: consecutive lanes write consecutive elements of one digit (~32 per digit and tile), instead
-// of one isolated 8 + 4 byte store per element (the first version: 18.7 ms per pass over 1e9 elements).
-constexpr int RS_SUB = 8;                     // sub-rounds per wave and tile
-constexpr int RS_TILE = RS_BLOCK * RS_SUB;    // 8192 elements
-__global__ __launch_bounds__(RS_BLOCK) void radix_scatter_kernel(const uint64_t* code, const uint32_t* val, int64_t n, int64_t per,
-                                                                 int shift, const unsigned long long* offsets, int nb,
-                                                                 uint64_t* code_out, uint32_t* val_out) {
-    extern __shared__ uint64_t rs_lds[];
-    uint64_t* scode = rs_lds;                                  // [RS_TILE]
-    uint32_t* sval = (uint32_t*)(rs_lds + RS_TILE);            // [RS_TILE]
-    uint32_t* wcnt = sval + RS_TILE;                           // [RS_WAVES][256] per-wave digit counts -> bases
-    uint32_t* off = wcnt + RS_WAVES * 256;                     // [256] start of each digit inside the staged tile
-    uint32_t* tot = off + 256;                                 // [256] elements of each digit in this tile
-    __shared__ unsigned long long run[256];
-    __shared__ uint32_t wtot[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 256) run[tid] = offsets[(int64_t)tid * nb + blockIdx.x];
-    for (int i = tid; i < RS_WAVES * 256; i += RS_BLOCK) wcnt[i] = 0;
-    __syncthreads();
-    uint32_t* mycnt = wcnt + wave * 256;
-    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
-    for (int64_t base = lo; base < hi; base += RS_TILE) {
-        // ---- load + rank inside the wave
-        uint64_t c[RS_SUB];
-        uint32_t v[RS_SUB], lpos[RS_SUB];
-        const int64_t wbase = base + (int64_t)wave * (64 * RS_SUB) + lane;
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t nfull = n & ~63LL;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nfull; i += stride) hist8_wave(h, code[i], lane);   // whole waves only
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - nfull)) {
+        const uint64_t c = code[nfull + threadIdx.x];
 #pragma unroll
-        for (int k = 0; k < RS_SUB; k++) {
+        for (int b = 0; b < 8; b++) atomicAdd(&h[b * 256 + ((uint32_t)(c >> (8 * b)) & 255u)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * 256; i += 256)
+        if (h[i]) atomicAdd(&ghist[i], (unsigned long long)h[i]);
+}
+
+// ghist[8][256] -> exclusive scan per digit position (the first output slot of every digit value)
+__global__ __launch_bounds__(256) void radix_bases_kernel(const unsigned long long* ghist, unsigned long long* bases) {
+    __shared__ unsigned long long wt[4];
+    const int d = threadIdx.x, lane = d & 63, wave = d >> 6;
+    for (int b = 0; b < 8; b++) {
+        const unsigned long long x = ghist[b * 256 + d];
+        unsigned long long inc = x;
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) { const unsigned long long o = __shfl_up(inc, k); if (lane >= k) inc += o; }
+        if (lane == 63) wt[wave] = inc;
+        __syncthreads();
+        unsigned long long add = 0;
+        for (int w = 0; w < wave; w++) add += wt[w];
+        bases[b * 256 + d] = add + inc - x;
+        __syncthreads();
+    }
+}
+
+struct OsArgs {
+    const uint64_t* code;
+    const uint32_t* val;
+    int64_t n, ntiles;
+    int shift;
+    const unsigned long long* base;   // [256] exclusive digit bases of this pass
+    unsigned long long* status;       // [ntiles][256]
+    unsigned int* ticket;
+    unsigned long long tag;           // (pass + 1) << 60: status words of other passes read as "not published yet"
+    uint64_t* code_out;
+    uint32_t* val_out;
+    int64_t* idx_out;                 // last pass of the last key: row ids widened to int64 straight into the caller's buffer
+};
+
+// Tile shapes tried on 1e9 fp64 keys (ms per pass): 512 x 16 (this one) 6.1; 1024 threads x 8 9.4 (spills at 64 VGPRs);
+// 512 x 8 = 4096-element tiles, three workgroups per CU 8.0 (runs half as long).
+__global__ __launch_bounds__(OS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void onesweep_kernel(OsArgs a) {
+    extern __shared__ uint64_t os_lds[];
+    uint64_t* stage = os_lds;                                  // [OS_TILE] codes by digit; reused for the row ids
+    uint32_t* stage32 = (uint32_t*)os_lds;
+    uint32_t* wcnt = (uint32_t*)(os_lds + OS_TILE);            // [OS_WAVES][256] per-wave digit counts -> bases
+    uint32_t* off = wcnt + OS_WAVES * 256;                     // [256] start of each digit inside the staged tile
+    uint32_t* tot = off + 256;                                 // [256] elements of each digit in this tile
+    __shared__ unsigned long long run[256];                    // global output position of the tile's first element of each digit
+    __shared__ uint32_t wtot[4];
+    __shared__ uint32_t s_tile;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* mycnt = wcnt + wave * 256;
+    for (;;) {
+        if (tid == 0) s_tile = atomicAdd(a.ticket, 1u);
+        for (int i = tid; i < OS_WAVES * 256; i += OS_BLOCK) wcnt[i] = 0;
+        __syncthreads();
+        const int64_t t = (int64_t)s_tile;
+        if (t >= a.ntiles) break;
+        const int64_t base = t * OS_TILE;
+        const int64_t hi = base + OS_TILE < a.n ? base + OS_TILE : a.n;
+        // ---- load + rank inside the wave (wave w owns elements [w * 1024, (w + 1) * 1024) of the tile)
+        uint64_t c[OS_SUB];
+        uint32_t v[OS_SUB], lp[OS_SUB / 2];   // lp: two 16-bit positions per register
+        const int64_t wbase = base + (int64_t)wave * (64 * OS_SUB) + lane;
+#pragma unroll
+        for (int k = 0; k < OS_SUB; k++) {
             const int64_t i = wbase + k * 64;
-            c[k] = i < hi ? code[i] : 0;
-            v[k] = i < hi ? val[i] : 0;
+            c[k] = i < hi ? a.code[i] : 0;
+            v[k] = i < hi ? (a.val ? a.val[i] : (uint32_t)i) : 0;   // val == NULL: the rows are still in their original order
         }
 #pragma unroll
-        for (int k = 0; k < RS_SUB; k++) {
+        for (int k = 0; k < OS_SUB; k++) {
             const bool in = wbase + k * 64 < hi;
-            const uint32_t dg = (uint32_t)(c[k] >> shift) & 255u;
+            const uint32_t dg = (uint32_t)(c[k] >> a.shift) & 255u;
             uint64_t m = __ballot(in);
 #pragma unroll
             for (int bit = 0; bit < 8; bit++) {
@@ -169,22 +212,25 @@ __global__ __launch_bounds__(RS_BLOCK) void radix_scatter_kernel(const uint64_t*
                 m &= ((dg >> bit) & 1u) ? bb : ~bb;
             }
             const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            lpos[k] = 0;
+            uint32_t lpos = 0;
             if (in) {
-                lpos[k] = mycnt[dg] + before;                 // LDS ops of one wave execute in order
+                lpos = mycnt[dg] + before;                    // LDS ops of one wave execute in order
                 if (before == 0) mycnt[dg] += (uint32_t)__popcll(m);
             }
+            if ((k & 1) == 0) lp[k >> 1] = lpos; else lp[k >> 1] |= lpos << 16;
         }
         __syncthreads();
-        // ---- per digit: wave counts -> exclusive bases over the waves, tile total; then digit offsets
+        // ---- per digit: wave counts -> exclusive bases over the waves, tile total (published at once), digit offsets
         if (tid < 256) {
             uint32_t s = 0;
 #pragma unroll
-            for (int w = 0; w < RS_WAVES; w++) { uint32_t t = wcnt[w * 256 + tid]; wcnt[w * 256 + tid] = s; s += t; }
+            for (int w = 0; w < OS_WAVES; w++) { const uint32_t x = wcnt[w * 256 + tid]; wcnt[w * 256 + tid] = s; s += x; }
             tot[tid] = s;
+            __hip_atomic_store(&a.status[t * 256 + tid], a.tag | (t == 0 ? OS_PREFIX : 0ULL) | (unsigned long long)s, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
             uint32_t inc = s;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
             off[tid] = inc - s;
             if (lane == 63) wtot[wave] = inc;
         }
@@ -195,95 +241,155 @@ __global__ __launch_bounds__(RS_BLOCK) void radix_scatter_kernel(const uint64_t*
             off[tid] += add;
         }
         __syncthreads();
-        // ---- stage by digit
+        // ---- stage the codes by digit
 #pragma unroll
-        for (int k = 0; k < RS_SUB; k++) {
+        for (int k = 0; k < OS_SUB; k++) {
             if (wbase + k * 64 < hi) {
-                const uint32_t dg = (uint32_t)(c[k] >> shift) & 255u;
-                const uint32_t pos = off[dg] + mycnt[dg] + lpos[k];
-                scode[pos] = c[k];
-                sval[pos] = v[k];
+                const uint32_t dg = (uint32_t)(c[k] >> a.shift) & 255u;
+                const uint32_t pos = ((lp[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) + off[dg] + mycnt[dg];
+                lp[k >> 1] = (lp[k >> 1] & (0xFFFFu << (16 * ((k & 1) ^ 1)))) | (pos << (16 * (k & 1)));
+                stage[pos] = c[k];
+            }
+        }
+        // ---- chained scan over the earlier tiles (one thread per digit value)
+        if (tid < 256) {
+            unsigned long long excl = 0;
+            if (t > 0) {
+                int64_t look = t - 1;
+                for (;;) {
+                    const unsigned long long sv = __hip_atomic_load(&a.status[look * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((sv & OS_TAG_MASK) != a.tag) { __builtin_amdgcn_s_sleep(1); continue; }
+                    excl += sv & OS_VAL_MASK;
+                    if (sv & OS_PREFIX) break;
+                    look--;
+                }
+                __hip_atomic_store(&a.status[t * 256 + tid], a.tag | OS_PREFIX | (excl + tot[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            run[tid] = a.base[tid] + excl;
+        }
+        __syncthreads();
+        // ---- copy the codes out in runs; remember each element's digit for the row-id round
+        const uint32_t total = (uint32_t)(hi - base);
+        uint32_t dgs[OS_SUB / 4];
+#pragma unroll
+        for (int j = 0; j < OS_SUB; j++) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)j * OS_BLOCK;
+            uint32_t dg = 0;
+            if (i < total) {
+                const uint64_t cc = stage[i];
+                dg = (uint32_t)(cc >> a.shift) & 255u;
+                if (a.code_out) a.code_out[run[dg] + (i - off[dg])] = cc;
+            }
+            if ((j & 3) == 0) dgs[j >> 2] = dg; else dgs[j >> 2] |= dg << (8 * (j & 3));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < OS_SUB; k++)
+            if (wbase + k * 64 < hi) stage32[(lp[k >> 1] >> (16 * (k & 1))) & 0xFFFFu] = v[k];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < OS_SUB; j++) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)j * OS_BLOCK;
+            if (i < total) {
+                const uint32_t dg = (dgs[j >> 2] >> (8 * (j & 3))) & 255u;
+                const unsigned long long pos = run[dg] + (i - off[dg]);
+                if (a.idx_out) a.idx_out[pos] = (int64_t)stage32[i];
+                else a.val_out[pos] = stage32[i];
             }
         }
         __syncthreads();
-        // ---- copy out in runs
-        const uint32_t total = (uint32_t)((hi - base) < RS_TILE ? (hi - base) : RS_TILE);
-        for (uint32_t i = tid; i < total; i += RS_BLOCK) {
-            const uint64_t cc = scode[i];
-            const uint32_t dg = (uint32_t)(cc >> shift) & 255u;
-            const unsigned long long pos = run[dg] + (i - off[dg]);
-            code_out[pos] = cc;
-            val_out[pos] = sval[i];
-        }
-        __syncthreads();
-        if (tid < 256) run[tid] += tot[tid];
-        for (int i = tid; i < RS_WAVES * 256; i += RS_BLOCK) wcnt[i] = 0;
-        __syncthreads();
     }
 }
-constexpr size_t RS_LDS_BYTES = (size_t)RS_TILE * 12 + (size_t)RS_WAVES * 256 * 4 + 2 * 256 * 4;
 
 struct RadixBufs {
     uint64_t* code[2];
     uint32_t* val[2];
-    uint32_t* counts;
-    unsigned long long* offsets;
-    unsigned long long* red;
+    unsigned long long* red;          // [0..1] unused, [4] caller's flag word, [8..15] tickets (as uint32 pairs)
+    unsigned long long* ghist;        // [8][256] digit histograms of the whole array, then [8][256] exclusive bases
+    unsigned long long* status;       // [ntiles][256] chained-scan status words
     int cur = 0;
-    int nb = 0;
-    int64_t per = 0;
+    int64_t ntiles = 0;
 };
 
 static int radix_alloc(RadixBufs* r, int64_t n) {
-    int64_t nb = (n + 16383) / 16384;
-    if (nb > RS_MAX_BLOCKS) nb = RS_MAX_BLOCKS;
-    if (nb < 1) nb = 1;
-    r->nb = (int)nb;
-    r->per = (n + nb - 1) / nb;
+    r->ntiles = (n + OS_TILE - 1) / OS_TILE;
     for (int k = 0; k < 2; k++) {
         r->code[k] = (uint64_t*)pool_alloc((size_t)(n ? n : 1) * 8);
         r->val[k] = (uint32_t*)pool_alloc((size_t)(n ? n : 1) * 4);
         if (!r->code[k] || !r->val[k]) return 1;
     }
-    r->counts = (uint32_t*)pool_alloc((size_t)256 * nb * 4);
-    r->offsets = (unsigned long long*)pool_alloc((size_t)256 * nb * 8);
-    r->red = (unsigned long long*)pool_alloc(64);
-    return (r->counts && r->offsets && r->red) ? 0 : 1;
+    r->red = (unsigned long long*)pool_alloc(128);
+    r->ghist = (unsigned long long*)pool_alloc((size_t)2 * 8 * 256 * 8);
+    r->status = (unsigned long long*)pool_alloc((size_t)(r->ntiles ? r->ntiles : 1) * 256 * 8);
+    return (r->red && r->ghist && r->status) ? 0 : 1;
 }
 static void radix_free(RadixBufs* r) {
     for (int k = 0; k < 2; k++) { pool_free(r->code[k]); pool_free(r->val[k]); }
-    pool_free(r->counts); pool_free(r->offsets); pool_free(r->red);
+    pool_free(r->red); pool_free(r->ghist); pool_free(r->status);
 }
 
 // sort (code[cur], val[cur]) stably by the bytes of code that are not constant
 // extra (optional): receives r->red[4], a flag word the caller's previous kernel may have set (read back with the
-// same synchronisation as the digit masks)
-static int radix_sort_codes(RadixBufs* r, int64_t n, hipStream_t s, unsigned long long* extra = nullptr) {
+// same synchronisation as the digit histograms)
+// idx_out (optional): the caller's int64 row-id buffer.  When this call runs the LAST pass of the whole sort (no class pass
+// will follow: !cls_possible or the flag word is 0) that pass writes the widened row ids straight into it and skips the
+// code output; *wrote_idx tells the caller.
+// hist_ready: r->ghist already holds the digit histograms of the codes (sort_encode_kernel accumulated them)
+// ident (optional, in/out): the row ids r->val[r->cur] are the identity and NOT materialised; the first executed pass makes them up
+static int radix_sort_codes(RadixBufs* r, int64_t n, hipStream_t s, unsigned long long* extra = nullptr, int64_t* idx_out = nullptr,
+                            bool cls_possible = false, bool* wrote_idx = nullptr, bool hist_ready = false, bool* ident = nullptr) {
+    if (wrote_idx) *wrote_idx = false;
     if (n <= 1) { if (extra) { VNM_HIP(hipMemcpyAsync(extra, r->red + 4, 8, hipMemcpyDeviceToHost, s)); VNM_HIP(hipStreamSynchronize(s)); } return 0; }
     static bool attr_set = false;
     if (!attr_set) {
-        VNM_HIP(hipFuncSetAttribute((const void*)radix_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS_LDS_BYTES));
+        VNM_HIP(hipFuncSetAttribute((const void*)onesweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OS_LDS_BYTES));
         attr_set = true;
     }
-    unsigned long long init[2] = {0ULL, ~0ULL}, red[5];
-    VNM_HIP(hipMemcpyAsync(r->red, init, 16, hipMemcpyHostToDevice, s));
-    int g = device_info().num_cus * (n >= (1 << 24) ? 4 : 1);
-    int64_t need = (n + 255) / 256;
-    if (g > need) g = (int)need;
-    sort_orand_kernel<<<g, 256, 0, s>>>(r->code[r->cur], n, r->red);
-    VNM_HIP(hipMemcpyAsync(red, r->red, 40, hipMemcpyDeviceToHost, s));
+    const int cus = device_info().num_cus;
+    // ---- histograms of all eight digits in one read of the codes; status words and tickets cleared meanwhile
+    unsigned long long hist[8 * 256 + 1];
+    if (!hist_ready) VNM_HIP(hipMemsetAsync(r->ghist, 0, (size_t)8 * 256 * 8, s));
+    VNM_HIP(hipMemsetAsync(r->red + 8, 0, 64, s));
+    const int64_t ntiles = (n + OS_TILE - 1) / OS_TILE;   // <= r->ntiles: callers may sort fewer elements than they allocated for
+    VNM_HIP(hipMemsetAsync(r->status, 0, (size_t)ntiles * 256 * 8, s));
+    {
+        KernelTimer timer("radix_hist", s);
+        int g = cus * 8;
+        const int64_t need = (n + 255) / 256;
+        if (g > need) g = (int)need;
+        if (!hist_ready) radix_hist_all_kernel<<<g, 256, 0, s>>>(r->code[r->cur], n, r->ghist);
+        radix_bases_kernel<<<1, 256, 0, s>>>(r->ghist, r->ghist + 8 * 256);
+    }
+    VNM_HIP(hipGetLastError());
+    VNM_HIP(hipMemcpyAsync(hist, r->ghist, (size_t)8 * 256 * 8, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipMemcpyAsync(hist + 8 * 256, r->red + 4, 8, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
-    if (extra) *extra = red[4];
-    uint64_t differ = red[0] ^ red[1];
+    if (extra) *extra = hist[8 * 256];
+    const bool cls_follows = cls_possible && hist[8 * 256] != 0;
+    int live[8], n_live = 0;
     for (int byte = 0; byte < 8; byte++) {
-        if (!((differ >> (8 * byte)) & 0xFF)) continue;
+        bool constant = false;      // one digit value holds every element: nothing to reorder
+        for (int d = 0; d < 256 && !constant; d++) constant = hist[byte * 256 + d] == (unsigned long long)n;
+        if (!constant) live[n_live++] = byte;
+    }
+    int g = (int)std::min<int64_t>(ntiles, (int64_t)cus * 2);
+    for (int k = 0; k < n_live; k++) {
+        const int byte = live[k];
         KernelTimer timer("radix_pass", s);
-        int shift = 8 * byte;
-        radix_hist_kernel<<<r->nb, 256, 0, s>>>(r->code[r->cur], n, r->per, shift, r->counts);
-        radix_scan_kernel<<<1, 256, 0, s>>>(r->counts, r->nb, r->offsets);
-        radix_scatter_kernel<<<r->nb, RS_BLOCK, RS_LDS_BYTES, s>>>(r->code[r->cur], r->val[r->cur], n, r->per, shift, r->offsets,
-                                                                   r->nb, r->code[r->cur ^ 1], r->val[r->cur ^ 1]);
+        OsArgs a{};
+        a.code = r->code[r->cur]; a.val = (ident && *ident) ? nullptr : r->val[r->cur]; a.n = n; a.ntiles = ntiles; a.shift = 8 * byte;
+        a.base = r->ghist + 8 * 256 + byte * 256;
+        a.status = r->status;
+        a.ticket = (unsigned int*)(r->red + 8) + byte;
+        a.tag = (unsigned long long)(byte + 1) << 60;
+        a.code_out = r->code[r->cur ^ 1]; a.val_out = r->val[r->cur ^ 1];
+        if (idx_out && !cls_follows && k == n_live - 1) {
+            a.idx_out = idx_out; a.code_out = nullptr;
+            if (wrote_idx) *wrote_idx = true;
+        }
+onesweep_kernel<<<g, OS_BLOCK, OS_LDS_BYTES, s>>>(a);
         r->cur ^= 1;
+        if (ident) *ident = false;
     }
     VNM_HIP(hipGetLastError());
     return 0;
@@ -513,27 +619,36 @@ static int grid_for(int64_t n) {
 }
 
 // full stable multi-key sort; result: row ids (uint32) in r->val[r->cur]
-static int full_sort(int n_keys, const vnm_dcol* keys, const int* orders, int64_t n, RadixBufs* r, hipStream_t s) {
-    uint8_t* cls = (uint8_t*)pool_alloc((size_t)(n ? n : 1));
-    if (!cls) return 1;
-    sort_iota_kernel<<<grid_for(n), 256, 0, s>>>(r->val[r->cur], n);
+// idx_out (optional): int64 output buffer; *wrote_idx = the last radix pass wrote it (else the caller widens r->val[r->cur])
+static int full_sort(int n_keys, const vnm_dcol* keys, const int* orders, int64_t n, RadixBufs* r, hipStream_t s,
+                     int64_t* idx_out = nullptr, bool* wrote_idx = nullptr) {
+    if (wrote_idx) *wrote_idx = false;
+    bool ident = true;   // no pass has run yet: the row ids are the identity and are not materialised (the first pass makes them up)
     for (int k = n_keys - 1; k >= 0; k--) {
-        // codes of key k in the current row order
+        // codes of key k in the current row order; their eight digit histograms come out of the same kernel
         VNM_HIP(hipMemsetAsync(r->red + 4, 0, 8, s));
-        sort_encode_kernel<<<grid_for(n), 256, 0, s>>>(keys[k], orders[k] == VNM_DESC, r->val[r->cur], n, r->code[r->cur], cls, r->red + 4);
+        VNM_HIP(hipMemsetAsync(r->ghist, 0, (size_t)8 * 256 * 8, s));
+        {
+            KernelTimer timer("sort_encode", s);
+            sort_encode_kernel<<<grid_for(n), 256, 0, s>>>(keys[k], orders[k] == VNM_DESC, ident ? nullptr : r->val[r->cur], n, r->code[r->cur],
+                                                           nullptr, r->red + 4, r->ghist, 0);
+        }
         unsigned long long any_special = 0;
-        VNM_TRY(radix_sort_codes(r, n, s, &any_special));
-        // class pass (values < NaN < NULL), more significant than the code: cls was computed in the order BEFORE
-        // the code passes, so recompute it in the current order
-        bool has_cls = (keys[k].validity != nullptr || type_is_float(keys[k].type)) && any_special != 0;  // no NaN / NULL at all: nothing to do
-        if (has_cls) {
-            sort_encode_kernel<<<grid_for(n), 256, 0, s>>>(keys[k], orders[k] == VNM_DESC, r->val[r->cur], n, r->code[r->cur ^ 1], cls, nullptr);
-            sort_cls_to_code_kernel<<<grid_for(n), 256, 0, s>>>(cls, n, r->code[r->cur]);
-            VNM_TRY(radix_sort_codes(r, n, s));
+        const bool cls_possible = keys[k].validity != nullptr || type_is_float(keys[k].type);
+        VNM_TRY(radix_sort_codes(r, n, s, &any_special, k == 0 ? idx_out : nullptr, cls_possible, wrote_idx, true, &ident));
+        // class pass (values < NaN < NULL), more significant than the code, over the classes in the CURRENT order
+        if (cls_possible && any_special != 0) {   // no NaN / NULL at all: nothing to do
+            VNM_HIP(hipMemsetAsync(r->ghist, 0, (size_t)8 * 256 * 8, s));
+            {
+                KernelTimer timer("sort_encode", s);
+                sort_encode_kernel<<<grid_for(n), 256, 0, s>>>(keys[k], orders[k] == VNM_DESC, ident ? nullptr : r->val[r->cur], n,
+                                                               r->code[r->cur], nullptr, nullptr, r->ghist, 1);
+            }
+            VNM_TRY(radix_sort_codes(r, n, s, nullptr, k == 0 ? idx_out : nullptr, false, wrote_idx, true, &ident));
         }
     }
     VNM_HIP(hipGetLastError());
-    pool_free(cls);
+    if (ident && !(wrote_idx && *wrote_idx)) sort_iota_kernel<<<grid_for(n), 256, 0, s>>>(r->val[r->cur], n);   // every key constant
     return 0;
 }
 
@@ -656,9 +771,6 @@ int vnm_sort_indices(int n_keys, const vnm_dcol* keys, const int* orders, int64_
             } else if ((int64_t)found >= limit && (int64_t)found <= cap) {
                 const int64_t c = (int64_t)found;
                 // canonical order: by row id, then (stable) by code, then by class
-                cr.nb = (int)std::min<int64_t>((c + 16383) / 16384, RS_MAX_BLOCKS);
-                if (cr.nb < 1) cr.nb = 1;
-                cr.per = (c + cr.nb - 1) / cr.nb;
                 uint64_t* code_keep = (uint64_t*)pool_alloc((size_t)c * 8);
                 if (!code_keep) return 1;
                 VNM_HIP(hipMemcpyAsync(code_keep, cr.code[0], (size_t)c * 8, hipMemcpyDeviceToDevice, s));
@@ -691,9 +803,10 @@ int vnm_sort_indices(int n_keys, const vnm_dcol* keys, const int* orders, int64_
 
     RadixBufs r{};
     VNM_TRY(radix_alloc(&r, n));
-    int rc = full_sort(n_keys, keys, orders, n, &r, s);
+    bool wrote = false;
+    int rc = full_sort(n_keys, keys, orders, n, &r, s, out_indices, &wrote);
     if (!rc) {
-        sort_widen_kernel<<<grid_for(n), 256, 0, s>>>(r.val[r.cur], n, out_indices);
+        if (!wrote) sort_widen_kernel<<<grid_for(n), 256, 0, s>>>(r.val[r.cur], n, out_indices);
         if (hipGetLastError() != hipSuccess) rc = set_error("vnm_sort_indices: kernel launch failed");
         if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = set_error("vnm_sort_indices: stream sync failed");
     }
