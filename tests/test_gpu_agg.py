@@ -751,7 +751,8 @@ def test_scan_kernel_nullable_input(vtype, pred, groups):
 
 @pytest.mark.parametrize("case", ["uniform", "negative_sorted", "uint64_high", "sample_misses", "second_batch_shifted", "heavy_key", "p1_7", "nonquantised"])
 @pytest.mark.parametrize("hint", [0, 600_000])
-def test_dense_key_partitioned_path(case, hint, monkeypatch):
+@pytest.mark.parametrize("groups", [900_000, 40_000], ids=["G9e5", "G4e4_split_final"])
+def test_dense_key_partitioned_path(case, hint, groups, monkeypatch):
     """Dense-key path (vnm_agg_dense.inc): int64 / uint64 keys whose sampled range fits 29 bits travel as scrambled
     codes, the final pass direct-addresses its LDS accumulators.  Checked bit-exact against the oracle: negative and
     sorted keys (the scrambling must spread them), keys above 2^63, keys the sample never saw (they spill to the scan
@@ -760,14 +761,15 @@ def test_dense_key_partitioned_path(case, hint, monkeypatch):
     monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
     if case == "p1_7":
         monkeypatch.setenv("VNM_DENSE_P1", "3")
+    # groups = 4e4: a range of 2^16 codes -> 16 final partitions, each split over many workgroups whose partial tables
+    # dpart_merge_kernel adds up
     rng = np.random.default_rng(len(case) + hint)
     n = 1_500_000
-    groups = 900_000
     base = rng.integers(0, groups, n).astype(np.int64)
     v = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
     kt = np.int64
     if case == "negative_sorted":
-        k = np.sort(base) - 450_000
+        k = np.sort(base) - groups // 2
     elif case == "uint64_high":
         k = base.astype(np.uint64) + np.uint64(2**63 + 12345)
         kt = np.uint64

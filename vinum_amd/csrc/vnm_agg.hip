@@ -2798,8 +2798,9 @@ int estimate_groups(vnm_agg* h, const vnm_dcol& key, int64_t nrows, int64_t* est
         if (d > (double)m) d = (double)m;
         if (d < 1) d = 1;
         const double frac = d / (double)m;
-        // solve d/m = (1 - exp(-x)) / x for x = m / G by bisection
-        double lo = 1e-9, hi = 64.0;
+        // solve d/m = (1 - exp(-x)) / x for x = m / G by bisection (x -> 1 / frac when the sample saw every group many times:
+        // the upper bound must cover m / d, a bound of 64 turned G = 1e5 into an estimate of 3.1e5 and a second partition level)
+        double lo = 1e-9, hi = 2.0 / frac + 64.0;
         for (int it = 0; it < 80; it++) {
             double x = 0.5 * (lo + hi);
             double f = (1.0 - exp(-x)) / x;
@@ -3105,7 +3106,10 @@ int plan_dense(vnm_agg* h, const vnm_dcol& key, int64_t nrows, hipStream_t s) {
     int bits = 1;
     while (bits < 64 && ((hi - lo) >> bits) != 0) bits++;
     if (bits > DP_MAX_BITS) return 0;
-    if (bits < DP_TBITS_MIN + 9) return 0;  // fewer than 512 final partitions: the LDS scan / hash paths serve small ranges
+    // ranges below 2^20 leave too few final partitions to fill the chip with one workgroup each: their final pass splits
+    // every partition over several workgroups and merges the partial tables (dpart_merge_kernel).  Below 2^14 codes the
+    // LDS scan kernels are the better tool.
+    if (bits < (int)env_i64("VNM_DENSE_MIN_BITS", 14)) return 0;
     const uint64_t extra = ((1ULL << bits) - 1) - (hi - lo);
     lo = lo > extra / 2 ? lo - extra / 2 : 0;
     DenseMap& mp = h->dmap;
@@ -3131,6 +3135,9 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     tb = std::max(DP_TBITS_MIN, std::min(DP_TBITS_MAX, tb));
     while (tb > DP_TBITS_MIN && mp.bits - tb < 11) tb--;
     while (tb < DP_TBITS_MAX && mp.bits - tb > 18) tb++;
+    // ranges of up to 2^22 codes: ONE scatter level (at most 512 partitions) with the largest table that allows it
+    if (mp.bits <= DP_TBITS_MAX + 9 && env_i64("VNM_DENSE_ONE_LEVEL", 1)) tb = std::max(DP_TBITS_MIN, std::min(DP_TBITS_MAX, mp.bits - (int)env_i64("VNM_DENSE_ONE_P", 8)));
+    if (mp.bits < 20) tb = (int)env_i64("VNM_DENSE_SMALL_TBITS", 12);   // split final pass: few partitions, long write runs in pass 1
     const int pbits = mp.bits - tb;
     const int levels = pbits > 9 ? 2 : 1;
     // pass 1 moves 12-byte entries out of 16-byte rows, pass 2 moves 10-byte entries out of 12: the SMALLER fan-out goes
@@ -3147,6 +3154,12 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     const int64_t rows_per_wg = tiles_per_wg * tile1;
     const int64_t cap1 = ((rows_per_wg / np1 + rows_per_wg / np1 / 5 + 512) + 7) & ~7LL;
     const bool c16_1 = levels == 1;  // pass-1 remainders fit 16 bits when they are the final slots
+    // final partitions x splits >= ~4 workgroups per CU
+    int fsplits = 1;
+    if (levels == 1 && ((int64_t)1 << pbits) < (int64_t)cus * 2) {
+        fsplits = (int)std::min<int64_t>(grid1, ((int64_t)cus * env_i64("VNM_DENSE_SPLIT_WGS", 4) + ((int64_t)1 << pbits) - 1) >> pbits);
+        if (fsplits < 2) fsplits = 1;
+    }
     unsigned long long* flags = (unsigned long long*)pool_alloc(64);
     double* v1 = (double*)pool_alloc((size_t)np1 * grid1 * cap1 * 8);
     void* c1 = pool_alloc((size_t)np1 * grid1 * cap1 * (c16_1 ? 2 : 4));
@@ -3217,7 +3230,25 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     df.w_rows = a.hot_w_rows; df.w_valid = a.hot_w_valid; df.w_sum = a.hot_w_sum;
     df.w_lo = a.hot_comp && a.hot_w_sum >= 0 ? a.hot_w_sum + 1 : -1;
     df.dkey = rk; df.dacc = ra; df.dstride = dstride; df.flags = flags;
-    {
+    uint64_t* psum = nullptr; float* plo = nullptr; uint32_t* pcnt = nullptr;
+    if (fsplits > 1) {
+        const size_t cells = (size_t)nfinal * fsplits << tb;
+        psum = (uint64_t*)pool_alloc(cells * 8); plo = (float*)pool_alloc(cells * 4); pcnt = (uint32_t*)pool_alloc(cells * 4);
+        if (!psum || !plo || !pcnt) { release(); pool_free(spill); pool_free(rk); pool_free(ra); pool_free(psum); pool_free(plo); pool_free(pcnt); return 1; }
+        df.splits = fsplits; df.part_sum = psum; df.part_lo = plo; df.part_cnt = pcnt;
+        KernelTimer timer("agg_part_final", s);
+#define VNM_DFINS(TB_)                                                                                                 \
+    do {                                                                                                              \
+        const int blk = TB_ >= 13 ? 1024 : 512;                                                                       \
+        int occ = 0;                                                                                                  \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)dpart_final_kernel<uint16_t, TB_, true>, blk, 0) != hipSuccess || occ < 1) occ = 1; \
+        const int g3 = (int)std::min<int64_t>(nfinal * fsplits, (int64_t)cus * std::min(occ, 8));                     \
+        dpart_final_kernel<uint16_t, TB_, true><<<g3, blk, 0, s>>>(df);                                               \
+    } while (0)
+        if (tb == 11) VNM_DFINS(11); else if (tb == 12) VNM_DFINS(12); else VNM_DFINS(13);
+#undef VNM_DFINS
+        dpart_merge_kernel<<<(int)(nfinal << (tb - 9)), 512, 0, s>>>(df, tb);
+    } else {
         KernelTimer timer("agg_part_final", s);
 #define VNM_DFIN(TB_)                                                                                                  \
     do {                                                                                                              \
@@ -3235,6 +3266,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     VNM_HIP(hipMemcpyAsync(fl, flags, 24, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
     release();
+    pool_free(psum); pool_free(plo); pool_free(pcnt);
     if (fl[0]) {  // spill buffer full, dense output too small, or a compensation term beyond float range
         pool_free(rk); pool_free(ra); pool_free(spill);
         return 2;
