@@ -327,6 +327,25 @@ def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream,
     out["group-by G=7"] = _entry(f"SELECT k,sum(v),avg(v) WHERE v>{x_thr} GROUP BY k; N={n:.3g}, 7 groups", n, ms, sp,
                                  16.0 * n + 24.0 * state["ng"], state["ng"])
 
+    # ---- the same query over other group counts (keys folded with k % G): no cardinality cliff between the scan kernels,
+    # the direct-addressed LDS scan, the one- and two-level dense paths
+    sweep = {}
+    for gs in (1_000, 10_000, 100_000, 1_000_000, 10_000_000):
+        if gs >= groups:
+            continue
+        kg = ops.project(("mod", "k", gs), {"k": kcol}, length=n, stream=stream)
+
+        def gbs():
+            agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())])
+            agg.set_predicate(">", x_thr)
+            agg.next([kg], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
+            state["ng"] = agg.finish(stream=stream)
+        ms, sp = _measure(torch, lib, ctypes, gbs, AGG_SPANS, steps, warmup + 1)
+        sweep[f"{gs:.0e}"] = {"ms_per_step": round(ms, 3), "kernels_ms": {k_: round(v_, 3) for k_, v_ in sp.items()}, "result_rows": int(state["ng"])}
+        del kg
+    out["group-by sweep"] = {"workload": f"SELECT k,sum(v),avg(v) WHERE v>{x_thr} GROUP BY k (hint-less) over {n:.3g} rows, keys folded to G groups",
+                             "by_groups": sweep}
+
     # ---- configs[0]'s query shape at scale: SELECT k, count(*) GROUP BY k (no predicate, key column only)
     def gc():
         agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.COUNT_STAR, None, None)], expected_groups=7 if args.hint else 0)

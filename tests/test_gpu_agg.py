@@ -751,7 +751,7 @@ def test_scan_kernel_nullable_input(vtype, pred, groups):
 
 @pytest.mark.parametrize("case", ["uniform", "negative_sorted", "uint64_high", "sample_misses", "second_batch_shifted", "heavy_key", "p1_7", "nonquantised"])
 @pytest.mark.parametrize("hint", [0, 600_000])
-@pytest.mark.parametrize("groups", [900_000, 40_000], ids=["G9e5", "G4e4_split_final"])
+@pytest.mark.parametrize("groups", [900_000, 40_000, 3_000], ids=["G9e5", "G4e4_split_final", "G3e3_lds_scan"])
 def test_dense_key_partitioned_path(case, hint, groups, monkeypatch):
     """Dense-key path (vnm_agg_dense.inc): int64 / uint64 keys whose sampled range fits 29 bits travel as scrambled
     codes, the final pass direct-addresses its LDS accumulators.  Checked bit-exact against the oracle: negative and
@@ -762,7 +762,7 @@ def test_dense_key_partitioned_path(case, hint, groups, monkeypatch):
     if case == "p1_7":
         monkeypatch.setenv("VNM_DENSE_P1", "3")
     # groups = 4e4: a range of 2^16 codes -> 16 final partitions, each split over many workgroups whose partial tables
-    # dpart_merge_kernel adds up
+    # dpart_merge_kernel adds up; groups = 3e3 (hint-less): no scatter, every workgroup scans rows into a whole-range LDS table
     rng = np.random.default_rng(len(case) + hint)
     n = 1_500_000
     base = rng.integers(0, groups, n).astype(np.int64)

@@ -3100,16 +3100,19 @@ int plan_dense(vnm_agg* h, const vnm_dcol& key, int64_t nrows, hipStream_t s) {
     // the next power of two
     const uint64_t span_s = got[1] - got[0];
     if (span_s >= (1ULL << DP_MAX_BITS)) return 0;
-    const uint64_t margin = span_s / 8 + 4096;
+    // (small ranges: a tighter margin, so that up to ~7000 sampled codes still fit the 2^13-slot scan table)
+    const uint64_t margin = span_s < (1ULL << 13) ? span_s / 16 + 64 : span_s / 8 + 4096;
     uint64_t lo = got[0] > margin ? got[0] - margin : 0;
     uint64_t hi = got[1] < ~0ULL - margin ? got[1] + margin : ~0ULL;
     int bits = 1;
     while (bits < 64 && ((hi - lo) >> bits) != 0) bits++;
     if (bits > DP_MAX_BITS) return 0;
     // ranges below 2^20 leave too few final partitions to fill the chip with one workgroup each: their final pass splits
-    // every partition over several workgroups and merges the partial tables (dpart_merge_kernel).  Below 2^14 codes the
-    // LDS scan kernels are the better tool.
-    if (bits < (int)env_i64("VNM_DENSE_MIN_BITS", 14)) return 0;
+    // every partition over several workgroups and merges the partial tables (dpart_merge_kernel).  Up to 2^13 codes need
+    // no partitioning at all (dense_state = 2).
+    const bool small = bits < (int)env_i64("VNM_DENSE_MIN_BITS", 14);   // at most 2^13 codes: the direct-addressed LDS scan (dscan_kernel)
+    if (small) bits = DP_TBITS_MAX;   // always the 2^13-slot table: one 1024-thread workgroup per CU measured fastest at every G
+                                      // (G = 300 / 1000: 2.83 / 2.84 ms; 2^12 slots, two 512-thread workgroups: 3.04 / 3.07; 2^11, four: 3.50 / 3.65)
     const uint64_t extra = ((1ULL << bits) - 1) - (hi - lo);
     lo = lo > extra / 2 ? lo - extra / 2 : 0;
     DenseMap& mp = h->dmap;
@@ -3122,7 +3125,67 @@ int plan_dense(vnm_agg* h, const vnm_dcol& key, int64_t nrows, hipStream_t s) {
     for (int it = 0; it < 5; it++) inv *= 2u - mp.mul * inv;
     mp.mul_inv = inv;
     h->dense_span = (int64_t)1 << bits;
-    h->dense_state = 1;
+    h->dense_state = small ? 2 : 1;
+    return 0;
+}
+
+// Ranges of at most 2^13 codes: one scan with the whole table in LDS.  Same return convention as the partitioned variant.
+int dense_scan_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s, ulonglong2** spill_out, int64_t* n_spill_out) {
+    const int cus = device_info().num_cus;
+    const int tb = DP_TBITS_MAX;
+    if (h->dmap.bits != tb) return 2;
+    const int slots = 1 << tb;
+    const int block = 1024;
+    const int grid = (int)std::min<int64_t>((int64_t)cus, std::max<int64_t>(1, (nrows / 2 + block - 1) / block));
+    const size_t cells = (size_t)grid * slots;
+    unsigned long long* flags = (unsigned long long*)pool_alloc(64);
+    uint64_t* psum = (uint64_t*)pool_alloc(cells * 8);
+    float* plo = (float*)pool_alloc(cells * 4);
+    uint32_t* pcnt = (uint32_t*)pool_alloc(cells * 4);
+    const int64_t spill_cap = nrows / 2 + (1 << 20);
+    ulonglong2* spill = (ulonglong2*)pool_alloc((size_t)spill_cap * 16);
+    const int64_t dstride = slots + 2;
+    uint64_t* rk = (uint64_t*)pool_alloc((size_t)dstride * 8 * 2);
+    uint64_t* ra = (uint64_t*)pool_alloc((size_t)dstride * 8 * h->plan.n_words);
+    auto release = [&]() { pool_free(flags); pool_free(psum); pool_free(plo); pool_free(pcnt); };
+    if (!flags || !psum || !plo || !pcnt || !spill || !rk || !ra) { release(); pool_free(spill); pool_free(rk); pool_free(ra); return 1; }
+    VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
+    DScanArgs d{};
+    d.map = h->dmap;
+    d.map.mul = 1; d.map.mul_inv = 1;
+    d.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
+    d.vp = (const double*)a.cols[0].values + a.cols[0].offset;
+    d.has_expr = a.has_expr; d.expr = a.expr;
+    d.pp = h->pred_set ? (const double*)a.pred.values + a.pred.offset : nullptr;
+    d.has_pred = h->pred_set; d.pred_is_v = a.hot_pred_is_v; d.op = a.p.op; d.thr = a.p.dval;
+    d.nrows = nrows;
+    d.comp = a.hot_comp && a.hot_w_sum >= 0;
+    d.part_sum = psum; d.part_lo = plo; d.part_cnt = pcnt;
+    d.flags = flags; d.spill = spill; d.spill_cap = spill_cap;
+    DFinalArgs df{};
+    df.map = d.map;
+    df.nfinal = 1; df.splits = grid;
+    df.part_sum = psum; df.part_lo = plo; df.part_cnt = pcnt;
+    df.w_rows = a.hot_w_rows; df.w_valid = a.hot_w_valid; df.w_sum = a.hot_w_sum;
+    df.w_lo = d.comp ? a.hot_w_sum + 1 : -1;
+    df.dkey = rk; df.dacc = ra; df.dstride = dstride; df.flags = flags;
+    {
+        KernelTimer timer("agg_scan", s);
+        dscan_kernel<DP_TBITS_MAX><<<grid, block, 0, s>>>(d);
+        dpart_merge_kernel<<<1 << (tb - 9), 512, 0, s>>>(df, tb);
+    }
+    VNM_HIP(hipGetLastError());
+    unsigned long long fl[3];
+    VNM_HIP(hipMemcpyAsync(fl, flags, 24, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    release();
+    if (fl[0]) { pool_free(rk); pool_free(ra); pool_free(spill); return 2; }
+    if (fl[2]) { *spill_out = spill; *n_spill_out = (int64_t)fl[2]; }
+    else { pool_free(spill); *spill_out = nullptr; *n_spill_out = 0; }
+    if ((int64_t)fl[2] > nrows / 16) h->dense_state = -1;  // the sampled range does not describe the data: stop trying
+    h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
+    h->run_dir = nullptr; h->run_nfin = 0;
+    h->have_run = true;
     return 0;
 }
 
@@ -3687,13 +3750,34 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         }
         if (h->dense_state == 1 && h->dense_span <= 32 * h->hint && h->dense_span <= 4 * nrows) dense_go = true;
     }
+    ulonglong2* spill = nullptr;  // entries the partitioned / dense paths could not place (heavy keys, keys outside the sampled range): aggregated below
+    int64_t n_spill = 0;
+    // a few hundred to a few thousand groups in a small key range: the direct-addressed LDS scan (vnm_agg_dense.inc)
+    bool dscan_done = false;
+    if (dense_shape && !dense_go && h->hint >= env_i64("VNM_DSCAN_MIN_GROUPS", 128) && h->hint <= (1 << DP_TBITS_MAX) &&
+        getenv("VNM_AGG_NO_DSCAN") == nullptr) {
+        if (h->dense_state == 0) {
+            KernelTimer timer("agg_estimate", s);
+            VNM_TRY(plan_dense(h, keys[0], nrows, s));
+        }
+        if (h->dense_state == 2) {
+            if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
+            const int prc = dense_scan_aggregate(h, a, nrows, s, &spill, &n_spill);
+            if (prc == 1) return 1;
+            if (prc == 0 && !spill) { h->rows_seen += nrows; return 0; }
+            if (prc == 0) {  // the scan below runs over the spilled entries only (predicate already applied)
+                a.ent = spill;
+                a.nrows = n_spill;
+                a.p.enabled = 0;
+                dscan_done = true;
+            }
+        }
+    }
     // many groups: radix-partitioned path (no per-row HBM atomics); falls through when it does not apply
     // ... from the point where the groups stop fitting the LDS table of the scan kernel (flush storms otherwise:
     // MIN+MAX with 2000 groups and a 2048-slot table ran at 38 ms)
     const int64_t part_min = env_i64("VNM_AGG_PART_MIN_GROUPS", std::min<int64_t>(2400, (int64_t)S * 6 / 10));
-    ulonglong2* spill = nullptr;  // entries the partitioned path could not place (heavy keys): aggregated below
-    int64_t n_spill = 0;
-    if (part_ok && (h->hint > part_min || dense_go) && getenv("VNM_AGG_NO_PART") == nullptr) {
+    if (!dscan_done && part_ok && (h->hint > part_min || dense_go) && getenv("VNM_AGG_NO_PART") == nullptr) {
         if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
         const bool can_spill = hot_scan && !hot_two && !hot_vnull && getenv("VNM_AGG_NO_SPILL") == nullptr;
         int prc = 2;
