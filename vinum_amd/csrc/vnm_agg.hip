@@ -2849,7 +2849,9 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     const int64_t tile1 = wide ? pw_tile(E) : PT_TILE;
     const size_t ebytes = (size_t)E * 8;
     if (wide) { spill_out = nullptr; n_spill_out = nullptr; }
-    const int levels = nfin > l1_max ? 2 : 1;
+    // twice the usual first-level fan-out still beats a second level that would only split in two (G = 3e5 sparse keys:
+    // 512 partitions in one pass 7.4 + 1.9 ms; 256 x 2: 6.7 + 3.7 + 2.0)
+    const int levels = nfin > std::min<int64_t>(l1_max * 2, PT_MAXP) ? 2 : 1;
     const int np1 = levels == 2 ? (int)l1_max : (int)nfin;
     const int np2 = levels == 2 ? (int)(nfin / l1_max) : 0;
     const int grid1 = (int)std::min<int64_t>((int64_t)cus * 2, (nrows + tile1 - 1) / tile1);
