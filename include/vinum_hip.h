@@ -314,7 +314,12 @@ int vnm_csv_parse_block(const char* host_text, int64_t nbytes, int skip_header, 
                         const int* field_idx, const int* types, vnm_dcol* out_cols, int64_t* n_rows, int* fallback,
                         void* stream);
 
-/* device memory helpers for hosts without a GPU allocator of their own (ctypes / cgo bindings) */
+/* device memory helpers for hosts without a GPU allocator of their own (ctypes / cgo bindings).
+ * vnm_malloc / vnm_free go through the library's caching allocator: a freed block is handed to the NEXT
+ * request of a similar size at once, without waiting for the device.  That is safe while everything that
+ * touches the block is enqueued on ONE stream (work is ordered on it; the entry points that return counts or
+ * flags also synchronise it).  A host that spreads calls over several streams must synchronise the stream
+ * that last used a block before vnm_free (as with hipFree, minus its implicit device synchronisation). */
 void* vnm_malloc(int64_t bytes);
 int vnm_free(void* p);
 int vnm_memcpy_h2d(void* dst, const void* src, int64_t bytes);

@@ -2859,13 +2859,14 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     const int64_t tiles_per_wg = ((nrows + tile1 - 1) / tile1 + grid1 - 1) / grid1;
     const int64_t rows_per_wg = tiles_per_wg * tile1;
     const int64_t cap1 = rows_per_wg / np1 + rows_per_wg / np1 / 5 + 512;
-    unsigned long long* flags = (unsigned long long*)pool_alloc(64);
-    ulonglong2* e1 = (ulonglong2*)pool_alloc((size_t)np1 * grid1 * cap1 * ebytes);
-    uint32_t* c1 = (uint32_t*)pool_alloc((size_t)np1 * grid1 * 4);
+    PoolScope pool;   // every block of this attempt; the ones handed on are keep()-ed
+    unsigned long long* flags = (unsigned long long*)pool.take(64);
+    ulonglong2* e1 = (ulonglong2*)pool.take((size_t)np1 * grid1 * cap1 * ebytes);
+    uint32_t* c1 = (uint32_t*)pool.take((size_t)np1 * grid1 * 4);
     if (!flags || !e1 || !c1) return 1;
     VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
     const int64_t spill_cap = spill_out ? nrows / 2 + (1 << 20) : 0;
-    ulonglong2* spill = spill_out ? (ulonglong2*)pool_alloc((size_t)spill_cap * 16) : nullptr;
+    ulonglong2* spill = spill_out ? (ulonglong2*)pool.take((size_t)spill_cap * 16) : nullptr;
     if (spill_out && !spill) return 1;
     PartArgs p1{};
     p1.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
@@ -2911,10 +2912,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     };
     {
         int ov = overflowed();
-        if (ov) {
-            pool_free(e1); pool_free(c1); pool_free(flags); pool_free(spill);
-            return ov < 0 ? set_error("aggregate: partition pass failed") : 2;
-        }
+        if (ov) return ov < 0 ? set_error("aggregate: partition pass failed") : 2;
     }
 
     const ulonglong2* fin_e = e1;
@@ -2927,8 +2925,8 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         // worst case: every row survived and spread evenly; 25 % slack + constant
         const int64_t per_pg = (int64_t)grid1 * rows_per_wg / np1 / split2;
         const int64_t cap2 = per_pg / np2 + per_pg / np2 / 4 + 256;
-        e2 = (ulonglong2*)pool_alloc((size_t)np1 * np2 * split2 * cap2 * ebytes);
-        c2 = (uint32_t*)pool_alloc((size_t)np1 * np2 * split2 * 4);
+        e2 = (ulonglong2*)pool.take((size_t)np1 * np2 * split2 * cap2 * ebytes);
+        c2 = (uint32_t*)pool.take((size_t)np1 * np2 * split2 * 4);
         if (!e2 || !c2) return 1;
         PartArgs p2{};
         p2.in_entries = e1; p2.in_counts = c1; p2.in_cap = cap1; p2.in_regions = grid1; p2.in_split = split2;
@@ -2954,10 +2952,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         VNM_HIP(hipGetLastError());
         {
             int ov = overflowed();
-            if (ov) {
-                pool_free(e1); pool_free(c1); pool_free(e2); pool_free(c2); pool_free(flags); pool_free(spill);
-                return ov < 0 ? set_error("aggregate: partition pass failed") : 2;
-            }
+            if (ov) return ov < 0 ? set_error("aggregate: partition pass failed") : 2;
         }
         fin_e = e2; fin_c = c2; fin_cap = cap2; nfinal = (int64_t)np1 * np2; fin_regions = p2.in_split;
     }
@@ -2977,12 +2972,12 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     const bool dup_run = splits > 1 && !to_table;
     // dense output sized from the hint (guarded in the kernel)
     const int64_t dstride = to_table ? 2 : std::min<int64_t>(nrows, (h->hint * 2 + (1 << 20)) * (dup_run ? splits : 1)) + 2;
-    uint64_t* rk = (uint64_t*)pool_alloc((size_t)dstride * 8 * 2);
-    uint64_t* ra = (uint64_t*)pool_alloc((size_t)dstride * 8 * h->plan.n_words);
+    uint64_t* rk = (uint64_t*)pool.take((size_t)dstride * 8 * 2);
+    uint64_t* ra = (uint64_t*)pool.take((size_t)dstride * 8 * h->plan.n_words);
     if (!rk || !ra) return 1;
     unsigned long long* dir = nullptr;
     if (!to_table && !dup_run) {   // the partition directory only describes runs with ONE workgroup per partition
-        dir = (unsigned long long*)pool_alloc((size_t)nfinal * 16);
+        dir = (unsigned long long*)pool.take((size_t)nfinal * 16);
         if (!dir) return 1;
     }
     PartAggArgs pa{};
@@ -3053,20 +3048,17 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     unsigned long long fl[3];
     VNM_HIP(hipMemcpyAsync(fl, flags, 24, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
-    pool_free(e1); pool_free(c1); pool_free(e2); pool_free(c2); pool_free(flags);
+    pool.done(e1); pool.done(c1); pool.done(e2); pool.done(c2); pool.done(flags);
     if (fl[0]) {  // more groups than hinted / spill buffer full: use the general path for this batch
-        pool_free(rk); pool_free(ra); pool_free(dir); pool_free(spill);
         if (to_table) { table_free(&h->g); h->have_table = false; }  // drop the partial merge
         return 3;  // only the final pass fails this way: the hint was too small, more partitions would do
     }
     if (spill_out) {
-        if (fl[2]) { *spill_out = spill; *n_spill_out = (int64_t)fl[2]; }
-        else { pool_free(spill); *spill_out = nullptr; *n_spill_out = 0; }
+        if (fl[2]) { pool.keep(spill); *spill_out = spill; *n_spill_out = (int64_t)fl[2]; }   // the caller owns it now
+        else { *spill_out = nullptr; *n_spill_out = 0; }
     }
-    if (to_table) {  // the groups already live in the HBM table
-        pool_free(rk); pool_free(ra);
-        return 0;
-    }
+    if (to_table) return 0;  // the groups already live in the HBM table
+    pool.keep(rk); pool.keep(ra); pool.keep(dir);   // the run belongs to the handle
     h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
     h->run_dir = dir; h->run_nfin = dir ? nfinal : 0;
     h->have_run = true;
@@ -3754,6 +3746,9 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     }
     ulonglong2* spill = nullptr;  // entries the partitioned / dense paths could not place (heavy keys, keys outside the sampled range): aggregated below
     int64_t n_spill = 0;
+    unsigned int* progress = nullptr;
+    PoolSlotGuard<ulonglong2> spill_guard(&spill);       // both go back to the pool on every way out of this function
+    PoolSlotGuard<unsigned int> progress_guard(&progress);
     // a few hundred to a few thousand groups in a small key range: the direct-addressed LDS scan (vnm_agg_dense.inc)
     bool dscan_done = false;
     if (dense_shape && !dense_go && h->hint >= env_i64("VNM_DSCAN_MIN_GROUPS", 128) && h->hint <= (1 << DP_TBITS_MAX) &&
@@ -3825,7 +3820,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     int grid = h->single ? cus : cus * 4;
     if (grid > a.ntiles) grid = (int)a.ntiles;
     a.margin = (int64_t)grid * (h->single ? (a.lds_slots + 2 + (hot_scan ? HOT_TILE : lds_tile)) : AGG_TILE);
-    unsigned int* progress = (unsigned int*)pool_alloc((size_t)grid * 4);
+    progress = (unsigned int*)pool_alloc((size_t)grid * 4);
     if (!progress) return 1;
     VNM_HIP(hipMemsetAsync(progress, 0, (size_t)grid * 4, s));
     a.progress = progress;
@@ -3904,8 +3899,6 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         if (h->hint <= 0 && round >= 1) new_cap = h->g.cap * 16;
         VNM_TRY(table_grow(h, new_cap, s));
     }
-    pool_free(progress);
-    pool_free(spill);
     h->rows_seen += nrows;
     return 0;
 }

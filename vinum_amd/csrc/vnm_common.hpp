@@ -49,6 +49,45 @@ int ensure_init();
 void* pool_alloc(size_t bytes);
 void pool_free(void* p);
 void pool_trim();
+// Pool blocks owned by a scope: every early return (VNM_HIP / VNM_TRY included) gives them back.  take() = pool_alloc
+// registered with the scope; keep(p) = ownership moves elsewhere (a handle, the caller); done(p) = free it now.
+struct PoolScope {
+    static constexpr int MAX = 24;
+    void* blocks[MAX];
+    int n = 0;
+    PoolScope() = default;
+    PoolScope(const PoolScope&) = delete;
+    PoolScope& operator=(const PoolScope&) = delete;
+    void* take(size_t bytes) {
+        void* p = pool_alloc(bytes);
+        if (p) {
+            if (n < MAX) blocks[n++] = p;
+            else { pool_free(p); p = nullptr; }
+        }
+        return p;
+    }
+    void keep(void* p) {
+        for (int i = 0; i < n; i++)
+            if (blocks[i] == p) { blocks[i] = blocks[--n]; return; }
+    }
+    void done(void* p) {
+        if (!p) return;
+        keep(p);
+        pool_free(p);
+    }
+    ~PoolScope() {
+        for (int i = 0; i < n; i++) pool_free(blocks[i]);
+    }
+};
+// frees *slot (whatever it points to by then) when the scope ends
+template <class T>
+struct PoolSlotGuard {
+    T** slot;
+    explicit PoolSlotGuard(T** s) : slot(s) {}
+    PoolSlotGuard(const PoolSlotGuard&) = delete;
+    PoolSlotGuard& operator=(const PoolSlotGuard&) = delete;
+    ~PoolSlotGuard() { if (*slot) pool_free((void*)*slot); }
+};
 
 // Optional kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
 // KernelTimer brackets the dominant kernel of an operator call; elapsed time is resolved lazily.
