@@ -1,5 +1,6 @@
 """GPU parity: hash group-by aggregate (HIP, through the C ABI) vs golden vectors of the real reference,
 the reference's gtest known answers, and the oracle on seeded inputs."""
+import ctypes
 import os
 
 import numpy as np
@@ -758,6 +759,7 @@ def test_dense_key_partitioned_path(case, hint, groups, monkeypatch):
     sorted keys (the scrambling must spread them), keys above 2^63, keys the sample never saw (they spill to the scan
     kernel), a later batch outside the code range, one key holding a third of the rows (region overflow -> spill)."""
     from oracle import oracle as O
+    from vinum_amd import _lib as L
     monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
     if case == "p1_7":
         monkeypatch.setenv("VNM_DENSE_P1", "3")
@@ -793,7 +795,23 @@ def test_dense_key_partitioned_path(case, hint, groups, monkeypatch):
         batches = t.to_batches() + t2.to_batches()
     funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.COUNT_STAR, "", "n")]
     for pred in (("v", ">", 64.0), None):
+        check_path = case == "uniform" and hint == 0
+        if check_path:
+            L.lib().vnm_set_profiling(1)    # (re)starts the kernel-span counters
         got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=pred, expected_groups=hint)
+        if check_path:   # the path this parametrisation is about really ran
+            def launches(name):
+                ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+                L.lib().vnm_profile_query(name, ctypes.byref(ms), ctypes.byref(cnt))
+                return cnt.value
+            scan, p1, p2 = launches(b"agg_scan"), launches(b"agg_part_scatter1"), launches(b"agg_part_scatter2")
+            L.lib().vnm_set_profiling(0)
+            if groups == 3_000:
+                assert scan == len(batches) and p1 == 0, (scan, p1, p2)          # direct-addressed LDS scan per batch
+            else:
+                # ONE scatter level (split / plain final pass).  A scan launch = spilled keys; the short second batch of the
+                # 9e5-group case is below the dense path's rows-per-code bound and takes two hash levels
+                assert p1 == len(batches) and p2 <= (1 if groups == 900_000 else 0), (scan, p1, p2)
         o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
         for b in batches:
             if pred:
@@ -893,3 +911,69 @@ def test_streamed_batches_mid_cardinality(groups):
     for b in batches:
         o.next(O.filter_batch(b, O.cmp_mask(b.column(1), O.GT, 20.0)))
     util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"streamed G={groups}")
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS", "48")))))
+def test_random_hot_shape_paths_vs_oracle(seed, monkeypatch):
+    """Seeded differential test of the north-star shape (int64 / uint64 key, float64 value, sum / avg / count, optional
+    float64 predicate) across everything that decides its path: key range from a few hundred to millions of codes (direct-
+    addressed LDS scan, split final pass, one / two scatter levels), sparse 64-bit keys (hash partitions), negative /
+    sorted / clustered / heavy / outlying keys (spill), right, wrong and absent hints, one to three batches whose key ranges
+    may drift, quantised and arbitrary values.  Keys, counts and quantised sums bit-exact; arbitrary float sums within the
+    usual tolerance of the sequential oracle sum."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(52_000 + seed)
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "50000")
+    n = int(rng.integers(200_000, 900_000))
+    groups = int(rng.choice([150, 700, 3_000, 7_500, 20_000, 120_000, 400_000, 2_500_000]))
+    lo = int(rng.choice([0, -groups // 2, 10**12, -(2**62)]))
+    pattern = str(rng.choice(["uniform", "sorted", "clustered", "heavy", "outliers", "sparse"]))
+    base = rng.integers(0, groups, n).astype(np.int64)
+    if pattern == "sorted":
+        base = np.sort(base)
+    elif pattern == "clustered":
+        base = (base // 64) * 64 + (np.arange(n) % 3)
+    elif pattern == "heavy":
+        base[rng.random(n) < 0.3] = groups // 3
+    k = base + lo
+    if pattern == "outliers":
+        k[rng.integers(0, n, 40)] = lo + groups * 50 + rng.integers(0, 1000, 40)
+    elif pattern == "sparse":
+        k = base * 1_000_003_337 + lo
+    unsigned = lo >= 0 and rng.random() < 0.3
+    karr = pa.array(k.astype(np.uint64) if unsigned else k)
+    quantised = rng.random() < 0.7
+    v = rng.integers(-2**13, 2**13, n).astype(np.float64) / 128.0 if quantised else rng.lognormal(1.0, 1.5, n) * rng.choice([-1.0, 1.0], n)
+    cols = {"k": karr, "v": pa.array(v)}
+    pred = None
+    r = rng.random()
+    if r < 0.35:
+        pred = ("v", ">", 3.0)
+    elif r < 0.6:
+        cols["p"] = pa.array(rng.integers(0, 2**12, n).astype(np.float64) / 64.0)
+        pred = ("p", "<=", 40.0)
+    t = pa.table(cols)
+    nb = int(rng.choice([1, 1, 2, 3]))
+    batches = util.sliced_batches(t, (n // nb + 2) & ~1)     # even offsets: the 16-byte pair loads apply
+    if nb > 1 and rng.random() < 0.4:                        # a later batch in a shifted key range
+        m = 120_000
+        k2 = rng.integers(0, groups, m).astype(np.int64) + lo + groups * 3
+        c2 = {"k": pa.array(k2.astype(np.uint64) if unsigned else k2), "v": pa.array(rng.integers(0, 2**13, m).astype(np.float64) / 128.0)}
+        if "p" in cols:
+            c2["p"] = pa.array(rng.integers(0, 2**12, m).astype(np.float64) / 64.0)
+        batches = batches + pa.table(c2).to_batches()
+    hint = int(rng.choice([0, 0, groups, groups * 40, max(1, groups // 50)]))
+    funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.COUNT, "v", "c"), (O.COUNT_STAR, "", "n")]
+    funcs = [funcs[i] for i in sorted(rng.choice(4, size=int(rng.integers(1, 5)), replace=False))]
+    if not any(f[1] for f in funcs):
+        funcs.append((O.SUM, "v", "s"))
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=pred, expected_groups=hint)
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    names = t.schema.names
+    for b in batches:
+        if pred:
+            op = {">": O.GT, "<=": O.LE}[pred[1]]
+            b = O.filter_batch(b, O.cmp_mask(b.column(names.index(pred[0])), op, pred[2]))
+        o.next(b)
+    what = f"seed {seed}: G~{groups} lo={lo} {pattern} unsigned={unsigned} quantised={quantised} hint={hint} pred={pred} batches={len(batches)}"
+    util.assert_agg_equal(got, o.result(), funcs, ["k"], exact_float_inputs=("v",) if quantised else (), what=what)
