@@ -913,6 +913,66 @@ def test_streamed_batches_mid_cardinality(groups):
     util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"streamed G={groups}")
 
 
+@pytest.mark.parametrize("program", ["count_star", "minmax_f64", "sum_i64_count", "distinct", "min_u64_avg"])
+@pytest.mark.parametrize("groups", [1_500_000, 40_000, 3_000], ids=["G1.5e6", "G4e4_split_final", "G3e3_lds_scan"])
+@pytest.mark.parametrize("hint", [0, 2_000_000])
+def test_dense_paths_generic_programs(program, groups, hint, monkeypatch):
+    """The dense-key paths with generic accumulator programs (dgen_* kernels): COUNT(*)-only and DISTINCT travel as bare codes,
+    MIN / MAX / integer sums / AVG of int64, uint64 and float64 inputs as raw 64-bit values; two scatter levels or one, plain
+    or split final pass, whole-table LDS scan; predicate on another column; keys outside the sampled range spill."""
+    from oracle import oracle as O
+    from vinum_amd import _lib as L
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(groups + len(program) + hint)
+    n = 2_400_000 if groups > 1_000_000 else 1_200_000
+    k = rng.integers(0, groups, n).astype(np.int64) - groups // 3
+    # a few keys far outside the range, on rows the range sample (row i * len / 2^18 of each batch) never looks at: they spill
+    blen = n // 2 + 2
+    for start in range(0, n, blen):
+        ln = min(blen, n - start)
+        m = min(ln, 1 << 18)
+        unsampled = np.setdiff1d(np.arange(ln), (np.arange(m, dtype=np.int64) * ln) // m)
+        k[start + unsampled[:: max(1, len(unsampled) // 7)][:7]] = 10**9 + start
+    cols = {"k": pa.array(k)}
+    if program == "minmax_f64":
+        cols["v"] = pa.array(rng.normal(0, 100, n))
+        funcs = [(O.MIN, "v", "lo"), (O.MAX, "v", "hi")]
+    elif program == "sum_i64_count":
+        cols["v"] = pa.array(rng.integers(-2**40, 2**40, n).astype(np.int64))
+        funcs = [(O.SUM, "v", "s"), (O.COUNT, "v", "c"), (O.COUNT_STAR, "", "n")]
+    elif program == "min_u64_avg":
+        cols["v"] = pa.array(rng.integers(0, 2**63, n).astype(np.uint64) * np.uint64(2) + np.uint64(1))
+        funcs = [(O.MIN, "v", "lo"), (O.AVG, "v", "a"), (O.MAX, "v", "hi")]
+    elif program == "distinct":
+        funcs = []
+    else:
+        funcs = [(O.COUNT_STAR, "", "n")]
+    cols["p"] = pa.array(rng.integers(0, 2**12, n).astype(np.float64) / 64.0)
+    t = pa.table(cols)
+    batches = util.sliced_batches(t, blen)
+    names = t.schema.names
+    for pred in (("p", ">", 20.0), None):
+        L.lib().vnm_set_profiling(1)
+        got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=pred, expected_groups=hint)
+        def launches(name):
+            ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+            L.lib().vnm_profile_query(name, ctypes.byref(ms), ctypes.byref(cnt))
+            return cnt.value
+        p1 = launches(b"agg_part_scatter1")
+        L.lib().vnm_set_profiling(0)
+        # the dense kernels really ran: a scatter level per batch, or none at all for the small range (min_u64_avg keeps five
+        # words per slot in LDS -- min, max, two 32-bit sum lanes, count: 2048-slot scan tables do not hold 3000 groups, so it
+        # scatters there as well)
+        if hint == 0:
+            assert p1 == (0 if groups == 3_000 and program != "min_u64_avg" else len(batches)), (program, groups, p1)
+        o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+        for b in batches:
+            if pred:
+                b = O.filter_batch(b, O.cmp_mask(b.column(names.index("p")), O.GT, 20.0))
+            o.next(b)
+        util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"dense generic {program} G={groups} hint={hint} pred={pred}")
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS", "48")))))
 def test_random_hot_shape_paths_vs_oracle(seed, monkeypatch):
     """Seeded differential test of the north-star shape (int64 / uint64 key, float64 value, sum / avg / count, optional

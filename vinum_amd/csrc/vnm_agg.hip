@@ -2612,6 +2612,7 @@ struct vnm_agg {
     int dense_state = 0;
     DenseMap dmap{};
     int64_t dense_span = 0;  // 2^bits: upper bound of the groups a dense run can hold
+    uint64_t dense_rlo = 0, dense_rhi = 0;  // the sampled (widened) range itself, as order-preserving unsigned images
     bool rank_aligned = false;  // vnm_agg_set_exchange_mode: only run layouts every rank derives identically
     // expression input (vnm_agg_set_input_expr): the functions reading plan column expr_col get an expression's value
     int expr_col = -1;
@@ -3104,6 +3105,7 @@ int plan_dense(vnm_agg* h, const vnm_dcol& key, int64_t nrows, hipStream_t s) {
     // ranges below 2^20 leave too few final partitions to fill the chip with one workgroup each: their final pass splits
     // every partition over several workgroups and merges the partial tables (dpart_merge_kernel).  Up to 2^13 codes need
     // no partitioning at all (dense_state = 2).
+    h->dense_rlo = lo; h->dense_rhi = hi;
     const bool small = bits < (int)env_i64("VNM_DENSE_MIN_BITS", 14);   // at most 2^13 codes: the direct-addressed LDS scan (dscan_kernel)
     if (small) bits = DP_TBITS_MAX;   // always the 2^13-slot table: one 1024-thread workgroup per CU measured fastest at every G
                                       // (G = 300 / 1000: 2.83 / 2.84 ms; 2^12 slots, two 512-thread workgroups: 3.04 / 3.07; 2^11, four: 3.50 / 3.65)
@@ -3123,13 +3125,115 @@ int plan_dense(vnm_agg* h, const vnm_dcol& key, int64_t nrows, hipStream_t s) {
     return 0;
 }
 
+// Generic accumulator programs on the dense paths (dgen_* kernels): every AccKind at most once over at most one plain
+// 8-byte input column, at most one COUNT(*) word (it lives in the slot's row counter).  Fills the program part of `g`;
+// false = not expressible.
+bool dgen_program(const vnm_agg* h, const AggArgs& a, DGenArgs* g) {
+    const AggPlan& p = h->plan;
+    if (p.n_cols > 1 || p.n_words > AGG_MAX_WORDS) return false;
+    g->has_val = p.n_cols == 1;
+    g->vtype = p.n_cols == 1 ? a.cols[0].type : VNM_F64;
+    g->comp = 0;
+    g->wpack = ~0ULL;
+    g->n_words = p.n_words;
+    int w_rows = -1;
+    for (int o = 0; o < p.n_ops; o++) {
+        const AccOp& op = p.ops[o];
+        if (op.kind == A_COUNT_ROWS) { if (w_rows >= 0) return false; w_rows = op.word; }
+    }
+    int n_lds = 0;
+    for (int w = 0; w < p.n_words; w++) {
+        g->merge[w] = p.merge[w];
+        g->lds_word[w] = w == w_rows ? -1 : n_lds++;
+        if (p.merge[w] == M_ADD_F64C) g->comp = 1;
+    }
+    if (n_lds > DG_MAX_WORDS - 1) return false;
+    g->n_lds = n_lds;
+    for (int o = 0; o < p.n_ops; o++) {
+        const AccOp& op = p.ops[o];
+        if (op.kind == A_COUNT_ROWS) continue;
+        if (op.col != 0 || op.kind < 0 || op.kind > A_MAX || op.word >= 63 || ((g->wpack >> (6 * op.kind)) & 63ULL) != 63) return false;
+        g->wpack = (g->wpack & ~(63ULL << (6 * op.kind))) | ((unsigned long long)g->lds_word[op.word] << (6 * op.kind));
+    }
+    // a compensated sum's lo word must follow its hi word in LDS as well
+    for (int w = 0; w + 1 < p.n_words; w++)
+        if (p.merge[w] == M_ADD_F64C && (g->lds_word[w] < 0 || g->lds_word[w + 1] != g->lds_word[w] + 1)) return false;
+    return true;
+}
+// bytes of LDS per slot of a generic table
+inline int dgen_slot_bytes(const DGenArgs& g) { return 8 * g.n_lds + 4; }
+
 // Ranges of at most 2^13 codes: one scan with the whole table in LDS.  Same return convention as the partitioned variant.
-int dense_scan_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s, ulonglong2** spill_out, int64_t* n_spill_out) {
+int dense_scan_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s, ulonglong2** spill_out, int64_t* n_spill_out, bool generic = false) {
     const int cus = device_info().num_cus;
-    const int tb = DP_TBITS_MAX;
-    if (h->dmap.bits != tb) return 2;
-    const int slots = 1 << tb;
+    if (h->dmap.bits != DP_TBITS_MAX) return 2;
     const int block = 1024;
+    if (generic) {
+        DGenArgs g{};
+        if (!dgen_program(h, a, &g)) return 2;
+        // the largest table (<= 2^13 slots) that fits 144 KB of LDS must hold the sampled range
+        int tb = DP_TBITS_MAX;
+        while (tb > 9 && ((size_t)dgen_slot_bytes(g) << tb) > 144 * 1024) tb--;
+        const uint64_t need = h->dense_rhi - h->dense_rlo;
+        if (need >= (1ULL << tb)) return 2;
+        const int slots = 1 << tb;
+        const size_t lds = (size_t)slots * dgen_slot_bytes(g);
+        const int per_cu = lds <= 72 * 1024 ? 2 : 1;
+        const int grid = (int)std::min<int64_t>((int64_t)cus * per_cu, std::max<int64_t>(1, (nrows / 2 + block - 1) / block));
+        PoolScope pool;
+        unsigned long long* flags = (unsigned long long*)pool.take(64);
+        uint64_t* pw = (uint64_t*)pool.take(std::max<size_t>(8, (size_t)grid * g.n_lds * slots * 8));
+        uint32_t* pc = (uint32_t*)pool.take((size_t)grid * slots * 4);
+        const int64_t spill_cap = nrows / 2 + (1 << 20);
+        ulonglong2* spill = (ulonglong2*)pool.take((size_t)spill_cap * 16);
+        const int64_t dstride = slots + 2;
+        uint64_t* rk = (uint64_t*)pool.take((size_t)dstride * 8 * 2);
+        uint64_t* ra = (uint64_t*)pool.take((size_t)dstride * 8 * std::max(1, h->plan.n_words));
+        if (!flags || !pw || !pc || !spill || !rk || !ra) return 1;
+        VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
+        g.map = h->dmap; g.map.mul = 1; g.map.mul_inv = 1;
+        if (tb != DP_TBITS_MAX) {   // a smaller table: centre the sampled range in it
+            const uint64_t extra = ((1ULL << tb) - 1) - need;
+            g.map.lo_u = h->dense_rlo > extra / 2 ? h->dense_rlo - extra / 2 : 0;
+            g.map.bits = tb;
+            g.map.mask = (uint32_t)((1ULL << tb) - 1);
+        }
+        g.tbits = tb;
+        g.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
+        g.vp = g.has_val ? (const double*)a.cols[0].values + a.cols[0].offset : nullptr;
+        g.pp = h->pred_set ? (const double*)a.pred.values + a.pred.offset : nullptr;
+        g.has_pred = h->pred_set; g.pred_is_v = a.hot_pred_is_v; g.op = a.p.op; g.thr = a.p.dval;
+        g.nrows = nrows;
+        g.spill = spill; g.spill_cap = spill_cap;
+        g.dkey = rk; g.dacc = ra; g.dstride = dstride; g.flags = flags;
+        g.nfinal = 1; g.splits = grid; g.part_w = pw; g.part_cnt = pc;
+        {
+            KernelTimer timer("agg_scan", s);
+            if (g.has_val) {
+                VNM_HIP(hipFuncSetAttribute((const void*)dgen_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                dgen_scan_kernel<true><<<grid, block, lds, s>>>(g);
+            } else {
+                VNM_HIP(hipFuncSetAttribute((const void*)dgen_scan_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                dgen_scan_kernel<false><<<grid, block, lds, s>>>(g);
+            }
+            dgen_merge_kernel<<<std::max(1, slots / 512), 512, 0, s>>>(g);
+        }
+        VNM_HIP(hipGetLastError());
+        unsigned long long fl[3];
+        VNM_HIP(hipMemcpyAsync(fl, flags, 24, hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipStreamSynchronize(s));
+        if (fl[0]) return 2;
+        if (fl[2]) { pool.keep(spill); *spill_out = spill; *n_spill_out = (int64_t)fl[2]; }
+        else { *spill_out = nullptr; *n_spill_out = 0; }
+        if ((int64_t)fl[2] > nrows / 16) h->dense_state = -1;
+        pool.keep(rk); pool.keep(ra);
+        h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
+        h->run_dir = nullptr; h->run_nfin = 0;
+        h->have_run = true;
+        return 0;
+    }
+    const int tb = DP_TBITS_MAX;
+    const int slots = 1 << tb;
     const int grid = (int)std::min<int64_t>((int64_t)cus, std::max<int64_t>(1, (nrows / 2 + block - 1) / block));
     const size_t cells = (size_t)grid * slots;
     unsigned long long* flags = (unsigned long long*)pool_alloc(64);
@@ -3184,9 +3288,13 @@ int dense_scan_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_
 }
 
 // returns 0 = done (run stored), 2 = not applicable / failed (caller continues with the hash-partitioned path), 1 = error
-int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s, ulonglong2** spill_out, int64_t* n_spill_out) {
+int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s, ulonglong2** spill_out, int64_t* n_spill_out,
+                                bool generic = false) {
     const int cus = device_info().num_cus;
     const DenseMap& mp = h->dmap;
+    DGenArgs g{};
+    if (generic && !dgen_program(h, a, &g)) return 2;
+    const bool has_val = generic ? g.has_val != 0 : true;
     // slots per final partition: the largest table that still leaves >= 2048 final partitions (8 per CU)
     int tb = (int)env_i64("VNM_DENSE_TBITS", 12);
     tb = std::max(DP_TBITS_MIN, std::min(DP_TBITS_MAX, tb));
@@ -3195,6 +3303,13 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     // ranges of up to 2^22 codes: ONE scatter level (at most 512 partitions) with the largest table that allows it
     if (mp.bits <= DP_TBITS_MAX + 9 && env_i64("VNM_DENSE_ONE_LEVEL", 1)) tb = std::max(DP_TBITS_MIN, std::min(DP_TBITS_MAX, mp.bits - (int)env_i64("VNM_DENSE_ONE_P", 8)));
     if (mp.bits < 20) tb = (int)env_i64("VNM_DENSE_SMALL_TBITS", 12);   // split final pass: few partitions, long write runs in pass 1
+    if (generic) {   // the table must fit 64 KB of LDS (80 KB at most: one workgroup per CU less)
+        int tmax = DP_TBITS_MAX;
+        while (tmax > 9 && ((size_t)dgen_slot_bytes(g) << tmax) > 64 * 1024) tmax--;   // (the generic kernels take the table size at run time)
+        if (((size_t)dgen_slot_bytes(g) << tmax) > 80 * 1024) return 2;
+        if (tb > tmax) tb = tmax;
+        if (mp.bits - tb > 18) return 2;
+    }
     const int pbits = mp.bits - tb;
     const int levels = pbits > 9 ? 2 : 1;
     // pass 1 moves 12-byte entries out of 16-byte rows, pass 2 moves 10-byte entries out of 12: the SMALLER fan-out goes
@@ -3218,7 +3333,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         if (fsplits < 2) fsplits = 1;
     }
     unsigned long long* flags = (unsigned long long*)pool_alloc(64);
-    double* v1 = (double*)pool_alloc((size_t)np1 * grid1 * cap1 * 8);
+    double* v1 = (double*)pool_alloc(has_val ? (size_t)np1 * grid1 * cap1 * 8 : 8);
     void* c1 = pool_alloc((size_t)np1 * grid1 * cap1 * (c16_1 ? 2 : 4));
     uint32_t* n1 = (uint32_t*)pool_alloc((size_t)np1 * grid1 * 4);
     const int64_t spill_cap = nrows / 2 + (1 << 20);
@@ -3231,7 +3346,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     DPartArgs d1{};
     d1.map = mp;
     d1.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
-    d1.vp = (const double*)a.cols[0].values + a.cols[0].offset;
+    d1.vp = has_val ? (const double*)a.cols[0].values + a.cols[0].offset : nullptr;
     d1.has_expr = a.has_expr; d1.expr = a.expr;
     d1.pp = h->pred_set ? (const double*)a.pred.values + a.pred.offset : nullptr;
     d1.has_pred = h->pred_set; d1.pred_is_v = a.hot_pred_is_v; d1.op = a.p.op; d1.thr = a.p.dval;
@@ -3245,8 +3360,13 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     d1.flags = flags; d1.spill = spill; d1.spill_cap = spill_cap;
     {
         KernelTimer timer("agg_part_scatter1", s);
-        if (c16_1) dpart_scatter_kernel<true, uint16_t><<<grid1, PT_BLOCK, 0, s>>>(d1);
-        else dpart_scatter_kernel<true, uint32_t><<<grid1, PT_BLOCK, 0, s>>>(d1);
+        if (has_val) {
+            if (c16_1) dpart_scatter_kernel<true, uint16_t><<<grid1, PT_BLOCK, 0, s>>>(d1);
+            else dpart_scatter_kernel<true, uint32_t><<<grid1, PT_BLOCK, 0, s>>>(d1);
+        } else {
+            if (c16_1) dpart_scatter_kernel<true, uint16_t, false><<<grid1, PT_BLOCK, 0, s>>>(d1);
+            else dpart_scatter_kernel<true, uint32_t, false><<<grid1, PT_BLOCK, 0, s>>>(d1);
+        }
     }
     VNM_HIP(hipGetLastError());
     const double* fin_v = v1; const void* fin_c = c1; const uint32_t* fin_n = n1;
@@ -3255,7 +3375,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     if (levels == 2) {
         const int64_t per_pg = (int64_t)grid1 * rows_per_wg / np1 / split2;
         const int64_t cap2 = ((per_pg / np2 + per_pg / np2 / 4 + 256) + 7) & ~7LL;
-        v2 = (double*)pool_alloc((size_t)np1 * np2 * split2 * cap2 * 8);
+        v2 = (double*)pool_alloc(has_val ? (size_t)np1 * np2 * split2 * cap2 * 8 : 8);
         c2 = pool_alloc((size_t)np1 * np2 * split2 * cap2 * 2);
         n2 = (uint32_t*)pool_alloc((size_t)np1 * np2 * split2 * 4);
         if (!v2 || !c2 || !n2) { release(); pool_free(spill); return 1; }
@@ -3269,7 +3389,8 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         d2.flags = flags; d2.spill = spill; d2.spill_cap = spill_cap;
         {
             KernelTimer timer("agg_part_scatter2", s);
-            dpart_scatter_kernel<false, uint16_t><<<np1 * split2, PT_BLOCK, 0, s>>>(d2);
+            if (has_val) dpart_scatter_kernel<false, uint16_t><<<np1 * split2, PT_BLOCK, 0, s>>>(d2);
+            else dpart_scatter_kernel<false, uint16_t, false><<<np1 * split2, PT_BLOCK, 0, s>>>(d2);
         }
         VNM_HIP(hipGetLastError());
         fin_v = v2; fin_c = c2; fin_n = n2; fin_cap = cap2; fin_regions = split2;
@@ -3288,7 +3409,37 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     df.w_lo = a.hot_comp && a.hot_w_sum >= 0 ? a.hot_w_sum + 1 : -1;
     df.dkey = rk; df.dacc = ra; df.dstride = dstride; df.flags = flags;
     uint64_t* psum = nullptr; float* plo = nullptr; uint32_t* pcnt = nullptr;
-    if (fsplits > 1) {
+    if (generic) {
+        const size_t slots = (size_t)1 << tb;
+        const size_t lds = slots * dgen_slot_bytes(g);
+        g.map = mp; g.tbits = tb;
+        g.pstride = df.pstride; g.rstride = df.rstride;
+        g.vals = fin_v; g.codes = fin_c; g.counts = fin_n; g.cap = fin_cap; g.regions = fin_regions; g.nfinal = nfinal;
+        g.dkey = rk; g.dacc = ra; g.dstride = dstride; g.flags = flags;
+        if (fsplits > 1) {
+            const size_t work = (size_t)nfinal * fsplits;
+            psum = (uint64_t*)pool_alloc(std::max<size_t>(8, work * g.n_lds * slots * 8));
+            pcnt = (uint32_t*)pool_alloc(work * slots * 4);
+            if (!psum || !pcnt) { release(); pool_free(spill); pool_free(rk); pool_free(ra); pool_free(psum); pool_free(pcnt); return 1; }
+            g.splits = fsplits; g.part_w = psum; g.part_cnt = pcnt;
+        }
+        KernelTimer timer("agg_part_final", s);
+#define VNM_DGFIN(HV_, SP_)                                                                                            \
+    do {                                                                                                              \
+        VNM_HIP(hipFuncSetAttribute((const void*)dgen_final_kernel<HV_, SP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        int occ = 0;                                                                                                  \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)dgen_final_kernel<HV_, SP_>, 512, lds) != hipSuccess || occ < 1) occ = 1; \
+        const int g3 = (int)std::min<int64_t>(nfinal * (SP_ ? fsplits : 1), (int64_t)cus * std::min(occ, 8));         \
+        dgen_final_kernel<HV_, SP_><<<g3, 512, lds, s>>>(g);                                                          \
+    } while (0)
+        if (fsplits > 1) {
+            if (has_val) VNM_DGFIN(true, true); else VNM_DGFIN(false, true);
+            dgen_merge_kernel<<<(int)(nfinal << (tb - 9)), 512, 0, s>>>(g);
+        } else {
+            if (has_val) VNM_DGFIN(true, false); else VNM_DGFIN(false, false);
+        }
+#undef VNM_DGFIN
+    } else if (fsplits > 1) {
         const size_t cells = (size_t)nfinal * fsplits << tb;
         psum = (uint64_t*)pool_alloc(cells * 8); plo = (float*)pool_alloc(cells * 4); pcnt = (uint32_t*)pool_alloc(cells * 4);
         if (!psum || !plo || !pcnt) { release(); pool_free(spill); pool_free(rk); pool_free(ra); pool_free(psum); pool_free(plo); pool_free(pcnt); return 1; }
@@ -3324,6 +3475,9 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     VNM_HIP(hipStreamSynchronize(s));
     release();
     pool_free(psum); pool_free(plo); pool_free(pcnt);
+    if (getenv("VNM_AGG_TRACE"))
+        fprintf(stderr, "[agg] dense%s: bits %d tb %d levels %d p1 %d p2 %d splits %d -> fail %llu groups %llu spilled %llu (dstride %lld)\n", generic ? " generic" : "",
+                mp.bits, tb, levels, p1, p2, fsplits, fl[0], fl[1], fl[2], (long long)dstride);
     if (fl[0]) {  // spill buffer full, dense output too small, or a compensation term beyond float range
         pool_free(rk); pool_free(ra); pool_free(spill);
         return 2;
@@ -3685,6 +3839,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     // the partitioned path also takes ANY accumulator program over at most one 8-byte input column: its entries
     // carry (key, raw value bits) and only the final pass interprets them
     bool part_ok = hot;
+    bool narrow_generic = false;   // a generic program over (key, one plain 8-byte value or none): the dgen_* dense kernels take it too
     if (!hot && h->single && h->plan.n_cols <= 3 && type_width(keys[0].type) == 8 && !keys[0].validity &&
         (keys[0].offset & 1) == 0 && getenv("VNM_AGG_NO_PART_GENERIC") == nullptr &&
         (size_t)(PA_SLOTS + 1) * 8 * (1 + h->plan.n_words) <= 150 * 1024) {
@@ -3707,6 +3862,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         const bool wide = !narrow && h->plan.n_cols >= 1 && h->plan.n_cols + (any_null ? 1 : 0) <= 3 &&
                           getenv("VNM_AGG_NO_PART_WIDE") == nullptr;
         part_ok = narrow || wide;
+        narrow_generic = narrow;
         a.part_generic = part_ok;
         a.part_wide = wide;
         a.part_vmask = wide && any_null;
@@ -3720,7 +3876,10 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     // bits.  It needs to know that G is LARGE, not how large: when the small sample of the estimator cannot settle G, its
     // lower bound is enough (span <= 32 G: the direct-addressed slots are reasonably filled) and the HyperLogLog pass
     // (0.85 ms) is skipped; the hash-partitioned path below still estimates properly if the dense attempt fails.
-    const bool dense_shape = hot && part_ok && !h->rank_aligned && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
+    // (generic programs: only where the spilled entries -- keys outside the sampled range -- have a kernel to go to)
+    const bool dense_generic = !hot && narrow_generic && hot_scan && !hot_two && !hot_vnull && !a.has_expr &&
+                               getenv("VNM_AGG_NO_DENSE_GENERIC") == nullptr && getenv("VNM_AGG_NO_SPILL") == nullptr;
+    const bool dense_shape = (hot || dense_generic) && part_ok && !h->rank_aligned && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
                              getenv("VNM_AGG_NO_DENSE") == nullptr;
     bool dense_go = false;
     if (part_ok && h->hint == 0 && !h->estimated && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
@@ -3759,7 +3918,10 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         }
         if (h->dense_state == 2) {
             if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
-            const int prc = dense_scan_aggregate(h, a, nrows, s, &spill, &n_spill);
+            int prc = dense_scan_aggregate(h, a, nrows, s, &spill, &n_spill, dense_generic);
+            // a generic program whose table for this range does not fit LDS: the same 2^13 codes through one scatter level
+            // (four partitions of 2^11 slots, split final pass) instead
+            if (prc == 2 && dense_generic && h->dense_state == 2) prc = dense_partitioned_aggregate(h, a, nrows, s, &spill, &n_spill, true);
             if (prc == 1) return 1;
             if (prc == 0 && !spill) { h->rows_seen += nrows; return 0; }
             if (prc == 0) {  // the scan below runs over the spilled entries only (predicate already applied)
@@ -3779,7 +3941,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         const bool can_spill = hot_scan && !hot_two && !hot_vnull && getenv("VNM_AGG_NO_SPILL") == nullptr;
         int prc = 2;
         if (dense_go && (h->hint > part_min || h->hint == 0)) {
-            prc = dense_partitioned_aggregate(h, a, nrows, s, &spill, &n_spill);
+            prc = dense_partitioned_aggregate(h, a, nrows, s, &spill, &n_spill, dense_generic);
             if (prc == 2 && h->hint == 0) {  // the dense attempt failed before G was ever estimated
                 int64_t est = 0;
                 VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s));
