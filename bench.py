@@ -352,6 +352,13 @@ def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream,
         agg.next([k7], [None], nrows=n, stream=stream)
         state["ng"] = agg.finish(stream=stream)
     ms, sp = _measure(torch, lib, ctypes, gc, AGG_SPANS, steps + 2, warmup + 1)
+    def gcl():
+        agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.COUNT_STAR, None, None)])
+        agg.next([kcol], [None], nrows=n, stream=stream)
+        state["ng_l"] = agg.finish(stream=stream)
+    ms_l, sp_l = _measure(torch, lib, ctypes, gcl, AGG_SPANS, steps, warmup + 1)
+    out["configs[0] query shape, large G"] = _entry(f"SELECT k,count(*) GROUP BY k; N={n:.3g}, G={groups:.3g} (hint-less; the entries are bare key codes)",
+                                                    n, ms_l, sp_l, 8.0 * n + 16.0 * state["ng_l"], state["ng_l"])
     out["configs[0] query shape"] = _entry(f"SELECT k,count(*) GROUP BY k; N={n:.3g}, 7 groups (the 1M-row CSV query of configs[0], at scale)",
                                            n, ms, sp, 8.0 * n + 16.0 * state["ng"], state["ng"])
     del k7

@@ -16,7 +16,8 @@ prof() {  # name, rocprof args..., -- bench args
     python $ROOT/tools/rocpd_summary.py "$db" vnm
     echo
 }
-for wl in "groupby --groups 1e8" "groupby --groups 7" "groupby --groups 1e6" "filter" "topk" "project"; do
+for wl in "groupby --groups 1e8" "groupby --groups 7" "groupby --groups 1e3" "groupby --groups 1e5" "groupby --groups 1e6" \
+          "groupby --groups 1e8 --shape count_star" "filter" "topk" "topk --limit 0" "project"; do
     tag=$(echo $wl | tr -d ' -' ); 
     prof ks_$tag --kernel-trace -- --workload $wl --steps 5 --warmup 2 > $OUT/${R}_rocprofv3_kernel_stats_$tag.txt
 done
