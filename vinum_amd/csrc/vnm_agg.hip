@@ -3879,8 +3879,9 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     // (generic programs: only where the spilled entries -- keys outside the sampled range -- have a kernel to go to)
     const bool dense_generic = !hot && narrow_generic && hot_scan && !hot_two && !hot_vnull && !a.has_expr &&
                                getenv("VNM_AGG_NO_DENSE_GENERIC") == nullptr && getenv("VNM_AGG_NO_SPILL") == nullptr;
-    const bool dense_shape = (hot || dense_generic) && part_ok && !h->rank_aligned && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
-                             getenv("VNM_AGG_NO_DENSE") == nullptr;
+    const bool dense_base = (hot || dense_generic) && part_ok && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
+                            getenv("VNM_AGG_NO_DENSE") == nullptr;
+    bool dense_shape = dense_base && !h->rank_aligned;
     bool dense_go = false;
     if (part_ok && h->hint == 0 && !h->estimated && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
         getenv("VNM_AGG_NO_ESTIMATE") == nullptr) {
@@ -3895,6 +3896,9 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         }
         if (est) { h->hint = est; h->estimated = true; }
     }
+    // rank-aligned operators (multi-GPU) keep hash partitions so that every rank cuts its result the same way -- which only
+    // the partition-aligned exchange of LARGE results needs; small results travel by one all-gather and are merged by key
+    if (dense_base && h->rank_aligned && h->hint > 0 && h->hint <= env_i64("VNM_ALIGNED_DENSE_MAX", 1 << 19)) dense_shape = true;
     const int64_t part_min0 = env_i64("VNM_AGG_PART_MIN_GROUPS", std::min<int64_t>(2400, (int64_t)S * 6 / 10));
     if (dense_shape && !dense_go && h->hint > part_min0) {
         if (h->dense_state == 0) {
