@@ -125,3 +125,27 @@ def test_random_filters_vs_oracle(seed):
     exp = O.filter_batch(batch, O.cmp_mask(arr, ocode, lit))
     util.assert_batches_equal(got, exp, what=f"seed {seed}: n={n} off={offset} {col}:{arr.type} {op} {lit} "
                                              f"cols {[str(a.type) for a in arrays]}")
+
+
+@pytest.mark.parametrize("scheme", ["flat_gives_up", "cooperative_only", "flat"])
+def test_filter_launch_schemes(scheme, monkeypatch):
+    """The filter is launched one workgroup per tile with BOUNDED look-backs first and repeated with cooperative persistent
+    workgroups if one of them gave up.  A spin limit of zero polls makes (nearly) every tile give up: the first attempt's output
+    is discarded and the cooperative repeat must deliver the exact result."""
+    from vinum_amd.device import DeviceColumn
+    from vinum_amd import ops
+    if scheme == "flat_gives_up":
+        monkeypatch.setenv("VNM_FILTER_SPIN_LIMIT", "1")
+        monkeypatch.setenv("VNM_FILTER_SLEEP", "0")
+    elif scheme == "cooperative_only":
+        monkeypatch.setenv("VNM_FILTER_PERSIST", "1")
+    rng = np.random.default_rng(11)
+    n = 30_000_001
+    x = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
+    y = rng.integers(-2**40, 2**40, n).astype(np.int64)
+    cx, cy = DeviceColumn.from_numpy(x), DeviceColumn.from_numpy(y)
+    for thr in [1.28, 64.0, 126.7]:
+        outs, k = ops.filter_cmp(cx, ">", thr, [cx, cy])
+        keep = x > thr
+        assert k == int(keep.sum())
+        assert np.array_equal(outs[0].to_numpy(), x[keep]) and np.array_equal(outs[1].to_numpy(), y[keep])

@@ -4557,7 +4557,8 @@ int vnm_agg_result_device(vnm_agg* h, int n_cols, const int* which, void* const*
         }
         if (n == 0) continue;
         VNM_HIP(hipMemsetAsync(ctl, 0, 16 * FIN_MAX_COLS, s));
-        const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_info().num_cus * 16);
+        // one thread per group (a grid-stride loop over 16 workgroups per CU: 1.38 instead of 1.21 ms for 1e8 groups x 3 columns)
+        const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)1 << 30);
         {
             KernelTimer timer("agg_finalize", s);
             agg_finalize_kernel<<<grid, 256, 0, s>>>(m);

@@ -43,10 +43,12 @@ struct FilterArgs {
     int64_t length;     // logical rows
     int64_t phys_base;  // first physical element index covered by tile 0 (even)
     int64_t ntiles;
-    unsigned long long* ctl;  // [0] ticket, [1] total
+    unsigned long long* ctl;  // [0] ticket, [1] total, [2..4] look-back statistics, [5] a look-back gave up
     unsigned long long* status;
     unsigned long long* gstatus;  // one word per group of 64 tiles (two-level look-back)
     int lb_sleep;  // look-back back-off between polls, in units of s_sleep(1)
+    int spin_limit;  // polls after which a look-back gives up (ctl[5] = 1, the host repeats the filter with the cooperative
+                     // launch); 0 = never (cooperative launch: every predecessor is resident)
     int debug;  // timing experiments only: 1 = skip look-back (outputs are wrong)
 };
 
@@ -70,12 +72,19 @@ __device__ __forceinline__ void lb_backoff(int n) {
 // its own group; the last tile of a group publishes the group aggregate as soon as those are visible
 // (independent of any prefix), and prefixes then travel over group words, 64 groups = 4096 tiles per round.
 // Returns the exclusive prefix of `tile`; `total` is the tile's own survivor count.
+// spin_limit > 0: give up (return -1) after that many fruitless polls.
 __device__ __forceinline__ int64_t lookback2(unsigned long long* status, unsigned long long* gstatus, int64_t tile,
-                                             int lane, uint32_t total, uint64_t& rounds, int nsleep) {
+                                             int lane, uint32_t total, uint64_t& rounds, int nsleep, int spin_limit = 0) {
     const int64_t g = tile >> 6;
     const int r = (int)(tile & 63);
     int64_t local = 0;
     bool have_inc = false;
+    int spins = 0;
+#define VNM_LB_WAIT()                                                   \
+    do {                                                                \
+        if (spin_limit > 0 && ++spins > spin_limit) return -1;          \
+        lb_backoff(nsleep);                                             \
+    } while (0)
     if (r > 0) {
         for (;;) {
             rounds++;
@@ -87,11 +96,11 @@ __device__ __forceinline__ int64_t lookback2(unsigned long long* status, unsigne
             if (incl_mask) {
                 int first = __ffsll((unsigned long long)incl_mask) - 1;
                 uint64_t need = first == 0 ? 0ULL : (~0ULL >> (64 - first));
-                if (zero_mask & need) { lb_backoff(nsleep); continue; }
+                if (zero_mask & need) { VNM_LB_WAIT(); continue; }
                 if (lane > first) val = 0;
                 have_inc = true;
             } else if (zero_mask) {
-                lb_backoff(nsleep);
+                VNM_LB_WAIT();
                 continue;
             }
 #pragma unroll
@@ -117,10 +126,10 @@ __device__ __forceinline__ int64_t lookback2(unsigned long long* status, unsigne
         if (incl_mask) {
             int first = __ffsll((unsigned long long)incl_mask) - 1;
             uint64_t need = first == 0 ? 0ULL : (~0ULL >> (64 - first));
-            if (zero_mask & need) { lb_backoff(nsleep); continue; }
+            if (zero_mask & need) { VNM_LB_WAIT(); continue; }
             if (lane > first) val = 0;
         } else if (zero_mask) {
-            lb_backoff(nsleep);
+            VNM_LB_WAIT();
             continue;
         }
 #pragma unroll
@@ -130,6 +139,7 @@ __device__ __forceinline__ int64_t lookback2(unsigned long long* status, unsigne
         look -= 64;
     }
     return gp + local;
+#undef VNM_LB_WAIT
 }
 
 // =======================================================================================================
@@ -217,6 +227,7 @@ __device__ __forceinline__ void filter_tile(const FilterArgs& a, const int64_t t
         if (lane < NSEG) s_excl[lane] = inc - c;
         const uint32_t total = __shfl(inc, 63);
         int64_t excl = 0;
+        bool aborted = false;
         if (tile == 0) {
             if (lane == 0) __hip_atomic_store(&a.status[0], ST_INC | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (a.debug & 1) {
@@ -225,7 +236,12 @@ __device__ __forceinline__ void filter_tile(const FilterArgs& a, const int64_t t
             if (lane == 0) __hip_atomic_store(&a.status[tile], ST_AGG | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint64_t rounds = 0;
             uint64_t t0 = STATS ? __builtin_readcyclecounter() : 0;
-            excl = lookback2(a.status, a.gstatus, tile, lane, total, rounds, a.lb_sleep);
+            excl = lookback2(a.status, a.gstatus, tile, lane, total, rounds, a.lb_sleep, a.spin_limit);
+            if (excl < 0) {   // gave up (plain launch and a predecessor that never came): everything later still terminates
+                if (lane == 0) a.ctl[5] = 1;
+                excl = 0;
+                aborted = true;
+            }
             if (lane == 0) {
                 __hip_atomic_store(&a.status[tile], ST_INC | (uint64_t)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((tile & 63) == 63)
@@ -238,13 +254,14 @@ __device__ __forceinline__ void filter_tile(const FilterArgs& a, const int64_t t
             }
         }
         if (lane == 0) {
-            s_base = excl;
+            s_base = aborted ? -1 : excl;
             if (tile == a.ntiles - 1) a.ctl[1] = (unsigned long long)(excl + total);
         }
     }
     __syncthreads();
     if (a.debug & 4) return;
     const int64_t base = s_base;
+    if (base < 0) return;   // no output position: the host repeats the whole filter
     if (HOT) {
         // one payload column is the predicate column itself: its values are still in registers
         if (a.reuse_idx == 0) {
@@ -319,6 +336,16 @@ void filter_tile_kernel(FilterArgs a) {
     }
 }
 
+// ONE workgroup per tile, plain launch: 5-8 % faster (the dispatcher replaces a finished workgroup at once instead of the
+// persistent ones walking in rounds).  Its look-backs rely on workgroups being dispatched in index order -- true of the
+// hardware dispatcher, not a promise of HIP -- so they are bounded (FilterArgs::spin_limit): should a predecessor ever fail to
+// show up, the waiting tiles give up one after the other, the kernel ends, and the host repeats the filter cooperatively.
+template <int MODE, int FB, int CH, bool HOT, bool STATS, bool PAYLOOP>
+__global__ __launch_bounds__(FB) __attribute__((amdgpu_waves_per_eu(CH == 4 ? 8 : (CH == 16 ? VNM_F16W : 5), 8)))
+void filter_tile_flat_kernel(FilterArgs a) {
+    filter_tile<MODE, FB, CH, HOT, STATS, PAYLOOP>(a, (int64_t)blockIdx.x);
+}
+
 // byte-per-row validity -> Arrow bitmap (LSB first), 8 rows per lane
 __global__ void pack_validity_kernel(const uint8_t* bytes, int64_t n, uint8_t* bits) {
     const int64_t nb = (n + 7) >> 3;
@@ -363,51 +390,59 @@ static int launch_filter(FilterArgs& a, int mode, int64_t* out_count, hipStream_
     size_t sbytes = (size_t)(a.ntiles + ngroups + 8) * 8;
     unsigned long long* scratch = (unsigned long long*)pool_alloc(sbytes);
     if (!scratch) return 1;
-    VNM_HIP(hipMemsetAsync(scratch, 0, sbytes, s));
     a.ctl = scratch;
     a.status = scratch + 8;
     a.gstatus = scratch + 8 + a.ntiles;
     a.debug = env_int("VNM_FILTER_DEBUG", 0);
     a.lb_sleep = env_int("VNM_FILTER_SLEEP", 16);
-    // persistent workgroups, grid = what is co-resident; see filter_tile_kernel for the two tile hand-out schemes
-    // VNM_FILTER_PERSIST=0 (measurement only): one workgroup per tile, plain launch -- 5-8 % faster, but its
-    // forward progress relies on workgroups being dispatched in index order, which HIP does not promise
-    const bool persist = env_int("VNM_FILTER_PERSIST", 1) != 0;
-    auto launch = [&](auto kernel, int threads) -> int {
-        if (!persist) {
-            kernel<<<(int)a.ntiles, threads, 0, s>>>(a);
-            return 0;
-        }
-        int per_cu = 0;
-        VNM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0));
-        if (per_cu < 1) return set_error("filter: kernel does not fit a CU");
-        int64_t grid = (int64_t)per_cu * device_info().num_cus;
-        if (grid > a.ntiles) grid = a.ntiles;
-        void* params[] = {(void*)&a};
-        VNM_HIP(hipLaunchCooperativeKernel((const void*)kernel, dim3((int)grid), dim3(threads), params, 0, s));
-        return 0;
-    };
-    {
-    KernelTimer timer("filter_kernel", s);
-    int rc;
-    if (hot) {
-        if (fb == 1024 && (a.debug & 8)) rc = launch(filter_tile_kernel<CMP_F64, 1024, 4, true, true, false>, 1024);
-        else if (fb == 1024) rc = launch(filter_tile_kernel<CMP_F64, 1024, 4, true, false, false>, 1024);
-        else if (fb == 256) rc = launch(filter_tile_kernel<CMP_F64, 256, 16, true, false, false>, 256);
-        else rc = launch(filter_tile_kernel<CMP_F64, 512, 8, true, false, false>, 512);
-    } else if (hot_pred) {
-        rc = launch(filter_tile_kernel<CMP_F64, 512, 8, true, false, true>, 512);  // float64 predicate, several payload columns
-    } else if (mode == MODE_MASK) {
-        rc = launch(filter_tile_kernel<MODE_MASK, 512, 8, false, false, true>, 512);
-    } else {
-        rc = launch(filter_tile_kernel<CMP_I64, 512, 8, false, false, true>, 512);  // generic pred_eval path
-    }
-    if (rc) { pool_free(scratch); return rc; }
-    }
-    VNM_HIP(hipGetLastError());
+    // Two launch schemes (filter_tile_kernel / filter_tile_flat_kernel).  The plain one-workgroup-per-tile launch goes first;
+    // if one of its bounded look-backs gave up (ctl[5]) the filter is repeated with persistent workgroups launched
+    // cooperatively, which cannot wait on a workgroup that is not resident.  VNM_FILTER_PERSIST=1 skips the first attempt.
     unsigned long long total = 0;
-    VNM_HIP(hipMemcpyAsync(&total, scratch + 1, 8, hipMemcpyDeviceToHost, s));
-    VNM_HIP(hipStreamSynchronize(s));
+    for (int attempt = env_int("VNM_FILTER_PERSIST", 0) != 0 ? 1 : 0; attempt < 2; attempt++) {
+        const bool persist = attempt == 1;
+        a.spin_limit = persist ? 0 : env_int("VNM_FILTER_SPIN_LIMIT", 200000);   // ~0.5 us per poll
+        VNM_HIP(hipMemsetAsync(scratch, 0, sbytes, s));
+        auto launch = [&](auto kernel, auto flat_kernel, int threads) -> int {
+            if (!persist) {
+                flat_kernel<<<(int)a.ntiles, threads, 0, s>>>(a);
+                return 0;
+            }
+            int per_cu = 0;
+            VNM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0));
+            if (per_cu < 1) return set_error("filter: kernel does not fit a CU");
+            int64_t grid = (int64_t)per_cu * device_info().num_cus;
+            if (grid > a.ntiles) grid = a.ntiles;
+            void* params[] = {(void*)&a};
+            VNM_HIP(hipLaunchCooperativeKernel((const void*)kernel, dim3((int)grid), dim3(threads), params, 0, s));
+            return 0;
+        };
+#define VNM_FL(...) launch(filter_tile_kernel<__VA_ARGS__>, filter_tile_flat_kernel<__VA_ARGS__>,
+        {
+            KernelTimer timer("filter_kernel", s);
+            int rc;
+            if (hot) {
+                if (fb == 1024 && (a.debug & 8)) rc = VNM_FL(CMP_F64, 1024, 4, true, true, false) 1024);
+                else if (fb == 1024) rc = VNM_FL(CMP_F64, 1024, 4, true, false, false) 1024);
+                else if (fb == 256) rc = VNM_FL(CMP_F64, 256, 16, true, false, false) 256);
+                else rc = VNM_FL(CMP_F64, 512, 8, true, false, false) 512);
+            } else if (hot_pred) {
+                rc = VNM_FL(CMP_F64, 512, 8, true, false, true) 512);  // float64 predicate, several payload columns
+            } else if (mode == MODE_MASK) {
+                rc = VNM_FL(MODE_MASK, 512, 8, false, false, true) 512);
+            } else {
+                rc = VNM_FL(CMP_I64, 512, 8, false, false, true) 512);  // generic pred_eval path
+            }
+            if (rc) { pool_free(scratch); return rc; }
+        }
+#undef VNM_FL
+        VNM_HIP(hipGetLastError());
+        unsigned long long res[6] = {0, 0, 0, 0, 0, 0};
+        VNM_HIP(hipMemcpyAsync(res, scratch, sizeof(res), hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipStreamSynchronize(s));
+        total = res[1];
+        if (!res[5]) break;   // (a cooperative launch never sets it)
+    }
     if (a.debug & 8) {
         unsigned long long st[3] = {0, 0, 0};
         VNM_HIP(hipMemcpy(st, scratch + 2, 24, hipMemcpyDeviceToHost));

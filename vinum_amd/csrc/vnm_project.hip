@@ -519,7 +519,11 @@ static int project_impl(int n_ins, const vnm_expr_ins* program, int n_cols, cons
     a.n_ins = total;
     if (length <= 0) return 0;
     const size_t lds = (size_t)(depth > 1 ? depth - 1 : 1) * PJ_R * PJ_BLOCK * 8;
-    int grid = device_info().num_cus * 8;
+    // ONE workgroup per tile: a workgroup loads, computes and stores with nothing of its own to overlap, so it is the
+    // dispatcher that keeps the memory system busy (three expressions over 1e9 rows: 8 workgroups per CU looping over tiles
+    // 11.15 ms, 32 per CU 10.2, 128 per CU 9.7, one per tile 9.27 = 5.2 TB/s)
+    int64_t grid64 = getenv("VNM_PJ_GRID") ? (int64_t)device_info().num_cus * atoi(getenv("VNM_PJ_GRID")) : (int64_t)1 << 30;
+    int grid = (int)grid64;
     int64_t need = (length + PJ_TILE - 1) / PJ_TILE;
     if (grid > need) grid = (int)need;
     if (lds > 64 * 1024)   // depth >= 10: beyond the default dynamic LDS limit

@@ -611,8 +611,8 @@ __global__ void take_kernel(vnm_dcol c, const int64_t* idx, int64_t n, void* out
     }
 }
 
-static int grid_for(int64_t n) {
-    int g = device_info().num_cus * 8;
+static int grid_for(int64_t n, int per_cu = 8) {
+    int g = device_info().num_cus * per_cu;
     int64_t need = (n + 255) / 256;
     if (need < 1) need = 1;
     return g > need ? (int)need : g;
@@ -630,8 +630,8 @@ static int full_sort(int n_keys, const vnm_dcol* keys, const int* orders, int64_
         VNM_HIP(hipMemsetAsync(r->ghist, 0, (size_t)8 * 256 * 8, s));
         {
             KernelTimer timer("sort_encode", s);
-            sort_encode_kernel<<<grid_for(n), 256, 0, s>>>(keys[k], orders[k] == VNM_DESC, ident ? nullptr : r->val[r->cur], n, r->code[r->cur],
-                                                           nullptr, r->red + 4, r->ghist, 0);
+            sort_encode_kernel<<<grid_for(n, 64), 256, 0, s>>>(keys[k], orders[k] == VNM_DESC, ident ? nullptr : r->val[r->cur], n, r->code[r->cur],
+                                                               nullptr, r->red + 4, r->ghist, 0);   // 64 workgroups per CU: 3.3 ms per 1e9 keys (8: 3.55)
         }
         unsigned long long any_special = 0;
         const bool cls_possible = keys[k].validity != nullptr || type_is_float(keys[k].type);
@@ -641,8 +641,8 @@ static int full_sort(int n_keys, const vnm_dcol* keys, const int* orders, int64_
             VNM_HIP(hipMemsetAsync(r->ghist, 0, (size_t)8 * 256 * 8, s));
             {
                 KernelTimer timer("sort_encode", s);
-                sort_encode_kernel<<<grid_for(n), 256, 0, s>>>(keys[k], orders[k] == VNM_DESC, ident ? nullptr : r->val[r->cur], n,
-                                                               r->code[r->cur], nullptr, nullptr, r->ghist, 1);
+                sort_encode_kernel<<<grid_for(n, 64), 256, 0, s>>>(keys[k], orders[k] == VNM_DESC, ident ? nullptr : r->val[r->cur], n,
+                                                                   r->code[r->cur], nullptr, nullptr, r->ghist, 1);
             }
             VNM_TRY(radix_sort_codes(r, n, s, nullptr, k == 0 ? idx_out : nullptr, false, wrote_idx, true, &ident));
         }
