@@ -32,7 +32,16 @@ _NP = {I8: np.int8, I16: np.int16, I32: np.int32, I64: np.int64, U8: np.uint8, U
 
 
 def build(force=False):
-    """gcc -O2 -shared oracle/vinum_oracle.c -> oracle/_build/libvinum_oracle.so"""
+    """gcc -O2 -shared oracle/vinum_oracle.c -> oracle/_build/libvinum_oracle.so
+    VNM_ORACLE_SANITIZE=1 (tests/test_oracle_golden.py::test_oracle_under_asan_ubsan): an -O1 -fsanitize=address,undefined
+    build in its own file; the process must have libasan preloaded."""
+    if os.environ.get("VNM_ORACLE_SANITIZE") == "1":
+        so = os.path.join(_HERE, "_build", "libvinum_oracle_asan.so")
+        if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(_SRC):
+            os.makedirs(os.path.dirname(so), exist_ok=True)
+            subprocess.check_call(["gcc", "-O1", "-g", "-std=gnu11", "-fPIC", "-shared", "-fsanitize=address,undefined",
+                                   "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-o", so, _SRC, "-lm"])
+        return so
     if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= os.path.getmtime(_SRC):
         return _SO
     os.makedirs(os.path.dirname(_SO), exist_ok=True)

@@ -5,6 +5,8 @@
 (3) when oracle/_ref is present (build container), live comparison against the real reference.
 All comparisons are bit-exact (the oracle follows the reference's evaluation order).
 """
+import os
+
 import numpy as np
 import pyarrow as pa
 import pytest
@@ -119,3 +121,24 @@ def test_oracle_float_sum_order_and_minmax_rule_match_the_reference():
         for b in util.sliced_batches(table, chunk):
             o.next(b)
         util.assert_batches_equal(o.result(), util.read_ipc(out), key_names=["k"], what=out)
+
+
+def test_oracle_under_asan_ubsan():
+    """The C restatement (oracle/vinum_oracle.c) under AddressSanitizer + UndefinedBehaviorSanitizer: the golden aggregate,
+    sort and filter cases and the gtest known answers are replayed in a child process that preloads libasan and loads an
+    instrumented build of the oracle.  A heap overflow, use after free or signed overflow in the oracle would make every
+    parity test built on it meaningless."""
+    import subprocess
+    import sys
+    libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("gcc has no libasan here")
+    env = dict(os.environ, VNM_ORACLE_SANITIZE="1", LD_PRELOAD=libasan,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.abspath(__file__),
+                        "-k", "gtest_known_answers or reference_golden or emit_null"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert "passed" in r.stdout and "ERROR: AddressSanitizer" not in tail and "runtime error" not in tail, tail
