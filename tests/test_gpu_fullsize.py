@@ -136,6 +136,62 @@ def test_groupby_1e9_rows(groups, hint):
     _free()
 
 
+@pytest.mark.parametrize("groups", [1_000, 100_000, 100_000_000], ids=["G1e3", "G1e5", "G1e8"])
+def test_generic_programs_1e9_rows(groups):
+    """The generic dense paths at full size (whole-table LDS scan, split final pass, two scatter levels):
+    SELECT k, count(*) GROUP BY k and SELECT k, min(v), max(v), count(*) WHERE v > X GROUP BY k over 1e9 rows, finalised on
+    the device and compared with torch.bincount / scatter_reduce for EVERY group."""
+    torch = _torch()
+    import bench
+    from vinum_amd import _lib as L
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    n = N_FULL
+    k, v = _gen(n, groups)
+    kc, vc = DeviceColumn.from_torch(k), DeviceColumn.from_torch(v)
+    # ---- count(*): the entries are bare key codes
+    agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.COUNT_STAR, None, None)])
+    agg.next([kc], [None], nrows=n)
+    ng = agg.finish()
+    cols = agg.result_device()
+    fk = _as_tensor(cols[0].values_ptr, ng)
+    fc = _as_tensor(cols[1].values_ptr, ng)
+    ref = torch.bincount(k, minlength=groups)
+    assert ng == int((ref > 0).sum())
+    assert int(fc.sum()) == n
+    assert bool(torch.equal(ref[fk], fc)), "count(*) differs from torch.bincount for some group"
+    assert torch.unique(fk).numel() == ng
+    agg.close()
+    del ref, fk, fc, cols
+    _free()
+    # ---- min, max, count(*) with the predicate on the value column
+    x = bench.threshold_for(0.5)
+    agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.MIN, 1, pa.float64()), (L.MAX, 1, pa.float64()), (L.COUNT_STAR, None, None)])
+    agg.set_predicate(">", x)
+    agg.next([kc], [vc, vc, None], pred=vc, nrows=n)
+    ng = agg.finish()
+    cols = agg.result_device()
+    fk = _as_tensor(cols[0].values_ptr, ng)
+    fmin = _as_tensor(cols[1].values_ptr, ng, "<f8")
+    fmax = _as_tensor(cols[2].values_ptr, ng, "<f8")
+    fc = _as_tensor(cols[3].values_ptr, ng)
+    keep = v > x
+    ks, vs = k[keep], v[keep]
+    del keep
+    rc = torch.bincount(ks, minlength=groups)
+    assert ng == int((rc > 0).sum())
+    assert bool(torch.equal(rc[fk], fc))
+    del rc
+    rmin = torch.full((groups,), float("inf"), dtype=torch.float64, device=k.device).scatter_reduce_(0, ks, vs, "amin")
+    assert bool(torch.equal(rmin[fk], fmin)), "min(v) differs from scatter_reduce(amin) for some group"
+    del rmin
+    rmax = torch.full((groups,), float("-inf"), dtype=torch.float64, device=k.device).scatter_reduce_(0, ks, vs, "amax")
+    assert bool(torch.equal(rmax[fk], fmax)), "max(v) differs from scatter_reduce(amax) for some group"
+    agg.close()
+    del k, v, ks, vs, rmax
+    _free()
+
+
 def test_filter_1e9_rows():
     """BASELINE configs[1] at full size: WHERE v > X -> compacted column; order preserving, so the output must EQUAL
     torch's boolean indexing."""
