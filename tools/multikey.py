@@ -1,4 +1,5 @@
-"""Multi-column GROUP BY (MultiNumericalHashAggregate shape) timing: SELECT k1,k2,sum(v),count(*) GROUP BY k1,k2."""
+"""Multi-column GROUP BY (MultiNumericalHashAggregate shape) timing: SELECT k1,k2,sum(v),count(*) GROUP BY k1,k2.
+usage: multikey.py N G1 G2 [wide]"""
 import sys, time
 sys.path.insert(0, ".")
 import torch, pyarrow as pa
@@ -11,6 +12,9 @@ dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(1)
 k1 = torch.randint(0, g1, (n,), device=dev, dtype=torch.int64, generator=g)
 k2 = torch.randint(0, g2, (n,), device=dev, dtype=torch.int64, generator=g)
+if len(sys.argv) > 4 and sys.argv[4] == "wide":      # ranges whose product does not fit 63 bits: the wide-key table
+    k1 = k1 * (1 << 44) - (1 << 61)
+    k2 = k2 * (1 << 40) + 12345
 v = torch.randint(0, 2**14, (n,), device=dev, dtype=torch.int64, generator=g).to(torch.float64) / 128.0
 c1, c2, cv = DeviceColumn.from_torch(k1), DeviceColumn.from_torch(k2), DeviceColumn.from_torch(v)
 for rep in range(3):
