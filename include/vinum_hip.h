@@ -256,6 +256,11 @@ void vnm_agg_op_destroy(vnm_agg_op* h);
 int vnm_sort_indices(int n_keys, const vnm_dcol* keys, const int* orders, int64_t length,
                      int64_t limit /* <=0: full sort; >0: only the first `limit` rows are needed */,
                      int64_t* out_indices /* device, length entries (first `limit` valid) */, void* stream);
+/* The same, and -- for a full sort whose first key is int64 / uint64 / float64 without NULL, NaN or -0.0 -- the sorted
+ * values of that key straight from the sort (out_sorted_key0: device, length x 8 bytes; *wrote_key0 = 1), which saves
+ * the caller the gather (vnm_take: 25 ms per 1e9 rows) for that column.  *wrote_key0 = 0: gather as usual. */
+int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, int64_t length, int64_t limit,
+                           int64_t* out_indices, void* out_sorted_key0, int* wrote_key0, void* stream);
 int vnm_take(const vnm_dcol* col, const int64_t* indices, int64_t n, void* out_values, uint8_t* out_valid,
              void* stream);
 typedef struct vnm_sort_op vnm_sort_op;

@@ -16,10 +16,17 @@ def gpu_sort(table: pa.Table, cols, orders, limit=0) -> pa.RecordBatch:
     from vinum_amd import ops
     t = table.combine_chunks()
     dev = {n: DeviceColumn.from_arrow(t.column(n)) for n in t.schema.names}
-    idx = ops.sort_indices([dev[c] for c in cols], orders, limit=limit)
     n = limit if limit else t.num_rows
-    return pa.RecordBatch.from_arrays([ops.take(dev[name], idx, n).to_arrow() for name in t.schema.names],
-                                      names=t.schema.names)
+    sorted_key = None
+    if limit:
+        idx = ops.sort_indices([dev[c] for c in cols], orders, limit=limit)
+    else:
+        # the full sort may hand its first key back already sorted (vnm_sort_indices_keyed): it must then be what the gather gives
+        idx, sorted_key = ops.sort_indices_keyed([dev[c] for c in cols], orders)
+        if sorted_key is not None:
+            util.assert_col_equal(sorted_key.to_arrow(), ops.take(dev[cols[0]], idx, n).to_arrow(), f"sorted key {cols[0]} vs gather")
+    return pa.RecordBatch.from_arrays([(sorted_key if (sorted_key is not None and name == cols[0]) else ops.take(dev[name], idx, n)).to_arrow()
+                                       for name in t.schema.names], names=t.schema.names)
 
 
 @pytest.mark.parametrize("case", MAN["sort"], ids=lambda c: c["name"])
@@ -371,3 +378,46 @@ def test_out_of_range_literal_true_division_vs_numpy():
     for e in [("add", "u64", -60), ("mod", "i8", 300), ("mul", -1, "u8"), ("sub", 300, "i8")]:
         with pytest.raises(Exception, match="out of bounds"):
             ops.project_many([e], dev, length=3)
+
+
+@pytest.mark.parametrize("kind", ["f64", "i64_desc", "u64", "negzero", "nan", "null", "i32", "two_keys"])
+def test_full_sort_returns_its_first_key_sorted(kind):
+    """vnm_sort_indices_keyed: for an 8-byte first key without NULL / NaN / -0.0 the sorted key column comes out of the last radix
+    pass (rebuilt from the codes) and must equal the gather bit for bit; with a NaN, a NULL, a -0.0 (whose code is that of +0.0)
+    or a narrower key the sort declines and the caller gathers."""
+    from vinum_amd.device import DeviceColumn
+    from vinum_amd import ops
+    rng = np.random.default_rng(len(kind))
+    n = 300_001
+    order = 1 if kind == "i64_desc" else 0
+    mask = None
+    if kind in ("f64", "negzero", "nan", "null", "two_keys"):
+        v = np.round(rng.normal(0, 50, n), 2)
+        v[v == 0] = 0.0
+        if kind == "negzero":
+            v[17] = -0.0
+        if kind == "nan":
+            v[23] = np.nan
+        if kind == "null":
+            mask = np.zeros(n, bool); mask[5] = True
+    elif kind == "u64":
+        v = rng.integers(0, 2**63, n).astype(np.uint64) * np.uint64(2) + np.uint64(1)
+    elif kind == "i32":
+        v = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+    else:
+        v = rng.integers(-2**62, 2**62, n).astype(np.int64)
+    arr = pa.array(v, mask=mask)
+    keys = [DeviceColumn.from_arrow(arr)]
+    orders = [order]
+    if kind == "two_keys":
+        keys.append(DeviceColumn.from_arrow(pa.array(rng.integers(0, 5, n).astype(np.int64))))
+        orders.append(1)
+    idx, sk = ops.sort_indices_keyed(keys, orders)
+    gathered = ops.take(keys[0], idx, n).to_arrow()
+    if kind in ("negzero", "nan", "null", "i32"):
+        assert sk is None
+    else:
+        assert sk is not None
+        util.assert_col_equal(sk.to_arrow(), gathered, kind)
+        got = sk.to_numpy()
+        assert (np.diff(got.astype(np.float64)) <= 0).all() if order else (np.diff(got.astype(np.float64)) >= 0).all()

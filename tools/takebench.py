@@ -20,3 +20,10 @@ for rep in range(3):
     torch.cuda.synchronize(); t3 = time.perf_counter()
     print(f"rep {rep}: sort {1e3*(t1-t0):.1f} ms, take(v) {1e3*(t2-t1):.1f} ms, take(a) {1e3*(t3-t2):.1f} ms")
     del idx, sv, sa
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    idx, sk = ops.sort_indices_keyed([cv], [L.DESC])       # the sorted key comes out of the last radix pass: no gather for it
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    sa = ops.take(ca, idx, n)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"rep {rep}: keyed sort {1e3*(t1-t0):.1f} ms (sorted key returned: {sk is not None}), take(a) {1e3*(t2-t1):.1f} ms")
+    del idx, sk, sa

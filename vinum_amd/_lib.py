@@ -86,6 +86,7 @@ PROTOTYPES = {
     "vnm_agg_op_result": (c_int, [c_void, c_void, c_void]),
     "vnm_agg_op_destroy": (None, [c_void]),
     "vnm_sort_indices": (c_int, [c_int, c_void, c_void, c_i64, c_i64, c_void, c_void]),
+    "vnm_sort_indices_keyed": (c_int, [c_int, c_void, c_void, c_i64, c_i64, c_void, c_void, c_void, c_void]),
     "vnm_take": (c_int, [c_void, c_void, c_i64, c_void, c_void, c_void]),
     "vnm_sort_op_create": (c_void, [c_int, c_void, c_void]),
     "vnm_sort_op_next": (c_int, [c_void, c_void, c_void]),

@@ -137,9 +137,14 @@ class SortOperator(Operator):
             [pa.array([], f.type) for f in table.schema], names=table.schema.names), dicts).columns
         n = table.num_rows
         k = self._limit if 0 < self._limit < n else 0
-        idx = ops.sort_indices([dev[c] for c in self._cols], self._orders, limit=k)
         m = k if k else n
-        yield DeviceRecordBatch({name: ops.take(col, idx, m) for name, col in dev.items()}, m)
+        sorted_key = None
+        if k:
+            idx = ops.sort_indices([dev[c] for c in self._cols], self._orders, limit=k)
+        else:   # a full sort hands its first key back sorted: one gather less
+            idx, sorted_key = ops.sort_indices_keyed([dev[c] for c in self._cols], self._orders)
+        yield DeviceRecordBatch({name: sorted_key if (sorted_key is not None and name == self._cols[0]) else ops.take(col, idx, m)
+                                 for name, col in dev.items()}, m)
 
 
 class SliceOperator(Operator):

@@ -26,12 +26,14 @@ namespace vnm {
 
 
 // ---- key encoding ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void encode_key(const vnm_dcol& c, int64_t row, int desc, uint64_t* code, uint32_t* cls) {
+// negzero (optional): set when the row holds -0.0 (its code is that of +0.0, so the value cannot be rebuilt from the code)
+__device__ __forceinline__ void encode_key(const vnm_dcol& c, int64_t row, int desc, uint64_t* code, uint32_t* cls, bool* negzero = nullptr) {
     if (!col_valid(c, row)) { *code = 0; *cls = 2; return; }
     uint64_t e;
     if (type_is_float(c.type)) {
         double d = col_f64(c, row);
         if (d != d) { *code = 0; *cls = 1; return; }
+        if (negzero && d == 0.0 && __double_as_longlong(d) != 0) *negzero = true;
         if (d == 0.0) d = 0.0;  // -0.0 and +0.0 compare equal in Arrow's sort: ties keep row order
         e = enc_f64(d);
     } else if (type_is_unsigned(c.type)) {
@@ -57,7 +59,8 @@ __device__ __forceinline__ void hist8_wave(uint32_t* h, uint64_t c, int lane) {
 
 // code[i] (and cls[i] when cls != NULL) for row idx[i] (idx == NULL: identity); class_codes: code[i] = the row's class
 // (0 value, 1 NaN, 2 NULL) instead -- the input of the class pass
-// any_cls (optional): set to 1 when some row is NaN or NULL (class != 0) -- lets the caller skip the class pass
+// any_cls (optional): bit 0 set when some row is NaN or NULL (class != 0) -- lets the caller skip the class pass; bit 1 when some
+// row is -0.0
 // ghist (optional): the eight digit histograms of the codes are accumulated on the way (radix_sort_codes then needs no
 // histogram pass of its own: one read of the codes less)
 __global__ __launch_bounds__(256) void sort_encode_kernel(vnm_dcol c, int desc, const uint32_t* idx, int64_t n, uint64_t* code, uint8_t* cls,
@@ -70,10 +73,10 @@ __global__ __launch_bounds__(256) void sort_encode_kernel(vnm_dcol c, int desc, 
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t nfull = n & ~63LL;
-    bool special = false;
+    bool special = false, negz = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         uint64_t e; uint32_t k;
-        encode_key(c, idx ? (int64_t)idx[i] : i, desc, &e, &k);
+        encode_key(c, idx ? (int64_t)idx[i] : i, desc, &e, &k, &negz);
         if (class_codes) e = k;
         code[i] = e;
         if (cls) cls[i] = (uint8_t)k;
@@ -87,6 +90,7 @@ __global__ __launch_bounds__(256) void sort_encode_kernel(vnm_dcol c, int desc, 
         }
     }
     if (any_cls && __ballot(special) && lane == 0) atomicOr(any_cls, 1ULL);
+    if (any_cls && __ballot(negz) && lane == 0) atomicOr(any_cls, 2ULL);   // bit 1: a -0.0 (the codes do not carry its sign)
     if (ghist) {
         __syncthreads();
         for (int i = threadIdx.x; i < 8 * 256; i += 256)
@@ -167,6 +171,8 @@ struct OsArgs {
     uint64_t* code_out;
     uint32_t* val_out;
     int64_t* idx_out;                 // last pass of the last key: row ids widened to int64 straight into the caller's buffer
+    uint64_t* key_out;                // ... and (optional) the sorted values of key 0 rebuilt from their codes: saves the caller a gather
+    int key_type, key_desc;
 };
 
 // Tile shapes tried on 1e9 fp64 keys (ms per pass): 512 x 16 (this one) 6.1; 1024 threads x 8 9.4 (spills at 64 VGPRs);
@@ -279,6 +285,11 @@ __global__ __launch_bounds__(OS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
                 const uint64_t cc = stage[i];
                 dg = (uint32_t)(cc >> a.shift) & 255u;
                 if (a.code_out) a.code_out[run[dg] + (i - off[dg])] = cc;
+                if (a.key_out) {
+                    const uint64_t e = a.key_desc ? ~cc : cc;
+                    a.key_out[run[dg] + (i - off[dg])] = a.key_type == VNM_F64 ? (uint64_t)__double_as_longlong(dec_f64(e))
+                                                       : (a.key_type == VNM_I64 ? (uint64_t)dec_i64(e) : e);
+                }
             }
             if ((j & 3) == 0) dgs[j >> 2] = dg; else dgs[j >> 2] |= dg << (8 * (j & 3));
         }
@@ -336,8 +347,12 @@ static void radix_free(RadixBufs* r) {
 // code output; *wrote_idx tells the caller.
 // hist_ready: r->ghist already holds the digit histograms of the codes (sort_encode_kernel accumulated them)
 // ident (optional, in/out): the row ids r->val[r->cur] are the identity and NOT materialised; the first executed pass makes them up
+// key_out / key_type / key_desc / wrote_key (optional): see OsArgs::key_out; only together with idx_out, and only when the flag
+// word says the key holds no NaN / NULL / -0.0
 static int radix_sort_codes(RadixBufs* r, int64_t n, hipStream_t s, unsigned long long* extra = nullptr, int64_t* idx_out = nullptr,
-                            bool cls_possible = false, bool* wrote_idx = nullptr, bool hist_ready = false, bool* ident = nullptr) {
+                            bool cls_possible = false, bool* wrote_idx = nullptr, bool hist_ready = false, bool* ident = nullptr,
+                            uint64_t* key_out = nullptr, int key_type = 0, int key_desc = 0, bool* wrote_key = nullptr) {
+    if (wrote_key) *wrote_key = false;
     if (wrote_idx) *wrote_idx = false;
     if (n <= 1) { if (extra) { VNM_HIP(hipMemcpyAsync(extra, r->red + 4, 8, hipMemcpyDeviceToHost, s)); VNM_HIP(hipStreamSynchronize(s)); } return 0; }
     static bool attr_set = false;
@@ -365,7 +380,7 @@ static int radix_sort_codes(RadixBufs* r, int64_t n, hipStream_t s, unsigned lon
     VNM_HIP(hipMemcpyAsync(hist + 8 * 256, r->red + 4, 8, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
     if (extra) *extra = hist[8 * 256];
-    const bool cls_follows = cls_possible && hist[8 * 256] != 0;
+    const bool cls_follows = cls_possible && (hist[8 * 256] & 1ULL) != 0;
     int live[8], n_live = 0;
     for (int byte = 0; byte < 8; byte++) {
         bool constant = false;      // one digit value holds every element: nothing to reorder
@@ -386,6 +401,10 @@ static int radix_sort_codes(RadixBufs* r, int64_t n, hipStream_t s, unsigned lon
         if (idx_out && !cls_follows && k == n_live - 1) {
             a.idx_out = idx_out; a.code_out = nullptr;
             if (wrote_idx) *wrote_idx = true;
+            if (key_out && hist[8 * 256] == 0) {
+                a.key_out = key_out; a.key_type = key_type; a.key_desc = key_desc;
+                if (wrote_key) *wrote_key = true;
+            }
         }
 onesweep_kernel<<<g, OS_BLOCK, OS_LDS_BYTES, s>>>(a);
         r->cur ^= 1;
@@ -620,9 +639,13 @@ static int grid_for(int64_t n, int per_cu = 8) {
 
 // full stable multi-key sort; result: row ids (uint32) in r->val[r->cur]
 // idx_out (optional): int64 output buffer; *wrote_idx = the last radix pass wrote it (else the caller widens r->val[r->cur])
+// key_out (optional, with idx_out): the sorted values of key 0 (8-byte types, no NaN / NULL / -0.0 in it): *wrote_key
 static int full_sort(int n_keys, const vnm_dcol* keys, const int* orders, int64_t n, RadixBufs* r, hipStream_t s,
-                     int64_t* idx_out = nullptr, bool* wrote_idx = nullptr) {
+                     int64_t* idx_out = nullptr, bool* wrote_idx = nullptr, uint64_t* key_out = nullptr, bool* wrote_key = nullptr) {
     if (wrote_idx) *wrote_idx = false;
+    if (wrote_key) *wrote_key = false;
+    const int kt0 = keys[0].type;
+    if (!(kt0 == VNM_F64 || kt0 == VNM_I64 || kt0 == VNM_U64)) key_out = nullptr;
     bool ident = true;   // no pass has run yet: the row ids are the identity and are not materialised (the first pass makes them up)
     for (int k = n_keys - 1; k >= 0; k--) {
         // codes of key k in the current row order; their eight digit histograms come out of the same kernel
@@ -635,9 +658,10 @@ static int full_sort(int n_keys, const vnm_dcol* keys, const int* orders, int64_
         }
         unsigned long long any_special = 0;
         const bool cls_possible = keys[k].validity != nullptr || type_is_float(keys[k].type);
-        VNM_TRY(radix_sort_codes(r, n, s, &any_special, k == 0 ? idx_out : nullptr, cls_possible, wrote_idx, true, &ident));
+        VNM_TRY(radix_sort_codes(r, n, s, &any_special, k == 0 ? idx_out : nullptr, cls_possible, wrote_idx, true, &ident,
+                                 k == 0 ? key_out : nullptr, kt0, orders[0] == VNM_DESC, wrote_key));
         // class pass (values < NaN < NULL), more significant than the code, over the classes in the CURRENT order
-        if (cls_possible && any_special != 0) {   // no NaN / NULL at all: nothing to do
+        if (cls_possible && (any_special & 1ULL) != 0) {   // no NaN / NULL at all: nothing to do
             VNM_HIP(hipMemsetAsync(r->ghist, 0, (size_t)8 * 256 * 8, s));
             {
                 KernelTimer timer("sort_encode", s);
@@ -660,6 +684,12 @@ extern "C" {
 
 int vnm_sort_indices(int n_keys, const vnm_dcol* keys, const int* orders, int64_t length, int64_t limit,
                      int64_t* out_indices, void* stream) {
+    return vnm_sort_indices_keyed(n_keys, keys, orders, length, limit, out_indices, nullptr, nullptr, stream);
+}
+
+int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, int64_t length, int64_t limit,
+                           int64_t* out_indices, void* out_sorted_key0, int* wrote_key0, void* stream) {
+    if (wrote_key0) *wrote_key0 = 0;
     VNM_TRY(ensure_init());
     if (n_keys < 1 || n_keys > 16) return set_error("vnm_sort_indices: 1..16 sort keys");
     if (length >= (1LL << 32)) return set_error("vnm_sort_indices: at most 2^32 - 1 rows per sort");
@@ -803,8 +833,9 @@ int vnm_sort_indices(int n_keys, const vnm_dcol* keys, const int* orders, int64_
 
     RadixBufs r{};
     VNM_TRY(radix_alloc(&r, n));
-    bool wrote = false;
-    int rc = full_sort(n_keys, keys, orders, n, &r, s, out_indices, &wrote);
+    bool wrote = false, wrote_key = false;
+    int rc = full_sort(n_keys, keys, orders, n, &r, s, out_indices, &wrote, (uint64_t*)out_sorted_key0, &wrote_key);
+    if (!rc && wrote_key0) *wrote_key0 = wrote_key ? 1 : 0;
     if (!rc) {
         if (!wrote) sort_widen_kernel<<<grid_for(n), 256, 0, s>>>(r.val[r.cur], n, out_indices);
         if (hipGetLastError() != hipSuccess) rc = set_error("vnm_sort_indices: kernel launch failed");

@@ -336,6 +336,22 @@ def sort_indices(keys, orders, limit=0, stream=None) -> DeviceBuffer:
     return out
 
 
+def sort_indices_keyed(keys, orders, stream=None):
+    """Full sort that also hands back the SORTED FIRST KEY when the sort can rebuild it from its codes (int64 / uint64 /
+    float64 without NULL, NaN or -0.0): (row ids, DeviceColumn or None).  The caller then gathers (`take`) only the other
+    columns -- a gather is 25 ms per 1e9 rows and column, half of what the sort itself costs."""
+    n = keys[0].length
+    out = DeviceBuffer(max(n, 1) * 8)
+    keybuf = DeviceBuffer(max(n, 1) * 8)
+    wrote = ctypes.c_int(0)
+    od = (ctypes.c_int * len(orders))(*orders)
+    L.check(L.lib().vnm_sort_indices_keyed(len(keys), dcol_array(keys), od, n, 0, out.ptr, keybuf.ptr, ctypes.byref(wrote),
+                                           _stream_ptr(stream)))
+    if not wrote.value:
+        return out, None
+    return out, keys[0].like(keybuf, None, 0, n)
+
+
 def take(col: DeviceColumn, indices: DeviceBuffer, n, stream=None) -> DeviceColumn:
     """compute::Take for one column (sort.cpp:40)."""
     lib = L.lib()
