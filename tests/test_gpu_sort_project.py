@@ -421,3 +421,35 @@ def test_full_sort_returns_its_first_key_sorted(kind):
         util.assert_col_equal(sk.to_arrow(), gathered, kind)
         got = sk.to_numpy()
         assert (np.diff(got.astype(np.float64)) <= 0).all() if order else (np.diff(got.astype(np.float64)) >= 0).all()
+
+
+@pytest.mark.parametrize("shape", ["distinct_first_key", "ties_on_first_key", "few_values_first_key", "specials"])
+@pytest.mark.parametrize("k", [10, 3000])
+def test_topk_multi_key_equals_full_sort_prefix(shape, k):
+    """ORDER BY a [DESC], b, c LIMIT K: candidates are selected on the first key alone (everything that beats the threshold, ties
+    included) and only they are sorted by all keys; the first K rows must be those of the stable full sort (the oracle), also when
+    the first key ties heavily (the candidate set outgrows its buffer and the full sort takes over) or holds NaN / NULL."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(len(shape) * 7 + k)
+    n = 1_200_000
+    if shape == "distinct_first_key":
+        a = rng.permutation(n).astype(np.float64)
+    elif shape == "ties_on_first_key":
+        a = np.round(rng.normal(0, 1000, n), 0)            # ~6000 distinct values: ties of ~200 rows each
+    elif shape == "few_values_first_key":
+        a = rng.integers(0, 4, n).astype(np.float64)       # every row ties: the fast path must hand over
+    else:
+        a = np.round(rng.normal(0, 1000, n), 0)
+        a[rng.random(n) < 0.002] = np.nan
+    mask = (rng.random(n) < 0.002) if shape == "specials" else None
+    b = rng.integers(-50, 50, n).astype(np.int64)
+    c = rng.integers(0, 2**31, n).astype(np.int32)
+    t = pa.table({"rowid": pa.array(np.arange(n, dtype=np.int64)), "a": pa.array(a, mask=mask),
+                  "b": pa.array(b, mask=(rng.random(n) < 0.01) if shape == "specials" else None), "c": pa.array(c)})
+    for orders in ([1, 0, 1], [0, 1, 0]):
+        got = gpu_sort(t, ["a", "b", "c"], orders, limit=k)
+        s = O.OracleSort(["a", "b", "c"], orders)
+        for bt in t.to_batches():
+            s.next(bt)
+        exp = s.sorted().slice(0, k)
+        util.assert_batches_equal(got, exp, what=f"multi-key topk {shape} k={k} orders={orders}")

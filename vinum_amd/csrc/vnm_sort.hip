@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <vector>
 
 #include "vnm_common.hpp"
 
@@ -605,6 +606,10 @@ __global__ void gather_u64_kernel(const uint64_t* src, const uint32_t* idx, int6
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = src[idx[i]];
 }
+__global__ void gather_i64_kernel(const int64_t* src, const int64_t* idx, int64_t n, int64_t* out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = src[idx[i]];
+}
 __global__ void gather_u32_kernel(const uint32_t* src, const uint32_t* idx, int64_t n, uint32_t* out) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = src[idx[i]];
@@ -700,7 +705,11 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
     const int64_t n = length;
 
     // ---- LIMIT K fast path: one scan selects the candidates ----
-    const bool try_topk = limit > 0 && n_keys == 1 && limit * 8 < n && n >= (1 << 16) && getenv("VNM_SORT_NO_TOPK") == nullptr;
+    // Several sort keys: the same selection on the FIRST key -- every row that beats the threshold on key 0, ties included, is a
+    // candidate (a row that loses on key 0 loses whatever its other keys are) -- and the candidates alone go through the full
+    // multi-key sort.
+    const bool try_topk = limit > 0 && limit * 8 < n && n >= (1 << 16) && getenv("VNM_SORT_NO_TOPK") == nullptr &&
+                          (n_keys == 1 || getenv("VNM_SORT_NO_TOPK_MULTI") == nullptr);
     if (try_topk) {
         const int desc = orders[0] == VNM_DESC;
         static bool ts_attr = false;
@@ -785,7 +794,48 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
             VNM_HIP(hipStreamSynchronize(s));
             int rc2 = 0;
             bool done = false;
-            if ((int64_t)found >= limit && (int64_t)found <= TS_MAX && getenv("VNM_SORT_NO_SMALL") == nullptr) {
+            if (n_keys > 1) {
+                if ((int64_t)found >= limit && (int64_t)found <= cap) {
+                    const int64_t c = (int64_t)found;
+                    PoolScope pool;
+                    // the candidates in ROW order (the multi-key sort below is stable over it)
+                    u32_to_code_kernel<<<grid_for(c), 256, 0, s>>>(crows, c, cr.code[0]);
+                    sort_iota_kernel<<<grid_for(c), 256, 0, s>>>(cr.val[0], c);
+                    cr.cur = 0;
+                    rc2 = radix_sort_codes(&cr, c, s);
+                    int64_t* rows64 = (int64_t*)pool.take((size_t)c * 8);
+                    int64_t* perm = (int64_t*)pool.take((size_t)c * 8);
+                    if (!rc2 && (!rows64 || !perm)) rc2 = 1;
+                    if (!rc2) VNM_HIP(hipMemcpyAsync(rows64, cr.code[cr.cur], (size_t)c * 8, hipMemcpyDeviceToDevice, s));   // the codes ARE the row ids
+                    // their key columns, gathered
+                    std::vector<vnm_dcol> sub((size_t)n_keys);
+                    for (int j = 0; j < n_keys && !rc2; j++) {
+                        const int w = type_width(keys[j].type);
+                        void* dv = pool.take((size_t)c * w);
+                        uint8_t* db = keys[j].validity ? (uint8_t*)pool.take((size_t)c) : nullptr;
+                        uint8_t* bm = keys[j].validity ? (uint8_t*)pool.take((size_t)(c + 7) / 8 + 8) : nullptr;
+                        if (!dv || (keys[j].validity && (!db || !bm))) { rc2 = 1; break; }
+                        take_kernel<<<grid_for(c), 256, 0, s>>>(keys[j], rows64, c, dv, db);
+                        if (bm) rc2 = vnm_pack_validity(db, c, bm, (void*)s);
+                        sub[j] = keys[j];
+                        sub[j].values = dv; sub[j].validity = bm; sub[j].offset = 0; sub[j].length = c;
+                    }
+                    if (!rc2) {
+                        RadixBufs r2{};
+                        rc2 = radix_alloc(&r2, c);
+                        bool wrote = false;
+                        if (!rc2) rc2 = full_sort(n_keys, sub.data(), orders, c, &r2, s, perm, &wrote);
+                        if (!rc2 && !wrote) sort_widen_kernel<<<grid_for(c), 256, 0, s>>>(r2.val[r2.cur], c, perm);
+                        if (!rc2) {
+                            gather_i64_kernel<<<grid_for(limit), 256, 0, s>>>(rows64, perm, limit, out_indices);
+                            VNM_HIP(hipGetLastError());
+                            VNM_HIP(hipStreamSynchronize(s));
+                            done = true;
+                        }
+                        radix_free(&r2);
+                    }
+                }
+            } else if ((int64_t)found >= limit && (int64_t)found <= TS_MAX && getenv("VNM_SORT_NO_SMALL") == nullptr) {
                 // few candidates: one workgroup sorts them in LDS and writes the first K row ids
                 const int c = (int)found;
                 int np2 = 64;
