@@ -321,7 +321,9 @@ struct RadixBufs {
     unsigned long long* status;       // [ntiles][256] chained-scan status words
     int cur = 0;
     int64_t ntiles = 0;
+    ~RadixBufs();   // gives the blocks back (early returns included)
 };
+static void radix_free(RadixBufs* r);
 
 static int radix_alloc(RadixBufs* r, int64_t n) {
     r->ntiles = (n + OS_TILE - 1) / OS_TILE;
@@ -335,10 +337,12 @@ static int radix_alloc(RadixBufs* r, int64_t n) {
     r->status = (unsigned long long*)pool_alloc((size_t)(r->ntiles ? r->ntiles : 1) * 256 * 8);
     return (r->red && r->ghist && r->status) ? 0 : 1;
 }
-static void radix_free(RadixBufs* r) {
-    for (int k = 0; k < 2; k++) { pool_free(r->code[k]); pool_free(r->val[k]); }
+static void radix_free(RadixBufs* r) {   // idempotent: ~RadixBufs calls it again on every way out of a scope
+    for (int k = 0; k < 2; k++) { pool_free(r->code[k]); pool_free(r->val[k]); r->code[k] = nullptr; r->val[k] = nullptr; }
     pool_free(r->red); pool_free(r->ghist); pool_free(r->status);
+    r->red = nullptr; r->ghist = nullptr; r->status = nullptr;
 }
+RadixBufs::~RadixBufs() { radix_free(this); }
 
 // sort (code[cur], val[cur]) stably by the bytes of code that are not constant
 // extra (optional): receives r->red[4], a flag word the caller's previous kernel may have set (read back with the
@@ -727,9 +731,10 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
         uint64_t t_code = 0;
         if (ok && rnk < TB_BLOCKS / 4 && m >= TB_BLOCKS * 64) {
             // small ranks: the rnk-th best of the 4096 block winners (one scan of the sample, one workgroup sort)
-            uint64_t* bcode = (uint64_t*)pool_alloc(TB_BLOCKS * 8);
-            uint8_t* bcls = (uint8_t*)pool_alloc(TB_BLOCKS);
-            unsigned long long* thr = (unsigned long long*)pool_alloc(64);
+            PoolScope tpool;
+            uint64_t* bcode = (uint64_t*)tpool.take(TB_BLOCKS * 8);
+            uint8_t* bcls = (uint8_t*)tpool.take(TB_BLOCKS);
+            unsigned long long* thr = (unsigned long long*)tpool.take(64);
             if (!bcode || !bcls || !thr) return 1;
             {
                 KernelTimer timer("topk_sample", s);
@@ -741,7 +746,6 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
             VNM_HIP(hipStreamSynchronize(s));
             t_cls = (uint32_t)th[0];
             t_code = th[1];
-            pool_free(bcode); pool_free(bcls); pool_free(thr);
         } else if (ok) {
             // larger ranks: the r01 route -- sort a 2^18-key sample by (class, code) with the grid-wide radix sort and read
             // the threshold off it (its ~130 small launches cost ~1.5 ms, which only matters for small K)
@@ -751,12 +755,13 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
             if (ok) {
                 RadixBufs sr{};
                 VNM_TRY(radix_alloc(&sr, ms_));
-                uint8_t* scls = (uint8_t*)pool_alloc((size_t)ms_);
+                PoolScope spool;
+                uint8_t* scls = (uint8_t*)spool.take((size_t)ms_);
                 if (!scls) return 1;
                 topk_sample_kernel<<<grid_for(ms_), 256, 0, s>>>(keys[0], desc, n, ms_, sr.code[0], scls);
                 sort_iota_kernel<<<grid_for(ms_), 256, 0, s>>>(sr.val[0], ms_);
                 int rc = radix_sort_codes(&sr, ms_, s);
-                uint64_t* scode_sorted = (uint64_t*)pool_alloc((size_t)ms_ * 8);
+                uint64_t* scode_sorted = (uint64_t*)spool.take((size_t)ms_ * 8);
                 if (rc || !scode_sorted) return 1;
                 VNM_HIP(hipMemcpyAsync(scode_sorted, sr.code[sr.cur], (size_t)ms_ * 8, hipMemcpyDeviceToDevice, s));
                 gather_u8_kernel<<<grid_for(ms_), 256, 0, s>>>(scls, sr.val[sr.cur], ms_, sr.code[sr.cur]);
@@ -771,8 +776,6 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
                 VNM_HIP(hipMemcpyAsync(&t_code, scode_sorted + pos_in_code_sorted, 8, hipMemcpyDeviceToHost, s));
                 VNM_HIP(hipStreamSynchronize(s));
                 t_cls = (uint32_t)cls64;
-                pool_free(scode_sorted);
-                pool_free(scls);
                 radix_free(&sr);
             }
         }
@@ -780,9 +783,10 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
             const int64_t cap = std::max<int64_t>(limit * 4 + 65536, 1 << 20);
             RadixBufs cr{};
             VNM_TRY(radix_alloc(&cr, cap));
-            uint8_t* ccls = (uint8_t*)pool_alloc((size_t)cap);
-            uint32_t* crows = (uint32_t*)pool_alloc((size_t)cap * 4);
-            unsigned long long* cnt = (unsigned long long*)pool_alloc(64);
+            PoolScope cpool;
+            uint8_t* ccls = (uint8_t*)cpool.take((size_t)cap);
+            uint32_t* crows = (uint32_t*)cpool.take((size_t)cap * 4);
+            unsigned long long* cnt = (unsigned long long*)cpool.take(64);
             if (!ccls || !crows || !cnt) return 1;
             VNM_HIP(hipMemsetAsync(cnt, 0, 8, s));
             {
@@ -851,7 +855,7 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
             } else if ((int64_t)found >= limit && (int64_t)found <= cap) {
                 const int64_t c = (int64_t)found;
                 // canonical order: by row id, then (stable) by code, then by class
-                uint64_t* code_keep = (uint64_t*)pool_alloc((size_t)c * 8);
+                uint64_t* code_keep = (uint64_t*)cpool.take((size_t)c * 8);
                 if (!code_keep) return 1;
                 VNM_HIP(hipMemcpyAsync(code_keep, cr.code[0], (size_t)c * 8, hipMemcpyDeviceToDevice, s));
                 // pass group 1: key = row id, value = candidate slot
@@ -871,9 +875,7 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
                     VNM_HIP(hipStreamSynchronize(s));
                     done = true;
                 }
-                pool_free(code_keep);
             }
-            pool_free(ccls); pool_free(crows); pool_free(cnt);
             radix_free(&cr);
             if (rc2) return rc2;
             if (done) return 0;
