@@ -473,6 +473,11 @@ def main():
                                       [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
                                       expected_groups=groups if args.hint else 0, rank_aligned=(world > 1 or force_exchange))
             agg.set_predicate(">", x_thr)
+            if (world > 1 or force_exchange) and not args.hint:
+                # hint-less on several ranks: agree on ONE group-count estimate, or ranks may cut their results into
+                # different numbers of partitions (distributed.agree_on_group_count)
+                from vinum_amd import distributed as D
+                D.agree_on_group_count(agg, kcol, n, device, stream=stream)
             agg.next([kcol], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
         ng = agg.finish(stream=stream)
         if world > 1 or force_exchange:

@@ -149,6 +149,11 @@ int vnm_agg_set_predicate(vnm_agg* h, int enabled, int op, int scalar_is_float, 
  * vnm_agg_run_partitions / _reorder / vnm_agg_merge_partitioned); the dense-key path, whose code range comes from a
  * per-rank sample, is not used. */
 int vnm_agg_set_exchange_mode(vnm_agg* h, int rank_aligned);
+/* The operator's own group-count estimate for a batch (the sample it would take itself: exact for up to ~30 k groups,
+ * HyperLogLog beyond), WITHOUT aggregating anything; 0 = not applicable (the key is not a plain 8-byte column).
+ * Multi-GPU hosts call it on every rank, agree on the maximum and pass it to vnm_agg_set_hint, so that all ranks cut their
+ * results into the same partitions (the partition count follows the hint). */
+int vnm_agg_estimate_groups(vnm_agg* h, int64_t nrows, const vnm_dcol* key, int64_t* estimate, void* stream);
 /* expected number of groups (0 = unknown): sizes the table and picks the kernel strategy */
 int vnm_agg_set_hint(vnm_agg* h, int64_t expected_groups);
 /* BaseAggregate::Next (base_aggregate.cpp:23-45).  inputs[i] is the input column of func i (ignored for

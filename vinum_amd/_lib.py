@@ -76,6 +76,7 @@ PROTOTYPES = {
     "vnm_agg_result_func": (c_int, [c_void, c_int, c_void, c_void, c_void]),
     "vnm_agg_result_key_device": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void]),
     "vnm_agg_result_device": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
+    "vnm_agg_estimate_groups": (c_int, [c_void, c_i64, c_void, c_void, c_void]),
     "vnm_agg_result_func_device": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_void]),
     "vnm_agg_plan_host": (c_int, [c_int, c_int, c_void, c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_void,
                                   c_void, c_void]),

@@ -3661,6 +3661,17 @@ int vnm_agg_set_hint(vnm_agg* h, int64_t expected_groups) {
     return 0;
 }
 
+int vnm_agg_estimate_groups(vnm_agg* h, int64_t nrows, const vnm_dcol* key, int64_t* estimate, void* stream) {
+    VNM_TRY(ensure_init());
+    if (!h || !key || !estimate) return set_error("vnm_agg_estimate_groups: null argument");
+    *estimate = 0;
+    if (nrows <= 0 || type_width(key->type) != 8 || key->validity || (key->offset & 1)) return 0;   // the estimator reads plain 8-byte keys
+    int64_t est = 0;
+    VNM_TRY(estimate_groups(h, *key, nrows, &est, as_stream(stream)));
+    *estimate = est;
+    return 0;
+}
+
 int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs,
                         const vnm_dcol* pred, void* stream) {
     VNM_TRY(ensure_init());

@@ -150,6 +150,20 @@ def exchange_partition_aligned(agg, make_merged, device, group=None):
     return merged
 
 
+def agree_on_group_count(agg, key, nrows, device, group=None, stream=None):
+    """Every rank estimates its batch's group count with the operator's own estimator, the ranks agree on the MAXIMUM (one
+    8-byte all_reduce) and hand it to the operator as its hint.  The number of hash partitions follows the hint, so without
+    this two ranks whose estimates fall on either side of a power-of-two boundary (G = 1e8: 1.2e8 / 900 = 133 k vs the boundary
+    at 131 072) would cut their results differently and the partition-aligned exchange would fall back to the bucketed one."""
+    est = agg.estimate_groups(key, nrows, stream=stream)
+    t = torch.tensor([est], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    est = int(t.item())
+    if est > 0:
+        agg.set_hint(est)
+    return est
+
+
 # ---- small result sets: ONE all_gather, every rank merges everything ----------------------------------------------
 SMALL_G_ROWS = 1 << 20   # partial groups per rank up to which the all-gather path is used
 

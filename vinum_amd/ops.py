@@ -226,6 +226,16 @@ class DeviceAggregate:
             arrays.append(_func_array(f, in_t, kind.value, cells, valid))
         return pa.RecordBatch.from_arrays(arrays, names=names)
 
+    def estimate_groups(self, key, nrows, stream=None) -> int:
+        """The operator's own group-count estimate for a batch, without aggregating it (vnm_agg_estimate_groups); 0 = not
+        applicable.  distributed.agree_on_group_count() makes every rank use the same value."""
+        est = ctypes.c_int64(0)
+        L.check(L.lib().vnm_agg_estimate_groups(self._h, int(nrows), ctypes.byref(key.dcol()), ctypes.byref(est), _stream_ptr(stream)))
+        return est.value
+
+    def set_hint(self, expected_groups):
+        L.check(L.lib().vnm_agg_set_hint(self._h, int(expected_groups)))
+
     def result_device(self, key_indices=None, stream=None):
         """BaseAggregate::Result with the columns LEFT IN HBM: selected group keys first, then the functions
         (base_aggregate.cpp:47-68), finalised by a device kernel straight into Arrow-layout buffers (typed values +
