@@ -1004,6 +1004,11 @@ def test_random_hot_shape_paths_vs_oracle(seed, monkeypatch):
     karr = pa.array(k.astype(np.uint64) if unsigned else k)
     quantised = rng.random() < 0.7
     v = rng.integers(-2**13, 2**13, n).astype(np.float64) / 128.0 if quantised else rng.lognormal(1.0, 1.5, n) * rng.choice([-1.0, 1.0], n)
+    if rng.random() < 0.25:      # infinities and NaNs: a group's sum is +-inf, or NaN once it holds a NaN or both infinities
+        sp = rng.integers(0, n, 60)
+        v[sp[:20]] = np.inf
+        v[sp[20:40]] = -np.inf
+        v[sp[40:]] = np.nan
     cols = {"k": karr, "v": pa.array(v)}
     pred = None
     r = rng.random()
