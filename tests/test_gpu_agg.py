@@ -1042,3 +1042,24 @@ def test_random_hot_shape_paths_vs_oracle(seed, monkeypatch):
         o.next(b)
     what = f"seed {seed}: G~{groups} lo={lo} {pattern} unsigned={unsigned} quantised={quantised} hint={hint} pred={pred} batches={len(batches)}"
     util.assert_agg_equal(got, o.result(), funcs, ["k"], exact_float_inputs=("v",) if quantised else (), what=what)
+
+
+@pytest.mark.parametrize("groups", [50, 20_000, 700_000, 3_000_000])
+def test_estimate_groups_entry(groups):
+    """vnm_agg_estimate_groups (what ranks all_reduce before a multi-GPU step): the operator's own estimate of a batch's group
+    count without aggregating it -- never below the truth (partitions are sized from it) and at most 1.3x the size of the key
+    population it was drawn from (the uniform-occupancy model extrapolates to the population, plus a 15-20 % margin)."""
+    from vinum_amd.device import DeviceColumn
+    from vinum_amd import ops
+    from vinum_amd import _lib as L
+    rng = np.random.default_rng(groups)
+    n = 4_000_000
+    k = rng.integers(0, groups, n).astype(np.int64) * 7919 - 5
+    truth = len(np.unique(k))
+    agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.COUNT_STAR, None, None)])
+    est = agg.estimate_groups(DeviceColumn.from_numpy(k), n)
+    assert truth <= est <= 1.3 * min(groups, n) + 16, (groups, truth, est)
+    # a key the estimator cannot read (int32) reports 0: callers then skip the agreement step
+    agg32 = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int32()], [(L.COUNT_STAR, None, None)])
+    assert agg32.estimate_groups(DeviceColumn.from_numpy(k.astype(np.int32)), n) == 0
+    agg.close(); agg32.close()
