@@ -505,7 +505,7 @@ def test_multi_key_packed_composite_keys(scenario):
         util.assert_agg_equal(got, o.result(), funcs, names, what=f"packed multi-key {scenario} pred={pred}")
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS", "60")))))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS", "100")))))
 def test_random_plans_vs_oracle(seed, monkeypatch):
     """Seeded differential test over the whole dispatch space: random key columns (1-3, mixed widths, NULLs), random
     function lists over random typed inputs (NULLs, narrow types), random group counts, hints (right / absent),
@@ -973,7 +973,7 @@ def test_dense_paths_generic_programs(program, groups, hint, monkeypatch):
         util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"dense generic {program} G={groups} hint={hint} pred={pred}")
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS", "48")))))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS", "96")))))
 def test_random_hot_shape_paths_vs_oracle(seed, monkeypatch):
     """Seeded differential test of the north-star shape (int64 / uint64 key, float64 value, sum / avg / count, optional
     float64 predicate) across everything that decides its path: key range from a few hundred to millions of codes (direct-

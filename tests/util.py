@@ -67,10 +67,17 @@ def canon(batch, key_names):
         return batch
     idxs = [batch.schema.names.index(k) for k in key_names]
     idxs += [i for i in range(batch.num_columns) if i not in idxs]  # tie-break: remaining columns
-    keys = []
-    for i in idxs:
-        valid, vals = _bits(batch.column(i))
-        keys.append([(0 if v else 1, int(x)) for v, x in zip(valid, vals)])
+    cols = [_bits(batch.column(i)) for i in idxs]
+    if all(isinstance(vals, np.ndarray) for _, vals in cols):
+        # (null flag, bit pattern) per column, first column most significant: one lexsort instead of a Python sort of tuples
+        # (results with ~1e6 groups made the large dense-path tests spend most of their time here)
+        sort_keys = []
+        for valid, vals in cols:
+            sort_keys.append((~valid).astype(np.uint8))
+            sort_keys.append(vals.astype(np.uint64))
+        order = np.lexsort(sort_keys[::-1])
+        return batch.take(pa.array(order.astype(np.int64)))
+    keys = [[(0 if v else 1, int(x)) for v, x in zip(valid, vals)] for valid, vals in cols]
     order = sorted(range(batch.num_rows), key=lambda r: tuple(k[r] for k in keys))
     return batch.take(pa.array(order, pa.int64()))
 
