@@ -3357,6 +3357,10 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     // pass 2 and the final pass 15-20 % slower (their reads become 150 KB chunks 75 MB apart) -> partition-major stays
     const int pmajor = (int)env_i64("VNM_DENSE_PRODUCER_MAJOR", 0);
     d1.producer_major = pmajor;
+    // Non-temporal stores for pass 1's runs when a wide second level follows: pass 2 then reads them 15-20 % faster and the query
+    // gains 0.4 ms (1.1 ms in sustained runs) at G = 1e8 (p2 = 8); with p2 = 6 (G = 1e7) or a single level it is neutral to
+    // slightly worse, so it stays off there.  In pass 2 itself such stores cost 0.3 ms.  (VNM_DENSE_NT: bit 0 pass 1, bit 1 pass 2)
+    d1.nt_store = (int)env_i64("VNM_DENSE_NT", levels == 2 && np2 >= 256 ? 1 : 0) & 1;
     d1.flags = flags; d1.spill = spill; d1.spill_cap = spill_cap;
     {
         KernelTimer timer("agg_part_scatter1", s);
@@ -3387,6 +3391,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         d2.out_vals = v2; d2.out_codes = c2; d2.out_counts = n2; d2.out_cap = cap2;
         d2.nparts = np2; d2.out_bits = tb;
         d2.flags = flags; d2.spill = spill; d2.spill_cap = spill_cap;
+        d2.nt_store = ((int)env_i64("VNM_DENSE_NT", 0) >> 1) & 1;
         {
             KernelTimer timer("agg_part_scatter2", s);
             if (has_val) dpart_scatter_kernel<false, uint16_t><<<np1 * split2, PT_BLOCK, 0, s>>>(d2);
