@@ -146,8 +146,9 @@ void vnm_agg_destroy(vnm_agg* h);
 int vnm_agg_set_predicate(vnm_agg* h, int enabled, int op, int scalar_is_float, double dval, int64_t ival);
 /* Multi-GPU: the finished result of this handle will be exchanged with other ranks.  rank_aligned = 1 restricts the
  * operator to run layouts that every rank derives identically from the keys alone (hash partitions: owner(f) = f * P / F,
- * vnm_agg_run_partitions / _reorder / vnm_agg_merge_partitioned); the dense-key path, whose code range comes from a
- * per-rank sample, is not used. */
+ * vnm_agg_run_partitions / _reorder / vnm_agg_merge_partitioned); the dense-key paths, whose code range comes from a
+ * per-rank sample, are only used while the group count stays small enough for the all-gather exchange, where nothing
+ * needs aligning. */
 int vnm_agg_set_exchange_mode(vnm_agg* h, int rank_aligned);
 /* The operator's own group-count estimate for a batch (the sample it would take itself: exact for up to ~30 k groups,
  * HyperLogLog beyond), WITHOUT aggregating anything; 0 = not applicable (the key is not a plain 8-byte column).
@@ -261,7 +262,8 @@ void vnm_agg_op_destroy(vnm_agg_op* h);
 int vnm_sort_indices(int n_keys, const vnm_dcol* keys, const int* orders, int64_t length,
                      int64_t limit /* <=0: full sort; >0: only the first `limit` rows are needed */,
                      int64_t* out_indices /* device, length entries (first `limit` valid) */, void* stream);
-/* The same, and -- for a full sort whose first key is int64 / uint64 / float64 without NULL, NaN or -0.0 -- the sorted
+/* The same (Sort::Sorted = SortIndices + Take of EVERY column, sort.cpp:22-40), and -- for a full sort whose first key is
+ * int64 / uint64 / float64 without NULL, NaN or -0.0 -- the sorted
  * values of that key straight from the sort (out_sorted_key0: device, length x 8 bytes; *wrote_key0 = 1), which saves
  * the caller the gather (vnm_take: 25 ms per 1e9 rows) for that column.  *wrote_key0 = 0: gather as usual. */
 int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, int64_t length, int64_t limit,
