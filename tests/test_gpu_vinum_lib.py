@@ -228,3 +228,33 @@ def test_string_keys_and_distinct_through_the_planner():
     exp_d = t.select(["city_from", "is_rush"]).group_by(["city_from", "is_rush"], use_threads=False).aggregate([])
     key = lambda r: (r["city_from"] is None, r["city_from"] or "", r["is_rush"] is None, bool(r["is_rush"]))
     assert sorted(d.to_pylist(), key=key) == sorted(exp_d.to_pylist(), key=key)
+
+
+def test_small_batches_are_coalesced_and_large_ones_are_not():
+    """vnm_agg_op_next keeps batches below 2^20 rows until 2^22 rows are waiting (the reference streams 10 000-row batches by
+    default) and stages larger ones directly; any interleaving of the two must give the result of the whole table."""
+    from vinum_amd import vinum_lib as V
+    rng = np.random.default_rng(5)
+    n = 6_500_000
+    t = pa.table({"k": pa.array(rng.integers(0, 5000, n).astype(np.int64), mask=rng.random(n) < 0.01),
+                  "v": pa.array(rng.integers(-2**13, 2**13, n).astype(np.float64) / 128.0, mask=rng.random(n) < 0.02),
+                  "w": pa.array(rng.integers(-2**40, 2**40, n).astype(np.int64))})
+    defs = [V.AggFuncDef(V.AggFuncType.SUM, "v", "s"), V.AggFuncDef(V.AggFuncType.AVG, "w", "a"), V.AggFuncDef(V.AggFuncType.MIN, "v", "lo"),
+            V.AggFuncDef(V.AggFuncType.COUNT_STAR, "", "n")]
+
+    def run(cuts):
+        op = V.SingleNumericalHashAggregate(["k"], ["k"], defs)
+        pos = 0
+        for c in cuts:
+            for b in t.slice(pos, c).to_batches():
+                op.next(b)
+            pos += c
+        assert pos == n
+        return op.result()
+
+    whole = run([n])
+    tiny = [10_000] * 300                      # 3e6 rows in reference-sized batches: coalesced, flushed at result() at the latest
+    mixed = run(tiny + [2_000_000] + [10_000] * 50 + [n - 3_000_000 - 2_000_000 - 500_000])
+    only_tiny = run([10_000] * (n // 10_000) + [n % 10_000])
+    for got in (mixed, only_tiny):
+        util.assert_batches_equal(got, whole, key_names=["k"], what="coalesced vs one batch")

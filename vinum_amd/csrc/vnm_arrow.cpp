@@ -164,6 +164,35 @@ int stage_child(const struct ArrowArray* batch, int ci, const ColType& t, vnm_dc
 // =========================================================================================================
 // aggregate operator
 // =========================================================================================================
+// Child column `ci` of several imported batches -> ONE column in HBM: values (and validity bits) are laid end to end on the host,
+// then staged in one go (Table::FromRecordBatches + one H2D, as Sort does, sort.cpp:16).
+int stage_children(const std::vector<std::unique_ptr<ImportedBatch>>& batches, int ci, const ColType& t, int64_t total, vnm_dcol* out) {
+    const int w = type_width(t.type);
+    std::vector<uint8_t> vals((size_t)(total ? total : 1) * w);
+    std::vector<uint8_t> bits;
+    bool any_null = false;
+    for (auto& b : batches) if (b->arr.children[ci]->null_count != 0 && b->arr.children[ci]->buffers[0]) any_null = true;
+    if (any_null) bits.assign((size_t)(total + 7) / 8 + 1, 0);
+    int64_t pos = 0;
+    for (auto& b : batches) {
+        const struct ArrowArray* ch = b->arr.children[ci];
+        const int64_t off = ch->offset + b->arr.offset, len = b->arr.length;
+        if (len) memcpy(&vals[(size_t)pos * w], (const uint8_t*)ch->buffers[1] + (size_t)off * w, (size_t)len * w);
+        if (any_null) {
+            const uint8_t* bm = (ch->null_count != 0) ? (const uint8_t*)ch->buffers[0] : nullptr;
+            for (int64_t i = 0; i < len; i++) {
+                const bool ok = !bm || ((bm[(off + i) >> 3] >> ((off + i) & 7)) & 1);
+                if (ok) bits[(size_t)(pos + i) >> 3] |= (uint8_t)(1u << ((pos + i) & 7));
+            }
+        }
+        pos += len;
+    }
+    VNM_TRY(vnm_stage_column(vals.data(), any_null ? bits.data() : nullptr, 0, total, t.type, out, nullptr));
+    out->flags = t.flags;
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return set_error("staging failed");
+    return 0;
+}
+
 struct vnm_agg_op {
     int kind;
     std::vector<std::string> groupby, agg_cols, in_cols, out_cols;
@@ -172,6 +201,10 @@ struct vnm_agg_op {
     bool inited = false;
     std::vector<int> key_idx, in_idx, aggcol_key;  // child indices; agg_col -> position in groupby
     std::vector<ColType> key_t, in_t;
+    // small batches wait here until they add up to a device-sized one (vnm_agg_op_next)
+    std::vector<std::unique_ptr<ImportedBatch>> pending;
+    int64_t pending_rows = 0;
+    std::vector<std::string> formats;   // child formats of the first batch: later batches must match on the columns used
 };
 
 static int agg_op_init(vnm_agg_op* h, const struct ArrowSchema* sch) {
@@ -245,17 +278,78 @@ vnm_agg_op* vnm_agg_op_create(int kind, int n_groupby, const char** groupby_cols
 
 void vnm_agg_op_destroy(vnm_agg_op* h) {
     if (!h) return;
+    for (auto& b : h->pending) b->drop();
     if (h->dev) vnm_agg_destroy(h->dev);
     delete h;
 }
 
+// one device batch out of everything that is pending
+static int agg_op_flush(vnm_agg_op* h) {
+    if (h->pending.empty()) return 0;
+    const int64_t total = h->pending_rows;
+    std::vector<vnm_dcol> keys(h->key_idx.size()), inputs(h->funcs.size());
+    std::map<int, vnm_dcol> staged;
+    int rc = 0;
+    auto get = [&](int ci, const ColType& t, vnm_dcol* out) -> int {
+        auto it = staged.find(ci);
+        if (it == staged.end()) {
+            vnm_dcol d;
+            VNM_TRY(stage_children(h->pending, ci, t, total, &d));
+            it = staged.emplace(ci, d).first;
+        }
+        *out = it->second;
+        return 0;
+    };
+    for (size_t j = 0; !rc && j < h->key_idx.size(); j++) rc = get(h->key_idx[j], h->key_t[j], &keys[j]);
+    for (size_t i = 0; !rc && i < h->funcs.size(); i++) {
+        memset(&inputs[i], 0, sizeof(vnm_dcol));
+        inputs[i].length = total;
+        if (h->in_idx[i] >= 0) rc = get(h->in_idx[i], h->in_t[i], &inputs[i]);
+    }
+    if (!rc && total > 0) rc = vnm_agg_next_device(h->dev, total, keys.data(), inputs.data(), nullptr, nullptr);
+    if (hipStreamSynchronize(nullptr) != hipSuccess && !rc) rc = set_error("vnm_agg_op_next: stream synchronisation failed");
+    for (auto& kv : staged) vnm_free_column(&kv.second);
+    for (auto& b : h->pending) b->drop();
+    h->pending.clear();
+    h->pending_rows = 0;
+    return rc;
+}
+
+// The reference streams 10 000-row batches by default (vinum/__init__.py:52, table_batch_reader.cpp:5-16); a launch per such
+// batch would cost more than its rows.  Batches below 2^20 rows are therefore kept (the operator owns them: Arrow C Data
+// move semantics) until 2^22 rows are waiting -- or result() is called -- and then go to the device as ONE batch; a large batch
+// is staged straight from its own buffers as before.  Aggregates do not depend on where batches are cut (every accumulator
+// merges commutatively, float sums are compensated), so the result is the same.
 int vnm_agg_op_next(vnm_agg_op* h, struct ArrowArray* batch, struct ArrowSchema* schema) {
     if (!h || !batch || !schema) return set_error("vnm_agg_op_next: null argument");
-    ImportedBatch ib;
+    std::unique_ptr<ImportedBatch> ibp(new ImportedBatch());
+    ImportedBatch& ib = *ibp;
     ib.arr = *batch; ib.sch = *schema; ib.live = true;
     batch->release = nullptr; schema->release = nullptr;  // ownership moved (Arrow C Data Interface move semantics)
     int rc = 0;
-    if (!h->inited) rc = agg_op_init(h, &ib.sch);
+    if (!h->inited) {
+        rc = agg_op_init(h, &ib.sch);
+        if (!rc) {
+            h->formats.clear();
+            for (int64_t c = 0; c < ib.sch.n_children; c++) h->formats.push_back(ib.sch.children[c]->format ? ib.sch.children[c]->format : "");
+        }
+    } else {
+        // the columns the operator reads must be where -- and what -- they were in the first batch
+        auto same = [&](int ci) { return ci < (int)ib.sch.n_children && ci < (int)h->formats.size() && ib.sch.children[ci]->format &&
+                                         h->formats[(size_t)ci] == ib.sch.children[ci]->format; };
+        for (size_t j = 0; !rc && j < h->key_idx.size(); j++) if (!same(h->key_idx[j])) rc = set_error("vnm_agg_op_next: the batch schema changed");
+        for (size_t i = 0; !rc && i < h->funcs.size(); i++) if (h->in_idx[i] >= 0 && !same(h->in_idx[i])) rc = set_error("vnm_agg_op_next: the batch schema changed");
+    }
+    if (rc) { ib.drop(); return rc; }
+    static const int64_t small_rows = getenv("VNM_AGG_COALESCE_BELOW") ? atoll(getenv("VNM_AGG_COALESCE_BELOW")) : (1 << 20);
+    static const int64_t flush_rows = getenv("VNM_AGG_COALESCE_ROWS") ? atoll(getenv("VNM_AGG_COALESCE_ROWS")) : (1 << 22);
+    if (ib.arr.length < small_rows) {
+        h->pending_rows += ib.arr.length;
+        h->pending.push_back(std::move(ibp));
+        return h->pending_rows >= flush_rows ? agg_op_flush(h) : 0;
+    }
+    rc = agg_op_flush(h);   // (rows that arrived earlier go first; the order does not matter to the result)
+    if (rc) { ib.drop(); return rc; }
     std::vector<vnm_dcol> keys(h->key_idx.size()), inputs(h->funcs.size());
     std::map<int, vnm_dcol> staged;
     hipStream_t s = nullptr;
@@ -285,6 +379,7 @@ int vnm_agg_op_next(vnm_agg_op* h, struct ArrowArray* batch, struct ArrowSchema*
 int vnm_agg_op_result(vnm_agg_op* h, struct ArrowArray* out, struct ArrowSchema* out_schema) {
     if (!h || !out || !out_schema) return set_error("vnm_agg_op_result: null argument");
     if (!h->inited) return set_error("vnm_agg_op_result: no batch was ever passed to next()");
+    VNM_TRY(agg_op_flush(h));
     int64_t n = 0;
     VNM_TRY(vnm_agg_finish(h->dev, &n, nullptr));
     const int64_t ncols = (int64_t)h->agg_cols.size() + (int64_t)h->funcs.size();
