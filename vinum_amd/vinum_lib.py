@@ -283,14 +283,32 @@ class Sort:
             raise RuntimeError(L.last_error())
 
     def next(self, batch: pa.RecordBatch) -> None:
-        c = _CStructs()
-        batch._export_to_c(c.arr_ptr, c.sch_ptr)
-        if L.lib().vnm_sort_op_next(self._h, c.arr_ptr, c.sch_ptr) != 0:
-            raise RuntimeError(L.last_error())
+        # Sort::Next only retains the batch (sort.cpp:11-13); nothing can fail before sorted().  Small batches (the reference's
+        # default is 10 000 rows) are kept here and cross the boundary joined, as in the aggregates.
+        if not hasattr(self, "_pending"):
+            self._pending, self._pending_rows = [], 0
+        if self._pending and batch.schema != self._pending[0].schema:
+            self._flush()
+        self._pending.append(batch)
+        self._pending_rows += batch.num_rows
+        if self._pending_rows >= (1 << 24):
+            self._flush()
+
+    def _flush(self) -> None:
+        pending, self._pending, self._pending_rows = getattr(self, "_pending", None), [], 0
+        if not pending:
+            return
+        joined = pa.Table.from_batches(pending).combine_chunks() if len(pending) > 1 else pa.Table.from_batches(pending)
+        for b in (joined.to_batches() or pending[:1]):
+            c = _CStructs()
+            b._export_to_c(c.arr_ptr, c.sch_ptr)
+            if L.lib().vnm_sort_op_next(self._h, c.arr_ptr, c.sch_ptr) != 0:
+                raise RuntimeError(L.last_error())
 
     def sorted(self, limit: int = 0) -> pa.RecordBatch:
         """limit (extension, default 0 = everything): only the first `limit` rows are needed (LIMIT pushed
         into the sort; identical rows to sorting everything and slicing)."""
+        self._flush()
         c = _CStructs()
         if L.lib().vnm_sort_op_sorted(self._h, int(limit), c.arr_ptr, c.sch_ptr) != 0:
             raise RuntimeError(L.last_error())
