@@ -250,9 +250,32 @@ class GenericHashAggregate:
         self._inner = cls(self._groupby, self._agg_cols, self._funcs)
 
     def next(self, batch: pa.RecordBatch) -> None:
-        import numpy as np
+        # the first batch fixes the schema (and raises what the reference raises); later small batches are encoded together:
+        # dictionary-encoding 10 000 rows at a time costs more in Python than in work
         if self._inner is None:
             self._init(batch)
+            self._pending, self._pending_rows = [], 0
+            self._encode_and_send(batch)
+            return
+        if batch.num_rows >= (1 << 20):
+            self._flush()
+            self._encode_and_send(batch)
+            return
+        if self._pending and batch.schema != self._pending[0].schema:
+            self._flush()
+        self._pending.append(batch)
+        self._pending_rows += batch.num_rows
+        if self._pending_rows >= (1 << 22):
+            self._flush()
+
+    def _flush(self) -> None:
+        pending, self._pending, self._pending_rows = self._pending, [], 0
+        if pending:
+            for b in pa.Table.from_batches(pending).combine_chunks().to_batches():
+                self._encode_and_send(b)
+
+    def _encode_and_send(self, batch: pa.RecordBatch) -> None:
+        import numpy as np
         arrays, names = [], []
         for i, name in enumerate(batch.schema.names):
             col = batch.column(i)
@@ -269,6 +292,7 @@ class GenericHashAggregate:
     def result(self) -> pa.RecordBatch:
         if self._inner is None:
             raise RuntimeError("GenericHashAggregate.result() before any batch")
+        self._flush()
         res = self._inner.result()
         arrays = [self._dicts[n].decode(res.column(i)) if n in self._dicts else res.column(i) for i, n in enumerate(res.schema.names)]
         return pa.RecordBatch.from_arrays(arrays, names=res.schema.names)
