@@ -633,7 +633,7 @@ def main():
         k2 = key if key in tj else (key[:-5] if tf == "r01_traffic.json" and args.hint and key[:-5] in tj else None)
         if k2:
             ent = tj[k2]
-            # two kinds of box in this pool (profiles/tuning_log_r02.md): take the PMC profile whose pass-1 duration matches
+            # pass 1 runs in one of two states, decided per process (profiles/tuning_log_r02.md): take the PMC profile whose pass-1 duration matches
             # the one measured live
             live = spans.get("agg_part_scatter1", (None,))[0]
             cands = [ent] + list(ent.get("variants", []))
