@@ -3324,7 +3324,11 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     split2 = std::max(split2, std::min(grid1, (cus * 2 + np1 - 1) / np1));
     const int64_t tiles_per_wg = ((nrows + tile1 - 1) / tile1 + grid1 - 1) / grid1;
     const int64_t rows_per_wg = tiles_per_wg * tile1;
-    const int64_t cap1 = ((rows_per_wg / np1 + rows_per_wg / np1 / 5 + 512) + 7) & ~7LL;
+    int64_t cap1v = ((rows_per_wg / np1 + rows_per_wg / np1 / 5 + 512) + 15) & ~15LL;
+    // region stride = an ODD number of 128-byte lines: the lines the resident workgroups keep open in one partition then spread
+    // over the L2 sets instead of sharing their low index bits (two sessions of 5-6 process pairs: 11.73 -> 11.25 and 11.27 -> 11.17 ms)
+    if (env_i64("VNM_DENSE_ODD_CAP", 1) && ((cap1v / 16) & 1) == 0) cap1v += 16;
+    const int64_t cap1 = cap1v;
     const bool c16_1 = levels == 1;  // pass-1 remainders fit 16 bits when they are the final slots
     // final partitions x splits >= ~4 workgroups per CU
     int fsplits = 1;
@@ -3378,7 +3382,8 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     int fin_regions = grid1;
     if (levels == 2) {
         const int64_t per_pg = (int64_t)grid1 * rows_per_wg / np1 / split2;
-        const int64_t cap2 = ((per_pg / np2 + per_pg / np2 / 4 + 256) + 7) & ~7LL;
+        int64_t cap2 = ((per_pg / np2 + per_pg / np2 / 4 + 256) + 15) & ~15LL;
+        if (env_i64("VNM_DENSE_ODD_CAP", 1) && ((cap2 / 16) & 1) == 0) cap2 += 16;
         v2 = (double*)pool_alloc(has_val ? (size_t)np1 * np2 * split2 * cap2 * 8 : 8);
         c2 = pool_alloc((size_t)np1 * np2 * split2 * cap2 * 2);
         n2 = (uint32_t*)pool_alloc((size_t)np1 * np2 * split2 * 4);
