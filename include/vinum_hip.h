@@ -334,6 +334,9 @@ int vnm_csv_parse_block(const char* host_text, int64_t nbytes, int skip_header, 
  * that last used a block before vnm_free (as with hipFree, minus its implicit device synchronisation). */
 void* vnm_malloc(int64_t bytes);
 int vnm_free(void* p);
+/* hand every block the caching allocator holds but nobody uses back to the device (hipFree); returns the
+ * bytes released.  For long-lived hosts that want the HBM back between queries; live blocks are untouched. */
+int64_t vnm_pool_trim(void);
 int vnm_memcpy_h2d(void* dst, const void* src, int64_t bytes);
 int vnm_memcpy_d2h(void* dst, const void* src, int64_t bytes);
 int vnm_memset(void* dst, int value, int64_t bytes);

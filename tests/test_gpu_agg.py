@@ -505,6 +505,90 @@ def test_multi_key_packed_composite_keys(scenario):
         util.assert_agg_equal(got, o.result(), funcs, names, what=f"packed multi-key {scenario} pred={pred}")
 
 
+@pytest.mark.parametrize("scenario", ["two_wide_int64", "float_and_wide", "many_distinct", "new_values_later",
+                                      "three_wide", "four_wide", "six_wide_no_fit", "wide_plus_dims", "table_overflow"])
+def test_multi_key_dictionary_coded_fields(scenario):
+    """Key columns whose RANGES do not fit the packed word but whose distinct values do (hashed ids, float64 keys): the widest
+    columns are coded through per-column dictionaries (code = table slot) and the rest packs as before, so the single-key paths
+    apply instead of the wide-key table.  Covered: the value that equals the table's EMPTY sentinel (int64 -1), NULL keys, NaN /
+    -0.0 / 0.0 / inf as distinct bit patterns (array_iterators.h:239-248), dictionaries growing in later batches, and a
+    dictionary that overflows (demotion to the wide-key table, results intact).  Bit-exact against the oracle."""
+    import ctypes
+    from oracle import oracle as O
+    from vinum_amd import _lib as L
+    rng = np.random.default_rng(len(scenario) * 7 + 1)
+    n = 300_000
+    expect_demote = False
+
+    def wide_values(count, seed):
+        vals = np.random.default_rng(seed).integers(-2**63, 2**63 - 1, count).astype(np.int64)
+        vals[0] = -1                                   # bit pattern of the table's EMPTY word
+        vals[1 % count] = np.iinfo(np.int64).min
+        return vals
+    if scenario == "two_wide_int64":
+        a = pa.array(wide_values(30, 1)[rng.integers(0, 30, n)], mask=rng.random(n) < 0.03)
+        b = pa.array(wide_values(20, 2)[rng.integers(0, 20, n)])
+        keys = {"a": a, "b": b}
+    elif scenario == "float_and_wide":
+        fv = np.array([np.nan, -0.0, 0.0, np.inf, -np.inf, 1e300, -1e-300, 2.5, np.float64.fromhex("0x1.8p+1")] + list(rng.random(40) * 1e9))
+        a = pa.array(fv[rng.integers(0, len(fv), n)], mask=rng.random(n) < 0.02)
+        b = pa.array(wide_values(50, 3)[rng.integers(0, 50, n)], mask=rng.random(n) < 0.02)
+        keys = {"a": a, "b": b}
+    elif scenario == "many_distinct":
+        a = pa.array(wide_values(120_000, 4)[rng.integers(0, 120_000, n)])
+        b = pa.array(wide_values(3, 5)[rng.integers(0, 3, n)])
+        keys = {"a": a, "b": b}
+    elif scenario == "new_values_later":
+        ia = np.concatenate([rng.integers(0, 40, n // 2), rng.integers(20, 4000, n - n // 2)])
+        a = pa.array(wide_values(4000, 6)[ia])
+        b = pa.array(wide_values(10, 7)[rng.integers(0, 10, n)])
+        keys = {"a": a, "b": b}
+    elif scenario in ("three_wide", "four_wide", "six_wide_no_fit"):   # 6 x (12 + 1) bits do not fit: the wide-key table takes it
+        nk = {"three_wide": 3, "four_wide": 4, "six_wide_no_fit": 6}[scenario]
+        keys = {c: pa.array(wide_values(6 + i, 8 + i)[rng.integers(0, 6 + i, n)], mask=rng.random(n) < 0.01) for i, c in enumerate("abcdef"[:nk])}
+    elif scenario == "wide_plus_dims":
+        keys = {"a": pa.array(rng.integers(0, 12, n).astype(np.int32)),
+                "b": pa.array(wide_values(500, 11)[rng.integers(0, 500, n)]),
+                "c": pa.array(rng.integers(-3, 3, n).astype(np.int8), mask=rng.random(n) < 0.1)}
+    else:  # the second batch has more distinct values than the table of the first (2^20 slots) can take
+        n = 1_700_000
+        first = 200_000
+        ia = np.concatenate([rng.integers(0, 10, first), np.arange(n - first)])
+        a = pa.array(wide_values(n - first, 12)[ia])
+        b = pa.array(wide_values(2, 13)[rng.integers(0, 2, n)])
+        keys = {"a": a, "b": b}
+        expect_demote = True
+    v = pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0)
+    t = pa.table({**keys, "v": v})
+    names = list(keys)
+    funcs = [(O.SUM, "v", "s"), (O.COUNT_STAR, "", "n"), (O.MAX, "v", "hi")]
+    if scenario == "table_overflow":
+        batches = [t.slice(0, 200_000).to_batches()[0], t.slice(200_000).combine_chunks().to_batches()[0]]
+    else:
+        batches = util.sliced_batches(t, n // 2)
+
+    def launches(name):
+        ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+        L.lib().vnm_profile_query(name, ctypes.byref(ms), ctypes.byref(cnt))
+        return cnt.value
+    for pred in (None, ("v", ">", 64.0)):
+        L.lib().vnm_set_profiling(1)
+        got = gpu_aggregate(O.MULTI, names, names, funcs, batches, predicate=pred)
+        packs, demotes = launches(b"agg_pack_keys"), launches(b"agg_demote")
+        L.lib().vnm_set_profiling(0)
+        if scenario == "six_wide_no_fit":
+            assert packs == 0 and demotes == 0, (packs, demotes)
+        else:
+            assert packs == len(batches), (packs, demotes)          # every batch went through the pack kernel ...
+            assert demotes == (1 if expect_demote else 0), (packs, demotes)   # ... and stayed packed unless the dictionary overflowed
+        o = O.OracleAggregate(O.MULTI, names, names, funcs)
+        for bt in batches:
+            if pred:
+                bt = O.filter_batch(bt, O.cmp_mask(bt.column(len(names)), O.GT, 64.0))
+            o.next(bt)
+        util.assert_agg_equal(got, o.result(), funcs, names, what=f"dictionary-coded keys {scenario} pred={pred}")
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS", "100")))))
 def test_random_plans_vs_oracle(seed, monkeypatch):
     """Seeded differential test over the whole dispatch space: random key columns (1-3, mixed widths, NULLs), random

@@ -121,3 +121,22 @@ def test_where_expression_trees_match_numpy_and_arrow():
         exp = t.filter(pa.array(mask))
         util.assert_batches_equal(got.combine_chunks().to_batches()[0] if got.num_rows else got.to_batches()[0] if got.to_batches() else exp.slice(0, 0).combine_chunks().to_batches()[0],
                                   exp.combine_chunks().to_batches()[0], what=str(expr))
+
+
+def test_pool_trim_releases_cached_blocks_only():
+    """vnm_pool_trim: freed blocks are cached for reuse (a same-size request gets the same block back), trim hands them to the
+    device and reports their bytes, and live blocks keep their contents."""
+    from vinum_amd.device import DeviceBuffer, pool_trim
+    pool_trim()
+    live = DeviceBuffer.from_host(np.arange(1 << 16, dtype=np.int64))
+    a = DeviceBuffer(48 << 20)
+    ptr = a.ptr
+    a.free()
+    b = DeviceBuffer(48 << 20)
+    assert b.ptr == ptr                      # reuse without going to the device
+    b.free()
+    released = pool_trim()
+    assert released >= 48 << 20
+    assert pool_trim() == 0                  # nothing cached any more
+    np.testing.assert_array_equal(live.to_host(np.int64, 1 << 16), np.arange(1 << 16, dtype=np.int64))
+    live.free()

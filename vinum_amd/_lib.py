@@ -100,6 +100,7 @@ PROTOTYPES = {
     "vnm_csv_parse_block": (c_int, [c_void, c_i64, c_int, c_int, c_int, c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
     "vnm_malloc": (c_void, [c_i64]),
     "vnm_free": (c_int, [c_void]),
+    "vnm_pool_trim": (c_i64, []),
     "vnm_memcpy_h2d": (c_int, [c_void, c_void, c_i64]),
     "vnm_memcpy_d2h": (c_int, [c_void, c_void, c_i64]),
     "vnm_memset": (c_int, [c_void, c_int, c_i64]),

@@ -2331,13 +2331,51 @@ __global__ void fill_u64_kernel(uint64_t* p, uint64_t v, int64_t n) {
 // word never equals the EMPTY sentinel.  A later batch outside the ranges demotes the operator to the wide-key
 // table (the groups so far are unpacked and merged there).
 // =======================================================================================================
+//
+// Dictionary-coded fields.  A key column whose RANGE is too wide for the word (hashed ids, float64 keys, two full-range
+// int64 columns) but whose distinct values are few enough gets its code from a per-column open-addressing table in HBM
+// instead: code = the slot the value was inserted at (one CAS per new value, a plain read for every other row -- a
+// slot changes once, EMPTY -> value, so whatever a lane reads that is not EMPTY is final), decode = table[code].  The
+// table has 2^dbits slots sized from the distinct-count estimate of the first batch; the value EMPTY itself owns the
+// extra slot 2^dbits, whose word stays EMPTY and therefore decodes to itself.  The field is dbits + 1 bits wide, so
+// two such columns always fit.  A probe chain beyond DICT_MAX_PROBES (the table filling up in later batches) raises
+// the same out-of-range flag as a plain field: the operator demotes to the wide-key table.
 struct PackParams {
     int n;
     int shift[AGG_MAX_KEYS];
     int bits[AGG_MAX_KEYS];
     uint64_t lo[AGG_MAX_KEYS];   // value bits of code 0
+    uint64_t* dtab[AGG_MAX_KEYS];   // dictionary-coded field: its table [2^dbits + 1], else nullptr
+    int dbits[AGG_MAX_KEYS];
     vnm_dcol cols[AGG_MAX_KEYS];
 };
+
+constexpr int DICT_MAX_PROBES = 256;
+
+__device__ __forceinline__ uint64_t dict_mix(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    return x ^ (x >> 33);
+}
+
+// code of value bits kb in the field's table (inserting it if new); `bad` when the chain is too long
+__device__ __forceinline__ uint64_t dict_code(uint64_t* tab, int dbits, uint64_t kb, bool& bad) {
+    const uint64_t mask = (1ULL << dbits) - 1;
+    if (kb == EMPTY) return mask + 1;
+    uint64_t slot = dict_mix(kb) & mask;
+    for (int probe = 0; probe < DICT_MAX_PROBES; probe++) {
+        uint64_t cur = tab[slot];
+        if (cur == EMPTY) {   // (or a stale line of this CU's L1: the CAS at the L2 tells.  Re-reading past the L1 first -- an
+                              // agent-scope load anywhere in this loop -- made the whole kernel 30 % slower, taken or not)
+            cur = atomicCAS((unsigned long long*)&tab[slot], (unsigned long long)EMPTY, (unsigned long long)kb);
+            if (cur == EMPTY) return slot;
+        }
+        if (cur == kb) return slot;
+        slot = (slot + 1) & mask;
+    }
+    bad = true;
+    return 0;
+}
 
 // per key column: min / max of the key bits as int64 (order-preserving encoding for the unsigned atomics)
 __global__ __launch_bounds__(256) void key_range_kernel(PackParams p, int64_t nrows, unsigned long long* out /* [n][2] */) {
@@ -2385,8 +2423,11 @@ __global__ __launch_bounds__(256) void key_pack_kernel(PackParams p, int64_t nro
                 const int64_t ic = i < nrows ? i : nrows - 1;
                 uint64_t code = cap;
                 if (col_valid(p.cols[j], ic)) {
-                    code = col_key_bits(p.cols[j], ic) - p.lo[j];
-                    bad = bad || (i < nrows && code >= cap);
+                    if (p.dtab[j]) code = dict_code(p.dtab[j], p.dbits[j], col_key_bits(p.cols[j], ic), bad);
+                    else {
+                        code = col_key_bits(p.cols[j], ic) - p.lo[j];
+                        bad = bad || (i < nrows && code >= cap);
+                    }
                 }
                 w[u] |= (code & cap) << p.shift[j];
             }
@@ -2410,7 +2451,7 @@ __global__ __launch_bounds__(256) void key_unpack_kernel(PackParams p, const uin
             const uint64_t cap = (1ULL << p.bits[j]) - 1;
             const uint64_t code = (w >> p.shift[j]) & cap;
             const bool isnull = code == cap;
-            dkey[(int64_t)j * stride + i] = isnull ? 0 : p.lo[j] + code;
+            dkey[(int64_t)j * stride + i] = isnull ? 0 : (p.dtab[j] ? p.dtab[j][code] : p.lo[j] + code);
             if (isnull) nullmask |= 1ULL << j;
         }
         dkey[(int64_t)p.n * stride + i] = nullmask;
@@ -3531,6 +3572,13 @@ namespace {
 // Decide the packing from the key ranges of the first batch: field j holds value codes [0, cap_j) + the NULL code.
 // Spare bits are spread over the fields and the observed range is centred in its field, so later batches may
 // drift in both directions.  Returns true and fills h->pack when the keys fit 63 bits.
+void free_pack_tables(vnm_agg* h) {
+    for (int j = 0; j < AGG_MAX_KEYS; j++) {
+        if (h->pack.dtab[j]) pool_free(h->pack.dtab[j]);
+        h->pack.dtab[j] = nullptr;
+    }
+}
+
 bool plan_packing(vnm_agg* h, const vnm_dcol* keys, int64_t nrows, hipStream_t s, int* err) {
     *err = 0;
     const int n = h->plan.n_keys;
@@ -3556,14 +3604,58 @@ bool plan_packing(vnm_agg* h, const vnm_dcol* keys, int64_t nrows, hipStream_t s
         mn[j] = any ? (int64_t)(got[2 * j] ^ 0x8000000000000000ULL) : 0;
         const int64_t mx = any ? (int64_t)(got[2 * j + 1] ^ 0x8000000000000000ULL) : 0;
         span[j] = (uint64_t)mx - (uint64_t)mn[j];
-        if (span[j] >= (1ULL << 61)) return false;
-        const uint64_t need = span[j] + 2;  // values + the NULL code
         int b = 1;
-        while ((1ULL << b) < need) b++;
+        if (span[j] >= (1ULL << 61)) b = 64;   // only as a dictionary-coded field
+        else {
+            const uint64_t need = span[j] + 2;  // values + the NULL code
+            while ((1ULL << b) < need) b++;
+        }
         need_bits[j] = b;
         total += b;
     }
-    if (total > 63) return false;
+    // ranges too wide for one word: the widest columns become dictionary-coded fields (see PackParams) until the rest
+    // fits.  Each table gets 2.5x the column's estimated distinct count (the estimator reads 8-byte columns;
+    // others are taken as all-distinct up to 2^27), at least 2^12 slots -- and up to 2^20 where bits are left over, so
+    // that a dictionary planned from a small first batch has room for what later batches bring.
+    for (int j = 0; j < AGG_MAX_KEYS; j++) { p.dtab[j] = nullptr; p.dbits[j] = 0; }
+    bool is_dict[AGG_MAX_KEYS] = {};
+    int range_bits[AGG_MAX_KEYS];
+    for (int j = 0; j < n; j++) range_bits[j] = need_bits[j];
+    while (total > 63) {
+        int w = -1;
+        for (int j = 0; j < n; j++)
+            if (!is_dict[j] && (w < 0 || need_bits[j] > need_bits[w])) w = j;
+        if (w < 0 || getenv("VNM_AGG_NO_DICT") != nullptr) return false;
+        int64_t est = std::min<int64_t>(nrows, 1 << 27);
+        if (type_width(keys[w].type) == 8 && (keys[w].offset & 1) == 0) {   // (whatever NULL slots hold only adds to the estimate)
+            if (estimate_groups(h, keys[w], nrows, &est, s)) { *err = 1; return false; }
+        }
+        int tb = 12;
+        while (tb < 30 && (1LL << tb) < est * 5 / 2) tb++;
+        if (tb + 1 >= need_bits[w]) return false;   // no narrower than its range: nothing left to gain
+        is_dict[w] = true;
+        p.dbits[w] = tb;
+        total += tb + 1 - need_bits[w];
+        need_bits[w] = tb + 1;
+        span[w] = 0;
+        mn[w] = 0;
+    }
+    for (bool grew = true; grew && total < 63;) {
+        grew = false;
+        for (int j = 0; j < n && total < 63; j++)
+            if (is_dict[j] && p.dbits[j] < 20 && p.dbits[j] + 2 < range_bits[j]) { p.dbits[j]++; need_bits[j]++; total++; grew = true; }
+    }
+    for (int j = 0; j < n; j++) {
+        if (!is_dict[j]) continue;
+        const size_t bytes = ((size_t)(1ULL << p.dbits[j]) + 1) * 8;
+        p.dtab[j] = (uint64_t*)pool_alloc(bytes);
+        if (!p.dtab[j]) { *err = 1; free_pack_tables(h); return false; }
+        if (hipMemsetAsync(p.dtab[j], 0xFF, bytes, s) != hipSuccess) {
+            *err = set_error("aggregate: key dictionary memset failed");
+            free_pack_tables(h);
+            return false;
+        }
+    }
     const int extra = (63 - total) / n;
     int shift = 0;
     for (int j = 0; j < n; j++) {
@@ -3574,7 +3666,7 @@ bool plan_packing(vnm_agg* h, const vnm_dcol* keys, int64_t nrows, hipStream_t s
         shift += b;
         const uint64_t cap = (1ULL << b) - 1;
         const uint64_t slack = cap - (span[j] + 1);
-        p.lo[j] = (uint64_t)mn[j] - slack / 2;
+        p.lo[j] = p.dtab[j] ? 0 : (uint64_t)mn[j] - slack / 2;
     }
     return true;
 }
@@ -3591,7 +3683,10 @@ int demote_packed(vnm_agg* h, hipStream_t s) {
         if (!keys) rc = 1;
         if (!rc) {
             int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_info().num_cus * 8);
-            key_unpack_kernel<<<grid, 256, 0, s>>>(h->pack, in->dkey, n, keys, n);
+            {
+                KernelTimer timer("agg_demote", s);
+                key_unpack_kernel<<<grid, 256, 0, s>>>(h->pack, in->dkey, n, keys, n);
+            }
             uint64_t* kp[AGG_MAX_KEYS + 1];
             uint64_t* ap[AGG_MAX_WORDS];
             for (int j = 0; j < kw; j++) kp[j] = keys + (size_t)j * n;
@@ -3602,6 +3697,8 @@ int demote_packed(vnm_agg* h, hipStream_t s) {
         pool_free(keys);
     }
     vnm_agg_destroy(in);
+    if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = set_error("aggregate: demotion failed");
+    free_pack_tables(h);   // the unpack above was their last reader
     return rc;
 }
 
@@ -3642,6 +3739,7 @@ vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs,
 void vnm_agg_destroy(vnm_agg* h) {
     if (!h) return;
     if (h->inner) { vnm_agg_destroy(h->inner); h->inner = nullptr; }
+    free_pack_tables(h);
     if (h->have_table) table_free(&h->g);
     invalidate_result(h);
     drop_run(h);

@@ -48,7 +48,7 @@ int ensure_init();
 // re-used across calls so steady-state batches never hit hipMalloc/hipFree.
 void* pool_alloc(size_t bytes);
 void pool_free(void* p);
-void pool_trim();
+size_t pool_trim();  // releases the cached blocks, returns their bytes
 // Pool blocks owned by a scope: every early return (VNM_HIP / VNM_TRY included) gives them back.  take() = pool_alloc
 // registered with the scope; keep(p) = ownership moves elsewhere (a handle, the caller); done(p) = free it now.
 struct PoolScope {

@@ -87,13 +87,16 @@ void pool_free(void* p) {
     g_free.emplace(it->second, p);
 }
 
-void pool_trim() {
+size_t pool_trim() {
     std::lock_guard<std::mutex> g(g_pool_mu);
+    size_t bytes = 0;
     for (auto& kv : g_free) {
+        bytes += kv.first;
         g_sizes.erase(kv.second);
         (void)hipFree(kv.second);
     }
     g_free.clear();
+    return bytes;
 }
 
 Predicate make_predicate(int col_type, bool col_has_nulls, int op, int scalar_is_float, double dval, int64_t ival) {
@@ -335,6 +338,10 @@ void* vnm_malloc(int64_t bytes) {
 int vnm_free(void* p) {
     pool_free(p);
     return 0;
+}
+
+int64_t vnm_pool_trim(void) {
+    return (int64_t)pool_trim();
 }
 
 int vnm_memcpy_h2d(void* dst, const void* src, int64_t bytes) {

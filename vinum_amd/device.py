@@ -43,6 +43,12 @@ def is_supported(t: pa.DataType) -> bool:
         return False
 
 
+def pool_trim() -> int:
+    """Give the HBM the library's caching allocator holds but nobody uses back to the device; returns the bytes released
+    (vnm_pool_trim).  Live buffers are untouched."""
+    return int(L.lib().vnm_pool_trim())
+
+
 class DeviceBuffer:
     """Owning handle on library-allocated HBM."""
 
