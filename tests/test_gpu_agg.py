@@ -505,6 +505,53 @@ def test_multi_key_packed_composite_keys(scenario):
         util.assert_agg_equal(got, o.result(), funcs, names, what=f"packed multi-key {scenario} pred={pred}")
 
 
+@pytest.mark.parametrize("ncols,nulls", [(3, False), (4, False), (5, False), (4, True), (5, True), (6, False), (7, False)])
+def test_many_input_columns_take_the_partitioned_path(ncols, nulls):
+    """SELECT k, sum(c1), min(c2), avg(c3), ... GROUP BY k with many groups: the partition entries carry the key and up to six
+    input values (or five and a validity word), and the final pass shrinks its LDS table until the accumulator words fit
+    (three float SUMs + counts used to exceed the LDS and fall back to per-row HBM atomics: 300 ms per 1e9 rows).  Seven columns
+    still take the general path.  Mixed column types, NULLs, a predicate; bit-exact against the oracle."""
+    import ctypes
+    from oracle import oracle as O
+    from vinum_amd import _lib as L
+    rng = np.random.default_rng(ncols * 2 + nulls)
+    n, groups = 1_500_000, 60_000
+    k = rng.integers(0, groups, n).astype(np.int64) * 977 - 12345
+    cols = {"k": pa.array(k)}
+    funcs = []
+    kinds = [O.SUM, O.MIN, O.AVG, O.MAX, O.COUNT, O.SUM, O.MIN]
+    for c in range(ncols):
+        if c % 3 == 0:
+            vals = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
+        elif c % 3 == 1:
+            vals = rng.integers(-2**31, 2**31, n).astype(np.int32)
+        else:
+            vals = rng.integers(-2**40, 2**40, n).astype(np.int64)
+        mask = (rng.random(n) < 0.1) if (nulls and c % 2 == 0) else None
+        cols[f"c{c}"] = pa.array(vals, mask=mask)
+        funcs.append((kinds[c], f"c{c}", f"f{c}"))
+    funcs.append((O.COUNT_STAR, "", "n"))
+    t = pa.table(cols)
+    batches = util.sliced_batches(t, n // 2)
+
+    def launches(name):
+        ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+        L.lib().vnm_profile_query(name, ctypes.byref(ms), ctypes.byref(cnt))
+        return cnt.value
+    for pred in (None, ("c0", ">", 64.0)):
+        L.lib().vnm_set_profiling(1)
+        got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=pred, expected_groups=groups)
+        p1 = launches(b"agg_part_scatter1")
+        L.lib().vnm_set_profiling(0)
+        assert (p1 == 0) if ncols == 7 else (p1 >= 1), p1
+        o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+        for bt in batches:
+            if pred:
+                bt = O.filter_batch(bt, O.cmp_mask(bt.column(1), O.GT, 64.0))
+            o.next(bt)
+        util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"{ncols} input columns nulls={nulls} pred={pred}")
+
+
 @pytest.mark.parametrize("scenario", ["two_wide_int64", "float_and_wide", "many_distinct", "new_values_later",
                                       "three_wide", "four_wide", "six_wide_no_fit", "wide_plus_dims", "table_overflow"])
 def test_multi_key_dictionary_coded_fields(scenario):

@@ -1,0 +1,33 @@
+"""C input columns: SELECT k, sum(c1), ..., sum(cC), count(*) GROUP BY k  (wide partition entries carry key + C values).
+usage: manycol.py N G C"""
+import sys, time
+sys.path.insert(0, ".")
+import torch, pyarrow as pa
+from vinum_amd import _lib as L, ops
+from vinum_amd.device import DeviceColumn
+n = int(float(sys.argv[1])); G = int(float(sys.argv[2])); C = int(sys.argv[3])
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev); g.manual_seed(1)
+k = torch.randint(0, G, (n,), device=dev, dtype=torch.int64, generator=g)
+cols = [torch.randint(0, 2**14, (n,), device=dev, dtype=torch.int64, generator=g).to(torch.float64) / 128.0 for _ in range(C)]
+ck = DeviceColumn.from_torch(k)
+cc = [DeviceColumn.from_torch(c) for c in cols]
+import ctypes
+lib = L.lib()
+for rep in range(3):
+    lib.vnm_set_profiling(1)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1 + i, pa.float64()) for i in range(C)] + [(L.COUNT_STAR, None, None)],
+                              expected_groups=G)
+    agg.next([ck], cc + [None], nrows=n)
+    ng = agg.finish()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    spans = {}
+    for nm in (b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final"):
+        ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+        lib.vnm_profile_query(nm, ctypes.byref(ms), ctypes.byref(cnt))
+        if cnt.value:
+            spans[nm.decode()] = round(ms.value, 2)
+    lib.vnm_set_profiling(0)
+    print(f"C={C} G={G}: {dt*1e3:.1f} ms, {ng} groups  {spans}")
+    del agg

@@ -125,7 +125,7 @@ struct AggArgs {
     const ulonglong2* ent;  // agg_hot_kernel<FROM_ENT>: (key, value bits) entries spilled by the partitioned path
     int part_generic;  // partitioned path with a generic accumulator program over one 8-byte column (or none)
     int part_vtype;
-    int part_vtypes[3];  // wide entries: type of each input column
+    int part_vtypes[6];  // wide entries: type of each input column
     int part_wide;       // wide entries (several input columns, NULLs, narrow types, any predicate column)
     int part_vmask;      // ... with a validity word
     int debug;  // timing experiments (VNM_AGG_DEBUG): 1 = no accumulator ops, 2 = no probes either, 4 = no room check
@@ -1279,7 +1279,7 @@ struct PartArgs {
     int64_t spill_cap;
     int debug;
     // wide entries (part_scatter_wide_kernel): key + nval raw values per entry
-    vnm_dcol vcols[3];   // input columns (any numeric type, NULLs allowed)
+    vnm_dcol vcols[6];   // input columns (any numeric type, NULLs allowed)
     int nval;
     int has_vmask;       // last entry word = validity bits of the input columns (some column has a bitmap)
     Predicate wp;        // generic predicate over wpred (any type)
@@ -1492,13 +1492,13 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------
-// Wide entries: aggregates over 2-3 input columns carry (key, v1, v2[, v3]) = E 8-byte words per entry.  Same
+// Wide entries: aggregates over 2-6 input columns carry (key, v1, v2[, v3 ...]) = E <= 7 8-byte words per entry.  Same
 // passes and region bookkeeping as part_scatter_kernel, 4096-entry tiles (the LDS stage holds E words per entry),
 // 8-byte column loads, no prefetch and no spill buffer: a straightforward version -- it only has to beat the HBM
 // atomics of the general path (two input columns, G >= 1e5: 217-250 ms per 1e9 rows).
 // -------------------------------------------------------------------------------------------------------
 // items per lane and tile: one- and two-word entries get 8192-entry tiles (twice the run length), wider ones 4096
-constexpr int pw_items(int E) { return E <= 2 ? 8 : 4; }
+constexpr int pw_items(int E) { return E <= 2 ? 8 : (E <= 4 ? 4 : 2); }   // 2048-entry tiles for 5- to 7-word entries (up to 112 KB of LDS)
 constexpr int pw_tile(int E) { return PT_BLOCK * pw_items(E); }
 // IT: items per lane and tile (8 only for one- and two-word entries; pass 2 keeps 4 when it has few sub-partitions:
 // its runs are long anyway and three resident workgroups beat one)
@@ -1662,13 +1662,13 @@ struct PartAggArgs {
     int ent_words;   // 2 = (key, value); 3 / 4 = key + values [+ validity word] (wide entries)
     int has_vmask;   // wide entries: last word = validity bits of the input columns
     int wide;        // values are raw bits of any numeric width (vtypes[]), not 8-byte values of type vtype
-    int vtypes[3];
+    int vtypes[6];
     AccOp ops[AGG_MAX_OPS];
     int merge[AGG_MAX_WORDS];
     // the same program as a table (part_agg_generic_kernel, when every (kind, column) occurs once): 6 bits per
     // AccKind = accumulator word, 63 = absent; COUNT(*) separately.  Two scalar registers per column instead of
     // kernel-argument loads (and their lgkmcnt waits) inside the entry loop.
-    unsigned long long wpack[3];
+    unsigned long long wpack[6];
     int w_rows_g, use_table, nval;
     int slots;  // LDS table size of part_agg_generic_kernel
     int comp;   // float64 sums are compensated (hi, lo) pairs
@@ -2875,14 +2875,18 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     const int64_t l1_cap = env_i64("VNM_AGG_PART_L1_MAX", 256) * 512;
     const bool small_tables = a.part_generic && (size_t)(PA_SLOTS + 1) * 8 * (1 + h->plan.n_words) > 54 * 1024 &&
                               h->hint / 450 < l1_cap && getenv("VNM_AGG_NO_SMALL_TABLES") == nullptr;
-    const int pa_slots = small_tables ? PA_SLOTS / 2 : PA_SLOTS;
-    const int64_t per_final = env_i64("VNM_AGG_PART_GROUPS", small_tables ? 450 : 900);
+    int pa_slots = small_tables ? PA_SLOTS / 2 : PA_SLOTS;
+    // ... and programs with so many words that even that table exceeds the LDS (three compensated float SUMs + their
+    // counts + COUNT(*) = 10 words: 180 KB at 2048 slots) halve it until it fits: more, smaller partitions instead of
+    // the HBM-atomics path (300 ms per 1e9 rows)
+    while (a.part_generic && pa_slots > 256 && (size_t)(pa_slots + 1) * 8 * (1 + h->plan.n_words) > 150 * 1024) pa_slots /= 2;
+    const int64_t per_final = env_i64("VNM_AGG_PART_GROUPS", 900 * pa_slots / PA_SLOTS);
     int64_t nfin = 2;
     while (nfin * per_final < h->hint) nfin *= 2;
     const int64_t l1_max = env_i64("VNM_AGG_PART_L1_MAX", 256);
     if (nfin > l1_max * 512) {
         // two levels give at most l1_max * 512 partitions: still fine while a partition's groups fit the LDS table
-        if (h->hint / (l1_max * 512) > 1600) return 2;  // would need a third level
+        if (h->hint / (l1_max * 512) > 1600 * pa_slots / PA_SLOTS) return 2;  // would need a third level
         nfin = l1_max * 512;
     }
     // entry = key + one value (16 bytes, tuned kernels) or key + 2-3 values (wide entries)
@@ -2900,7 +2904,11 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     const int split2 = std::max(2, (grid1 + PT_MAX_REGIONS - 1) / PT_MAX_REGIONS);  // pass-2 workgroups per partition
     const int64_t tiles_per_wg = ((nrows + tile1 - 1) / tile1 + grid1 - 1) / grid1;
     const int64_t rows_per_wg = tiles_per_wg * tile1;
-    const int64_t cap1 = rows_per_wg / np1 + rows_per_wg / np1 / 5 + 512;
+    // region slack: a partition holds per_final / 2 ... per_final keys, so its share of the rows scatters by 1 / sqrt(keys)
+    // around the mean (small LDS tables -> few keys per partition -> up to +42 %; measured: 225 keys per partition
+    // overflowed the 25 % regions of pass 2 at G = 3e5 and 1e6)
+    const double slack = std::max(0.0, 4.5 / std::sqrt((double)std::max<int64_t>(per_final, 16) / 2.0));
+    const int64_t cap1 = rows_per_wg / np1 + (int64_t)((double)(rows_per_wg / np1) * std::max(0.2, slack)) + 512;
     PoolScope pool;   // every block of this attempt; the ones handed on are keep()-ed
     unsigned long long* flags = (unsigned long long*)pool.take(64);
     ulonglong2* e1 = (ulonglong2*)pool.take((size_t)np1 * grid1 * cap1 * ebytes);
@@ -2940,7 +2948,8 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         VNM_HIP(hipFuncSetAttribute((const void*)part_scatter_wide_kernel<FR, E_, IT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         part_scatter_wide_kernel<FR, E_, IT_><<<GRID, PT_BLOCK, lds, s>>>(ARGS);                                     \
     } while (0)
-            if (E == 1) VNM_PSW(true, 1, 8, grid1, p1); else if (E == 2) VNM_PSW(true, 2, 8, grid1, p1); else if (E == 3) VNM_PSW(true, 3, 4, grid1, p1); else VNM_PSW(true, 4, 4, grid1, p1);
+            if (E == 1) VNM_PSW(true, 1, 8, grid1, p1); else if (E == 2) VNM_PSW(true, 2, 8, grid1, p1); else if (E == 3) VNM_PSW(true, 3, 4, grid1, p1); else if (E == 4) VNM_PSW(true, 4, 4, grid1, p1);
+            else if (E == 5) VNM_PSW(true, 5, 2, grid1, p1); else if (E == 6) VNM_PSW(true, 6, 2, grid1, p1); else VNM_PSW(true, 7, 2, grid1, p1);
         }
     }
     VNM_HIP(hipGetLastError());
@@ -2966,7 +2975,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     if (levels == 2) {
         // worst case: every row survived and spread evenly; 25 % slack + constant
         const int64_t per_pg = (int64_t)grid1 * rows_per_wg / np1 / split2;
-        const int64_t cap2 = per_pg / np2 + per_pg / np2 / 4 + 256;
+        const int64_t cap2 = per_pg / np2 + (int64_t)((double)(per_pg / np2) * std::max(0.25, slack)) + 256;
         e2 = (ulonglong2*)pool.take((size_t)np1 * np2 * split2 * cap2 * ebytes);
         c2 = (uint32_t*)pool.take((size_t)np1 * np2 * split2 * 4);
         if (!e2 || !c2) return 1;
@@ -2983,11 +2992,12 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
             if (!wide) part_scatter_kernel<false><<<np1 * p2.in_split, PT_BLOCK, 0, s>>>(p2);
             else {
                 const bool big2 = E <= 2 && np2 >= 128;
-                const size_t lds = (size_t)PT_BLOCK * (big2 ? 8 : 4) * ebytes;
+                const size_t lds = (size_t)PT_BLOCK * (big2 ? 8 : (E <= 4 ? 4 : 2)) * ebytes;
                 const int g2 = np1 * p2.in_split;
                 if (E == 1) { if (big2) VNM_PSW(false, 1, 8, g2, p2); else VNM_PSW(false, 1, 4, g2, p2); }
                 else if (E == 2) { if (big2) VNM_PSW(false, 2, 8, g2, p2); else VNM_PSW(false, 2, 4, g2, p2); }
-                else if (E == 3) VNM_PSW(false, 3, 4, g2, p2); else VNM_PSW(false, 4, 4, g2, p2);
+                else if (E == 3) VNM_PSW(false, 3, 4, g2, p2); else if (E == 4) VNM_PSW(false, 4, 4, g2, p2);
+                else if (E == 5) VNM_PSW(false, 5, 2, g2, p2); else if (E == 6) VNM_PSW(false, 6, 2, g2, p2); else VNM_PSW(false, 7, 2, g2, p2);
             }
         }
 #undef VNM_PSW
@@ -3060,16 +3070,16 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
             pa.ent_words = E;
             pa.wide = wide;
             pa.has_vmask = a.part_vmask;
-            for (int c = 0; c < 3; c++) pa.vtypes[c] = a.part_vtypes[c];
+            for (int c = 0; c < 6; c++) pa.vtypes[c] = a.part_vtypes[c];
             pa.nval = h->plan.n_cols;
             pa.w_rows_g = -1;
             pa.use_table = getenv("VNM_AGG_NO_PART_TABLE") == nullptr;
-            for (int c = 0; c < 3; c++) pa.wpack[c] = ~0ULL;
+            for (int c = 0; c < 6; c++) pa.wpack[c] = ~0ULL;
             for (int o = 0; o < h->plan.n_ops && pa.use_table; o++) {
                 const AccOp& op = h->plan.ops[o];
                 if (op.kind == A_COUNT_ROWS) { if (pa.w_rows_g >= 0) pa.use_table = 0; pa.w_rows_g = op.word; continue; }
                 const int c = op.col < 0 ? 0 : op.col;
-                if (c > 2 || op.kind < 0 || op.kind > A_MAX || op.word >= 63 || ((pa.wpack[c] >> (6 * op.kind)) & 63ULL) != 63) { pa.use_table = 0; break; }
+                if (c > 5 || op.kind < 0 || op.kind > A_MAX || op.word >= 63 || ((pa.wpack[c] >> (6 * op.kind)) & 63ULL) != 63) { pa.use_table = 0; break; }
                 pa.wpack[c] = (pa.wpack[c] & ~(63ULL << (6 * op.kind))) | ((unsigned long long)op.word << (6 * op.kind));
             }
 #define VNM_PAG(E_, T_)                                                                                              \
@@ -3078,8 +3088,8 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
         fit_grid((const void*)part_agg_generic_kernel<E_, T_>, lds_bytes);                                           \
         part_agg_generic_kernel<E_, T_><<<g3, PA_BLOCK, lds_bytes, s>>>(pa);                                         \
     } while (0)
-            if (pa.use_table) { if (E == 1) VNM_PAG(1, true); else if (E == 2) VNM_PAG(2, true); else if (E == 3) VNM_PAG(3, true); else VNM_PAG(4, true); }
-            else { if (E == 1) VNM_PAG(1, false); else if (E == 2) VNM_PAG(2, false); else if (E == 3) VNM_PAG(3, false); else VNM_PAG(4, false); }
+            if (pa.use_table) { if (E == 1) VNM_PAG(1, true); else if (E == 2) VNM_PAG(2, true); else if (E == 3) VNM_PAG(3, true); else if (E == 4) VNM_PAG(4, true); else if (E == 5) VNM_PAG(5, true); else if (E == 6) VNM_PAG(6, true); else VNM_PAG(7, true); }
+            else { if (E == 1) VNM_PAG(1, false); else if (E == 2) VNM_PAG(2, false); else if (E == 3) VNM_PAG(3, false); else if (E == 4) VNM_PAG(4, false); else if (E == 5) VNM_PAG(5, false); else if (E == 6) VNM_PAG(6, false); else VNM_PAG(7, false); }
 #undef VNM_PAG
         } else {
             fit_grid((const void*)part_agg_kernel, 0);
@@ -3959,9 +3969,9 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     // carry (key, raw value bits) and only the final pass interprets them
     bool part_ok = hot;
     bool narrow_generic = false;   // a generic program over (key, one plain 8-byte value or none): the dgen_* dense kernels take it too
-    if (!hot && h->single && h->plan.n_cols <= 3 && type_width(keys[0].type) == 8 && !keys[0].validity &&
+    if (!hot && h->single && h->plan.n_cols <= 6 && type_width(keys[0].type) == 8 && !keys[0].validity &&
         (keys[0].offset & 1) == 0 && getenv("VNM_AGG_NO_PART_GENERIC") == nullptr &&
-        (size_t)(PA_SLOTS + 1) * 8 * (1 + h->plan.n_words) <= 150 * 1024) {
+        (size_t)(256 + 1) * 8 * (1 + h->plan.n_words) <= 150 * 1024) {   // (the final pass shrinks its LDS table to fit)
         // narrow entries (key, value): at most one 8-byte input column without NULLs, float64 predicate column
         bool narrow = h->plan.n_cols <= 1;
         bool any_null = false;
@@ -3977,8 +3987,8 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
             a.hot_pred_is_v = h->plan.n_cols == 1 && a.pred.values == a.cols[0].values && a.pred.offset == a.cols[0].offset;
         }
         // wide entries take the rest: several columns, NULLs, narrow types, any predicate -- while key + values
-        // (+ validity word) fit four words
-        const bool wide = !narrow && h->plan.n_cols >= 1 && h->plan.n_cols + (any_null ? 1 : 0) <= 3 &&
+        // (+ validity word) fit seven words
+        const bool wide = !narrow && h->plan.n_cols >= 1 && h->plan.n_cols + (any_null ? 1 : 0) <= 6 &&
                           getenv("VNM_AGG_NO_PART_WIDE") == nullptr;
         part_ok = narrow || wide;
         narrow_generic = narrow;
