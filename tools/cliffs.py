@@ -1,6 +1,6 @@
 """Cliff finder: one process, a matrix of GROUP BY shapes (key kind x group count x aggregate program x predicate) over the same
 resident columns, second-run wall time each, scaled to ms per 1e9 rows and sorted -- anything far above its neighbours took a
-slow dispatch path.  usage: cliffs.py [N]"""
+slow dispatch path.  usage: cliffs.py [N] [nulls]   (nulls: the second matrix -- nullable keys and nullable input columns)"""
 import itertools, sys, time
 sys.path.insert(0, ".")
 import torch, pyarrow as pa
@@ -17,11 +17,11 @@ f32 = torch.rand(n, device=dev, dtype=torch.float32, generator=g)
 valid_bits = torch.randint(0, 256, ((n + 7) // 8,), device=dev, dtype=torch.uint8, generator=g) | 1   # ~half the rows NULL
 
 
+NULLS = len(sys.argv) > 2 and sys.argv[2] == "nulls"
+
+
 def col(t, nullable=False):
-    c = DeviceColumn.from_torch(t)
-    if nullable:
-        c = DeviceColumn.from_torch(t, validity=valid_bits) if "validity" in DeviceColumn.from_torch.__code__.co_varnames else c
-    return c
+    return DeviceColumn.from_torch(t, validity=valid_bits if nullable else None)
 
 
 def keyset(kind, G):
@@ -38,6 +38,11 @@ def keyset(kind, G):
     if kind == "wide2":
         g1 = max(1, int(G ** 0.5))
         return [(col((base % g1) * (1 << 44) - (1 << 61)), pa.int64()), (col((base // g1) * (1 << 40) + 12345), pa.int64())]
+    if kind == "i64n":
+        return [(col(base * 977 - 5, True), pa.int64())]
+    if kind == "i64x2n":
+        g1 = max(1, int(G ** 0.5))
+        return [(col(base % g1, True), pa.int64()), (col(base // g1), pa.int64())]
     raise ValueError(kind)
 
 
@@ -53,15 +58,27 @@ PROGRAMS = {
     "sum_f64+sum_i64+min_i32": lambda: ([(L.SUM, 1, pa.float64()), (L.SUM, 2, pa.int64()), (L.MIN, 3, pa.int32())], [col(f64), col(i64), col(i32)]),
     "count_f64+count*": lambda: ([(L.COUNT, 1, pa.float64()), (L.COUNT_STAR, None, None)], [col(f64), None]),
 }
+if NULLS:
+    PROGRAMS = {
+        "count*": PROGRAMS["count*"],
+        "sum_f64": PROGRAMS["sum_f64"],
+        "sum_f64n": lambda: ([(L.SUM, 1, pa.float64())], [col(f64, True)]),
+        "sum_avg_f64n": lambda: ([(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())], [col(f64, True)] * 2),
+        "minmax_i64n": lambda: ([(L.MIN, 1, pa.int64()), (L.MAX, 1, pa.int64())], [col(i64, True)] * 2),
+        "count_f64n+count*": lambda: ([(L.COUNT, 1, pa.float64()), (L.COUNT_STAR, None, None)], [col(f64, True), None]),
+        "sum_f64n+max_i64": lambda: ([(L.SUM, 1, pa.float64()), (L.MAX, 2, pa.int64())], [col(f64, True), col(i64)]),
+        "avg_i32n": lambda: ([(L.AVG, 1, pa.int32())], [col(i32, True)]),
+    }
 PREDS = {"none": None, "f64>": ("f64", ">", 32.0), "i32>": ("i32", ">", 0)}
-pred_cols = {"f64": col(f64), "i32": col(i32)}
+pred_cols = {"f64": col(f64, NULLS), "i32": col(i32)}
 
 rows = []
-for kind, G in itertools.product(["i64", "i32", "f64", "i64x2", "wide2"], [10, 10_000, 1_000_000, 20_000_000]):
+KINDS = ["i64", "i64n", "i64x2n"] if NULLS else ["i64", "i32", "f64", "i64x2", "wide2"]
+for kind, G in itertools.product(KINDS, [10, 10_000, 1_000_000, 20_000_000]):
     ks = keyset(kind, G)
     for pname, mk in PROGRAMS.items():
         for prname, pr in PREDS.items():
-            if prname != "none" and pname not in ("sum_f64", "sum_avg_f64", "minmax_i64", "sum_f64+max_i64"):
+            if prname != "none" and pname not in ("sum_f64", "sum_avg_f64", "minmax_i64", "sum_f64+max_i64", "sum_f64n", "sum_avg_f64n", "minmax_i64n"):
                 continue
             spec, inputs = mk()
             ms = None

@@ -1388,13 +1388,15 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_kernel(PartArgs a) {
             if (tid == 0) { s_spill_base = atomicAdd(&a.flags[2], (unsigned long long)nspill); s_spill = 0; }
             __syncthreads();
             const unsigned long long sb = s_spill_base;
+            // the spill buffer itself full (more than half of the rows in overflowing regions): one flag store per tile,
+            // not one per lost entry (agent-scope stores to one address serialise: 50 ms per 1e8 of them)
+            if (tid == 0 && (int64_t)(sb + nspill) > a.spill_cap) __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (uint32_t i = tid; i < total; i += PT_BLOCK) {
                 uint32_t p = part_of[i];
                 uint32_t j = cursor[p] + (i - off[p]);
                 if (j < (uint32_t)a.out_cap) continue;
                 const unsigned long long pos = sb + atomicAdd(&s_spill, 1u);
                 if ((int64_t)pos < a.spill_cap) a.spill[pos] = stage[i];
-                else __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
             if (tid == 0) s_spill = 0;
@@ -1509,6 +1511,7 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_wide_kernel(PartArgs a)
     __shared__ uint16_t part_of[PW_TILE];
     __shared__ uint32_t cnt[PT_MAXP], off[PT_MAXP], cursor[PT_MAXP];
     __shared__ uint32_t s_total;
+    __shared__ uint32_t s_over;   // a region of this workgroup is full: the attempt is lost, stop working on it
     __shared__ uint32_t wtot[PT_MAXP / 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1516,6 +1519,7 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_wide_kernel(PartArgs a)
     const uint32_t pmask = (uint32_t)np - 1;
     const int npad = np < 64 ? 64 : np;
     for (int i = tid; i < PT_MAXP; i += PT_BLOCK) { cnt[i] = 0; cursor[i] = 0; }
+    if (tid == 0) s_over = 0;
     __syncthreads();
     uint64_t* const oute = (uint64_t*)a.out_entries;
     const uint64_t* const ine = (const uint64_t*)a.in_entries;
@@ -1571,7 +1575,7 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_wide_kernel(PartArgs a)
                 uint64_t* dst = oute + (((out_base + (int64_t)p * out_stride) * a.out_cap + j) * E);
 #pragma unroll
                 for (int e = 0; e < E; e++) dst[e] = wstage[i * E + e];
-            } else __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else s_over = 1;   // (an agent-scope store per lost entry here: 1e8 rows of one heavy key = 50 ms of stores to one address)
         }
         __syncthreads();
         if (tid < np) { cursor[tid] += cnt[tid]; cnt[tid] = 0; }
@@ -1579,7 +1583,7 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_wide_kernel(PartArgs a)
     };
     if (FROM_ROWS) {
         const int64_t ntiles = (a.nrows + PW_TILE - 1) / PW_TILE;
-        for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (int64_t tile = blockIdx.x; tile < ntiles && !s_over; tile += gridDim.x) {
             uint32_t valid = 0;
 #pragma unroll
             for (int k = 0; k < PW_ITEMS; k++) {
@@ -1617,7 +1621,7 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_wide_kernel(PartArgs a)
         int reg[PW_ITEMS];
 #pragma unroll
         for (int k = 0; k < PW_ITEMS; k++) reg[k] = 0;
-        for (uint32_t t0 = 0; t0 < total_in; t0 += PW_TILE) {
+        for (uint32_t t0 = 0; t0 < total_in && !s_over; t0 += PW_TILE) {
             uint32_t valid = 0;
 #pragma unroll
             for (int k = 0; k < PW_ITEMS; k++) {
@@ -1635,6 +1639,7 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_wide_kernel(PartArgs a)
             process_tile(valid);
         }
     }
+    if (tid == 0 && s_over) __hip_atomic_store(&a.flags[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < np) a.out_counts[out_base + (int64_t)tid * out_stride] = cursor[tid] < (uint32_t)a.out_cap ? cursor[tid] : (uint32_t)a.out_cap;
 }
 
