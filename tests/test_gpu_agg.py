@@ -505,6 +505,57 @@ def test_multi_key_packed_composite_keys(scenario):
         util.assert_agg_equal(got, o.result(), funcs, names, what=f"packed multi-key {scenario} pred={pred}")
 
 
+@pytest.mark.parametrize("program", ["count", "two_cols", "nullable_col", "three_cols_i32"])
+@pytest.mark.parametrize("heavy", ["null_key_half", "one_value_half", "three_values_2pct"])
+def test_heavy_keys_spill_from_wide_entries(program, heavy):
+    """A key holding half of the rows (NULL keys, a default value) or a few keys with 2 % each, next to 60 000 ordinary groups:
+    their partition regions fill up and the wide scatter kernels spill the entries (as the hot shape always did); the spilled
+    entries come back as columns (spill_unzip_kernel) for the general scan, the rest stays on the partitioned path.  Before: one
+    full region sent the whole batch to the per-row HBM-atomics path.  Bit-exact against the oracle."""
+    import ctypes
+    from oracle import oracle as O
+    from vinum_amd import _lib as L
+    rng = np.random.default_rng(len(program) * 31 + len(heavy))
+    n, groups = 1_200_000, 60_000
+    k = rng.integers(0, groups, n).astype(np.int64) * 977 - 12345
+    kmask = None
+    if heavy == "null_key_half":
+        kmask = rng.random(n) < 0.5
+    elif heavy == "one_value_half":
+        k[rng.random(n) < 0.5] = 7
+    else:
+        r = rng.random(n)
+        for j, val in enumerate((-1, 5, 2**40)):          # -1: the bit pattern of the tables' EMPTY word
+            k[(r >= 0.02 * j) & (r < 0.02 * (j + 1))] = val
+    cols = {"k": pa.array(k, mask=kmask)}
+    cols["a"] = pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0)
+    cols["b"] = pa.array(rng.integers(-2**40, 2**40, n).astype(np.int64), mask=(rng.random(n) < 0.2) if program == "nullable_col" else None)
+    cols["c"] = pa.array(rng.integers(-2**20, 2**20, n).astype(np.int32))
+    funcs = {"count": [(O.COUNT_STAR, "", "n")],
+             "two_cols": [(O.SUM, "a", "s"), (O.MAX, "b", "hi"), (O.COUNT_STAR, "", "n")],
+             "nullable_col": [(O.SUM, "a", "s"), (O.MIN, "b", "lo"), (O.COUNT, "b", "nb")],
+             "three_cols_i32": [(O.AVG, "a", "m"), (O.SUM, "b", "sb"), (O.MIN, "c", "lo"), (O.COUNT_STAR, "", "n")]}[program]
+    t = pa.table(cols)
+    batches = util.sliced_batches(t, n // 2)
+
+    def launches(name):
+        ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+        L.lib().vnm_profile_query(name, ctypes.byref(ms), ctypes.byref(cnt))
+        return cnt.value
+    for pred in (None, ("a", ">", 64.0)):
+        L.lib().vnm_set_profiling(1)
+        got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=pred, expected_groups=groups)
+        fin = launches(b"agg_part_final")
+        L.lib().vnm_set_profiling(0)
+        assert fin >= len(batches), fin              # every batch finished on the partitioned path
+        o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+        for bt in batches:
+            if pred:
+                bt = O.filter_batch(bt, O.cmp_mask(bt.column(1), O.GT, 64.0))
+            o.next(bt)
+        util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"heavy keys {heavy} {program} pred={pred}")
+
+
 @pytest.mark.parametrize("ncols,nulls", [(3, False), (4, False), (5, False), (4, True), (5, True), (6, False), (7, False)])
 def test_many_input_columns_take_the_partitioned_path(ncols, nulls):
     """SELECT k, sum(c1), min(c2), avg(c3), ... GROUP BY k with many groups: the partition entries carry the key and up to six

@@ -1511,7 +1511,9 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_wide_kernel(PartArgs a)
     __shared__ uint16_t part_of[PW_TILE];
     __shared__ uint32_t cnt[PT_MAXP], off[PT_MAXP], cursor[PT_MAXP];
     __shared__ uint32_t s_total;
-    __shared__ uint32_t s_over;   // a region of this workgroup is full: the attempt is lost, stop working on it
+    __shared__ uint32_t s_over;   // a region of this workgroup is full and there is no spill buffer (or it is full too): the attempt is lost, stop working on it
+    __shared__ uint32_t s_spill;
+    __shared__ unsigned long long s_spill_base;
     __shared__ uint32_t wtot[PT_MAXP / 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1519,9 +1521,10 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_wide_kernel(PartArgs a)
     const uint32_t pmask = (uint32_t)np - 1;
     const int npad = np < 64 ? 64 : np;
     for (int i = tid; i < PT_MAXP; i += PT_BLOCK) { cnt[i] = 0; cursor[i] = 0; }
-    if (tid == 0) s_over = 0;
+    if (tid == 0) { s_over = 0; s_spill = 0; }
     __syncthreads();
     uint64_t* const oute = (uint64_t*)a.out_entries;
+    uint64_t* const spill = (uint64_t*)a.spill;   // [spill_cap][E] words: entries of full regions (heavy keys), as in part_scatter_kernel
     const uint64_t* const ine = (const uint64_t*)a.in_entries;
     int64_t out_base, out_stride;
     if (FROM_ROWS) { out_base = blockIdx.x; out_stride = gridDim.x; }
@@ -1575,7 +1578,32 @@ __global__ __launch_bounds__(PT_BLOCK) void part_scatter_wide_kernel(PartArgs a)
                 uint64_t* dst = oute + (((out_base + (int64_t)p * out_stride) * a.out_cap + j) * E);
 #pragma unroll
                 for (int e = 0; e < E; e++) dst[e] = wstage[i * E + e];
-            } else s_over = 1;   // (an agent-scope store per lost entry here: 1e8 rows of one heavy key = 50 ms of stores to one address)
+            } else if (spill) atomicAdd(&s_spill, 1u);
+            else s_over = 1;   // (an agent-scope store per lost entry here: 1e8 rows of one heavy key = 50 ms of stores to one address)
+        }
+        __syncthreads();
+        const uint32_t nspill = s_spill;  // uniform: read by everyone before thread 0 resets it
+        if (nspill) {   // one global atomic per tile reserves the spilled entries' places; they are found again here
+            __syncthreads();
+            if (tid == 0) {
+                s_spill_base = atomicAdd(&a.flags[2], (unsigned long long)nspill);
+                s_spill = 0;
+                if ((int64_t)(s_spill_base + nspill) > a.spill_cap) s_over = 1;
+            }
+            __syncthreads();
+            const unsigned long long sb = s_spill_base;
+            for (uint32_t i = tid; i < total; i += PT_BLOCK) {
+                uint32_t p = part_of[i];
+                uint32_t j = cursor[p] + (i - off[p]);
+                if (j < (uint32_t)a.out_cap) continue;
+                const unsigned long long pos = sb + atomicAdd(&s_spill, 1u);
+                if ((int64_t)pos < a.spill_cap) {
+#pragma unroll
+                    for (int e = 0; e < E; e++) spill[pos * E + e] = wstage[i * E + e];
+                }
+            }
+            __syncthreads();
+            if (tid == 0) s_spill = 0;
         }
         __syncthreads();
         if (tid < np) { cursor[tid] += cnt[tid]; cnt[tid] = 0; }
@@ -2861,6 +2889,43 @@ int estimate_groups(vnm_agg* h, const vnm_dcol& key, int64_t nrows, int64_t* est
     return 0;
 }
 
+// Spilled wide entries [n][E] -> plain columns (key, the input columns at their own widths, validity bitmaps for the
+// nullable ones), so that the general scan takes them like any batch.
+struct UnzipArgs {
+    const uint64_t* ent;
+    int64_t n;
+    int E, nval, has_vmask;
+    uint64_t* key;
+    void* vals[6];
+    int widths[6];
+    unsigned long long* valid[6];   // nullptr: the column had no bitmap
+};
+__global__ __launch_bounds__(256) void spill_unzip_kernel(UnzipArgs u) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t n64 = (u.n + 63) / 64 * 64;   // whole waves: the ballots below cover 64 consecutive entries
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n64; i += stride) {
+        const bool in = i < u.n;
+        const uint64_t* e = u.ent + (in ? i : u.n - 1) * u.E;
+        if (in) u.key[i] = e[0];
+        const uint64_t vmask = u.has_vmask ? e[u.E - 1] : ~0ULL;
+        for (int c = 0; c < u.nval; c++) {
+            const uint64_t raw = e[1 + c];
+            if (in) {
+                switch (u.widths[c]) {
+                    case 1: ((uint8_t*)u.vals[c])[i] = (uint8_t)raw; break;
+                    case 2: ((uint16_t*)u.vals[c])[i] = (uint16_t)raw; break;
+                    case 4: ((uint32_t*)u.vals[c])[i] = (uint32_t)raw; break;
+                    default: ((uint64_t*)u.vals[c])[i] = raw; break;
+                }
+            }
+            if (u.valid[c]) {
+                const unsigned long long b = __ballot(in && ((vmask >> c) & 1ULL));
+                if ((threadIdx.x & 63) == 0) u.valid[c][i >> 6] = b;
+            }
+        }
+    }
+}
+
 }  // namespace
 static int merge_run_into_table(vnm_agg* h, hipStream_t s);
 namespace {
@@ -2899,7 +2964,6 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     const bool wide = a.part_wide != 0;  // generic column accessors (any width, NULLs, any predicate column)
     const int64_t tile1 = wide ? pw_tile(E) : PT_TILE;
     const size_t ebytes = (size_t)E * 8;
-    if (wide) { spill_out = nullptr; n_spill_out = nullptr; }
     // twice the usual first-level fan-out still beats a second level that would only split in two (G = 3e5 sparse keys:
     // 512 partitions in one pass 7.4 + 1.9 ms; 256 x 2: 6.7 + 3.7 + 2.0)
     const int levels = nfin > std::min<int64_t>(l1_max * 2, PT_MAXP) ? 2 : 1;
@@ -2921,7 +2985,7 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
     if (!flags || !e1 || !c1) return 1;
     VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
     const int64_t spill_cap = spill_out ? nrows / 2 + (1 << 20) : 0;
-    ulonglong2* spill = spill_out ? (ulonglong2*)pool.take((size_t)spill_cap * 16) : nullptr;
+    ulonglong2* spill = spill_out ? (ulonglong2*)pool.take((size_t)spill_cap * (wide ? ebytes : 16)) : nullptr;   // wide: [spill_cap][E] words
     if (spill_out && !spill) return 1;
     PartArgs p1{};
     p1.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
@@ -4044,6 +4108,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     ulonglong2* spill = nullptr;  // entries the partitioned / dense paths could not place (heavy keys, keys outside the sampled range): aggregated below
     int64_t n_spill = 0;
     unsigned int* progress = nullptr;
+    PoolScope unzip;   // spilled wide entries as columns
     PoolSlotGuard<ulonglong2> spill_guard(&spill);       // both go back to the pool on every way out of this function
     PoolSlotGuard<unsigned int> progress_guard(&progress);
     // a few hundred to a few thousand groups in a small key range: the direct-addressed LDS scan (vnm_agg_dense.inc)
@@ -4076,8 +4141,17 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     const int64_t part_min = env_i64("VNM_AGG_PART_MIN_GROUPS", std::min<int64_t>(2400, (int64_t)S * 6 / 10));
     if (!dscan_done && part_ok && (h->hint > part_min || dense_go) && getenv("VNM_AGG_NO_PART") == nullptr) {
         if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
-        const bool can_spill = hot_scan && !hot_two && !hot_vnull && getenv("VNM_AGG_NO_SPILL") == nullptr;
+        // wide entries (any program over up to six columns, key-only entries) spill as whole entries; they come back as
+        // plain columns for the general scan below (spill_unzip_kernel)
+        const bool spill_wide = a.part_wide && h->single && !a.has_expr && getenv("VNM_AGG_NO_SPILL") == nullptr && getenv("VNM_AGG_NO_WIDE_SPILL") == nullptr;
+        const bool can_spill = (hot_scan && !hot_two && !hot_vnull && getenv("VNM_AGG_NO_SPILL") == nullptr) || spill_wide;
         int prc = 2;
+        bool spill_is_wide = false;   // the spill holds [n][E]-word entries of the wide scatter kernels (not the (key, value) pairs of the hot / dense paths)
+        auto run_partitioned = [&]() {
+            const int r = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
+            spill_is_wide = r == 0 && spill != nullptr && a.part_wide != 0;
+            return r;
+        };
         if (dense_go && (h->hint > part_min || h->hint == 0)) {
             prc = dense_partitioned_aggregate(h, a, nrows, s, &spill, &n_spill, dense_generic);
             if (prc == 2 && h->hint == 0) {  // the dense attempt failed before G was ever estimated
@@ -4087,11 +4161,11 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
                 h->estimated = true;
             }
         }
-        if (prc == 2 && h->hint > part_min) prc = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
+        if (prc == 2 && h->hint > part_min) prc = run_partitioned();
         if (prc == 2 && a.part_wide && h->plan.n_cols == 0) {  // key-only entries and a region overflowed: see above
             h->key_only_failed = true;
             a.part_wide = 0;
-            prc = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
+            prc = run_partitioned();
         }
         // more groups than hinted (a partition overflowed its LDS table, or the dense output its allocation): estimate
         // the group count from the keys (< 1 ms) and partition again (~12 ms per attempt) before giving in to the HBM
@@ -4103,11 +4177,35 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
                 h->estimated = true;
             }
             h->hint = std::min<int64_t>(std::max<int64_t>(h->hint * 4, est + est / 4), (int64_t)1600 * env_i64("VNM_AGG_PART_L1_MAX", 256) * 512);
-            prc = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
+            prc = run_partitioned();
         }
         if (prc == 0 && !spill) { h->rows_seen += nrows; return 0; }
         if (prc == 1) return 1;
-        if (prc == 0) {  // the scan below runs over the spilled entries only (predicate already applied)
+        if (prc == 0 && spill_is_wide) {   // spilled wide entries -> columns; the general scan takes them as a batch of its own
+            const int E = 1 + h->plan.n_cols + (a.part_vmask ? 1 : 0);
+            UnzipArgs u{};
+            u.ent = (const uint64_t*)spill; u.n = n_spill; u.E = E; u.nval = h->plan.n_cols; u.has_vmask = a.part_vmask;
+            u.key = (uint64_t*)unzip.take((size_t)n_spill * 8);
+            bool ok = u.key != nullptr;
+            for (int c = 0; c < h->plan.n_cols && ok; c++) {
+                u.widths[c] = type_width(a.cols[c].type);
+                u.vals[c] = unzip.take((size_t)n_spill * u.widths[c]);
+                u.valid[c] = a.cols[c].validity ? (unsigned long long*)unzip.take((size_t)((n_spill + 63) / 64) * 8) : nullptr;
+                ok = u.vals[c] && (!a.cols[c].validity || u.valid[c]);
+            }
+            if (!ok) return 1;
+            const int ugrid = (int)std::min<int64_t>((n_spill + 255) / 256, (int64_t)cus * 8);
+            spill_unzip_kernel<<<ugrid, 256, 0, s>>>(u);
+            VNM_HIP(hipGetLastError());
+            a.keys[0].values = u.key; a.keys[0].validity = nullptr; a.keys[0].offset = 0; a.keys[0].length = n_spill;
+            for (int c = 0; c < h->plan.n_cols; c++) {
+                a.cols[c].values = u.vals[c]; a.cols[c].validity = (const uint8_t*)u.valid[c]; a.cols[c].offset = 0; a.cols[c].length = n_spill;
+            }
+            a.nrows = n_spill;
+            a.ntiles = (n_spill + AGG_TILE - 1) / AGG_TILE;
+            a.p.enabled = 0;
+            hot_scan = false;
+        } else if (prc == 0) {  // the scan below runs over the spilled entries only (predicate already applied)
             a.ent = spill;
             a.nrows = n_spill;
             a.p.enabled = 0;
