@@ -32,8 +32,11 @@ for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], spec)
     agg.next([ck], inputs, nrows=n)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
     ng = agg.finish()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    phases = f"create+next {1e3*(t1-t0):.1f} ms, finish {1e3*(time.perf_counter()-t1):.1f} ms"
+
     spans = {}
     for nm in (b"agg_pack_keys", b"agg_estimate", b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final", b"agg_part_merge", b"agg_demote"):
         ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
@@ -42,4 +45,4 @@ for rep in range(3):
             spans[nm.decode()[4:]] = (round(ms.value, 2), cnt.value)
     lib.vnm_set_profiling(0)
     agg.close()
-print(f"{mode} G={G} frac={frac} {prog}: {dt*1e3:.1f} ms, {ng} groups  {spans}")
+print(f"{mode} G={G} frac={frac} {prog}: {dt*1e3:.1f} ms ({phases}), {ng} groups  {spans}")

@@ -1226,6 +1226,63 @@ __global__ void agg_compact_special_kernel(CompactArgs c) {
     }
 }
 
+
+// -------------------------------------------------------------------------------------------------------
+// A dense run (the partitioned path's G groups) next to an HBM table holding far fewer groups (spilled heavy keys and
+// the odd entry of an over-full region): fold the TABLE into the RUN instead of inserting G groups into the table
+// (G = 2e7: 9 ms of per-group CAS against one pass over the run's key words).  Every run row probes the table
+// read-only (same hash and probe sequence as gt_find_single) and merges the slot's accumulator words into its own --
+// run rows and table slots are unique, nothing contends -- marking the slot; slots no run row carried are appended
+// behind the run (the caller checked the room).
+// -------------------------------------------------------------------------------------------------------
+struct PatchArgs {
+    AggPlan plan;
+    GTable g;
+    uint64_t* rkey;         // [2][rstride]: key word, null word
+    uint64_t* racc;         // [W][rstride]
+    int64_t rn, rstride;
+    uint8_t* found;         // [cap + 2]
+    unsigned long long* appended;
+};
+__global__ __launch_bounds__(256) void run_patch_kernel(PatchArgs a) {
+    const uint64_t mask = a.g.cap - 1;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.rn; i += stride) {
+        const uint64_t k = a.rkey[i], nm = a.rkey[a.rstride + i];
+        uint64_t slot = ~0ULL;
+        if (nm) { if (a.g.tag[a.g.cap + 1] != EMPTY) slot = a.g.cap + 1; }
+        else if (k == EMPTY) { if (a.g.tag[a.g.cap] != EMPTY) slot = a.g.cap; }
+        else {
+            uint64_t h = hash_u64(k) & mask;
+            for (uint64_t probes = 0; probes <= mask; probes++) {
+                const uint64_t t = a.g.tag[h];
+                if (t == k) { slot = h; break; }
+                if (t == EMPTY) break;
+                h = (h + 1) & mask;
+            }
+        }
+        if (slot == ~0ULL) continue;
+        for (int w = 0; w < a.plan.n_words; w++) {
+            const uint64_t v = a.g.acc[(uint64_t)w * a.g.stride + slot];
+            const int mk = a.plan.merge[w];
+            if (v != merge_init(mk)) g_merge(&a.racc[(int64_t)w * a.rstride + i], mk, v, a.rstride);
+        }
+        a.found[slot] = 1;
+    }
+}
+__global__ __launch_bounds__(256) void run_patch_append_kernel(PatchArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x; slot < (int64_t)a.g.cap + 2; slot += stride) {
+        const uint64_t t = a.g.tag[slot];
+        if (t == EMPTY || a.found[slot]) continue;
+        const int64_t pos = a.rn + (int64_t)atomicAdd(a.appended, 1ULL);
+        if (pos >= a.rstride) continue;   // cannot happen while the table's fill count holds (the host checks the total)
+        a.rkey[pos] = slot < (int64_t)a.g.cap ? t : (slot == (int64_t)a.g.cap ? EMPTY : 0);
+        a.rkey[a.rstride + pos] = slot == (int64_t)a.g.cap + 1 ? 1 : 0;
+        for (int w = 0; w < a.plan.n_words; w++) a.racc[(int64_t)w * a.rstride + pos] = a.g.acc[(uint64_t)w * a.g.stride + slot];
+    }
+}
+
 // =======================================================================================================
 // Radix-partitioned aggregation for LARGE group counts (hot shape only).
 //
@@ -3638,6 +3695,46 @@ static int merge_run_into_table(vnm_agg* h, hipStream_t s) {
     return rc;
 }
 
+
+// see run_patch_kernel; *done = false leaves everything as it was (the caller merges the run into the table instead)
+static int merge_table_into_run(vnm_agg* h, hipStream_t s, bool* done) {
+    *done = false;
+    if (!h->have_run || !h->have_table || !h->single || h->plan.n_keys != 1 || h->g.kwt != 0 || getenv("VNM_AGG_NO_RUN_PATCH") != nullptr) return 0;
+    unsigned long long fill = 0;
+    VNM_HIP(hipMemcpyAsync(&fill, h->g.ctl + 2, 8, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    const int64_t tmax = (int64_t)fill + 2;   // + the two special groups
+    if (tmax * 8 > h->run_n || h->run_n + tmax > h->run_stride - 2) return 0;
+    PoolScope pool;
+    const size_t fbytes = ((size_t)h->g.cap + 2 + 15) / 8 * 8;
+    uint8_t* found = (uint8_t*)pool.take(fbytes + 8);
+    if (!found) return 1;
+    VNM_HIP(hipMemsetAsync(found, 0, fbytes + 8, s));
+    PatchArgs a{};
+    a.plan = h->plan; a.g = h->g;
+    a.rkey = h->run_key; a.racc = h->run_acc; a.rn = h->run_n; a.rstride = h->run_stride;
+    a.found = found;
+    a.appended = (unsigned long long*)(found + fbytes);
+    const int cus = device_info().num_cus;
+    run_patch_kernel<<<(int)std::min<int64_t>((h->run_n + 255) / 256, (int64_t)cus * 8), 256, 0, s>>>(a);
+    run_patch_append_kernel<<<(int)std::min<int64_t>(((int64_t)h->g.cap + 2 + 255) / 256, (int64_t)cus * 8), 256, 0, s>>>(a);
+    VNM_HIP(hipGetLastError());
+    unsigned long long appended = 0;
+    VNM_HIP(hipMemcpyAsync(&appended, a.appended, 8, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    if ((int64_t)appended > tmax) return set_error("aggregate: more table groups than the table's fill count (internal error)");
+    h->run_n += (int64_t)appended;
+    if (appended) {   // the partition directory no longer describes the whole run
+        pool_free(h->run_dir);
+        h->run_dir = nullptr;
+        h->run_nfin = 0;
+    }
+    table_free(&h->g);
+    h->have_table = false;
+    *done = true;
+    return 0;
+}
+
 // ---- packed composite keys: host side ----------------------------------------------------------------------
 extern "C" int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream);
 extern "C" int vnm_agg_merge_device(vnm_agg* h, int64_t n, uint64_t* const* key_words, uint64_t* const* acc_words, void* stream);
@@ -4455,6 +4552,10 @@ int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream) {
         h->n_groups = n;
         if (n_groups) *n_groups = n;
         return 0;
+    }
+    if (h->have_run && h->have_table) {   // a big run + a few spilled groups in the table: fold the table into the run
+        bool patched = false;
+        VNM_TRY(merge_table_into_run(h, s, &patched));
     }
     if (h->have_run && !h->have_table) {  // the partitioned path already produced the dense result
         h->dkey = h->run_key; h->dacc = h->run_acc; h->dstride = h->run_stride; h->n_groups = h->run_n;
