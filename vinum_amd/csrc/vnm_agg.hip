@@ -2131,7 +2131,7 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
 // Cardinality estimate for operators that were given no hint: insert a strided sample of the keys into a
 // scratch table (tags only) and count the distinct ones.  Solving d = G (1 - exp(-m / G)) for G (uniform
 // model) on the host then sizes the partitions; an underestimate only costs the fallback to the general path.
-__global__ void agg_sample_kernel(const uint64_t* keys, int64_t nrows, int64_t m, GTable g) {
+__global__ void agg_sample_kernel(const uint64_t* keys, int64_t nrows, int64_t m, GTable g, unsigned int* cnt) {
     __shared__ unsigned s_new;
     if (threadIdx.x == 0) s_new = 0;
     __syncthreads();
@@ -2139,10 +2139,39 @@ __global__ void agg_sample_kernel(const uint64_t* keys, int64_t nrows, int64_t m
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
         int64_t row = (int64_t)(((__int128)i * nrows) / m);
         uint64_t key = keys[row];
-        if (key != EMPTY) gt_find_single(g, key, &s_new);
+        uint64_t slot = ~0ULL;
+        if (key != EMPTY) {
+            slot = gt_find_single(g, key, &s_new);
+            if (slot >= g.cap) slot = ~0ULL;
+        }
+        // per-key sample counts (the heavy keys' share of the rows).  A heavy key means most lanes of a wave hold the
+        // same slot, and atomics on one address serialise (half of the sample one key: 3 ms): up to three rounds pick the
+        // first pending lane's slot and add all its lanes at once.
+        const int lane = threadIdx.x & 63;
+        for (int r = 0; r < 3; r++) {
+            const unsigned long long pending = __ballot(slot != ~0ULL);
+            if (!pending) break;
+            const uint64_t first = __shfl(slot, __ffsll((long long)pending) - 1);
+            const unsigned long long same = __ballot(slot == first);
+            if (slot == first) {
+                if (lane == __ffsll((long long)same) - 1) atomicAdd(&cnt[first], (unsigned int)__popcll(same));
+                slot = ~0ULL;
+            }
+        }
+        if (slot != ~0ULL) atomicAdd(&cnt[slot], 1u);
     }
     __syncthreads();
     if (threadIdx.x == 0) fold_new(g, &s_new);
+}
+// keys with more than `thresh` sample rows: ctl[4] += their rows, ctl[5] += their number
+__global__ void agg_sample_heavy_kernel(const unsigned int* cnt, int64_t slots, unsigned int thresh, unsigned long long* ctl) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long rows = 0, keys = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += stride) {
+        const unsigned int c = cnt[i];
+        if (c > thresh) { rows += c; keys++; }
+    }
+    if (rows) { atomicAdd(&ctl[4], rows); atomicAdd(&ctl[5], keys); }
 }
 
 // HyperLogLog over a strided sample (4096 registers, ~1.6 % error): LDS max per workgroup, then one
@@ -2873,6 +2902,8 @@ int estimate_groups(vnm_agg* h, const vnm_dcol& key, int64_t nrows, int64_t* est
     const uint64_t* kp = (const uint64_t*)key.values + key.offset;
     int64_t sizes[2] = {std::min<int64_t>(nrows, 1 << 18), std::min<int64_t>(nrows, 1 << 24)};
     *est = 0;
+    double heavy_share = 0.0;   // share of the rows held by heavy keys, and how many of those there are (from tier 0's sample)
+    int64_t heavy_keys = 0;
     // tier 0: small sample into a scratch table (exact distinct count of the sample, ~50 us)
     {
         const int64_t m = sizes[0];
@@ -2881,30 +2912,44 @@ int estimate_groups(vnm_agg* h, const vnm_dcol& key, int64_t nrows, int64_t* est
         t.stride = t.cap + 2;
         t.tag = (uint64_t*)pool_alloc(t.stride * 8);
         t.ctl = (unsigned long long*)pool_alloc(64);
-        if (!t.tag || !t.ctl) return 1;
+        unsigned int* cnt = (unsigned int*)pool_alloc(t.cap * 4);
+        if (!t.tag || !t.ctl || !cnt) return 1;
         VNM_HIP(hipMemsetAsync(t.tag, 0xFF, t.stride * 8, s));
         VNM_HIP(hipMemsetAsync(t.ctl, 0, 64, s));
+        VNM_HIP(hipMemsetAsync(cnt, 0, t.cap * 4, s));
         int grid = (int)std::min<int64_t>((m + 255) / 256, (int64_t)device_info().num_cus * 8);
-        agg_sample_kernel<<<grid, 256, 0, s>>>(kp, nrows, m, t);
+        agg_sample_kernel<<<grid, 256, 0, s>>>(kp, nrows, m, t, cnt);
+        agg_sample_heavy_kernel<<<grid, 256, 0, s>>>(cnt, (int64_t)t.cap, (unsigned int)std::max<int64_t>(64, m / 256), t.ctl);
         VNM_HIP(hipGetLastError());
-        unsigned long long d = 0;
-        VNM_HIP(hipMemcpyAsync(&d, t.ctl + 2, 8, hipMemcpyDeviceToHost, s));
+        unsigned long long got[6] = {0, 0, 0, 0, 0, 0};
+        VNM_HIP(hipMemcpyAsync(got, t.ctl, 48, hipMemcpyDeviceToHost, s));
         VNM_HIP(hipStreamSynchronize(s));
         pool_free(t.tag);
         pool_free(t.ctl);
+        pool_free(cnt);
+        unsigned long long d = got[2];
         if (d == 0) d = 1;
-        if ((double)d / (double)m < 0.125 || m == nrows) {  // the sample saw (nearly) every group
+        // Heavy keys (each with > 0.4 % of the sample: NULLs, a default value) break the uniform model below -- half of the
+        // rows in one key halves d / m and G came out 2.2x too small.  They are taken out: the model sees the remaining keys
+        // over the remaining rows, and the heavy keys are added back as what they are, a handful of groups.
+        if ((double)got[4] >= 0.02 * (double)m && got[5] < d) {
+            heavy_share = std::min(0.999, (double)got[4] / (double)m);
+            heavy_keys = (int64_t)got[5];
+        }
+        const double m0 = (double)m * (1.0 - heavy_share);
+        const double d0 = (double)d - (double)heavy_keys;
+        if (d0 / m0 < 0.125 || m == nrows) {  // the sample saw (nearly) every group
             *est = (int64_t)((double)d * (m == nrows ? 1.0 : 1.15)) + 1;
             return 0;
         }
         if (tier0_lb) {
-            const double frac = std::min(0.97, (double)d / (double)m);  // beyond 0.97 the sample has no resolution: G >= ~16 m
+            const double frac = std::min(0.97, d0 / m0);  // beyond 0.97 the sample has no resolution: G >= ~16 m
             double lo = 1e-9, hi = 64.0;
             for (int it = 0; it < 80; it++) {
                 const double x = 0.5 * (lo + hi);
                 if ((1.0 - exp(-x)) / x > frac) lo = x; else hi = x;
             }
-            *tier0_lb = (int64_t)((double)m / (0.5 * (lo + hi)));
+            *tier0_lb = (int64_t)(m0 / (0.5 * (lo + hi)));
             return 0;
         }
     }
@@ -2928,8 +2973,10 @@ int estimate_groups(vnm_agg* h, const vnm_dcol& key, int64_t nrows, int64_t* est
         double d = alpha * (double)HLL_M * (double)HLL_M / sum;
         if (d <= 2.5 * HLL_M && zeros) d = (double)HLL_M * log((double)HLL_M / zeros);  // linear counting
         if (d > (double)m) d = (double)m;
+        d -= (double)heavy_keys;
         if (d < 1) d = 1;
-        const double frac = d / (double)m;
+        const double mm = (double)m * (1.0 - heavy_share);   // the rows of the sample that are not a heavy key's
+        const double frac = std::min(1.0, d / mm);
         // solve d/m = (1 - exp(-x)) / x for x = m / G by bisection (x -> 1 / frac when the sample saw every group many times:
         // the upper bound must cover m / d, a bound of 64 turned G = 1e5 into an estimate of 3.1e5 and a second partition level)
         double lo = 1e-9, hi = 2.0 / frac + 64.0;
@@ -2938,8 +2985,9 @@ int estimate_groups(vnm_agg* h, const vnm_dcol& key, int64_t nrows, int64_t* est
             double f = (1.0 - exp(-x)) / x;
             if (f > frac) lo = x; else hi = x;
         }
-        double G = (double)m / (0.5 * (lo + hi));
-        if (frac > 0.97) G = (double)m * 30.0;  // beyond the resolution of the sample: at least this many
+        double G = mm / (0.5 * (lo + hi));
+        if (frac > 0.97) G = mm * 30.0;  // beyond the resolution of the sample: at least this many
+        G += (double)heavy_keys;
         if (G > (double)nrows) G = (double)nrows;
         *est = (int64_t)(G * 1.2) + 1;
     }
