@@ -2145,10 +2145,10 @@ __global__ void agg_sample_kernel(const uint64_t* keys, int64_t nrows, int64_t m
             if (slot >= g.cap) slot = ~0ULL;
         }
         // per-key sample counts (the heavy keys' share of the rows).  A heavy key means most lanes of a wave hold the
-        // same slot, and atomics on one address serialise (half of the sample one key: 3 ms): up to three rounds pick the
-        // first pending lane's slot and add all its lanes at once.
+        // same slot, and atomics on one address serialise (half of the sample one key: 3 ms; seven groups: +0.2 ms on a 3 ms
+        // query): up to eight rounds pick the first pending lane's slot and add all its lanes at once.
         const int lane = threadIdx.x & 63;
-        for (int r = 0; r < 3; r++) {
+        for (int r = 0; r < 8; r++) {
             const unsigned long long pending = __ballot(slot != ~0ULL);
             if (!pending) break;
             const uint64_t first = __shfl(slot, __ffsll((long long)pending) - 1);
