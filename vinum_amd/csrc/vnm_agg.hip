@@ -3544,7 +3544,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     const int p2 = pbits - p1;
     const int np1 = 1 << p1, np2 = levels == 2 ? 1 << p2 : 0;
     const int64_t tile1 = PT_TILE;
-    const int grid1 = (int)std::min<int64_t>((int64_t)cus * 2, (nrows + tile1 - 1) / tile1);
+    const int grid1 = (int)std::min<int64_t>((int64_t)cus * env_i64("VNM_DENSE_GRID1_PER_CU", 2), (nrows + tile1 - 1) / tile1);
     int split2 = std::max(2, (grid1 + PT_MAX_REGIONS - 1) / PT_MAX_REGIONS);
     split2 = std::max(split2, std::min(grid1, (cus * 2 + np1 - 1) / np1));
     const int64_t tiles_per_wg = ((nrows + tile1 - 1) / tile1 + grid1 - 1) / grid1;
@@ -3591,9 +3591,41 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     // slightly worse, so it stays off there.  In pass 2 itself such stores cost 0.3 ms.  (VNM_DENSE_NT: bit 0 pass 1, bit 1 pass 2)
     d1.nt_store = (int)env_i64("VNM_DENSE_NT", levels == 2 && np2 >= 256 ? 1 : 0) & 1;
     d1.flags = flags; d1.spill = spill; d1.spill_cap = spill_cap;
+    // ring-buffer scatter (dring_scatter_kernel): whole 16-entry blocks only.  Ring capacity = what fits 128 KB of LDS, at
+    // most 64 entries per partition; fan-outs that leave less than two blocks per ring keep the tile-sorting kernel.
+    const int use_ring = (int)env_i64("VNM_DENSE_RING", 3);   // bit 0: pass 1, bit 1: pass 2
+    const int ring_blk = 1024;
+    auto ring_cap_for = [&](int np, size_t esize) -> int {
+        int cap = (int)((size_t)(env_i64("VNM_DENSE_RING_LDS", ring_blk >= 1024 ? 128 : (ring_blk >= 512 ? 72 : 48)) * 1024) / ((size_t)np * esize) / DR_FB) * DR_FB;
+        cap = std::min(cap, (int)env_i64("VNM_DENSE_RING_CAP", 80));
+        return cap >= 2 * DR_FB ? cap : 0;
+    };
+    int ring_pairs = (int)env_i64("VNM_DENSE_RING_PAIRS", 4);   // pass 1; pass 2 (every entry survives, more partitions): VNM_DENSE_RING_PAIRS2
+#define VNM_DRING_B(FR_, CT_, HV_, BLK_, PR_, PV_, GRID_, ARGS_, CAP_)                                                   \
+    do {                                                                                                                \
+        const size_t lds_ = (((size_t)(ARGS_).nparts * (CAP_) * ((HV_ ? 8 : 0) + sizeof(CT_))) + 15) & ~(size_t)15;       \
+        VNM_HIP(hipFuncSetAttribute((const void*)dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+        dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_><<<GRID_, BLK_, lds_, s>>>(ARGS_, CAP_);                      \
+    } while (0)
+#define VNM_DRING_P(FR_, CT_, HV_, PV_, GRID_, ARGS_, CAP_)                                                              \
+    do {                                                                                                                \
+        if (ring_pairs >= 4 && !PV_) VNM_DRING_B(FR_, CT_, HV_, 1024, 4, PV_, GRID_, ARGS_, CAP_);                       \
+        else if (ring_pairs >= 2) VNM_DRING_B(FR_, CT_, HV_, 1024, 2, PV_, GRID_, ARGS_, CAP_);                          \
+        else VNM_DRING_B(FR_, CT_, HV_, 1024, 1, PV_, GRID_, ARGS_, CAP_);                                               \
+    } while (0)
+    // (a predicate column of its own: three loads per pair of rows, at most two pairs per lane and sub-tile fit the registers)
+#define VNM_DRING(FR_, CT_, HV_, GRID_, ARGS_, CAP_)                                                                     \
+    do {                                                                                                                \
+        if (FR_ && (ARGS_).has_pred && !(ARGS_).pred_is_v) VNM_DRING_P(FR_, CT_, HV_, FR_, GRID_, ARGS_, CAP_);           \
+        else VNM_DRING_P(FR_, CT_, HV_, false, GRID_, ARGS_, CAP_);                                                      \
+    } while (0)
+    const int rcap1 = (use_ring & 1) && !a.has_expr ? ring_cap_for(np1, (has_val ? 8 : 0) + (c16_1 ? 2 : 4)) : 0;
     {
         KernelTimer timer("agg_part_scatter1", s);
-        if (has_val) {
+        if (rcap1) {
+            if (has_val) { if (c16_1) VNM_DRING(true, uint16_t, true, grid1, d1, rcap1); else VNM_DRING(true, uint32_t, true, grid1, d1, rcap1); }
+            else { if (c16_1) VNM_DRING(true, uint16_t, false, grid1, d1, rcap1); else VNM_DRING(true, uint32_t, false, grid1, d1, rcap1); }
+        } else if (has_val) {
             if (c16_1) dpart_scatter_kernel<true, uint16_t><<<grid1, PT_BLOCK, 0, s>>>(d1);
             else dpart_scatter_kernel<true, uint32_t><<<grid1, PT_BLOCK, 0, s>>>(d1);
         } else {
@@ -3622,14 +3654,20 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         d2.nparts = np2; d2.out_bits = tb;
         d2.flags = flags; d2.spill = spill; d2.spill_cap = spill_cap;
         d2.nt_store = ((int)env_i64("VNM_DENSE_NT", 0) >> 1) & 1;
+        const int rcap2 = (use_ring & 2) ? ring_cap_for(np2, (has_val ? 8 : 0) + 2) : 0;
+        ring_pairs = (int)env_i64("VNM_DENSE_RING_PAIRS2", 2);
         {
             KernelTimer timer("agg_part_scatter2", s);
-            if (has_val) dpart_scatter_kernel<false, uint16_t><<<np1 * split2, PT_BLOCK, 0, s>>>(d2);
+            if (rcap2) { if (has_val) VNM_DRING(false, uint16_t, true, np1 * split2, d2, rcap2); else VNM_DRING(false, uint16_t, false, np1 * split2, d2, rcap2); }
+            else if (has_val) dpart_scatter_kernel<false, uint16_t><<<np1 * split2, PT_BLOCK, 0, s>>>(d2);
             else dpart_scatter_kernel<false, uint16_t, false><<<np1 * split2, PT_BLOCK, 0, s>>>(d2);
         }
         VNM_HIP(hipGetLastError());
         fin_v = v2; fin_c = c2; fin_n = n2; fin_cap = cap2; fin_regions = split2;
     }
+#undef VNM_DRING
+#undef VNM_DRING_P
+#undef VNM_DRING_B
     const int64_t nfinal = (int64_t)1 << pbits;
     const int64_t dstride = std::min<int64_t>(h->dense_span, nrows) + 2;
     rk = (uint64_t*)pool_alloc((size_t)dstride * 8 * 2);
