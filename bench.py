@@ -282,9 +282,11 @@ def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream,
                                       expected_groups=hint)
             agg.set_predicate(">", x_thr)
             agg.next([kcol], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
-            state["ng"] = agg.finish(stream=stream)
             if finalize:
                 state["cols"] = agg.result_device(stream=stream)   # key, sum(v), avg(v) as Arrow-layout HBM buffers
+                state["ng"] = agg.result_rows
+            else:
+                state["ng"] = agg.finish(stream=stream)
             state["agg"] = agg
         return run
 

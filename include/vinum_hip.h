@@ -225,6 +225,38 @@ int vnm_agg_result_device(vnm_agg* h, int n_cols, const int* which, void* const*
                           uint8_t* const* out_bitmaps, int* out_kinds, int64_t* null_counts, void* stream);
 int vnm_agg_result_func_device(vnm_agg* h, int func_idx, void* out_values, uint8_t* out_bitmap, int* out_kind,
                                int64_t* null_count, void* stream);
+/* BaseAggregate::Result (base_aggregate.cpp:47-68: Reserve(G) on every builder, Summarize every group, one RecordBatch)
+ * with the output columns ALLOCATED BY THE LIBRARY -- the group count is only known once the last pass has run, exactly as
+ * the reference's builders only learn it in SummarizeGroups (single_numerical_hash_aggregate.cpp:48-68).  When the last
+ * batch went through the dense-key path, its direct-addressed final pass is still pending at this point and writes the
+ * result columns ITSELF (key, SUM, AVG, COUNT of a float64 column: the Summarize expressions of agg_funcs.h:139-142,
+ * 286-292, 519-522 evaluated where the accumulators live) -- no dense partial state, no second kernel re-reading it.
+ * Every other state: vnm_agg_finish + vnm_agg_result_device.  *n_groups = rows; out_values[c] = vnm_malloc block of
+ * >= *n_groups cells of the column's output type (as vnm_agg_result_device); out_bitmaps[c] = validity bitmap block or
+ * NULL when the column has no NULL result.  The CALLER frees both with vnm_free.  Returns 2 like vnm_agg_result_device. */
+int vnm_agg_result_device_alloc(vnm_agg* h, int n_cols, const int* which, void** out_values, uint8_t** out_bitmaps,
+                                int* out_kinds, int64_t* null_counts, int64_t* n_groups, void* stream);
+
+/* Multi-GPU, large results (legal because base_aggregate.cpp:23-45 only ever Init()s or Update()s a group's
+ * state: partial states of disjoint row sets merge commutatively).  The dense-key path replaces a key by a code inside a
+ * key RANGE; when all ranks use the SAME range, their direct-addressed final tables are slot-compatible: they add up
+ * element by element, a key's owner is a range of codes, and nothing has to be bucketed, counted or re-ordered.
+ *   vnm_agg_dense_range      this rank's sampled key range of a batch, as order-preserving unsigned images (*lo > *hi: the
+ *                            key type has no dense path).  Ranks reduce lo by MIN, hi by MAX ...
+ *   vnm_agg_set_dense_range  ... and give every operator the agreed range BEFORE its first batch (lo > hi: none).
+ *   vnm_agg_dense_table      after ONE batch: *table = 2^*bits slots {double sum; float lo; uint32 count} (count 0 = no
+ *                            group), slot = scrambled key code; NULL when the batch did not take that path (spilled keys,
+ *                            another aggregate shape, several batches): the caller falls back to the owner-bucketed
+ *                            exchange.  geometry[4] = {range start, bits, multiplier, sign}: must agree on all ranks.
+ *                            The table belongs to the handle.
+ *   vnm_agg_merge_dense_tables   owner side: slices [code0, code0 + n) of the nsrc ranks' tables (rank order) -> the
+ *                            result of the EMPTY handle h (`like`: any handle that produced one of the tables).  Sums merge
+ *                            with the library's compensated add, in rank order: the result does not depend on the owner. */
+int vnm_agg_dense_range(vnm_agg* h, int64_t nrows, const vnm_dcol* key, uint64_t* lo, uint64_t* hi, void* stream);
+int vnm_agg_set_dense_range(vnm_agg* h, int key_type, uint64_t lo, uint64_t hi);
+int vnm_agg_dense_table(vnm_agg* h, void** table, int* bits, uint64_t* geometry, void* stream);
+int vnm_agg_merge_dense_tables(vnm_agg* h, const vnm_agg* like, int nsrc, const void* const* slices, uint64_t code0,
+                               int64_t n, void* stream);
 
 /* Host-only helpers (no GPU touched): how (functions, input types) lower onto 64-bit accumulator words
  * with commutative merge kinds (0 add-u64, 1 add-f64, 2 min-u64, 3 max-u64, 4 compensated add-f64: the high

@@ -76,6 +76,11 @@ PROTOTYPES = {
     "vnm_agg_result_func": (c_int, [c_void, c_int, c_void, c_void, c_void]),
     "vnm_agg_result_key_device": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void]),
     "vnm_agg_result_device": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
+    "vnm_agg_result_device_alloc": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
+    "vnm_agg_dense_range": (c_int, [c_void, c_i64, c_void, c_void, c_void, c_void]),
+    "vnm_agg_set_dense_range": (c_int, [c_void, c_int, ctypes.c_uint64, ctypes.c_uint64]),
+    "vnm_agg_dense_table": (c_int, [c_void, c_void, c_void, c_void, c_void]),
+    "vnm_agg_merge_dense_tables": (c_int, [c_void, c_void, c_int, c_void, ctypes.c_uint64, c_i64, c_void]),
     "vnm_agg_estimate_groups": (c_int, [c_void, c_i64, c_void, c_void, c_void]),
     "vnm_agg_result_func_device": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_void]),
     "vnm_agg_plan_host": (c_int, [c_int, c_int, c_void, c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_void,

@@ -2731,6 +2731,16 @@ __global__ __launch_bounds__(256) void agg_finalize_kernel(FinMulti m) {
 // ==========================================================================================================
 using namespace vnm;
 
+struct DensePending {
+    DFinalArgs df;         // inputs of the final pass (outputs filled in by whoever completes it)
+    int tb = 0;
+    int64_t nfinal = 0;
+    int64_t dstride = 0;   // bound of the groups the pass can produce
+    std::vector<void*> blocks;   // pool blocks the entries live in
+    DTabSlot* table = nullptr;   // DF_TABLE result (kept until the handle goes: the exchange reads it)
+    ~DensePending() { for (void* b : blocks) pool_free(b); pool_free(table); }
+};
+
 struct vnm_agg {
     AggPlan plan;
     FuncOut outs[AGG_MAX_FUNCS];
@@ -2774,6 +2784,11 @@ struct vnm_agg {
     int64_t dense_span = 0;  // 2^bits: upper bound of the groups a dense run can hold
     uint64_t dense_rlo = 0, dense_rhi = 0;  // the sampled (widened) range itself, as order-preserving unsigned images
     bool rank_aligned = false;  // vnm_agg_set_exchange_mode: only run layouts every rank derives identically
+    // dense path, final pass DEFERRED (round 3): the scatter passes of the last batch are done, the direct-addressed final pass
+    // has not run yet -- what it writes depends on who asks: another batch / finish() -> the dense partial state (a run),
+    // vnm_agg_result_device_alloc -> the result columns themselves, vnm_agg_dense_table -> the tables for the multi-GPU exchange
+    struct DensePending* pending = nullptr;
+    bool range_given = false;   // vnm_agg_set_dense_range: the code range is the caller's (agreed by all ranks), not a sample's
     // expression input (vnm_agg_set_input_expr): the functions reading plan column expr_col get an expression's value
     int expr_col = -1;
     std::vector<vnm_expr_ins> expr_prog;
@@ -3298,7 +3313,9 @@ int partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream
 // ---- dense-key partitioned path: host side (kernels in vnm_agg_dense.inc) ------------------------------------
 // Sample the key range of the first large batch and derive the code map.  dense_state = 1 when the (widened) range fits
 // DP_MAX_BITS bits and is large enough to fill the chip with final partitions.
+int plan_dense_from_range(vnm_agg* h, int key_type, uint64_t got0, uint64_t got1);
 int plan_dense(vnm_agg* h, const vnm_dcol& key, int64_t nrows, hipStream_t s) {
+    if (h->range_given) return 0;   // vnm_agg_set_dense_range: the map stays the one all ranks derived
     h->dense_state = -1;
     if (key.type != VNM_I64 && key.type != VNM_U64) return 0;
     const uint64_t sign = key.type == VNM_I64 ? 0x8000000000000000ULL : 0ULL;
@@ -3316,6 +3333,15 @@ int plan_dense(vnm_agg* h, const vnm_dcol& key, int64_t nrows, hipStream_t s) {
     VNM_HIP(hipStreamSynchronize(s));
     pool_free(d);
     if (got[0] > got[1]) return 0;
+    return plan_dense_from_range(h, key.type, got[0], got[1]);
+}
+
+// The code map from a (sampled) key range [got0, got1] of order-preserving unsigned images.
+int plan_dense_from_range(vnm_agg* h, int key_type, uint64_t got0, uint64_t got1) {
+    h->dense_state = -1;
+    if (key_type != VNM_I64 && key_type != VNM_U64) return 0;
+    const uint64_t sign = key_type == VNM_I64 ? 0x8000000000000000ULL : 0ULL;
+    const unsigned long long got[2] = {got0, got1};
     // widen by 1/8 of the sampled span on both sides (the sample misses the true extremes), then centre the range in
     // the next power of two
     const uint64_t span_s = got[1] - got[0];
@@ -3512,6 +3538,81 @@ int dense_scan_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_
     return 0;
 }
 
+// The plain (one workgroup per partition) final pass of the dense path in one of its output modes.
+int launch_dense_final(const DFinalArgs& df, int tb, int out, bool lo64, hipStream_t s) {
+    const int cus = device_info().num_cus;
+    KernelTimer timer("agg_part_final", s);
+#define VNM_DFIN(TB_, OUT_, LOT_)                                                                                      \
+    do {                                                                                                              \
+        const int blk = TB_ >= 13 ? 1024 : 512;                                                                       \
+        int occ = 0;                                                                                                  \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)dpart_final_kernel<uint16_t, TB_, false, OUT_, LOT_>, blk, 0) != hipSuccess || occ < 1) occ = 1; \
+        const int g3 = (int)std::min<int64_t>(df.nfinal, (int64_t)cus * std::min(occ, (int)env_i64("VNM_PA_OCC", 8))); \
+        dpart_final_kernel<uint16_t, TB_, false, OUT_, LOT_><<<g3, blk, 0, s>>>(df);                                  \
+    } while (0)
+#define VNM_DFIN_O(TB_)                                                                                                \
+    do {                                                                                                              \
+        if (out == DF_COLS) VNM_DFIN(TB_, DF_COLS, float); else if (out == DF_TABLE) VNM_DFIN(TB_, DF_TABLE, float);   \
+        else VNM_DFIN(TB_, DF_RUN, float);                                                                            \
+    } while (0)
+    if (lo64) {   // compensation terms beyond the float range (|sum| > ~1e54): 64-bit terms, tables of at most 2^12 slots
+        if (tb == 11) { if (out == DF_COLS) VNM_DFIN(11, DF_COLS, double); else VNM_DFIN(11, DF_RUN, double); }
+        else if (tb == 12) { if (out == DF_COLS) VNM_DFIN(12, DF_COLS, double); else VNM_DFIN(12, DF_RUN, double); }
+        else return set_error("aggregate: no 64-bit compensation variant for this table size (internal error)");
+    } else if (tb == 11) VNM_DFIN_O(11); else if (tb == 12) VNM_DFIN_O(12); else VNM_DFIN_O(13);
+#undef VNM_DFIN_O
+#undef VNM_DFIN
+    VNM_HIP(hipGetLastError());
+    return 0;
+}
+
+// Runs the deferred final pass of the dense path.  DF_RUN: the pending state becomes the handle's run (and is released);
+// DF_COLS: `cols` names the output columns (capacity pending->dstride), *n_out = groups written, the pending entries STAY (a later
+// finish() can still produce the partial state); DF_TABLE: the tables go to pending->table (rc 2: compensation terms out of the
+// float range -- the caller uses another exchange).
+int complete_pending(vnm_agg* h, hipStream_t s, int out = DF_RUN, const DFinalArgs* cols = nullptr, int64_t* n_out = nullptr) {
+    DensePending* pd = h->pending;
+    if (!pd) return 0;
+    DFinalArgs df = pd->df;
+    PoolScope pool;
+    uint64_t* rk = nullptr; uint64_t* ra = nullptr;
+    if (out == DF_RUN) {
+        rk = (uint64_t*)pool.take((size_t)pd->dstride * 8 * 2);
+        ra = (uint64_t*)pool.take((size_t)pd->dstride * 8 * h->plan.n_words);
+        if (!rk || !ra) return 1;
+        df.dkey = rk; df.dacc = ra;
+    } else if (out == DF_COLS) {
+        df.n_out = cols->n_out;
+        for (int c = 0; c < cols->n_out; c++) { df.out_kind[c] = cols->out_kind[c]; df.out_ptr[c] = cols->out_ptr[c]; }
+    } else {
+        if (!pd->table) pd->table = (DTabSlot*)pool_alloc(sizeof(DTabSlot) << df.map.bits);
+        if (!pd->table) return 1;
+        df.table = pd->table;
+    }
+    df.dstride = pd->dstride;
+    unsigned long long fl[3] = {0, 0, 0};
+    for (int attempt = 0; attempt < 2; attempt++) {
+        VNM_HIP(hipMemsetAsync(df.flags, 0, 16, s));   // [0] failure, [1] dense count ([2]: the scatter passes' spill count, consumed)
+        VNM_TRY(launch_dense_final(df, pd->tb, out, attempt == 1, s));
+        VNM_HIP(hipMemcpyAsync(fl, df.flags, 16, hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipStreamSynchronize(s));
+        if (!fl[0]) break;
+        if (out == DF_TABLE) return 2;
+        if (attempt == 1) return set_error("aggregate: dense final pass failed (internal error)");
+    }
+    if (getenv("VNM_AGG_TRACE")) fprintf(stderr, "[agg] dense final (deferred): mode %d -> groups %llu\n", out, fl[1]);
+    if (n_out) *n_out = (int64_t)fl[1];
+    if (out == DF_RUN) {
+        pool.keep(rk); pool.keep(ra);
+        h->run_key = rk; h->run_acc = ra; h->run_stride = pd->dstride; h->run_n = (int64_t)fl[1];
+        h->run_dir = nullptr; h->run_nfin = 0;
+        h->have_run = true;
+        delete pd;
+        h->pending = nullptr;
+    }
+    return 0;
+}
+
 // returns 0 = done (run stored), 2 = not applicable / failed (caller continues with the hash-partitioned path), 1 = error
 int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s, ulonglong2** spill_out, int64_t* n_spill_out,
                                 bool generic = false) {
@@ -3598,6 +3699,9 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     auto ring_cap_for = [&](int np, size_t esize) -> int {
         int cap = (int)((size_t)(env_i64("VNM_DENSE_RING_LDS", ring_blk >= 1024 ? 128 : (ring_blk >= 512 ? 72 : 48)) * 1024) / ((size_t)np * esize) / DR_FB) * DR_FB;
         cap = std::min(cap, (int)env_i64("VNM_DENSE_RING_CAP", 80));
+        // few partitions: long runs anyway (and 8192 entries per sub-tile on a handful of ring cursors: G = 1e4, four partitions,
+        // pass 1 8.6 ms against 5.0 with the tile-sorting kernel)
+        if (np < env_i64("VNM_DENSE_RING_MIN_NP", 32)) return 0;
         return cap >= 2 * DR_FB ? cap : 0;
     };
     int ring_pairs = (int)env_i64("VNM_DENSE_RING_PAIRS", 4);   // pass 1; pass 2 (every entry survives, more partitions): VNM_DENSE_RING_PAIRS2
@@ -3729,18 +3833,28 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         if (tb == 11) VNM_DFINS(11); else if (tb == 12) VNM_DFINS(12); else VNM_DFINS(13);
 #undef VNM_DFINS
         dpart_merge_kernel<<<(int)(nfinal << (tb - 9)), 512, 0, s>>>(df, tb);
+    } else if (tb <= 12 && env_i64("VNM_DENSE_DEFER", 1)) {
+        // The final pass is DEFERRED: what it should write depends on what comes next (complete_pending).  The scatter passes
+        // have to be known good first.
+        unsigned long long fl0[3];
+        VNM_HIP(hipMemcpyAsync(fl0, flags, 24, hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipStreamSynchronize(s));
+        if (getenv("VNM_AGG_TRACE"))
+            fprintf(stderr, "[agg] dense: bits %d tb %d levels %d p1 %d p2 %d -> scatter fail %llu spilled %llu, final pass deferred (bound %lld)\n",
+                    mp.bits, tb, levels, p1, p2, fl0[0], fl0[2], (long long)dstride);
+        if (fl0[0]) { release(); pool_free(rk); pool_free(ra); pool_free(spill); return 2; }
+        pool_free(rk); pool_free(ra);   // (the run is allocated when the pass runs)
+        if (fl0[2]) { *spill_out = spill; *n_spill_out = (int64_t)fl0[2]; }
+        else { pool_free(spill); *spill_out = nullptr; *n_spill_out = 0; }
+        if ((int64_t)fl0[2] > nrows / 16) h->dense_state = -1;
+        DensePending* pd = new DensePending();
+        df.dkey = nullptr; df.dacc = nullptr;
+        pd->df = df; pd->tb = tb; pd->nfinal = nfinal; pd->dstride = dstride;
+        pd->blocks = {flags, v1, c1, n1, v2, c2, n2};
+        h->pending = pd;
+        return 0;
     } else {
-        KernelTimer timer("agg_part_final", s);
-#define VNM_DFIN(TB_)                                                                                                  \
-    do {                                                                                                              \
-        const int blk = TB_ >= 13 ? 1024 : 512;                                                                       \
-        int occ = 0;                                                                                                  \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)dpart_final_kernel<uint16_t, TB_>, blk, 0) != hipSuccess || occ < 1) occ = 1; \
-        const int g3 = (int)std::min<int64_t>(nfinal, (int64_t)cus * std::min(occ, (int)env_i64("VNM_PA_OCC", 8)));   \
-        dpart_final_kernel<uint16_t, TB_><<<g3, blk, 0, s>>>(df);                                                     \
-    } while (0)
-        if (tb == 11) VNM_DFIN(11); else if (tb == 12) VNM_DFIN(12); else VNM_DFIN(13);
-#undef VNM_DFIN
+        VNM_TRY(launch_dense_final(df, tb, DF_RUN, false, s));
     }
     VNM_HIP(hipGetLastError());
     unsigned long long fl[3];
@@ -4005,6 +4119,7 @@ void vnm_agg_destroy(vnm_agg* h) {
     if (h->have_table) table_free(&h->g);
     invalidate_result(h);
     drop_run(h);
+    delete h->pending;
     delete h;
 }
 
@@ -4049,6 +4164,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     if (h->pred_set && !pred) return set_error("vnm_agg_next_device: predicate set but no predicate column given");
     hipStream_t s = as_stream(stream);
     invalidate_result(h);
+    if (h->pending) VNM_TRY(complete_pending(h, s));   // another batch: the previous one's final pass produces its partial state now
     if (nrows <= 0) {
         if (h->plan.n_keys == 0 || h->hint <= 0) VNM_TRY(ensure_table(h, nrows, s));
         return 0;
@@ -4262,7 +4378,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
                                getenv("VNM_AGG_NO_DENSE_GENERIC") == nullptr && getenv("VNM_AGG_NO_SPILL") == nullptr;
     const bool dense_base = (hot || dense_generic) && part_ok && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
                             getenv("VNM_AGG_NO_DENSE") == nullptr;
-    bool dense_shape = dense_base && !h->rank_aligned;
+    bool dense_shape = dense_base && (!h->rank_aligned || h->range_given);   // rank-aligned: only with a code range all ranks agreed on
     bool dense_go = false;
     if (part_ok && h->hint == 0 && !h->estimated && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
         getenv("VNM_AGG_NO_ESTIMATE") == nullptr) {
@@ -4639,6 +4755,7 @@ int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream) {
         if (n_groups) *n_groups = n;
         return 0;
     }
+    if (h->pending) VNM_TRY(complete_pending(h, s));   // the deferred final pass of the dense path, as a run
     if (h->have_run && h->have_table) {   // a big run + a few spilled groups in the table: fold the table into the run
         bool patched = false;
         VNM_TRY(merge_table_into_run(h, s, &patched));
@@ -5007,6 +5124,160 @@ int vnm_agg_result_func_device(vnm_agg* h, int func_idx, void* out_values, uint8
     if (!h) return set_error("vnm_agg_result_func_device: null handle");
     if (func_idx < 0 || func_idx >= h->n_funcs) return set_error("vnm_agg_result_func_device: function index out of range");
     return vnm_agg_result_device(h, 1, &func_idx, &out_values, &out_bitmap, out_kind, null_count, stream);
+}
+
+// BaseAggregate::Result with library-allocated output columns.  When the last batch went through the dense path and its
+// final pass is still pending, that pass writes the result columns itself (fused finalisation); otherwise finish + the
+// finalisation kernel.  out_values[c] / out_bitmaps[c] are vnm_malloc blocks the CALLER frees (vnm_free); a column without
+// NULLs gets no bitmap (nullptr).
+int vnm_agg_result_device_alloc(vnm_agg* h, int n_cols, const int* which, void** out_values, uint8_t** out_bitmaps, int* out_kinds,
+                                int64_t* null_counts, int64_t* n_groups, void* stream) {
+    VNM_TRY(ensure_init());
+    if (!h) return set_error("vnm_agg_result_device_alloc: null handle");
+    if (n_cols < 0 || (n_cols > 0 && (!which || !out_values || !out_bitmaps)) || !n_groups) return set_error("vnm_agg_result_device_alloc: bad arguments");
+    for (int c = 0; c < n_cols; c++) {
+        const int w = which[c];
+        if (w >= 0 ? w >= h->n_funcs : ~w >= h->plan.n_keys) return set_error("vnm_agg_result_device_alloc: column index out of range");
+        out_values[c] = nullptr; out_bitmaps[c] = nullptr;
+    }
+    hipStream_t s = as_stream(stream);
+    auto free_outputs = [&]() { for (int c = 0; c < n_cols; c++) { pool_free(out_values[c]); pool_free(out_bitmaps[c]); out_values[c] = nullptr; out_bitmaps[c] = nullptr; } };
+    DensePending* pd = h->inner ? nullptr : h->pending;
+    bool fused = pd && !h->have_table && !h->have_run && h->n_groups < 0 && n_cols >= 1 && n_cols <= DF_MAX_OUT && getenv("VNM_AGG_NO_FUSED_RESULT") == nullptr;
+    DFinalArgs cols{};
+    for (int c = 0; c < n_cols && fused; c++) {
+        const int w = which[c];
+        if (w < 0) { cols.out_kind[c] = DF_KEY; if (out_kinds) out_kinds[c] = -1; continue; }
+        const FuncOut& fo = h->outs[w];
+        if (fo.func == VNM_COUNT_STAR || fo.func == VNM_COUNT) { cols.out_kind[c] = DF_COUNT; if (out_kinds) out_kinds[c] = VNM_OUT_U64; }
+        else if (fo.func == VNM_SUM && fo.in_type == VNM_F64) { cols.out_kind[c] = DF_SUM; if (out_kinds) out_kinds[c] = VNM_OUT_F64; }
+        else if (fo.func == VNM_AVG && fo.in_type == VNM_F64) { cols.out_kind[c] = DF_AVG; if (out_kinds) out_kinds[c] = VNM_OUT_F64; }
+        else fused = false;
+    }
+    if (fused) {
+        cols.n_out = n_cols;
+        for (int c = 0; c < n_cols; c++) {
+            out_values[c] = pool_alloc((size_t)pd->dstride * 8);
+            if (!out_values[c]) { free_outputs(); return 1; }
+            cols.out_ptr[c] = out_values[c];
+            if (null_counts) null_counts[c] = 0;   // every group of this shape saw a non-NULL input: no NULL results
+        }
+        int64_t n = 0;
+        const int rc = complete_pending(h, s, DF_COLS, &cols, &n);
+        if (rc) { free_outputs(); return rc; }
+        *n_groups = n;
+        return 0;
+    }
+    int64_t n = 0;
+    VNM_TRY(vnm_agg_finish(h, &n, stream));
+    *n_groups = n;
+    std::vector<int64_t> nulls((size_t)std::max(n_cols, 1), 0);
+    for (int c = 0; c < n_cols; c++) {
+        out_values[c] = pool_alloc((size_t)std::max<int64_t>(n, 1) * 8);
+        out_bitmaps[c] = (uint8_t*)pool_alloc((size_t)((n + 63) / 64 + 1) * 8);
+        if (!out_values[c] || !out_bitmaps[c]) { free_outputs(); return 1; }
+    }
+    const int rc = vnm_agg_result_device(h, n_cols, which, out_values, out_bitmaps, out_kinds, nulls.data(), stream);
+    if (rc) { free_outputs(); return rc; }
+    for (int c = 0; c < n_cols; c++) {
+        if (null_counts) null_counts[c] = nulls[c];
+        if (nulls[c] == 0) { pool_free(out_bitmaps[c]); out_bitmaps[c] = nullptr; }
+    }
+    return 0;
+}
+
+// ---- multi-GPU: the dense path with a code range all ranks agree on ---------------------------------------------------------
+// vnm_agg_dense_range: this rank's sampled key range of a batch (order-preserving unsigned images; lo > hi: no dense path for this
+// key type / range).  The ranks reduce lo by MIN and hi by MAX and hand the result to vnm_agg_set_dense_range: every rank then
+// derives the SAME code map, so the direct-addressed tables of the final pass are slot-compatible across ranks.
+int vnm_agg_dense_range(vnm_agg* h, int64_t nrows, const vnm_dcol* key, uint64_t* lo, uint64_t* hi, void* stream) {
+    VNM_TRY(ensure_init());
+    if (!h || !key || !lo || !hi) return set_error("vnm_agg_dense_range: bad argument");
+    *lo = ~0ULL; *hi = 0;
+    if (!h->single || h->plan.n_keys != 1 || nrows <= 0 || (key->type != VNM_I64 && key->type != VNM_U64) || key->validity) return 0;
+    hipStream_t s = as_stream(stream);
+    const uint64_t sign = key->type == VNM_I64 ? 0x8000000000000000ULL : 0ULL;
+    unsigned long long* d = (unsigned long long*)pool_alloc(64);
+    if (!d) return 1;
+    const unsigned long long init[2] = {~0ULL, 0ULL};
+    unsigned long long got[2];
+    VNM_HIP(hipMemcpyAsync(d, init, 16, hipMemcpyHostToDevice, s));
+    const int64_t m = std::min<int64_t>(nrows, 1 << 18);
+    const int grid = (int)std::min<int64_t>((m + 255) / 256, (int64_t)device_info().num_cus * 4);
+    dense_sample_range_kernel<<<grid, 256, 0, s>>>((const uint64_t*)key->values + key->offset, nrows, m, sign, d);
+    VNM_HIP(hipGetLastError());
+    VNM_HIP(hipMemcpyAsync(got, d, 16, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    pool_free(d);
+    *lo = got[0]; *hi = got[1];
+    return 0;
+}
+
+int vnm_agg_set_dense_range(vnm_agg* h, int key_type, uint64_t lo, uint64_t hi) {
+    if (!h) return set_error("vnm_agg_set_dense_range: null handle");
+    h->range_given = false;
+    h->dense_state = -1;
+    if (lo > hi) return 0;
+    VNM_TRY(plan_dense_from_range(h, key_type, lo, hi));
+    h->range_given = h->dense_state == 1;
+    return 0;
+}
+
+// The direct-addressed tables of the (deferred) final pass: *table = 2^bits slots of {sum f64, lo f32, count u32}, slot = code'.
+// *table = nullptr when the handle holds anything else (no dense batch, spilled keys, several batches): use another exchange.
+// The geometry words let the ranks check that they really derived the same map: {lo_u, bits, mul, sign}.
+int vnm_agg_dense_table(vnm_agg* h, void** table, int* bits, uint64_t* geometry, void* stream) {
+    VNM_TRY(ensure_init());
+    if (!h || !table || !bits) return set_error("vnm_agg_dense_table: bad argument");
+    *table = nullptr; *bits = 0;
+    DensePending* pd = h->inner ? nullptr : h->pending;
+    if (!pd || h->have_table || h->have_run || h->n_groups >= 0) return 0;
+    const int rc = complete_pending(h, as_stream(stream), DF_TABLE);
+    if (rc == 2) return 0;
+    if (rc) return rc;
+    *table = pd->table;
+    *bits = pd->df.map.bits;
+    if (geometry) { geometry[0] = pd->df.map.lo_u; geometry[1] = (uint64_t)pd->df.map.bits; geometry[2] = pd->df.map.mul; geometry[3] = pd->df.map.sign; }
+    return 0;
+}
+
+// Owner side: `nsrc` slices of such tables (slots [code0, code0 + n) of every rank, in rank order) -> this (empty) handle's result.
+// The map is the one of `like` (any handle that produced one of the tables).
+int vnm_agg_merge_dense_tables(vnm_agg* h, const vnm_agg* like, int nsrc, const void* const* slices, uint64_t code0, int64_t n, void* stream) {
+    VNM_TRY(ensure_init());
+    if (!h || !like || !like->pending || nsrc < 1 || nsrc > 64 || !slices || n < 0) return set_error("vnm_agg_merge_dense_tables: bad argument");
+    if (h->have_table || h->have_run || h->pending) return set_error("vnm_agg_merge_dense_tables: the handle must be empty");
+    if (h->plan.n_words != like->plan.n_words) return set_error("vnm_agg_merge_dense_tables: different aggregate programs");
+    hipStream_t s = as_stream(stream);
+    invalidate_result(h);
+    const DFinalArgs& ld = like->pending->df;
+    PoolScope pool;
+    const int64_t dstride = n + 2;
+    uint64_t* rk = (uint64_t*)pool.take((size_t)dstride * 8 * 2);
+    uint64_t* ra = (uint64_t*)pool.take((size_t)dstride * 8 * h->plan.n_words);
+    unsigned long long* flags = (unsigned long long*)pool.take(64);
+    if (!rk || !ra || !flags) return 1;
+    VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
+    DTabMergeArgs a{};
+    a.map = ld.map;
+    for (int r = 0; r < nsrc; r++) a.src[r] = (const DTabSlot*)slices[r];
+    a.nsrc = nsrc; a.n = n; a.code0 = (uint32_t)code0;
+    a.w_rows = ld.w_rows; a.w_valid = ld.w_valid; a.w_sum = ld.w_sum; a.w_lo = ld.w_lo;
+    a.dkey = rk; a.dacc = ra; a.dstride = dstride; a.flags = flags;
+    if (n > 0) {
+        KernelTimer timer("agg_table_merge", s);
+        dtable_merge_kernel<<<(int)((n + 511) / 512), 512, 0, s>>>(a);
+    }
+    VNM_HIP(hipGetLastError());
+    unsigned long long fl[2];
+    VNM_HIP(hipMemcpyAsync(fl, flags, 16, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    if (fl[0]) return set_error("vnm_agg_merge_dense_tables: output overflow (internal error)");
+    pool.keep(rk); pool.keep(ra);
+    h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
+    h->run_dir = nullptr; h->run_nfin = 0;
+    h->have_run = true;
+    return 0;
 }
 
 // host-only helpers: plan lowering and finalisation from accumulator words (no GPU needed)

@@ -59,6 +59,14 @@ class DeviceBuffer:
             raise L.VinumHipError(L.last_error())
 
     @staticmethod
+    def adopt(ptr: int, nbytes: int) -> "DeviceBuffer":
+        """Take ownership of a block the library allocated for the caller (vnm_agg_result_device_alloc)."""
+        b = DeviceBuffer.__new__(DeviceBuffer)
+        b.nbytes = int(nbytes)
+        b.ptr = int(ptr)
+        return b
+
+    @staticmethod
     def from_host(arr: np.ndarray) -> "DeviceBuffer":
         arr = np.ascontiguousarray(arr)
         b = DeviceBuffer(arr.nbytes)

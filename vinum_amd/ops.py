@@ -242,28 +242,57 @@ class DeviceAggregate:
         validity bitmap) -- no accumulator words cross PCIe.  Returns DeviceColumns.  An int64 / uint64 SUM that
         overflows 64 bits (-> decimal128, agg_funcs.h:366-389) raises NeedsHostFinalize: use result_arrays()."""
         lib = L.lib()
-        n = self.finish(stream=stream)
         if key_indices is None:
             key_indices = range(len(self.key_arrow))
         which = [~j for j in key_indices] + list(range(len(self.funcs)))
         nc = len(which)
-        nb = ((n + 63) // 64) * 8
-        vals = [DeviceBuffer(max(n, 1) * 8) for _ in which]
-        bitmaps = [DeviceBuffer(max(nb, 8)) for _ in which]
+        if nc == 0:
+            return []
+        # the library allocates the columns: the group count is only known once the last pass has run, and a pending
+        # dense-path final pass writes the result columns itself (vnm_agg_result_device_alloc)
         c_which = (ctypes.c_int * nc)(*which)
-        c_vals = (ctypes.c_void_p * nc)(*[v.ptr for v in vals])
-        c_bitmaps = (ctypes.c_void_p * nc)(*[b.ptr for b in bitmaps])
+        c_vals = (ctypes.c_void_p * nc)()
+        c_bitmaps = (ctypes.c_void_p * nc)()
         kinds = (ctypes.c_int * nc)()
         nulls = (ctypes.c_int64 * nc)()
-        rc = lib.vnm_agg_result_device(self._h, nc, c_which, c_vals, c_bitmaps, kinds, nulls, _stream_ptr(stream))
+        ng = ctypes.c_int64(0)
+        rc = lib.vnm_agg_result_device_alloc(self._h, nc, c_which, c_vals, c_bitmaps, kinds, nulls, ctypes.byref(ng), _stream_ptr(stream))
         if rc == 2:
             raise NeedsHostFinalize(L.last_error() or "a 64-bit SUM overflowed: decimal128 result")
         L.check(rc)
+        n = ng.value
+        self.result_rows = n
         cols = []
         for c, w in enumerate(which):
             t = self.key_arrow[~w] if w < 0 else _func_arrow_type(self.funcs[w][0], self.funcs[w][2], kinds[c])
-            cols.append(DeviceColumn(vals[c], bitmaps[c] if nulls[c] else None, 0, n, t))
+            vals = DeviceBuffer.adopt(c_vals[c], max(n, 1) * 8)
+            bitmap = DeviceBuffer.adopt(c_bitmaps[c], ((n + 63) // 64) * 8) if c_bitmaps[c] else None
+            cols.append(DeviceColumn(vals, bitmap if nulls[c] else None, 0, n, t))
         return cols
+
+    # -- multi-GPU: the dense-key path with a code range all ranks agree on (vinum_amd.distributed.exchange_dense_tables) --
+    def dense_range(self, key, nrows, stream=None):
+        """(lo, hi) of this rank's sampled key range as order-preserving unsigned images; lo > hi: no dense path."""
+        lo, hi = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        L.check(L.lib().vnm_agg_dense_range(self._h, int(nrows), ctypes.byref(key.dcol()), ctypes.byref(lo), ctypes.byref(hi),
+                                            _stream_ptr(stream)))
+        return lo.value, hi.value
+
+    def set_dense_range(self, lo, hi):
+        L.check(L.lib().vnm_agg_set_dense_range(self._h, physical_type(self.key_arrow[0])[0], int(lo), int(hi)))
+
+    def dense_table(self, stream=None):
+        """(ptr, bits, geometry) of the direct-addressed tables of the pending final pass, or None."""
+        ptr, bits = ctypes.c_void_p(0), ctypes.c_int(0)
+        geo = (ctypes.c_uint64 * 4)()
+        L.check(L.lib().vnm_agg_dense_table(self._h, ctypes.byref(ptr), ctypes.byref(bits), geo, _stream_ptr(stream)))
+        if not ptr.value:
+            return None
+        return ptr.value, bits.value, tuple(int(g) for g in geo)
+
+    def merge_dense_tables(self, like, slice_ptrs, code0, n, stream=None):
+        P = (ctypes.c_void_p * len(slice_ptrs))(*slice_ptrs)
+        L.check(L.lib().vnm_agg_merge_dense_tables(self._h, like._h, len(slice_ptrs), P, int(code0), int(n), _stream_ptr(stream)))
 
     def close(self):
         if getattr(self, "_h", None):
