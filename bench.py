@@ -234,7 +234,7 @@ def _spans(lib, ctypes, names, steps):
     return out
 
 
-AGG_SPANS = [b"agg_estimate", b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final", b"agg_finalize"]
+AGG_SPANS = [b"agg_estimate", b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final", b"agg_finalize", b"agg_table_merge"]
 
 
 def _measure(torch, lib, ctypes, fn, span_names, steps, warmup):
@@ -293,14 +293,15 @@ def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream,
     # ---- the headline query with the group count given (vnm_agg_set_hint): not reachable through the reference boundary
     # (two warm-up calls: the previous step's operator / outputs stay alive while the next step allocates, so the caching
     # allocator only reaches its steady state -- no hipMalloc, ~25 ms per GB, inside the timed steps -- after the second)
-    ms, sp = _measure(torch, lib, ctypes, headline(groups), AGG_SPANS, steps, warmup + 1)
-    out["configs[2] hinted"] = _entry(f"the headline query with expected_groups={groups:.3g} passed to the operator", n, ms, sp,
+    ms, sp = _measure(torch, lib, ctypes, headline(groups, finalize=True), AGG_SPANS, steps, warmup + 1)
+    out["configs[2] hinted"] = _entry(f"the headline query (result columns included) with expected_groups={groups:.3g} passed to the operator", n, ms, sp,
                                       16.0 * n + 24.0 * state["ng"], state["ng"])
-    # ---- the headline query end to end: next + finish + the three result columns finalised on the device
-    ms, sp = _measure(torch, lib, ctypes, headline(0, finalize=True), AGG_SPANS, steps, warmup + 1)
-    out["end_to_end"] = _entry("configs[2] hint-less incl. BaseAggregate::Result: key, sum(v), avg(v) finalised by a device kernel "
-                               "into Arrow-layout buffers in HBM (vnm_agg_result_*_device); input resident in HBM", n, ms, sp,
-                               16.0 * n + 24.0 * state["ng"], state["ng"])
+    # ---- the headline query stopping at the dense PARTIAL state (key, sum hi / lo, count words: what a further batch or the
+    # multi-GPU exchange would merge into) instead of the result columns -- the r01 / r02 headline
+    ms, sp = _measure(torch, lib, ctypes, headline(0, finalize=False), AGG_SPANS, steps, warmup + 1)
+    out["partial_state"] = _entry("configs[2] hint-less up to vnm_agg_finish: dense partial state (key, sum, compensation, count words) "
+                                  "instead of the finalised key / sum / avg columns of the headline; input resident in HBM", n, ms, sp,
+                                  16.0 * n + 24.0 * state["ng"], state["ng"])
     state.clear()
     # ---- configs[1]
     dst = torch.empty(n, dtype=torch.float64, device=device)
@@ -480,10 +481,18 @@ def main():
                 # different numbers of partitions (distributed.agree_on_group_count)
                 from vinum_amd import distributed as D
                 D.agree_on_group_count(agg, kcol, n, device, stream=stream)
+            if world > 1 or force_exchange:
+                # ... and on ONE key range: the dense-key path then gives slot-compatible tables on every rank
+                from vinum_amd import distributed as D
+                if os.environ.get("VNM_BENCH_EXCHANGE", "dense") == "dense":
+                    D.agree_on_dense_range(agg, kcol, n, device, stream=stream)
             agg.next([kcol], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
-        ng = agg.finish(stream=stream)
         if world > 1 or force_exchange:
-            ng = exchange_and_merge(agg, ng)
+            ng = exchange_and_merge(agg, None)
+        else:
+            # BaseAggregate::Result: the result COLUMNS (key, sum, avg as Arrow-layout buffers in HBM) are part of the step
+            state["cols"] = agg.result_device(stream=stream)
+            ng = agg.result_rows
         state["out_rows"] = ng
         state.pop("agg", None)
         state["agg"] = agg  # keep the last result alive for the sanity check; previous one is freed
@@ -494,11 +503,27 @@ def main():
         (vinum_amd/distributed.py)."""
         from vinum_amd import distributed as D
         kw, aw = agg.layout()
+        want = os.environ.get("VNM_BENCH_EXCHANGE", "dense")
+        # the last pass of the aggregation itself (the dense path's deferred final pass, here writing its direct-addressed tables)
+        got = agg.dense_table(stream=stream) if want == "dense" else None
+        torch.cuda.synchronize()
         t_a = time.perf_counter()
-        # large G: partition-aligned exchange (owners merge hash partitions in LDS, no HBM atomics)
         make = lambda: ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
                                            [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())])
-        merged = D.exchange_partition_aligned(agg, make, device)
+        # large G through the dense-key path with an agreed code range: the final pass's direct-addressed tables travel as
+        # they are (equal known splits, no bucketing) and add up slot by slot on their owner
+        merged = D.exchange_dense(agg, make, device, stream=stream, got=got) if want == "dense" else None
+        if merged is not None:
+            out = merged.finish(stream=stream)
+            torch.cuda.synchronize()
+            ph = state.setdefault("phases", {"bucket": 0.0, "all_to_all": 0.0, "merge": 0.0, "partition_aligned": 0.0, "dense_tables": 0.0})
+            ph["dense_tables"] = ph.get("dense_tables", 0.0) + (time.perf_counter() - t_a) * 1e3
+            state["merged"] = merged
+            state["exchange_kind"] = "dense_tables"
+            return out
+        ng = agg.finish(stream=stream)
+        # large G otherwise: partition-aligned exchange (owners merge hash partitions in LDS, no HBM atomics)
+        merged = D.exchange_partition_aligned(agg, make, device) if want in ("dense", "aligned") else None
         if merged is not None:
             out = merged.finish(stream=stream)
             torch.cuda.synchronize()

@@ -144,3 +144,83 @@ def test_small_group_allgather_exchange_and_distributed_topk_gloo(tmp_path):
     for o in outs:
         assert np.array_equal(o["tid"], want)
         assert np.array_equal(o["tv"].view(np.uint64), v[want].view(np.uint64))
+
+
+# ---- dense-key tables: range agreement + equal-split all_to_all + slot-wise merge (distributed.exchange_dense_tables) ----
+_SLOT = np.dtype([("sum", "<f8"), ("lo", "<f4"), ("cnt", "<u4")])   # struct DTabSlot, 16 bytes
+
+
+class _FakeRangeAgg:
+    """Stand-in for DeviceAggregate.dense_range / set_dense_range (the reductions and the agreement are under test)."""
+
+    def __init__(self, lo, hi):
+        self.lo, self.hi, self.got = lo, hi, None
+
+    def dense_range(self, key, nrows, stream=None):
+        return self.lo, self.hi
+
+    def set_dense_range(self, lo, hi):
+        self.got = (lo, hi)
+
+
+def _worker_dense(rank, world, port, tmp, bits, mismatch, max_elems=0):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vinum_amd import distributed as D
+    if max_elems:
+        D._MAX_ELEMS_PER_PEER = max_elems     # force the several-rounds path of large tables
+    # 1. range agreement: images beyond 2^63 must survive the trip through int64 reductions
+    ranges = [((1 << 63) + 5, (1 << 63) + 900), ((1 << 63) - 70, (1 << 63) + 100), (3, (1 << 64) - 2)]
+    fake = _FakeRangeAgg(*ranges[rank])
+    agreed = D.agree_on_dense_range(fake, None, 10, torch.device("cpu"))
+    exp = (min(r[0] for r in ranges[:world]), max(r[1] for r in ranges[:world]))
+    assert agreed == exp and fake.got == exp, (agreed, exp)
+    # a rank without a range switches it off for everybody
+    fake2 = _FakeRangeAgg(1, 0) if rank == world - 1 else _FakeRangeAgg(5, 10)
+    assert D.agree_on_dense_range(fake2, None, 10, torch.device("cpu")) is None and fake2.got == (1, 0)
+    # 2. the exchange: per-rank tables over `bits` bits of code
+    rng = np.random.default_rng(50 + rank)
+    nslots = 1 << bits
+    tab = np.zeros(nslots, _SLOT)
+    occ = rng.random(nslots) < 0.6
+    tab["cnt"][occ] = rng.integers(1, 9, occ.sum())
+    tab["sum"][occ] = rng.integers(0, 2**14, occ.sum()) / 128.0
+    table = torch.from_numpy(tab.view(np.int64).reshape(nslots, 2).copy())
+    geo = (1000, bits, 0x9E3779B1, 1 << 63)
+    if mismatch and rank == 1:
+        geo = (1001, bits, 0x9E3779B1, 1 << 63)
+
+    def merge(recv, code0, nloc):
+        r = recv.numpy().reshape(-1).view(_SLOT).reshape(world, nloc)
+        return code0, r["cnt"].sum(axis=0, dtype=np.uint64), r["sum"].sum(axis=0)
+
+    got = D.exchange_dense_tables(table, geo, merge)
+    if mismatch:
+        assert got is None
+        got = (0, np.zeros(0, np.uint64), np.zeros(0))
+    np.savez(os.path.join(tmp, f"dense_{rank}.npz"), code0=got[0], c=got[1], s=got[2], tab=tab.view(np.uint8))
+    # 3. a rank WITHOUT a table: everybody falls back together
+    assert D.exchange_dense_tables(None if rank == 0 else table, geo, merge) is None or world == 1 and False
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bits,mismatch,max_elems", [(2, 10, False, 0), (3, 9, False, 0), (2, 10, True, 0), (3, 9, False, 100), (1, 8, False, 100)])
+def test_dense_table_exchange_gloo(tmp_path, world, bits, mismatch, max_elems):
+    port = 29500 + ((os.getpid() + 7 * world + bits + max_elems) % 1000)
+    mp.spawn(_worker_dense, args=(world, port, str(tmp_path), bits, mismatch, max_elems), nprocs=world, join=True)
+    if mismatch:
+        return
+    from vinum_amd import distributed as D
+    outs = [np.load(tmp_path / f"dense_{r}.npz") for r in range(world)]
+    tabs = [o["tab"].view(_SLOT) for o in outs]
+    exp_c = sum(t["cnt"].astype(np.uint64) for t in tabs)
+    exp_s = sum(t["sum"] for t in tabs)
+    bounds = D.table_bounds(1 << bits, world)     # owners' shards tile the code space, also when world does not divide it
+    for r, o in enumerate(outs):
+        assert int(o["code0"]) == bounds[r] and len(o["c"]) == bounds[r + 1] - bounds[r]
+        assert np.array_equal(o["c"], exp_c[bounds[r]:bounds[r + 1]])
+        assert np.array_equal(o["s"], exp_s[bounds[r]:bounds[r + 1]])   # quantised: exact in any order

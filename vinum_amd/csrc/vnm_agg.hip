@@ -5266,7 +5266,7 @@ int vnm_agg_merge_dense_tables(vnm_agg* h, const vnm_agg* like, int nsrc, const 
     a.dkey = rk; a.dacc = ra; a.dstride = dstride; a.flags = flags;
     if (n > 0) {
         KernelTimer timer("agg_table_merge", s);
-        dtable_merge_kernel<<<(int)((n + 511) / 512), 512, 0, s>>>(a);
+        dtable_merge_kernel<<<(int)((n + DTM_PER * DTM_BLOCK - 1) / (DTM_PER * DTM_BLOCK)), DTM_BLOCK, 0, s>>>(a);
     }
     VNM_HIP(hipGetLastError());
     unsigned long long fl[2];

@@ -164,6 +164,120 @@ def agree_on_group_count(agg, key, nrows, device, group=None, stream=None):
     return est
 
 
+# ---- large results of the dense-key path: direct-addressed tables, exchanged as they are ------------------------------------
+class _RawView:
+    """A raw device pointer as a __cuda_array_interface__ object (zero copy into torch)."""
+
+    def __init__(self, ptr, n, typestr="<i8"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def _u64_to_ordered_i64(u: int) -> int:
+    """Order-preserving map of an unsigned 64-bit value onto int64 (torch has no uint64 reductions)."""
+    u ^= 1 << 63
+    return u - (1 << 64) if u >= (1 << 63) else u
+
+
+def _ordered_i64_to_u64(v: int) -> int:
+    return (v + (1 << 64) if v < 0 else v) ^ (1 << 63)
+
+
+def agree_on_dense_range(agg, key, nrows, device, group=None, stream=None):
+    """Every rank samples the key range of its batch (vnm_agg_dense_range); the ranks agree on [MIN lo, MAX hi] with one
+    16-byte all_gather per rank and hand it to their operators (vnm_agg_set_dense_range): all of them then derive the SAME
+    code map, so the direct-addressed tables of the dense path's final pass are slot-compatible (exchange_dense_tables).
+    A rank without such a range (empty batch, another key type) switches it off for everybody.  Returns (lo, hi) or None."""
+    world = dist.get_world_size(group)
+    lo, hi = agg.dense_range(key, nrows, stream=stream)
+    ok = 1 if lo <= hi else 0
+    t = torch.tensor([ok, _u64_to_ordered_i64(lo), _u64_to_ordered_i64(hi)], dtype=torch.int64, device=device)
+    allt = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allt, t, group=group)
+    rows = [x.tolist() for x in allt]
+    if not all(r[0] for r in rows):
+        agg.set_dense_range(1, 0)
+        return None
+    lo = _ordered_i64_to_u64(min(r[1] for r in rows))
+    hi = _ordered_i64_to_u64(max(r[2] for r in rows))
+    agg.set_dense_range(lo, hi)
+    return lo, hi
+
+
+def table_bounds(nslots: int, world: int):
+    """Owner o holds the slots (= scrambled key codes) [bounds[o], bounds[o + 1])."""
+    return [o * nslots // world for o in range(world + 1)]
+
+
+def exchange_dense_tables(table, geometry, merge_slices, group=None):
+    """table: this rank's direct-addressed final-pass tables as an int64 tensor [nslots, 2] (16-byte slots {sum f64, lo f32,
+    count u32}; vnm_agg_dense_table) or None when its batch did not take that path; geometry: the code map's
+    (range start, bits, multiplier, sign).  When EVERY rank holds a table of the same geometry: ONE all_to_all with equal,
+    known splits (owner o gets the slot range table_bounds()[o : o + 2] of every rank -- nothing is bucketed, counted or
+    re-ordered, no sizes are exchanged) and merge_slices(recv [world * nloc, 2], code0, nloc) adds the world slices up
+    (vnm_agg_merge_dense_tables).  Returns its result, or None when some rank has no table / another geometry (all ranks
+    agree on that: one all_gather of the 5-word signature), in which case the caller uses another exchange."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = table.device if table is not None else None
+    if dev is None:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    sig = [1 if table is not None else 0] + ([_u64_to_ordered_i64(int(g)) for g in geometry] if table is not None else [0, 0, 0, 0])
+    t = torch.tensor(sig, dtype=torch.int64, device=dev)
+    allt = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allt, t, group=group)
+    rows = [x.tolist() for x in allt]
+    if not all(r[0] == 1 and r == rows[0] for r in rows):
+        return None
+    nslots = int(table.shape[0])
+    bounds = table_bounds(nslots, world)
+    nloc = bounds[rank + 1] - bounds[rank]
+    recv = torch.empty((world * nloc, 2), dtype=torch.int64, device=dev)
+    biggest = max(bounds[o + 1] - bounds[o] for o in range(world))
+    rounds = max(1, -(-(biggest * 2) // _MAX_ELEMS_PER_PEER))
+    if rounds == 1:
+        dist.all_to_all_single(recv.view(-1), table.view(-1), output_split_sizes=[nloc * 2] * world,
+                               input_split_sizes=[(bounds[o + 1] - bounds[o]) * 2 for o in range(world)], group=group)
+        return merge_slices(recv, bounds[rank], nloc)
+    # slices beyond 1 GiB per peer (one or two ranks with a 2^27-slot table): several rounds over sub-ranges of every owner's
+    # slots, so that no single transfer comes near the 2^31-byte counts of the transport
+    step = -(-biggest // rounds)
+    for r in range(rounds):
+        s_lo = [min(bounds[o] + r * step, bounds[o + 1]) for o in range(world)]
+        s_hi = [min(bounds[o] + (r + 1) * step, bounds[o + 1]) for o in range(world)]
+        r_lo, r_hi = min(r * step, nloc), min((r + 1) * step, nloc)
+        send = table[s_lo[0]:s_hi[0]] if world == 1 else torch.cat([table[a:b] for a, b in zip(s_lo, s_hi)])
+        rbuf = recv[r_lo:r_hi] if world == 1 else torch.empty((world * (r_hi - r_lo), 2), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(rbuf.view(-1), send.contiguous().view(-1), output_split_sizes=[(r_hi - r_lo) * 2] * world,
+                               input_split_sizes=[(b - a) * 2 for a, b in zip(s_lo, s_hi)], group=group)
+        if world > 1:
+            for src in range(world):
+                recv[src * nloc + r_lo: src * nloc + r_hi] = rbuf[src * (r_hi - r_lo):(src + 1) * (r_hi - r_lo)]
+    return merge_slices(recv, bounds[rank], nloc)
+
+
+_UNSET = object()
+
+
+def exchange_dense(agg, make_merged, device, group=None, stream=None, got=_UNSET):
+    """The device wrapper of exchange_dense_tables for a DeviceAggregate whose (single) batch went through the dense path
+    with an agreed code range.  Returns the merged DeviceAggregate (this rank's shard of the result) or None.
+    got: the result of agg.dense_table() when the caller has already run that (final) pass."""
+    if got is _UNSET:
+        got = agg.dense_table(stream=stream)
+    table, geo = None, (0, 0, 0, 0)
+    if got is not None:
+        ptr, bits, geo = got
+        table = torch.as_tensor(_RawView(ptr, 2 << bits), device=device).view(-1, 2)
+
+    def merge(recv, code0, nloc):
+        world = dist.get_world_size(group)
+        merged = make_merged()
+        merged.merge_dense_tables(agg, [recv.data_ptr() + r * nloc * 16 for r in range(world)], code0, nloc, stream=stream)
+        merged._keep = recv
+        return merged
+    return exchange_dense_tables(table, geo, merge, group)
+
+
 # ---- small result sets: ONE all_gather, every rank merges everything ----------------------------------------------
 SMALL_G_ROWS = 1 << 20   # partial groups per rank up to which the all-gather path is used
 
