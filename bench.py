@@ -213,6 +213,16 @@ def check_groupby(torch, dist, state, k, v, x_thr, world, rank, device, exchange
         bad = torch.tensor([float((own != rank).sum())], dtype=torch.float64, device=device)
         dist.all_reduce(bad)
         ok["every_key_on_its_owner"] = bad.item() == 0.0
+    if world == 1 and not exchanged and state.get("cols") is not None and n:
+        # the step's RESULT COLUMNS (written by the fused final pass) against the dense partial state of the same operator:
+        # same keys, sum = hi (+ lo), avg = sum / count -- compared as sorted-by-key columns
+        ck, cs, ca = state["cols"][:3]
+        rk = torch.as_tensor(CudaArrayView(ck.values_ptr, n, "<i8"), device=device)
+        rs = torch.as_tensor(CudaArrayView(cs.values_ptr, n, "<f8"), device=device)
+        ra = torch.as_tensor(CudaArrayView(ca.values_ptr, n, "<f8"), device=device)
+        o1, o2 = torch.argsort(rk), torch.argsort(keys)
+        ok["result_columns_match"] = bool(ck.length == n and torch.equal(rk[o1], keys[o2]) and torch.equal(rs[o1], sm[o2])
+                                          and torch.equal(ra[o1], sm[o2] / cnt[o2].to(torch.float64)))
     assert all(val for key, val in ok.items() if isinstance(val, bool)), f"multi-GPU result check failed: {ok}"
     return ok
 

@@ -467,6 +467,83 @@ def test_partition_aligned_exchange_simulated(world):
     util.assert_agg_equal(got, o_.result(), funcs, ["k"], what=f"partition-aligned world={world}")
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("values", ["quantised", "lognormal"])
+def test_dense_table_exchange_simulated(world, values, monkeypatch):
+    """Dense-table multi-GPU merge on one GPU (distributed.exchange_dense_tables routed by hand): `world` operators play the
+    ranks; they agree on ONE key range (MIN / MAX of their sampled ranges), so their dense-path final passes write
+    slot-compatible direct-addressed tables; owner o takes the slot range table_bounds()[o : o + 2] of every table and adds the
+    slices up slot by slot.  The union of the owners' shards must equal the oracle on the union of the data -- bit for bit on
+    quantised values, and the exactly rounded sum (math.fsum) on lognormal ones, whatever the number of ranks."""
+    import math
+    import torch
+    from oracle import oracle as O
+    from vinum_amd import distributed as D
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")   # the large-batch paths with test-sized inputs
+    monkeypatch.setenv("VNM_DENSE_ONE_LEVEL", "0")              # ... and the two-level layout of the 1e8-group case at 2^21 codes
+    G = 1_500_000
+    n = 600_000
+    spec = [(O.SUM, 1, pa.float64()), (O.AVG, 1, pa.float64()), (O.COUNT_STAR, None, None)]
+    funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.COUNT_STAR, "", "n")]
+    aggs, tables, cols = [], [], []
+    ranges = []
+    for r in range(world):
+        rng = np.random.default_rng(70 + r)
+        k = rng.integers(0, G, n).astype(np.int64) - 1_000_000 + 17 * r
+        v = (rng.integers(0, 2**14, n).astype(np.float64) / 128.0) if values == "quantised" else rng.lognormal(3.0, 2.0, n)
+        tables.append(pa.table({"k": k, "v": v}))
+        kc, vc = DeviceColumn.from_torch(torch.from_numpy(k).cuda()), DeviceColumn.from_torch(torch.from_numpy(v).cuda())
+        a = ops.DeviceAggregate(O.SINGLE, [pa.int64()], spec, expected_groups=G, rank_aligned=True)
+        a.set_predicate(">", 1.0)
+        ranges.append(a.dense_range(kc, n))
+        aggs.append(a); cols.append((kc, vc))
+    lo, hi = min(r[0] for r in ranges), max(r[1] for r in ranges)
+    assert lo <= hi
+    got_tabs = []
+    for a, (kc, vc) in zip(aggs, cols):
+        a.set_dense_range(lo, hi)
+        a.next([kc], [vc, vc, None], pred=vc, nrows=n)
+        got = a.dense_table()
+        assert got is not None, "the batch must have gone through the dense path with its final pass pending"
+        got_tabs.append(got)
+    assert all(g[1:] == got_tabs[0][1:] for g in got_tabs), "every rank must derive the same code map"
+    bits = got_tabs[0][1]
+    bounds = D.table_bounds(1 << bits, world)
+    views = [torch.as_tensor(D._RawView(g[0], 2 << bits), device="cuda").view(-1, 2) for g in got_tabs]
+    got_batches = []
+    for o in range(world):
+        nloc = bounds[o + 1] - bounds[o]
+        recv = torch.cat([t[bounds[o]:bounds[o + 1]] for t in views]).contiguous()
+        m = ops.DeviceAggregate(O.SINGLE, [pa.int64()], spec)
+        m.merge_dense_tables(aggs[0], [recv.data_ptr() + r * nloc * 16 for r in range(world)], bounds[o], nloc)
+        got_batches.append(m.result_arrays([0], ["k"], ["s", "a", "n"]))
+    got = pa.Table.from_batches(got_batches).combine_chunks().to_batches()[0]
+    o_ = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for t in tables:
+        for b in t.to_batches():
+            o_.next(O.filter_batch(b, O.cmp_mask(b.column(1), O.GT, 1.0)))
+    exp = o_.result()
+    if values == "quantised":
+        util.assert_agg_equal(got, exp, funcs, ["k"], what=f"dense tables world={world}")
+    else:
+        g, e = util.canon(got, ["k"]), util.canon(exp, ["k"])
+        assert g.column(0).equals(e.column(0)) and g.column(2 + 1).equals(e.column(3))
+        allk = np.concatenate([t.column("k").to_numpy() for t in tables])
+        allv = np.concatenate([t.column("v").to_numpy() for t in tables])
+        keep = allv > 1.0
+        order = np.argsort(allk[keep], kind="stable")
+        ks, vs = allk[keep][order], allv[keep][order]
+        starts = np.flatnonzero(np.r_[True, ks[1:] != ks[:-1]])
+        exact = np.array([math.fsum(vs[a:b].tolist()) for a, b in zip(starts, np.r_[starts[1:], len(vs)])])
+        by_key = np.argsort(g.column(0).to_numpy(), kind="stable")     # (canon orders by bit pattern: negative keys last)
+        assert np.array_equal(g.column(0).to_numpy()[by_key], ks[starts])
+        assert np.array_equal(g.column(1).to_numpy()[by_key], exact), "float SUM must be the exactly rounded sum for every number of ranks"
+    # the same operators still give their own partial state afterwards (the pending entries stay until the handle goes)
+    assert aggs[0].finish() > 0
+
+
 @pytest.mark.parametrize("scenario", ["dims", "nulls_and_negatives", "float_key", "demote_on_later_batch", "unpackable"])
 def test_multi_key_packed_composite_keys(scenario):
     """Multi-column GROUP BY: key columns whose observed ranges fit 63 bits are packed into one word per row and run

@@ -1,0 +1,42 @@
+"""bench.py --check through every multi-GPU exchange route with ONE rank (VNM_BENCH_FORCE_EXCHANGE=1: the RCCL collectives run
+against the rank itself), at sizes that reach the large-batch paths: the property checks of the last step (survivors and totals
+conserved, every key on one owner) must hold for the dense-table, partition-aligned, owner-bucketed and all-gather exchanges,
+and for the single-GPU headline with its fused result columns."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra_env, *args):
+    env = dict(os.environ)
+    env.update(extra_env)
+    env.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-also", "--no-cpu-baseline",
+                        "--check", *args], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("route,env,args", [
+    ("dense_tables", {"VNM_BENCH_FORCE_EXCHANGE": "1"}, ["--rows", "3e7", "--groups", "1e7"]),
+    ("partition_aligned", {"VNM_BENCH_FORCE_EXCHANGE": "1", "VNM_BENCH_EXCHANGE": "aligned"}, ["--rows", "3e7", "--groups", "1e7"]),
+    ("bucketed", {"VNM_BENCH_FORCE_EXCHANGE": "1", "VNM_BENCH_EXCHANGE": "bucketed"}, ["--rows", "3e7", "--groups", "1e7"]),
+    ("allgather_small", {"VNM_BENCH_FORCE_EXCHANGE": "1"}, ["--rows", "3e7", "--groups", "1e5"]),
+])
+def test_bench_check_exchange_routes(route, env, args):
+    j = _bench(env, *args)
+    assert j["check"]["exchange"] == route, j["check"]
+    assert j["check"]["survivors_conserved"] and j["check"]["totals_conserved"]
+    assert j["exchange_ms_per_step"] is not None
+
+
+def test_bench_check_single_gpu_headline_with_result_columns():
+    j = _bench({}, "--rows", "3e7", "--groups", "1e7")
+    assert j["check"]["survivors_conserved"] and j["check"]["totals_conserved"]
+    assert j["check"].get("result_columns_match") is True
