@@ -30,14 +30,23 @@ def _taxi_csv(n, seed=0):
 def test_config1_groupby_passenger_count_stream_csv():
     from vinum_amd.query import select
     from vinum_amd.core import AggregateFunction as F
-    data, t = _taxi_csv(200_000)
+    # BASELINE.json configs[0] at its own size: the 1M-row CSV, `SELECT passenger_count, count(*) ... GROUP BY passenger_count`
+    # (+ avg(fare_amount)), against the ORACLE fed with the same record batches the CSV reader delivers: keys and counts bit for
+    # bit, the float AVG held to the exact-mean bound (util.assert_agg_equal with `source`)
+    from oracle import oracle as O
+    data, t = _taxi_csv(1_000_000)
     reader = pacsv.open_csv(io.BytesIO(data), read_options=pacsv.ReadOptions(block_size=1 << 20))
     got = select(reader, columns=["passenger_count"], group_by=["passenger_count"],
-                 aggregates=[F("count", None, "cnt"), F("avg", "fare_amount", "avg_fare")]).sort_by("passenger_count")
-    exp = t.group_by("passenger_count").aggregate([("fare_amount", "count"), ("fare_amount", "mean")]).sort_by("passenger_count")
-    assert got.column("passenger_count").to_pylist() == exp.column("passenger_count").to_pylist()
-    assert got.column("cnt").to_pylist() == exp.column("fare_amount_count").to_pylist()
-    assert np.allclose(got.column("avg_fare").to_numpy(), exp.column("fare_amount_mean").to_numpy(), rtol=1e-12)
+                 aggregates=[F("count", None, "cnt"), F("avg", "fare_amount", "avg_fare")])
+    funcs = [(O.COUNT_STAR, "", "cnt"), (O.AVG, "fare_amount", "avg_fare")]
+    o = O.OracleAggregate(O.SINGLE, ["passenger_count"], ["passenger_count"], funcs)
+    fed = []
+    for b in pacsv.open_csv(io.BytesIO(data), read_options=pacsv.ReadOptions(block_size=1 << 20)):
+        b = b.select(["fare_amount", "passenger_count"])
+        o.next(b)
+        fed.append(b)
+    util.assert_agg_equal(got.combine_chunks().to_batches()[0], o.result(), funcs, ["passenger_count"], exact_float_inputs=(),
+                          source=fed, what="config1")
 
 
 def test_config2_filter():

@@ -47,7 +47,8 @@ def test_reference_golden_through_vinum_lib(case):
     agg = _agg(case["kind"], case["groupby"], case["agg_cols"], funcs)
     for b in util.sliced_batches(table, case["chunk"]):
         agg.next(b)
-    util.assert_agg_equal(agg.result(), expected, funcs, case["agg_cols"], what=case["name"])
+    util.assert_agg_equal(agg.result(), expected, funcs, case["agg_cols"], what=case["name"],
+                          source=table if list(case["agg_cols"]) == list(case["groupby"]) else None)
 
 
 @pytest.mark.parametrize("case", MAN["sort"], ids=lambda c: c["name"])
@@ -141,7 +142,7 @@ def test_random_aggregates_through_vinum_lib(seed):
     for b in batches:
         agg.next(b)
         o.next(b)
-    util.assert_agg_equal(agg.result(), o.result(), funcs, key_names,
+    util.assert_agg_equal(agg.result(), o.result(), funcs, key_names, source=batches,
                           what=f"seed {seed}: keys {[str(cols[k].type) for k in key_names]} inputs "
                                f"{[str(cols[v].type) for v in in_names]} G~{groups} off={off} cuts={cuts}")
 

@@ -136,22 +136,99 @@ def assert_batches_equal(actual, expected, key_names=None, float_ulps=0, positio
         assert_col_equal(actual.column(i), expected.column(i), f"{what}:{actual.schema.names[i]}", ulps=float_ulps)
 
 
-def assert_agg_equal(actual, expected, funcs, key_names, exact_float_inputs=("v_f64q", "fare", "v"), what=""):
+def _schema_of(source):
+    return source.schema if isinstance(source, pa.Table) else list(source)[0].schema
+
+
+def exact_group_sums(source, key_names, col):
+    """{canonical key tuple: (math.fsum of the non-NULL values of `col`, their count)} over the record batches `source`
+    (the rows that were actually aggregated, i.e. after the predicate).  float32 inputs are summed as the doubles they convert
+    to, as the reference and the device do (agg_func_factory.cpp:126-131)."""
+    import math
+    t = pa.Table.from_batches(list(source)).combine_chunks() if not isinstance(source, pa.Table) else source.combine_chunks()
+    n = t.num_rows
+    keycols = []
+    for k in key_names:
+        valid, vals = _bits(t.column(k))
+        keycols.append((~valid).astype(np.uint64))
+        keycols.append(np.asarray(vals, dtype=np.uint64))
+    arr = t.column(col).combine_chunks()
+    vvalid = np.ones(n, bool) if arr.null_count == 0 else np.array(arr.is_valid())
+    x = arr.fill_null(0).to_numpy(zero_copy_only=False).astype(np.float64)
+    if keycols:
+        stacked = np.stack(keycols, axis=1) if n else np.zeros((0, len(keycols)), np.uint64)
+        uniq, inv = np.unique(stacked, axis=0, return_inverse=True)
+        inv = np.asarray(inv).reshape(-1)
+    else:
+        uniq, inv = np.zeros((1, 0), np.uint64), np.zeros(n, np.int64)
+    order = np.argsort(inv, kind="stable")
+    inv_s, x_s, v_s = inv[order], x[order], vvalid[order]
+    starts = np.searchsorted(inv_s, np.arange(len(uniq)), side="left")
+    ends = np.searchsorted(inv_s, np.arange(len(uniq)), side="right")
+    out = {}
+    for g in range(len(uniq)):
+        seg = x_s[starts[g]:ends[g]][v_s[starts[g]:ends[g]]]
+        out[tuple(int(w) for w in uniq[g])] = (math.fsum(seg.tolist()), int(seg.size))
+    return out
+
+
+def _assert_float_agg_exact(a, e, f, exact_rows, name, what):
+    """SUM / AVG over arbitrary floats.  The reference adds sequentially in row order (agg_funcs.h:294-305), so its result depends
+    on the order; ours is the correctly rounded exact sum whatever the order.  Asserted: ours is within 1 ULP of the exact value
+    (math.fsum; AVG: fsum / count, the division rounds once more) and never further from the reference than the reference is from
+    the exact value (+ 1 ULP) -- the bound of tests/test_gpu_float.py, instead of an rtol."""
+    assert a.type == e.type, f"{what}:{name}: type {a.type} != {e.type}"
+    va, _ = _bits(a)
+    ve, _ = _bits(e)
+    assert np.array_equal(va, ve), f"{what}:{name}: validity differs"
+    dt = np.float64 if pa.types.is_float64(e.type) else np.float32
+    fa = a.fill_null(0).to_numpy(zero_copy_only=False).astype(dt)
+    fe = e.fill_null(0).to_numpy(zero_copy_only=False).astype(dt)
+    ex = np.array([(s if f == 4 else (s / c if c else 0.0)) for s, c in exact_rows], dtype=np.float64).astype(dt)
+    live = va & np.isfinite(ex.astype(np.float64)) & np.isfinite(fe.astype(np.float64))
+    d_ours = np.where(live, _ulp_diff(np.where(live, fa, 0).astype(dt), np.where(live, ex, 0).astype(dt)), 0)
+    bad = np.nonzero(d_ours > 1)[0]
+    assert bad.size == 0, f"{what}:{name}: {bad.size} groups are not the (correctly rounded) exact value, e.g. row {bad[0]}: {fa[bad[0]]!r} vs exact {ex[bad[0]]!r}"
+    d_ref = np.where(live, _ulp_diff(np.where(live, fe, 0).astype(dt), np.where(live, ex, 0).astype(dt)), 0)
+    d_both = np.where(live, _ulp_diff(np.where(live, fa, 0).astype(dt), np.where(live, fe, 0).astype(dt)), 0)
+    bad = np.nonzero(d_both > d_ref + 1)[0]
+    assert bad.size == 0, f"{what}:{name}: {bad.size} groups further from the reference than the reference is from the exact value"
+    # non-finite results (inf / NaN inputs, overflow): the same class of value as the reference
+    nf = va & ~live
+    assert np.array_equal(np.isnan(fa[nf]), np.isnan(fe[nf])) and np.array_equal(fa[nf][~np.isnan(fa[nf])], fe[nf][~np.isnan(fe[nf])]), \
+        f"{what}:{name}: non-finite results differ"
+
+
+def assert_agg_equal(actual, expected, funcs, key_names, exact_float_inputs=("v_f64q", "fare", "v"), what="", source=None):
     """Aggregate parity: bit-exact for keys, counts, integer sums, decimals, MIN/MAX and float sums over
-    exactly-representable (quantised) inputs; SUM/AVG over arbitrary floats are order dependent (the
-    reference adds in row order, agg_funcs.h:294-305) so those columns use rtol=1e-12, atol=1e-9
-    (the reference's own tests use np.allclose defaults, rtol=1e-5: vinum/tests/conftest.py:128-142)."""
+    exactly-representable (quantised) inputs.  SUM/AVG over arbitrary floats are order dependent in the reference (it adds in
+    row order, agg_funcs.h:294-305): with `source` (the record batches that were aggregated, after any predicate) those columns
+    are held to the exact-sum bound of _assert_float_agg_exact; without it to rtol=1e-12 / atol=1e-9 (the reference's own tests
+    use np.allclose defaults, rtol=1e-5: vinum/tests/conftest.py:128-142)."""
     actual = canon(actual, key_names)
     expected = canon(expected, key_names)
     assert actual.num_rows == expected.num_rows, f"{what}: rows {actual.num_rows} != {expected.num_rows}"
     assert actual.schema.names == expected.schema.names, f"{what}: {actual.schema.names} != {expected.schema.names}"
-    loose = set()
+    loose = {}
     for f, col, out in funcs:
         if f in (4, 5) and col and col not in exact_float_inputs:
-            loose.add(out)
+            loose[out] = (f, col)
+    exact_cache = {}
     for i, name in enumerate(actual.schema.names):
         a, e = actual.column(i), expected.column(i)
-        if name in loose and pa.types.is_floating(e.type):
+        if name in loose and source is not None and not pa.types.is_floating(_schema_of(source).field(loose[name][1]).type):
+            assert_col_equal(a, e, f"{what}:{name}")     # SUM / AVG of integers and temporals: exact arithmetic, bit for bit
+        elif name in loose and pa.types.is_floating(e.type) and source is not None and all(k in expected.schema.names for k in key_names):
+            f, col = loose[name]
+            if col not in exact_cache:
+                exact_cache[col] = exact_group_sums(source, key_names, col)
+            kb = [_bits(expected.column(k)) for k in key_names]
+            rows = []
+            for r in range(expected.num_rows):
+                key = tuple(x for valid, vals in kb for x in (int(not valid[r]), int(vals[r])))
+                rows.append(exact_cache[col][key])
+            _assert_float_agg_exact(a, e, f, rows, name, what)
+        elif name in loose and pa.types.is_floating(e.type):
             assert a.type == e.type, f"{what}:{name}: type {a.type} != {e.type}"
             va, _ = _bits(a)
             ve, _ = _bits(e)

@@ -282,7 +282,9 @@ __global__ __launch_bounds__(256) void csv_parse_kernel(CsvArgs a) {
                 fstart = i + 1;
             }
         }
-        if (field != a.n_fields) a.flags[20] = 1;            // ragged row: pyarrow raises on it, so does the caller
+        // ragged row: pyarrow raises on it, so does the caller.  An EMPTY line is not a row at all for pyarrow (ignore_empty_lines):
+        // it is flagged the same way even in a one-column file, so that the block takes pyarrow's row count.
+        if (field != a.n_fields || len == 0) a.flags[20] = 1;
         for (; c < a.n_cols; c++) { ((uint64_t*)a.out_values[c])[r] = 0; a.out_valid[c][r] = 0; }
     }
 }

@@ -133,27 +133,36 @@ class GpuCsvReader:
         cols = {}
         nrows = None
         host_cols = [n for n in self._want if n not in gpu_cols]
-        if gpu_cols:
-            k = len(gpu_cols)
-            fidx = (ctypes.c_int * k)(*[self._names.index(n) for n in gpu_cols])
-            types = (ctypes.c_int * k)(*[L.I64 if self.schema.field(n).type == pa.int64() else L.F64 for n in gpu_cols])
+        whole_block_on_host = False
+        # the library parses at most 16 columns per call (CSV_MAX_COLS): wide files go in chunks of ascending field indices
+        for c0 in range(0, len(gpu_cols), 16):
+            chunk = gpu_cols[c0:c0 + 16]
+            k = len(chunk)
+            fidx = (ctypes.c_int * k)(*[self._names.index(n) for n in chunk])
+            types = (ctypes.c_int * k)(*[L.I64 if self.schema.field(n).type == pa.int64() else L.F64 for n in chunk])
             out = (L.DCol * k)()
             n_rows = ctypes.c_int64(0)
             fb = (ctypes.c_int * (k + 2))()
             L.check(lib.vnm_csv_parse_block(text_ptr, length, 0, ord(","), len(self._names), k, fidx, types, out, ctypes.byref(n_rows), fb, None))
+            owned = [_OwnedColumn(out[i], self.schema.field(n).type) for i, n in enumerate(chunk)]
+            if fb[k] or fb[k + 1]:          # quotes / ragged or empty rows: the whole block goes through pyarrow (which raises on ragged rows)
+                whole_block_on_host = True
+                break
+            assert nrows is None or nrows == n_rows.value
             nrows = n_rows.value
-            owned = [_OwnedColumn(out[i], self.schema.field(n).type) for i, n in enumerate(gpu_cols)]
-            if fb[k] or fb[k + 1]:          # quotes / ragged rows: the whole block goes through pyarrow (which raises on ragged rows)
-                host_cols, gpu_cols = list(self._want), []
-            else:
-                for i, n in enumerate(gpu_cols):
-                    if fb[i]:
-                        host_cols.append(n)    # a field the exact device parser does not cover
-                    else:
-                        cols[n] = owned[i]
+            for i, n in enumerate(chunk):
+                if fb[i]:
+                    host_cols.append(n)    # a field the exact device parser does not cover
+                else:
+                    cols[n] = owned[i]
+        if whole_block_on_host:
+            host_cols, cols, nrows = list(self._want), {}, None
         if host_cols:
             t = self._host_parse(bytes(self._buf[off:off + length]), host_cols)
-            nrows = t.num_rows if nrows is None else nrows
+            # pyarrow's row count is the reference's (it skips empty lines); device-parsed columns of the same block must agree
+            if nrows is not None and nrows != t.num_rows:
+                raise pa.ArrowInvalid(f"CSV block: the device parser saw {nrows} rows, pyarrow {t.num_rows}")
+            nrows = t.num_rows
             b = t.combine_chunks().to_batches()[0] if t.num_rows else None
             staged = DeviceRecordBatch.from_arrow(b, self._dicts) if b is not None else None
             for n in host_cols:
