@@ -115,12 +115,32 @@ def cpu_baseline(args, x_thr):
     batches = [make(chunk) for _ in range(n_batches)]
     t = run(batches)
     kind = "reference" if (use_ref or args.workload == "filter") else "port"
+    # an INDEPENDENT CPU line on the same sample (BASELINE.md 3 iv): pyarrow.compute's own filter and Table.group_by
+    # (Arrow's multi-threaded C++ kernels, nothing of the reference or of this repo in them)
+    indep = None
+    try:
+        import pyarrow.compute as pc
+        tb = pa.Table.from_batches(batches)
+        t0 = time.perf_counter()
+        ft = tb.filter(pc.greater(tb.column("v"), x_thr))
+        t_f = time.perf_counter() - t0
+        if args.workload == "filter":
+            indep = {"what": "pyarrow.compute: Table.filter(pc.greater(v, X))", "rows_per_s": tb.num_rows / t_f, "threads": pa.cpu_count()}
+        else:
+            t0 = time.perf_counter()
+            gr = ft.group_by("k").aggregate([("v", "sum"), ("v", "mean")])
+            t_g = time.perf_counter() - t0
+            indep = {"what": "pyarrow.compute: Table.filter(pc.greater(v, X)).group_by('k').aggregate([sum, mean])",
+                     "rows_per_s": tb.num_rows / (t_f + t_g), "filter_s": t_f, "group_by_s": t_g, "groups": gr.num_rows, "threads": pa.cpu_count()}
+        del tb, ft
+    except Exception as e:
+        indep = {"error": str(e)}
     all_cores = None
     try:
         all_cores = cpu_baseline_all_cores(args, x_thr, use_ref)
     except Exception as e:  # reporting only
         all_cores = {"value": None, "error": str(e)}
-    return {"value": n_batches * chunk / t, "unit": "rows/s", "cores": 1, "kind": kind, "all_cores": all_cores,
+    return {"value": n_batches * chunk / t, "unit": "rows/s", "cores": 1, "kind": kind, "all_cores": all_cores, "pyarrow_compute": indep,
             "sample": f"{n_batches} batches x {chunk} rows of the same synthetic workload "
                       f"(G={groups}, s={args.selectivity}), single-threaded like the reference executor; "
                       + ("NumPy compare + pyarrow filter" if args.workload == "filter" else
@@ -392,7 +412,59 @@ def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream,
         state["outs"] = ops.project_many([("add", ("mul", "v", 2), 1), ("sub", "v", "a"), ("mul", "a", "b")], cols, length=n, stream=stream)
     ms, sp = _measure(torch, lib, ctypes, proj, [b"project_kernel"], steps, warmup + 1)
     out["configs[4] projection"] = _entry(f"projection v*2+1, v-a, a*b over {n:.3g} fp64 rows (one fused kernel)", n, ms, sp, 48.0 * n, n)
+    del v4, ca, cb, cols, v4col
     state.clear()
+    # ---- BASELINE configs[3], the ONE-GPU leg: the same query over 60 HBM-resident batches of 2^24 rows streamed into ONE operator
+    # (what TableReaderOperator / stream_csv hand the aggregate), G = 1e6 and G = 7
+    B = 1 << 24
+    nb = min(60, max(1, n // B))
+    for gs, tag in ((1_000_000, "G=1e6"), (7, "G=7")):
+        if gs > groups:
+            continue
+        kg = ops.project(("mod", "k", gs), {"k": kcol}, length=n, stream=stream)
+        kt = torch.as_tensor(CudaArrayView(kg.values_ptr, n, "<i8"), device=device)
+        vt = torch.as_tensor(CudaArrayView(vcol.values_ptr, n, "<f8"), device=device)
+        parts = [(DeviceColumn.from_torch(kt[i * B:(i + 1) * B]), DeviceColumn.from_torch(vt[i * B:(i + 1) * B])) for i in range(nb)]
+
+        def streamed():
+            agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())])
+            agg.set_predicate(">", x_thr)
+            for kc_, vc_ in parts:
+                agg.next([kc_], [vc_, vc_], pred=vc_, nrows=B, stream=stream)
+            state["cols"] = agg.result_device(stream=stream)
+            state["ng"] = agg.result_rows
+        ms, sp = _measure(torch, lib, ctypes, streamed, AGG_SPANS, 2, 1)
+        out[f"configs[3] one-GPU leg, {tag}"] = _entry(
+            f"{nb} batches x 2^24 rows (HBM-resident) streamed into one operator, result columns included; {tag}", nb * B, ms, sp,
+            16.0 * nb * B + 24.0 * state["ng"], state["ng"], {"batches": nb, "ms_per_batch": ms / nb})
+        del parts, kt, vt, kg
+    state.clear()
+    # ---- SURVEY.md 8d's second line: END TO END from HOST memory -- Arrow record batches in pageable host memory through the
+    # Arrow-level boundary (vnm_agg_op_next / vnm_agg_op_result = vinum_lib.SingleNumericalHashAggregate.next / .result):
+    # pinned double-buffered staging -> HBM -> fused filter-less aggregate -> Arrow result on the host.  2^24-row batches.
+    try:
+        from vinum_amd import vinum_lib as vl
+        ne = min(n, 1 << 27)
+        rng = np.random.default_rng(7)
+        hk = rng.integers(0, 1000, ne).astype(np.int64)
+        hv = rng.integers(0, 1 << 14, ne).astype(np.float64) / 128.0
+        hb = pa.table({"k": hk, "v": hv}).to_batches(max_chunksize=B)
+        best = None
+        for rep in range(3):
+            agg = vl.SingleNumericalHashAggregate(["k"], ["k"], [vl.AggFuncDef(vl.SUM, "v", "s"), vl.AggFuncDef(vl.AVG, "v", "a")])
+            t0 = time.perf_counter()
+            for b in hb:
+                agg.next(b)
+            res = agg.result()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out["h2d_end_to_end"] = {"workload": f"SELECT k,sum(v),avg(v) GROUP BY k over {ne:.3g} HOST-resident rows (pageable Arrow buffers, 1000 groups) in "
+                                             f"2^24-row record batches through vnm_agg_op_next / vnm_agg_op_result, Arrow result on the host",
+                                 "rows_per_s": ne / best, "ms": best * 1e3, "pcie_GB_per_s": 16.0 * ne / best / 1e9, "result_rows": res.num_rows,
+                                 "note": "PCIe-inclusive: never the bench value (inputs of `value` are resident in HBM)"}
+        del hb, hk, hv
+    except Exception as e:
+        out["h2d_end_to_end"] = {"error": str(e)}
     return out
 
 
@@ -661,7 +733,7 @@ def main():
     # HBM bytes per step from the PMC passes of the SAME command (tools/profile.sh -> profiles/rNN_rocprofv3_pmc_*.txt),
     # newest round first; hinted and hint-less runs take different paths, so they have different entries
     key = f"{args.workload}_N{n:.0e}_G{groups:.0e}_s{args.selectivity}" + ("_hint" if args.hint else "")
-    for tf in ("r02_traffic.json", "r01_traffic.json"):
+    for tf in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", tf)) as f:
                 tj = json.load(f)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the rocprofv3 summaries kept under profiles/ (run on the GPU box: gpurun -- 'bash tools/profile.sh r01').
 # Kernel trace and each PMC counter are collected in SEPARATE runs (MI355X_MICROARCH.md, HBM section).
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
@@ -21,9 +21,9 @@ for wl in "groupby --groups 1e8" "groupby --groups 7" "groupby --groups 1e3" "gr
     tag=$(echo $wl | tr -d ' -' ); 
     prof ks_$tag --kernel-trace -- --workload $wl --steps 5 --warmup 2 > $OUT/${R}_rocprofv3_kernel_stats_$tag.txt
 done
-for wl in "groupby --groups 1e8" "filter"; do
+for wl in "groupby --groups 1e8" "filter" "groupby --groups 1e6" "topk --limit 0"; do
     tag=$(echo $wl | tr -d ' -' )
     { prof pf_$tag --pmc FETCH_SIZE --kernel-trace -- --workload $wl --steps 2 --warmup 1
       prof pw_$tag --pmc WRITE_SIZE --kernel-trace -- --workload $wl --steps 2 --warmup 1; } > $OUT/${R}_rocprofv3_pmc_$tag.txt
 done
-ls -la $OUT
+cd $ROOT && cp $OUT/${R}_*.txt profiles/ 2>/dev/null; python tools/traffic_from_pmc.py $R; cp profiles/${R}_traffic.json $OUT/; ls -la $OUT
