@@ -265,6 +265,132 @@ def filter_batch(batch: pa.RecordBatch, mask: np.ndarray, mask_valid=None) -> pa
     return pa.RecordBatch.from_arrays(arrays, names=batch.schema.names)
 
 
+GENERIC = 3   # GenericHashAggregate: a class of the reference's pybind module, not a kind of the C restatement
+
+
+def _is_numeric_type(t: pa.DataType) -> bool:        # vinum/core/aggregate.py:63-66
+    return pa.types.is_integer(t) or pa.types.is_floating(t) or pa.types.is_temporal(t)
+
+
+class OracleGenericAggregate:
+    """TEST INFRASTRUCTURE (pure Python row loops: small inputs only).  Restates what the reference does with NON-NUMERIC data:
+
+    * group keys of any type -- GenericHashAggregate keys its map on vectors of arrow::Scalar, equal when every scalar Equals
+      (a NULL scalar equals a NULL scalar): generic_hash_aggregate.h:10-45, generic_hash_aggregate.cpp:14-40.  Restated as:
+      every non-numeric key value is replaced by the index of its first appearance (a Python dict: value equality), NULL stays
+      NULL, and the coded rows go through the C restatement of Single/MultiNumericalHashAggregate -- which groups by value
+      equality with NULL as a group of its own, i.e. the same partition of the rows;
+    * COUNT over a non-numeric column -- CountFunc only consults IsNull (agg_funcs.h:129-161): an int8 column with the same
+      validity is counted instead;
+    * MIN / MAX over strings -- StringMinMaxFunc, agg_funcs.h:219-261: NULL rows are skipped, a group's state starts NULL,
+      `if ((row_val < last_view) ^ is_max) last = row_val` with string_view's byte-wise operator<.  Restated row by row.
+    kind: ONE_GROUP / SINGLE / MULTI / GENERIC (the reference's Single and Multi classes accept string aggregate inputs too:
+    TEST_F Single_/Multi_Int64Grp_StringArgFuncs, hash_agg_test.cpp:866-884)."""
+
+    def __init__(self, kind, groupby_cols, agg_cols, funcs):
+        self.kind, self.groupby, self.agg_cols, self.funcs = kind, list(groupby_cols), list(agg_cols), [tuple(f) for f in funcs]
+        self._inner = None
+        self._codes = {}          # key column -> {python value: code}
+        self._values = {}         # key column -> [python value per code]
+        self._types = {}
+        self._str = {}            # (group key tuple) -> [state per string function]
+        self._str_funcs = []
+
+    def _init(self, schema):
+        for c in self.groupby:
+            if schema.get_field_index(c) < 0:
+                raise RuntimeError("Column not found: " + c)
+            if not _is_numeric_type(schema.field(c).type):
+                self._codes[c], self._values[c], self._types[c] = {}, [], schema.field(c).type
+        self._stand_in = set()
+        self._schema_types = {f.name: f.type for f in schema}
+        for i, (f, col, out) in enumerate(self.funcs):
+            if col and not _is_numeric_type(schema.field(col).type):
+                if f == COUNT:
+                    self._stand_in.add(col)
+                elif f in (MIN, MAX):
+                    self._str_funcs.append(i)
+                else:
+                    raise RuntimeError("Column data type is not supported by " + ("sum()." if f == SUM else "avg()."))
+        inner_kind = ONE_GROUP if not self.groupby else (SINGLE if len(self.groupby) == 1 and self.kind != MULTI else MULTI)
+        self._numeric_funcs = [fn for i, fn in enumerate(self.funcs) if i not in self._str_funcs]
+        self._inner = OracleAggregate(inner_kind, self.groupby, self.groupby, self._numeric_funcs)
+
+    def next(self, batch: pa.RecordBatch):
+        if self._inner is None:
+            self._init(batch.schema)
+        n = batch.num_rows
+        arrays, names = [], []
+        key_rows = []
+        for name in batch.schema.names:
+            col = batch.column(batch.schema.get_field_index(name))
+            if name in self._codes:
+                codes, table, vals = [], self._codes[name], self._values[name]
+                for v in col.to_pylist():
+                    if v is None:
+                        codes.append(None)
+                    else:
+                        if v not in table:
+                            table[v] = len(vals)
+                            vals.append(v)
+                        codes.append(table[v])
+                col = pa.array(codes, type=pa.int32())
+            elif name in self._stand_in:
+                col = pa.array([0 if ok else None for ok in col.is_valid().to_pylist()], type=pa.int8())
+            elif not _is_numeric_type(col.type):
+                continue
+            arrays.append(col); names.append(name)
+        coded = pa.RecordBatch.from_arrays(arrays, names=names)
+        self._inner.next(coded)
+        if self._str_funcs:
+            keys = [coded.column(coded.schema.get_field_index(c)) for c in self.groupby]
+            # group identity as the numeric classes see it: the key's bit pattern, NULL its own group
+            kb = [[(None if v is None else (float(v).hex() if isinstance(v, float) else v)) for v in k.to_pylist()] for k in keys]
+            ins = {i: batch.column(batch.schema.get_field_index(self.funcs[i][1])).to_pylist() for i in self._str_funcs}
+            for r in range(n):
+                g = tuple(k[r] for k in kb)
+                st = self._str.setdefault(g, [None] * len(self._str_funcs))       # Init: NULL unless the first row has a value
+                for j, i in enumerate(self._str_funcs):
+                    v = ins[i][r]
+                    if v is None:
+                        continue                                                   # NextIfNull: skipped
+                    vb = v.encode() if isinstance(v, str) else bytes(v)
+                    if st[j] is None:
+                        st[j] = (vb, v)
+                    elif (vb < st[j][0]) ^ (self.funcs[i][0] == MAX):
+                        st[j] = (vb, v)
+
+    def result(self) -> pa.RecordBatch:
+        res = self._inner.result()
+        nk = len(self.groupby)
+        rows = res.num_rows
+        key_cols = [res.column(j) for j in range(nk)]
+        kb = [[(None if v is None else (float(v).hex() if isinstance(v, float) else v)) for v in k.to_pylist()] for k in key_cols]
+        out_arrays, out_names = [], []
+        for c in self.agg_cols:
+            col = res.column(res.schema.get_field_index(c))
+            if c in self._codes:
+                vals = self._values[c]
+                col = pa.array([None if v is None else vals[v] for v in col.to_pylist()], type=self._types[c])
+            out_arrays.append(col); out_names.append(c)
+        ni = 0
+        for i, (f, colname, out) in enumerate(self.funcs):
+            if i in self._str_funcs:
+                j = self._str_funcs.index(i)
+                vals = []
+                for r in range(rows):
+                    st = self._str.get(tuple(k[r] for k in kb), [None] * len(self._str_funcs))[j]
+                    vals.append(None if st is None else st[1])
+                out_arrays.append(pa.array(vals, type=self._in_type(colname)))
+            else:
+                out_arrays.append(res.column(nk + ni)); ni += 1
+            out_names.append(out)
+        return pa.RecordBatch.from_arrays(out_arrays, names=out_names)
+
+    def _in_type(self, colname):
+        return self._schema_types[colname]
+
+
 class OracleSort:
     """Sort.next/sorted (sort.cpp:11-63): buffer batches, stable multi-key sort, take all columns."""
 

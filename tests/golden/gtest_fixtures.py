@@ -10,8 +10,11 @@ Source of the numbers: /root/reference/vinum_cpp/test/hash_agg_test.cpp
     sorted ascending by the listed key column(s) (nulls last) and compared exactly (:75-136).
 
 Only values, validity flags, types and the (groupby_cols, agg_cols, agg_funcs) triples are
-recorded here.  String/boolean-keyed cases (GenericHashAggregate) and string MIN/MAX are out of
-scope for the GPU path and are not transcribed.
+recorded here.  Round 3: the string / boolean columns of the test table, the GenericHashAggregate
+runs of every case (TEST_F Generic_* :816-824, :846-854, :886-894, :916-924, :936-944, :976-984),
+the string-keyed case (CreateStringGrp_DoubleArgFuncs :286-338), the boolean-keyed case
+(CreateBooleanGrp_DateArgFuncs :601-650, TEST_F :946-954) and the string MIN / MAX case
+(CreateInt64Grp_StringArgFuncs :439-477, TEST_F Single_/Multi_/Generic_ :866-894) are transcribed too.
 
 Expected output column NAMES are ours (out_col_name of each AggFuncDef); the gtest's expected
 schemas carry different labels, so comparisons are positional.
@@ -21,6 +24,7 @@ import pyarrow as pa
 
 COUNT_STAR, COUNT, MIN, MAX, SUM, AVG = range(6)
 ONE_GROUP, SINGLE, MULTI = range(3)
+GENERIC = 3      # GenericHashAggregate (vinum/core/vinum_lib.cpp:92-109): not a kind of the C ABI, a class of vinum_amd.vinum_lib
 
 
 def _arr(vals, valid, t):
@@ -39,12 +43,23 @@ T, F = True, False
 ALL8 = [T] * 8
 
 
+def _str(vals, valid):
+    return pa.array([v if ok else None for v, ok in zip(vals, valid)], type=pa.string())
+
+
 def test_table() -> pa.Table:
-    """hash_agg_test.cpp:155-249 (numeric / temporal columns only)."""
+    """hash_agg_test.cpp:155-249"""
     cols = {
         "id": _arr([1, 2, 3, 4, 5, 6, 7, 8], ALL8, "int64"),
         "timestamp_int64": _arr([1602127614, 1602217613, 1602304012, 1602390411, 0, 1602563209, 0, 1602736007],
                                 [T, T, T, T, F, T, F, T], "int64"),
+        "date": _str(["", "2020-10-09T04:26:53", "2020-10-10T04:26:52", "2020-10-11T04:26:51", "2020-10-12T04:26:50",
+                      "2020-10-13T04:26:49", "0", "2020-10-15T04:26:47"], [F, T, T, T, T, T, F, T]),
+        "is_vendor": pa.array([v if ok else None for v, ok in zip([True, True, False, False, True, False, False, False],
+                                                                  [T, T, T, F, T, F, F, F])], type=pa.bool_()),
+        "city_from": _str(["", "Munich", "", "San Francisco", "Berlin", "Munich", "Berlin", "Berlin"], [F, T, F, T, T, T, T, T]),
+        "city_to": _str(["Munich", "Riva", "Naples", "Naples", "Riva", "Riva", "Munich", "Munich"], ALL8),
+        "name": _str(["Joe", "", "Joseph", "Joseph", "", "Jonas", "Joseph", "Joe"], [T, F, T, T, F, T, T, T]),
         "lat": _arr([52.51, 48.51, 44.89, 42.89, 44.89, 48.51, 44.89, 52.51], ALL8, "float64"),
         "lng": _arr([13.66, 12.3, 14.23, 15.89, 14.23, 12.3, 14.23, 13.66], ALL8, "float64"),
         "total": _arr([0, 143.15, 33.4, 53.1, 0, 0, 33.4, 0], [F, T, T, T, F, F, T, F], "float64"),
@@ -93,7 +108,7 @@ def _dec(vals):
 CASES = {
     # CreateDoubleGrp_IntArgFuncs :344-390; TEST_F Single_/Multi_DoubleGrp_IntArgFuncs :826-844
     "double_grp__int_arg_funcs": dict(
-        table="test", kinds=[SINGLE, MULTI], groupby=["lat"], agg_cols=["lat"],
+        table="test", kinds=[SINGLE, MULTI, GENERIC], groupby=["lat"], agg_cols=["lat"],
         funcs=[(COUNT_STAR, "", "count"), (MIN, "id", "min_0"), (MAX, "id", "max_0"),
                (SUM, "id", "sum_0"), (AVG, "id", "avg_0")],
         sort_cols=[0],
@@ -120,7 +135,7 @@ CASES = {
         ]),
     # CreateInt8Grp_DoubleArgFuncs :492-546; TEST_F Single_/Multi_Int8Grp_DoubleArgFuncs :896-914
     "int8_grp__double_arg_funcs": dict(
-        table="test", kinds=[SINGLE, MULTI], groupby=["grp_int8"], agg_cols=["grp_int8"],
+        table="test", kinds=[SINGLE, MULTI, GENERIC], groupby=["grp_int8"], agg_cols=["grp_int8"],
         funcs=[(COUNT_STAR, "", "count"), (COUNT, "total", "count_9"), (MIN, "lat", "min_6"),
                (MAX, "lat", "max_6"), (SUM, "lat", "sum_6"), (AVG, "lat", "avg_6")],
         sort_cols=[0],
@@ -135,7 +150,7 @@ CASES = {
         ]),
     # CreateMultiIntGrp_DateArgFuncs :548-611; TEST_F Multi_MultiIntGrp_DateArgFuncs :926-934
     "multi_int_grp__date_arg_funcs": dict(
-        table="test", kinds=[MULTI], groupby=["grp_neg_int8", "date64", "time32", "timestamp"],
+        table="test", kinds=[MULTI, GENERIC], groupby=["grp_neg_int8", "date64", "time32", "timestamp"],
         agg_cols=["grp_neg_int8", "date64", "time32", "timestamp"],
         funcs=[(COUNT_STAR, "", "count"), (MIN, "date64", "min_12"), (MAX, "timestamp", "max_14"),
                (SUM, "time32", "sum_13")],
@@ -156,7 +171,7 @@ CASES = {
         ]),
     # CreateNegInt64Grp_TimestampArgFuncs :652-707; TEST_F Single_/Multi_NegInt64Grp_... :956-974
     "neg_int64_grp__timestamp_arg_funcs": dict(
-        table="test", kinds=[SINGLE, MULTI], groupby=["grp_neg_int64"], agg_cols=["grp_neg_int64"],
+        table="test", kinds=[SINGLE, MULTI, GENERIC], groupby=["grp_neg_int64"], agg_cols=["grp_neg_int64"],
         funcs=[(COUNT_STAR, "", "count"), (COUNT, "timestamp", "count_ts"), (MIN, "timestamp", "min_14"),
                (MAX, "timestamp", "max_14"), (AVG, "grp_int8", "avg_10"), (AVG, "grp_neg_int8", "avg_11")],
         sort_cols=[0],
@@ -169,6 +184,50 @@ CASES = {
             _arr([1611664420588, 1611664414385, 1611664420588, 0], [T, T, T, F], "timestamp_ms"),
             _arr([3.0, 1.5, 1.5, 1.0], [T] * 4, "float32"),
             _arr([3.0, 0, 0, 1.0], [T] * 4, "float32"),
+        ]),
+    # CreateStringGrp_DoubleArgFuncs :286-338; TEST_F Generic_StringGrp_DoubleArgFuncs :816-824
+    "string_grp__double_arg_funcs": dict(
+        table="test", kinds=[GENERIC], groupby=["city_from"], agg_cols=["city_from"],
+        funcs=[(COUNT_STAR, "", "count"), (COUNT, "total", "count_9"), (MIN, "lat", "min_6"),
+               (MAX, "lat", "max_6"), (SUM, "lat", "sum_6"), (AVG, "lat", "avg_6")],
+        sort_cols=[0],
+        expected=[
+            _str(["Berlin", "Munich", "San Francisco", ""], [T, T, T, F]),
+            _arr([3, 2, 1, 2], [T] * 4, "uint64"),
+            _arr([1, 1, 1, 1], [T] * 4, "uint64"),
+            _arr([44.89, 48.51, 42.89, 44.89], [T] * 4, "float64"),
+            _arr([52.51, 48.51, 42.89, 52.51], [T] * 4, "float64"),
+            _arr([142.29, 97.02, 42.89, 97.4], [T] * 4, "float64"),
+            _arr([47.43, 48.51, 42.89, 48.7], [T] * 4, "float64"),
+        ]),
+    # CreateInt64Grp_StringArgFuncs :439-477; TEST_F Single_/Multi_/Generic_Int64Grp_StringArgFuncs :866-894
+    # (COUNT, MIN and MAX of a STRING column: StringMinMaxFunc agg_funcs.h:219-261)
+    "int64_grp__string_arg_funcs": dict(
+        table="test", kinds=[SINGLE, MULTI, GENERIC], groupby=["id"], agg_cols=["id"],
+        funcs=[(COUNT, "date", "count_2"), (MIN, "date", "min_2"), (MAX, "date", "max_2")],
+        sort_cols=[0],
+        expected=[
+            _arr([1, 2, 3, 4, 5, 6, 7, 8], ALL8, "int64"),
+            _arr([0, 1, 1, 1, 1, 1, 0, 1], ALL8, "uint64"),
+            _str(["", "2020-10-09T04:26:53", "2020-10-10T04:26:52", "2020-10-11T04:26:51", "2020-10-12T04:26:50",
+                  "2020-10-13T04:26:49", "", "2020-10-15T04:26:47"], [F, T, T, T, T, T, F, T]),
+            _str(["", "2020-10-09T04:26:53", "2020-10-10T04:26:52", "2020-10-11T04:26:51", "2020-10-12T04:26:50",
+                  "2020-10-13T04:26:49", "", "2020-10-15T04:26:47"], [F, T, T, T, T, T, F, T]),
+        ]),
+    # CreateBooleanGrp_DateArgFuncs :601-650; TEST_F BooleanGrp_DateArgFuncs :946-954 (sorted by column 1, the count: Arrow
+    # cannot sort booleans).  SUM(time32) keeps time32 (agg_func_factory.cpp:132-137), AVG is float64.
+    "boolean_grp__date_arg_funcs": dict(
+        table="test", kinds=[GENERIC], groupby=["is_vendor"], agg_cols=["is_vendor"],
+        funcs=[(COUNT_STAR, "", "count"), (MIN, "time32", "min_12"), (MAX, "time32", "max_14"),
+               (SUM, "time32", "sum_13"), (AVG, "time32", "avg_13")],
+        sort_cols=[1],
+        expected=[
+            pa.array([False, True, None], type=pa.bool_()),
+            _arr([1, 3, 4], [T] * 3, "uint64"),
+            _arr([0, 7, 7], [F, T, T], "time32ms"),
+            _arr([0, 41, 130], [F, T, T], "time32ms"),
+            _arr([0, 48, 267], [F, T, T], "time32ms"),
+            _arr([0, 24.0, 89.0], [F, T, T], "float64"),
         ]),
     # CreateNoGrp_AggFuncs :709-757; TEST_F NoGrp_AggFuncs :986-993
     "no_grp__agg_funcs": dict(

@@ -43,6 +43,10 @@ def _bits(arr: pa.Array):
     if pa.types.is_decimal(t):
         vals = [int(x) if x is not None else 0 for x in arr.to_pylist()]
         return valid, vals
+    if pa.types.is_string(t) or pa.types.is_large_string(t) or pa.types.is_binary(t) or pa.types.is_large_binary(t):
+        return valid, [x if x is not None else "" for x in arr.to_pylist()]     # (string MIN / MAX, string group keys)
+    if pa.types.is_boolean(t):
+        return valid, np.where(valid, arr.fill_null(False).to_numpy(zero_copy_only=False).astype(np.uint64), 0)
     width = t.bit_width // 8
     view_t = {1: pa.uint8(), 2: pa.uint16(), 4: pa.uint32(), 8: pa.uint64()}[width]
     raw = arr.view(view_t) if t != view_t else arr
@@ -105,8 +109,8 @@ def assert_col_equal(a: pa.Array, e: pa.Array, name="", ulps=0, check_type=True)
     va, xa = _bits(a)
     ve, xe = _bits(e)
     assert np.array_equal(va, ve), f"{name}: validity differs at rows {np.nonzero(va != ve)[0][:8]}"
-    if pa.types.is_decimal(a.type):
-        assert xa == xe, f"{name}: decimal values differ"
+    if isinstance(xa, list):
+        assert xa == xe, f"{name}: values differ: {[(x, y) for x, y in zip(xa, xe) if x != y][:4]}"
         return
     if ulps and pa.types.is_floating(a.type):
         dt = np.float64 if pa.types.is_float64(a.type) else np.float32

@@ -90,12 +90,113 @@ def _cstrs(items):
     return arr
 
 
+def _is_numeric(t: pa.DataType) -> bool:        # vinum/core/aggregate.py:63-66
+    return pa.types.is_integer(t) or pa.types.is_floating(t) or pa.types.is_temporal(t)
+
+
+def _canonical_order(batch: pa.RecordBatch, key_names):
+    """Row order by the key columns' (NULL flag, bit pattern): the same for two results over the same groups whatever order their
+    operators emitted them in (group identity is the key's bit pattern -- -0.0 and +0.0 are two groups, NULL is one)."""
+    import numpy as np
+    if batch.num_rows <= 1 or not key_names:
+        return np.arange(batch.num_rows)
+    keys = []
+    for k in key_names:
+        a = batch.column(batch.schema.names.index(k))
+        valid = np.ones(len(a), bool) if a.null_count == 0 else a.is_valid().to_numpy(zero_copy_only=False)
+        w = a.type.bit_width // 8
+        raw = a.view({1: pa.uint8(), 2: pa.uint16(), 4: pa.uint32(), 8: pa.uint64()}[w]).fill_null(0).to_numpy(zero_copy_only=False)
+        keys.append((~valid).astype(np.uint8))
+        keys.append(np.where(valid, raw.astype(np.uint64), 0))
+    return np.lexsort(keys[::-1])
+
+
+class _StringMinMax:
+    """MIN / MAX of string / binary columns (StringMinMaxFunc, agg_funcs.h:219-261: NULLs skipped, all-NULL group -> NULL, byte-wise
+    `row < last`), for every operator class (the reference runs Single_/Multi_/Generic_Int64Grp_StringArgFuncs,
+    hash_agg_test.cpp:866-894).  The GPU aggregates order-preserving RANKS: per batch the column is dictionary-encoded (Arrow C++,
+    one pass), the batch's dictionary is sorted, and a numeric operator of the caller's class takes MIN / MAX of the int32 ranks per
+    group; the winners go back to strings -- one candidate per group, batch and function.  result() ranks the candidates of all
+    batches against each other and takes MIN / MAX once more.  Strings never reach the device; string comparisons happen once per
+    distinct value (the dictionary sort), not once per row."""
+
+    def __init__(self, op_cls, groupby_cols, funcs):
+        self._cls, self._groupby = op_cls, list(groupby_cols)
+        self._funcs = list(funcs)                       # AggFuncDefs (MIN / MAX over non-numeric columns)
+        self._partials = []
+
+    def _aggregate(self, key_arrays, rank_arrays, names_of):
+        """one numeric operator over (keys, int32 rank columns): MIN / MAX per function"""
+        defs = [AggFuncDef(f.func, names_of[i], f"r{i}") for i, f in enumerate(self._funcs)]
+        op = self._cls(defs) if self._cls is OneGroupAggregate else self._cls(self._groupby, self._groupby, defs)
+        cols = list(key_arrays) + list(rank_arrays.values())
+        names = list(self._groupby) + list(rank_arrays.keys())
+        op.next(pa.RecordBatch.from_arrays(cols, names=names))
+        return op.result()
+
+    @staticmethod
+    def _ranks(column):
+        """(int32 ranks with the column's NULLs, sorted dictionary): rank order == byte-wise string order"""
+        import numpy as np
+        import pyarrow.compute as pc
+        if isinstance(column, pa.ChunkedArray):
+            column = column.combine_chunks()
+        enc = column.dictionary_encode()
+        d = enc.dictionary
+        if pa.types.is_string(d.type) or pa.types.is_large_string(d.type):
+            d_sort = d.cast(pa.large_binary() if pa.types.is_large_string(d.type) else pa.binary())   # byte-wise, as string_view's operator<
+        else:
+            d_sort = d
+        order = pc.sort_indices(d_sort).to_numpy(zero_copy_only=False)
+        rank_of = np.empty(len(d), np.int32)
+        rank_of[order] = np.arange(len(d), dtype=np.int32)
+        idx = enc.indices
+        ranks = rank_of[idx.fill_null(0).to_numpy(zero_copy_only=False).astype(np.int64)] if len(d) else np.zeros(len(idx), np.int32)
+        mask = ~idx.is_valid().to_numpy(zero_copy_only=False) if idx.null_count else None
+        return pa.array(ranks, type=pa.int32(), mask=mask), d.take(pa.array(order))
+
+    def next(self, key_arrays, batch: pa.RecordBatch) -> None:
+        ranks, dicts, names_of = {}, {}, []
+        for f in self._funcs:
+            c = f.column_name
+            if c not in ranks:
+                ranks[c], dicts[c] = self._ranks(batch.column(batch.schema.names.index(c)))
+            names_of.append(c)
+        res = self._aggregate(key_arrays, ranks, names_of)
+        nk = len(self._groupby)
+        cand = [dicts[f.column_name].take(res.column(nk + i)) for i, f in enumerate(self._funcs)]     # NULL rank -> NULL string
+        self._partials.append(pa.RecordBatch.from_arrays([res.column(j) for j in range(nk)] + cand,
+                                                         names=self._groupby + [f"s{i}" for i in range(len(self._funcs))]))
+
+    def result(self) -> pa.RecordBatch:
+        """(keys..., one string column per function), one row per group"""
+        t = pa.Table.from_batches(self._partials).combine_chunks()
+        nk = len(self._groupby)
+        if len(self._partials) == 1:
+            return t.to_batches()[0]
+        # candidates of all batches against each other: one shared sorted dictionary per function, ranks, MIN / MAX again
+        ranks, dicts, names_of = {}, {}, []
+        for i in range(len(self._funcs)):
+            ranks[f"c{i}"], dicts[f"c{i}"] = self._ranks(t.column(nk + i))
+            names_of.append(f"c{i}")
+        res = self._aggregate([t.column(j).combine_chunks() for j in range(nk)], ranks, names_of)
+        cand = [dicts[f"c{i}"].take(res.column(nk + i)) for i in range(len(self._funcs))]
+        return pa.RecordBatch.from_arrays([res.column(j) for j in range(nk)] + cand,
+                                          names=self._groupby + [f"s{i}" for i in range(len(self._funcs))])
+
+
 class _HashAggregateBase:
     _KIND = None
 
     def __init__(self, groupby_cols, agg_cols, agg_funcs):
+        self._groupby, self._agg_cols, self._funcs = list(groupby_cols), list(agg_cols), list(agg_funcs)
+        self._h = None
+        self._strmm = None          # _StringMinMax for MIN / MAX over non-numeric columns
+        self._stand_in = set()      # non-numeric columns that are only COUNTed: an int8 column with the same validity stands in
+        self._create(self._groupby, self._agg_cols, self._funcs)
+
+    def _create(self, groupby_cols, agg_cols, agg_funcs):
         lib = L.lib()
-        groupby_cols, agg_cols, agg_funcs = list(groupby_cols), list(agg_cols), list(agg_funcs)
         ftypes = (ctypes.c_int * max(len(agg_funcs), 1))(*[int(f.func) for f in agg_funcs])
         self._h = lib.vnm_agg_op_create(self._KIND, len(groupby_cols), _cstrs(groupby_cols), len(agg_cols),
                                         _cstrs(agg_cols), len(agg_funcs), ftypes,
@@ -103,6 +204,54 @@ class _HashAggregateBase:
                                         _cstrs([f.out_col_name for f in agg_funcs]))
         if not self._h:
             raise RuntimeError(L.last_error())
+
+    def _first_batch(self, batch: pa.RecordBatch) -> None:
+        """The first batch fixes the schema (base_aggregate.cpp:91-119).  Functions over NON-NUMERIC columns: COUNT counts through
+        an int8 stand-in with the column's validity; MIN / MAX of strings / binaries go to _StringMinMax; SUM / AVG raise what the
+        reference raises (agg_func_factory.cpp:174,245)."""
+        schema = batch.schema
+        str_funcs = []
+        for f in self._funcs:
+            c = f.column_name
+            if not c or c not in schema.names or _is_numeric(schema.field(c).type):
+                continue
+            t = schema.field(c).type
+            if f.func == AggFuncType.COUNT:
+                self._stand_in.add(c)
+            elif f.func in (AggFuncType.MIN, AggFuncType.MAX) and (pa.types.is_string(t) or pa.types.is_large_string(t) or pa.types.is_binary(t)
+                                                                  or pa.types.is_large_binary(t)):
+                str_funcs.append(f)
+            else:
+                raise RuntimeError({AggFuncType.MIN: "Column data type is not supported by min()/max().",
+                                    AggFuncType.MAX: "Column data type is not supported by min()/max().",
+                                    AggFuncType.SUM: "Column data type is not supported by sum().",
+                                    AggFuncType.AVG: "Column data type is not supported by avg()."}[f.func])
+        if str_funcs:
+            for c in self._groupby:
+                if c not in schema.names:
+                    raise RuntimeError(f"Column not found: {c}")
+            # the numeric operator keeps every other function and emits ALL group-by columns: the two results are lined up by key
+            L.lib().vnm_agg_op_destroy(self._h)
+            self._h = None
+            rest = [f for f in self._funcs if f not in str_funcs]
+            self._create(self._groupby, self._groupby, rest)
+            self._strmm = _StringMinMax(type(self), self._groupby, str_funcs)
+
+    def _numeric_view(self, batch: pa.RecordBatch) -> pa.RecordBatch:
+        """what crosses the boundary: numeric columns as they are, COUNT-only non-numeric columns as their int8 stand-ins"""
+        import numpy as np
+        if not self._stand_in and self._strmm is None:
+            return batch
+        arrays, names = [], []
+        for i, name in enumerate(batch.schema.names):
+            col = batch.column(i)
+            if name in self._stand_in:
+                col = pa.array(np.zeros(len(col), np.int8), mask=(~col.is_valid().to_numpy(zero_copy_only=False)) if col.null_count else None)
+            elif not _is_numeric(col.type):
+                continue
+            arrays.append(col)
+            names.append(name)
+        return pa.RecordBatch.from_arrays(arrays, names=names)
 
     # The reference streams 10 000-row batches by default (vinum/__init__.py:52).  Handing each of them to the library costs ~50 us
     # of Python + Arrow C export per batch -- 20x what its rows cost on the device -- so batches below 2^20 rows are kept here
@@ -112,6 +261,9 @@ class _HashAggregateBase:
     _FLUSH_ROWS = 1 << 22
 
     def _send(self, batch: pa.RecordBatch) -> None:
+        if self._strmm is not None:
+            self._strmm.next([batch.column(batch.schema.names.index(c)) for c in self._groupby], batch)
+        batch = self._numeric_view(batch)
         c = _CStructs()
         batch._export_to_c(c.arr_ptr, c.sch_ptr)
         if L.lib().vnm_agg_op_next(self._h, c.arr_ptr, c.sch_ptr) != 0:
@@ -129,6 +281,7 @@ class _HashAggregateBase:
             # the FIRST batch goes straight through: it fixes the schema, and an unknown column or an unsupported type must raise
             # from this call as it does in the reference (base_aggregate.cpp:91-131)
             self._pending, self._pending_rows = [], 0
+            self._first_batch(batch)
             self._send(batch)
             return
         if batch.num_rows >= self._SMALL_ROWS:
@@ -147,7 +300,30 @@ class _HashAggregateBase:
         c = _CStructs()
         if L.lib().vnm_agg_op_result(self._h, c.arr_ptr, c.sch_ptr) != 0:
             raise RuntimeError(L.last_error())
-        return pa.RecordBatch._import_from_c(c.arr_ptr, c.sch_ptr)
+        res = pa.RecordBatch._import_from_c(c.arr_ptr, c.sch_ptr)
+        return res if self._strmm is None else self._with_strings(res)
+
+    def _with_strings(self, res: pa.RecordBatch) -> pa.RecordBatch:
+        """BaseAggregate::Result's column order (base_aggregate.cpp:52-60): the selected group-by columns, then EVERY function in
+        AggFuncDef order -- the numeric ones from the device operator, the string MIN / MAX from _StringMinMax, rows lined up by
+        the group keys."""
+        if not hasattr(self, "_pending"):            # no batch at all: nothing to line up (the numeric result is what there is)
+            return res
+        smm = self._strmm.result()
+        o_num, o_str = _canonical_order(res, self._groupby), _canonical_order(smm, self._groupby)
+        assert len(o_num) == len(o_str), "the numeric and the string results must hold the same groups"
+        res, smm = res.take(pa.array(o_num)), smm.take(pa.array(o_str))
+        arrays, names = [], []
+        for c in self._agg_cols:
+            arrays.append(res.column(res.schema.names.index(c))); names.append(c)
+        nk = len(self._groupby)
+        for f in self._funcs:
+            if f in self._strmm._funcs:
+                arrays.append(smm.column(nk + self._strmm._funcs.index(f)))
+            else:
+                arrays.append(res.column(res.schema.names.index(f.out_col_name)))
+            names.append(f.out_col_name)
+        return pa.RecordBatch.from_arrays(arrays, names=names)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -209,10 +385,6 @@ class KeyDictionary:
         return self.values.take(codes)
 
 
-def _is_numeric(t: pa.DataType) -> bool:        # vinum/core/aggregate.py:63-66
-    return pa.types.is_integer(t) or pa.types.is_floating(t) or pa.types.is_temporal(t)
-
-
 class GenericHashAggregate:
     """GROUP BY over keys of ANY Arrow type -- strings, bools, decimals, mixed with numeric keys
     (vinum/core/vinum_lib.cpp:92-109, vinum_cpp/src/operators/aggregate/generic_hash_aggregate.{h,cpp}).
@@ -220,14 +392,13 @@ class GenericHashAggregate:
     Non-numeric key columns are dictionary-encoded on ingest (KeyDictionary) and the query runs through the numeric GPU
     operators (single key: the whole single-key machinery incl. the partitioned paths; several keys: packed composite
     keys); result() maps the codes back, so key columns keep their type.  Aggregate INPUT columns must be numeric --
-    COUNT(col) of a non-numeric column counts through an int8 stand-in with the same validity; MIN / MAX of strings
-    (agg_funcs.h:219-261) are not available on the GPU path and raise."""
+    COUNT(col) of a non-numeric column counts through an int8 stand-in with the same validity and MIN / MAX of strings
+    (agg_funcs.h:219-261) are ranks-on-the-device (_StringMinMax), both in the numeric classes underneath."""
 
     def __init__(self, groupby_cols, agg_cols, agg_funcs):
         self._groupby, self._agg_cols, self._funcs = list(groupby_cols), list(agg_cols), list(agg_funcs)
         self._inner = None
         self._dicts = {}
-        self._stand_in = set()
 
     def _init(self, batch: pa.RecordBatch):
         schema = batch.schema
@@ -237,15 +408,7 @@ class GenericHashAggregate:
             t = schema.field(c).type
             if not _is_numeric(t):
                 self._dicts[c] = KeyDictionary(t)
-        for f in self._funcs:
-            if f.column_name and f.column_name in schema.names and not _is_numeric(schema.field(f.column_name).type):
-                if f.func != AggFuncType.COUNT:
-                    raise RuntimeError({AggFuncType.MIN: "Column data type is not supported by min()/max().",
-                                        AggFuncType.MAX: "Column data type is not supported by min()/max().",
-                                        AggFuncType.SUM: "Column data type is not supported by sum().",
-                                        AggFuncType.AVG: "Column data type is not supported by avg()."}[f.func]
-                                       + " (non-numeric aggregate inputs are CPU-only in the reference; not on the GPU path)")
-                self._stand_in.add(f.column_name)
+        # (functions over non-numeric columns -- COUNT, string MIN / MAX -- are the numeric classes' business: _first_batch)
         cls = SingleNumericalHashAggregate if len(self._groupby) == 1 else MultiNumericalHashAggregate
         self._inner = cls(self._groupby, self._agg_cols, self._funcs)
 
@@ -275,15 +438,15 @@ class GenericHashAggregate:
                 self._encode_and_send(b)
 
     def _encode_and_send(self, batch: pa.RecordBatch) -> None:
-        import numpy as np
+        fn_inputs = {f.column_name for f in self._funcs if f.column_name}
         arrays, names = [], []
         for i, name in enumerate(batch.schema.names):
             col = batch.column(i)
             if name in self._dicts:
+                if name in fn_inputs:
+                    raise RuntimeError("a non-numeric column cannot be a group key and an aggregate input at once on the GPU path")
                 col = self._dicts[name].encode(col)
-            elif name in self._stand_in:
-                col = pa.array(np.zeros(len(col), np.int8), mask=(~col.is_valid().to_numpy(zero_copy_only=False)) if col.null_count else None)
-            elif not _is_numeric(col.type):
+            elif not _is_numeric(col.type) and name not in fn_inputs:
                 continue                                     # neither a key nor an input: never staged
             arrays.append(col)
             names.append(name)
