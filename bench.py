@@ -679,7 +679,8 @@ def main():
     check = None
     if args.check and args.workload == "groupby" and args.shape == "hot":
         check = check_groupby(torch, dist, state, k, v, x_thr, world, rank, device, force_exchange)
-    names = {"filter": [b"filter_kernel"], "topk": [b"topk_sample", b"topk_select", b"topk_small_sort", b"sort_encode", b"radix_hist", b"radix_pass"], "project": [b"project_kernel"]}.get(
+    names = {"filter": [b"filter_kernel"], "topk": [b"topk_sample", b"topk_select", b"topk_small_sort", b"sort_encode", b"radix_hist", b"radix_pass",
+                                                    b"sort_sample", b"sort_scatter1", b"sort_scatter2", b"sort_local"], "project": [b"project_kernel"]}.get(
         args.workload, AGG_SPANS)
     spans = {}
     for nm in names:

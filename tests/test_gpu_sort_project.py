@@ -453,3 +453,54 @@ def test_topk_multi_key_equals_full_sort_prefix(shape, k):
             s.next(bt)
         exp = s.sorted().slice(0, k)
         util.assert_batches_equal(got, exp, what=f"multi-key topk {shape} k={k} orders={orders}")
+
+
+@pytest.mark.parametrize("case", ["f64_normal", "f64_desc_nan_negzero", "i64_few_dups", "u64_desc", "runs_of_100", "heavy_value_declines", "tiny_buckets"])
+def test_sample_sort_equals_the_lsd_sort(case, monkeypatch):
+    """The sample sort of one 8-byte key (vnm_sort_sample.inc: splitters from a sorted sample, two ring scatters into 2^18 buckets,
+    per-bucket LSD sort in LDS, rows of equal key by row id) must give the SAME row ids as the eight-pass LSD sort -- the order is
+    total (key, then row id: Sort::Sorted is stable, sort.cpp:22-40) -- and the same rebuilt key column.  Rows with equal keys in
+    short and long runs, NaN / -0.0, descending order, and data it declines (one value holding 10 % of the rows)."""
+    import torch
+    from vinum_amd import _lib as L
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    rng = np.random.default_rng(77)
+    n = 3_000_000 if case != "tiny_buckets" else 300_000
+    order = L.ASC
+    if case == "f64_normal":
+        v = rng.normal(11.0, 3.0, n)
+    elif case == "f64_desc_nan_negzero":
+        v = rng.normal(0.0, 1.0, n); v[::977] = np.nan; v[5::1201] = -0.0; v[7::1201] = 0.0; order = L.DESC
+    elif case == "i64_few_dups":
+        v = rng.integers(0, n // 4, n).astype(np.int64) - n // 8
+    elif case == "u64_desc":
+        v = rng.integers(0, 2**63, n).astype(np.uint64) * 2 + rng.integers(0, 2, n).astype(np.uint64); order = L.DESC
+    elif case == "runs_of_100":
+        v = (rng.integers(0, n // 100, n) * 1_000_003).astype(np.int64)
+    elif case == "heavy_value_declines":
+        v = rng.normal(0.0, 1.0, n); v[::10] = 12.5
+    else:
+        v = rng.normal(0.0, 1.0, n)
+    t = torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).cuda()
+    col = DeviceColumn.from_torch(t)
+    if v.dtype == np.uint64:
+        col = DeviceColumn(col._values, None, 0, n, pa.uint64(), keep=t)
+    monkeypatch.setenv("VNM_SORT_NO_SAMPLE", "1")
+    ref_idx, ref_key = ops.sort_indices_keyed([col], [order])
+    ref = torch.as_tensor(_RawI64(ref_idx.ptr, n), device="cuda").clone()
+    monkeypatch.delenv("VNM_SORT_NO_SAMPLE")
+    monkeypatch.setenv("VNM_SSORT_MIN_ROWS", "1000")
+    got_idx, got_key = ops.sort_indices_keyed([col], [order])
+    got = torch.as_tensor(_RawI64(got_idx.ptr, n), device="cuda")
+    assert bool(torch.equal(got, ref)), f"{case}: {int((got != ref).sum())} positions differ"
+    assert (got_key is None) == (ref_key is None)
+    if got_key is not None:
+        a = torch.as_tensor(_RawI64(got_key.values_ptr, n), device="cuda")
+        b = torch.as_tensor(_RawI64(ref_key.values_ptr, n), device="cuda")
+        assert bool(torch.equal(a, b))
+
+
+class _RawI64:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}

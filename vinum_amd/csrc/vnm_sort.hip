@@ -639,11 +639,143 @@ __global__ void take_kernel(vnm_dcol c, const int64_t* idx, int64_t n, void* out
     }
 }
 
+static int64_t env_sort_i64(const char* name, int64_t dflt) {
+    const char* v = getenv(name);
+    return v ? atoll(v) : dflt;
+}
+
 static int grid_for(int64_t n, int per_cu = 8) {
     int g = device_info().num_cus * per_cu;
     int64_t need = (n + 255) / 256;
     if (need < 1) need = 1;
     return g > need ? (int)need : g;
+}
+
+#include "vnm_sort_sample.inc"
+
+// Sample sort of one 8-byte key without a validity bitmap (see vnm_sort_sample.inc).  0 = done (idx_out written, *wrote_key),
+// 2 = not applicable / a bucket outgrew its room (the caller sorts with the LSD passes), 1 = error.
+static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_out, uint64_t* key_out, bool* wrote_key, hipStream_t s) {
+    if (wrote_key) *wrote_key = false;
+    const int cus = device_info().num_cus;
+    const int64_t nb = (int64_t)SS_B * SS_B;
+    const int64_t m = std::min<int64_t>(n, (int64_t)1 << 23);
+    static bool attr_set = false;
+    const size_t lds_sc = (size_t)SS_B * SS_CAP * 12;
+    if (!attr_set) {
+        VNM_HIP(hipFuncSetAttribute((const void*)ssort_scatter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc));
+        VNM_HIP(hipFuncSetAttribute((const void*)ssort_scatter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc));
+        VNM_HIP(hipFuncSetAttribute((const void*)ssort_local_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SL_LDS_BYTES));
+        VNM_HIP(hipFuncSetAttribute((const void*)onesweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OS_LDS_BYTES));
+        attr_set = true;
+    }
+    PoolScope pool;
+    // ---- splitters from a sorted sample
+    uint64_t* split = (uint64_t*)pool.take((size_t)nb * 8);
+    unsigned long long* flags = (unsigned long long*)pool.take(64);
+    if (!split || !flags) return 1;
+    VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
+    {
+        RadixBufs sr{};
+        VNM_TRY(radix_alloc(&sr, m));
+        {
+            KernelTimer timer("sort_sample", s);
+            ssort_sample_kernel<<<grid_for(m), 256, 0, s>>>(key, desc, n, m, sr.code[0]);
+        }
+        sort_iota_kernel<<<grid_for(m), 256, 0, s>>>(sr.val[0], m);
+        sr.cur = 0;
+        VNM_TRY(radix_sort_codes(&sr, m, s));
+        ssort_splitters_kernel<<<(int)((nb + 255) / 256), 256, 0, s>>>(sr.code[sr.cur], m, nb, split, flags);
+        VNM_HIP(hipGetLastError());
+        unsigned long long dup = 0;
+        VNM_HIP(hipMemcpyAsync(&dup, flags, 8, hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipStreamSynchronize(s));    // (sr goes back to the pool here)
+        if (dup) {
+            if (getenv("VNM_SORT_TRACE")) fprintf(stderr, "[sort] sample sort declined: equal splitters (heavily duplicated keys)\n");
+            return 2;
+        }
+    }
+    // ---- level 1
+    const int grid1 = (int)std::min<int64_t>((int64_t)cus * env_sort_i64("VNM_SSORT_GRID1_PER_CU", 1), std::max<int64_t>(1, (n + 2 * SS_BLOCK - 1) / (2 * SS_BLOCK)));
+    const int64_t sub = 2 * SS_BLOCK;
+    const int64_t rows_per_wg = (((n + sub - 1) / sub + grid1 - 1) / grid1) * sub;
+    const int64_t cap1 = ((rows_per_wg / SS_B + rows_per_wg / SS_B / 4 + 96) + 7) & ~7LL;
+    uint64_t* c1 = (uint64_t*)pool.take((size_t)SS_B * grid1 * cap1 * 8);
+    uint32_t* r1 = (uint32_t*)pool.take((size_t)SS_B * grid1 * cap1 * 4);
+    uint32_t* n1 = (uint32_t*)pool.take((size_t)SS_B * grid1 * 4);
+    if (!c1 || !r1 || !n1) return 1;
+    SsArgs a1{};
+    a1.key = key; a1.desc = desc; a1.nrows = n; a1.split = split;
+    a1.out_code = c1; a1.out_row = r1; a1.out_counts = n1; a1.out_cap = cap1; a1.flags = flags;
+    {
+        KernelTimer timer("sort_scatter1", s);
+        ssort_scatter_kernel<true><<<grid1, SS_BLOCK, lds_sc, s>>>(a1);
+    }
+    VNM_HIP(hipGetLastError());
+    // ---- level 2
+    int split2 = std::max(1, (grid1 + SS_MAX_REGIONS - 1) / SS_MAX_REGIONS);
+    split2 = std::max(split2, (int)env_sort_i64("VNM_SSORT_SPLIT2", 1));
+    const int64_t avg_bucket = n / nb + 1;
+    const int64_t cap2 = ((std::min<int64_t>(SS_LOCAL, avg_bucket * 2 / split2 + avg_bucket / 2 + 128)) + 7) & ~7LL;
+    uint64_t* c2 = (uint64_t*)pool.take((size_t)nb * split2 * cap2 * 8);
+    uint32_t* r2 = (uint32_t*)pool.take((size_t)nb * split2 * cap2 * 4);
+    uint32_t* n2 = (uint32_t*)pool.take((size_t)nb * split2 * 4);
+    unsigned long long* offs = (unsigned long long*)pool.take((size_t)(nb + 1) * 8);
+    if (!c2 || !r2 || !n2 || !offs) return 1;
+    SsArgs a2{};
+    a2.split = split; a2.in_code = c1; a2.in_row = r1; a2.in_counts = n1; a2.in_cap = cap1; a2.in_regions = grid1; a2.in_split = split2;
+    a2.out_code = c2; a2.out_row = r2; a2.out_counts = n2; a2.out_cap = cap2; a2.flags = flags;
+    {
+        KernelTimer timer("sort_scatter2", s);
+        ssort_scatter_kernel<false><<<SS_B * split2, SS_BLOCK, lds_sc, s>>>(a2);
+    }
+    ssort_offsets_kernel<<<1, 1024, 0, s>>>(n2, split2, nb, offs, flags);
+    VNM_HIP(hipGetLastError());
+    unsigned long long fl[2] = {0, 0};
+    VNM_HIP(hipMemcpyAsync(fl, flags, 16, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    if (getenv("VNM_SORT_TRACE")) fprintf(stderr, "[sort] sample sort: n %lld grid1 %d cap1 %lld split2 %d cap2 %lld -> fail %llu special %llu\n",
+                                          (long long)n, grid1, (long long)cap1, split2, (long long)cap2, fl[0], fl[1]);
+    if (fl[0]) return 2;
+    {
+        const int dbg = (int)env_sort_i64("VNM_SSORT_DEBUG", 0);
+        if (dbg == 7 || dbg == 8) {
+            uint32_t* seen = (uint32_t*)pool.take((size_t)n * 4);
+            if (!seen) return 1;
+            VNM_HIP(hipMemsetAsync(seen, 0, (size_t)n * 4, s));
+            VNM_HIP(hipMemsetAsync(flags + 4, 0, 8, s));
+            if (dbg == 7) ssort_check_kernel<<<4096, 256, 0, s>>>(r2, n2, cap2, nb * split2, seen, n, flags + 4);
+            else ssort_check_kernel<<<4096, 256, 0, s>>>(r1, n1, cap1, (int64_t)SS_B * grid1, seen, n, flags + 4);
+            std::vector<uint32_t> hs((size_t)n);
+            unsigned long long badv = 0;
+            VNM_HIP(hipMemcpy(hs.data(), seen, (size_t)n * 4, hipMemcpyDeviceToHost));
+            VNM_HIP(hipMemcpy(&badv, flags + 4, 8, hipMemcpyDeviceToHost));
+            int64_t miss = 0, dup = 0, firstmiss = -1;
+            for (int64_t i = 0; i < n; i++) { if (hs[i] == 0) { if (firstmiss < 0) firstmiss = i; miss++; } else if (hs[i] > 1) dup++; }
+            fprintf(stderr, "[sort] debug level %d regions: %lld rows missing (first %lld), %lld duplicated, %llu out of range\n", dbg == 7 ? 2 : 1,
+                    (long long)miss, (long long)firstmiss, (long long)dup, badv);
+        }
+    }
+    // ---- per-bucket LDS sort, straight into the caller's buffers
+    SsLocalArgs la{};
+    la.code = c2; la.row = r2; la.counts = n2; la.cap = cap2; la.split = split2; la.offs = offs; la.nbuckets = nb;
+    la.idx_out = idx_out;
+    const bool keyed = key_out != nullptr && fl[1] == 0;
+    la.key_out = keyed ? key_out : nullptr; la.key_type = key.type; la.key_desc = desc; la.flags = flags;
+    la.debug = (int)env_sort_i64("VNM_SSORT_DEBUG", 0);
+    {
+        KernelTimer timer("sort_local", s);
+        ssort_local_kernel<<<(int)std::min<int64_t>(nb, (int64_t)cus * 64), SL_BLOCK, SL_LDS_BYTES, s>>>(la);
+    }
+    VNM_HIP(hipGetLastError());
+    VNM_HIP(hipStreamSynchronize(s));
+    if (la.debug == 6) {
+        unsigned long long f6[8];
+        VNM_HIP(hipMemcpy(f6, flags, 64, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[sort] debug: %llu positions beyond the end (max %llu), %llu in the long path\n", f6[2], f6[3], f6[4]);
+    }
+    if (wrote_key) *wrote_key = keyed;
+    return 0;
 }
 
 // full stable multi-key sort; result: row ids (uint32) in r->val[r->cur]
@@ -883,6 +1015,14 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
         // fall through to the full sort (ties / NaN / NULL heavy data, or an unlucky sample)
     }
 
+    // one 8-byte key without NULLs, many rows: sample sort (two bucket scatters + a sort in LDS) instead of eight LSD passes
+    if (n_keys == 1 && !keys[0].validity && (keys[0].type == VNM_F64 || keys[0].type == VNM_I64 || keys[0].type == VNM_U64) &&
+        n >= env_sort_i64("VNM_SSORT_MIN_ROWS", (int64_t)1 << 24) && getenv("VNM_SORT_NO_SAMPLE") == nullptr) {
+        bool wk = false;
+        const int rc = sample_sort(keys[0], orders[0] == VNM_DESC, n, out_indices, (uint64_t*)out_sorted_key0, &wk, s);
+        if (rc == 1) return 1;
+        if (rc == 0) { if (wrote_key0) *wrote_key0 = wk ? 1 : 0; return 0; }
+    }
     RadixBufs r{};
     VNM_TRY(radix_alloc(&r, n));
     bool wrote = false, wrote_key = false;
