@@ -224,3 +224,47 @@ def test_dense_table_exchange_gloo(tmp_path, world, bits, mismatch, max_elems):
         assert int(o["code0"]) == bounds[r] and len(o["c"]) == bounds[r + 1] - bounds[r]
         assert np.array_equal(o["c"], exp_c[bounds[r]:bounds[r + 1]])
         assert np.array_equal(o["s"], exp_s[bounds[r]:bounds[r + 1]])   # quantised: exact in any order
+
+
+# ---- distributed sample sort (distributed.sample_sort_exchange) ----------------------------------------------------------------
+def _worker_ssort(rank, world, port, tmp, case):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vinum_amd import distributed as D
+    rng = np.random.default_rng(300 + rank)
+    n = [5000, 0, 7001][rank % 3] if case == "uneven" else 6000
+    if case == "ints":
+        v = rng.integers(-50, 50, n).astype(np.int64)                       # heavy ties: ids must break them
+    else:
+        v = rng.normal(0, 1, n)
+        v[::97] = np.nan; v[3::101] = -0.0; v[5::101] = 0.0; v[::7] = np.round(v[::7], 1)
+    counts = [([5000, 0, 7001][r % 3] if case == "uneven" else 6000) for r in range(world)]
+    off = sum(counts[:rank])
+    ids = torch.arange(off, off + n, dtype=torch.int64)
+
+    def sort_local(codes, rids):                                             # (code, id) order with plain torch ops
+        o1 = torch.argsort(rids, stable=True)
+        return o1[torch.argsort(codes[o1], stable=True)]
+    keys, gids = D.sample_sort_exchange(torch.from_numpy(v), ids, case == "desc", sort_local, samples_per_rank=512)
+    np.savez(os.path.join(tmp, f"ss_{rank}.npz"), k=keys.numpy(), i=gids.numpy(), v=v)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "asc"), (2, "desc"), (3, "uneven"), (2, "ints")])
+def test_distributed_sample_sort_gloo(tmp_path, world, case):
+    port = 29500 + ((os.getpid() + 13 * world + len(case)) % 1000)
+    mp.spawn(_worker_ssort, args=(world, port, str(tmp_path), case), nprocs=world, join=True)
+    outs = [np.load(tmp_path / f"ss_{r}.npz") for r in range(world)]
+    allv = np.concatenate([o["v"] for o in outs])
+    got_ids = np.concatenate([o["i"] for o in outs])                       # ranks' slices in rank order = the global order
+    got_keys = np.concatenate([o["k"] for o in outs])
+    # the reference's order: Arrow SortIndices over the concatenated table (stable; NaN last in both directions)
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    exp = pc.sort_indices(pa.table({"v": allv}), sort_keys=[("v", "descending" if case == "desc" else "ascending")]).to_numpy()
+    assert np.array_equal(got_ids, exp)
+    assert np.array_equal(got_keys.view(np.int64), allv[exp].view(np.int64))

@@ -504,3 +504,41 @@ def test_sample_sort_equals_the_lsd_sort(case, monkeypatch):
 class _RawI64:
     def __init__(self, ptr, n):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+@pytest.mark.parametrize("desc", [False, True])
+def test_distributed_sample_sort_simulated(world, desc):
+    """distributed.sample_sort_exchange on one GPU: `world` shards play the ranks (contiguous row ranges), the splitters come from
+    the union of their samples, the blocks are routed by hand exactly as the all_to_all would deliver them (by owner, in source-
+    rank order), every owner sorts what it got with the library's stable single-key sort over the order codes -- and the ranks'
+    slices, concatenated in rank order, must be the row ids of the SINGLE-GPU sort of the whole column (vnm_sort_indices)."""
+    import torch
+    from vinum_amd import _lib as L
+    from vinum_amd import distributed as D
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    rng = np.random.default_rng(5)
+    n = 1_200_000
+    v = rng.normal(0.0, 1.0, n); v[::997] = np.nan; v[5::1201] = -0.0; v[::11] = np.round(v[::11], 2)
+    tv = torch.from_numpy(v).cuda()
+    ref_idx = ops.sort_indices([DeviceColumn.from_torch(tv)], [L.DESC if desc else L.ASC])
+    ref = torch.as_tensor(_RawI64(ref_idx.ptr, n), device="cuda").clone()
+    bounds = np.linspace(0, n, world + 1).astype(int)
+    codes = [D._order_key(tv[bounds[r]:bounds[r + 1]], desc) for r in range(world)]
+    splitters = D.ssort_splitters([D.ssort_sample(c, 4096) for c in codes], world)
+    got = []
+    for o in range(world):
+        blocks_c, blocks_i = [], []
+        for r in range(world):                                  # what owner o receives: source-rank order, row order inside
+            own = D.ssort_owner(codes[r], splitters)
+            sel = own == o
+            blocks_c.append(codes[r][sel])
+            blocks_i.append(torch.arange(bounds[r], bounds[r + 1], device="cuda", dtype=torch.int64)[sel])
+        rc, rid = torch.cat(blocks_c).contiguous(), torch.cat(blocks_i).contiguous()
+        if len(rc):
+            perm_buf = ops.sort_indices([DeviceColumn.from_torch(rc)], [L.ASC])      # stable: ties keep the (rank, row) = id order
+            perm = torch.as_tensor(_RawI64(perm_buf.ptr, len(rc)), device="cuda")
+            got.append(rid[perm])
+    got = torch.cat(got)
+    assert bool(torch.equal(got, ref)), f"world {world} desc {desc}: {int((got != ref).sum())} positions differ"

@@ -663,9 +663,12 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
     static bool attr_set = false;
     const size_t lds_sc = (size_t)SS_B * SS_CAP * 12;
     if (!attr_set) {
-        VNM_HIP(hipFuncSetAttribute((const void*)ssort_scatter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc));
-        VNM_HIP(hipFuncSetAttribute((const void*)ssort_scatter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc));
-        VNM_HIP(hipFuncSetAttribute((const void*)ssort_local_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SL_LDS_BYTES));
+        VNM_HIP(hipFuncSetAttribute((const void*)ssort_scatter_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc));
+        VNM_HIP(hipFuncSetAttribute((const void*)ssort_scatter_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc));
+        VNM_HIP(hipFuncSetAttribute((const void*)ssort_scatter_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc));
+        VNM_HIP(hipFuncSetAttribute((const void*)ssort_scatter_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc));
+        VNM_HIP(hipFuncSetAttribute((const void*)ssort_local_kernel<512, 10, 4096, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)SS_SMALL * 12 + 4096 * 4)));
+        VNM_HIP(hipFuncSetAttribute((const void*)ssort_local_kernel<1024, 8, 8192, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)SS_LOCAL * 12 + 8192 * 4)));
         VNM_HIP(hipFuncSetAttribute((const void*)onesweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OS_LDS_BYTES));
         attr_set = true;
     }
@@ -697,7 +700,7 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
     }
     // ---- level 1
     const int grid1 = (int)std::min<int64_t>((int64_t)cus * env_sort_i64("VNM_SSORT_GRID1_PER_CU", 1), std::max<int64_t>(1, (n + 2 * SS_BLOCK - 1) / (2 * SS_BLOCK)));
-    const int64_t sub = 2 * SS_BLOCK;
+    const int64_t sub = 2 * SS_BLOCK * (env_sort_i64("VNM_SSORT_PAIRS1", 1) >= 2 ? 2 : 1);
     const int64_t rows_per_wg = (((n + sub - 1) / sub + grid1 - 1) / grid1) * sub;
     const int64_t cap1 = ((rows_per_wg / SS_B + rows_per_wg / SS_B / 4 + 96) + 7) & ~7LL;
     uint64_t* c1 = (uint64_t*)pool.take((size_t)SS_B * grid1 * cap1 * 8);
@@ -709,7 +712,8 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
     a1.out_code = c1; a1.out_row = r1; a1.out_counts = n1; a1.out_cap = cap1; a1.flags = flags;
     {
         KernelTimer timer("sort_scatter1", s);
-        ssort_scatter_kernel<true><<<grid1, SS_BLOCK, lds_sc, s>>>(a1);
+        if (env_sort_i64("VNM_SSORT_PAIRS1", 1) >= 2) ssort_scatter_kernel<true, 2><<<grid1, SS_BLOCK, lds_sc, s>>>(a1);
+        else ssort_scatter_kernel<true, 1><<<grid1, SS_BLOCK, lds_sc, s>>>(a1);
     }
     VNM_HIP(hipGetLastError());
     // ---- level 2
@@ -727,7 +731,8 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
     a2.out_code = c2; a2.out_row = r2; a2.out_counts = n2; a2.out_cap = cap2; a2.flags = flags;
     {
         KernelTimer timer("sort_scatter2", s);
-        ssort_scatter_kernel<false><<<SS_B * split2, SS_BLOCK, lds_sc, s>>>(a2);
+        if (env_sort_i64("VNM_SSORT_PAIRS2", 1) >= 2) ssort_scatter_kernel<false, 2><<<SS_B * split2, SS_BLOCK, lds_sc, s>>>(a2);
+        else ssort_scatter_kernel<false, 1><<<SS_B * split2, SS_BLOCK, lds_sc, s>>>(a2);
     }
     ssort_offsets_kernel<<<1, 1024, 0, s>>>(n2, split2, nb, offs, flags);
     VNM_HIP(hipGetLastError());
@@ -765,7 +770,8 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
     la.debug = (int)env_sort_i64("VNM_SSORT_DEBUG", 0);
     {
         KernelTimer timer("sort_local", s);
-        ssort_local_kernel<<<(int)std::min<int64_t>(nb, (int64_t)cus * 64), SL_BLOCK, SL_LDS_BYTES, s>>>(la);
+        ssort_local_kernel<512, 10, 4096, false><<<(int)std::min<int64_t>(nb, (int64_t)cus * 64), 512, (size_t)SS_SMALL * 12 + 4096 * 4, s>>>(la);
+        ssort_local_kernel<1024, 8, 8192, true><<<(int)std::min<int64_t>(nb, (int64_t)cus * 16), 1024, (size_t)SS_LOCAL * 12 + 8192 * 4, s>>>(la);
     }
     VNM_HIP(hipGetLastError());
     VNM_HIP(hipStreamSynchronize(s));

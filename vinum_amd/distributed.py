@@ -339,3 +339,80 @@ def topk_exchange(values: torch.Tensor, row_ids: torch.Tensor, k: int, descendin
         order = torch.argsort(v, descending=descending, stable=True)
         v, ids = v[order], ids[order]
     return v[:k], ids[:k]
+
+
+# ---- ORDER BY over batch-sharded rows: distributed sample sort -----------------------------------------------------------
+def _order_key(v: torch.Tensor, descending: bool) -> torch.Tensor:
+    """A float64 / int64 key as an int64 whose ASCENDING order is the requested order with NaN last in both directions and
+    -0.0 == +0.0 (Arrow's SortIndices, sort.cpp:22-37): the order-preserving code of the single-GPU sort (vnm_sort.hip:
+    encode_key), computed with torch ops so that the same function serves the CPU (gloo) tests."""
+    if v.dtype == torch.float64:
+        x = torch.where(v == 0, torch.zeros_like(v), v)               # -0.0 -> +0.0
+        bits = x.view(torch.int64)
+        code = torch.where(bits < 0, ~bits, bits | torch.iinfo(torch.int64).min)    # unsigned order-preserving image ...
+        code = code ^ torch.iinfo(torch.int64).min                                   # ... as a signed int64 with the same order
+        if descending:
+            code = ~code
+        return torch.where(torch.isnan(v), torch.full_like(code, torch.iinfo(torch.int64).max), code)
+    code = v.to(torch.int64)
+    return ~code if descending else code
+
+
+def ssort_sample(code: torch.Tensor, m: int) -> torch.Tensor:
+    """strided sample of at most m order codes"""
+    n = int(code.shape[0])
+    m = min(n, m)
+    if not m:
+        return code[:0]
+    return code[(torch.arange(m, device=code.device, dtype=torch.int64) * n) // m]
+
+
+def ssort_splitters(samples, world: int) -> torch.Tensor:
+    """world - 1 splitters: the sorted union of the ranks' samples cut into `world` equal parts"""
+    union, _ = torch.sort(torch.cat(list(samples)))
+    if not len(union) or world <= 1:
+        return union[:0]
+    cut = (torch.arange(1, world, device=union.device, dtype=torch.int64) * len(union)) // world
+    return union[cut]
+
+
+def ssort_owner(code: torch.Tensor, splitters: torch.Tensor) -> torch.Tensor:
+    """rank whose splitter range holds the code (code == splitter -> the upper rank: equal codes never split)"""
+    if not len(splitters):
+        return torch.zeros_like(code)
+    return torch.searchsorted(splitters, code, right=True)
+
+
+def sample_sort_exchange(keys: torch.Tensor, global_ids: torch.Tensor, descending: bool, sort_local, group=None,
+                         samples_per_rank: int = 4096):
+    """Distributed `ORDER BY key [DESC]` (Sort::Sorted semantics, sort.cpp:15-63: stable, NaN after every
+    number in both directions) over rows sharded by batch: rank r holds keys[r] with their GLOBAL row ids (ranks hold
+    contiguous, ascending id ranges).
+      1. every rank contributes a strided sample of its order codes; one all_gather; the sorted union is cut into `world`
+         equal parts: world - 1 SPLITTERS, the same on every rank;
+      2. rows go to the rank whose splitter range holds their code (rows of equal code always meet on one rank): one
+         variable-size all_to_all of (code, global id, key bits) triples, blocks in source-rank order;
+      3. sort_local(codes, ids) -> permutation: the receiving rank sorts what it got by (code, id) -- on the GPU the library's
+         single-key sort over the codes (stable over blocks that arrive in id order), in the CPU tests a torch sort.
+    Returns (keys, global_ids) of this rank's slice of the global order: concatenating the ranks' results in rank order IS the
+    sorted table (rank 0 holds the first rows)."""
+    world = dist.get_world_size(group)
+    code = _order_key(keys, descending)
+    samp = ssort_sample(code, samples_per_rank)
+    m = int(samp.shape[0])
+    padded = torch.full((samples_per_rank + 1,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=code.device)
+    padded[:m] = samp
+    padded[samples_per_rank] = m
+    allp = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(allp, padded, group=group)
+    splitters = ssort_splitters([p_[: int(p_[samples_per_rank])] for p_ in allp], world)
+    owner = ssort_owner(code, splitters)
+    order = torch.argsort(owner, stable=True)                            # by owner, source row order kept
+    counts = torch.bincount(owner, minlength=world)
+    send = torch.stack([code[order], global_ids[order].to(torch.int64),
+                        (keys.view(torch.int64) if keys.dtype == torch.float64 else keys.to(torch.int64))[order]], dim=1).contiguous()
+    recv = exchange(send, counts, group)
+    rc, rid, rk = recv[:, 0].contiguous(), recv[:, 1].contiguous(), recv[:, 2].contiguous()
+    perm = sort_local(rc, rid)
+    out_keys = rk[perm]
+    return (out_keys.view(torch.float64) if keys.dtype == torch.float64 else out_keys.to(keys.dtype)), rid[perm]
