@@ -2732,14 +2732,17 @@ __global__ __launch_bounds__(256) void agg_finalize_kernel(FinMulti m) {
 using namespace vnm;
 
 struct DensePending {
-    DFinalArgs df;         // inputs of the final pass (outputs filled in by whoever completes it)
-    int tb = 0;
+    DFinalArgs df;         // what every batch shares: the code map, the words of the plan, the flags block
+    int tb = 0, levels = 0, p1 = 0, fsplits = 1;
     int64_t nfinal = 0;
     int64_t dstride = 0;   // bound of the groups the pass can produce
+    std::vector<DSet> sets;      // one per batch whose scatter passes are done
     std::vector<void*> blocks;   // pool blocks the entries live in
+    DSet* dsets = nullptr;       // device copy of `sets` (refreshed by complete_pending)
     DTabSlot* table = nullptr;   // DF_TABLE result (kept until the handle goes: the exchange reads it)
-    ~DensePending() { for (void* b : blocks) pool_free(b); pool_free(table); }
+    ~DensePending() { for (void* b : blocks) pool_free(b); pool_free(table); pool_free(dsets); }
 };
+constexpr size_t DP_MAX_SETS = 512;   // batches a deferred pass may span (then it runs, as a run, and a new one starts)
 
 struct vnm_agg {
     AggPlan plan;
@@ -2788,6 +2791,7 @@ struct vnm_agg {
     // has not run yet -- what it writes depends on who asks: another batch / finish() -> the dense partial state (a run),
     // vnm_agg_result_device_alloc -> the result columns themselves, vnm_agg_dense_table -> the tables for the multi-GPU exchange
     struct DensePending* pending = nullptr;
+    bool dense_by_bound = false;   // the first batch went dense on the sample's LOWER bound of the group count (no estimate exists)
     bool range_given = false;   // vnm_agg_set_dense_range: the code range is the caller's (agreed by all ranks), not a sample's
     // expression input (vnm_agg_set_input_expr): the functions reading plan column expr_col get an expression's value
     int expr_col = -1;
@@ -3573,6 +3577,7 @@ int launch_dense_final(const DFinalArgs& df, int tb, int out, bool lo64, hipStre
 int complete_pending(vnm_agg* h, hipStream_t s, int out = DF_RUN, const DFinalArgs* cols = nullptr, int64_t* n_out = nullptr) {
     DensePending* pd = h->pending;
     if (!pd) return 0;
+    if (out == DF_RUN && h->have_run) VNM_TRY(merge_run_into_table(h, s));   // (a run of another path: it has to make room)
     DFinalArgs df = pd->df;
     PoolScope pool;
     uint64_t* rk = nullptr; uint64_t* ra = nullptr;
@@ -3585,22 +3590,52 @@ int complete_pending(vnm_agg* h, hipStream_t s, int out = DF_RUN, const DFinalAr
         df.n_out = cols->n_out;
         for (int c = 0; c < cols->n_out; c++) { df.out_kind[c] = cols->out_kind[c]; df.out_ptr[c] = cols->out_ptr[c]; }
     } else {
+        if (pd->tb > 12) return 2;   // (the exchange of 2^13-slot tables is not wired up: the caller takes another route)
         if (!pd->table) pd->table = (DTabSlot*)pool_alloc(sizeof(DTabSlot) << df.map.bits);
         if (!pd->table) return 1;
         df.table = pd->table;
     }
     df.dstride = pd->dstride;
+    pool_free(pd->dsets);
+    pd->dsets = (DSet*)pool_alloc(pd->sets.size() * sizeof(DSet));
+    if (!pd->dsets) return 1;
+    VNM_HIP(hipMemcpyAsync(pd->dsets, pd->sets.data(), pd->sets.size() * sizeof(DSet), hipMemcpyHostToDevice, s));
+    df.sets = pd->dsets; df.nsets = (int)pd->sets.size();
     unsigned long long fl[3] = {0, 0, 0};
+    uint64_t* psum = nullptr; float* plo = nullptr; uint32_t* pcnt = nullptr;
+    if (pd->fsplits > 1) {   // few final partitions: each is shared by `fsplits` workgroups (partial tables + dpart_merge_kernel)
+        if (out == DF_TABLE) return 2;
+        const size_t cells = (size_t)pd->nfinal * pd->fsplits << pd->tb;
+        psum = (uint64_t*)pool.take(cells * 8); plo = (float*)pool.take(cells * 4); pcnt = (uint32_t*)pool.take(cells * 4);
+        if (!psum || !plo || !pcnt) return 1;
+    }
     for (int attempt = 0; attempt < 2; attempt++) {
         VNM_HIP(hipMemsetAsync(df.flags, 0, 16, s));   // [0] failure, [1] dense count ([2]: the scatter passes' spill count, consumed)
-        VNM_TRY(launch_dense_final(df, pd->tb, out, attempt == 1, s));
+        if (attempt == 0 && pd->fsplits > 1) {
+            DFinalArgs ds = df;
+            ds.splits = pd->fsplits; ds.part_sum = psum; ds.part_lo = plo; ds.part_cnt = pcnt;
+            const int cus = device_info().num_cus;
+            KernelTimer timer("agg_part_final", s);
+            const int g3 = (int)std::min<int64_t>(pd->nfinal * pd->fsplits, (int64_t)cus * 8);
+            if (pd->tb == 11) dpart_final_kernel<uint16_t, 11, true><<<g3, 512, 0, s>>>(ds);
+            else if (pd->tb == 12) dpart_final_kernel<uint16_t, 12, true><<<g3, 512, 0, s>>>(ds);
+            else dpart_final_kernel<uint16_t, 13, true><<<g3, 1024, 0, s>>>(ds);
+            if (out != DF_COLS) ds.n_out = 0;
+            dpart_merge_kernel<<<(int)(pd->nfinal << (pd->tb - 9)), 512, 0, s>>>(ds, pd->tb);
+            VNM_HIP(hipGetLastError());
+        } else if (attempt == 1 && pd->tb == 13) {
+            // 64-bit compensation terms only fit 2^12-slot tables: every partition in two halves (slot bit 12 = 0, then 1)
+            df.sub_bits = 1;
+            for (int sub = 0; sub < 2; sub++) { df.sub = sub; VNM_TRY(launch_dense_final(df, 12, out, true, s)); }
+        } else VNM_TRY(launch_dense_final(df, pd->tb, out, attempt == 1, s));
         VNM_HIP(hipMemcpyAsync(fl, df.flags, 16, hipMemcpyDeviceToHost, s));
         VNM_HIP(hipStreamSynchronize(s));
         if (!fl[0]) break;
         if (out == DF_TABLE) return 2;
         if (attempt == 1) return set_error("aggregate: dense final pass failed (internal error)");
     }
-    if (getenv("VNM_AGG_TRACE")) fprintf(stderr, "[agg] dense final (deferred): mode %d -> groups %llu\n", out, fl[1]);
+    if (getenv("VNM_AGG_TRACE")) fprintf(stderr, "[agg] dense final (deferred, %zu batch%s): mode %d -> groups %llu\n", pd->sets.size(),
+                                         pd->sets.size() == 1 ? "" : "es", out, fl[1]);
     if (n_out) *n_out = (int64_t)fl[1];
     if (out == DF_RUN) {
         pool.keep(rk); pool.keep(ra);
@@ -3786,6 +3821,13 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     df.w_lo = a.hot_comp && a.hot_w_sum >= 0 ? a.hot_w_sum + 1 : -1;
     df.dkey = rk; df.dacc = ra; df.dstride = dstride; df.flags = flags;
     uint64_t* psum = nullptr; float* plo = nullptr; uint32_t* pcnt = nullptr;
+    // the branches that write a run of their own: a pending (deferred) pass of earlier batches runs first and its run makes room
+    const bool own_run = generic || !env_i64("VNM_DENSE_DEFER", 1);
+    if (own_run && h->pending) {
+        int rc = complete_pending(h, s);
+        if (!rc) rc = merge_run_into_table(h, s);
+        if (rc) { release(); pool_free(spill); pool_free(rk); pool_free(ra); return 1; }
+    }
     if (generic) {
         const size_t slots = (size_t)1 << tb;
         const size_t lds = slots * dgen_slot_bytes(g);
@@ -3816,7 +3858,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
             if (has_val) VNM_DGFIN(true, false); else VNM_DGFIN(false, false);
         }
 #undef VNM_DGFIN
-    } else if (fsplits > 1) {
+    } else if (fsplits > 1 && own_run) {
         const size_t cells = (size_t)nfinal * fsplits << tb;
         psum = (uint64_t*)pool_alloc(cells * 8); plo = (float*)pool_alloc(cells * 4); pcnt = (uint32_t*)pool_alloc(cells * 4);
         if (!psum || !plo || !pcnt) { release(); pool_free(spill); pool_free(rk); pool_free(ra); pool_free(psum); pool_free(plo); pool_free(pcnt); return 1; }
@@ -3833,9 +3875,9 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         if (tb == 11) VNM_DFINS(11); else if (tb == 12) VNM_DFINS(12); else VNM_DFINS(13);
 #undef VNM_DFINS
         dpart_merge_kernel<<<(int)(nfinal << (tb - 9)), 512, 0, s>>>(df, tb);
-    } else if (tb <= 12 && env_i64("VNM_DENSE_DEFER", 1)) {
-        // The final pass is DEFERRED: what it should write depends on what comes next (complete_pending).  The scatter passes
-        // have to be known good first.
+    } else if (env_i64("VNM_DENSE_DEFER", 1)) {
+        // The final pass is DEFERRED: what it should write depends on what comes next (complete_pending), and the batches of a
+        // stream share ONE final pass.  The scatter passes have to be known good first.
         unsigned long long fl0[3];
         VNM_HIP(hipMemcpyAsync(fl0, flags, 24, hipMemcpyDeviceToHost, s));
         VNM_HIP(hipStreamSynchronize(s));
@@ -3847,11 +3889,30 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         if (fl0[2]) { *spill_out = spill; *n_spill_out = (int64_t)fl0[2]; }
         else { pool_free(spill); *spill_out = nullptr; *n_spill_out = 0; }
         if ((int64_t)fl0[2] > nrows / 16) h->dense_state = -1;
-        DensePending* pd = new DensePending();
-        df.dkey = nullptr; df.dacc = nullptr;
-        pd->df = df; pd->tb = tb; pd->nfinal = nfinal; pd->dstride = dstride;
-        pd->blocks = {flags, v1, c1, n1, v2, c2, n2};
-        h->pending = pd;
+        DensePending* pd = h->pending;
+        // batches join a pending pass of the same geometry; anything else (or a very long stream) runs it first
+        if (pd && (pd->tb != tb || pd->levels != levels || pd->p1 != p1 || pd->fsplits != fsplits || pd->sets.size() >= DP_MAX_SETS ||
+                   memcmp(&pd->df.map, &mp, sizeof(DenseMap)) != 0)) {
+            const int rc = complete_pending(h, s);
+            if (rc) { release(); return rc; }
+            pd = nullptr;
+        }
+        if (!pd) {
+            pd = new DensePending();
+            df.dkey = nullptr; df.dacc = nullptr;
+            pd->df = df; pd->tb = tb; pd->levels = levels; pd->p1 = p1; pd->fsplits = fsplits; pd->nfinal = nfinal; pd->dstride = 0;
+            pd->blocks.push_back(flags);
+            h->pending = pd;
+        } else pool_free(flags);
+        pd->dstride = std::min<int64_t>(h->dense_span, pd->dstride + nrows) + 2;
+        DSet st{};
+        st.vals = fin_v; st.codes = fin_c; st.counts = fin_n; st.cap = fin_cap; st.pstride = df.pstride; st.rstride = df.rstride; st.regions = fin_regions;
+        st.pad = fin_cap < 2048 ? 1 : 0;   // small regions: one wave per region in the final pass
+        pd->sets.push_back(st);
+        if (levels == 2) {   // the first level's regions have been consumed by the second scatter pass
+            pool_free(v1); pool_free(c1); pool_free(n1);
+            pd->blocks.push_back(v2); pd->blocks.push_back(c2); pd->blocks.push_back(n2);
+        } else { pd->blocks.push_back(v1); pd->blocks.push_back(c1); pd->blocks.push_back(n1); }
         return 0;
     } else {
         VNM_TRY(launch_dense_final(df, tb, DF_RUN, false, s));
@@ -4164,7 +4225,6 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     if (h->pred_set && !pred) return set_error("vnm_agg_next_device: predicate set but no predicate column given");
     hipStream_t s = as_stream(stream);
     invalidate_result(h);
-    if (h->pending) VNM_TRY(complete_pending(h, s));   // another batch: the previous one's final pass produces its partial state now
     if (nrows <= 0) {
         if (h->plan.n_keys == 0 || h->hint <= 0) VNM_TRY(ensure_table(h, nrows, s));
         return 0;
@@ -4392,7 +4452,9 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
             else VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s));   // too sparse (or not a code-able key): full estimate
         }
         if (est) { h->hint = est; h->estimated = true; }
+        else if (dense_go) { h->estimated = true; h->dense_by_bound = true; }   // later batches of the stream: no sample again
     }
+    if (dense_shape && !dense_go && h->dense_by_bound && h->hint == 0 && h->dense_state == 1 && h->dense_span <= 4 * nrows) dense_go = true;
     // rank-aligned operators (multi-GPU) keep hash partitions so that every rank cuts its result the same way -- which only
     // the partition-aligned exchange of LARGE results needs; small results travel by one all-gather and are merged by key
     if (dense_base && h->rank_aligned && h->hint > 0 && h->hint <= env_i64("VNM_ALIGNED_DENSE_MAX", 1 << 19)) dense_shape = true;
@@ -4419,6 +4481,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
             VNM_TRY(plan_dense(h, keys[0], nrows, s));
         }
         if (h->dense_state == 2) {
+            if (h->pending) VNM_TRY(complete_pending(h, s));   // (this path makes a run of its own)
             if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
             int prc = dense_scan_aggregate(h, a, nrows, s, &spill, &n_spill, dense_generic);
             // a generic program whose table for this range does not fit LDS: the same 2^13 codes through one scatter level
@@ -4447,6 +4510,8 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         int prc = 2;
         bool spill_is_wide = false;   // the spill holds [n][E]-word entries of the wide scatter kernels (not the (key, value) pairs of the hot / dense paths)
         auto run_partitioned = [&]() {
+            if (h->pending && complete_pending(h, s)) return 1;     // (the hash-partitioned path makes a run of its own)
+            if (h->have_run && merge_run_into_table(h, s)) return 1;
             const int r = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
             spill_is_wide = r == 0 && spill != nullptr && a.part_wide != 0;
             return r;
