@@ -455,12 +455,13 @@ def test_topk_multi_key_equals_full_sort_prefix(shape, k):
         util.assert_batches_equal(got, exp, what=f"multi-key topk {shape} k={k} orders={orders}")
 
 
-@pytest.mark.parametrize("case", ["f64_normal", "f64_desc_nan_negzero", "i64_few_dups", "u64_desc", "runs_of_100", "heavy_value_declines", "tiny_buckets"])
+@pytest.mark.parametrize("case", ["f64_normal", "f64_desc_nan_negzero", "i64_few_dups", "u64_desc", "runs_of_100", "heavy_value", "heavy_values_and_nans_desc",
+                                  "low_cardinality_declines", "tiny_buckets", "odd_size"])
 def test_sample_sort_equals_the_lsd_sort(case, monkeypatch):
     """The sample sort of one 8-byte key (vnm_sort_sample.inc: splitters from a sorted sample, two ring scatters into 2^18 buckets,
     per-bucket LSD sort in LDS, rows of equal key by row id) must give the SAME row ids as the eight-pass LSD sort -- the order is
     total (key, then row id: Sort::Sorted is stable, sort.cpp:22-40) -- and the same rebuilt key column.  Rows with equal keys in
-    short and long runs, NaN / -0.0, descending order, and data it declines (one value holding 10 % of the rows)."""
+    short and long runs, NaN / -0.0, descending order, heavy values (side list), and data it declines (1000 distinct values)."""
     import torch
     from vinum_amd import _lib as L
     from vinum_amd import ops
@@ -478,8 +479,14 @@ def test_sample_sort_equals_the_lsd_sort(case, monkeypatch):
         v = rng.integers(0, 2**63, n).astype(np.uint64) * 2 + rng.integers(0, 2, n).astype(np.uint64); order = L.DESC
     elif case == "runs_of_100":
         v = (rng.integers(0, n // 100, n) * 1_000_003).astype(np.int64)
-    elif case == "heavy_value_declines":
-        v = rng.normal(0.0, 1.0, n); v[::10] = 12.5
+    elif case == "heavy_value":                       # one value holds 10 % of the rows: its rows bypass the buckets (side list)
+        v = rng.normal(0.0, 1.0, n); v[::10] = 0.25
+    elif case == "heavy_values_and_nans_desc":        # several heavy values, the smallest and the largest key among them, and NaNs
+        v = rng.normal(0.0, 1.0, n); v[::7] = 12.5; v[3::11] = -40.0; v[5::13] = np.nan; v[1::17] = 0.0; v[2::170] = -0.0; order = L.DESC
+    elif case == "low_cardinality_declines":          # 1000 distinct values: more heavy codes than the side list takes -> LSD sort
+        v = rng.integers(0, 1000, n).astype(np.float64)
+    elif case == "odd_size":
+        n = 2_999_999 + 4096 * 3 + 17; v = rng.normal(0.0, 1.0, n)
     else:
         v = rng.normal(0.0, 1.0, n)
     t = torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).cuda()

@@ -673,11 +673,19 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
         attr_set = true;
     }
     PoolScope pool;
-    // ---- splitters from a sorted sample
+    // ---- splitters from a sorted sample; heavy codes = runs of equal splitters
     uint64_t* split = (uint64_t*)pool.take((size_t)nb * 8);
     unsigned long long* flags = (unsigned long long*)pool.take(64);
-    if (!split || !flags) return 1;
+    uint64_t* heavy = (uint64_t*)pool.take((size_t)SS_MAX_HEAVY * 8);
+    unsigned long long* lb = (unsigned long long*)pool.take((size_t)(SS_MAX_HEAVY + 1) * 8 * 2);   // lb[65], then hstart[64]
+    unsigned int* hb = (unsigned int*)pool.take((size_t)(SS_MAX_HEAVY + 2) * 4);                   // hb[64], then the heavy counter
+    if (!split || !flags || !heavy || !lb || !hb) return 1;
+    unsigned long long* hstart = lb + SS_MAX_HEAVY + 1;
+    unsigned int* nheavy_d = hb + SS_MAX_HEAVY;
     VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
+    VNM_HIP(hipMemsetAsync(nheavy_d, 0, 4, s));
+    int nheavy = 0;
+    unsigned long long eq_pairs = 0;
     {
         RadixBufs sr{};
         VNM_TRY(radix_alloc(&sr, m));
@@ -688,19 +696,35 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
         sort_iota_kernel<<<grid_for(m), 256, 0, s>>>(sr.val[0], m);
         sr.cur = 0;
         VNM_TRY(radix_sort_codes(&sr, m, s));
-        ssort_splitters_kernel<<<(int)((nb + 255) / 256), 256, 0, s>>>(sr.code[sr.cur], m, nb, split, flags);
+        ssort_splitters_kernel<<<(int)((nb + 255) / 256), 256, 0, s>>>(sr.code[sr.cur], m, nb, split, flags, heavy, nheavy_d);
         VNM_HIP(hipGetLastError());
-        unsigned long long dup = 0;
-        VNM_HIP(hipMemcpyAsync(&dup, flags, 8, hipMemcpyDeviceToHost, s));
+        unsigned long long too_many = 0;
+        unsigned int nh = 0;
+        VNM_HIP(hipMemcpyAsync(&eq_pairs, flags + 3, 8, hipMemcpyDeviceToHost, s));
+        uint64_t hcodes[SS_MAX_HEAVY];
+        VNM_HIP(hipMemcpyAsync(&too_many, flags, 8, hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipMemcpyAsync(&nh, nheavy_d, 4, hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipMemcpyAsync(hcodes, heavy, sizeof(hcodes), hipMemcpyDeviceToHost, s));
         VNM_HIP(hipStreamSynchronize(s));    // (sr goes back to the pool here)
-        if (dup) {
-            if (getenv("VNM_SORT_TRACE")) fprintf(stderr, "[sort] sample sort declined: equal splitters (heavily duplicated keys)\n");
+        if (too_many || nh > (unsigned int)SS_MAX_HEAVY || getenv("VNM_SSORT_NO_HEAVY") != nullptr && nh) {
+            if (getenv("VNM_SORT_TRACE")) fprintf(stderr, "[sort] sample sort declined: %u heavily duplicated values\n", nh);
             return 2;
         }
+        nheavy = (int)nh;
+        if (nheavy) {
+            std::sort(hcodes, hcodes + nheavy);
+            VNM_HIP(hipMemcpyAsync(heavy, hcodes, (size_t)nheavy * 8, hipMemcpyHostToDevice, s));
+        }
     }
+    // rows of heavy codes bypass the buckets: (heavy index << 32 | row id) entries in a side list, sorted below
+    // (room: every run of r equal splitters stands for at most (r + 1) buckets' worth of rows)
+    const int64_t side_cap = nheavy ? std::min<int64_t>(n, (int64_t)((double)(eq_pairs + 2 * (unsigned long long)nheavy) * (double)n / (double)nb * 1.3) + 65536) : 0;
+    RadixBufs side{};
+    if (nheavy) VNM_TRY(radix_alloc(&side, side_cap));
     // ---- level 1
-    const int grid1 = (int)std::min<int64_t>((int64_t)cus * env_sort_i64("VNM_SSORT_GRID1_PER_CU", 1), std::max<int64_t>(1, (n + 2 * SS_BLOCK - 1) / (2 * SS_BLOCK)));
-    const int64_t sub = 2 * SS_BLOCK * (env_sort_i64("VNM_SSORT_PAIRS1", 1) >= 2 ? 2 : 1);
+    const int pairs1 = env_sort_i64("VNM_SSORT_PAIRS1", 1) >= 2 ? 2 : 1;
+    const int64_t sub = 2 * SS_BLOCK * pairs1;
+    const int grid1 = (int)std::min<int64_t>((int64_t)cus * env_sort_i64("VNM_SSORT_GRID1_PER_CU", 1), std::max<int64_t>(1, (n + sub - 1) / sub));
     const int64_t rows_per_wg = (((n + sub - 1) / sub + grid1 - 1) / grid1) * sub;
     const int64_t cap1 = ((rows_per_wg / SS_B + rows_per_wg / SS_B / 4 + 96) + 7) & ~7LL;
     uint64_t* c1 = (uint64_t*)pool.take((size_t)SS_B * grid1 * cap1 * 8);
@@ -710,9 +734,10 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
     SsArgs a1{};
     a1.key = key; a1.desc = desc; a1.nrows = n; a1.split = split;
     a1.out_code = c1; a1.out_row = r1; a1.out_counts = n1; a1.out_cap = cap1; a1.flags = flags;
+    a1.heavy = heavy; a1.nheavy = nheavy; a1.side = nheavy ? (unsigned long long*)side.code[0] : nullptr; a1.side_cap = side_cap;
     {
         KernelTimer timer("sort_scatter1", s);
-        if (env_sort_i64("VNM_SSORT_PAIRS1", 1) >= 2) ssort_scatter_kernel<true, 2><<<grid1, SS_BLOCK, lds_sc, s>>>(a1);
+        if (pairs1 == 2) ssort_scatter_kernel<true, 2><<<grid1, SS_BLOCK, lds_sc, s>>>(a1);
         else ssort_scatter_kernel<true, 1><<<grid1, SS_BLOCK, lds_sc, s>>>(a1);
     }
     VNM_HIP(hipGetLastError());
@@ -734,13 +759,27 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
         if (env_sort_i64("VNM_SSORT_PAIRS2", 1) >= 2) ssort_scatter_kernel<false, 2><<<SS_B * split2, SS_BLOCK, lds_sc, s>>>(a2);
         else ssort_scatter_kernel<false, 1><<<SS_B * split2, SS_BLOCK, lds_sc, s>>>(a2);
     }
-    ssort_offsets_kernel<<<1, 1024, 0, s>>>(n2, split2, nb, offs, flags);
     VNM_HIP(hipGetLastError());
-    unsigned long long fl[2] = {0, 0};
-    VNM_HIP(hipMemcpyAsync(fl, flags, 16, hipMemcpyDeviceToHost, s));
+    unsigned long long fl[3] = {0, 0, 0};
+    VNM_HIP(hipMemcpyAsync(fl, flags, 24, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
-    if (getenv("VNM_SORT_TRACE")) fprintf(stderr, "[sort] sample sort: n %lld grid1 %d cap1 %lld split2 %d cap2 %lld -> fail %llu special %llu\n",
-                                          (long long)n, grid1, (long long)cap1, split2, (long long)cap2, fl[0], fl[1]);
+    if (fl[0]) {
+        if (getenv("VNM_SORT_TRACE")) fprintf(stderr, "[sort] sample sort: a region overflowed, LSD sort instead\n");
+        return 2;
+    }
+    // ---- the heavy rows: their side list sorted by (heavy index, row id) is their part of the output
+    const int64_t side_len = (int64_t)fl[2];
+    if (nheavy) {
+        side.cur = 0;
+        if (side_len > 1) VNM_TRY(radix_sort_codes(&side, side_len, s, nullptr, nullptr, false, nullptr, false, nullptr));
+        ssort_heavy_bounds_kernel<<<1, 128, 0, s>>>((const unsigned long long*)side.code[side.cur], side_len, heavy, nheavy, split, nb, lb, hb);
+    }
+    ssort_offsets_kernel<<<1, 1024, 0, s>>>(n2, split2, nb, offs, flags, nheavy, hb, lb, hstart);
+    VNM_HIP(hipGetLastError());
+    VNM_HIP(hipMemcpyAsync(fl, flags, 8, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    if (getenv("VNM_SORT_TRACE")) fprintf(stderr, "[sort] sample sort: n %lld grid1 %d cap1 %lld split2 %d cap2 %lld heavy %d (%lld rows) -> fail %llu special %llu\n",
+                                          (long long)n, grid1, (long long)cap1, split2, (long long)cap2, nheavy, (long long)side_len, fl[0], fl[1]);
     if (fl[0]) return 2;
     {
         const int dbg = (int)env_sort_i64("VNM_SSORT_DEBUG", 0);
@@ -772,6 +811,9 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
         KernelTimer timer("sort_local", s);
         ssort_local_kernel<512, 10, 4096, false><<<(int)std::min<int64_t>(nb, (int64_t)cus * 64), 512, (size_t)SS_SMALL * 12 + 4096 * 4, s>>>(la);
         ssort_local_kernel<1024, 8, 8192, true><<<(int)std::min<int64_t>(nb, (int64_t)cus * 16), 1024, (size_t)SS_LOCAL * 12 + 8192 * 4, s>>>(la);
+        if (nheavy && side_len > 0)
+            ssort_heavy_write_kernel<<<grid_for(side_len), 256, 0, s>>>((const unsigned long long*)side.code[side.cur], side_len, heavy, lb, hstart, idx_out,
+                                                                        keyed ? key_out : nullptr, key.type, desc);
     }
     VNM_HIP(hipGetLastError());
     VNM_HIP(hipStreamSynchronize(s));
