@@ -648,12 +648,15 @@ def test_heavy_keys_spill_from_wide_entries(program, heavy):
         util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"heavy keys {heavy} {program} pred={pred}")
 
 
-@pytest.mark.parametrize("ncols,nulls", [(3, False), (4, False), (5, False), (4, True), (5, True), (6, False), (7, False)])
+@pytest.mark.parametrize("ncols,nulls", [(3, False), (4, False), (5, False), (4, True), (5, True), (6, False), (6, True), (7, False),
+                                         (8, True), (12, False), (14, True)])
 def test_many_input_columns_take_the_partitioned_path(ncols, nulls):
     """SELECT k, sum(c1), min(c2), avg(c3), ... GROUP BY k with many groups: the partition entries carry the key and up to six
     input values (or five and a validity word), and the final pass shrinks its LDS table until the accumulator words fit
-    (three float SUMs + counts used to exceed the LDS and fall back to per-row HBM atomics: 300 ms per 1e9 rows).  Seven columns
-    still take the general path.  Mixed column types, NULLs, a predicate; bit-exact against the oracle."""
+    (three float SUMs + counts used to exceed the LDS and fall back to per-row HBM atomics: 300 ms per 1e9 rows).  More columns
+    than that (seven, or six with NULLs) split the program into sub-operators over the same key whose results are joined by
+    key (round 3; before: the LDS scan and its flush storms).  Mixed column types, NULLs, a predicate, two batches; bit-exact
+    against the oracle."""
     import ctypes
     from oracle import oracle as O
     from vinum_amd import _lib as L
@@ -672,10 +675,13 @@ def test_many_input_columns_take_the_partitioned_path(ncols, nulls):
             vals = rng.integers(-2**40, 2**40, n).astype(np.int64)
         mask = (rng.random(n) < 0.1) if (nulls and c % 2 == 0) else None
         cols[f"c{c}"] = pa.array(vals, mask=mask)
-        funcs.append((kinds[c], f"c{c}", f"f{c}"))
-    funcs.append((O.COUNT_STAR, "", "n"))
+        funcs.append((kinds[c % len(kinds)], f"c{c}", f"f{c}"))
+        if c % 4 == 1:
+            funcs.append((O.AVG, f"c{c}", f"g{c}"))      # a second function of the same column: the two stay in one part
+    funcs.insert(2, (O.COUNT_STAR, "", "n"))
     t = pa.table(cols)
     batches = util.sliced_batches(t, n // 2)
+    split = ncols + (1 if nulls else 0) > 6
 
     def launches(name):
         ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
@@ -684,15 +690,85 @@ def test_many_input_columns_take_the_partitioned_path(ncols, nulls):
     for pred in (None, ("c0", ">", 64.0)):
         L.lib().vnm_set_profiling(1)
         got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=pred, expected_groups=groups)
-        p1 = launches(b"agg_part_scatter1")
+        p1, joins, scans = launches(b"agg_part_scatter1"), launches(b"agg_split_join"), launches(b"agg_scan")
         L.lib().vnm_set_profiling(0)
-        assert (p1 == 0) if ncols == 7 else (p1 >= 1), p1
+        assert p1 >= 1, p1
+        assert joins == (1 if split else 0), joins
+        assert scans == 0, scans                       # no batch went through the LDS scan / HBM table
         o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
         for bt in batches:
             if pred:
                 bt = O.filter_batch(bt, O.cmp_mask(bt.column(1), O.GT, 64.0))
             o.next(bt)
         util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"{ncols} input columns nulls={nulls} pred={pred}")
+
+
+@pytest.mark.parametrize("scenario", ["hintless", "two_keys_packed", "merged_afterwards", "narrow_key"])
+def test_split_program_scenarios(scenario):
+    """The program split (eight input columns) where the operator has to find out for itself that the groups are many (no
+    hint: estimate on the first batch), under packed composite keys and a packed int32 key (the single-key operator inside
+    splits), and when foreign partial state is merged into the operator afterwards (the parts are joined first)."""
+    import ctypes
+    from oracle import oracle as O
+    from vinum_amd import _lib as L
+    rng = np.random.default_rng(len(scenario))
+    n = (1 << 22) + 12345 if scenario in ("hintless", "narrow_key") else 1_200_000
+    groups = 40_000
+    g = rng.integers(0, groups, n)
+    cols = {}
+    if scenario == "two_keys_packed":
+        cols["a"] = pa.array((g % 200).astype(np.int64) - 7)
+        cols["b"] = pa.array((g // 200).astype(np.int32))
+        keys, kind = ["a", "b"], O.MULTI
+    elif scenario == "narrow_key":
+        cols["k"] = pa.array(g.astype(np.int32) - 5)
+        keys, kind = ["k"], O.SINGLE
+    else:
+        cols["k"] = pa.array(g.astype(np.int64) * 31 - 5)
+        keys, kind = ["k"], O.SINGLE
+    funcs = []
+    kinds = [O.SUM, O.MAX, O.AVG, O.MIN, O.COUNT, O.SUM, O.AVG, O.MAX]
+    for c in range(8):
+        vals = rng.integers(0, 2**14, n).astype(np.float64) / 64.0 if c % 2 == 0 else rng.integers(-2**40, 2**40, n).astype(np.int64)
+        cols[f"c{c}"] = pa.array(vals)
+        funcs.append((kinds[c], f"c{c}", f"f{c}"))
+    funcs.append((O.COUNT_STAR, "", "n"))
+    t = pa.table(cols)
+    batches = util.sliced_batches(t, n if scenario in ("hintless", "narrow_key") else n // 3)
+    hint = 0 if scenario in ("hintless", "narrow_key") else groups
+
+    def launches(name):
+        ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+        L.lib().vnm_profile_query(name, ctypes.byref(ms), ctypes.byref(cnt))
+        return cnt.value
+    o = O.OracleAggregate(kind, keys, keys, funcs)
+    for bt in batches:
+        o.next(bt)
+    L.lib().vnm_set_profiling(1)
+    if scenario == "merged_afterwards":
+        from vinum_amd import ops
+        from vinum_amd.device import DeviceColumn
+        schema = t.schema
+        fspec = [(f, schema.names.index(col) if col else None, schema.field(col).type if col else None) for f, col, _ in funcs]
+        halves = []
+        for part in (batches[:2], batches[2:]):
+            agg = ops.DeviceAggregate(kind, [pa.int64()], fspec, expected_groups=groups)
+            for b in part:
+                dk = DeviceColumn.from_arrow(b.column(0))
+                agg.next([dk], [DeviceColumn.from_arrow(b.column(schema.names.index(col))) if col else None for _, col, _ in funcs], nrows=b.num_rows)
+            halves.append(agg)
+        a, b2 = halves
+        nb = b2.finish()
+        kw, aw = b2.dense_ptrs()
+        a.merge(nb, kw, aw)      # a still holds its parts: they are joined, then b2's groups merged in
+        got = a.result_arrays([0], keys, [f[2] for f in funcs])
+        a.close(); b2.close()
+    else:
+        got = gpu_aggregate(kind, keys, keys, funcs, batches, expected_groups=hint)
+    joins = launches(b"agg_split_join")
+    L.lib().vnm_set_profiling(0)
+    assert joins >= 1, joins
+    util.assert_agg_equal(got, o.result(), funcs, keys, what=f"split program, {scenario}")
 
 
 @pytest.mark.parametrize("scenario", ["two_wide_int64", "float_and_wide", "many_distinct", "new_values_later",

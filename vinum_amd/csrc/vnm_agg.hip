@@ -2803,6 +2803,13 @@ struct vnm_agg {
     PackParams pack{};
     int c_funcs[AGG_MAX_FUNCS], c_in_types[AGG_MAX_FUNCS], c_in_flags[AGG_MAX_FUNCS], c_in_col_ids[AGG_MAX_FUNCS];
     bool c_has_ids = false;
+    // program split (round 3): more input columns than one partition entry carries (key + six words) used to mean the LDS
+    // scan with its flush storms at large G.  The function list is cut into sub-operators over a few columns each, all over
+    // the same key; every batch goes through each of them and their results are joined by key when the state is needed
+    // (collapse_parts: a run in ascending key order).
+    std::vector<vnm_agg*> parts;
+    std::vector<std::vector<int>> part_funcs;   // [part][function of the part] -> function index here
+    bool split_tried = false;
 };
 
 namespace {
@@ -4139,6 +4146,132 @@ int demote_packed(vnm_agg* h, hipStream_t s) {
     return rc;
 }
 
+
+// ---- program split --------------------------------------------------------------------------------------------------------
+__global__ void part_gather_kernel(const uint64_t* __restrict__ src, const int64_t* __restrict__ perm, uint64_t* __restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[perm[i]];
+}
+// both sub-operators saw the same rows: their sorted key lists must be the same list
+__global__ void part_keycheck_kernel(const uint64_t* __restrict__ k0, const int64_t* __restrict__ p0, const uint64_t* __restrict__ kc,
+                                     const int64_t* __restrict__ pc, int64_t n, unsigned long long* flag) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) bad = bad || k0[p0[i]] != kc[pc[i]];
+    if (bad) __hip_atomic_store(flag, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+void drop_parts(vnm_agg* h) {
+    for (vnm_agg* c : h->parts) vnm_agg_destroy(c);
+    h->parts.clear();
+    h->part_funcs.clear();
+}
+
+// cut the function list by input column: `per` columns to a part (balanced), COUNT(*) with the first one
+int make_parts(vnm_agg* h, int per) {
+    const int nc = h->plan.n_cols;
+    const int k = (nc + per - 1) / per;
+    std::vector<int> part_of_col(nc);
+    for (int c = 0; c < nc; c++) part_of_col[c] = (int)((int64_t)c * k / nc);
+    h->part_funcs.assign(k, std::vector<int>());
+    for (int i = 0; i < h->n_funcs; i++) h->part_funcs[h->func_col[i] < 0 ? 0 : part_of_col[h->func_col[i]]].push_back(i);
+    const int kt = h->plan.key_types[0];
+    for (int p = 0; p < k; p++) {
+        int funcs[AGG_MAX_FUNCS], types[AGG_MAX_FUNCS], flags[AGG_MAX_FUNCS], ids[AGG_MAX_FUNCS];
+        const int nf = (int)h->part_funcs[p].size();
+        for (int q = 0; q < nf; q++) {
+            const int i = h->part_funcs[p][q];
+            funcs[q] = h->c_funcs[i]; types[q] = h->c_in_types[i]; flags[q] = h->c_in_flags[i]; ids[q] = h->func_col[i];   // (the distinct column: sharing survives)
+        }
+        vnm_agg* c = vnm_agg_create(VNM_SINGLE_NUMERICAL, 1, &kt, nf, funcs, types, flags, ids);
+        if (!c) { drop_parts(h); return 1; }
+        c->hint = h->hint;
+        c->estimated = h->estimated;
+        c->split_tried = true;
+        h->parts.push_back(c);
+    }
+    return 0;
+}
+
+int next_parts(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs, const vnm_dcol* pred, void* stream) {
+    for (size_t p = 0; p < h->parts.size(); p++) {
+        vnm_agg* c = h->parts[p];
+        vnm_dcol in[AGG_MAX_FUNCS];
+        const int nf = (int)h->part_funcs[p].size();
+        for (int q = 0; q < nf; q++) in[q] = inputs[h->part_funcs[p][q]];
+        VNM_TRY(vnm_agg_set_predicate(c, h->pred_set ? 1 : 0, h->pred_op, h->pred_is_float, h->pred_dval, h->pred_ival));
+        VNM_TRY(vnm_agg_next_device(c, nrows, keys, in, pred, stream));
+    }
+    h->rows_seen += nrows;
+    return 0;
+}
+
+// The parts' results joined by key into ONE run of this operator (ascending key bits), the parts destroyed.  Every part
+// grouped the same rows, so every part holds the same keys: sorting each part's keys gives the permutation that lines its
+// accumulator words up with the others'.
+int collapse_parts(vnm_agg* h, hipStream_t s) {
+    if (h->parts.empty()) return 0;
+    KernelTimer timer("agg_split_join", s);
+    const int k = (int)h->parts.size();
+    int64_t n = -1;
+    for (int p = 0; p < k; p++) {
+        int64_t np = 0;
+        VNM_TRY(vnm_agg_finish(h->parts[p], &np, (void*)s));
+        if (n >= 0 && np != n) return set_error("aggregate: the parts of a split program disagree on the group count (%lld / %lld; internal error)", (long long)n, (long long)np);
+        n = np;
+    }
+    if (h->have_run || h->have_table || h->pending) return set_error("aggregate: split program with state of its own (internal error)");
+    if (n > 0) {
+        PoolScope pool;
+        const int64_t stride = n + 2;
+        uint64_t* rk = (uint64_t*)pool_alloc((size_t)stride * 8 * 2);
+        uint64_t* ra = (uint64_t*)pool_alloc((size_t)stride * 8 * h->plan.n_words);
+        unsigned long long* flag = (unsigned long long*)pool.take(64);
+        std::vector<int64_t*> perm(k, nullptr);
+        bool ok = rk && ra && flag;
+        for (int p = 0; p < k && ok; p++) ok = (perm[p] = (int64_t*)pool.take((size_t)n * 8)) != nullptr;
+        if (!ok) { pool_free(rk); pool_free(ra); return 1; }
+        int rc = hipMemsetAsync(flag, 0, 8, s) != hipSuccess || hipMemsetAsync(rk + stride, 0, (size_t)stride * 8, s) != hipSuccess;
+        const int asc = VNM_ASC;
+        for (int p = 0; p < k && !rc; p++) {
+            vnm_dcol kc{};
+            kc.values = h->parts[p]->dkey; kc.type = VNM_U64; kc.length = n;
+            rc = vnm_sort_indices(1, &kc, &asc, n, 0, perm[p], (void*)s);
+        }
+        const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_info().num_cus * 8);
+        if (!rc) {
+            part_gather_kernel<<<grid, 256, 0, s>>>(h->parts[0]->dkey, perm[0], rk, n);
+            for (int p = 1; p < k; p++) part_keycheck_kernel<<<grid, 256, 0, s>>>(h->parts[0]->dkey, perm[0], h->parts[p]->dkey, perm[p], n, flag);
+            std::vector<char> done(h->plan.n_words, 0);
+            for (int p = 0; p < k; p++) {
+                const vnm_agg* c = h->parts[p];
+                for (size_t q = 0; q < h->part_funcs[p].size(); q++) {
+                    const FuncOut& mine = h->outs[h->part_funcs[p][q]];
+                    const FuncOut& theirs = c->outs[q];
+                    const int pw[3] = {mine.w_valid, mine.w_a, mine.w_b}, cw[3] = {theirs.w_valid, theirs.w_a, theirs.w_b};
+                    for (int j = 0; j < 3; j++) {
+                        if (pw[j] < 0 || done[pw[j]]) continue;
+                        if (cw[j] < 0) { rc = set_error("aggregate: split program, accumulator layouts differ (internal error)"); break; }
+                        done[pw[j]] = 1;
+                        part_gather_kernel<<<grid, 256, 0, s>>>(c->dacc + (size_t)cw[j] * c->dstride, perm[p], ra + (size_t)pw[j] * stride, n);
+                    }
+                }
+            }
+            for (int w = 0; w < h->plan.n_words && !rc; w++)
+                if (!done[w]) rc = set_error("aggregate: split program, accumulator word %d has no source (internal error)", w);
+        }
+        unsigned long long bad = 0;
+        if (!rc && (hipGetLastError() != hipSuccess || hipMemcpyAsync(&bad, flag, 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                    hipStreamSynchronize(s) != hipSuccess))
+            rc = set_error("aggregate: joining the parts of a split program failed");
+        if (!rc && bad) rc = set_error("aggregate: the parts of a split program hold different keys (internal error)");
+        if (rc) { pool_free(rk); pool_free(ra); return rc; }
+        h->run_key = rk; h->run_acc = ra; h->run_stride = stride; h->run_n = n; h->have_run = true;
+    }
+    drop_parts(h);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -4176,6 +4309,7 @@ vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs,
 void vnm_agg_destroy(vnm_agg* h) {
     if (!h) return;
     if (h->inner) { vnm_agg_destroy(h->inner); h->inner = nullptr; }
+    drop_parts(h);
     free_pack_tables(h);
     if (h->have_table) table_free(&h->g);
     invalidate_result(h);
@@ -4280,6 +4414,27 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
             }
             pool_free(packed);
             VNM_TRY(demote_packed(h, s));  // keys outside the packed ranges: continue with the wide-key table
+        }
+    }
+
+    // more input columns than a partition entry carries (or as many, plus a validity word) and many groups: split the program
+    if (!h->parts.empty()) return next_parts(h, nrows, keys, inputs, pred, stream);
+    if (!h->split_tried && key_plain && h->single && keys[0].type == h->plan.key_types[0] && !h->have_table && !h->have_run && !h->pending &&
+        !h->expr_active && getenv("VNM_AGG_NO_SPLIT") == nullptr) {
+        bool any_null = false;
+        for (int c = 0; c < h->plan.n_cols; c++) any_null = any_null || inputs[h->col_first_func[c]].validity != nullptr;
+        if (h->plan.n_cols + (any_null ? 1 : 0) > env_i64("VNM_AGG_SPLIT_MIN_COLS", 6)) {
+            h->split_tried = true;
+            if (h->hint == 0 && !h->estimated && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) && getenv("VNM_AGG_NO_ESTIMATE") == nullptr) {
+                int64_t est = 0;
+                KernelTimer timer("agg_estimate", s);
+                VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s));
+                if (est) { h->hint = est; h->estimated = true; }
+            }
+            if (h->hint > env_i64("VNM_AGG_PART_MIN_GROUPS", std::min<int64_t>(2400, (int64_t)lds_slots_for(h->plan) * 6 / 10))) {
+                VNM_TRY(make_parts(h, (int)env_i64("VNM_AGG_SPLIT_COLS", any_null ? 5 : 6)));
+                return next_parts(h, nrows, keys, inputs, pred, stream);
+            }
         }
     }
 
@@ -4752,6 +4907,7 @@ int vnm_agg_merge_device(vnm_agg* h, int64_t n, uint64_t* const* key_words, uint
     if (!h) return set_error("vnm_agg_merge_device: null handle");
     hipStream_t s = as_stream(stream);
     if (h->inner) VNM_TRY(demote_packed(h, s));
+    VNM_TRY(collapse_parts(h, s));
     invalidate_result(h);
     VNM_TRY(ensure_table(h, n, s));
     if (n <= 0) return 0;
@@ -4820,6 +4976,7 @@ int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream) {
         if (n_groups) *n_groups = n;
         return 0;
     }
+    VNM_TRY(collapse_parts(h, s));                     // a split program: its parts joined by key, as a run
     if (h->pending) VNM_TRY(complete_pending(h, s));   // the deferred final pass of the dense path, as a run
     if (h->have_run && h->have_table) {   // a big run + a few spilled groups in the table: fold the table into the run
         bool patched = false;
