@@ -14,6 +14,7 @@ f64 = torch.randint(0, 2**14, (n,), device=dev, dtype=torch.int64, generator=g).
 i64 = torch.randint(-2**40, 2**40, (n,), device=dev, dtype=torch.int64, generator=g)
 i32 = torch.randint(-2**20, 2**20, (n,), device=dev, dtype=torch.int32, generator=g)
 f32 = torch.rand(n, device=dev, dtype=torch.float32, generator=g)
+f64b, f64c, i64b, i64c = f64 * 3.0 + 1.0, 4096.0 - f64, i64 // 3, -i64
 valid_bits = torch.randint(0, 256, ((n + 7) // 8,), device=dev, dtype=torch.uint8, generator=g) | 1   # ~half the rows NULL
 
 
@@ -38,6 +39,9 @@ def keyset(kind, G):
     if kind == "wide2":
         g1 = max(1, int(G ** 0.5))
         return [(col((base % g1) * (1 << 44) - (1 << 61)), pa.int64()), (col((base // g1) * (1 << 40) + 12345), pa.int64())]
+    if kind == "wide3hi":   # three wide columns, each with as many distinct values as there are groups: > 63 bits even as dictionary codes
+        return [(col(base * 977_000_003 - (1 << 61)), pa.int64()), (col((base ^ 0x5DEECE66D) * 1_000_003 + 17), pa.int64()),
+                (col(base * (1 << 33) - 99), pa.int64())]
     if kind == "i64n":
         return [(col(base * 977 - 5, True), pa.int64())]
     if kind == "i64x2n":
@@ -56,6 +60,11 @@ PROGRAMS = {
     "sum_f32": lambda: ([(L.SUM, 1, pa.float32())], [col(f32)]),
     "sum_f64+max_i64": lambda: ([(L.SUM, 1, pa.float64()), (L.MAX, 2, pa.int64())], [col(f64), col(i64)]),
     "sum_f64+sum_i64+min_i32": lambda: ([(L.SUM, 1, pa.float64()), (L.SUM, 2, pa.int64()), (L.MIN, 3, pa.int32())], [col(f64), col(i64), col(i32)]),
+    "7cols": lambda: ([(L.SUM, 1, pa.float64()), (L.SUM, 2, pa.int64()), (L.MIN, 3, pa.int32()), (L.AVG, 4, pa.float32()), (L.MAX, 5, pa.float64()),
+                       (L.SUM, 6, pa.int64()), (L.AVG, 7, pa.float64()), (L.COUNT_STAR, None, None)],
+                      [col(f64), col(i64), col(i32), col(f32), col(f64b), col(i64b), col(f64c), None]),
+    "12cols": lambda: ([(L.SUM, 1 + j, pa.float64() if j % 2 == 0 else pa.int64()) for j in range(12)],
+                       [col((f64, i64, f64b, i64b, f64c, i64c)[j % 6]) for j in range(12)]),
     "count_f64+count*": lambda: ([(L.COUNT, 1, pa.float64()), (L.COUNT_STAR, None, None)], [col(f64), None]),
 }
 if NULLS:
@@ -73,7 +82,7 @@ PREDS = {"none": None, "f64>": ("f64", ">", 32.0), "i32>": ("i32", ">", 0)}
 pred_cols = {"f64": col(f64, NULLS), "i32": col(i32)}
 
 rows = []
-KINDS = ["i64", "i64n", "i64x2n"] if NULLS else ["i64", "i32", "f64", "i64x2", "wide2"]
+KINDS = ["i64", "i64n", "i64x2n"] if NULLS else ["i64", "i32", "f64", "i64x2", "wide2", "wide3hi"]
 for kind, G in itertools.product(KINDS, [10, 10_000, 1_000_000, 20_000_000]):
     ks = keyset(kind, G)
     for pname, mk in PROGRAMS.items():

@@ -1065,7 +1065,7 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
 
     // one 8-byte key without NULLs, many rows: sample sort (two bucket scatters + a sort in LDS) instead of eight LSD passes
     if (n_keys == 1 && !keys[0].validity && (keys[0].type == VNM_F64 || keys[0].type == VNM_I64 || keys[0].type == VNM_U64) &&
-        n >= env_sort_i64("VNM_SSORT_MIN_ROWS", (int64_t)1 << 24) && getenv("VNM_SORT_NO_SAMPLE") == nullptr) {
+        n >= env_sort_i64("VNM_SSORT_MIN_ROWS", (int64_t)1 << 28) && getenv("VNM_SORT_NO_SAMPLE") == nullptr) {
         bool wk = false;
         const int rc = sample_sort(keys[0], orders[0] == VNM_DESC, n, out_indices, (uint64_t*)out_sorted_key0, &wk, s);
         if (rc == 1) return 1;
