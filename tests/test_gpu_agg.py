@@ -703,6 +703,87 @@ def test_many_input_columns_take_the_partitioned_path(ncols, nulls):
         util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"{ncols} input columns nulls={nulls} pred={pred}")
 
 
+@pytest.mark.parametrize("scenario", ["three_wide_high_cardinality", "nulls_and_floats", "dictionary_grows", "eight_columns",
+                                      "merged_afterwards", "few_groups"])
+def test_tuple_dictionary_for_keys_beyond_one_word(scenario, monkeypatch):
+    """Key sets that do not fit 63 bits even as per-column dictionary codes (several wide columns with many distinct values
+    EACH) used to aggregate with one HBM atomic per row and accumulator word (agg_wide_kernel).  Round 3: the wide-key table is
+    a DICTIONARY tuple -> group id (tuple_gid_kernel), the ids go through the single-key operator and the stored tuples are
+    the result's keys.  Several batches, NULL keys, float keys (-0.0 / NaN identity as in the wide table), a predicate, a
+    dictionary that has to grow between and inside batches, a program wide enough to be split behind it, foreign partial
+    state merged in afterwards; bit-exact against the oracle."""
+    import ctypes
+    from oracle import oracle as O
+    from vinum_amd import _lib as L
+    rng = np.random.default_rng(len(scenario))
+    if scenario == "three_wide_high_cardinality":     # 2.4e6 distinct values per column: 3 x (23 + 1) bits of dictionary codes
+        n, groups = 3_000_000, 2_400_000
+    else:                                             # the small cases switch the per-column dictionaries off to get here
+        n, groups = 900_000, (40 if scenario == "few_groups" else 150_000)
+        monkeypatch.setenv("VNM_AGG_NO_DICT", "1")
+    g = rng.integers(0, groups, n)
+    mix = lambda x, m: (x * m) % (2**62) - 2**61             # noqa: E731  (wide, distinct per group)
+    cols = {"a": pa.array(mix(g.astype(np.int64), 977_000_003)), "b": pa.array(mix(g.astype(np.int64) ^ 0x5DEECE66D, 1_000_003)),
+            "c": pa.array(g.astype(np.int64) * (1 << 33) - 99)}
+    if scenario == "nulls_and_floats":
+        f = (g % 1000).astype(np.float64) * 1e300 * np.where(g % 2 == 0, 1.0, -1.0)
+        f[g % 997 == 0] = np.nan
+        f[g % 991 == 0] = -0.0
+        f[g % 983 == 0] = 0.0
+        cols["c"] = pa.array(f)
+        cols["a"] = pa.array(cols["a"].to_numpy(), mask=(g % 13 == 0))
+        cols["b"] = pa.array(cols["b"].to_numpy(), mask=(g % 17 == 0))
+    keys = ["a", "b", "c"]
+    ncol = 8 if scenario == "eight_columns" else 2
+    funcs = []
+    kinds = [O.SUM, O.MAX, O.AVG, O.MIN, O.COUNT, O.SUM, O.AVG, O.MAX]
+    for c in range(ncol):
+        vals = rng.integers(0, 2**14, n).astype(np.float64) / 64.0 if c % 2 == 0 else rng.integers(-2**40, 2**40, n).astype(np.int64)
+        cols[f"c{c}"] = pa.array(vals, mask=(rng.random(n) < 0.05) if c == 1 else None)
+        funcs.append((kinds[c], f"c{c}", f"f{c}"))
+    funcs.append((O.COUNT_STAR, "", "n"))
+    t = pa.table(cols)
+    if scenario == "dictionary_grows":       # a tiny first batch sizes the dictionary; the later ones bring the groups
+        batches = [t.slice(0, 2000).to_batches()[0]] + util.sliced_batches(t.slice(2000), 300_000)
+    else:
+        batches = util.sliced_batches(t, n // 3)
+
+    def launches(name):
+        ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+        L.lib().vnm_profile_query(name, ctypes.byref(ms), ctypes.byref(cnt))
+        return cnt.value
+    for pred in ((None,) if scenario in ("merged_afterwards", "eight_columns") else (None, ("c0", ">", 100.0))):
+        o = O.OracleAggregate(O.MULTI, keys, keys, funcs)
+        for bt in batches:
+            o.next(O.filter_batch(bt, O.cmp_mask(bt.column(3), O.GT, 100.0)) if pred else bt)
+        L.lib().vnm_set_profiling(1)
+        if scenario == "merged_afterwards":
+            from vinum_amd import ops
+            from vinum_amd.device import DeviceColumn
+            names = t.schema.names
+            fspec = [(f, names.index(col) if col else None, t.schema.field(col).type if col else None) for f, col, _ in funcs]
+            halves = []
+            for part in (batches[:2], batches[2:]):
+                agg = ops.DeviceAggregate(O.MULTI, [pa.int64()] * 3, fspec, expected_groups=groups)
+                for b in part:
+                    agg.next([DeviceColumn.from_arrow(b.column(j)) for j in range(3)],
+                             [DeviceColumn.from_arrow(b.column(names.index(col))) if col else None for _, col, _ in funcs], nrows=b.num_rows)
+                halves.append(agg)
+            a, b2 = halves
+            nb = b2.finish()
+            kw, aw = b2.dense_ptrs()
+            a.merge(nb, kw, aw)            # a leaves tuple mode: its groups go to its own wide-key table first
+            got = a.result_arrays([0, 1, 2], keys, [f[2] for f in funcs])
+            a.close(); b2.close()
+        else:
+            got = gpu_aggregate(O.MULTI, keys, keys, funcs, batches, predicate=pred,
+                                expected_groups=0 if scenario in ("dictionary_grows", "few_groups") else groups)
+        ids, packs = launches(b"agg_tuple_ids"), launches(b"agg_pack_keys")
+        L.lib().vnm_set_profiling(0)
+        assert ids >= len(batches) and packs == 0, (ids, packs)
+        util.assert_agg_equal(got, o.result(), funcs, keys, what=f"tuple dictionary {scenario} pred={pred}")
+
+
 @pytest.mark.parametrize("scenario", ["hintless", "two_keys_packed", "merged_afterwards", "narrow_key"])
 def test_split_program_scenarios(scenario):
     """The program split (eight input columns) where the operator has to find out for itself that the groups are many (no

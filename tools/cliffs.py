@@ -83,6 +83,9 @@ pred_cols = {"f64": col(f64, NULLS), "i32": col(i32)}
 
 rows = []
 KINDS = ["i64", "i64n", "i64x2n"] if NULLS else ["i64", "i32", "f64", "i64x2", "wide2", "wide3hi"]
+import os
+if os.environ.get("CLIFF_KINDS"):
+    KINDS = os.environ["CLIFF_KINDS"].split(",")
 for kind, G in itertools.product(KINDS, [10, 10_000, 1_000_000, 20_000_000]):
     ks = keyset(kind, G)
     for pname, mk in PROGRAMS.items():

@@ -897,6 +897,112 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggArgs a) {
 }
 
 // =======================================================================================================
+// Kernel 2b (round 3): tuple dictionary.  Key sets too wide to pack into one word even as per-column dictionary codes
+// used to aggregate right here, with one HBM atomic per row and accumulator word (150-570 ms per 1e9 rows).  Instead the
+// wide-key table becomes a DICTIONARY: find-or-insert per row as above, but the slot holds a GROUP ID, handed out when the
+// slot is claimed, and the row's id is all that leaves the kernel.  The ids then go through the single-key operator like
+// any 8-byte key (dense path, partitions, ...), and the tuples stored here are the result's key columns.  Ids come from
+// per-workgroup chunks of the global counter (an LDS atomic inside the claim; a global one per chunk: one atomic on ONE
+// address per new group would serialise 2e7 of them) -- so the id space has holes (< 2x), which nobody minds -- and they
+// survive a rehash of the table (they are its accumulator word: ADD-merged with nothing).
+// =======================================================================================================
+__device__ __forceinline__ uint64_t tdict_find(const GTable& g, const uint64_t* kw, uint64_t tagv, unsigned* newc, unsigned long long* s_gnext) {
+    const uint64_t mask = g.cap - 1;
+    uint64_t h = (tagv ^ (tagv >> 29)) & mask;
+    for (;;) {
+        uint64_t t = ld_agent(&g.tag[h]);
+        if (t == tagv) {
+            bool eq = true;
+            for (int i = 0; i < g.kwt; i++) eq = eq && (ld_agent(&g.keyw[(uint64_t)i * g.stride + h]) == kw[i]);
+            if (eq) return ld_agent(&g.acc[h]) - 1;
+            h = (h + 1) & mask;
+            continue;
+        }
+        if (t == EMPTY) {
+            uint64_t expected = EMPTY;
+            if (__hip_atomic_compare_exchange_strong(&g.tag[h], &expected, LOCKED, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+                const uint64_t gid = atomicAdd(s_gnext, 1ULL);
+                for (int i = 0; i < g.kwt; i++) st_agent(&g.keyw[(uint64_t)i * g.stride + h], kw[i]);
+                st_agent(&g.acc[h], gid + 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                st_agent(&g.tag[h], tagv);
+                atomicAdd(newc, 1u);
+                return gid;
+            }
+            continue;
+        }
+        if (t == LOCKED) continue;
+        h = (h + 1) & mask;
+    }
+}
+
+__global__ __launch_bounds__(256) void tuple_gid_kernel(AggArgs a, uint64_t* __restrict__ out_gid, unsigned long long* gnext) {
+    __shared__ int64_t s_tile;
+    __shared__ unsigned s_new;
+    __shared__ unsigned long long s_gnext, s_gend;
+    if (threadIdx.x == 0) { s_new = 0; s_gnext = 0; s_gend = 0; }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    const int nk = a.plan.n_keys;
+    unsigned it = a.progress[blockIdx.x];
+    for (;; it++) {
+        const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
+        if (tile >= a.ntiles) break;
+        __syncthreads();
+        if (tid == 0) {
+            const bool room = table_has_room(a, &s_new);
+            if (room && s_gend - s_gnext < (unsigned long long)AGG_TILE) {   // every row of a tile may be a new group
+                const unsigned long long base = atomicAdd(gnext, 2ULL * AGG_TILE);
+                s_gnext = base; s_gend = base + 2ULL * AGG_TILE;
+            }
+            s_tile = room ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_tile) break;
+        for (int r = 0; r < AGG_TILE / 256; r++) {
+            const int64_t row = tile * AGG_TILE + (int64_t)r * 256 + tid;
+            if (row >= a.nrows) continue;
+            if (a.p.enabled && !pred_eval(a.p, a.pred, row)) { out_gid[row] = 0; continue; }   // (the operator behind drops the row itself)
+            uint64_t kw[AGG_MAX_KEYS + 1];
+            uint64_t nullmask = 0;
+#pragma unroll
+            for (int j = 0; j < AGG_MAX_KEYS; j++) {
+                if (j < nk) {
+                    bool ok = col_valid(a.keys[j], row);
+                    kw[j] = ok ? col_key_bits(a.keys[j], row) : 0;
+                    if (!ok) nullmask |= 1ULL << j;
+                }
+            }
+            kw[nk] = nullmask;
+            out_gid[row] = tdict_find(a.g, kw, wide_tag(kw, nk + 1), &s_new, &s_gnext);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { fold_new(a.g, &s_new); a.progress[blockIdx.x] = it; }
+}
+
+// the dictionary's tuples laid out by group id: by_gid [kwt][ngid]
+__global__ void tuple_sweep_kernel(GTable g, uint64_t* __restrict__ by_gid, int64_t ngid) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < (int64_t)g.cap; h += stride) {
+        const uint64_t t = g.tag[h];
+        if (t == EMPTY || t == LOCKED) continue;
+        const int64_t gid = (int64_t)g.acc[h] - 1;
+        if (gid < 0 || gid >= ngid) continue;
+        for (int j = 0; j < g.kwt; j++) by_gid[(int64_t)j * ngid + gid] = g.keyw[(uint64_t)j * g.stride + h];
+    }
+}
+__global__ void tuple_keys_kernel(const uint64_t* __restrict__ by_gid, int64_t ngid, int kwt, const uint64_t* __restrict__ gids, int64_t n,
+                                  uint64_t* __restrict__ dkey, int64_t dstride) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t gid = (int64_t)gids[i];
+        for (int j = 0; j < kwt; j++) dkey[(int64_t)j * dstride + i] = gid < ngid ? by_gid[(int64_t)j * ngid + gid] : 0;
+    }
+}
+
+// =======================================================================================================
 // Kernel 3: no GROUP BY.  Per-lane private accumulators in LDS (no atomics, no conflicts), block tree
 // reduction, one agent-scope atomic per word per block into group slot 0.
 // =======================================================================================================
@@ -2807,6 +2913,11 @@ struct vnm_agg {
     // scan with its flush storms at large G.  The function list is cut into sub-operators over a few columns each, all over
     // the same key; every batch goes through each of them and their results are joined by key when the state is needed
     // (collapse_parts: a run in ascending key order).
+    // tuple dictionary (round 3, tuple_gid_kernel): key sets that do not pack into one word.  tdict is a keys-only operator of
+    // the same key columns whose wide-key table maps tuple -> group id; `inner` aggregates by that id
+    vnm_agg* tdict = nullptr;
+    unsigned long long* tnext = nullptr;   // device: first group id not handed out yet
+    bool tuple_mode = false;
     std::vector<vnm_agg*> parts;
     std::vector<std::vector<int>> part_funcs;   // [part][function of the part] -> function index here
     bool split_tried = false;
@@ -4115,6 +4226,102 @@ bool plan_packing(vnm_agg* h, const vnm_dcol* keys, int64_t nrows, hipStream_t s
     return true;
 }
 
+// ---- tuple dictionary: host side (tuple_gid_kernel) ---------------------------------------------------------------------
+int enter_tuple_mode(vnm_agg* h, hipStream_t s) {
+    h->tdict = vnm_agg_create(VNM_MULTI_NUMERICAL, h->plan.n_keys, h->plan.key_types, 0, nullptr, nullptr, nullptr, nullptr);
+    if (!h->tdict) return 1;
+    h->tdict->hint = h->hint;
+    const int kt = VNM_U64;
+    h->inner = vnm_agg_create(VNM_SINGLE_NUMERICAL, 1, &kt, h->n_funcs, h->c_funcs, h->c_in_types, h->c_in_flags,
+                              h->c_has_ids ? h->c_in_col_ids : nullptr);
+    if (!h->inner) return 1;
+    h->inner->hint = h->hint;
+    h->tnext = (unsigned long long*)pool_alloc(64);
+    if (!h->tnext) return 1;
+    VNM_HIP(hipMemsetAsync(h->tnext, 0, 8, s));
+    h->tuple_mode = true;
+    return 0;
+}
+
+void leave_tuple_mode(vnm_agg* h) {
+    if (h->tdict) vnm_agg_destroy(h->tdict);
+    h->tdict = nullptr;
+    pool_free(h->tnext);
+    h->tnext = nullptr;
+    h->tuple_mode = false;
+}
+
+// one batch: every row's tuple -> group id (find-or-insert in the dictionary), then the ids through the single-key operator
+int tuple_next(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs, const vnm_dcol* pred, hipStream_t s) {
+    vnm_agg* d = h->tdict;
+    PoolScope pool;
+    uint64_t* gid = (uint64_t*)pool.take((size_t)nrows * 8);
+    if (!gid) return 1;
+    AggArgs a{};
+    a.plan = d->plan;
+    for (int j = 0; j < h->plan.n_keys; j++) a.keys[j] = keys[j];
+    if (h->pred_set) {
+        a.pred = *pred;
+        a.p = make_predicate(pred->type, pred->validity != nullptr, h->pred_op, h->pred_is_float, h->pred_dval, h->pred_ival);
+    }
+    a.nrows = nrows;
+    a.ntiles = (nrows + AGG_TILE - 1) / AGG_TILE;
+    VNM_TRY(ensure_table(d, nrows, s));
+    int grid = device_info().num_cus * 4;
+    if (grid > a.ntiles) grid = (int)a.ntiles;
+    a.margin = (int64_t)grid * AGG_TILE;
+    unsigned int* progress = (unsigned int*)pool.take((size_t)grid * 4);
+    if (!progress) return 1;
+    VNM_HIP(hipMemsetAsync(progress, 0, (size_t)grid * 4, s));
+    a.progress = progress;
+    for (int round = 0;; round++) {
+        while ((int64_t)(d->g.cap * 7 / 10) < a.margin + 1) VNM_TRY(table_grow(d, d->g.cap * 4, s));
+        VNM_HIP(hipMemsetAsync(d->g.ctl, 0, 16, s));
+        a.g = d->g;
+        a.fill_limit = (int64_t)(d->g.cap * 7 / 10);
+        {
+            KernelTimer timer("agg_tuple_ids", s);
+            tuple_gid_kernel<<<grid, 256, 0, s>>>(a, gid, h->tnext);
+        }
+        VNM_HIP(hipGetLastError());
+        unsigned long long ctl[4];
+        VNM_HIP(hipMemcpyAsync(ctl, d->g.ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipStreamSynchronize(s));
+        if (!ctl[1]) break;   // no workgroup ran out of room
+        VNM_TRY(table_grow(d, d->g.cap * (round >= 1 ? 16 : 4), s));   // blocks resume from progress[]
+    }
+    vnm_dcol gk{};
+    gk.values = gid; gk.type = VNM_U64; gk.length = nrows;
+    int rc = vnm_agg_set_predicate(h->inner, h->pred_set ? 1 : 0, h->pred_op, h->pred_is_float, h->pred_dval, h->pred_ival);
+    if (!rc) rc = vnm_agg_next_device(h->inner, nrows, &gk, inputs, pred, (void*)s);
+    if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = set_error("aggregate: tuple-dictionary batch failed");
+    if (!rc) h->rows_seen += nrows;
+    return rc;
+}
+
+// the key words of the inner operator's n finished groups in this operator's wide layout: keys [kw][stride]
+int inner_keys(vnm_agg* h, const vnm_agg* in, int64_t n, uint64_t* keys, int64_t stride, hipStream_t s) {
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_info().num_cus * 8);
+    if (!h->tuple_mode) {
+        key_unpack_kernel<<<grid, 256, 0, s>>>(h->pack, in->dkey, n, keys, stride);
+        VNM_HIP(hipGetLastError());
+        return 0;
+    }
+    unsigned long long ngid = 0;
+    VNM_HIP(hipMemcpyAsync(&ngid, h->tnext, 8, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    const GTable& g = h->tdict->g;
+    PoolScope pool;
+    uint64_t* by_gid = (uint64_t*)pool.take((size_t)g.kwt * (size_t)(ngid ? ngid : 1) * 8);
+    if (!by_gid) return 1;
+    KernelTimer timer("agg_tuple_keys", s);
+    tuple_sweep_kernel<<<(int)std::min<int64_t>(((int64_t)g.cap + 255) / 256, (int64_t)device_info().num_cus * 8), 256, 0, s>>>(g, by_gid, (int64_t)ngid);
+    tuple_keys_kernel<<<grid, 256, 0, s>>>(by_gid, (int64_t)ngid, g.kwt, in->dkey, n, keys, stride);
+    VNM_HIP(hipGetLastError());
+    VNM_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
 // leave packed mode: the groups aggregated so far are unpacked and merged into h's own (wide-key) table
 int demote_packed(vnm_agg* h, hipStream_t s) {
     vnm_agg* in = h->inner;
@@ -4129,13 +4336,13 @@ int demote_packed(vnm_agg* h, hipStream_t s) {
             int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_info().num_cus * 8);
             {
                 KernelTimer timer("agg_demote", s);
-                key_unpack_kernel<<<grid, 256, 0, s>>>(h->pack, in->dkey, n, keys, n);
+                rc = inner_keys(h, in, n, keys, n, s);
             }
             uint64_t* kp[AGG_MAX_KEYS + 1];
             uint64_t* ap[AGG_MAX_WORDS];
             for (int j = 0; j < kw; j++) kp[j] = keys + (size_t)j * n;
             for (int w = 0; w < h->plan.n_words; w++) ap[w] = in->dacc + (size_t)w * in->dstride;
-            rc = vnm_agg_merge_device(h, n, kp, ap, (void*)s);
+            if (!rc) rc = vnm_agg_merge_device(h, n, kp, ap, (void*)s);
             if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = set_error("aggregate: demotion failed");
         }
         pool_free(keys);
@@ -4143,6 +4350,7 @@ int demote_packed(vnm_agg* h, hipStream_t s) {
     vnm_agg_destroy(in);
     if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = set_error("aggregate: demotion failed");
     free_pack_tables(h);   // the unpack above was their last reader
+    leave_tuple_mode(h);
     return rc;
 }
 
@@ -4327,6 +4535,7 @@ void vnm_agg_destroy(vnm_agg* h) {
     if (!h) return;
     if (h->inner) { vnm_agg_destroy(h->inner); h->inner = nullptr; }
     drop_parts(h);
+    leave_tuple_mode(h);
     free_pack_tables(h);
     if (h->have_table) table_free(&h->g);
     invalidate_result(h);
@@ -4402,7 +4611,13 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
                 if (!h->inner) return 1;
                 h->inner->hint = h->hint;
             } else if (err) return err;
+            else if (!h->single && !h->have_run && !h->pending && getenv("VNM_AGG_NO_TUPLE") == nullptr) {
+                // too wide for one word even as per-column dictionary codes: tuple -> group id through a dictionary
+                // (before: agg_wide_kernel, one HBM atomic per row and accumulator word)
+                VNM_TRY(enter_tuple_mode(h, s));
+            }
         }
+        if (h->tuple_mode) return tuple_next(h, nrows, keys, inputs, pred, s);
         if (h->inner) {
             for (int j = 0; j < h->plan.n_keys; j++) h->pack.cols[j] = keys[j];
             uint64_t* packed = (uint64_t*)pool_alloc((size_t)nrows * 8);
@@ -4981,8 +5196,7 @@ int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream) {
         h->dacc = (uint64_t*)pool_alloc((size_t)h->dstride * 8 * h->plan.n_words);
         if (!h->dkey || !h->dacc) return 1;
         if (n > 0) {
-            int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_info().num_cus * 8);
-            key_unpack_kernel<<<grid, 256, 0, s>>>(h->pack, h->inner->dkey, n, h->dkey, h->dstride);
+            VNM_TRY(inner_keys(h, h->inner, n, h->dkey, h->dstride, s));
             for (int w = 0; w < h->plan.n_words; w++)
                 VNM_HIP(hipMemcpyAsync(h->dacc + (size_t)w * h->dstride, h->inner->dacc + (size_t)w * h->inner->dstride, (size_t)n * 8,
                                        hipMemcpyDeviceToDevice, s));
