@@ -898,62 +898,104 @@ __global__ __launch_bounds__(256) void agg_wide_kernel(AggArgs a) {
 
 // =======================================================================================================
 // Kernel 2b (round 3): tuple dictionary.  Key sets too wide to pack into one word even as per-column dictionary codes
-// used to aggregate right here, with one HBM atomic per row and accumulator word (150-570 ms per 1e9 rows).  Instead the
-// wide-key table becomes a DICTIONARY: find-or-insert per row as above, but the slot holds a GROUP ID, handed out when the
-// slot is claimed, and the row's id is all that leaves the kernel.  The ids then go through the single-key operator like
-// any 8-byte key (dense path, partitions, ...), and the tuples stored here are the result's key columns.  Ids come from
-// per-workgroup chunks of the global counter (an LDS atomic inside the claim; a global one per chunk: one atomic on ONE
-// address per new group would serialise 2e7 of them) -- so the id space has holes (< 2x), which nobody minds -- and they
-// survive a rehash of the table (they are its accumulator word: ADD-merged with nothing).
+// used to aggregate in agg_wide_kernel, with one HBM atomic per row and accumulator word (150-570 ms per 1e9 rows).
+// Instead a DICTIONARY maps the key tuple to a GROUP ID -- find-or-insert per row, the id is all that leaves the kernel --
+// the ids go through the single-key operator like any 8-byte key (dense path, partitions, ...), and the tuples stored here
+// are the result's key columns.
+// Layout: ONE 64-byte line per slot (128 for more than five key columns): [tag, id + 1, key words ...] -- a probe reads
+// one line (the wide-key table's column arrays: six lines per row, 200 ms per 1e9 rows at G = 2e7).  A reader issues
+// all loads of the line at once; the claimer writes id and key words, drains, then publishes the tag, so a reader that saw
+// the tag with stale words behind it simply reads those words again (they are ordered behind the tag then).
+// Ids come from per-workgroup chunks of a global counter (an LDS atomic inside the claim, one global atomic per chunk:
+// one atomic on ONE address per new group would serialise 2e7 of them) -- the id space has holes (< 2x), which nobody
+// minds -- and they survive a rehash.
 // =======================================================================================================
-__device__ __forceinline__ uint64_t tdict_find(const GTable& g, const uint64_t* kw, uint64_t tagv, unsigned* newc, unsigned long long* s_gnext) {
-    const uint64_t mask = g.cap - 1;
+struct TDict {
+    uint64_t* slot;                // [cap][sw]
+    uint64_t cap;
+    int kwt, sw;                   // key words per tuple (n_keys + 1), words per slot (8 or 16)
+    unsigned long long* ctl;       // [1] a workgroup ran out of room  [2] fill
+};
+struct TupArgs {
+    int nk;
+    vnm_dcol keys[AGG_MAX_KEYS];
+    Predicate p;
+    vnm_dcol pred;
+    int64_t nrows, ntiles, margin, fill_limit;
+    TDict d;
+    unsigned int* progress;
+    uint64_t* out;
+    unsigned long long* gnext;
+};
+
+template <int KWT>
+__device__ __forceinline__ uint64_t tdict_find(const TDict& d, const uint64_t* kw, uint64_t tagv, unsigned* newc, unsigned long long* s_gnext) {
+    const uint64_t mask = d.cap - 1;
     uint64_t h = (tagv ^ (tagv >> 29)) & mask;
     for (;;) {
-        uint64_t t = ld_agent(&g.tag[h]);
+        uint64_t* const base = d.slot + h * (uint64_t)d.sw;
+        const uint64_t t = ld_agent(base);
+        uint64_t g = ld_agent(base + 1);
+        uint64_t k[KWT];
+#pragma unroll
+        for (int i = 0; i < KWT; i++) k[i] = ld_agent(base + 2 + i);
         if (t == tagv) {
             bool eq = true;
-            for (int i = 0; i < g.kwt; i++) eq = eq && (ld_agent(&g.keyw[(uint64_t)i * g.stride + h]) == kw[i]);
-            if (eq) return ld_agent(&g.acc[h]) - 1;
+#pragma unroll
+            for (int i = 0; i < KWT; i++) eq = eq & (k[i] == kw[i]);
+            if (!eq) {       // another tuple with this tag -- or this line's words were read before the tag's owner wrote them
+                eq = true;
+#pragma unroll
+                for (int i = 0; i < KWT; i++) eq = eq & (ld_agent(base + 2 + i) == kw[i]);
+            }
+            if (eq) {
+                if (g == EMPTY) g = ld_agent(base + 1);
+                return g - 1;
+            }
             h = (h + 1) & mask;
             continue;
         }
         if (t == EMPTY) {
             uint64_t expected = EMPTY;
-            if (__hip_atomic_compare_exchange_strong(&g.tag[h], &expected, LOCKED, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+            if (__hip_atomic_compare_exchange_strong(base, &expected, LOCKED, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 const uint64_t gid = atomicAdd(s_gnext, 1ULL);
-                for (int i = 0; i < g.kwt; i++) st_agent(&g.keyw[(uint64_t)i * g.stride + h], kw[i]);
-                st_agent(&g.acc[h], gid + 1);
+                st_agent(base + 1, gid + 1);
+#pragma unroll
+                for (int i = 0; i < KWT; i++) st_agent(base + 2 + i, kw[i]);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                st_agent(&g.tag[h], tagv);
+                st_agent(base, tagv);
                 atomicAdd(newc, 1u);
                 return gid;
             }
-            continue;
+            continue;   // someone else is claiming this slot: look at it again
         }
         if (t == LOCKED) continue;
         h = (h + 1) & mask;
     }
 }
 
-__global__ __launch_bounds__(256) void tuple_gid_kernel(AggArgs a, uint64_t* __restrict__ out_gid, unsigned long long* gnext) {
+template <int KWT>
+__global__ __launch_bounds__(256) void tuple_gid_kernel(TupArgs a) {
     __shared__ int64_t s_tile;
     __shared__ unsigned s_new;
     __shared__ unsigned long long s_gnext, s_gend;
     if (threadIdx.x == 0) { s_new = 0; s_gnext = 0; s_gend = 0; }
     __syncthreads();
     const int tid = threadIdx.x;
-    const int nk = a.plan.n_keys;
+    constexpr int NK = KWT - 1;
     unsigned it = a.progress[blockIdx.x];
     for (;; it++) {
         const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
         if (tile >= a.ntiles) break;
         __syncthreads();
         if (tid == 0) {
-            const bool room = table_has_room(a, &s_new);
+            const unsigned v = atomicExch(&s_new, 0u);
+            if (v) atomicAdd(&a.d.ctl[2], (unsigned long long)v);
+            const unsigned long long fill = __hip_atomic_load(&a.d.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool room = (int64_t)fill + a.margin <= a.fill_limit;
+            if (!room) __hip_atomic_store(&a.d.ctl[1], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (room && s_gend - s_gnext < (unsigned long long)AGG_TILE) {   // every row of a tile may be a new group
-                const unsigned long long base = atomicAdd(gnext, 2ULL * AGG_TILE);
+                const unsigned long long base = atomicAdd(a.gnext, 2ULL * AGG_TILE);
                 s_gnext = base; s_gend = base + 2ULL * AGG_TILE;
             }
             s_tile = room ? 1 : 0;
@@ -963,34 +1005,58 @@ __global__ __launch_bounds__(256) void tuple_gid_kernel(AggArgs a, uint64_t* __r
         for (int r = 0; r < AGG_TILE / 256; r++) {
             const int64_t row = tile * AGG_TILE + (int64_t)r * 256 + tid;
             if (row >= a.nrows) continue;
-            if (a.p.enabled && !pred_eval(a.p, a.pred, row)) { out_gid[row] = 0; continue; }   // (the operator behind drops the row itself)
-            uint64_t kw[AGG_MAX_KEYS + 1];
+            if (a.p.enabled && !pred_eval(a.p, a.pred, row)) { a.out[row] = 0; continue; }   // (the operator behind drops the row itself)
+            uint64_t kw[KWT];
             uint64_t nullmask = 0;
 #pragma unroll
-            for (int j = 0; j < AGG_MAX_KEYS; j++) {
-                if (j < nk) {
-                    bool ok = col_valid(a.keys[j], row);
-                    kw[j] = ok ? col_key_bits(a.keys[j], row) : 0;
-                    if (!ok) nullmask |= 1ULL << j;
-                }
+            for (int j = 0; j < NK; j++) {
+                const bool ok = col_valid(a.keys[j], row);
+                kw[j] = ok ? col_key_bits(a.keys[j], row) : 0;
+                if (!ok) nullmask |= 1ULL << j;
             }
-            kw[nk] = nullmask;
-            out_gid[row] = tdict_find(a.g, kw, wide_tag(kw, nk + 1), &s_new, &s_gnext);
+            kw[NK] = nullmask;
+            a.out[row] = tdict_find<KWT>(a.d, kw, wide_tag(kw, KWT), &s_new, &s_gnext);
         }
     }
     __syncthreads();
-    if (tid == 0) { fold_new(a.g, &s_new); a.progress[blockIdx.x] = it; }
+    if (tid == 0) {
+        const unsigned v = atomicExch(&s_new, 0u);
+        if (v) atomicAdd(&a.d.ctl[2], (unsigned long long)v);
+        a.progress[blockIdx.x] = it;
+    }
+}
+
+// a bigger dictionary: every slot moves as it is (the tuples are distinct: the first free slot of its probe sequence)
+__global__ void tdict_rehash_kernel(TDict from, TDict to) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const uint64_t mask = to.cap - 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)from.cap; i += stride) {
+        const uint64_t* src = from.slot + (uint64_t)i * from.sw;
+        const uint64_t t = src[0];
+        if (t == EMPTY || t == LOCKED) continue;
+        uint64_t h = (t ^ (t >> 29)) & mask;
+        for (;;) {
+            uint64_t* dst = to.slot + h * (uint64_t)to.sw;
+            uint64_t expected = EMPTY;
+            if (__hip_atomic_compare_exchange_strong(dst, &expected, t, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                for (int w = 1; w < 2 + from.kwt; w++) dst[w] = src[w];
+                break;
+            }
+            h = (h + 1) & mask;
+        }
+    }
 }
 
 // the dictionary's tuples laid out by group id: by_gid [kwt][ngid]
-__global__ void tuple_sweep_kernel(GTable g, uint64_t* __restrict__ by_gid, int64_t ngid) {
+__global__ void tuple_sweep_kernel(TDict d, uint64_t* __restrict__ by_gid, int64_t ngid) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < (int64_t)g.cap; h += stride) {
-        const uint64_t t = g.tag[h];
+    for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < (int64_t)d.cap; h += stride) {
+        const uint64_t* src = d.slot + (uint64_t)h * d.sw;
+        const uint64_t t = src[0];
         if (t == EMPTY || t == LOCKED) continue;
-        const int64_t gid = (int64_t)g.acc[h] - 1;
+        const int64_t gid = (int64_t)src[1] - 1;
         if (gid < 0 || gid >= ngid) continue;
-        for (int j = 0; j < g.kwt; j++) by_gid[(int64_t)j * ngid + gid] = g.keyw[(uint64_t)j * g.stride + h];
+        for (int j = 0; j < d.kwt; j++) by_gid[(int64_t)j * ngid + gid] = src[2 + j];
     }
 }
 __global__ void tuple_keys_kernel(const uint64_t* __restrict__ by_gid, int64_t ngid, int kwt, const uint64_t* __restrict__ gids, int64_t n,
@@ -2913,9 +2979,10 @@ struct vnm_agg {
     // scan with its flush storms at large G.  The function list is cut into sub-operators over a few columns each, all over
     // the same key; every batch goes through each of them and their results are joined by key when the state is needed
     // (collapse_parts: a run in ascending key order).
-    // tuple dictionary (round 3, tuple_gid_kernel): key sets that do not pack into one word.  tdict is a keys-only operator of
-    // the same key columns whose wide-key table maps tuple -> group id; `inner` aggregates by that id
-    vnm_agg* tdict = nullptr;
+    // tuple dictionary (round 3, tuple_gid_kernel): key sets that do not pack into one word.  tdict maps tuple -> group id;
+    // `inner` aggregates by that id
+    TDict tdict{};
+    int64_t widest_est = 0;                // plan_packing: the largest distinct-count estimate of a single key column
     unsigned long long* tnext = nullptr;   // device: first group id not handed out yet
     bool tuple_mode = false;
     std::vector<vnm_agg*> parts;
@@ -4185,6 +4252,7 @@ bool plan_packing(vnm_agg* h, const vnm_dcol* keys, int64_t nrows, hipStream_t s
         if (type_width(keys[w].type) == 8 && (keys[w].offset & 1) == 0) {   // (whatever NULL slots hold only adds to the estimate)
             if (estimate_groups(h, keys[w], nrows, &est, s)) { *err = 1; return false; }
         }
+        h->widest_est = std::max<int64_t>(h->widest_est, est);   // (a lower bound of the tuple count: sizes the tuple dictionary)
         int tb = 12;
         while (tb < 30 && (1LL << tb) < est * 5 / 2) tb++;
         if (tb + 1 >= need_bits[w]) return false;   // no narrower than its range: nothing left to gain
@@ -4227,10 +4295,39 @@ bool plan_packing(vnm_agg* h, const vnm_dcol* keys, int64_t nrows, hipStream_t s
 }
 
 // ---- tuple dictionary: host side (tuple_gid_kernel) ---------------------------------------------------------------------
-int enter_tuple_mode(vnm_agg* h, hipStream_t s) {
-    h->tdict = vnm_agg_create(VNM_MULTI_NUMERICAL, h->plan.n_keys, h->plan.key_types, 0, nullptr, nullptr, nullptr, nullptr);
-    if (!h->tdict) return 1;
-    h->tdict->hint = h->hint;
+int tdict_alloc(TDict* d, uint64_t cap, int kwt, hipStream_t s) {
+    memset(d, 0, sizeof(*d));
+    d->cap = cap; d->kwt = kwt; d->sw = kwt <= 6 ? 8 : 16;
+    d->slot = (uint64_t*)pool_alloc((size_t)cap * d->sw * 8);
+    d->ctl = (unsigned long long*)pool_alloc(64);
+    if (!d->slot || !d->ctl) return 1;
+    VNM_HIP(hipMemsetAsync(d->slot, 0xFF, (size_t)cap * d->sw * 8, s));
+    VNM_HIP(hipMemsetAsync(d->ctl, 0, 64, s));
+    return 0;
+}
+
+void tdict_free(TDict* d) {
+    pool_free(d->slot);
+    pool_free(d->ctl);
+    memset(d, 0, sizeof(*d));
+}
+
+int tdict_grow(TDict* d, uint64_t new_cap, hipStream_t s) {
+    TDict nd;
+    VNM_TRY(tdict_alloc(&nd, new_cap, d->kwt, s));
+    VNM_HIP(hipMemcpyAsync(nd.ctl + 2, d->ctl + 2, 8, hipMemcpyDeviceToDevice, s));   // the fill carries over
+    tdict_rehash_kernel<<<(int)std::min<int64_t>(((int64_t)d->cap + 255) / 256, (int64_t)device_info().num_cus * 8), 256, 0, s>>>(*d, nd);
+    VNM_HIP(hipGetLastError());
+    VNM_HIP(hipStreamSynchronize(s));
+    tdict_free(d);
+    *d = nd;
+    return 0;
+}
+
+int enter_tuple_mode(vnm_agg* h, int64_t nrows, hipStream_t s) {
+    uint64_t want = h->hint > 0 ? (uint64_t)h->hint * 2 : std::max<uint64_t>((uint64_t)1 << 21, (uint64_t)h->widest_est * 2);
+    if (h->hint <= 0 && (uint64_t)nrows * 2 < want) want = (uint64_t)(nrows > 512 ? nrows : 512) * 2;
+    VNM_TRY(tdict_alloc(&h->tdict, pow2_at_least(want < 1024 ? 1024 : want), h->plan.n_keys + 1, s));
     const int kt = VNM_U64;
     h->inner = vnm_agg_create(VNM_SINGLE_NUMERICAL, 1, &kt, h->n_funcs, h->c_funcs, h->c_in_types, h->c_in_flags,
                               h->c_has_ids ? h->c_in_col_ids : nullptr);
@@ -4244,8 +4341,7 @@ int enter_tuple_mode(vnm_agg* h, hipStream_t s) {
 }
 
 void leave_tuple_mode(vnm_agg* h) {
-    if (h->tdict) vnm_agg_destroy(h->tdict);
-    h->tdict = nullptr;
+    if (h->tdict.slot) tdict_free(&h->tdict);
     pool_free(h->tnext);
     h->tnext = nullptr;
     h->tuple_mode = false;
@@ -4253,45 +4349,49 @@ void leave_tuple_mode(vnm_agg* h) {
 
 // one batch: every row's tuple -> group id (find-or-insert in the dictionary), then the ids through the single-key operator
 int tuple_next(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs, const vnm_dcol* pred, hipStream_t s) {
-    vnm_agg* d = h->tdict;
+    TDict* d = &h->tdict;
     PoolScope pool;
-    uint64_t* gid = (uint64_t*)pool.take((size_t)nrows * 8);
-    if (!gid) return 1;
-    AggArgs a{};
-    a.plan = d->plan;
-    for (int j = 0; j < h->plan.n_keys; j++) a.keys[j] = keys[j];
+    TupArgs a{};
+    a.out = (uint64_t*)pool.take((size_t)nrows * 8);
+    if (!a.out) return 1;
+    a.nk = h->plan.n_keys;
+    for (int j = 0; j < a.nk; j++) a.keys[j] = keys[j];
     if (h->pred_set) {
         a.pred = *pred;
         a.p = make_predicate(pred->type, pred->validity != nullptr, h->pred_op, h->pred_is_float, h->pred_dval, h->pred_ival);
     }
     a.nrows = nrows;
     a.ntiles = (nrows + AGG_TILE - 1) / AGG_TILE;
-    VNM_TRY(ensure_table(d, nrows, s));
-    int grid = device_info().num_cus * 4;
+    a.gnext = h->tnext;
+    int grid = device_info().num_cus * (int)env_i64("VNM_TUPLE_GRID_PER_CU", 4)   /* (more workgroups = a larger margin of free slots = a larger table: 8 per CU 11.9 ms, 4 per CU 7.8 ms per 2e8 rows at G = 1e6) */;
     if (grid > a.ntiles) grid = (int)a.ntiles;
     a.margin = (int64_t)grid * AGG_TILE;
-    unsigned int* progress = (unsigned int*)pool.take((size_t)grid * 4);
-    if (!progress) return 1;
-    VNM_HIP(hipMemsetAsync(progress, 0, (size_t)grid * 4, s));
-    a.progress = progress;
+    a.progress = (unsigned int*)pool.take((size_t)grid * 4);
+    if (!a.progress) return 1;
+    VNM_HIP(hipMemsetAsync(a.progress, 0, (size_t)grid * 4, s));
     for (int round = 0;; round++) {
-        while ((int64_t)(d->g.cap * 7 / 10) < a.margin + 1) VNM_TRY(table_grow(d, d->g.cap * 4, s));
-        VNM_HIP(hipMemsetAsync(d->g.ctl, 0, 16, s));
-        a.g = d->g;
-        a.fill_limit = (int64_t)(d->g.cap * 7 / 10);
+        while ((int64_t)(d->cap * 7 / 10) < a.margin + 1) VNM_TRY(tdict_grow(d, d->cap * 4, s));
+        VNM_HIP(hipMemsetAsync(d->ctl, 0, 16, s));   // [1] the flag; [2] fill persists
+        a.d = *d;
+        a.fill_limit = (int64_t)(d->cap * 7 / 10);
         {
             KernelTimer timer("agg_tuple_ids", s);
-            tuple_gid_kernel<<<grid, 256, 0, s>>>(a, gid, h->tnext);
+            switch (d->kwt) {
+#define VNM_TG(K) case K: tuple_gid_kernel<K><<<grid, 256, 0, s>>>(a); break;
+                VNM_TG(3) VNM_TG(4) VNM_TG(5) VNM_TG(6) VNM_TG(7) VNM_TG(8) VNM_TG(9)
+#undef VNM_TG
+                default: return set_error("aggregate: tuple dictionary over %d key columns (internal error)", d->kwt - 1);
+            }
         }
         VNM_HIP(hipGetLastError());
         unsigned long long ctl[4];
-        VNM_HIP(hipMemcpyAsync(ctl, d->g.ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipMemcpyAsync(ctl, d->ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
         VNM_HIP(hipStreamSynchronize(s));
         if (!ctl[1]) break;   // no workgroup ran out of room
-        VNM_TRY(table_grow(d, d->g.cap * (round >= 1 ? 16 : 4), s));   // blocks resume from progress[]
+        VNM_TRY(tdict_grow(d, d->cap * (round >= 1 ? 16 : 4), s));   // the workgroups resume from progress[]
     }
     vnm_dcol gk{};
-    gk.values = gid; gk.type = VNM_U64; gk.length = nrows;
+    gk.values = a.out; gk.type = VNM_U64; gk.length = nrows;
     int rc = vnm_agg_set_predicate(h->inner, h->pred_set ? 1 : 0, h->pred_op, h->pred_is_float, h->pred_dval, h->pred_ival);
     if (!rc) rc = vnm_agg_next_device(h->inner, nrows, &gk, inputs, pred, (void*)s);
     if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = set_error("aggregate: tuple-dictionary batch failed");
@@ -4310,7 +4410,7 @@ int inner_keys(vnm_agg* h, const vnm_agg* in, int64_t n, uint64_t* keys, int64_t
     unsigned long long ngid = 0;
     VNM_HIP(hipMemcpyAsync(&ngid, h->tnext, 8, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
-    const GTable& g = h->tdict->g;
+    const TDict& g = h->tdict;
     PoolScope pool;
     uint64_t* by_gid = (uint64_t*)pool.take((size_t)g.kwt * (size_t)(ngid ? ngid : 1) * 8);
     if (!by_gid) return 1;
@@ -4614,7 +4714,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
             else if (!h->single && !h->have_run && !h->pending && getenv("VNM_AGG_NO_TUPLE") == nullptr) {
                 // too wide for one word even as per-column dictionary codes: tuple -> group id through a dictionary
                 // (before: agg_wide_kernel, one HBM atomic per row and accumulator word)
-                VNM_TRY(enter_tuple_mode(h, s));
+                VNM_TRY(enter_tuple_mode(h, nrows, s));
             }
         }
         if (h->tuple_mode) return tuple_next(h, nrows, keys, inputs, pred, s);
