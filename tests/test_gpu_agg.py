@@ -921,8 +921,10 @@ def test_multi_key_dictionary_coded_fields(scenario):
     for pred in (None, ("v", ">", 64.0)):
         L.lib().vnm_set_profiling(1)
         got = gpu_aggregate(O.MULTI, names, names, funcs, batches, predicate=pred)
-        packs, demotes = launches(b"agg_pack_keys"), launches(b"agg_demote")
+        packs, demotes, ids = launches(b"agg_pack_keys"), launches(b"agg_demote"), launches(b"agg_tuple_ids")
         L.lib().vnm_set_profiling(0)
+        # what does not (or no longer) pack goes on through the tuple dictionary, not through the wide-key table's per-row atomics
+        assert (ids >= 1) == (scenario == "six_wide_no_fit" or expect_demote), (ids, scenario)
         if scenario == "six_wide_no_fit":
             assert packs == 0 and demotes == 0, (packs, demotes)
         else:

@@ -144,8 +144,16 @@ def test_filter_launch_schemes(scheme, monkeypatch):
     x = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
     y = rng.integers(-2**40, 2**40, n).astype(np.int64)
     cx, cy = DeviceColumn.from_numpy(x), DeviceColumn.from_numpy(y)
+    import ctypes
+    from vinum_amd import _lib as L
+    L.lib().vnm_set_profiling(1)
     for thr in [1.28, 64.0, 126.7]:
         outs, k = ops.filter_cmp(cx, ">", thr, [cx, cy])
         keep = x > thr
         assert k == int(keep.sum())
         assert np.array_equal(outs[0].to_numpy(), x[keep]) and np.array_equal(outs[1].to_numpy(), y[keep])
+    ms, retries = ctypes.c_double(0), ctypes.c_int64(0)
+    L.lib().vnm_profile_query(b"filter_retry", ctypes.byref(ms), ctypes.byref(retries))
+    L.lib().vnm_set_profiling(0)
+    # the retry counter: every filter repeated when the look-backs give up at once, none otherwise
+    assert retries.value == (3 if scheme == "flat_gives_up" else 0), retries.value

@@ -278,6 +278,28 @@ def test_small_batches_are_coalesced_and_large_ones_are_not():
         util.assert_batches_equal(got, whole, key_names=["k"], what="coalesced vs one batch")
 
 
+def test_a_later_batch_with_another_schema_raises_from_its_own_next():
+    """Small batches wait in the wrapper and cross the boundary joined -- but only batches that cannot raise: a batch whose
+    schema differs from the first batch's goes through in the call that brought it, so what the library raises (a key column
+    that changed its type, a missing column) comes from the offending next(), as in the reference, not from result()."""
+    from vinum_amd import vinum_lib as V
+    defs = [V.AggFuncDef(V.AggFuncType.SUM, "v", "s"), V.AggFuncDef(V.AggFuncType.COUNT_STAR, "", "n")]
+    good = pa.RecordBatch.from_arrays([pa.array([1, 2, 2], pa.int64()), pa.array([1.0, 2.0, 3.0])], names=["k", "v"])
+    other_type = pa.RecordBatch.from_arrays([pa.array([1.0, 2.0]), pa.array([1.0, 2.0])], names=["k", "v"])
+    missing = pa.RecordBatch.from_arrays([pa.array([1, 2], pa.int64())], names=["k"])
+    for bad in (other_type, missing):
+        for cls in (V.SingleNumericalHashAggregate, V.MultiNumericalHashAggregate, V.GenericHashAggregate):
+            op = cls(["k"], ["k"], defs)
+            op.next(good)
+            op.next(good)                      # (small: waits in the wrapper)
+            with pytest.raises(Exception):
+                op.next(bad)
+    op = V.SingleNumericalHashAggregate(["k"], ["k"], defs)    # same schema throughout: nothing raises, small batches are joined
+    for _ in range(5):
+        op.next(good)
+    assert sorted(op.result().to_pylist(), key=lambda r: r["k"]) == [{"k": 1, "s": 5.0, "n": 5}, {"k": 2, "s": 25.0, "n": 10}]
+
+
 @pytest.mark.parametrize("seed", list(range(12)))
 def test_generic_keys_and_string_min_max_vs_oracle(seed):
     """f3 against the oracle's restatement of GenericHashAggregate / StringMinMaxFunc (generic_hash_aggregate.h:10-45,

@@ -1047,6 +1047,25 @@ __global__ void tdict_rehash_kernel(TDict from, TDict to) {
     }
 }
 
+// tuples given as key-word arrays (the finished groups of an operator that leaves its packed form): insert, hand back the ids
+template <int KWT>
+__global__ __launch_bounds__(256) void tuple_words_kernel(TDict d, const uint64_t* __restrict__ words /* [KWT][n] */, int64_t n, int64_t per_block,
+                                                          uint64_t* __restrict__ out, unsigned long long* gnext) {
+    __shared__ unsigned s_new;
+    __shared__ unsigned long long s_gnext;
+    const int64_t lo = (int64_t)blockIdx.x * per_block, hi = lo + per_block < n ? lo + per_block : n;
+    if (threadIdx.x == 0) { s_new = 0; s_gnext = lo < hi ? atomicAdd(gnext, (unsigned long long)(hi - lo)) : 0ULL; }
+    __syncthreads();
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        uint64_t kw[KWT];
+#pragma unroll
+        for (int j = 0; j < KWT; j++) kw[j] = words[(int64_t)j * n + i];
+        out[i] = tdict_find<KWT>(d, kw, wide_tag(kw, KWT), &s_new, &s_gnext);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_new) atomicAdd(&d.ctl[2], (unsigned long long)s_new);
+}
+
 // the dictionary's tuples laid out by group id: by_gid [kwt][ngid]
 __global__ void tuple_sweep_kernel(TDict d, uint64_t* __restrict__ by_gid, int64_t ngid) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -4422,6 +4441,59 @@ int inner_keys(vnm_agg* h, const vnm_agg* in, int64_t n, uint64_t* keys, int64_t
     return 0;
 }
 
+// A later batch does not fit the packing (a key outside the packed ranges, a per-column dictionary that is full): the operator
+// moves to the tuple dictionary -- the finished groups' tuples are inserted there and their partial state is re-keyed by id --
+// instead of to the wide-key table and its per-row atomics for the rest of the stream.
+int packed_to_tuple(vnm_agg* h, int64_t nrows, hipStream_t s) {
+    vnm_agg* in = h->inner;
+    int64_t n = 0;
+    VNM_TRY(vnm_agg_finish(in, &n, (void*)s));
+    h->inner = nullptr;   // (enter_tuple_mode makes the new one)
+    const int kw = h->plan.kw;
+    PoolScope pool;
+    uint64_t* words = nullptr;
+    int rc = 0;
+    if (n > 0) {
+        words = (uint64_t*)pool.take((size_t)kw * n * 8);
+        if (!words) rc = 1;
+        if (!rc) {
+            KernelTimer timer("agg_demote", s);
+            key_unpack_kernel<<<(int)std::min<int64_t>((n + 255) / 256, (int64_t)device_info().num_cus * 8), 256, 0, s>>>(h->pack, in->dkey, n, words, n);
+        }
+        if (!rc && (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = set_error("aggregate: unpacking the groups failed");
+    }
+    free_pack_tables(h);   // the unpack above was their last reader
+    h->widest_est = std::max<int64_t>(h->widest_est, n);
+    if (!rc) rc = enter_tuple_mode(h, std::max<int64_t>(nrows, n), s);
+    if (!rc && n > 0) {
+        TDict* d = &h->tdict;
+        while (!rc && (int64_t)(d->cap * 7 / 10) < n + 1) rc = tdict_grow(d, d->cap * 4, s);
+        uint64_t* gid = (uint64_t*)pool.take((size_t)n * 16);   // ids, then the (all-zero) null-mask word of the single id key
+        if (!rc && !gid) rc = 1;
+        if (!rc && hipMemsetAsync(gid + n, 0, (size_t)n * 8, s) != hipSuccess) rc = set_error("aggregate: memset failed");
+        if (!rc) {
+            const int grid = (int)std::min<int64_t>((n + 2047) / 2048, (int64_t)device_info().num_cus * 8);
+            const int64_t per_block = (n + grid - 1) / grid;
+            KernelTimer timer("agg_tuple_ids", s);
+            switch (d->kwt) {
+#define VNM_TW(K) case K: tuple_words_kernel<K><<<grid, 256, 0, s>>>(*d, words, n, per_block, gid, h->tnext); break;
+                VNM_TW(3) VNM_TW(4) VNM_TW(5) VNM_TW(6) VNM_TW(7) VNM_TW(8) VNM_TW(9)
+#undef VNM_TW
+                default: rc = set_error("aggregate: tuple dictionary over %d key columns (internal error)", d->kwt - 1);
+            }
+        }
+        if (!rc) {
+            uint64_t* kp[2] = {gid, gid + n};
+            uint64_t* ap[AGG_MAX_WORDS];
+            for (int w = 0; w < h->plan.n_words; w++) ap[w] = in->dacc + (size_t)w * in->dstride;
+            rc = vnm_agg_merge_device(h->inner, n, kp, ap, (void*)s);
+        }
+        if (!rc && (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = set_error("aggregate: moving the groups to the tuple dictionary failed");
+    }
+    vnm_agg_destroy(in);
+    return rc;
+}
+
 // leave packed mode: the groups aggregated so far are unpacked and merged into h's own (wide-key) table
 int demote_packed(vnm_agg* h, hipStream_t s) {
     vnm_agg* in = h->inner;
@@ -4745,7 +4817,11 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
                 return rc;
             }
             pool_free(packed);
-            VNM_TRY(demote_packed(h, s));  // keys outside the packed ranges: continue with the wide-key table
+            if (!h->single && getenv("VNM_AGG_NO_TUPLE") == nullptr) {   // keys outside the packed ranges: on through the tuple dictionary
+                VNM_TRY(packed_to_tuple(h, nrows, s));
+                return tuple_next(h, nrows, keys, inputs, pred, s);
+            }
+            VNM_TRY(demote_packed(h, s));  // (a packed SINGLE key: its own general path; or the dictionary switched off: the wide-key table)
         }
     }
 
@@ -4927,6 +5003,12 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
                             getenv("VNM_AGG_NO_DENSE") == nullptr;
     bool dense_shape = dense_base && (!h->rank_aligned || h->range_given);   // rank-aligned: only with a code range all ranks agreed on
     bool dense_go = false;
+    // a stream that went dense on the sample's lower bound (no group count exists) and now brings a batch too short for the
+    // code range: this batch and the rest need a number after all (without one they took the LDS scan and its flush storms)
+    if (h->dense_by_bound && h->hint == 0 && !(dense_shape && h->dense_state == 1 && h->dense_span <= 4 * nrows)) {
+        h->estimated = false;
+        h->dense_by_bound = false;
+    }
     if (part_ok && h->hint == 0 && !h->estimated && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
         getenv("VNM_AGG_NO_ESTIMATE") == nullptr) {
         int64_t est = 0, dense_lb = 0;
@@ -5435,7 +5517,8 @@ int vnm_agg_run_reorder(vnm_agg* h, int world, uint64_t* out_rows, uint32_t* out
     a.dir = h->run_dir;
     a.out = out_rows;
     a.part_counts = out_part_counts;
-    a.prefix = (unsigned long long*)pool_alloc((size_t)(a.nfin + 1) * 8);
+    PoolScope pool;   // (every way out frees the prefix)
+    a.prefix = (unsigned long long*)pool.take((size_t)(a.nfin + 1) * 8);
     if (!a.prefix) return 1;
     run_prefix_kernel<<<1, 1024, 0, s>>>(a);
     run_reorder_kernel<<<(int)std::min<int64_t>(a.nfin, (int64_t)device_info().num_cus * 8), 256, 0, s>>>(a);
@@ -5448,7 +5531,6 @@ int vnm_agg_run_reorder(vnm_agg* h, int world, uint64_t* out_rows, uint32_t* out
     }
     VNM_HIP(hipStreamSynchronize(s));
     for (int o = 0; o < world; o++) owner_counts_host[o] = (int64_t)(bounds[o + 1] - bounds[o]);
-    pool_free(a.prefix);
     return 0;
 }
 
@@ -5478,11 +5560,12 @@ int vnm_agg_merge_partitioned(vnm_agg* h, int world, int64_t nlocal, const uint6
         if ((int64_t)run != src_row_offsets_host[r + 1]) return set_error("vnm_agg_merge_partitioned: partition counts of source %d do not add up", r);
         total = (int64_t)run;
     }
-    unsigned long long* dpre = (unsigned long long*)pool_alloc(pre.size() * 8);
-    unsigned long long* flags = (unsigned long long*)pool_alloc(64);
+    PoolScope pool;   // every way out frees the four blocks; the run's two are handed to the handle (keep) on success
+    unsigned long long* dpre = (unsigned long long*)pool.take(pre.size() * 8);
+    unsigned long long* flags = (unsigned long long*)pool.take(64);
     const int64_t dstride = total + 2;
-    uint64_t* rk = (uint64_t*)pool_alloc((size_t)dstride * 16);
-    uint64_t* ra = (uint64_t*)pool_alloc((size_t)dstride * 8 * h->plan.n_words);
+    uint64_t* rk = (uint64_t*)pool.take((size_t)dstride * 16);
+    uint64_t* ra = (uint64_t*)pool.take((size_t)dstride * 8 * h->plan.n_words);
     if (!dpre || !flags || !rk || !ra) return 1;
     VNM_HIP(hipMemcpyAsync(dpre, pre.data(), pre.size() * 8, hipMemcpyHostToDevice, s));
     VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
@@ -5501,12 +5584,11 @@ int vnm_agg_merge_partitioned(vnm_agg* h, int world, int64_t nlocal, const uint6
     unsigned long long fl[2];
     VNM_HIP(hipMemcpyAsync(fl, flags, 16, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
-    pool_free(dpre); pool_free(flags);
     if (fl[0]) {
-        pool_free(rk); pool_free(ra);
         set_error("vnm_agg_merge_partitioned: a partition holds more groups than the LDS table (use vnm_agg_merge_rows)");
         return 2;  // capacity, not an error of the data: the handle is still empty and the caller falls back
     }
+    pool.keep(rk); pool.keep(ra);
     h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
     h->have_run = true;
     return 0;

@@ -322,6 +322,15 @@ int vnm_csv_parse_block(const char* host_text, int64_t nbytes, int skip_header, 
     if (first >= nbytes) return 0;
     vnm_dcol text{};
     VNM_TRY(vnm_stage_column(host_text, nullptr, 0, nbytes, VNM_U8, &text, stream));   // the text crosses PCIe once
+    // every way out frees the staged text, the scratch blocks and -- unless the block is handed over -- the output columns
+    struct Cleanup {
+        vnm_dcol* text; vnm_dcol* out; int n; bool keep_out = false;
+        ~Cleanup() {
+            vnm_free_column(text);
+            if (!keep_out) for (int c = 0; c < n; c++) { vnm_free_column(&out[c]); memset(&out[c], 0, sizeof(vnm_dcol)); }
+        }
+    } cleanup{&text, out_cols, n_cols};
+    PoolScope pool;
     CsvArgs a{};
     a.text = (const uint8_t*)text.values;
     a.nbytes = nbytes;
@@ -331,11 +340,10 @@ int vnm_csv_parse_block(const char* host_text, int64_t nbytes, int skip_header, 
     a.n_fields = n_fields;
     a.n_cols = n_cols;
     for (int c = 0; c < n_cols; c++) { a.field_of[c] = field_idx[c]; a.type_of[c] = types[c]; }
-    a.slab_counts = (uint32_t*)pool_alloc((size_t)(a.nslabs + 1) * 4);
-    a.flags = (unsigned long long*)pool_alloc(256);
+    a.slab_counts = (uint32_t*)pool.take((size_t)(a.nslabs + 1) * 4);
+    a.flags = (unsigned long long*)pool.take(256);
     if (!a.slab_counts || !a.flags) return 1;
     VNM_HIP(hipMemsetAsync(a.flags, 0, 256, s));
-    int rc = 0;
     {
         KernelTimer timer("csv_tokenize", s);
         csv_count_kernel<<<(int)a.nslabs, 256, 0, s>>>(a);
@@ -346,49 +354,39 @@ int vnm_csv_parse_block(const char* host_text, int64_t nbytes, int skip_header, 
     VNM_HIP(hipStreamSynchronize(s));
     a.nrows = (int64_t)total;
     *n_rows = a.nrows;
-    uint8_t* valid_bytes[CSV_MAX_COLS] = {};
     if (a.nrows > 0) {
-        a.row_start = (int64_t*)pool_alloc((size_t)(a.nrows + 1) * 8);
-        if (!a.row_start) rc = 1;
-        for (int c = 0; !rc && c < n_cols; c++) {
-            a.out_values[c] = pool_alloc((size_t)a.nrows * 8);
-            valid_bytes[c] = (uint8_t*)pool_alloc((size_t)a.nrows);
-            a.out_valid[c] = valid_bytes[c];
-            if (!a.out_values[c] || !valid_bytes[c]) rc = 1;
+        a.row_start = (int64_t*)pool.take((size_t)(a.nrows + 1) * 8);
+        if (!a.row_start) return 1;
+        for (int c = 0; c < n_cols; c++) {
+            out_cols[c].values = a.out_values[c] = pool_alloc((size_t)a.nrows * 8);      // (owned by out_cols from here: Cleanup)
+            a.out_valid[c] = (uint8_t*)pool.take((size_t)a.nrows);
+            if (!a.out_values[c] || !a.out_valid[c]) return 1;
         }
-        if (!rc) {
+        {
             KernelTimer timer("csv_parse", s);
             csv_offsets_kernel<<<(int)a.nslabs, 256, 0, s>>>(a);
             const int grid = (int)std::min<int64_t>((a.nrows + 255) / 256, (int64_t)device_info().num_cus * 16);
             csv_parse_kernel<<<grid, 256, 0, s>>>(a);
         }
-        if (!rc && hipGetLastError() != hipSuccess) rc = set_error("vnm_csv_parse_block: kernel launch failed");
+        if (hipGetLastError() != hipSuccess) return set_error("vnm_csv_parse_block: kernel launch failed");
         // Arrow validity bitmaps
-        for (int c = 0; !rc && c < n_cols; c++) {
+        for (int c = 0; c < n_cols; c++) {
             uint8_t* bm = (uint8_t*)pool_alloc((size_t)((a.nrows + 63) / 64) * 8);
-            if (!bm) { rc = 1; break; }
-            rc = vnm_pack_validity(valid_bytes[c], a.nrows, bm, stream);
-            out_cols[c].values = a.out_values[c];
+            if (!bm) return 1;
             out_cols[c].validity = bm;
             out_cols[c].length = a.nrows;
             out_cols[c].type = types[c];
+            VNM_TRY(vnm_pack_validity(a.out_valid[c], a.nrows, bm, stream));
         }
     }
     unsigned long long fl[21] = {};
-    if (!rc) {
-        VNM_HIP(hipMemcpyAsync(fl, a.flags, sizeof(fl), hipMemcpyDeviceToHost, s));
-        VNM_HIP(hipStreamSynchronize(s));
-        for (int c = 0; c < n_cols; c++) fallback[c] = fl[1 + c] != 0;
-        fallback[n_cols] = fl[0] != 0;        // a quote character: the whole block needs the host reader
-        fallback[n_cols + 1] = fl[20] != 0;   // a row with a different number of fields
-    }
-    for (int c = 0; c < n_cols; c++) pool_free(valid_bytes[c]);
-    pool_free(a.row_start);
-    pool_free(a.slab_counts);
-    pool_free(a.flags);
-    vnm_free_column(&text);
-    if (rc) for (int c = 0; c < n_cols; c++) vnm_free_column(&out_cols[c]);
-    return rc;
+    VNM_HIP(hipMemcpyAsync(fl, a.flags, sizeof(fl), hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    for (int c = 0; c < n_cols; c++) fallback[c] = fl[1 + c] != 0;
+    fallback[n_cols] = fl[0] != 0;        // a quote character: the whole block needs the host reader
+    fallback[n_cols + 1] = fl[20] != 0;   // a row with a different number of fields
+    cleanup.keep_out = true;
+    return 0;
 }
 
 }  // extern "C"

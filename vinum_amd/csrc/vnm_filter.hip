@@ -419,7 +419,9 @@ static int launch_filter(FilterArgs& a, int mode, int64_t* out_count, hipStream_
         };
 #define VNM_FL(...) launch(filter_tile_kernel<__VA_ARGS__>, filter_tile_flat_kernel<__VA_ARGS__>,
         {
-            KernelTimer timer("filter_kernel", s);
+            // (the repeat after a look-back that gave up is a span of its own: `vnm_profile_query("filter_retry")` counts how often
+            //  a filter paid twice -- the first attempt's output positions were garbage and are overwritten here)
+            KernelTimer timer(persist && env_int("VNM_FILTER_PERSIST", 0) == 0 ? "filter_retry" : "filter_kernel", s);
             int rc;
             if (hot) {
                 if (fb == 1024 && (a.debug & 8)) rc = VNM_FL(CMP_F64, 1024, 4, true, true, false) 1024);

@@ -281,15 +281,16 @@ class _HashAggregateBase:
             # the FIRST batch goes straight through: it fixes the schema, and an unknown column or an unsupported type must raise
             # from this call as it does in the reference (base_aggregate.cpp:91-131)
             self._pending, self._pending_rows = [], 0
+            self._schema0 = batch.schema
             self._first_batch(batch)
             self._send(batch)
             return
-        if batch.num_rows >= self._SMALL_ROWS:
+        # a batch that can raise (any schema other than the first batch's) or that is large crosses the boundary in THIS call:
+        # what the reference raises from the offending Next() must not surface from a later next() or from result()
+        if batch.num_rows >= self._SMALL_ROWS or batch.schema != self._schema0:
             self._flush()
             self._send(batch)
             return
-        if self._pending and batch.schema != self._pending[0].schema:
-            self._flush()
         self._pending.append(batch)
         self._pending_rows += batch.num_rows
         if self._pending_rows >= self._FLUSH_ROWS:
@@ -418,14 +419,13 @@ class GenericHashAggregate:
         if self._inner is None:
             self._init(batch)
             self._pending, self._pending_rows = [], 0
+            self._schema0 = batch.schema
             self._encode_and_send(batch)
             return
-        if batch.num_rows >= (1 << 20):
+        if batch.num_rows >= (1 << 20) or batch.schema != self._schema0:   # (a schema change raises from this call, as in the reference)
             self._flush()
             self._encode_and_send(batch)
             return
-        if self._pending and batch.schema != self._pending[0].schema:
-            self._flush()
         self._pending.append(batch)
         self._pending_rows += batch.num_rows
         if self._pending_rows >= (1 << 22):
