@@ -344,6 +344,31 @@ int vnm_stage_column(const void* host_values, const uint8_t* host_validity, int6
                      int32_t type, vnm_dcol* out, void* stream);
 int vnm_free_column(vnm_dcol* col);
 
+/* ---- string dictionary: non-numeric GROUP BY keys -----------------------------------------------------------------------
+ * replaces the scalar-vector keyed map of GenericHashAggregate (vinum_cpp/src/operators/aggregate/generic_hash_aggregate.h:10-45:
+ * one hash + Equals of arrow::Scalar vectors per row) for utf8 / binary key columns: every row's value -> a running int32
+ * dictionary code (equal bytes <=> equal code, across all batches given to one handle); the codes then are an ordinary
+ * numeric key column of the aggregate operators.  NULL rows get code -1.  Codes are NOT dense (ids are handed out in chunks;
+ * vnm_strdict_ids = their upper bound).
+ * vnm_strdict_encode: one Arrow utf8 / large_utf8 / binary array as HOST buffers (offsets int32 or int64, data, validity bitmap
+ * or NULL, logical offset / length); offsets + bytes cross PCIe once, the codes come back to out_codes_host (length int32s).
+ * *n_new / *new_bytes: the values this call added to the dictionary; vnm_strdict_fetch_new copies their (id, length) pairs and
+ * concatenated bytes (in that order) to host buffers of n_new / n_new / new_bytes entries -- the caller's copy of the
+ * dictionary is the concatenation of these (how vinum_amd/vinum_lib.py decodes the result's key column).
+ * vnm_strdict_encode_device: the same over DEVICE buffers (offsets->values / ->type (VNM_I32 | VNM_I64) / ->offset /
+ * ->length = rows + 1; validity bitmap + bit offset or NULL; data = byte data_base of the Arrow data buffer). */
+typedef struct vnm_strdict vnm_strdict;
+vnm_strdict* vnm_strdict_create(void);
+void vnm_strdict_destroy(vnm_strdict* h);
+int64_t vnm_strdict_ids(vnm_strdict* h);
+int vnm_strdict_encode(vnm_strdict* h, const void* offsets_host, int offsets_are_64, const uint8_t* data_host,
+                       const uint8_t* validity_host, int64_t offset, int64_t length, int32_t* out_codes_host,
+                       int64_t* n_new, int64_t* new_bytes, void* stream);
+int vnm_strdict_encode_device(vnm_strdict* h, const vnm_dcol* offsets, const uint8_t* validity, int64_t validity_offset,
+                              const uint8_t* data, int64_t data_base, int32_t* out_codes, int64_t* n_new, int64_t* new_bytes,
+                              void* stream);
+int vnm_strdict_fetch_new(vnm_strdict* h, int32_t* ids_host, int32_t* lens_host, uint8_t* bytes_host);
+
 /* ---- CSV ingest ---------------------------------------------------------------------------------------
  * replaces, for numeric columns, the pyarrow.csv reader behind stream_csv() / read_csv() (vinum/io/arrow.py:58-61,106;
  * FileReaderOperator vinum/core/algebra.py:268-279): one block of CSV text (must end with '\n'; < 2 GiB) is staged once

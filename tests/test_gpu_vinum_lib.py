@@ -278,6 +278,58 @@ def test_small_batches_are_coalesced_and_large_ones_are_not():
         util.assert_batches_equal(got, whole, key_names=["k"], what="coalesced vs one batch")
 
 
+@pytest.mark.parametrize("case", ["cities", "high_cardinality", "large_string", "binary", "lengths_and_unicode", "all_null_and_empty"])
+def test_string_dictionary_on_the_device(case):
+    """KeyDictionary over utf8 / binary columns runs on the device (vnm_strdict_encode): across several batches, equal values
+    <=> equal codes, NULL stays NULL, and decode(codes) gives the values back -- sliced arrays (an Arrow offset that is not a
+    multiple of 8), empty strings, values longer than any hash step, two values that differ in their last byte only,
+    multi-byte UTF-8, 1.5e6 distinct values (the table grows inside a batch), int64 offsets, binary."""
+    from vinum_amd import vinum_lib as V
+    rng = np.random.default_rng(len(case))
+    typ = {"large_string": pa.large_string(), "binary": pa.binary()}.get(case, pa.string())
+    if case == "cities":
+        pool = [f"city_{i:05d}" for i in range(3000)] + ["", "a", "ab", "abcdefgh", "abcdefghi", "abcdefgh" * 20, "abcdefgh" * 20 + "x", "abcdefgh" * 20 + "y"]
+        n = 400_000
+    elif case == "high_cardinality":
+        pool = [f"k{i:x}_{(i * 2654435761) % 1000003}" for i in range(1_500_000)]
+        n = 3_000_000
+    elif case == "lengths_and_unicode":
+        pool = ["", "é", "éé", "日本語", "日本語の文字列", "ß" * 31, "ß" * 32, "x" * 7, "x" * 8, "x" * 9, "x" * 15, "x" * 16, "x" * 17, "x" * 1000, "x" * 999 + "y"]
+        n = 50_000
+    elif case == "all_null_and_empty":
+        pool = [""]
+        n = 10_000
+    else:
+        pool = [f"v{i}" * (1 + i % 5) for i in range(20_000)]
+        n = 300_000
+    vals = pa.array(pool, type=pa.string()).cast(typ) if case != "binary" else pa.array([p.encode() for p in pool], type=pa.binary())
+    idx = rng.integers(0, len(pool), n)
+    mask = rng.random(n) < (1.0 if case == "all_null_and_empty" else 0.03)
+    if case == "all_null_and_empty":
+        mask[::3] = False
+    col = vals.take(pa.array(idx, mask=mask))
+    d = V.KeyDictionary(typ)
+    cuts = [0, 13, n // 3 + 5, n // 3 + 5, 2 * n // 3 + 1, n]      # unaligned Arrow offsets, an empty batch
+    code_of = {}
+    for a, b in zip(cuts, cuts[1:]):
+        part = col.slice(a, b - a)
+        codes = d.encode(part)
+        assert codes.type == pa.int32() and len(codes) == len(part)
+        assert codes.null_count == part.null_count
+        assert np.array_equal(codes.is_valid().to_numpy(zero_copy_only=False), part.is_valid().to_numpy(zero_copy_only=False))
+        back = d.decode(codes)
+        assert back.equals(part), f"{case}: decode(encode(x)) != x in rows {a}..{b}"
+        # one code per value, the same in every batch
+        ci = codes.to_numpy(zero_copy_only=False)
+        ii = idx[a:b]
+        ok = ~mask[a:b]
+        for v, c in zip(ii[ok][:20000].tolist(), ci[ok][:20000].tolist()):
+            assert code_of.setdefault(v, c) == c
+    seen = {}
+    for v, c in code_of.items():
+        assert seen.setdefault(c, v) == v, "two values share a code"
+
+
 def test_a_later_batch_with_another_schema_raises_from_its_own_next():
     """Small batches wait in the wrapper and cross the boundary joined -- but only batches that cannot raise: a batch whose
     schema differs from the first batch's goes through in the call that brought it, so what the library raises (a key column
