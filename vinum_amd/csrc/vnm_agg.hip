@@ -928,21 +928,36 @@ struct TupArgs {
     unsigned long long* gnext;
 };
 
+// the line of one slot, all loads issued together
 template <int KWT>
-__device__ __forceinline__ uint64_t tdict_find(const TDict& d, const uint64_t* kw, uint64_t tagv, unsigned* newc, unsigned long long* s_gnext) {
+struct TLine { uint64_t t, g, k[KWT]; };
+template <int KWT>
+__device__ __forceinline__ void tdict_load(const TDict& d, uint64_t h, TLine<KWT>& l) {
+    const uint64_t* base = d.slot + h * (uint64_t)d.sw;
+    l.t = ld_agent(base);
+    l.g = ld_agent(base + 1);
+#pragma unroll
+    for (int i = 0; i < KWT; i++) l.k[i] = ld_agent(base + 2 + i);
+}
+
+// `first`: the line of the tuple's home slot, loaded by the caller ahead of time (two rows of a lane are in flight together)
+template <int KWT>
+__device__ __forceinline__ uint64_t tdict_find(const TDict& d, const uint64_t* kw, uint64_t tagv, unsigned* newc, unsigned long long* s_gnext,
+                                               const TLine<KWT>* first = nullptr) {
     const uint64_t mask = d.cap - 1;
     uint64_t h = (tagv ^ (tagv >> 29)) & mask;
+    bool pre = first != nullptr;
     for (;;) {
         uint64_t* const base = d.slot + h * (uint64_t)d.sw;
-        const uint64_t t = ld_agent(base);
-        uint64_t g = ld_agent(base + 1);
-        uint64_t k[KWT];
-#pragma unroll
-        for (int i = 0; i < KWT; i++) k[i] = ld_agent(base + 2 + i);
+        TLine<KWT> l;
+        if (pre) l = *first; else tdict_load<KWT>(d, h, l);
+        pre = false;
+        const uint64_t t = l.t;
+        uint64_t g = l.g;
         if (t == tagv) {
             bool eq = true;
 #pragma unroll
-            for (int i = 0; i < KWT; i++) eq = eq & (k[i] == kw[i]);
+            for (int i = 0; i < KWT; i++) eq = eq & (l.k[i] == kw[i]);
             if (!eq) {       // another tuple with this tag -- or this line's words were read before the tag's owner wrote them
                 eq = true;
 #pragma unroll
@@ -1002,20 +1017,35 @@ __global__ __launch_bounds__(256) void tuple_gid_kernel(TupArgs a) {
         }
         __syncthreads();
         if (!s_tile) break;
-        for (int r = 0; r < AGG_TILE / 256; r++) {
-            const int64_t row = tile * AGG_TILE + (int64_t)r * 256 + tid;
-            if (row >= a.nrows) continue;
-            if (a.p.enabled && !pred_eval(a.p, a.pred, row)) { a.out[row] = 0; continue; }   // (the operator behind drops the row itself)
-            uint64_t kw[KWT];
-            uint64_t nullmask = 0;
+        // two rows of a lane at a time: both home lines are requested before either is looked at (a probe is one dependent
+        // round trip to L2 / MALL / HBM; one row at a time left the lane idle for all of it)
+        for (int r = 0; r < AGG_TILE / 256; r += 2) {
+            uint64_t kw[2][KWT], tagv[2];
+            TLine<KWT> line[2];
+            bool live[2];
 #pragma unroll
-            for (int j = 0; j < NK; j++) {
-                const bool ok = col_valid(a.keys[j], row);
-                kw[j] = ok ? col_key_bits(a.keys[j], row) : 0;
-                if (!ok) nullmask |= 1ULL << j;
+            for (int e = 0; e < 2; e++) {
+                const int64_t row = tile * AGG_TILE + (int64_t)(r + e) * 256 + tid;
+                live[e] = row < a.nrows;
+                if (live[e] && a.p.enabled && !pred_eval(a.p, a.pred, row)) { a.out[row] = 0; live[e] = false; }   // (the operator behind drops the row itself)
+                if (!live[e]) continue;
+                uint64_t nullmask = 0;
+#pragma unroll
+                for (int j = 0; j < NK; j++) {
+                    const bool ok = col_valid(a.keys[j], row);
+                    kw[e][j] = ok ? col_key_bits(a.keys[j], row) : 0;
+                    if (!ok) nullmask |= 1ULL << j;
+                }
+                kw[e][NK] = nullmask;
+                tagv[e] = wide_tag(kw[e], KWT);
+                tdict_load<KWT>(a.d, (tagv[e] ^ (tagv[e] >> 29)) & (a.d.cap - 1), line[e]);
             }
-            kw[NK] = nullmask;
-            a.out[row] = tdict_find<KWT>(a.d, kw, wide_tag(kw, KWT), &s_new, &s_gnext);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                if (!live[e]) continue;
+                const int64_t row = tile * AGG_TILE + (int64_t)(r + e) * 256 + tid;
+                a.out[row] = tdict_find<KWT>(a.d, kw[e], tagv[e], &s_new, &s_gnext, &line[e]);
+            }
         }
     }
     __syncthreads();
