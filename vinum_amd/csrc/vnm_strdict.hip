@@ -21,7 +21,6 @@
 #include "vnm_common.hpp"
 
 namespace vnm {
-namespace {
 
 constexpr uint64_t SD_EMPTY = ~0ULL, SD_LOCKED = ~0ULL - 1, SD_NEW = 1ULL << 63;
 constexpr int SD_TILE = 2048;      // rows per workgroup and room check
@@ -299,7 +298,6 @@ int sdict_grow(SDict* d, uint64_t new_cap, hipStream_t s) {
     return 0;
 }
 
-}  // namespace
 }  // namespace vnm
 
 using namespace vnm;
