@@ -1397,33 +1397,57 @@ struct CompactArgs {
     int64_t dstride;
 };
 
+// One reservation per workgroup and 4096 slots (16 rounds x 4 waves: their 64 counts are scanned by one wave).  One per wave
+// and round was an atomic on ONE address per 64 slots: a 2^26-slot table = 1e6 of them, 9.5 ms for 2e7 groups.
+constexpr int CP_ROUNDS = 16;
 __global__ __launch_bounds__(256) void agg_compact_kernel(CompactArgs c) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    __shared__ unsigned int s_cnt[CP_ROUNDS * 4];
+    __shared__ unsigned long long s_base;
     const bool single = c.g.kwt == 0;
-    const int lane = threadIdx.x & 63;
-    const int64_t n_iter = ((int64_t)c.g.cap + stride - 1) / stride;
-    for (int64_t it = 0; it < n_iter; it++) {
-        int64_t i = it * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        bool occ = false;
-        if (i < (int64_t)c.g.cap) {
-            uint64_t t = c.g.tag[i];
-            occ = (t != EMPTY && (single || t != LOCKED));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t chunk = (int64_t)CP_ROUNDS * 256;
+    const int64_t nchunks = ((int64_t)c.g.cap + chunk - 1) / chunk;
+    const uint64_t lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        uint64_t ball[CP_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < CP_ROUNDS; r++) {
+            const int64_t i = ch * chunk + (int64_t)r * 256 + tid;
+            bool occ = false;
+            if (i < (int64_t)c.g.cap) {
+                const uint64_t t = c.g.tag[i];
+                occ = (t != EMPTY && (single || t != LOCKED));
+            }
+            ball[r] = __ballot(occ);
+            if (lane == 0) s_cnt[r * 4 + wave] = (unsigned int)__popcll(ball[r]);
         }
-        uint64_t b = __ballot(occ);
-        if (!b) continue;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&c.g.ctl[3], (unsigned long long)__popcll(b));
-        base = __shfl(base, 0);
-        if (!occ) continue;
-        uint64_t lt = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
-        int64_t pos = (int64_t)base + __popcll(b & lt);
-        if (single) {
-            c.dkey[pos] = c.g.tag[i];
-            c.dkey[c.dstride + pos] = 0;
-        } else {
-            for (int j = 0; j < c.g.kwt; j++) c.dkey[(int64_t)j * c.dstride + pos] = c.g.keyw[(uint64_t)j * c.g.stride + i];
+        __syncthreads();
+        if (tid < 64) {
+            const unsigned int v = s_cnt[tid];
+            unsigned int incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned int x = __shfl_up(incl, d);
+                if (tid >= d) incl += x;
+            }
+            s_cnt[tid] = incl - v;
+            if (tid == 63) s_base = incl ? atomicAdd(&c.g.ctl[3], (unsigned long long)incl) : 0ULL;
         }
-        for (int w = 0; w < c.plan.n_words; w++) c.dacc[(int64_t)w * c.dstride + pos] = c.g.acc[(uint64_t)w * c.g.stride + i];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CP_ROUNDS; r++) {
+            if (!((ball[r] >> lane) & 1ULL)) continue;
+            const int64_t i = ch * chunk + (int64_t)r * 256 + tid;
+            const int64_t pos = (int64_t)s_base + s_cnt[r * 4 + wave] + __popcll(ball[r] & lt);
+            if (single) {
+                c.dkey[pos] = c.g.tag[i];
+                c.dkey[c.dstride + pos] = 0;
+            } else {
+                for (int j = 0; j < c.g.kwt; j++) c.dkey[(int64_t)j * c.dstride + pos] = c.g.keyw[(uint64_t)j * c.g.stride + i];
+            }
+            for (int w = 0; w < c.plan.n_words; w++) c.dacc[(int64_t)w * c.dstride + pos] = c.g.acc[(uint64_t)w * c.g.stride + i];
+        }
+        __syncthreads();
     }
 }
 
@@ -4199,7 +4223,7 @@ static int merge_table_into_run(vnm_agg* h, hipStream_t s, bool* done) {
     VNM_HIP(hipMemcpyAsync(&fill, h->g.ctl + 2, 8, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
     const int64_t tmax = (int64_t)fill + 2;   // + the two special groups
-    if (tmax * 8 > h->run_n || h->run_n + tmax > h->run_stride - 2) return 0;
+    if (tmax * env_i64("VNM_RUN_PATCH_RATIO", 8) > h->run_n || h->run_n + tmax > h->run_stride - 2) return 0;
     PoolScope pool;
     const size_t fbytes = ((size_t)h->g.cap + 2 + 15) / 8 * 8;
     uint8_t* found = (uint8_t*)pool.take(fbytes + 8);
