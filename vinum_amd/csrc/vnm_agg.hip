@@ -1096,24 +1096,24 @@ __global__ __launch_bounds__(256) void tuple_words_kernel(TDict d, const uint64_
     if (threadIdx.x == 0 && s_new) atomicAdd(&d.ctl[2], (unsigned long long)s_new);
 }
 
-// the dictionary's tuples laid out by group id: by_gid [kwt][ngid]
-__global__ void tuple_sweep_kernel(TDict d, uint64_t* __restrict__ by_gid, int64_t ngid) {
+// group id -> slot (one 4-byte store per group; laying the tuples themselves out by id was four random 8-byte stores per group:
+// 3.2 ms at 2e7 groups), then the result's key words straight from the slots: one line per group
+__global__ __launch_bounds__(256) void tuple_sweep_kernel(TDict d, uint32_t* __restrict__ slot_of, int64_t ngid) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < (int64_t)d.cap; h += stride) {
-        const uint64_t* src = d.slot + (uint64_t)h * d.sw;
-        const uint64_t t = src[0];
-        if (t == EMPTY || t == LOCKED) continue;
-        const int64_t gid = (int64_t)src[1] - 1;
-        if (gid < 0 || gid >= ngid) continue;
-        for (int j = 0; j < d.kwt; j++) by_gid[(int64_t)j * ngid + gid] = src[2 + j];
+        const ulonglong2 w = *(const ulonglong2*)(d.slot + (uint64_t)h * d.sw);   // tag, id + 1
+        if (w.x == EMPTY || w.x == LOCKED) continue;
+        const int64_t gid = (int64_t)w.y - 1;
+        if (gid >= 0 && gid < ngid) slot_of[gid] = (uint32_t)h;
     }
 }
-__global__ void tuple_keys_kernel(const uint64_t* __restrict__ by_gid, int64_t ngid, int kwt, const uint64_t* __restrict__ gids, int64_t n,
+__global__ void tuple_keys_kernel(TDict d, const uint32_t* __restrict__ slot_of, int64_t ngid, const uint64_t* __restrict__ gids, int64_t n,
                                   uint64_t* __restrict__ dkey, int64_t dstride) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int64_t gid = (int64_t)gids[i];
-        for (int j = 0; j < kwt; j++) dkey[(int64_t)j * dstride + i] = gid < ngid ? by_gid[(int64_t)j * ngid + gid] : 0;
+        const uint64_t* src = gid < ngid ? d.slot + (uint64_t)slot_of[gid] * d.sw + 2 : nullptr;
+        for (int j = 0; j < d.kwt; j++) dkey[(int64_t)j * dstride + i] = src ? src[j] : 0;
     }
 }
 
@@ -4485,11 +4485,12 @@ int inner_keys(vnm_agg* h, const vnm_agg* in, int64_t n, uint64_t* keys, int64_t
     VNM_HIP(hipStreamSynchronize(s));
     const TDict& g = h->tdict;
     PoolScope pool;
-    uint64_t* by_gid = (uint64_t*)pool.take((size_t)g.kwt * (size_t)(ngid ? ngid : 1) * 8);
-    if (!by_gid) return 1;
+    if (g.cap >= (1ULL << 32)) return set_error("aggregate: tuple dictionary beyond 2^32 slots");
+    uint32_t* slot_of = (uint32_t*)pool.take((size_t)(ngid ? ngid : 1) * 4);
+    if (!slot_of) return 1;
     KernelTimer timer("agg_tuple_keys", s);
-    tuple_sweep_kernel<<<(int)std::min<int64_t>(((int64_t)g.cap + 255) / 256, (int64_t)device_info().num_cus * 8), 256, 0, s>>>(g, by_gid, (int64_t)ngid);
-    tuple_keys_kernel<<<grid, 256, 0, s>>>(by_gid, (int64_t)ngid, g.kwt, in->dkey, n, keys, stride);
+    tuple_sweep_kernel<<<(int)std::min<int64_t>(((int64_t)g.cap + 255) / 256, (int64_t)device_info().num_cus * 16), 256, 0, s>>>(g, slot_of, (int64_t)ngid);
+    tuple_keys_kernel<<<grid, 256, 0, s>>>(g, slot_of, (int64_t)ngid, in->dkey, n, keys, stride);
     VNM_HIP(hipGetLastError());
     VNM_HIP(hipStreamSynchronize(s));
     return 0;
