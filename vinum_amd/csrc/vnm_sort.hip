@@ -658,8 +658,13 @@ static int grid_for(int64_t n, int per_cu = 8) {
 static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_out, uint64_t* key_out, bool* wrote_key, hipStream_t s) {
     if (wrote_key) *wrote_key = false;
     const int cus = device_info().num_cus;
-    const int64_t nb = (int64_t)SS_B * SS_B;
-    const int64_t m = std::min<int64_t>(n, (int64_t)1 << 23);
+    // 512 x l2 buckets of ~2100-4200 rows: 2^18 at 1e9 rows, fewer below (2^18 buckets whatever n cost ~4.5 ms of fixed time:
+    // the 2^23-key sample and 2^18 nearly empty local-sort workgroups; 1.7e7 rows 5.2 ms against 1.4 with the LSD passes)
+    int l2 = 8;
+    while (l2 < SS_B && n / ((int64_t)SS_B * l2) > 4200) l2 *= 2;
+    l2 = (int)std::min<int64_t>(SS_B, std::max<int64_t>(8, env_sort_i64("VNM_SSORT_L2", l2)));
+    const int64_t nb = (int64_t)SS_B * l2;
+    const int64_t m = std::min<int64_t>(n, nb * 32);
     static bool attr_set = false;
     const size_t lds_sc = (size_t)SS_B * SS_CAP * 12;
     if (!attr_set) {
@@ -732,7 +737,7 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
     uint32_t* n1 = (uint32_t*)pool.take((size_t)SS_B * grid1 * 4);
     if (!c1 || !r1 || !n1) return 1;
     SsArgs a1{};
-    a1.key = key; a1.desc = desc; a1.nrows = n; a1.split = split;
+    a1.key = key; a1.desc = desc; a1.nrows = n; a1.split = split; a1.l2 = l2;
     a1.out_code = c1; a1.out_row = r1; a1.out_counts = n1; a1.out_cap = cap1; a1.flags = flags;
     a1.heavy = heavy; a1.nheavy = nheavy; a1.side = nheavy ? (unsigned long long*)side.code[0] : nullptr; a1.side_cap = side_cap;
     {
@@ -752,7 +757,7 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
     unsigned long long* offs = (unsigned long long*)pool.take((size_t)(nb + 1) * 8);
     if (!c2 || !r2 || !n2 || !offs) return 1;
     SsArgs a2{};
-    a2.split = split; a2.in_code = c1; a2.in_row = r1; a2.in_counts = n1; a2.in_cap = cap1; a2.in_regions = grid1; a2.in_split = split2;
+    a2.split = split; a2.l2 = l2; a2.in_code = c1; a2.in_row = r1; a2.in_counts = n1; a2.in_cap = cap1; a2.in_regions = grid1; a2.in_split = split2;
     a2.out_code = c2; a2.out_row = r2; a2.out_counts = n2; a2.out_cap = cap2; a2.flags = flags;
     {
         KernelTimer timer("sort_scatter2", s);
@@ -1065,7 +1070,7 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
 
     // one 8-byte key without NULLs, many rows: sample sort (two bucket scatters + a sort in LDS) instead of eight LSD passes
     if (n_keys == 1 && !keys[0].validity && (keys[0].type == VNM_F64 || keys[0].type == VNM_I64 || keys[0].type == VNM_U64) &&
-        n >= env_sort_i64("VNM_SSORT_MIN_ROWS", (int64_t)1 << 28) && getenv("VNM_SORT_NO_SAMPLE") == nullptr) {
+        n >= env_sort_i64("VNM_SSORT_MIN_ROWS", (int64_t)1 << 25) && getenv("VNM_SORT_NO_SAMPLE") == nullptr) {
         bool wk = false;
         const int rc = sample_sort(keys[0], orders[0] == VNM_DESC, n, out_indices, (uint64_t*)out_sorted_key0, &wk, s);
         if (rc == 1) return 1;
