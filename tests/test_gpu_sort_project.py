@@ -456,7 +456,7 @@ def test_topk_multi_key_equals_full_sort_prefix(shape, k):
 
 
 @pytest.mark.parametrize("case", ["f64_normal", "f64_desc_nan_negzero", "i64_few_dups", "u64_desc", "runs_of_100", "heavy_value", "heavy_values_and_nans_desc",
-                                  "low_cardinality_declines", "tiny_buckets", "odd_size"])
+                                  "low_cardinality_declines", "tiny_buckets", "odd_size", "fanout_16", "fanout_64_forced", "fanout_512_forced"])
 def test_sample_sort_equals_the_lsd_sort(case, monkeypatch):
     """The sample sort of one 8-byte key (vnm_sort_sample.inc: splitters from a sorted sample, two ring scatters into 2^18 buckets,
     per-bucket LSD sort in LDS, rows of equal key by row id) must give the SAME row ids as the eight-pass LSD sort -- the order is
@@ -487,6 +487,11 @@ def test_sample_sort_equals_the_lsd_sort(case, monkeypatch):
         v = rng.integers(0, 1000, n).astype(np.float64)
     elif case == "odd_size":
         n = 2_999_999 + 4096 * 3 + 17; v = rng.normal(0.0, 1.0, n)
+    elif case == "fanout_16":                          # the second level's fan-out follows n: 3.4e7 rows -> 512 x 16 buckets
+        n = (1 << 25) + 12345; v = rng.normal(0.0, 1.0, n); v[::1_000_003] = np.nan; order = L.DESC
+    elif case in ("fanout_64_forced", "fanout_512_forced"):
+        monkeypatch.setenv("VNM_SSORT_L2", case.split("_")[1])
+        v = rng.integers(-2**62, 2**62, n).astype(np.int64); v[::3] = v[1::3][:len(v[::3])]      # duplicates across rows
     else:
         v = rng.normal(0.0, 1.0, n)
     t = torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).cuda()
