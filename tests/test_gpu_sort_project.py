@@ -456,7 +456,8 @@ def test_topk_multi_key_equals_full_sort_prefix(shape, k):
 
 
 @pytest.mark.parametrize("case", ["f64_normal", "f64_desc_nan_negzero", "i64_few_dups", "u64_desc", "runs_of_100", "heavy_value", "heavy_values_and_nans_desc",
-                                  "low_cardinality_declines", "tiny_buckets", "odd_size", "fanout_16", "fanout_64_forced", "fanout_512_forced"])
+                                  "low_cardinality_declines", "tiny_buckets", "odd_size", "fanout_16", "fanout_64_forced", "fanout_512_forced",
+                                  "nulls_asc", "nulls_desc_nan_heavy", "half_null_unaligned", "mostly_null_declines"])
 def test_sample_sort_equals_the_lsd_sort(case, monkeypatch):
     """The sample sort of one 8-byte key (vnm_sort_sample.inc: splitters from a sorted sample, two ring scatters into 2^18 buckets,
     per-bucket LSD sort in LDS, rows of equal key by row id) must give the SAME row ids as the eight-pass LSD sort -- the order is
@@ -494,16 +495,37 @@ def test_sample_sort_equals_the_lsd_sort(case, monkeypatch):
         v = rng.integers(-2**62, 2**62, n).astype(np.int64); v[::3] = v[1::3][:len(v[::3])]      # duplicates across rows
     else:
         v = rng.normal(0.0, 1.0, n)
-    t = torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).cuda()
-    col = DeviceColumn.from_torch(t)
-    if v.dtype == np.uint64:
-        col = DeviceColumn(col._values, None, 0, n, pa.uint64(), keep=t)
+    mask = None
+    if case == "nulls_asc":                            # NULL rows: a class of the side list, behind every value, in row order
+        mask = rng.random(n) < 0.001
+    elif case == "nulls_desc_nan_heavy":
+        v[::5] = 3.5; v[3::1009] = np.nan; v[7::2003] = -0.0; mask = rng.random(n) < 0.02; order = L.DESC
+    elif case == "half_null_unaligned":
+        v = rng.integers(-2**40, 2**40, n).astype(np.int64); mask = rng.random(n) < 0.5
+    elif case == "mostly_null_declines":
+        mask = rng.random(n) < 0.9995
+    if mask is not None:
+        arr = pa.array(v, mask=mask)
+        if case == "half_null_unaligned":
+            arr = arr.slice(3, n - 5); n = len(arr)    # an Arrow offset that is not a multiple of 8 (odd: no 16-byte pairs)
+        col = DeviceColumn.from_arrow(arr)
+    else:
+        t = torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).cuda()
+        col = DeviceColumn.from_torch(t)
+        if v.dtype == np.uint64:
+            col = DeviceColumn(col._values, None, 0, n, pa.uint64(), keep=t)
     monkeypatch.setenv("VNM_SORT_NO_SAMPLE", "1")
     ref_idx, ref_key = ops.sort_indices_keyed([col], [order])
     ref = torch.as_tensor(_RawI64(ref_idx.ptr, n), device="cuda").clone()
     monkeypatch.delenv("VNM_SORT_NO_SAMPLE")
     monkeypatch.setenv("VNM_SSORT_MIN_ROWS", "1000")
+    import ctypes
+    L.lib().vnm_set_profiling(1)
     got_idx, got_key = ops.sort_indices_keyed([col], [order])
+    ms, local = ctypes.c_double(0), ctypes.c_int64(0)
+    L.lib().vnm_profile_query(b"sort_local", ctypes.byref(ms), ctypes.byref(local))
+    L.lib().vnm_set_profiling(0)
+    assert (local.value >= 1) == (case not in ("low_cardinality_declines", "mostly_null_declines")), (case, local.value)   # the path under test ran
     got = torch.as_tensor(_RawI64(got_idx.ptr, n), device="cuda")
     assert bool(torch.equal(got, ref)), f"{case}: {int((got != ref).sum())} positions differ"
     assert (got_key is None) == (ref_key is None)

@@ -664,7 +664,18 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
     while (l2 < SS_B && n / ((int64_t)SS_B * l2) > 4200) l2 *= 2;
     l2 = (int)std::min<int64_t>(SS_B, std::max<int64_t>(8, env_sort_i64("VNM_SSORT_L2", l2)));
     const int64_t nb = (int64_t)SS_B * l2;
-    const int64_t m = std::min<int64_t>(n, nb * 32);
+    // Samples per bucket: a bucket's share of the rows is ~Gamma(k) / k for k samples per bucket, and a bucket beyond the local
+    // sort's room (r times the mean) fails the whole attempt -- P ~ exp(-k (r - 1 - ln r)) per bucket.  At 1e9 rows r = 8192 / 3815
+    // = 2.15: with k = 32 about one data set in ten lost a bucket among its 2^18 (and paid the LSD sort on top of the wasted
+    // passes: 119 ms); k is chosen for P * buckets < 1e-7.
+    int64_t m;
+    {
+        const double mean = (double)n / (double)nb;
+        const double r = std::min<double>((double)SS_LOCAL, 2.5 * mean + 128.0) / mean;
+        const double need = (std::log((double)nb) + 16.0) / std::max(0.05, r - 1.0 - std::log(r));
+        const int64_t k = std::min<int64_t>(128, std::max<int64_t>(32, (int64_t)std::ceil(need)));
+        m = std::min<int64_t>(n, nb * env_sort_i64("VNM_SSORT_SAMPLES_PER_BUCKET", k));
+    }
     static bool attr_set = false;
     const size_t lds_sc = (size_t)SS_B * SS_CAP * 12;
     if (!attr_set) {
@@ -682,26 +693,43 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
     uint64_t* split = (uint64_t*)pool.take((size_t)nb * 8);
     unsigned long long* flags = (unsigned long long*)pool.take(64);
     uint64_t* heavy = (uint64_t*)pool.take((size_t)SS_MAX_HEAVY * 8);
-    unsigned long long* lb = (unsigned long long*)pool.take((size_t)(SS_MAX_HEAVY + 1) * 8 * 2);   // lb[65], then hstart[64]
+    unsigned long long* lb = (unsigned long long*)pool.take((size_t)(SS_MAX_HEAVY + 2) * 8 * 2);   // lb[66], then hstart[65] (+ the NULL class)
     unsigned int* hb = (unsigned int*)pool.take((size_t)(SS_MAX_HEAVY + 2) * 4);                   // hb[64], then the heavy counter
     if (!split || !flags || !heavy || !lb || !hb) return 1;
-    unsigned long long* hstart = lb + SS_MAX_HEAVY + 1;
+    unsigned long long* hstart = lb + SS_MAX_HEAVY + 2;
+    const int has_null = key.validity != nullptr;
     unsigned int* nheavy_d = hb + SS_MAX_HEAVY;
     VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
     VNM_HIP(hipMemsetAsync(nheavy_d, 0, 4, s));
     int nheavy = 0;
+    int64_t sample_nulls = 0, total_nulls = 0;
     unsigned long long eq_pairs = 0;
     {
         RadixBufs sr{};
         VNM_TRY(radix_alloc(&sr, m));
         {
             KernelTimer timer("sort_sample", s);
-            ssort_sample_kernel<<<grid_for(m), 256, 0, s>>>(key, desc, n, m, sr.code[0]);
+            ssort_sample_kernel<<<grid_for(m), 256, 0, s>>>(key, desc, n, m, sr.code[0], flags + 5);
         }
         sort_iota_kernel<<<grid_for(m), 256, 0, s>>>(sr.val[0], m);
         sr.cur = 0;
         VNM_TRY(radix_sort_codes(&sr, m, s));
-        ssort_splitters_kernel<<<(int)((nb + 255) / 256), 256, 0, s>>>(sr.code[sr.cur], m, nb, split, flags, heavy, nheavy_d);
+        int64_t m_valid = m;     // NULL rows of the sample stand at the end of its sorted order: the splitters come from the rest
+        if (has_null) {
+            unsigned long long sn = 0, tn = 0;
+            ssort_count_nulls_kernel<<<grid_for((n + 7) / 8), 256, 0, s>>>(key.validity, key.offset, n, flags + 6);
+            VNM_HIP(hipMemcpyAsync(&sn, flags + 5, 8, hipMemcpyDeviceToHost, s));
+            VNM_HIP(hipMemcpyAsync(&tn, flags + 6, 8, hipMemcpyDeviceToHost, s));
+            VNM_HIP(hipStreamSynchronize(s));
+            sample_nulls = (int64_t)sn;
+            total_nulls = (int64_t)tn;
+            m_valid = m - sample_nulls;
+            if (m_valid < nb * 4) {
+                if (getenv("VNM_SORT_TRACE")) fprintf(stderr, "[sort] sample sort declined: %lld of %lld sampled rows are NULL\n", (long long)sample_nulls, (long long)m);
+                return 2;
+            }
+        }
+        ssort_splitters_kernel<<<(int)((nb + 255) / 256), 256, 0, s>>>(sr.code[sr.cur], m_valid, nb, split, flags, heavy, nheavy_d);
         VNM_HIP(hipGetLastError());
         unsigned long long too_many = 0;
         unsigned int nh = 0;
@@ -723,9 +751,11 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
     }
     // rows of heavy codes bypass the buckets: (heavy index << 32 | row id) entries in a side list, sorted below
     // (room: every run of r equal splitters stands for at most (r + 1) buckets' worth of rows)
-    const int64_t side_cap = nheavy ? std::min<int64_t>(n, (int64_t)((double)(eq_pairs + 2 * (unsigned long long)nheavy) * (double)n / (double)nb * 1.3) + 65536) : 0;
+    // (+ the NULL rows, counted)
+    const double null_rows = (double)total_nulls;
+    const int64_t side_cap = (nheavy || has_null) ? std::min<int64_t>(n, (int64_t)((double)(eq_pairs + 2 * (unsigned long long)nheavy) * (double)n / (double)nb * 1.3 + null_rows) + 65536) : 0;
     RadixBufs side{};
-    if (nheavy) VNM_TRY(radix_alloc(&side, side_cap));
+    if (nheavy || has_null) VNM_TRY(radix_alloc(&side, side_cap));
     // ---- level 1
     const int pairs1 = env_sort_i64("VNM_SSORT_PAIRS1", 1) >= 2 ? 2 : 1;
     const int64_t sub = 2 * SS_BLOCK * pairs1;
@@ -739,7 +769,8 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
     SsArgs a1{};
     a1.key = key; a1.desc = desc; a1.nrows = n; a1.split = split; a1.l2 = l2;
     a1.out_code = c1; a1.out_row = r1; a1.out_counts = n1; a1.out_cap = cap1; a1.flags = flags;
-    a1.heavy = heavy; a1.nheavy = nheavy; a1.side = nheavy ? (unsigned long long*)side.code[0] : nullptr; a1.side_cap = side_cap;
+    a1.heavy = heavy; a1.nheavy = nheavy; a1.has_null = has_null;
+    a1.side = (nheavy || has_null) ? (unsigned long long*)side.code[0] : nullptr; a1.side_cap = side_cap;
     {
         KernelTimer timer("sort_scatter1", s);
         if (pairs1 == 2) ssort_scatter_kernel<true, 2><<<grid1, SS_BLOCK, lds_sc, s>>>(a1);
@@ -769,17 +800,18 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
     VNM_HIP(hipMemcpyAsync(fl, flags, 24, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
     if (fl[0]) {
-        if (getenv("VNM_SORT_TRACE")) fprintf(stderr, "[sort] sample sort: a region overflowed, LSD sort instead\n");
+        if (getenv("VNM_SORT_TRACE")) fprintf(stderr, "[sort] sample sort: a region overflowed (side list %llu of %lld, %lld NULL rows, %lld of %lld samples NULL, %d heavy values), LSD sort instead\n",
+                                              fl[2], (long long)side_cap, (long long)total_nulls, (long long)sample_nulls, (long long)m, nheavy);
         return 2;
     }
     // ---- the heavy rows: their side list sorted by (heavy index, row id) is their part of the output
     const int64_t side_len = (int64_t)fl[2];
-    if (nheavy) {
+    if (nheavy || has_null) {
         side.cur = 0;
         if (side_len > 1) VNM_TRY(radix_sort_codes(&side, side_len, s, nullptr, nullptr, false, nullptr, false, nullptr));
-        ssort_heavy_bounds_kernel<<<1, 128, 0, s>>>((const unsigned long long*)side.code[side.cur], side_len, heavy, nheavy, split, nb, lb, hb);
+        ssort_heavy_bounds_kernel<<<1, 128, 0, s>>>((const unsigned long long*)side.code[side.cur], side_len, heavy, nheavy, split, nb, lb, hb, has_null);
     }
-    ssort_offsets_kernel<<<1, 1024, 0, s>>>(n2, split2, nb, offs, flags, nheavy, hb, lb, hstart);
+    ssort_offsets_kernel<<<1, 1024, 0, s>>>(n2, split2, nb, offs, flags, nheavy, hb, lb, hstart, has_null);
     VNM_HIP(hipGetLastError());
     VNM_HIP(hipMemcpyAsync(fl, flags, 8, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
@@ -809,16 +841,16 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
     SsLocalArgs la{};
     la.code = c2; la.row = r2; la.counts = n2; la.cap = cap2; la.split = split2; la.offs = offs; la.nbuckets = nb;
     la.idx_out = idx_out;
-    const bool keyed = key_out != nullptr && fl[1] == 0;
+    const bool keyed = key_out != nullptr && fl[1] == 0 && !has_null;   // (a sorted key column with NULLs in it: the caller gathers)
     la.key_out = keyed ? key_out : nullptr; la.key_type = key.type; la.key_desc = desc; la.flags = flags;
     la.debug = (int)env_sort_i64("VNM_SSORT_DEBUG", 0);
     {
         KernelTimer timer("sort_local", s);
         ssort_local_kernel<512, 10, 4096, false><<<(int)std::min<int64_t>(nb, (int64_t)cus * 64), 512, (size_t)SS_SMALL * 12 + 4096 * 4, s>>>(la);
         ssort_local_kernel<1024, 8, 8192, true><<<(int)std::min<int64_t>(nb, (int64_t)cus * 16), 1024, (size_t)SS_LOCAL * 12 + 8192 * 4, s>>>(la);
-        if (nheavy && side_len > 0)
+        if ((nheavy || has_null) && side_len > 0)
             ssort_heavy_write_kernel<<<grid_for(side_len), 256, 0, s>>>((const unsigned long long*)side.code[side.cur], side_len, heavy, lb, hstart, idx_out,
-                                                                        keyed ? key_out : nullptr, key.type, desc);
+                                                                        keyed ? key_out : nullptr, key.type, desc, nheavy);
     }
     VNM_HIP(hipGetLastError());
     VNM_HIP(hipStreamSynchronize(s));
@@ -1069,7 +1101,7 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
     }
 
     // one 8-byte key without NULLs, many rows: sample sort (two bucket scatters + a sort in LDS) instead of eight LSD passes
-    if (n_keys == 1 && !keys[0].validity && (keys[0].type == VNM_F64 || keys[0].type == VNM_I64 || keys[0].type == VNM_U64) &&
+    if (n_keys == 1 && (!keys[0].validity || getenv("VNM_SSORT_NO_NULLS") == nullptr) && (keys[0].type == VNM_F64 || keys[0].type == VNM_I64 || keys[0].type == VNM_U64) &&
         n >= env_sort_i64("VNM_SSORT_MIN_ROWS", (int64_t)1 << 25) && getenv("VNM_SORT_NO_SAMPLE") == nullptr) {
         bool wk = false;
         const int rc = sample_sort(keys[0], orders[0] == VNM_DESC, n, out_indices, (uint64_t*)out_sorted_key0, &wk, s);
