@@ -258,6 +258,45 @@ def test_order_by_1e9_rows(limit):
     _free()
 
 
+def test_order_by_1e9_rows_with_null_keys():
+    """configs[4]'s NULL variant: ORDER BY v DESC over 1e9 fp64 rows, 0.1 % NaN and 0.1 % NULL keys: numbers non-increasing, then
+    the NaNs, then the NULL rows (Arrow SortIndices: for either direction); a permutation; ties, NaNs and NULLs in row order."""
+    torch = _torch()
+    from vinum_amd import _lib as L
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    n = N_FULL
+    g = torch.Generator(device="cuda"); g.manual_seed(4)
+    v = torch.randn(n, device="cuda", dtype=torch.float64, generator=g) * 3.0 + 11.0
+    v[::1000] = 12.5
+    v[7::1000] = float("nan")
+    bits = torch.full(((n + 7) // 8,), 255, dtype=torch.uint8, device="cuda")
+    bits[5::125] = 0b11110111                       # row 8 * (5 + 125 j) + 3 is NULL: 0.1 % of the rows
+    idx = ops.sort_indices([DeviceColumn.from_torch(v, validity=bits)], [L.DESC])
+    torch.cuda.synchronize()
+    ids = _as_tensor(idx.ptr, n)
+    assert int(ids.min()) >= 0 and int(ids.max()) < n
+    is_null = ((bits[ids >> 3] >> (ids & 7).to(torch.uint8)) & 1) == 0
+    n_null = int(is_null.sum())
+    assert n_null == (bits.numel() - 5 + 124) // 125
+    assert bool(is_null[n - n_null:].all())                    # the NULL rows last ...
+    tail = ids[n - n_null:]
+    assert bool((tail[1:] > tail[:-1]).all())                  # ... in row order
+    got = v[ids[: n - n_null]]
+    nn = int(torch.isnan(got).sum())
+    body = got[: n - n_null - nn]
+    assert not bool(torch.isnan(body).any()) and bool(torch.isnan(got[n - n_null - nn:]).all())
+    assert bool((body[1:] <= body[:-1]).all())
+    flag = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    flag[ids] = 1
+    assert bool(flag.all())
+    same = got[1:] == got[:-1]
+    head = ids[: n - n_null]
+    assert bool((head[1:][same] > head[:-1][same]).all())
+    del v, got, ids, idx, flag, bits
+    _free()
+
+
 def test_projection_1e9_rows():
     """BASELINE configs[4]: `v*2+1, v-a, a*b` over 1e9 rows, one fused kernel; IEEE double results bit-equal torch's
     (separate multiply and add: NumPy does not contract either)."""
