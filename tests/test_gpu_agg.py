@@ -784,6 +784,41 @@ def test_tuple_dictionary_for_keys_beyond_one_word(scenario, monkeypatch):
         util.assert_agg_equal(got, o.result(), funcs, keys, what=f"tuple dictionary {scenario} pred={pred}")
 
 
+@pytest.mark.parametrize("shape", ["split_program", "tuple_dictionary"])
+def test_split_and_tuple_paths_with_no_surviving_row(shape, monkeypatch):
+    """A predicate nothing passes (and one that a single row passes) under the split program and under the tuple dictionary:
+    zero groups / one group, through both result routes."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    n = 600_000
+    g = rng.integers(0, 50_000, n).astype(np.int64)
+    cols, keys, kind = {}, ["k"], O.SINGLE
+    if shape == "tuple_dictionary":
+        monkeypatch.setenv("VNM_AGG_NO_DICT", "1")
+        cols = {"a": pa.array(g * 977_000_003 - 2**61), "b": pa.array((g ^ 0x5DEECE66D) * 1_000_003), "c": pa.array(g * 2**33)}
+        keys, kind = ["a", "b", "c"], O.MULTI
+    else:
+        cols["k"] = pa.array(g * 31 - 7)
+    ncol = 8 if shape == "split_program" else 2
+    funcs = []
+    for c in range(ncol):
+        vals = rng.integers(0, 2**14, n).astype(np.float64) / 64.0
+        if c == 0:
+            vals[123_456] = 1e6                      # the one row the second predicate lets through
+        cols[f"c{c}"] = pa.array(vals)
+        funcs.append(((O.SUM, O.MAX, O.AVG, O.MIN)[c % 4], f"c{c}", f"f{c}"))
+    funcs.append((O.COUNT_STAR, "", "n"))
+    t = pa.table(cols)
+    batches = util.sliced_batches(t, n // 2)
+    for thr, expect in ((1e9, 0), (5e5, 1)):
+        got = gpu_aggregate(kind, keys, keys, funcs, batches, predicate=("c0", ">", thr), expected_groups=50_000)
+        assert got.num_rows == expect
+        o = O.OracleAggregate(kind, keys, keys, funcs)
+        for bt in batches:
+            o.next(O.filter_batch(bt, O.cmp_mask(bt.column(len(keys)), O.GT, thr)))
+        util.assert_agg_equal(got, o.result(), funcs, keys, what=f"{shape}: {expect} surviving row(s)")
+
+
 @pytest.mark.parametrize("scenario", ["hintless", "two_keys_packed", "merged_afterwards", "narrow_key"])
 def test_split_program_scenarios(scenario):
     """The program split (eight input columns) where the operator has to find out for itself that the groups are many (no
