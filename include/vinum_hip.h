@@ -47,6 +47,18 @@ struct ArrowArray {
 };
 #endif
 
+/* ---- Arrow C Stream Interface (https://arrow.apache.org/docs/format/CStreamInterface.html) ------ */
+#ifndef ARROW_C_STREAM_INTERFACE
+#define ARROW_C_STREAM_INTERFACE
+struct ArrowArrayStream {
+    int (*get_schema)(struct ArrowArrayStream*, struct ArrowSchema* out);
+    int (*get_next)(struct ArrowArrayStream*, struct ArrowArray* out);
+    const char* (*get_last_error)(struct ArrowArrayStream*);
+    void (*release)(struct ArrowArrayStream*);
+    void* private_data;
+};
+#endif
+
 /* ---- enums ---------------------------------------------------------------------------------- */
 /* physical column types; temporal Arrow types map to their storage integers */
 enum vnm_type { VNM_I8 = 0, VNM_I16, VNM_I32, VNM_I64, VNM_U8, VNM_U16, VNM_U32, VNM_U64, VNM_F32, VNM_F64 };
@@ -284,6 +296,11 @@ vnm_agg_op* vnm_agg_op_create(int kind, int n_groupby, const char** groupby_cols
                               const char** agg_cols, int n_funcs, const int* func_types,
                               const char** in_cols, const char** out_cols);
 int vnm_agg_op_next(vnm_agg_op* h, struct ArrowArray* batch, struct ArrowSchema* schema); /* consumes both */
+/* Every batch of an Arrow C stream, as one vnm_agg_op_next each (consumes and releases the stream).  The reference's pipeline
+ * hands over 10 000-row batches (vinum/__init__.py:52, table_batch_reader.cpp:5-16); crossing the language boundary once per
+ * few hundred of them instead of once each is what the caller saves -- the operator keeps small batches as they are (no
+ * concatenation on the host) and stages them to the device together. */
+int vnm_agg_op_next_stream(vnm_agg_op* h, struct ArrowArrayStream* stream);
 int vnm_agg_op_result(vnm_agg_op* h, struct ArrowArray* out, struct ArrowSchema* out_schema);
 void vnm_agg_op_destroy(vnm_agg_op* h);
 
@@ -305,6 +322,7 @@ int vnm_take(const vnm_dcol* col, const int64_t* indices, int64_t n, void* out_v
 typedef struct vnm_sort_op vnm_sort_op;
 vnm_sort_op* vnm_sort_op_create(int n, const char** cols, const int* orders);
 int vnm_sort_op_next(vnm_sort_op* h, struct ArrowArray* batch, struct ArrowSchema* schema);
+int vnm_sort_op_next_stream(vnm_sort_op* h, struct ArrowArrayStream* stream);   /* as vnm_agg_op_next_stream */
 int vnm_sort_op_sorted(vnm_sort_op* h, int64_t limit, struct ArrowArray* out, struct ArrowSchema* out_schema);
 void vnm_sort_op_destroy(vnm_sort_op* h);
 

@@ -103,6 +103,8 @@ PROTOTYPES = {
     "vnm_stage_column": (c_int, [c_void, c_void, c_i64, c_i64, ctypes.c_int32, c_void, c_void]),
     "vnm_free_column": (c_int, [c_void]),
     "vnm_csv_parse_block": (c_int, [c_void, c_i64, c_int, c_int, c_int, c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
+    "vnm_agg_op_next_stream": (c_int, [c_void, c_void]),
+    "vnm_sort_op_next_stream": (c_int, [c_void, c_void]),
     "vnm_strdict_create": (c_void, []),
     "vnm_strdict_destroy": (None, [c_void]),
     "vnm_strdict_ids": (c_i64, [c_void]),

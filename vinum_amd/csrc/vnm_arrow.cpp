@@ -168,10 +168,27 @@ int stage_child(const struct ArrowArray* batch, int ci, const ColType& t, vnm_dc
 // then staged in one go (Table::FromRecordBatches + one H2D, as Sort does, sort.cpp:16).
 int stage_children(const std::vector<std::unique_ptr<ImportedBatch>>& batches, int ci, const ColType& t, int64_t total, vnm_dcol* out) {
     const int w = type_width(t.type);
-    std::vector<uint8_t> vals((size_t)(total ? total : 1) * w);
-    std::vector<uint8_t> bits;
     bool any_null = false;
     for (auto& b : batches) if (b->arr.children[ci]->null_count != 0 && b->arr.children[ci]->buffers[0]) any_null = true;
+    if (!any_null) {   // the chunks go through the pinned ring as they are: no joined copy on the host
+        std::vector<const void*> srcs;
+        std::vector<size_t> sizes;
+        for (auto& b : batches) {
+            const struct ArrowArray* ch = b->arr.children[ci];
+            if (!b->arr.length) continue;
+            srcs.push_back((const uint8_t*)ch->buffers[1] + (size_t)(ch->offset + b->arr.offset) * w);
+            sizes.push_back((size_t)b->arr.length * w);
+        }
+        memset(out, 0, sizeof(*out));
+        void* dv = pool_alloc((size_t)(total ? total : 1) * w);
+        if (!dv) return 1;
+        out->values = dv; out->type = t.type; out->length = total; out->flags = t.flags;
+        const int rc = stage_chunks(dv, srcs.data(), sizes.data(), srcs.size(), nullptr);
+        if (rc || hipStreamSynchronize(nullptr) != hipSuccess) { pool_free(dv); out->values = nullptr; return rc ? rc : set_error("staging failed"); }
+        return 0;
+    }
+    std::vector<uint8_t> vals((size_t)(total ? total : 1) * w);
+    std::vector<uint8_t> bits;
     if (any_null) bits.assign((size_t)(total + 7) / 8 + 1, 0);
     int64_t pos = 0;
     for (auto& b : batches) {
@@ -255,6 +272,35 @@ static int agg_op_init(vnm_agg_op* h, const struct ArrowSchema* sch) {
     if (!h->dev) return 1;
     h->inited = true;
     return 0;
+}
+
+// pulls every batch of an Arrow C stream through `take` (which consumes array and schema); releases the stream
+template <class F>
+static int drain_stream(struct ArrowArrayStream* stream, const char* who, F take) {
+    int rc = 0;
+    for (;;) {
+        struct ArrowArray arr;
+        memset(&arr, 0, sizeof(arr));
+        if (stream->get_next(stream, &arr) != 0) {
+            const char* msg = stream->get_last_error ? stream->get_last_error(stream) : nullptr;
+            rc = set_error("%s: the stream failed: %s", who, msg ? msg : "(no message)");
+            break;
+        }
+        if (!arr.release) break;   // end of the stream
+        struct ArrowSchema sch;
+        memset(&sch, 0, sizeof(sch));
+        if (stream->get_schema(stream, &sch) != 0) {
+            arr.release(&arr);
+            rc = set_error("%s: the stream has no schema", who);
+            break;
+        }
+        rc = take(&arr, &sch);
+        if (arr.release) arr.release(&arr);     // (not taken: an error on the way)
+        if (sch.release) sch.release(&sch);
+        if (rc) break;
+    }
+    if (stream->release) stream->release(stream);
+    return rc;
 }
 
 extern "C" {
@@ -374,6 +420,11 @@ int vnm_agg_op_next(vnm_agg_op* h, struct ArrowArray* batch, struct ArrowSchema*
     for (auto& kv : staged) vnm_free_column(&kv.second);
     ib.drop();
     return rc;
+}
+
+int vnm_agg_op_next_stream(vnm_agg_op* h, struct ArrowArrayStream* stream) {
+    if (!h || !stream || !stream->get_next) return set_error("vnm_agg_op_next_stream: null argument");
+    return drain_stream(stream, "vnm_agg_op_next_stream", [&](struct ArrowArray* a, struct ArrowSchema* sc) { return vnm_agg_op_next(h, a, sc); });
 }
 
 int vnm_agg_op_result(vnm_agg_op* h, struct ArrowArray* out, struct ArrowSchema* out_schema) {
@@ -514,6 +565,11 @@ int vnm_sort_op_next(vnm_sort_op* h, struct ArrowArray* batch, struct ArrowSchem
     batch->release = nullptr; schema->release = nullptr;
     h->batches.push_back(std::move(ib));
     return 0;
+}
+
+int vnm_sort_op_next_stream(vnm_sort_op* h, struct ArrowArrayStream* stream) {
+    if (!h || !stream || !stream->get_next) return set_error("vnm_sort_op_next_stream: null argument");
+    return drain_stream(stream, "vnm_sort_op_next_stream", [&](struct ArrowArray* a, struct ArrowSchema* sc) { return vnm_sort_op_next(h, a, sc); });
 }
 
 // Sort::Sorted (sort.cpp:15-63).  limit > 0: only the first `limit` rows are produced (LIMIT pushed into the

@@ -46,6 +46,8 @@ int ensure_init();
 
 // Caching device allocator: operator scratch (hash tables, look-back status, dense results) is
 // re-used across calls so steady-state batches never hit hipMalloc/hipFree.
+// several host ranges end to end into one device range, through the pinned staging ring (vnm_runtime.cpp)
+int stage_chunks(void* dst, const void* const* srcs, const size_t* sizes, size_t n_chunks, hipStream_t stream);
 void* pool_alloc(size_t bytes);
 void pool_free(void* p);
 size_t pool_trim();  // releases the cached blocks, returns their bytes

@@ -1,5 +1,6 @@
 // Runtime plumbing of libvinum_hip.so: init, errors, caching device allocator, staging, memcpy helpers.
 #include <condition_variable>
+#include <functional>
 #include <cstring>
 #include <map>
 #include <thread>
@@ -183,6 +184,22 @@ public:
         cv_.notify_all();
         for (auto& t : workers_) t.join();
     }
+    // fn(part, parts) on every helper thread and on the caller (part 0); returns when all are done
+    void parallel(const std::function<void(int, int)>& fn) {
+        const int parts = (int)workers_.size() + 1;
+        if (parts == 1) { fn(0, 1); return; }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = &fn;
+            pending_ = (int)workers_.size();
+            gen_++;
+        }
+        cv_.notify_all();
+        fn(0, parts);
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
     void copy(void* dst, const void* src, size_t n) {
         const int parts = (int)workers_.size() + 1;
         if (parts == 1 || n < (4u << 20)) { memcpy(dst, src, n); return; }
@@ -209,8 +226,10 @@ private:
             const size_t lo = slice_ * (size_t)(idx + 1);
             uint8_t* d = dst_; const uint8_t* s = src_;
             const size_t n = n_, sl = slice_;
+            const std::function<void(int, int)>* fn = fn_;
             g.unlock();
-            if (lo < n) memcpy(d + lo, s + lo, lo + sl < n ? sl : n - lo);
+            if (fn) (*fn)(idx + 1, (int)workers_.size() + 1);
+            else if (lo < n) memcpy(d + lo, s + lo, lo + sl < n ? sl : n - lo);
             g.lock();
             if (--pending_ == 0) done_.notify_one();
         }
@@ -220,6 +239,7 @@ private:
     std::condition_variable cv_, done_;
     uint8_t* dst_ = nullptr; const uint8_t* src_ = nullptr;
     size_t n_ = 0, slice_ = 0;
+    const std::function<void(int, int)>* fn_ = nullptr;
     int pending_ = 0;
     uint64_t gen_ = 0;
     bool stop_ = false;
@@ -261,6 +281,47 @@ static int staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t stre
         slot ^= 1;
     }
     // order the caller's stream after the copies, and keep the pinned buffers safe for the next call
+    for (int i = 0; i < 2; i++)
+        if (used[i]) { VNM_HIP(hipStreamWaitEvent(stream, st.done[i], 0)); VNM_HIP(hipEventSynchronize(st.done[i])); }
+    return 0;
+}
+
+// Several host ranges laid end to end into ONE device range: the pinned buffers are filled from as many chunks as fit (the copy
+// threads share the chunks), one DMA per filled buffer.  For the record batches an operator kept while they were small: 10 000-row
+// batches are 80 KB per column -- a DMA (or a host-side concatenation first) per chunk cost more than the bytes.
+int stage_chunks(void* dst, const void* const* srcs, const size_t* sizes, size_t n_chunks, hipStream_t stream) {
+    std::lock_guard<std::mutex> g(g_stage_mu);
+    Stager& st = stager();
+    if (!st.init()) return set_error("staging: no pinned buffers");
+    struct Piece { size_t at; const uint8_t* src; size_t n; };
+    std::vector<Piece> pieces;
+    size_t dst_off = 0, chunk = 0, chunk_off = 0;
+    int slot = 0;
+    bool used[2] = {false, false};
+    while (chunk < n_chunks) {
+        pieces.clear();
+        size_t fill = 0;
+        while (chunk < n_chunks && fill < STAGE_BYTES) {
+            const size_t left = sizes[chunk] - chunk_off;
+            const size_t n = left < STAGE_BYTES - fill ? left : STAGE_BYTES - fill;
+            if (n) pieces.push_back(Piece{fill, (const uint8_t*)srcs[chunk] + chunk_off, n});
+            fill += n; chunk_off += n;
+            if (chunk_off == sizes[chunk]) { chunk++; chunk_off = 0; }
+        }
+        if (!fill) break;
+        if (used[slot]) VNM_HIP(hipEventSynchronize(st.done[slot]));   // the DMA that read this buffer is finished
+        uint8_t* pin = (uint8_t*)st.pin[slot];
+        const size_t np = pieces.size();
+        const std::function<void(int, int)> work = [&](int part, int parts) {
+            for (size_t i = np * (size_t)part / (size_t)parts; i < np * (size_t)(part + 1) / (size_t)parts; i++) memcpy(pin + pieces[i].at, pieces[i].src, pieces[i].n);
+        };
+        if (fill < (4u << 20)) work(0, 1); else copy_pool().parallel(work);
+        VNM_HIP(hipMemcpyAsync((uint8_t*)dst + dst_off, pin, fill, hipMemcpyHostToDevice, st.copy));
+        VNM_HIP(hipEventRecord(st.done[slot], st.copy));
+        used[slot] = true;
+        dst_off += fill;
+        slot ^= 1;
+    }
     for (int i = 0; i < 2; i++)
         if (used[i]) { VNM_HIP(hipStreamWaitEvent(stream, st.done[i], 0)); VNM_HIP(hipEventSynchronize(st.done[i])); }
     return 0;

@@ -270,8 +270,8 @@ class _HashAggregateBase:
 
     # The reference streams 10 000-row batches by default (vinum/__init__.py:52).  Handing each of them to the library costs ~50 us
     # of Python + Arrow C export per batch -- 20x what its rows cost on the device -- so batches below 2^20 rows are kept here
-    # (a list append) and cross the boundary joined into one batch once 2^22 rows are waiting, or at result().  (The C entry
-    # point coalesces small batches as well, for callers that are not this class.)
+    # (a list append) and cross the boundary together, as one Arrow C stream, once 2^22 rows are waiting, or at result(); the
+    # library keeps the small batches of a stream as they are and stages them to the device as one.
     _SMALL_ROWS = 1 << 20
     _FLUSH_ROWS = 1 << 22
 
@@ -286,10 +286,21 @@ class _HashAggregateBase:
 
     def _flush(self) -> None:
         pending, self._pending, self._pending_rows = getattr(self, "_pending", None), [], 0
-        if pending:
+        if not pending:
+            return
+        if self._stand_in or self._strmm is not None or len(pending) == 1:
+            # (stand-in / rank columns are built per batch: one joined batch, as before)
             joined = pa.Table.from_batches(pending).combine_chunks()
             for b in joined.to_batches():
                 self._send(b)
+            return
+        # the waiting batches cross the boundary as ONE Arrow C stream: no concatenation on the host (that copy was most of
+        # the cost: 0.8 GB per 5e7 rows), one call instead of one per batch; the library stages them to the device together
+        reader = pa.RecordBatchReader.from_batches(pending[0].schema, pending)
+        stream = ctypes.create_string_buffer(40)      # struct ArrowArrayStream: five pointers
+        reader._export_to_c(ctypes.addressof(stream))
+        if L.lib().vnm_agg_op_next_stream(self._h, ctypes.addressof(stream)) != 0:
+            raise RuntimeError(L.last_error())
 
     def next(self, batch: pa.RecordBatch) -> None:
         if not hasattr(self, "_pending"):
@@ -566,12 +577,12 @@ class Sort:
         pending, self._pending, self._pending_rows = getattr(self, "_pending", None), [], 0
         if not pending:
             return
-        joined = pa.Table.from_batches(pending).combine_chunks() if len(pending) > 1 else pa.Table.from_batches(pending)
-        for b in (joined.to_batches() or pending[:1]):
-            c = _CStructs()
-            b._export_to_c(c.arr_ptr, c.sch_ptr)
-            if L.lib().vnm_sort_op_next(self._h, c.arr_ptr, c.sch_ptr) != 0:
-                raise RuntimeError(L.last_error())
+        # one Arrow C stream for all waiting batches (no concatenation on the host; Sort::Next only retains them anyway)
+        reader = pa.RecordBatchReader.from_batches(pending[0].schema, pending)
+        stream = ctypes.create_string_buffer(40)      # struct ArrowArrayStream: five pointers
+        reader._export_to_c(ctypes.addressof(stream))
+        if L.lib().vnm_sort_op_next_stream(self._h, ctypes.addressof(stream)) != 0:
+            raise RuntimeError(L.last_error())
 
     def sorted(self, limit: int = 0) -> pa.RecordBatch:
         """limit (extension, default 0 = everything): only the first `limit` rows are needed (LIMIT pushed
