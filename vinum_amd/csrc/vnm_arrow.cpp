@@ -593,33 +593,13 @@ int vnm_sort_op_sorted(vnm_sort_op* h, int64_t limit, struct ArrowArray* out, st
         if (i < 0) return set_error("Failed to sort table.");
         key_col.push_back(i);
     }
-    // Table::FromRecordBatches: concatenate every column on the host, then stage once
+    // Table::FromRecordBatches: every column of all batches as ONE column in HBM (stage_children: the chunks go through the
+    // pinned ring as they are; columns with NULLs are joined on the host first)
     std::vector<vnm_dcol> dev((size_t)ncols);
     int rc = 0;
     for (int64_t c = 0; c < ncols && !rc; c++) {
-        int w = type_width(types[c].type);
-        std::vector<uint8_t> vals((size_t)(total ? total : 1) * w);
-        std::vector<uint8_t> bits;
-        bool any_null = false;
-        for (auto& b : h->batches) if (b->arr.children[c]->null_count != 0 && b->arr.children[c]->buffers[0]) any_null = true;
-        if (any_null) bits.assign((size_t)(total + 7) / 8 + 1, 0);
-        int64_t pos = 0;
-        for (auto& b : h->batches) {
-            const struct ArrowArray* ch = b->arr.children[c];
-            int64_t off = ch->offset + b->arr.offset, len = b->arr.length;
-            if (len) memcpy(&vals[(size_t)pos * w], (const uint8_t*)ch->buffers[1] + (size_t)off * w, (size_t)len * w);
-            if (any_null) {
-                const uint8_t* bm = (ch->null_count != 0) ? (const uint8_t*)ch->buffers[0] : nullptr;
-                for (int64_t i = 0; i < len; i++) {
-                    bool ok = !bm || ((bm[(off + i) >> 3] >> ((off + i) & 7)) & 1);
-                    if (ok) bits[(size_t)(pos + i) >> 3] |= (uint8_t)(1u << ((pos + i) & 7));
-                }
-            }
-            pos += len;
-        }
-        rc = vnm_stage_column(vals.data(), any_null ? bits.data() : nullptr, 0, total, types[c].type, &dev[c], nullptr);
-        dev[c].flags = types[c].flags;
-        if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = set_error("Sort: staging failed");
+        memset(&dev[c], 0, sizeof(vnm_dcol));
+        rc = stage_children(h->batches, (int)c, types[c], total, &dev[c]);
     }
     const int64_t n_out = (limit > 0 && limit < total) ? limit : total;
     int64_t* idx = nullptr;
