@@ -330,6 +330,47 @@ def test_string_dictionary_on_the_device(case):
         assert seen.setdefault(c, v) == v, "two values share a code"
 
 
+def test_small_nullable_batches_at_unaligned_offsets():
+    """Small batches are kept and staged together: values chunk by chunk through the pinned ring, validity bits laid end to end by
+    byte-wise shifts.  Batches of 9 999 and 10 007 rows cut from one table (Arrow offsets and lengths that are not multiples of 8),
+    some chunks without a bitmap at all: the aggregate must equal the one-batch run, the sort must equal Arrow's sort_indices."""
+    from vinum_amd import vinum_lib as V
+    rng = np.random.default_rng(21)
+    n = 1_203_457
+    k = pa.array(rng.integers(0, 3000, n).astype(np.int64), mask=rng.random(n) < 0.03)
+    v = pa.array(rng.integers(-2**13, 2**13, n).astype(np.float64) / 128.0, mask=rng.random(n) < 0.2)
+    w = pa.array(rng.integers(-2**40, 2**40, n).astype(np.int64))
+    t = pa.table({"k": k, "v": v, "w": w})
+    defs = [V.AggFuncDef(V.AggFuncType.SUM, "v", "s"), V.AggFuncDef(V.AggFuncType.COUNT, "v", "c"), V.AggFuncDef(V.AggFuncType.MIN, "w", "lo"),
+            V.AggFuncDef(V.AggFuncType.COUNT_STAR, "", "n")]
+
+    def pieces():
+        pos, i = 0, 0
+        while pos < n:
+            c = min((9_999, 10_007, 8, 1, 4_093)[i % 5], n - pos)
+            b = t.slice(pos, c).to_batches()[0]
+            if i % 7 == 3:      # a chunk whose columns carry no validity bitmap
+                b = pa.RecordBatch.from_arrays([pa.array(col.fill_null(0) if j else col.fill_null(-1)) for j, col in enumerate(b.columns)], names=b.schema.names)
+            yield b
+            pos += c; i += 1
+
+    op = V.SingleNumericalHashAggregate(["k"], ["k"], defs)
+    ref_batches = []
+    for b in pieces():
+        op.next(b); ref_batches.append(b)
+    got = op.result()
+    whole = pa.Table.from_batches(ref_batches).combine_chunks()
+    op1 = V.SingleNumericalHashAggregate(["k"], ["k"], defs)
+    op1.next(whole.to_batches()[0])
+    util.assert_batches_equal(got, op1.result(), key_names=["k"], what="small nullable batches vs one batch")
+    srt = V.Sort(["v", "w"], [V.SortOrder.DESC, V.SortOrder.ASC])
+    for b in ref_batches[:40]:
+        srt.next(b)
+    part = pa.Table.from_batches(ref_batches[:40]).combine_chunks()
+    exp = part.take(pc.sort_indices(part, sort_keys=[("v", "descending"), ("w", "ascending")]))      # (NULLs at the end: the default)
+    util.assert_batches_equal(srt.sorted(), exp.to_batches()[0], what="sort of small nullable batches")
+
+
 def test_a_later_batch_with_another_schema_raises_from_its_own_next():
     """Small batches wait in the wrapper and cross the boundary joined -- but only batches that cannot raise: a batch whose
     schema differs from the first batch's goes through in the call that brought it, so what the library raises (a key column
