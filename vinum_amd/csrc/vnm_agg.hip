@@ -3921,7 +3921,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     while (tb < DP_TBITS_MAX && mp.bits - tb > 18) tb++;
     // ranges of up to 2^22 codes: ONE scatter level (at most 512 partitions) with the largest table that allows it
     if (mp.bits <= DP_TBITS_MAX + 9 && env_i64("VNM_DENSE_ONE_LEVEL", 1)) tb = std::max(DP_TBITS_MIN, std::min(DP_TBITS_MAX, mp.bits - (int)env_i64("VNM_DENSE_ONE_P", 8)));
-    if (mp.bits < 20) tb = (int)env_i64("VNM_DENSE_SMALL_TBITS", 12);   // split final pass: few partitions, long write runs in pass 1
+    if (mp.bits < 20) tb = (int)env_i64("VNM_DENSE_SMALL_TBITS", 11);   // split final pass: few partitions, long write runs in pass 1 (r03: 2^11-slot tables, G = 2e4 / 5e4 / 1e5 / 3e5: 7.4 / 6.5 / 6.3 / 6.1 -> 5.8 / 5.6 / 5.5 / 5.8 ms with the ring scatter; 2^12 was the r02 optimum)
     if (generic) {   // the table must fit 64 KB of LDS (80 KB at most: one workgroup per CU less)
         int tmax = DP_TBITS_MAX;
         while (tmax > 9 && ((size_t)dgen_slot_bytes(g) << tmax) > 64 * 1024) tmax--;   // (the generic kernels take the table size at run time)
