@@ -1443,6 +1443,67 @@ def test_dense_paths_generic_programs(program, groups, hint, monkeypatch):
         util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"dense generic {program} G={groups} hint={hint} pred={pred}")
 
 
+@pytest.mark.parametrize("program", ["sum_avg_f64", "minmax_f64_count", "sum_i64_count_star", "avg_u64"])
+@pytest.mark.parametrize("groups", [1_500_000, 40_000, 3_000], ids=["G1.5e6", "G4e4_split_final", "G3e3_lds_scan"])
+@pytest.mark.parametrize("pred", ["self", "other", "none"])
+def test_dense_paths_nullable_value_column(program, groups, pred, monkeypatch):
+    """The dense-key paths over ONE NULLABLE 8-byte input column (VN kernels): a NULL value travels as a flag next to the entry's
+    code through one or two scatter levels (or is read from the bitmap by the LDS scan) -- the row counts for COUNT(*) and makes
+    its group exist (SUM / AVG / MIN / MAX of an all-NULL group are NULL), nothing else; under `WHERE v > x` the NULL rows are
+    dropped by the filter.  Sliced batches (odd bitmap offsets are not 16-byte aligned columns: those batches take the other
+    paths, even ones the dense kernels); keys outside the sampled range spill as two lists (entries, keys of NULL-value rows);
+    a group whose values are all NULL; hint-less.  Bit-exact against the oracle."""
+    from oracle import oracle as O
+    from vinum_amd import _lib as L
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(groups + len(program) * 7 + len(pred))
+    n = 2_400_000 if groups > 1_000_000 else 1_200_000
+    k = rng.integers(0, groups, n).astype(np.int64) - groups // 3
+    blen = n // 2 + 2
+    far = []
+    for start in range(0, n, blen):
+        ln = min(blen, n - start)
+        m = min(ln, 1 << 18)
+        unsampled = np.setdiff1d(np.arange(ln), (np.arange(m, dtype=np.int64) * ln) // m)
+        pick = start + unsampled[:: max(1, len(unsampled) // 9)][:9]
+        k[pick] = 10**9 + start + (np.arange(len(pick)) % 3)
+        far.extend(pick.tolist())
+    null = rng.random(n) < 0.12
+    null[far[::2]] = True                      # NULL-value rows among the keys that spill
+    null[far[1::2]] = False
+    null[k == (groups // 2 - groups // 3)] = True   # a group with nothing but NULLs
+    if program in ("sum_avg_f64", "minmax_f64_count"):
+        vals = rng.integers(-2**14, 2**14, n).astype(np.float64) / 128.0
+        funcs = ([(O.SUM, "v", "s"), (O.AVG, "v", "a")] if program == "sum_avg_f64"
+                 else [(O.MIN, "v", "lo"), (O.MAX, "v", "hi"), (O.COUNT, "v", "c")])
+    elif program == "sum_i64_count_star":
+        vals = rng.integers(-2**40, 2**40, n).astype(np.int64)
+        funcs = [(O.SUM, "v", "s"), (O.COUNT, "v", "c"), (O.COUNT_STAR, "", "n")]
+    else:
+        vals = rng.integers(0, 2**63, n).astype(np.uint64) * np.uint64(2) + np.uint64(1)
+        funcs = [(O.AVG, "v", "a"), (O.COUNT_STAR, "", "n")]
+    if pred == "self" and vals.dtype != np.float64:
+        pytest.skip("the fused predicate compares float64 columns")
+    cols = {"k": pa.array(k), "v": pa.array(vals, mask=null), "p": pa.array(rng.integers(0, 2**12, n).astype(np.float64) / 64.0)}
+    t = pa.table(cols)
+    batches = util.sliced_batches(t, blen)
+    predicate = {"self": ("v", ">", -20.0), "other": ("p", ">", 20.0), "none": None}[pred]
+    L.lib().vnm_set_profiling(1)
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=predicate)
+    ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+    L.lib().vnm_profile_query(b"agg_part_scatter1", ctypes.byref(ms), ctypes.byref(cnt))
+    L.lib().vnm_set_profiling(0)
+    if groups > 3_000:
+        assert cnt.value >= 1, "the dense scatter did not run over the nullable column"
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    names = t.schema.names
+    for b in batches:
+        if predicate:
+            b = O.filter_batch(b, O.cmp_mask(b.column(names.index(predicate[0])), O.GT, predicate[2]))
+        o.next(b)
+    util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"dense nullable {program} G={groups} pred={pred}")
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS", "96")))))
 def test_random_hot_shape_paths_vs_oracle(seed, monkeypatch):
     """Seeded differential test of the north-star shape (int64 / uint64 key, float64 value, sum / avg / count, optional

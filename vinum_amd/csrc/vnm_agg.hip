@@ -3282,6 +3282,21 @@ struct UnzipArgs {
     int widths[6];
     unsigned long long* valid[6];   // nullptr: the column had no bitmap
 };
+// The two spill lists of the dense path over a nullable value column -> columns: rows [0, n_ent) are the (key, value) entries,
+// rows [n_ent, n_ent + n_null) the keys whose value is NULL; `valid` = the value column's validity bitmap (64 rows per word).
+__global__ __launch_bounds__(256) void dense_vn_unzip_kernel(const ulonglong2* ent, int64_t n_ent, const uint64_t* nkeys, int64_t n_null,
+                                                             uint64_t* key, uint64_t* val, unsigned long long* valid) {
+    const int64_t n = n_ent + n_null;
+    const int64_t n64 = (n + 63) & ~63LL;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n64; i += (int64_t)gridDim.x * 256) {
+        bool ok = false;
+        if (i < n_ent) { const ulonglong2 e = ent[i]; key[i] = e.x; val[i] = e.y; ok = true; }
+        else if (i < n) { key[i] = nkeys[i - n_ent]; val[i] = 0; }
+        const unsigned long long b = __ballot(ok);
+        if ((threadIdx.x & 63) == 0) valid[i >> 6] = b;
+    }
+}
+
 __global__ __launch_bounds__(256) void spill_unzip_kernel(UnzipArgs u) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     const int64_t n64 = (u.n + 63) / 64 * 64;   // whole waves: the ballots below cover 64 consecutive entries
@@ -3677,13 +3692,17 @@ bool dgen_program(const vnm_agg* h, const AggArgs& a, DGenArgs* g) {
 inline int dgen_slot_bytes(const DGenArgs& g) { return 8 * g.n_lds + 4; }
 
 // Ranges of at most 2^13 codes: one scan with the whole table in LDS.  Same return convention as the partitioned variant.
-int dense_scan_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s, ulonglong2** spill_out, int64_t* n_spill_out, bool generic = false) {
+int dense_scan_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s, ulonglong2** spill_out, int64_t* n_spill_out, bool generic = false,
+                         uint64_t** nspill_out = nullptr, int64_t* n_nspill_out = nullptr) {
     const int cus = device_info().num_cus;
     if (h->dmap.bits != DP_TBITS_MAX) return 2;
     const int block = 1024;
+    if (nspill_out) { *nspill_out = nullptr; *n_nspill_out = 0; }
     if (generic) {
         DGenArgs g{};
         if (!dgen_program(h, a, &g)) return 2;
+        const bool vn = g.has_val && a.cols[0].validity != nullptr;   // nullable value column
+        if (vn && !nspill_out) return 2;
         // the largest table (<= 2^13 slots) that fits 144 KB of LDS must hold the sampled range
         int tb = DP_TBITS_MAX;
         while (tb > 9 && ((size_t)dgen_slot_bytes(g) << tb) > 144 * 1024) tb--;
@@ -3699,10 +3718,12 @@ int dense_scan_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_
         uint32_t* pc = (uint32_t*)pool.take((size_t)grid * slots * 4);
         const int64_t spill_cap = nrows / 2 + (1 << 20);
         ulonglong2* spill = (ulonglong2*)pool.take((size_t)spill_cap * 16);
+        const int64_t nspill_cap = vn ? nrows / 4 + (1 << 20) : 0;
+        uint64_t* nspill = vn ? (uint64_t*)pool.take((size_t)nspill_cap * 8) : nullptr;
         const int64_t dstride = slots + 2;
         uint64_t* rk = (uint64_t*)pool.take((size_t)dstride * 8 * 2);
         uint64_t* ra = (uint64_t*)pool.take((size_t)dstride * 8 * std::max(1, h->plan.n_words));
-        if (!flags || !pw || !pc || !spill || !rk || !ra) return 1;
+        if (!flags || !pw || !pc || !spill || !rk || !ra || (vn && !nspill)) return 1;
         VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
         g.map = h->dmap; g.map.mul = 1; g.map.mul_inv = 1;
         if (tb != DP_TBITS_MAX) {   // a smaller table: centre the sampled range in it
@@ -3718,11 +3739,15 @@ int dense_scan_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_
         g.has_pred = h->pred_set; g.pred_is_v = a.hot_pred_is_v; g.op = a.p.op; g.thr = a.p.dval;
         g.nrows = nrows;
         g.spill = spill; g.spill_cap = spill_cap;
+        if (vn) { g.vvalid = a.cols[0].validity; g.voff = a.cols[0].offset; g.nspill = nspill; g.nspill_cap = nspill_cap; }
         g.dkey = rk; g.dacc = ra; g.dstride = dstride; g.flags = flags;
         g.nfinal = 1; g.splits = grid; g.part_w = pw; g.part_cnt = pc;
         {
             KernelTimer timer("agg_scan", s);
-            if (g.has_val) {
+            if (vn) {
+                VNM_HIP(hipFuncSetAttribute((const void*)dgen_scan_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                dgen_scan_kernel<true, true><<<grid, block, lds, s>>>(g);
+            } else if (g.has_val) {
                 VNM_HIP(hipFuncSetAttribute((const void*)dgen_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 dgen_scan_kernel<true><<<grid, block, lds, s>>>(g);
             } else {
@@ -3732,13 +3757,14 @@ int dense_scan_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_
             dgen_merge_kernel<<<std::max(1, slots / 512), 512, 0, s>>>(g);
         }
         VNM_HIP(hipGetLastError());
-        unsigned long long fl[3];
-        VNM_HIP(hipMemcpyAsync(fl, flags, 24, hipMemcpyDeviceToHost, s));
+        unsigned long long fl[4];
+        VNM_HIP(hipMemcpyAsync(fl, flags, 32, hipMemcpyDeviceToHost, s));
         VNM_HIP(hipStreamSynchronize(s));
         if (fl[0]) return 2;
         if (fl[2]) { pool.keep(spill); *spill_out = spill; *n_spill_out = (int64_t)fl[2]; }
         else { *spill_out = nullptr; *n_spill_out = 0; }
-        if ((int64_t)fl[2] > nrows / 16) h->dense_state = -1;
+        if (vn && fl[3]) { pool.keep(nspill); *nspill_out = nspill; *n_nspill_out = (int64_t)fl[3]; }
+        if ((int64_t)(fl[2] + fl[3]) > nrows / 16) h->dense_state = -1;
         pool.keep(rk); pool.keep(ra);
         h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
         h->run_dir = nullptr; h->run_nfin = 0;
@@ -3907,13 +3933,17 @@ int complete_pending(vnm_agg* h, hipStream_t s, int out = DF_RUN, const DFinalAr
 }
 
 // returns 0 = done (run stored), 2 = not applicable / failed (caller continues with the hash-partitioned path), 1 = error
+// (nspill_out / n_nspill_out: keys of NULL-value rows that found no place -- nullable value column, generic programs only)
 int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s, ulonglong2** spill_out, int64_t* n_spill_out,
-                                bool generic = false) {
+                                bool generic = false, uint64_t** nspill_out = nullptr, int64_t* n_nspill_out = nullptr) {
     const int cus = device_info().num_cus;
     const DenseMap& mp = h->dmap;
     DGenArgs g{};
     if (generic && !dgen_program(h, a, &g)) return 2;
     const bool has_val = generic ? g.has_val != 0 : true;
+    const bool vn = generic && has_val && a.cols[0].validity != nullptr;   // nullable value column: NULL flags travel with the entries
+    if (vn && (!nspill_out || a.has_expr)) return 2;
+    if (nspill_out) { *nspill_out = nullptr; *n_nspill_out = 0; }
     // slots per final partition: the largest table that still leaves >= 2048 final partitions (8 per CU)
     int tb = (int)env_i64("VNM_DENSE_TBITS", 12);
     tb = std::max(DP_TBITS_MIN, std::min(DP_TBITS_MAX, tb));
@@ -3961,10 +3991,13 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     uint32_t* n1 = (uint32_t*)pool_alloc((size_t)np1 * grid1 * 4);
     const int64_t spill_cap = nrows / 2 + (1 << 20);
     ulonglong2* spill = (ulonglong2*)pool_alloc((size_t)spill_cap * 16);
+    const int64_t nspill_cap = vn ? nrows / 4 + (1 << 20) : 0;
+    uint64_t* nspill = vn ? (uint64_t*)pool_alloc((size_t)nspill_cap * 8) : nullptr;
+    PoolSlotGuard<uint64_t> nspill_guard(&nspill);   // handed to the caller only on success (below)
     double* v2 = nullptr; void* c2 = nullptr; uint32_t* n2 = nullptr;
     uint64_t* rk = nullptr; uint64_t* ra = nullptr;
     auto release = [&]() { pool_free(flags); pool_free(v1); pool_free(c1); pool_free(n1); pool_free(v2); pool_free(c2); pool_free(n2); };
-    if (!flags || !v1 || !c1 || !n1 || !spill) { release(); pool_free(spill); return 1;}
+    if (!flags || !v1 || !c1 || !n1 || !spill || (vn && !nspill)) { release(); pool_free(spill); return 1;}
     VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
     DPartArgs d1{};
     d1.map = mp;
@@ -3985,6 +4018,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     // slightly worse, so it stays off there.  In pass 2 itself such stores cost 0.3 ms.  (VNM_DENSE_NT: bit 0 pass 1, bit 1 pass 2)
     d1.nt_store = (int)env_i64("VNM_DENSE_NT", levels == 2 && np2 >= 256 ? 1 : 0) & 1;
     d1.flags = flags; d1.spill = spill; d1.spill_cap = spill_cap;
+    if (vn) { d1.vvalid = a.cols[0].validity; d1.voff = a.cols[0].offset; d1.nspill = nspill; d1.nspill_cap = nspill_cap; }
     // ring-buffer scatter (dring_scatter_kernel): whole 16-entry blocks only.  Ring capacity = what fits 128 KB of LDS, at
     // most 64 entries per partition; fan-outs that leave less than two blocks per ring keep the tile-sorting kernel.
     const int use_ring = (int)env_i64("VNM_DENSE_RING", 3);   // bit 0: pass 1, bit 1: pass 2
@@ -3998,28 +4032,39 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         return cap >= 2 * DR_FB ? cap : 0;
     };
     int ring_pairs = (int)env_i64("VNM_DENSE_RING_PAIRS", 4);   // pass 1; pass 2 (every entry survives, more partitions): VNM_DENSE_RING_PAIRS2
-#define VNM_DRING_B(FR_, CT_, HV_, BLK_, PR_, PV_, GRID_, ARGS_, CAP_)                                                   \
+#define VNM_DRING_B(FR_, CT_, HV_, BLK_, PR_, PV_, VN_, GRID_, ARGS_, CAP_)                                              \
     do {                                                                                                                \
         const size_t lds_ = (((size_t)(ARGS_).nparts * (CAP_) * ((HV_ ? 8 : 0) + sizeof(CT_))) + 15) & ~(size_t)15;       \
-        VNM_HIP(hipFuncSetAttribute((const void*)dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
-        dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_><<<GRID_, BLK_, lds_, s>>>(ARGS_, CAP_);                      \
+        VNM_HIP(hipFuncSetAttribute((const void*)dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+        dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_><<<GRID_, BLK_, lds_, s>>>(ARGS_, CAP_);                 \
     } while (0)
-#define VNM_DRING_P(FR_, CT_, HV_, PV_, GRID_, ARGS_, CAP_)                                                              \
+#define VNM_DRING_P(FR_, CT_, HV_, PV_, VN_, GRID_, ARGS_, CAP_)                                                         \
     do {                                                                                                                \
-        if (ring_pairs >= 4 && !PV_) VNM_DRING_B(FR_, CT_, HV_, 1024, 4, PV_, GRID_, ARGS_, CAP_);                       \
-        else if (ring_pairs >= 2) VNM_DRING_B(FR_, CT_, HV_, 1024, 2, PV_, GRID_, ARGS_, CAP_);                          \
-        else VNM_DRING_B(FR_, CT_, HV_, 1024, 1, PV_, GRID_, ARGS_, CAP_);                                               \
+        if (ring_pairs >= 4 && !PV_) VNM_DRING_B(FR_, CT_, HV_, 1024, 4, PV_, VN_, GRID_, ARGS_, CAP_);                  \
+        else if (ring_pairs >= 2) VNM_DRING_B(FR_, CT_, HV_, 1024, 2, PV_, VN_, GRID_, ARGS_, CAP_);                     \
+        else VNM_DRING_B(FR_, CT_, HV_, 1024, 1, PV_, VN_, GRID_, ARGS_, CAP_);                                          \
     } while (0)
     // (a predicate column of its own: three loads per pair of rows, at most two pairs per lane and sub-tile fit the registers)
 #define VNM_DRING(FR_, CT_, HV_, GRID_, ARGS_, CAP_)                                                                     \
     do {                                                                                                                \
-        if (FR_ && (ARGS_).has_pred && !(ARGS_).pred_is_v) VNM_DRING_P(FR_, CT_, HV_, FR_, GRID_, ARGS_, CAP_);           \
-        else VNM_DRING_P(FR_, CT_, HV_, false, GRID_, ARGS_, CAP_);                                                      \
+        if (FR_ && (ARGS_).has_pred && !(ARGS_).pred_is_v) VNM_DRING_P(FR_, CT_, HV_, FR_, false, GRID_, ARGS_, CAP_);    \
+        else VNM_DRING_P(FR_, CT_, HV_, false, false, GRID_, ARGS_, CAP_);                                               \
+    } while (0)
+    // pass 1 over a nullable value column
+#define VNM_DRING_VN(CT_, GRID_, ARGS_, CAP_)                                                                            \
+    do {                                                                                                                \
+        if ((ARGS_).has_pred && !(ARGS_).pred_is_v) VNM_DRING_P(true, CT_, true, true, true, GRID_, ARGS_, CAP_);         \
+        else VNM_DRING_P(true, CT_, true, false, true, GRID_, ARGS_, CAP_);                                              \
     } while (0)
     const int rcap1 = (use_ring & 1) && !a.has_expr ? ring_cap_for(np1, (has_val ? 8 : 0) + (c16_1 ? 2 : 4)) : 0;
     {
         KernelTimer timer("agg_part_scatter1", s);
-        if (rcap1) {
+        if (rcap1 && vn) {
+            if (c16_1) VNM_DRING_VN(uint16_t, grid1, d1, rcap1); else VNM_DRING_VN(uint32_t, grid1, d1, rcap1);
+        } else if (vn) {
+            if (c16_1) dpart_scatter_kernel<true, uint16_t, true, true><<<grid1, PT_BLOCK, 0, s>>>(d1);
+            else dpart_scatter_kernel<true, uint32_t, true, true><<<grid1, PT_BLOCK, 0, s>>>(d1);
+        } else if (rcap1) {
             if (has_val) { if (c16_1) VNM_DRING(true, uint16_t, true, grid1, d1, rcap1); else VNM_DRING(true, uint32_t, true, grid1, d1, rcap1); }
             else { if (c16_1) VNM_DRING(true, uint16_t, false, grid1, d1, rcap1); else VNM_DRING(true, uint32_t, false, grid1, d1, rcap1); }
         } else if (has_val) {
@@ -4050,6 +4095,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         d2.out_vals = v2; d2.out_codes = c2; d2.out_counts = n2; d2.out_cap = cap2;
         d2.nparts = np2; d2.out_bits = tb;
         d2.flags = flags; d2.spill = spill; d2.spill_cap = spill_cap;
+        d2.nspill = nspill; d2.nspill_cap = nspill_cap;
         d2.nt_store = ((int)env_i64("VNM_DENSE_NT", 0) >> 1) & 1;
         const int rcap2 = (use_ring & 2) ? ring_cap_for(np2, (has_val ? 8 : 0) + 2) : 0;
         ring_pairs = (int)env_i64("VNM_DENSE_RING_PAIRS2", 2);
@@ -4062,6 +4108,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         VNM_HIP(hipGetLastError());
         fin_v = v2; fin_c = c2; fin_n = n2; fin_cap = cap2; fin_regions = split2;
     }
+#undef VNM_DRING_VN
 #undef VNM_DRING
 #undef VNM_DRING_P
 #undef VNM_DRING_B
@@ -4176,21 +4223,22 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         VNM_TRY(launch_dense_final(df, tb, DF_RUN, false, s));
     }
     VNM_HIP(hipGetLastError());
-    unsigned long long fl[3];
-    VNM_HIP(hipMemcpyAsync(fl, flags, 24, hipMemcpyDeviceToHost, s));
+    unsigned long long fl[4];
+    VNM_HIP(hipMemcpyAsync(fl, flags, 32, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
     release();
     pool_free(psum); pool_free(plo); pool_free(pcnt);
     if (getenv("VNM_AGG_TRACE"))
-        fprintf(stderr, "[agg] dense%s: bits %d tb %d levels %d p1 %d p2 %d splits %d -> fail %llu groups %llu spilled %llu (dstride %lld)\n", generic ? " generic" : "",
-                mp.bits, tb, levels, p1, p2, fsplits, fl[0], fl[1], fl[2], (long long)dstride);
+        fprintf(stderr, "[agg] dense%s%s: bits %d tb %d levels %d p1 %d p2 %d splits %d -> fail %llu groups %llu spilled %llu + %llu NULL-value rows (dstride %lld)\n",
+                generic ? " generic" : "", vn ? " nullable" : "", mp.bits, tb, levels, p1, p2, fsplits, fl[0], fl[1], fl[2], fl[3], (long long)dstride);
     if (fl[0]) {  // spill buffer full, dense output too small, or a compensation term beyond float range
         pool_free(rk); pool_free(ra); pool_free(spill);
         return 2;
     }
     if (fl[2]) { *spill_out = spill; *n_spill_out = (int64_t)fl[2]; }
     else { pool_free(spill); *spill_out = nullptr; *n_spill_out = 0; }
-    if ((int64_t)fl[2] > nrows / 16) h->dense_state = -1;  // the sampled range does not describe the data: stop trying
+    if (vn && fl[3]) { *nspill_out = nspill; *n_nspill_out = (int64_t)fl[3]; nspill = nullptr; }
+    if ((int64_t)(fl[2] + fl[3]) > nrows / 16) h->dense_state = -1;  // the sampled range does not describe the data: stop trying
     h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
     h->run_dir = nullptr; h->run_nfin = 0;
     h->have_run = true;
@@ -5052,7 +5100,12 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     // lower bound is enough (span <= 32 G: the direct-addressed slots are reasonably filled) and the HyperLogLog pass
     // (0.85 ms) is skipped; the hash-partitioned path below still estimates properly if the dense attempt fails.
     // (generic programs: only where the spilled entries -- keys outside the sampled range -- have a kernel to go to)
-    const bool dense_generic = !hot && narrow_generic && hot_scan && !hot_two && !hot_vnull && !a.has_expr &&
+    // ... and ONE nullable 8-byte input column (hot_vnull; the predicate column, if any, without NULLs or that column itself): the
+    // entries carry a NULL flag next to the code (vnm_agg_dense.inc, VN kernels); what the dense pass cannot place comes back as
+    // two lists (entries, keys of NULL-value rows) and goes through the scan below as columns
+    const bool dense_vn = !hot && hot_scan && hot_vnull && !hot_two && !a.has_expr && part_ok && h->plan.n_cols == 1 &&
+                          getenv("VNM_AGG_NO_DENSE_VN") == nullptr;
+    const bool dense_generic = ((!hot && narrow_generic && hot_scan && !hot_two && !hot_vnull && !a.has_expr) || dense_vn) &&
                                getenv("VNM_AGG_NO_DENSE_GENERIC") == nullptr && getenv("VNM_AGG_NO_SPILL") == nullptr;
     const bool dense_base = (hot || dense_generic) && part_ok && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
                             getenv("VNM_AGG_NO_DENSE") == nullptr;
@@ -5092,10 +5145,32 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     }
     ulonglong2* spill = nullptr;  // entries the partitioned / dense paths could not place (heavy keys, keys outside the sampled range): aggregated below
     int64_t n_spill = 0;
+    uint64_t* nspill = nullptr;   // dense path over a nullable value column: keys of the NULL-value rows it could not place
+    int64_t n_nspill = 0;
+    bool scan_no_pred = false;    // ... whose rows come back as columns with the predicate already applied
     unsigned int* progress = nullptr;
     PoolScope unzip;   // spilled wide entries as columns
     PoolSlotGuard<ulonglong2> spill_guard(&spill);       // both go back to the pool on every way out of this function
+    PoolSlotGuard<uint64_t> nspill_guard(&nspill);
     PoolSlotGuard<unsigned int> progress_guard(&progress);
+    // the two spill lists of the nullable dense path -> key / value / validity columns for the scan below
+    auto vn_spill_to_columns = [&]() -> int {
+        const int64_t n = n_spill + n_nspill;
+        uint64_t* uk = (uint64_t*)unzip.take((size_t)n * 8);
+        uint64_t* uv = (uint64_t*)unzip.take((size_t)n * 8);
+        unsigned long long* ub = (unsigned long long*)unzip.take((size_t)((n + 63) / 64) * 8);
+        if (!uk || !uv || !ub) return 1;
+        const int ugrid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_info().num_cus * 8);
+        dense_vn_unzip_kernel<<<ugrid, 256, 0, s>>>(spill, n_spill, nspill, n_nspill, uk, uv, ub);
+        VNM_HIP(hipGetLastError());
+        a.keys[0].values = uk; a.keys[0].validity = nullptr; a.keys[0].offset = 0; a.keys[0].length = n;
+        a.cols[0].values = uv; a.cols[0].validity = (const uint8_t*)ub; a.cols[0].offset = 0; a.cols[0].length = n;
+        a.ent = nullptr;
+        a.nrows = n;
+        a.p.enabled = 0;
+        scan_no_pred = true;
+        return 0;
+    };
     // a few hundred to a few thousand groups in a small key range: the direct-addressed LDS scan (vnm_agg_dense.inc)
     bool dscan_done = false;
     if (dense_shape && !dense_go && h->hint >= env_i64("VNM_DSCAN_MIN_GROUPS", 128) && h->hint <= (1 << DP_TBITS_MAX) &&
@@ -5107,13 +5182,16 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         if (h->dense_state == 2) {
             if (h->pending) VNM_TRY(complete_pending(h, s));   // (this path makes a run of its own)
             if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
-            int prc = dense_scan_aggregate(h, a, nrows, s, &spill, &n_spill, dense_generic);
+            int prc = dense_scan_aggregate(h, a, nrows, s, &spill, &n_spill, dense_generic, &nspill, &n_nspill);
             // a generic program whose table for this range does not fit LDS: the same 2^13 codes through one scatter level
             // (four partitions of 2^11 slots, split final pass) instead
-            if (prc == 2 && dense_generic && h->dense_state == 2) prc = dense_partitioned_aggregate(h, a, nrows, s, &spill, &n_spill, true);
+            if (prc == 2 && dense_generic && h->dense_state == 2) prc = dense_partitioned_aggregate(h, a, nrows, s, &spill, &n_spill, true, &nspill, &n_nspill);
             if (prc == 1) return 1;
-            if (prc == 0 && !spill) { h->rows_seen += nrows; return 0; }
-            if (prc == 0) {  // the scan below runs over the spilled entries only (predicate already applied)
+            if (prc == 0 && !spill && !nspill) { h->rows_seen += nrows; return 0; }
+            if (prc == 0 && dense_vn) {
+                VNM_TRY(vn_spill_to_columns());
+                dscan_done = true;
+            } else if (prc == 0) {  // the scan below runs over the spilled entries only (predicate already applied)
                 a.ent = spill;
                 a.nrows = n_spill;
                 a.p.enabled = 0;
@@ -5132,6 +5210,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         const bool spill_wide = a.part_wide && h->single && !a.has_expr && getenv("VNM_AGG_NO_SPILL") == nullptr && getenv("VNM_AGG_NO_WIDE_SPILL") == nullptr;
         const bool can_spill = (hot_scan && !hot_two && !hot_vnull && getenv("VNM_AGG_NO_SPILL") == nullptr) || spill_wide;
         int prc = 2;
+        bool vn_spill = false;        // the spill lists of the nullable dense path (entries + keys of NULL-value rows)
         bool spill_is_wide = false;   // the spill holds [n][E]-word entries of the wide scatter kernels (not the (key, value) pairs of the hot / dense paths)
         auto run_partitioned = [&]() {
             if (h->pending && complete_pending(h, s)) return 1;     // (the hash-partitioned path makes a run of its own)
@@ -5141,7 +5220,8 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
             return r;
         };
         if (dense_go && (h->hint > part_min || h->hint == 0)) {
-            prc = dense_partitioned_aggregate(h, a, nrows, s, &spill, &n_spill, dense_generic);
+            prc = dense_partitioned_aggregate(h, a, nrows, s, &spill, &n_spill, dense_generic, &nspill, &n_nspill);
+            vn_spill = prc == 0 && dense_vn && (spill || nspill);
             if (prc == 2 && h->hint == 0) {  // the dense attempt failed before G was ever estimated
                 int64_t est = 0;
                 VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s));
@@ -5167,9 +5247,11 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
             h->hint = std::min<int64_t>(std::max<int64_t>(h->hint * 4, est + est / 4), (int64_t)1600 * env_i64("VNM_AGG_PART_L1_MAX", 256) * 512);
             prc = run_partitioned();
         }
-        if (prc == 0 && !spill) { h->rows_seen += nrows; return 0; }
+        if (prc == 0 && !spill && !nspill) { h->rows_seen += nrows; return 0; }
         if (prc == 1) return 1;
-        if (prc == 0 && spill_is_wide) {   // spilled wide entries -> columns; the general scan takes them as a batch of its own
+        if (prc == 0 && vn_spill) {
+            VNM_TRY(vn_spill_to_columns());
+        } else if (prc == 0 && spill_is_wide) {   // spilled wide entries -> columns; the general scan takes them as a batch of its own
             const int E = 1 + h->plan.n_cols + (a.part_vmask ? 1 : 0);
             UnzipArgs u{};
             u.ent = (const uint64_t*)spill; u.n = n_spill; u.E = E; u.nval = h->plan.n_cols; u.has_vmask = a.part_vmask;
@@ -5243,7 +5325,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         VNM_HIP(hipFuncSetAttribute((const void*)agg_hot_kernel<P, V, true, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
         agg_hot_kernel<P, V, true, false, false, false, true><<<grid, AGG_BLOCK, lds_bytes, s>>>(a);           \
     } while (0)
-                if (!h->pred_set) VNM_HOTN(false, false);
+                if (!h->pred_set || scan_no_pred) VNM_HOTN(false, false);
                 else if (a.hot_pred_is_v) VNM_HOTN(true, true);
                 else VNM_HOTN(true, false);
 #undef VNM_HOTN
