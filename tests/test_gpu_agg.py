@@ -1504,6 +1504,42 @@ def test_dense_paths_nullable_value_column(program, groups, pred, monkeypatch):
     util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"dense nullable {program} G={groups} pred={pred}")
 
 
+@pytest.mark.parametrize("program", ["hot", "minmax_count_star", "nullable_sum"])
+@pytest.mark.parametrize("groups", [1_500_000, 40_000], ids=["G1.5e6_two_levels", "G4e4_one_level"])
+@pytest.mark.parametrize("power", [4.0, 12.0])
+def test_dense_paths_skewed_keys(program, groups, power, monkeypatch):
+    """Skewed keys on the dense path: k = floor(G u^p) (p = 4: the first key holds ~3 % of the rows and hundreds of keys far more
+    than an even share; p = 12: ~30 % of the rows in one key).  The ring scatter gives a sub-tile two insert / flush rounds
+    and then spills what is still pending with ONE reservation per workgroup (1 round once a workgroup has spilled); full
+    regions spill whole blocks with one reservation per wave.  Hot shape (deferred final pass + spilled entries in the HBM table),
+    a generic program, and a nullable value column (NULL flags in the spilled entries: the two-list route).  Two batches;
+    bit-exact against the oracle."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(int(groups + power * 10 + len(program)))
+    n = 2_400_000
+    k = np.floor(groups * rng.random(n) ** power).astype(np.int64) + 5
+    v = rng.integers(-2**14, 2**14, n).astype(np.float64) / 128.0
+    mask = None
+    if program == "hot":
+        funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.COUNT_STAR, "", "n")]
+    elif program == "minmax_count_star":
+        funcs = [(O.MIN, "v", "lo"), (O.MAX, "v", "hi"), (O.COUNT_STAR, "", "n")]
+    else:
+        funcs = [(O.SUM, "v", "s"), (O.COUNT, "v", "c"), (O.COUNT_STAR, "", "n")]
+        mask = rng.random(n) < 0.2
+    t = pa.table({"k": pa.array(k), "v": pa.array(v, mask=mask)})
+    batches = util.sliced_batches(t, n // 2)
+    for predicate in (("v", ">", -40.0), None):
+        got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=predicate)
+        o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+        for b in batches:
+            if predicate:
+                b = O.filter_batch(b, O.cmp_mask(b.column(1), O.GT, predicate[2]))
+            o.next(b)
+        util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"skewed {program} G={groups} p={power} pred={predicate}")
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS", "96")))))
 def test_random_hot_shape_paths_vs_oracle(seed, monkeypatch):
     """Seeded differential test of the north-star shape (int64 / uint64 key, float64 value, sum / avg / count, optional

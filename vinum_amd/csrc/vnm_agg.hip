@@ -4031,17 +4031,29 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         if (np < env_i64("VNM_DENSE_RING_MIN_NP", 32)) return 0;
         return cap >= 2 * DR_FB ? cap : 0;
     };
+    const bool ring_limit = env_i64("VNM_DENSE_RING_LIMIT", 1) != 0;   // spill what two insert / flush rounds of a sub-tile leave pending (skew)
     int ring_pairs = (int)env_i64("VNM_DENSE_RING_PAIRS", 4);   // pass 1; pass 2 (every entry survives, more partitions): VNM_DENSE_RING_PAIRS2
 #define VNM_DRING_B(FR_, CT_, HV_, BLK_, PR_, PV_, VN_, GRID_, ARGS_, CAP_)                                              \
     do {                                                                                                                \
         const size_t lds_ = (((size_t)(ARGS_).nparts * (CAP_) * ((HV_ ? 8 : 0) + sizeof(CT_))) + 15) & ~(size_t)15;       \
-        VNM_HIP(hipFuncSetAttribute((const void*)dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
-        dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_><<<GRID_, BLK_, lds_, s>>>(ARGS_, CAP_);                 \
+        /* round limit (skew): two insert / flush rounds per sub-tile, where an even spread of a sub-tile's entries (every */ \
+        /* row surviving) fits ONE */                                                                                   \
+        if (2 * PR_ * BLK_ <= (ARGS_).nparts * ((CAP_) - DR_FB) && ring_limit) {                                        \
+            VNM_HIP(hipFuncSetAttribute((const void*)dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+            dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 2><<<GRID_, BLK_, lds_, s>>>(ARGS_, CAP_);          \
+        } else {                                                                                                        \
+            VNM_HIP(hipFuncSetAttribute((const void*)dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+            dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 0><<<GRID_, BLK_, lds_, s>>>(ARGS_, CAP_);          \
+        }                                                                                                               \
     } while (0)
+    // sub-tile = the largest of 4 / 2 / 1 pairs of rows per lane (at most ring_pairs) whose entries, evenly spread, fit one round
+    // of the rings: the round limit then applies (64 partitions: 2 pairs, 32: 1 pair)
 #define VNM_DRING_P(FR_, CT_, HV_, PV_, VN_, GRID_, ARGS_, CAP_)                                                         \
     do {                                                                                                                \
-        if (ring_pairs >= 4 && !PV_) VNM_DRING_B(FR_, CT_, HV_, 1024, 4, PV_, VN_, GRID_, ARGS_, CAP_);                  \
-        else if (ring_pairs >= 2) VNM_DRING_B(FR_, CT_, HV_, 1024, 2, PV_, VN_, GRID_, ARGS_, CAP_);                     \
+        int pr_ = ring_pairs >= 4 && !PV_ ? 4 : (ring_pairs >= 2 ? 2 : 1);                                              \
+        while (ring_limit && pr_ > 1 && 2 * pr_ * 1024 > (ARGS_).nparts * ((CAP_) - DR_FB)) pr_ >>= 1;                  \
+        if (pr_ == 4 && !PV_) VNM_DRING_B(FR_, CT_, HV_, 1024, 4, PV_, VN_, GRID_, ARGS_, CAP_);                         \
+        else if (pr_ >= 2) VNM_DRING_B(FR_, CT_, HV_, 1024, 2, PV_, VN_, GRID_, ARGS_, CAP_);                            \
         else VNM_DRING_B(FR_, CT_, HV_, 1024, 1, PV_, VN_, GRID_, ARGS_, CAP_);                                          \
     } while (0)
     // (a predicate column of its own: three loads per pair of rows, at most two pairs per lane and sub-tile fit the registers)
