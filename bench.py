@@ -333,6 +333,45 @@ def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream,
                                   "instead of the finalised key / sum / avg columns of the headline; input resident in HBM", n, ms, sp,
                                   16.0 * n + 24.0 * state["ng"], state["ng"])
     state.clear()
+    # ---- BASELINE.md section 3's "+- 1 % nulls" variant of the value column: the headline query with a validity bitmap on v (a NULL
+    # fails `v > X`; the dense path reads one validity byte per pair of rows) -- and the headline query over SKEWED keys,
+    # k = floor(G u^4) (the first key ~1 % of the rows, thousands of keys far above an even share: the ring scatter's round limit)
+    try:
+        gn = torch.Generator(device=device); gn.manual_seed(11)
+        bits = torch.full(((n + 7) // 8,), 255, dtype=torch.uint8, device=device)
+        holes = torch.randint(0, (n + 7) // 8, (n // 100,), device=device, generator=gn)
+        bits[holes] = bits[holes] & ~(torch.ones_like(holes, dtype=torch.uint8) << (holes % 8).to(torch.uint8))
+        vnull = DeviceColumn(vcol.values_ptr, bits.data_ptr(), 0, n, pa.float64(), keep=(bits,))
+
+        def with_nulls():
+            agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())])
+            agg.set_predicate(">", x_thr)
+            agg.next([kcol], [vnull, vnull], pred=vnull, nrows=n, stream=stream)
+            state["cols"] = agg.result_device(stream=stream)
+            state["ng"] = agg.result_rows
+        ms, sp = _measure(torch, lib, ctypes, with_nulls, AGG_SPANS, steps, warmup + 1)
+        out["configs[2] with ~1 % NULLs in v"] = _entry("the headline query (hint-less, result columns included) over a NULLABLE value column (~1 % of the rows NULL)",
+                                                        n, ms, sp, 16.125 * n + 24.0 * state["ng"], state["ng"])
+        state.clear()
+        del vnull, bits, holes
+        u = torch.rand(n, device=device, dtype=torch.float64, generator=gn)
+        ks = (u.pow_(4.0) * groups).to(torch.int64)
+        del u
+        kscol = DeviceColumn.from_torch(ks)
+
+        def skewed():
+            agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())])
+            agg.set_predicate(">", x_thr)
+            agg.next([kscol], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
+            state["cols"] = agg.result_device(stream=stream)
+            state["ng"] = agg.result_rows
+        ms, sp = _measure(torch, lib, ctypes, skewed, AGG_SPANS, steps, warmup + 1)
+        out["configs[2] over skewed keys"] = _entry(f"the headline query (hint-less, result columns included) over keys k = floor(G u^4), u uniform, G = {groups:.3g}",
+                                                    n, ms, sp, 16.0 * n + 24.0 * state["ng"], state["ng"])
+        state.clear()
+        del kscol, ks
+    except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down
+        out["configs[2] variants"] = {"error": repr(e)}
     # ---- configs[1]
     dst = torch.empty(n, dtype=torch.float64, device=device)
     cnt = ctypes.c_int64(0)

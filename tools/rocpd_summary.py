@@ -17,12 +17,12 @@ def main():
                           f"max(s.arch_vgpr_count), max(s.sgpr_count), max(d.group_segment_size), max(d.workgroup_size_x), max(d.grid_size_x) "
                           f"from {kd} d join {ks} s on d.kernel_id = s.id group by s.display_name order by 3 desc"))
     tot = sum(r[2] for r in rows) or 1
-    print(f"{'kernel':70s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'%':>6s} vgpr sgpr  lds  wg    grid")
+    print(f"{'kernel':96s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'%':>6s} vgpr sgpr  lds  wg    grid")
     for name, n, t, mn, mx, vg, sg, lds, wg, grid in rows:
         if flt and flt not in name:
             continue
-        short = name.split("(")[0][-70:]
-        print(f"{short:70s} {n:6d} {t / 1e6:10.3f} {t / n / 1e3:10.1f} {mn / 1e3:9.1f} {mx / 1e3:9.1f} {100.0 * t / tot:6.2f} {vg:4d} {sg:4d} {lds:5d} {wg:4d} {grid:7d}")
+        short = name.split("(")[0][-96:]
+        print(f"{short:96s} {n:6d} {t / 1e6:10.3f} {t / n / 1e3:10.1f} {mn / 1e3:9.1f} {mx / 1e3:9.1f} {100.0 * t / tot:6.2f} {vg:4d} {sg:4d} {lds:5d} {wg:4d} {grid:7d}")
     try:
         pe, pi = T("rocpd_pmc_event"), T("rocpd_info_pmc")
         q = (f"select s.display_name, p.name, count(*), avg(e.value) from {pe} e join {pi} p on e.pmc_id = p.id "
@@ -33,7 +33,7 @@ def main():
             for name, ctr, n, v in pm:
                 if flt and flt not in name:
                     continue
-                print(f"{name.split('(')[0][-70:]:70s} {ctr:14s} n={n:4d} avg={v:.6g}")
+                print(f"{name.split('(')[0][-96:]:96s} {ctr:14s} n={n:4d} avg={v:.6g}")
     except Exception as e:  # no counters in this run
         pass
 

@@ -3130,13 +3130,16 @@ int table_grow(vnm_agg* h, uint64_t new_cap, hipStream_t s) {
     return 0;
 }
 
-int ensure_table(vnm_agg* h, int64_t nrows, hipStream_t s) {
+// rows_only: the rows are what a partitioned pass spilled (the groups of the batch live in its run) -- the table is sized by them,
+// not by the group count hint (a handful of spilled entries under a hint of 1e8 groups used to get a 2^28-slot table: its memset,
+// and the walk over its slots at finish, cost 2-4 ms)
+int ensure_table(vnm_agg* h, int64_t nrows, hipStream_t s, bool rows_only = false) {
     if (h->have_table) return 0;
     uint64_t cap;
     if (h->plan.n_keys == 0) cap = 2;
     else {
         uint64_t want = h->hint > 0 ? (uint64_t)h->hint * 2 : (uint64_t)1 << 22;
-        if (h->hint <= 0 && (uint64_t)nrows * 2 < want) want = (uint64_t)(nrows > 512 ? nrows : 512) * 2;
+        if ((h->hint <= 0 || rows_only) && (uint64_t)nrows * 2 < want) want = (uint64_t)(nrows > 512 ? nrows : 512) * 2;
         cap = pow2_at_least(want < 1024 ? 1024 : want);
     }
     VNM_TRY(table_alloc(h, &h->g, cap, s));
@@ -5297,7 +5300,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         }
     }
     const int64_t scan_n = a.nrows;
-    VNM_TRY(ensure_table(h, scan_n, s));
+    VNM_TRY(ensure_table(h, scan_n, s, spill != nullptr || nspill != nullptr));
     if (hot_scan) a.ntiles = (scan_n + HOT_TILE - 1) / HOT_TILE;
     const int lds_tile = AGG_TILE;
     int grid = h->single ? cus : cus * 4;
