@@ -1540,6 +1540,46 @@ def test_dense_paths_skewed_keys(program, groups, power, monkeypatch):
         util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"skewed {program} G={groups} p={power} pred={predicate}")
 
 
+@pytest.mark.parametrize("values", ["quantised", "lognormal"])
+def test_stream_table_of_small_range_batches(values, monkeypatch):
+    """A stream of batches over a small dense key range (whole-table LDS scan per batch): the batches' per-workgroup tables are
+    added into ONE table that lives across the stream (dscan_accumulate_kernel) and the groups are written once
+    (flush_scan_pending).  Seven batches: four through the stream table (keys outside the sampled range spill on the way), a tiny
+    one (general scan, the table becomes a run first), one over a SHIFTED range (another code map: flush, new table), one more of
+    the first kind.  Bit-exact against the oracle; float sums = math.fsum whatever the batch order."""
+    import math
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(5 + len(values))
+    G = 3000
+    funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.COUNT_STAR, "", "n")]
+
+    def batch(n, lo, far=0):
+        k = rng.integers(0, G, n).astype(np.int64) + lo
+        if far:
+            m = min(n, 1 << 18)
+            unsampled = np.setdiff1d(np.arange(n), (np.arange(m, dtype=np.int64) * n) // m)
+            k[unsampled[:far]] = 10**12 + np.arange(far) % 3
+        v = (rng.integers(0, 2**14, n).astype(np.float64) / 128.0) if values == "quantised" else rng.lognormal(3.0, 2.0, n) * rng.choice([-1.0, 1.0], n)
+        return pa.record_batch({"k": pa.array(k), "v": pa.array(v)})
+    batches = [batch(600_000, -1000, far=5), batch(500_000, -1000), batch(700_000, -1000, far=3), batch(600_000, -1000),
+               batch(1_000, -1000), batch(600_000, 10_000_000), batch(600_000, -1000)]
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=("v", ">", -1e300))
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in batches:
+        o.next(O.filter_batch(b, O.cmp_mask(b.column(1), O.GT, -1e300)))
+    exp = o.result()
+    if values == "quantised":
+        util.assert_agg_equal(got, exp, funcs, ["k"], what="stream table")
+    else:
+        util.assert_agg_equal(got, exp, funcs, ["k"], exact_float_inputs=(), what="stream table", source=batches)
+    # the sums are the correctly rounded exact sums, batch order or not
+    allk = np.concatenate([b.column(0).to_numpy() for b in batches]); allv = np.concatenate([b.column(1).to_numpy() for b in batches])
+    gk = got.column(0).to_numpy(zero_copy_only=False); gs = got.column(1).to_numpy(zero_copy_only=False)
+    for key in (gk[0], gk[len(gk) // 2], gk[-1]):
+        assert gs[list(gk).index(key)] == math.fsum(allv[allk == key]), key
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS", "96")))))
 def test_random_hot_shape_paths_vs_oracle(seed, monkeypatch):
     """Seeded differential test of the north-star shape (int64 / uint64 key, float64 value, sum / avg / count, optional

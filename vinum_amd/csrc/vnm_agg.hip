@@ -11,6 +11,7 @@
 // So rows are pre-aggregated in a per-workgroup LDS hash table (keys + 64-bit accumulator words that
 // merge commutatively); only table flushes touch the HBM-resident table, with agent-scope atomics.
 // The fused WHERE predicate is evaluated in the scan, so no filtered batch is ever materialised.
+#include <memory>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(BLK) void agg_lds_kernel(AggArgs a) {
     // the margin the host reserves per workgroup (one LDS table + one tile) covers everything in between.
     bool need_check = true;
     uint32_t spread = 0;
-    int spread_state = (a.debug & 4) ? 2 : 0;
+    int spread_state = ((a.debug & 4) || a.ntiles < 64 * (int64_t)gridDim.x) ? 2 : 0;   // see agg_hot_kernel
     unsigned it = a.progress[blockIdx.x];
     for (;; it++) {
         const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
@@ -737,7 +738,10 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
     double2 pv[HOT_UNROLL];
     bool have = false;
     uint32_t spread = 0;
-    int spread_state = (a.debug & 4) ? 2 : 0;  // VNM_AGG_DEBUG & 4: no key copies (measurement)
+    // (no copies for short batches either: eight copies of every key are eight times the flush's atomics on the same few HBM
+    // addresses -- ~30 us per kernel with 7 groups and 256 workgroups, a third of a 2^24-row batch's 90 us; they pay from ~64
+    // tiles per workgroup on: 59 x 2^24-row batches, G = 7: 7.6 -> 5.8 ms)
+    int spread_state = ((a.debug & 4) || a.ntiles < 64 * (int64_t)gridDim.x) ? 2 : 0;  // VNM_AGG_DEBUG & 4: no key copies (measurement)
     bool need_check = true;
     unsigned it = a.progress[blockIdx.x];
     for (;; it++) {
@@ -2988,6 +2992,17 @@ struct DensePending {
     ~DensePending() { for (void* b : blocks) pool_free(b); pool_free(table); pool_free(dsets); }
 };
 constexpr size_t DP_MAX_SETS = 512;   // batches a deferred pass may span (then it runs, as a run, and a new one starts)
+// the table a stream of small-range batches accumulates in (dscan_accumulate_kernel); groups are written by flush_scan_pending
+struct DScanPending {
+    DFinalArgs df{};   // code map + the words of the plan
+    DScanTable t{};
+    int slots = 0;
+    uint64_t* part_sum = nullptr;   // the current batch's per-workgroup tables [cus][slots] (kept: no allocation per batch)
+    float* part_lo = nullptr;
+    uint32_t* part_cnt = nullptr;
+    unsigned long long* flags = nullptr;
+    ~DScanPending() { pool_free(t.sum); pool_free(t.lo); pool_free(t.cnt); pool_free(part_sum); pool_free(part_lo); pool_free(part_cnt); pool_free(flags); }
+};
 
 struct vnm_agg {
     AggPlan plan;
@@ -3036,6 +3051,7 @@ struct vnm_agg {
     // has not run yet -- what it writes depends on who asks: another batch / finish() -> the dense partial state (a run),
     // vnm_agg_result_device_alloc -> the result columns themselves, vnm_agg_dense_table -> the tables for the multi-GPU exchange
     struct DensePending* pending = nullptr;
+    struct DScanPending* scan_pending = nullptr;   // a stream of small-range batches: their table (see dense_scan_aggregate)
     bool dense_by_bound = false;   // the first batch went dense on the sample's LOWER bound of the group count (no estimate exists)
     bool range_given = false;   // vnm_agg_set_dense_range: the code range is the caller's (agreed by all ranks), not a sample's
     // expression input (vnm_agg_set_input_expr): the functions reading plan column expr_col get an expression's value
@@ -3328,6 +3344,7 @@ __global__ __launch_bounds__(256) void spill_unzip_kernel(UnzipArgs u) {
 
 }  // namespace
 static int merge_run_into_table(vnm_agg* h, hipStream_t s);
+static int flush_scan_pending(vnm_agg* h, hipStream_t s);
 namespace {
 
 // returns 0 = done (run stored), 2 = not applicable / overflowed (caller uses the general path), 1 = error
@@ -3777,55 +3794,61 @@ int dense_scan_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_
     const int tb = DP_TBITS_MAX;
     const int slots = 1 << tb;
     const int grid = (int)std::min<int64_t>((int64_t)cus, std::max<int64_t>(1, (nrows / 2 + block - 1) / block));
-    const size_t cells = (size_t)grid * slots;
-    unsigned long long* flags = (unsigned long long*)pool_alloc(64);
-    uint64_t* psum = (uint64_t*)pool_alloc(cells * 8);
-    float* plo = (float*)pool_alloc(cells * 4);
-    uint32_t* pcnt = (uint32_t*)pool_alloc(cells * 4);
+    // The batch's per-workgroup tables are added into the table of the STREAM (h->scan_pending, dscan_accumulate_kernel); the groups
+    // are written when something else needs them (flush_scan_pending).  59 x 2^24-row batches, G = 1000: 17.1 -> 5.5 ms per 1e9 rows.
+    DenseMap map = h->dmap;
+    map.mul = 1; map.mul_inv = 1;
+    if (h->scan_pending && memcmp(&h->scan_pending->df.map, &map, sizeof(DenseMap)) != 0) VNM_TRY(flush_scan_pending(h, s));
+    const bool comp = a.hot_comp && a.hot_w_sum >= 0;
+    if (!h->scan_pending) {
+        DScanPending* sp = new DScanPending();
+        sp->slots = slots;
+        sp->df.map = map;
+        sp->df.w_rows = a.hot_w_rows; sp->df.w_valid = a.hot_w_valid; sp->df.w_sum = a.hot_w_sum;
+        sp->df.w_lo = comp ? a.hot_w_sum + 1 : -1;
+        sp->t.sum = (double*)pool_alloc((size_t)slots * 8);
+        sp->t.lo = (double*)pool_alloc((size_t)slots * 8);
+        sp->t.cnt = (unsigned long long*)pool_alloc((size_t)slots * 8);
+        sp->part_sum = (uint64_t*)pool_alloc((size_t)cus * slots * 8);
+        sp->part_lo = (float*)pool_alloc((size_t)cus * slots * 4);
+        sp->part_cnt = (uint32_t*)pool_alloc((size_t)cus * slots * 4);
+        sp->flags = (unsigned long long*)pool_alloc(64);
+        if (!sp->t.sum || !sp->t.lo || !sp->t.cnt || !sp->part_sum || !sp->part_lo || !sp->part_cnt || !sp->flags) { delete sp; return 1; }
+        if (hipMemsetAsync(sp->t.sum, 0, (size_t)slots * 8, s) != hipSuccess || hipMemsetAsync(sp->t.lo, 0, (size_t)slots * 8, s) != hipSuccess ||
+            hipMemsetAsync(sp->t.cnt, 0, (size_t)slots * 8, s) != hipSuccess) { delete sp; return set_error("aggregate: memset of the stream table failed"); }
+        h->scan_pending = sp;
+    }
+    DScanPending* sp = h->scan_pending;
     const int64_t spill_cap = nrows / 2 + (1 << 20);
     ulonglong2* spill = (ulonglong2*)pool_alloc((size_t)spill_cap * 16);
-    const int64_t dstride = slots + 2;
-    uint64_t* rk = (uint64_t*)pool_alloc((size_t)dstride * 8 * 2);
-    uint64_t* ra = (uint64_t*)pool_alloc((size_t)dstride * 8 * h->plan.n_words);
-    auto release = [&]() { pool_free(flags); pool_free(psum); pool_free(plo); pool_free(pcnt); };
-    if (!flags || !psum || !plo || !pcnt || !spill || !rk || !ra) { release(); pool_free(spill); pool_free(rk); pool_free(ra); return 1; }
-    VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
+    if (!spill) return 1;
+    PoolSlotGuard<ulonglong2> spill_guard(&spill);
+    VNM_HIP(hipMemsetAsync(sp->flags, 0, 64, s));
     DScanArgs d{};
-    d.map = h->dmap;
-    d.map.mul = 1; d.map.mul_inv = 1;
+    d.map = map;
     d.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
     d.vp = (const double*)a.cols[0].values + a.cols[0].offset;
     d.has_expr = a.has_expr; d.expr = a.expr;
     d.pp = h->pred_set ? (const double*)a.pred.values + a.pred.offset : nullptr;
     d.has_pred = h->pred_set; d.pred_is_v = a.hot_pred_is_v; d.op = a.p.op; d.thr = a.p.dval;
     d.nrows = nrows;
-    d.comp = a.hot_comp && a.hot_w_sum >= 0;
-    d.part_sum = psum; d.part_lo = plo; d.part_cnt = pcnt;
-    d.flags = flags; d.spill = spill; d.spill_cap = spill_cap;
-    DFinalArgs df{};
-    df.map = d.map;
-    df.nfinal = 1; df.splits = grid;
-    df.part_sum = psum; df.part_lo = plo; df.part_cnt = pcnt;
-    df.w_rows = a.hot_w_rows; df.w_valid = a.hot_w_valid; df.w_sum = a.hot_w_sum;
-    df.w_lo = d.comp ? a.hot_w_sum + 1 : -1;
-    df.dkey = rk; df.dacc = ra; df.dstride = dstride; df.flags = flags;
+    d.comp = comp;
+    d.part_sum = sp->part_sum; d.part_lo = sp->part_lo; d.part_cnt = sp->part_cnt;
+    d.flags = sp->flags; d.spill = spill; d.spill_cap = spill_cap;
+    unsigned long long fl[3];
     {
         KernelTimer timer("agg_scan", s);
         dscan_kernel<DP_TBITS_MAX><<<grid, block, 0, s>>>(d);
-        dpart_merge_kernel<<<1 << (tb - 9), 512, 0, s>>>(df, tb);
+        VNM_HIP(hipGetLastError());
+        VNM_HIP(hipMemcpyAsync(fl, sp->flags, 24, hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipStreamSynchronize(s));
+        if (fl[0]) return 2;   // spill buffer full or a compensation term beyond float range: the batch goes another way, the stream's table is untouched
+        dscan_accumulate_kernel<<<slots / 64, 512, 0, s>>>(sp->part_sum, sp->part_lo, sp->part_cnt, grid, slots, sp->t);
+        VNM_HIP(hipGetLastError());
     }
-    VNM_HIP(hipGetLastError());
-    unsigned long long fl[3];
-    VNM_HIP(hipMemcpyAsync(fl, flags, 24, hipMemcpyDeviceToHost, s));
-    VNM_HIP(hipStreamSynchronize(s));
-    release();
-    if (fl[0]) { pool_free(rk); pool_free(ra); pool_free(spill); return 2; }
-    if (fl[2]) { *spill_out = spill; *n_spill_out = (int64_t)fl[2]; }
-    else { pool_free(spill); *spill_out = nullptr; *n_spill_out = 0; }
+    if (fl[2]) { *spill_out = spill; *n_spill_out = (int64_t)fl[2]; spill = nullptr; }
+    else { *spill_out = nullptr; *n_spill_out = 0; }
     if ((int64_t)fl[2] > nrows / 16) h->dense_state = -1;  // the sampled range does not describe the data: stop trying
-    h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
-    h->run_dir = nullptr; h->run_nfin = 0;
-    h->have_run = true;
     return 0;
 }
 
@@ -3934,6 +3957,7 @@ int complete_pending(vnm_agg* h, hipStream_t s, int out = DF_RUN, const DFinalAr
     }
     return 0;
 }
+
 
 // returns 0 = done (run stored), 2 = not applicable / failed (caller continues with the hash-partitioned path), 1 = error
 // (nspill_out / n_nspill_out: keys of NULL-value rows that found no place -- nullable value column, generic programs only)
@@ -4277,6 +4301,36 @@ static int merge_run_into_table(vnm_agg* h, hipStream_t s) {
     return rc;
 }
 
+
+// The table of a stream of small-range batches (DScanPending) -> a run.  Whatever the handle holds as a run already goes to the HBM
+// table first (one run at a time).
+static int flush_scan_pending(vnm_agg* h, hipStream_t s) {
+    DScanPending* sp = h->scan_pending;
+    if (!sp) return 0;
+    h->scan_pending = nullptr;
+    std::unique_ptr<DScanPending> own(sp);
+    if (h->pending) VNM_TRY(complete_pending(h, s, DF_RUN, nullptr, nullptr));
+    if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
+    const int64_t dstride = sp->slots + 2;
+    PoolScope pool;
+    uint64_t* rk = (uint64_t*)pool.take((size_t)dstride * 8 * 2);
+    uint64_t* ra = (uint64_t*)pool.take((size_t)dstride * 8 * std::max(1, h->plan.n_words));
+    if (!rk || !ra) return 1;
+    VNM_HIP(hipMemsetAsync(sp->flags, 0, 64, s));
+    DFinalArgs df = sp->df;
+    df.dkey = rk; df.dacc = ra; df.dstride = dstride; df.flags = sp->flags;
+    dscan_emit_kernel<<<sp->slots / 512, 512, 0, s>>>(df, sp->slots, sp->t);
+    VNM_HIP(hipGetLastError());
+    unsigned long long fl[2];
+    VNM_HIP(hipMemcpyAsync(fl, sp->flags, 16, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    if (fl[0]) return set_error("aggregate: the stream table holds more groups than slots (internal error)");
+    pool.keep(rk); pool.keep(ra);
+    h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
+    h->run_dir = nullptr; h->run_nfin = 0;
+    h->have_run = true;
+    return 0;
+}
 
 // see run_patch_kernel; *done = false leaves everything as it was (the caller merges the run into the table instead)
 static int merge_table_into_run(vnm_agg* h, hipStream_t s, bool* done) {
@@ -4834,6 +4888,7 @@ void vnm_agg_destroy(vnm_agg* h) {
     invalidate_result(h);
     drop_run(h);
     delete h->pending;
+    delete h->scan_pending;
     delete h;
 }
 
@@ -5191,6 +5246,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     };
     // a few hundred to a few thousand groups in a small key range: the direct-addressed LDS scan (vnm_agg_dense.inc)
     bool dscan_done = false;
+    bool dscan_stream = false;   // the batch went into the stream table (h->scan_pending)
     if (dense_shape && !dense_go && h->hint >= env_i64("VNM_DSCAN_MIN_GROUPS", 128) && h->hint <= (1 << DP_TBITS_MAX) &&
         getenv("VNM_AGG_NO_DSCAN") == nullptr) {
         if (h->dense_state == 0) {
@@ -5200,7 +5256,9 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         if (h->dense_state == 2) {
             if (h->pending) VNM_TRY(complete_pending(h, s));   // (this path makes a run of its own)
             if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
+            if (dense_generic && h->scan_pending) VNM_TRY(flush_scan_pending(h, s));
             int prc = dense_scan_aggregate(h, a, nrows, s, &spill, &n_spill, dense_generic, &nspill, &n_nspill);
+            dscan_stream = prc == 0 && !dense_generic;
             // a generic program whose table for this range does not fit LDS: the same 2^13 codes through one scatter level
             // (four partitions of 2^11 slots, split final pass) instead
             if (prc == 2 && dense_generic && h->dense_state == 2) prc = dense_partitioned_aggregate(h, a, nrows, s, &spill, &n_spill, true, &nspill, &n_nspill);
@@ -5217,6 +5275,8 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
             }
         }
     }
+    // (a batch that went another way than the stream table of the small-range scan: that table becomes a run first)
+    if (h->scan_pending && !dscan_stream) VNM_TRY(flush_scan_pending(h, s));
     // many groups: radix-partitioned path (no per-row HBM atomics); falls through when it does not apply
     // ... from the point where the groups stop fitting the LDS table of the scan kernel (flush storms otherwise:
     // MIN+MAX with 2000 groups and a 2048-slot table ran at 38 ms)
@@ -5544,6 +5604,7 @@ int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream) {
         if (n_groups) *n_groups = n;
         return 0;
     }
+    VNM_TRY(flush_scan_pending(h, s));                 // a stream of small-range batches: its table, as a run
     VNM_TRY(collapse_parts(h, s));                     // a split program: its parts joined by key, as a run
     if (h->pending) VNM_TRY(complete_pending(h, s));   // the deferred final pass of the dense path, as a run
     if (h->have_run && h->have_table) {   // a big run + a few spilled groups in the table: fold the table into the run
