@@ -3051,6 +3051,7 @@ struct vnm_agg {
     // has not run yet -- what it writes depends on who asks: another batch / finish() -> the dense partial state (a run),
     // vnm_agg_result_device_alloc -> the result columns themselves, vnm_agg_dense_table -> the tables for the multi-GPU exchange
     struct DensePending* pending = nullptr;
+    double heavy_share = 0.0;   // share of the rows held by heavy keys in the estimator's sample (0: none seen, or never sampled)
     struct DScanPending* scan_pending = nullptr;   // a stream of small-range batches: their table (see dense_scan_aggregate)
     bool dense_by_bound = false;   // the first batch went dense on the sample's LOWER bound of the group count (no estimate exists)
     bool range_given = false;   // vnm_agg_set_dense_range: the code range is the caller's (agreed by all ranks), not a sample's
@@ -3231,6 +3232,7 @@ int estimate_groups(vnm_agg* h, const vnm_dcol& key, int64_t nrows, int64_t* est
         if ((double)got[4] >= 0.02 * (double)m && got[5] < d) {
             heavy_share = std::min(0.999, (double)got[4] / (double)m);
             heavy_keys = (int64_t)got[5];
+            h->heavy_share = heavy_share;
         }
         const double m0 = (double)m * (1.0 - heavy_share);
         const double d0 = (double)d - (double)heavy_keys;
@@ -3962,14 +3964,17 @@ int complete_pending(vnm_agg* h, hipStream_t s, int out = DF_RUN, const DFinalAr
 // returns 0 = done (run stored), 2 = not applicable / failed (caller continues with the hash-partitioned path), 1 = error
 // (nspill_out / n_nspill_out: keys of NULL-value rows that found no place -- nullable value column, generic programs only)
 int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s, ulonglong2** spill_out, int64_t* n_spill_out,
-                                bool generic = false, uint64_t** nspill_out = nullptr, int64_t* n_nspill_out = nullptr) {
+                                bool generic = false, uint64_t** nspill_out = nullptr, int64_t* n_nspill_out = nullptr, bool vn_fold = false) {
     const int cus = device_info().num_cus;
     const DenseMap& mp = h->dmap;
     DGenArgs g{};
     if (generic && !dgen_program(h, a, &g)) return 2;
     const bool has_val = generic ? g.has_val != 0 : true;
-    const bool vn = generic && has_val && a.cols[0].validity != nullptr;   // nullable value column: NULL flags travel with the entries
-    if (vn && (!nspill_out || a.has_expr)) return 2;
+    // nullable value column: NULL flags travel with the entries (generic programs) -- or, vn_fold, the hot program filtered by that
+    // column itself: pass 1 drops the NULL rows with the filter and nothing after it ever sees a flag
+    const bool vn = has_val && a.cols[0].validity != nullptr && (generic || vn_fold);
+    if (vn && ((!vn_fold && !nspill_out) || a.has_expr)) return 2;
+    if (vn_fold && (generic || !a.hot_pred_is_v)) return 2;
     if (nspill_out) { *nspill_out = nullptr; *n_nspill_out = 0; }
     // slots per final partition: the largest table that still leaves >= 2048 final partitions (8 per CU)
     int tb = (int)env_i64("VNM_DENSE_TBITS", 12);
@@ -3998,6 +4003,9 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     const int grid1 = (int)std::min<int64_t>((int64_t)cus * env_i64("VNM_DENSE_GRID1_PER_CU", 2), (nrows + tile1 - 1) / tile1);
     int split2 = std::max(2, (grid1 + PT_MAX_REGIONS - 1) / PT_MAX_REGIONS);
     split2 = std::max(split2, std::min(grid1, (cus * 2 + np1 - 1) / np1));
+    // skewed keys (the estimator's sample saw heavy keys): more, smaller work items for pass 2 -- the partition that holds a heavy key
+    // has a multiple of the others' entries, and with cus * 2 work items for cus * 2 resident workgroups the heaviest sets the time
+    if (h->heavy_share >= 0.02) split2 = std::min(grid1, split2 * (int)env_i64("VNM_DENSE_SKEW_SPLIT", 4));
     const int64_t tiles_per_wg = ((nrows + tile1 - 1) / tile1 + grid1 - 1) / grid1;
     const int64_t rows_per_wg = tiles_per_wg * tile1;
     int64_t cap1v = ((rows_per_wg / np1 + rows_per_wg / np1 / 5 + 512) + 15) & ~15LL;
@@ -4018,13 +4026,14 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     uint32_t* n1 = (uint32_t*)pool_alloc((size_t)np1 * grid1 * 4);
     const int64_t spill_cap = nrows / 2 + (1 << 20);
     ulonglong2* spill = (ulonglong2*)pool_alloc((size_t)spill_cap * 16);
-    const int64_t nspill_cap = vn ? nrows / 4 + (1 << 20) : 0;
-    uint64_t* nspill = vn ? (uint64_t*)pool_alloc((size_t)nspill_cap * 8) : nullptr;
+    const bool vn_lists = vn && !vn_fold;
+    const int64_t nspill_cap = vn_lists ? nrows / 4 + (1 << 20) : 0;
+    uint64_t* nspill = vn_lists ? (uint64_t*)pool_alloc((size_t)nspill_cap * 8) : nullptr;
     PoolSlotGuard<uint64_t> nspill_guard(&nspill);   // handed to the caller only on success (below)
     double* v2 = nullptr; void* c2 = nullptr; uint32_t* n2 = nullptr;
     uint64_t* rk = nullptr; uint64_t* ra = nullptr;
     auto release = [&]() { pool_free(flags); pool_free(v1); pool_free(c1); pool_free(n1); pool_free(v2); pool_free(c2); pool_free(n2); };
-    if (!flags || !v1 || !c1 || !n1 || !spill || (vn && !nspill)) { release(); pool_free(spill); return 1;}
+    if (!flags || !v1 || !c1 || !n1 || !spill || (vn_lists && !nspill)) { release(); pool_free(spill); return 1;}
     VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
     DPartArgs d1{};
     d1.map = mp;
@@ -5104,7 +5113,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     a.hot_comp = 0;
     for (int w = 0; w < h->plan.n_words; w++) if (h->plan.merge[w] == M_ADD_F64C) a.hot_comp = 1;
     for (int k = 0; k < 9; k++) a.hot_w[k] = a.hot_w2[k] = -1;
-    bool hot = hot_scan && h->plan.n_cols == 1 && a.hot_vtype == VNM_F64 && !hot_vnull;
+    bool hot = hot_scan && h->plan.n_cols == 1 && a.hot_vtype == VNM_F64;   // (a nullable column: hot_prog below)
     if (hot_scan) {
         for (int o = 0; o < h->plan.n_ops; o++) {
             const AccOp& op = h->plan.ops[o];
@@ -5132,6 +5141,10 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         hot_scan = a.pred.type == VNM_F64 && (!a.pred.validity || (hot_vnull && a.hot_pred_is_v)) && (a.pred.offset & 1) == 0 && a.p.mode == CMP_F64;
         hot = hot && hot_scan;
     }
+    // the hot PROGRAM over a nullable column filtered by itself (`WHERE v > x`: a NULL fails the filter): the dense path drops the
+    // NULL rows in pass 1 and everything after it is the hot shape (vn_fold below); every other kernel of the hot shape reads no bitmap
+    const bool hot_prog = hot;
+    if (hot_vnull) hot = false;
     // the partitioned path also takes ANY accumulator program over at most one 8-byte input column: its entries
     // carry (key, raw value bits) and only the final pass interprets them
     bool part_ok = hot;
@@ -5178,6 +5191,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     // two lists (entries, keys of NULL-value rows) and goes through the scan below as columns
     const bool dense_vn = !hot && hot_scan && hot_vnull && !hot_two && !a.has_expr && part_ok && h->plan.n_cols == 1 &&
                           getenv("VNM_AGG_NO_DENSE_VN") == nullptr;
+    const bool vn_fold = dense_vn && hot_prog && h->pred_set && a.hot_pred_is_v && getenv("VNM_AGG_NO_VN_FOLD") == nullptr;
     const bool dense_generic = ((!hot && narrow_generic && hot_scan && !hot_two && !hot_vnull && !a.has_expr) || dense_vn) &&
                                getenv("VNM_AGG_NO_DENSE_GENERIC") == nullptr && getenv("VNM_AGG_NO_SPILL") == nullptr;
     const bool dense_base = (hot || dense_generic) && part_ok && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
@@ -5298,7 +5312,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
             return r;
         };
         if (dense_go && (h->hint > part_min || h->hint == 0)) {
-            prc = dense_partitioned_aggregate(h, a, nrows, s, &spill, &n_spill, dense_generic, &nspill, &n_nspill);
+            prc = dense_partitioned_aggregate(h, a, nrows, s, &spill, &n_spill, dense_generic && !vn_fold, &nspill, &n_nspill, vn_fold);
             vn_spill = prc == 0 && dense_vn && (spill || nspill);
             if (prc == 2 && h->hint == 0) {  // the dense attempt failed before G was ever estimated
                 int64_t est = 0;
