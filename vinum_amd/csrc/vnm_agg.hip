@@ -3229,10 +3229,10 @@ int estimate_groups(vnm_agg* h, const vnm_dcol& key, int64_t nrows, int64_t* est
         // Heavy keys (each with > 0.4 % of the sample: NULLs, a default value) break the uniform model below -- half of the
         // rows in one key halves d / m and G came out 2.2x too small.  They are taken out: the model sees the remaining keys
         // over the remaining rows, and the heavy keys are added back as what they are, a handful of groups.
+        h->heavy_share = got[5] ? (double)got[4] / (double)m : 0.0;   // (any key above 0.4 % of the sample: pass 2 of the dense path splits finer)
         if ((double)got[4] >= 0.02 * (double)m && got[5] < d) {
             heavy_share = std::min(0.999, (double)got[4] / (double)m);
             heavy_keys = (int64_t)got[5];
-            h->heavy_share = heavy_share;
         }
         const double m0 = (double)m * (1.0 - heavy_share);
         const double d0 = (double)d - (double)heavy_keys;
@@ -4005,7 +4005,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     split2 = std::max(split2, std::min(grid1, (cus * 2 + np1 - 1) / np1));
     // skewed keys (the estimator's sample saw heavy keys): more, smaller work items for pass 2 -- the partition that holds a heavy key
     // has a multiple of the others' entries, and with cus * 2 work items for cus * 2 resident workgroups the heaviest sets the time
-    if (h->heavy_share >= 0.02) split2 = std::min(grid1, split2 * (int)env_i64("VNM_DENSE_SKEW_SPLIT", 4));
+    if (h->heavy_share > 0.0) split2 = std::min(grid1, split2 * (int)env_i64("VNM_DENSE_SKEW_SPLIT", 8));
     const int64_t tiles_per_wg = ((nrows + tile1 - 1) / tile1 + grid1 - 1) / grid1;
     const int64_t rows_per_wg = tiles_per_wg * tile1;
     int64_t cap1v = ((rows_per_wg / np1 + rows_per_wg / np1 / 5 + 512) + 15) & ~15LL;
