@@ -3157,6 +3157,9 @@ int ensure_table(vnm_agg* h, int64_t nrows, hipStream_t s, bool rows_only = fals
     else {
         uint64_t want = h->hint > 0 ? (uint64_t)h->hint * 2 : (uint64_t)1 << 22;
         if ((h->hint <= 0 || rows_only) && (uint64_t)nrows * 2 < want) want = (uint64_t)(nrows > 512 ? nrows : 512) * 2;
+        // (spilled rows are mostly FEW keys -- a heavy key's 3e7 entries got a 2^26-slot table: its memset and the walks over its
+        // slots at finish, run_patch_append_kernel 2.9 ms; the scan grows the table when the keys are many after all)
+        if (rows_only && want > (1ULL << 20)) want = 1ULL << 20;
         cap = pow2_at_least(want < 1024 ? 1024 : want);
     }
     VNM_TRY(table_alloc(h, &h->g, cap, s));
@@ -4967,6 +4970,9 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
                                           h->c_has_ids ? h->c_in_col_ids : nullptr);
                 if (!h->inner) return 1;
                 h->inner->hint = h->hint;
+                // a nullable key column: its NULL code may be a heavy key of the inner operator, whose estimator is not asked when
+                // the caller gave a group count (the dense path then cuts pass 2 into more work items, see heavy_share)
+                for (int j = 0; j < h->plan.n_keys; j++) if (keys[j].validity) h->inner->heavy_share = std::max(h->inner->heavy_share, 0.01);
             } else if (err) return err;
             else if (!h->single && !h->have_run && !h->pending && getenv("VNM_AGG_NO_TUPLE") == nullptr) {
                 // too wide for one word even as per-column dictionary codes: tuple -> group id through a dictionary
