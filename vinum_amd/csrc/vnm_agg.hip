@@ -1492,8 +1492,26 @@ struct PatchArgs {
     int64_t rn, rstride;
     uint8_t* found;         // [cap + 2]
     unsigned long long* appended;
+    uint32_t* bloom;        // [PATCH_BLOOM_BITS / 32]: one bit per table key (a second hash)
 };
+// The table next to a big run mostly holds a handful of keys (spilled heavy keys, keys outside a sampled range) in millions of
+// slots: every run row probing it is a random HBM / MALL access (8.8e7 rows: 1.8 ms).  One bit per table key in a 64 KB filter
+// that every workgroup keeps in LDS sends only the rows that can match to the table.
+constexpr int PATCH_BLOOM_BITS = 1 << 19;
+__device__ __forceinline__ uint32_t patch_bloom_bit(uint64_t k) { return hash_u64(k ^ 0x9E3779B97F4A7C15ULL) & (PATCH_BLOOM_BITS - 1); }
+__global__ __launch_bounds__(256) void run_patch_bloom_kernel(PatchArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x; slot < (int64_t)a.g.cap; slot += stride) {
+        const uint64_t t = a.g.tag[slot];
+        if (t == EMPTY) continue;
+        const uint32_t b = patch_bloom_bit(t);
+        atomicOr(&a.bloom[b >> 5], 1u << (b & 31));
+    }
+}
 __global__ __launch_bounds__(256) void run_patch_kernel(PatchArgs a) {
+    __shared__ uint32_t lb[PATCH_BLOOM_BITS / 32];
+    for (int i = threadIdx.x; i < PATCH_BLOOM_BITS / 32; i += 256) lb[i] = a.bloom[i];
+    __syncthreads();
     const uint64_t mask = a.g.cap - 1;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.rn; i += stride) {
@@ -1502,6 +1520,8 @@ __global__ __launch_bounds__(256) void run_patch_kernel(PatchArgs a) {
         if (nm) { if (a.g.tag[a.g.cap + 1] != EMPTY) slot = a.g.cap + 1; }
         else if (k == EMPTY) { if (a.g.tag[a.g.cap] != EMPTY) slot = a.g.cap; }
         else {
+            const uint32_t bb = patch_bloom_bit(k);
+            if (!((lb[bb >> 5] >> (bb & 31)) & 1u)) continue;
             uint64_t h = hash_u64(k) & mask;
             for (uint64_t probes = 0; probes <= mask; probes++) {
                 const uint64_t t = a.g.tag[h];
@@ -4363,7 +4383,11 @@ static int merge_table_into_run(vnm_agg* h, hipStream_t s, bool* done) {
     a.rkey = h->run_key; a.racc = h->run_acc; a.rn = h->run_n; a.rstride = h->run_stride;
     a.found = found;
     a.appended = (unsigned long long*)(found + fbytes);
+    a.bloom = (uint32_t*)pool.take(PATCH_BLOOM_BITS / 8);
+    if (!a.bloom) return 1;
+    VNM_HIP(hipMemsetAsync(a.bloom, 0, PATCH_BLOOM_BITS / 8, s));
     const int cus = device_info().num_cus;
+    run_patch_bloom_kernel<<<(int)std::min<int64_t>(((int64_t)h->g.cap + 255) / 256, (int64_t)cus * 8), 256, 0, s>>>(a);
     run_patch_kernel<<<(int)std::min<int64_t>((h->run_n + 255) / 256, (int64_t)cus * 8), 256, 0, s>>>(a);
     run_patch_append_kernel<<<(int)std::min<int64_t>(((int64_t)h->g.cap + 2 + 255) / 256, (int64_t)cus * 8), 256, 0, s>>>(a);
     VNM_HIP(hipGetLastError());
