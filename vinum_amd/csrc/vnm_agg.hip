@@ -1542,14 +1542,27 @@ __global__ __launch_bounds__(1024) void run_patch_kernel(PatchArgs a) {
 }
 __global__ __launch_bounds__(256) void run_patch_append_kernel(PatchArgs a) {
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x; slot < (int64_t)a.g.cap + 2; slot += stride) {
-        const uint64_t t = a.g.tag[slot];
-        if (t == EMPTY || a.found[slot]) continue;
+    const int64_t nslots = (int64_t)a.g.cap + 2;
+    constexpr int U = 8;   // independent loads in flight (one slot per iteration: 0.51 ms for 2^23 slots, 150 GB/s)
+    for (int64_t s0 = (int64_t)blockIdx.x * 256 + threadIdx.x; s0 < nslots; s0 += stride * U) {
+      uint64_t tt[U]; uint8_t ff[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+          const int64_t sl = s0 + (int64_t)u * stride;
+          tt[u] = EMPTY; ff[u] = 1;
+          if (sl < nslots) { tt[u] = a.g.tag[sl]; ff[u] = a.found[sl]; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int64_t slot = s0 + (int64_t)u * stride;
+        const uint64_t t = tt[u];
+        if (slot >= nslots || t == EMPTY || ff[u]) continue;
         const int64_t pos = a.rn + (int64_t)atomicAdd(a.appended, 1ULL);
         if (pos >= a.rstride) continue;   // cannot happen while the table's fill count holds (the host checks the total)
         a.rkey[pos] = slot < (int64_t)a.g.cap ? t : (slot == (int64_t)a.g.cap ? EMPTY : 0);
         a.rkey[a.rstride + pos] = slot == (int64_t)a.g.cap + 1 ? 1 : 0;
         for (int w = 0; w < a.plan.n_words; w++) a.racc[(int64_t)w * a.rstride + pos] = a.g.acc[(uint64_t)w * a.g.stride + slot];
+      }
     }
 }
 
