@@ -1586,8 +1586,8 @@ def test_random_hot_shape_paths_vs_oracle(seed, monkeypatch):
     float64 predicate) across everything that decides its path: key range from a few hundred to millions of codes (direct-
     addressed LDS scan, split final pass, one / two scatter levels), sparse 64-bit keys (hash partitions), negative /
     sorted / clustered / heavy / outlying keys (spill), right, wrong and absent hints, one to three batches whose key ranges
-    may drift, quantised and arbitrary values.  Keys, counts and quantised sums bit-exact; arbitrary float sums within the
-    usual tolerance of the sequential oracle sum."""
+    may drift, quantised and arbitrary values.  Keys, counts and quantised sums bit-exact; arbitrary float sums held to the
+    exact-sum bound (util._assert_float_agg_exact)."""
     from oracle import oracle as O
     rng = np.random.default_rng(52_000 + seed)
     monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "50000")
@@ -1642,13 +1642,17 @@ def test_random_hot_shape_paths_vs_oracle(seed, monkeypatch):
     got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=pred, expected_groups=hint)
     o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
     names = t.schema.names
+    fed = []
     for b in batches:
         if pred:
             op = {">": O.GT, "<=": O.LE}[pred[1]]
             b = O.filter_batch(b, O.cmp_mask(b.column(names.index(pred[0])), op, pred[2]))
         o.next(b)
+        fed.append(b.select(["k", "v"]))
     what = f"seed {seed}: G~{groups} lo={lo} {pattern} unsigned={unsigned} quantised={quantised} hint={hint} pred={pred} batches={len(batches)}"
-    util.assert_agg_equal(got, o.result(), funcs, ["k"], exact_float_inputs=("v",) if quantised else (), what=what)
+    # arbitrary floats: held to the exact-sum bound (1 ULP of fsum, never further from the reference than the reference is from exact)
+    util.assert_agg_equal(got, o.result(), funcs, ["k"], exact_float_inputs=("v",) if quantised else (), what=what,
+                          source=None if quantised else fed)
 
 
 @pytest.mark.parametrize("groups", [50, 20_000, 700_000, 3_000_000])

@@ -1,0 +1,83 @@
+"""GPU parity, round 4: operator-state transitions the earlier suites never crossed -- NULL keys that first
+appear in a LATER batch of a stream whose first batches took the dense / partitioned / split / stream-table routes --
+and the asynchronous stream mode (no host read-back per next())."""
+import ctypes
+import os
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from tests import util
+from tests.test_gpu_agg import gpu_aggregate
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(kind, keys, funcs, batches, pred=None):
+    from oracle import oracle as O
+    o = O.OracleAggregate(kind, keys, keys, funcs)
+    for b in batches:
+        if pred:
+            b = O.filter_batch(b, O.cmp_mask(b.column(b.schema.names.index(pred[0])), O.GT, pred[2]))
+        o.next(b)
+    return o.result()
+
+
+@pytest.mark.parametrize("later", ["null_keys", "odd_offset", "null_keys_and_key_zero"])
+@pytest.mark.parametrize("route", ["dense_two_level", "dense_one_level", "dense_split_final", "stream_table", "hash_partitions",
+                                   "split_program"])
+@pytest.mark.parametrize("hint", [0, 1])
+def test_null_keys_first_appear_in_a_later_batch(route, later, hint, monkeypatch):
+    """ADVICE r03 (high + medium): the first batches of a single 8-byte key come without a validity bitmap and take a plain-key
+    route (dense deferred pass, hash partitions, the stream table of the small-range scan, the parts of a split program); a later
+    batch brings NULL keys (or an odd Arrow offset) and is not `key_plain` any more.  The operator used to enter packed mode
+    there and to return the inner operator's groups ONLY; the parts of a split program turned the NULL group into key 0.
+    base_aggregate.cpp:23-45 (state is batch-commutative), single_numerical_hash_aggregate.cpp:24-32 (null_group)."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    groups = {"dense_two_level": 1_500_000, "dense_one_level": 900_000, "dense_split_final": 40_000, "stream_table": 3_000,
+              "hash_partitions": 200_000, "split_program": 40_000}[route]
+    if route == "dense_two_level":
+        monkeypatch.setenv("VNM_DENSE_ONE_LEVEL", "0")
+    rng = np.random.default_rng(len(route) * 7 + len(later) + hint)
+    n1, n2 = 1_200_000, 700_001
+    mult = 7919 if route == "hash_partitions" else 1     # sparse keys: no dense code range
+
+    def keys(n):
+        return rng.integers(0, groups, n).astype(np.int64) * mult
+
+    ncols = 8 if route == "split_program" else 1
+    kinds = [O.SUM, O.MAX, O.AVG, O.MIN, O.COUNT, O.SUM, O.AVG, O.MAX]
+
+    def table(n, nullable):
+        k = keys(n)
+        k[::1013] = 0      # the real key 0 next to the NULL group (whose key word is 0 as well)
+        cols = {}
+        if nullable:
+            mask = rng.random(n) < 0.07
+            if later == "null_keys_and_key_zero":
+                mask[k == 0] = (np.arange(int((k == 0).sum())) % 2 == 0)
+            cols["k"] = pa.array(k, mask=mask)
+        else:
+            cols["k"] = pa.array(k)
+        for c in range(ncols):
+            vals = rng.integers(0, 2**14, n).astype(np.float64) / 64.0 if c % 2 == 0 else rng.integers(-2**40, 2**40, n).astype(np.int64)
+            cols["v" if ncols == 1 else f"c{c}"] = pa.array(vals)
+        return pa.table(cols)
+
+    t1, t2, t3 = table(n1, False), table(n2, later != "odd_offset"), table(n1 // 2, False)
+    b2 = t2.to_batches()[0]
+    if later == "odd_offset":
+        b2 = b2.slice(1)
+    batches = t1.to_batches() + [b2] + t3.to_batches()
+    if ncols == 1:
+        funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.COUNT_STAR, "", "n")]
+        pred = ("v", ">", 64.0)
+    else:
+        funcs = [(kinds[c], f"c{c}", f"f{c}") for c in range(ncols)] + [(O.COUNT_STAR, "", "n")]
+        pred = None
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=pred, expected_groups=groups if hint else 0)
+    exp = _oracle(O.SINGLE, ["k"], funcs, batches, pred)
+    assert got.num_rows == exp.num_rows, (got.num_rows, exp.num_rows)
+    util.assert_agg_equal(got, exp, funcs, ["k"], what=f"{route}, later batch with {later}", source=pa.Table.from_batches(batches) if not pred else None)

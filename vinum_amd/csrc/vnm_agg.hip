@@ -97,8 +97,24 @@ __device__ __forceinline__ double expr_eval1(const ExprProg& e, int64_t r) {
     return expr_eval<double>(e, [&](int c) { return e.cols[c][r]; }, 0.0);
 }
 
+// One record batch of a STREAM handed to a kernel as part of one logical batch (vnm_agg_set_async: batches wait in the operator and
+// go to the device together -- a launch per 2^24-row batch costs more in launch gaps, LDS table start-up and partial flushes than
+// its rows).  The hot shape only: 8-byte key, one plain float64 input column, float64 predicate column or none.  A segment owns
+// the tiles [first_tile, first_tile + ceil(nrows / tile)) of the launch; tiles never span segments.
+struct VSeg {
+    const uint64_t* kp;      // key values (Arrow offset applied; 16-byte aligned)
+    const uint64_t* vp;      // input column values
+    const double* pp;        // predicate column values (the input column itself when the predicate reads it)
+    const uint8_t* vvalid;   // validity bitmap of the input column or null (dense path over a nullable value column)
+    int64_t voff;
+    int64_t nrows;
+    int64_t first_tile;
+};
+
 struct AggArgs {
     AggPlan plan;
+    const VSeg* segs;  // agg_hot_kernel, nseg > 0: the rows are these segments (keys[0] / cols[0] / pred describe the first one)
+    int nseg;
     int has_expr;      // the (only) input column of this hot-shape plan is `expr`, not a.cols[0]
     ExprProg expr;
     vnm_dcol keys[AGG_MAX_KEYS];
@@ -319,18 +335,24 @@ __device__ __forceinline__ void lds_flush(const AggArgs& a, uint64_t* lkey, uint
 // Row-major slow path: rows (row0 + r * step for the bits r of `rows`) whose key is known to be valid, not NULL
 // and not the EMPTY sentinel are merged straight into the HBM table.  One ROLLED loop that re-reads what it needs
 // from memory, so it adds a few hundred bytes of code instead of a copy per unrolled row and op.
-__device__ __forceinline__ void agg_rows_to_table(const AggArgs& a, int64_t row0, int step, uint32_t rows, unsigned* s_new) {
+__device__ __forceinline__ uint64_t op_value_raw(int kind, int type, uint64_t raw);
+// (skp / svp: the rows are those of a stream segment -- plain 8-byte key and input column, see VSeg)
+__device__ __forceinline__ void agg_rows_to_table(const AggArgs& a, int64_t row0, int step, uint32_t rows, unsigned* s_new,
+                                                  const uint64_t* skp = nullptr, const uint64_t* svp = nullptr) {
 #pragma unroll 1
     for (int r = 0; rows; r++, rows >>= 1) {
         if (!(rows & 1u)) continue;
         const int64_t row = row0 + (int64_t)r * step;
-        const uint64_t gs = gt_find_single(a.g, col_key_bits(a.keys[0], row), s_new);
+        const uint64_t gs = gt_find_single(a.g, skp ? skp[row] : col_key_bits(a.keys[0], row), s_new);
 #pragma unroll 1
         for (int o = 0; o < a.plan.n_ops; o++) {
             const AccOp& op = a.plan.ops[o];
             uint64_t v;
             bool have;
-            if (a.has_expr && op.kind != A_COUNT_ROWS) {   // hot shape: COUNT / float64 SUM of the expression, never NULL
+            if (skp) {
+                v = op_value_raw(op.kind, a.hot_vtype, op.kind == A_COUNT_ROWS ? 0 : svp[row]);
+                have = true;
+            } else if (a.has_expr && op.kind != A_COUNT_ROWS) {   // hot shape: COUNT / float64 SUM of the expression, never NULL
                 v = op.kind == A_COUNT_VALID ? 1ULL : (uint64_t)__double_as_longlong(expr_eval1(a.expr, row));
                 have = true;
             } else have = op_value(op, a.cols, row, &v);
@@ -724,17 +746,32 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
 
     const unsigned flush_at = (unsigned)(S * 6 / 10);
     const uint32_t smask = (uint32_t)S - 1;
-    const uint64_t* kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
-    const uint64_t* vp = HAS_VAL ? (const uint64_t*)a.cols[0].values + a.cols[0].offset : kp;
-    const uint64_t* vp2 = TWO ? (const uint64_t*)a.cols[1].values + a.cols[1].offset : kp;
-    const double* pp = (const double*)a.pred.values + a.pred.offset;
+    // The rows of a tile: (segment, local tile) -- the record batches of a stream as one logical batch (VSeg; nseg = 0: the one batch
+    // of a.keys / a.cols / a.pred).  Uniform over the workgroup; the segment cursor only moves forward.
+    struct Cur { const uint64_t* kp; const uint64_t* vp; const uint64_t* vp2; const double* pp; const uint8_t* vbm; int64_t voff; int64_t nrows; int64_t lt; };
+    const int nseg = FROM_ENT ? 0 : a.nseg;
+    int sg = 0;
+    auto locate = [&](int64_t tile, Cur& c) {
+        if (nseg == 0) {
+            c.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
+            c.vp = HAS_VAL ? (const uint64_t*)a.cols[0].values + a.cols[0].offset : c.kp;
+            c.vp2 = TWO ? (const uint64_t*)a.cols[1].values + a.cols[1].offset : c.kp;
+            c.pp = (const double*)a.pred.values + a.pred.offset;
+            c.vbm = VNULL ? a.cols[0].validity : nullptr;
+            c.voff = VNULL ? a.cols[0].offset : 0;
+            c.nrows = a.nrows; c.lt = tile;
+            return;
+        }
+        while (sg + 1 < nseg && tile >= a.segs[sg + 1].first_tile) sg++;
+        const VSeg& sgm = a.segs[sg];
+        c.kp = sgm.kp; c.vp = HAS_VAL ? sgm.vp : sgm.kp; c.vp2 = sgm.kp; c.pp = sgm.pp; c.vbm = sgm.vvalid; c.voff = sgm.voff;
+        c.nrows = sgm.nrows; c.lt = tile - sgm.first_tile;
+    };
     const int op = a.p.op;
     const double thr = a.p.dval;
 
     ulonglong2 kk[HOT_UNROLL], vv[HOT_UNROLL], vw[HOT_UNROLL];  // this block's current (then next) tile, see below
     uint32_t vm[HOT_UNROLL];  // VNULL: validity bits of the pair (bit 0 / 1)
-    const uint8_t* vbm = VNULL ? a.cols[0].validity : nullptr;
-    const int64_t voff = VNULL ? a.cols[0].offset : 0;
     double2 pv[HOT_UNROLL];
     bool have = false;
     uint32_t spread = 0;
@@ -744,6 +781,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
     int spread_state = ((a.debug & 4) || a.ntiles < 64 * (int64_t)gridDim.x) ? 2 : 0;  // VNM_AGG_DEBUG & 4: no key copies (measurement)
     bool need_check = true;
     unsigned it = a.progress[blockIdx.x];
+    Cur cur{}, nxt{};
     for (;; it++) {
         const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
         if (tile >= a.ntiles) break;
@@ -752,14 +790,17 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
             __syncthreads();
             if (!s_go) break;
         }
-        const int64_t base = tile * HOT_TILE + 2 * tid;
+        if (have) cur = nxt; else locate(tile, cur);
+        const uint64_t* const kp = cur.kp; const uint64_t* const vp = cur.vp; const uint64_t* const vp2 = cur.vp2;
+        const double* const pp = cur.pp; const uint8_t* const vbm = cur.vbm; const int64_t voff = cur.voff;
+        const int64_t base = cur.lt * HOT_TILE + 2 * tid;
         uint32_t sat0 = 0, sat1 = 0;  // rows (even / odd element of chunk u) whose key the LDS table could not take
-        if (base + (int64_t)(HOT_UNROLL - 1) * 2 * AGG_BLOCK + 1 < a.nrows) {
+        if (cur.lt * HOT_TILE + HOT_TILE <= cur.nrows) {   // a full tile
             // Register rotation: as soon as chunk u of this tile has been copied out, chunk u of the block's NEXT
             // tile is requested into the same registers, so HBM loads are in flight while the LDS work of this tile
             // runs (one 1024-thread block per CU: without this the block alternates between a load phase and an
             // LDS phase -- G=1000 ran at 4.2 ms against 3.1 ms for G=7).
-#define VNM_HOT_LOAD(u, b)                                                                                      \
+#define VNM_HOT_LOAD(u, b, C)                                                                                   \
     do {                                                                                                       \
         const int64_t r_ = (b) + (int64_t)(u) * 2 * AGG_BLOCK;                                                 \
         if (FROM_ENT) {                                                                                        \
@@ -767,22 +808,23 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
             kk[u].x = e0.x; kk[u].y = e1.x;                                                                    \
             vv[u].x = e0.y; vv[u].y = e1.y;                                                                    \
         } else {                                                                                               \
-            kk[u] = *(const ulonglong2*)(kp + r_);                                                             \
+            kk[u] = *(const ulonglong2*)((C).kp + r_);                                                         \
             if (HAS_VAL) {                                                                                     \
                 if (a.has_expr) { const double2 ev_ = expr_eval2(a.expr, r_); vv[u].x = (unsigned long long)__double_as_longlong(ev_.x); vv[u].y = (unsigned long long)__double_as_longlong(ev_.y); } \
-                else vv[u] = *(const ulonglong2*)(vp + r_);                                                    \
+                else vv[u] = *(const ulonglong2*)((C).vp + r_);                                                \
             }                                                                                                  \
-            if (VNULL) vm[u] = (uint32_t)vbm[(voff + r_) >> 3] >> ((voff + r_) & 7);                           \
-            if (TWO) vw[u] = *(const ulonglong2*)(vp2 + r_);                                                   \
-            if (HAS_PRED && !PRED_IS_V) pv[u] = *(const double2*)(pp + r_);                                    \
+            if (VNULL) vm[u] = (uint32_t)(C).vbm[((C).voff + r_) >> 3] >> (((C).voff + r_) & 7);               \
+            if (TWO) vw[u] = *(const ulonglong2*)((C).vp2 + r_);                                               \
+            if (HAS_PRED && !PRED_IS_V) pv[u] = *(const double2*)((C).pp + r_);                                \
         }                                                                                                      \
     } while (0)
             if (!have) {
 #pragma unroll
-                for (int u = 0; u < HOT_UNROLL; u++) VNM_HOT_LOAD(u, base);
+                for (int u = 0; u < HOT_UNROLL; u++) VNM_HOT_LOAD(u, base, cur);
             }
-            const int64_t nbase = base + (int64_t)gridDim.x * HOT_TILE;
-            const bool nfull = tile + gridDim.x < a.ntiles && nbase + (int64_t)(HOT_UNROLL - 1) * 2 * AGG_BLOCK + 1 < a.nrows;
+            bool nfull = tile + gridDim.x < a.ntiles;
+            if (nfull) { locate(tile + gridDim.x, nxt); nfull = nxt.lt * HOT_TILE + HOT_TILE <= nxt.nrows; }
+            const int64_t nbase = nxt.lt * HOT_TILE + 2 * tid;
 #pragma unroll
             for (int u = 0; u < HOT_UNROLL; u++) {
                 const ulonglong2 k = kk[u];
@@ -792,7 +834,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                 // a NULL predicate value compares like NaN (pred_eval: the reference sees NumPy NaNs there)
                 const double p0 = PRED_IS_V ? (ok0 ? __longlong_as_double((long long)v0) : __builtin_nan("")) : pv[u].x;
                 const double p1 = PRED_IS_V ? (ok1 ? __longlong_as_double((long long)v1) : __builtin_nan("")) : pv[u].y;
-                if (nfull) VNM_HOT_LOAD(u, nbase);
+                if (nfull) VNM_HOT_LOAD(u, nbase, nxt);
                 if (!HAS_PRED || cmp_apply<double>(op, p0, thr)) {
                     int slot = hot_slot(lkey, S, smask, &s_fill, k.x, spread);
                     if (slot >= 0) {
@@ -817,7 +859,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
             for (int u = 0; u < HOT_UNROLL; u++)
                 for (int e = 0; e < 2; e++) {
                     int64_t r = base + (int64_t)u * 2 * AGG_BLOCK + e;
-                    if (r >= a.nrows) continue;
+                    if (r >= cur.nrows) continue;
                     const uint64_t vb = FROM_ENT ? a.ent[r].y : (HAS_VAL ? (a.has_expr ? (uint64_t)__double_as_longlong(expr_eval1(a.expr, r)) : vp[r]) : 0);
                     const uint64_t kb = FROM_ENT ? a.ent[r].x : kp[r];
                     const bool ok = !VNULL || ((vbm[(voff + r) >> 3] >> ((voff + r) & 7)) & 1);
@@ -834,8 +876,8 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
                 }
         }
         // saturated keys: straight to the HBM table, out of line (rows base + e + u * 2 * AGG_BLOCK)
-        if (!FROM_ENT && sat0) agg_rows_to_table(a, base, 2 * AGG_BLOCK, sat0, &s_new);
-        if (!FROM_ENT && sat1) agg_rows_to_table(a, base + 1, 2 * AGG_BLOCK, sat1, &s_new);
+        if (!FROM_ENT && sat0) agg_rows_to_table(a, base, 2 * AGG_BLOCK, sat0, &s_new, nseg ? kp : nullptr, vp);
+        if (!FROM_ENT && sat1) agg_rows_to_table(a, base + 1, 2 * AGG_BLOCK, sat1, &s_new, nseg ? kp : nullptr, vp);
         __syncthreads();
         const unsigned fill_now = s_fill;
         need_check = fill_now > (unsigned)S / 2;
@@ -3112,6 +3154,16 @@ struct vnm_agg {
     std::vector<vnm_agg*> parts;
     std::vector<std::vector<int>> part_funcs;   // [part][function of the part] -> function index here
     bool split_tried = false;
+    // Asynchronous streams (round 4, vnm_agg_set_async): hot-shape batches WAIT here (the caller keeps their buffers alive) and go
+    // to the device together as the segments of one logical batch -- at vnm_agg_sync / finish / result, when 2^30 rows or 256
+    // batches are waiting, or when a batch of another shape arrives.  No host read-back, allocation or launch per next().
+    bool async = false;
+    struct QBatch { int64_t nrows; vnm_dcol key, col, pred; };
+    std::vector<QBatch> q;
+    int64_t q_rows = 0;
+    bool q_pred_is_v = false;
+    const std::vector<QBatch>* segs_active = nullptr;   // set around the one vnm_agg_next_device call that processes the queue
+    std::vector<VSeg> seg_host;                         // the segment table of the last launch (kept until the next one: H2D source)
 };
 
 namespace {
@@ -3919,6 +3971,29 @@ int launch_dense_final(const DFinalArgs& df, int tb, int out, bool lo64, hipStre
     return 0;
 }
 
+// The waiting batches of a stream (h->segs_active) as the segment table of one launch whose tiles hold `tile` rows: every segment
+// starts a tile of its own.  The table lives in `pool` (freed in stream order); its host copy stays in the handle until the next one.
+int upload_segs(vnm_agg* h, int64_t tile, const VSeg** dev, int* nseg, int64_t* ntiles, PoolScope& pool, hipStream_t s) {
+    const std::vector<vnm_agg::QBatch>& q = *h->segs_active;
+    h->seg_host.resize(q.size());
+    int64_t t = 0;
+    for (size_t i = 0; i < q.size(); i++) {
+        VSeg& g = h->seg_host[i];
+        g.kp = (const uint64_t*)q[i].key.values + q[i].key.offset;
+        g.vp = (const uint64_t*)q[i].col.values + q[i].col.offset;
+        g.pp = h->pred_set ? (const double*)q[i].pred.values + q[i].pred.offset : nullptr;
+        g.vvalid = nullptr; g.voff = 0;
+        g.nrows = q[i].nrows;
+        g.first_tile = t;
+        t += (q[i].nrows + tile - 1) / tile;
+    }
+    VSeg* d = (VSeg*)pool.take(q.size() * sizeof(VSeg));
+    if (!d) return 1;
+    VNM_HIP(hipMemcpyAsync(d, h->seg_host.data(), q.size() * sizeof(VSeg), hipMemcpyHostToDevice, s));
+    *dev = d; *nseg = (int)q.size(); *ntiles = t;
+    return 0;
+}
+
 // Runs the deferred final pass of the dense path.  DF_RUN: the pending state becomes the handle's run (and is released);
 // DF_COLS: `cols` names the output columns (capacity pending->dstride), *n_out = groups written, the pending entries STAY (a later
 // finish() can still produce the partial state); DF_TABLE: the tables go to pending->table (rc 2: compensation terms out of the
@@ -4009,6 +4084,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     const bool has_val = generic ? g.has_val != 0 : true;
     // nullable value column: NULL flags travel with the entries (generic programs) -- or, vn_fold, the hot program filtered by that
     // column itself: pass 1 drops the NULL rows with the filter and nothing after it ever sees a flag
+    if (h->segs_active && generic) return 2;   // (stream segments: the hot program's ring scatter only)
     const bool vn = has_val && a.cols[0].validity != nullptr && (generic || vn_fold);
     if (vn && ((!vn_fold && !nspill_out) || a.has_expr)) return 2;
     if (vn_fold && (generic || !a.hot_pred_is_v)) return 2;
@@ -4109,6 +4185,8 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
 #define VNM_DRING_B(FR_, CT_, HV_, BLK_, PR_, PV_, VN_, GRID_, ARGS_, CAP_)                                              \
     do {                                                                                                                \
         const size_t lds_ = (((size_t)(ARGS_).nparts * (CAP_) * ((HV_ ? 8 : 0) + sizeof(CT_))) + 15) & ~(size_t)15;       \
+        /* the waiting batches of a stream: one segment each, sub-tiles of 2 * PR_ * BLK_ rows */                       \
+        if (FR_ && h->segs_active && upload_segs(h, (int64_t)2 * PR_ * BLK_, &(ARGS_).segs, &(ARGS_).nseg, &(ARGS_).nsub, seg_pool, s)) { release(); pool_free(spill); return 1; } \
         /* round limit (skew): two insert / flush rounds per sub-tile, where an even spread of a sub-tile's entries (every */ \
         /* row surviving) fits ONE */                                                                                   \
         if (2 * PR_ * BLK_ <= (ARGS_).nparts * ((CAP_) - DR_FB) && ring_limit) {                                        \
@@ -4142,6 +4220,8 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         else VNM_DRING_P(true, CT_, true, false, true, GRID_, ARGS_, CAP_);                                              \
     } while (0)
     const int rcap1 = (use_ring & 1) && !a.has_expr ? ring_cap_for(np1, (has_val ? 8 : 0) + (c16_1 ? 2 : 4)) : 0;
+    PoolScope seg_pool;
+    if (h->segs_active && (!rcap1 || vn)) { release(); pool_free(spill); return 2; }   // (only the ring scatter reads segments)
     {
         KernelTimer timer("agg_part_scatter1", s);
         if (rcap1 && vn) {
@@ -4757,7 +4837,9 @@ struct PartJoinArgs {
     int64_t n;
     const int64_t* perm;          // perm[i] = the part's group with the i-th smallest key
     const uint64_t* key_src;      // the part's key words
+    const uint64_t* mask_src;     // ... and its null-mask words (1 = the NULL-key group, whose key word is 0)
     uint64_t* key_out;            // first part: writes the joined key column; the others compare with it (same rows -> same keys)
+    uint64_t* mask_out;
     int check;
     unsigned long long* flag;
     int nw;
@@ -4769,11 +4851,18 @@ struct PartJoinArgs {
 __global__ __launch_bounds__(256) void part_join_kernel(PartJoinArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     bool bad = false;
+    // The parts are sorted by key word alone; the NULL-key group (key word 0, mask 1) and a real key 0 are then the first two
+    // rows in an order each part decides for itself: the real key goes first, the NULL group second, in every part.
+    bool swap01 = false;
+    if (a.n >= 2) {
+        const int64_t g0 = a.perm[0], g1 = a.perm[1];
+        swap01 = a.key_src[g0] == 0 && a.key_src[g1] == 0 && a.mask_src[g0] != 0 && a.mask_src[g1] == 0;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
-        const int64_t g = a.perm[i];
-        const uint64_t k = a.key_src[g];
-        if (a.check) bad = bad || a.key_out[i] != k;
-        else a.key_out[i] = k;
+        const int64_t g = a.perm[swap01 && i < 2 ? 1 - i : i];
+        const uint64_t k = a.key_src[g], m = a.mask_src[g];
+        if (a.check) bad = bad || a.key_out[i] != k || a.mask_out[i] != m;
+        else { a.key_out[i] = k; a.mask_out[i] = m; }
         for (int w = 0; w < a.nw; w++) a.dst[w][i] = a.src[w][g];
     }
     if (bad) __hip_atomic_store(a.flag, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -4850,7 +4939,7 @@ int collapse_parts(vnm_agg* h, hipStream_t s) {
         bool ok = rk && ra && flag;
         for (int p = 0; p < k && ok; p++) ok = (perm[p] = (int64_t*)pool.take((size_t)n * 8)) != nullptr;
         if (!ok) { pool_free(rk); pool_free(ra); return 1; }
-        int rc = hipMemsetAsync(flag, 0, 8, s) != hipSuccess || hipMemsetAsync(rk + stride, 0, (size_t)stride * 8, s) != hipSuccess;
+        int rc = hipMemsetAsync(flag, 0, 8, s) != hipSuccess;
         const int asc = VNM_ASC;
         for (int p = 0; p < k && !rc; p++) {
             vnm_dcol kc{};
@@ -4864,7 +4953,8 @@ int collapse_parts(vnm_agg* h, hipStream_t s) {
             for (int p = 0; p < k && !rc; p++) {
                 const vnm_agg* c = h->parts[p];
                 PartJoinArgs ja{};
-                ja.n = n; ja.perm = perm[p]; ja.key_src = c->dkey; ja.key_out = rk; ja.check = p > 0; ja.flag = flag;
+                ja.n = n; ja.perm = perm[p]; ja.key_src = c->dkey; ja.mask_src = c->dkey + c->dstride; ja.key_out = rk; ja.mask_out = rk + stride;
+                ja.check = p > 0; ja.flag = flag;
                 for (size_t q = 0; q < h->part_funcs[p].size() && !rc; q++) {
                     const FuncOut& mine = h->outs[h->part_funcs[p][q]];
                     const FuncOut& theirs = c->outs[q];
@@ -4976,13 +5066,20 @@ int vnm_agg_estimate_groups(vnm_agg* h, int64_t nrows, const vnm_dcol* key, int6
     return 0;
 }
 
-int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs,
-                        const vnm_dcol* pred, void* stream) {
+// rc of next_device_impl when the waiting batches of a stream (h->segs_active) would have to take a path whose kernels read ONE batch:
+// nothing has been aggregated, the caller sends the batches one by one
+constexpr int VNM_RC_SINGLY = 77;
+#define VNM_SEG_ONLY(what) do { if (h->segs_active) { if (getenv("VNM_AGG_TRACE")) fprintf(stderr, "[agg] stream segments: one by one (%s)\n", what); return VNM_RC_SINGLY; } } while (0)
+
+static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs,
+                            const vnm_dcol* pred, void* stream) {
     VNM_TRY(ensure_init());
     if (!h) return set_error("vnm_agg_next_device: null handle");
     if (h->pred_set && !pred) return set_error("vnm_agg_next_device: predicate set but no predicate column given");
     hipStream_t s = as_stream(stream);
     invalidate_result(h);
+    // rows the samplers may read through keys[0] (the first segment of a stream's waiting batches)
+    const int64_t est_rows = h->segs_active ? (*h->segs_active)[0].nrows : nrows;
     if (nrows <= 0) {
         if (h->plan.n_keys == 0 || h->hint <= 0) VNM_TRY(ensure_table(h, nrows, s));
         return 0;
@@ -4997,9 +5094,15 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     const bool pack_single = h->single && h->plan.n_keys == 1 && !key_plain &&
                              (h->hint > 2400 || (h->hint == 0 && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22)));
     if ((!h->single && h->plan.n_keys >= 2) || pack_single || (h->single && h->inner)) {
+        VNM_SEG_ONLY("packed keys");
         for (int j = 0; j < h->plan.n_keys; j++)
             if (keys[j].type != h->plan.key_types[j]) return set_error("vnm_agg_next_device: key %d changed type between batches", j);
-        if (!h->pack_tried && !h->have_table && getenv("VNM_AGG_NO_PACK") == nullptr) {
+        // ... only into an EMPTY handle: an operator that already holds groups of earlier batches in any form (HBM table, run,
+        // deferred dense pass, stream table, the parts of a split program) keeps them -- a single key whose FIRST batch was plain
+        // (no validity bitmap) and whose later batch brings NULL keys takes the general scan for that batch instead
+        // (the inner operator's result used to replace, not join, what the handle held)
+        const bool empty_handle = !h->have_table && !h->have_run && !h->pending && !h->scan_pending && h->parts.empty();
+        if (!h->pack_tried && empty_handle && getenv("VNM_AGG_NO_PACK") == nullptr) {
             h->pack_tried = true;
             int err = 0;
             if (plan_packing(h, keys, nrows, s, &err)) {
@@ -5012,7 +5115,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
                 // the caller gave a group count (the dense path then cuts pass 2 into more work items, see heavy_share)
                 for (int j = 0; j < h->plan.n_keys; j++) if (keys[j].validity) h->inner->heavy_share = std::max(h->inner->heavy_share, 0.01);
             } else if (err) return err;
-            else if (!h->single && !h->have_run && !h->pending && getenv("VNM_AGG_NO_TUPLE") == nullptr) {
+            else if (!h->single && getenv("VNM_AGG_NO_TUPLE") == nullptr) {
                 // too wide for one word even as per-column dictionary codes: tuple -> group id through a dictionary
                 // (before: agg_wide_kernel, one HBM atomic per row and accumulator word)
                 VNM_TRY(enter_tuple_mode(h, nrows, s));
@@ -5055,7 +5158,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     }
 
     // more input columns than a partition entry carries (or as many, plus a validity word) and many groups: split the program
-    if (!h->parts.empty()) return next_parts(h, nrows, keys, inputs, pred, stream);
+    if (!h->parts.empty()) { VNM_SEG_ONLY("split program"); return next_parts(h, nrows, keys, inputs, pred, stream); }
     if (!h->split_tried && key_plain && h->single && keys[0].type == h->plan.key_types[0] && !h->have_table && !h->have_run && !h->pending &&
         !h->expr_active && getenv("VNM_AGG_NO_SPLIT") == nullptr) {
         bool any_null = false;
@@ -5065,7 +5168,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
             if (h->hint == 0 && !h->estimated && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) && getenv("VNM_AGG_NO_ESTIMATE") == nullptr) {
                 int64_t est = 0;
                 KernelTimer timer("agg_estimate", s);
-                VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s));
+                VNM_TRY(estimate_groups(h, keys[0], est_rows, &est, s));
                 if (est) { h->hint = est; h->estimated = true; }
             }
             if (h->hint > env_i64("VNM_AGG_PART_MIN_GROUPS", std::min<int64_t>(2400, (int64_t)lds_slots_for(h->plan) * 6 / 10))) {
@@ -5093,6 +5196,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     const int cus = device_info().num_cus;
 
     if (h->plan.n_keys == 0) {
+        VNM_SEG_ONLY("no GROUP BY");
         VNM_TRY(ensure_table(h, nrows, s));
         a.g = h->g;
         int grid = cus * 8;
@@ -5253,11 +5357,11 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         int64_t est = 0, dense_lb = 0;
         KernelTimer timer("agg_estimate", s);
         // the small sample first: a conclusive (small) group count needs neither the key range nor HyperLogLog
-        VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s, dense_shape ? &dense_lb : nullptr));
+        VNM_TRY(estimate_groups(h, keys[0], est_rows, &est, s, dense_shape ? &dense_lb : nullptr));
         if (est == 0) {
-            if (h->dense_state == 0) VNM_TRY(plan_dense(h, keys[0], nrows, s));
+            if (h->dense_state == 0) VNM_TRY(plan_dense(h, keys[0], est_rows, s));
             if (h->dense_state == 1 && h->dense_span <= 32 * dense_lb && h->dense_span <= 4 * nrows) dense_go = true;
-            else VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s));   // too sparse (or not a code-able key): full estimate
+            else VNM_TRY(estimate_groups(h, keys[0], est_rows, &est, s));   // too sparse (or not a code-able key): full estimate
         }
         if (est) { h->hint = est; h->estimated = true; }
         else if (dense_go) { h->estimated = true; h->dense_by_bound = true; }   // later batches of the stream: no sample again
@@ -5270,7 +5374,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     if (dense_shape && !dense_go && h->hint > part_min0) {
         if (h->dense_state == 0) {
             KernelTimer timer("agg_estimate", s);
-            VNM_TRY(plan_dense(h, keys[0], nrows, s));
+            VNM_TRY(plan_dense(h, keys[0], est_rows, s));
         }
         if (h->dense_state == 1 && h->dense_span <= 32 * h->hint && h->dense_span <= 4 * nrows) dense_go = true;
     }
@@ -5309,9 +5413,10 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         getenv("VNM_AGG_NO_DSCAN") == nullptr) {
         if (h->dense_state == 0) {
             KernelTimer timer("agg_estimate", s);
-            VNM_TRY(plan_dense(h, keys[0], nrows, s));
+            VNM_TRY(plan_dense(h, keys[0], est_rows, s));
         }
         if (h->dense_state == 2) {
+            VNM_SEG_ONLY("small-range LDS scan");
             if (h->pending) VNM_TRY(complete_pending(h, s));   // (this path makes a run of its own)
             if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
             if (dense_generic && h->scan_pending) VNM_TRY(flush_scan_pending(h, s));
@@ -5349,6 +5454,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         bool vn_spill = false;        // the spill lists of the nullable dense path (entries + keys of NULL-value rows)
         bool spill_is_wide = false;   // the spill holds [n][E]-word entries of the wide scatter kernels (not the (key, value) pairs of the hot / dense paths)
         auto run_partitioned = [&]() {
+            if (h->segs_active) return VNM_RC_SINGLY;               // (its kernels read one batch)
             if (h->pending && complete_pending(h, s)) return 1;     // (the hash-partitioned path makes a run of its own)
             if (h->have_run && merge_run_into_table(h, s)) return 1;
             const int r = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
@@ -5360,7 +5466,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
             vn_spill = prc == 0 && dense_vn && (spill || nspill);
             if (prc == 2 && h->hint == 0) {  // the dense attempt failed before G was ever estimated
                 int64_t est = 0;
-                VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s));
+                VNM_TRY(estimate_groups(h, keys[0], est_rows, &est, s));
                 h->hint = est;
                 h->estimated = true;
             }
@@ -5377,7 +5483,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         for (int retry = 0; prc == 3 && retry < 2; retry++) {
             int64_t est = 0;
             if (retry == 0 && !h->estimated) {
-                VNM_TRY(estimate_groups(h, keys[0], nrows, &est, s));
+                VNM_TRY(estimate_groups(h, keys[0], est_rows, &est, s));
                 h->estimated = true;
             }
             h->hint = std::min<int64_t>(std::max<int64_t>(h->hint * 4, est + est / 4), (int64_t)1600 * env_i64("VNM_AGG_PART_L1_MAX", 256) * 512);
@@ -5385,6 +5491,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         }
         if (prc == 0 && !spill && !nspill) { h->rows_seen += nrows; return 0; }
         if (prc == 1) return 1;
+        if (prc == VNM_RC_SINGLY) { VNM_SEG_ONLY("hash partitions"); }
         if (prc == 0 && vn_spill) {
             VNM_TRY(vn_spill_to_columns());
         } else if (prc == 0 && spill_is_wide) {   // spilled wide entries -> columns; the general scan takes them as a batch of its own
@@ -5418,8 +5525,13 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         }
     }
     const int64_t scan_n = a.nrows;
+    PoolScope seg_pool;
+    if (h->segs_active && !a.ent) {   // the waiting batches of a stream as segments of one scan (agg_hot_kernel, the hot shape only)
+        if (!(hot_scan && hot) || scan_no_pred || a.has_expr) VNM_SEG_ONLY("general scan");
+    }
     VNM_TRY(ensure_table(h, scan_n, s, spill != nullptr || nspill != nullptr));
     if (hot_scan) a.ntiles = (scan_n + HOT_TILE - 1) / HOT_TILE;
+    if (h->segs_active && !a.ent) VNM_TRY(upload_segs(h, HOT_TILE, &a.segs, &a.nseg, &a.ntiles, seg_pool, s));
     const int lds_tile = AGG_TILE;
     int grid = h->single ? cus : cus * 4;
     if (grid > a.ntiles) grid = (int)a.ntiles;
@@ -5493,7 +5605,94 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
         VNM_HIP(hipMemcpyAsync(ctl, h->g.ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
         VNM_HIP(hipStreamSynchronize(s));
         if (ctl[1] == 2) return set_error("aggregate: HBM hash table overflow (internal error)");
-        // a hint below the partitioning threshold with far more actual groups ran this scan into flush storms (77 ms per
+        // a hint below the partitioning threshold with far more actual groups ran this scan into flush storms// The waiting batches of an asynchronous stream (vnm_agg_set_async) -> the device: as the segments of ONE logical batch where the
+// path's kernels take segments (the dense-key path's ring scatter, the hot-shape LDS scan), one by one otherwise.
+static int flush_queue(vnm_agg* h, void* stream) {
+    if (h->q.empty()) return 0;
+    std::vector<vnm_agg::QBatch> q;
+    q.swap(h->q);
+    const int64_t total = h->q_rows;
+    h->q_rows = 0;
+    int rc = VNM_RC_SINGLY;
+    auto one = [&](const vnm_agg::QBatch& b, int64_t n) {
+        vnm_dcol in[AGG_MAX_FUNCS];
+        for (int i = 0; i < h->n_funcs; i++) { memset(&in[i], 0, sizeof(vnm_dcol)); if (h->func_col[i] >= 0) in[i] = b.col; }
+        return next_device_impl(h, n, &b.key, in, h->pred_set ? &b.pred : nullptr, stream);
+    };
+    if (q.size() > 1 && getenv("VNM_AGG_NO_SEGMENTS") == nullptr) {
+        h->segs_active = &q;
+        rc = one(q[0], total);
+        h->segs_active = nullptr;
+    }
+    if (rc == VNM_RC_SINGLY) {
+        rc = 0;
+        for (size_t i = 0; i < q.size() && !rc; i++) rc = one(q[i], q[i].nrows);
+    }
+    return rc;
+}
+
+// does this batch have the shape whose kernels take stream segments (VSeg)?  The hot shape: one plain 8-byte key, {COUNT(*), COUNT,
+// SUM, AVG} of ONE plain float64 column, a plain float64 predicate column or none.
+static bool queueable(const vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs, const vnm_dcol* pred, bool* pred_is_v) {
+    if (!h->single || h->plan.n_keys != 1 || h->plan.n_cols != 1 || h->inner || !h->parts.empty() || h->tuple_mode || h->expr_col >= 0) return false;
+    if (nrows <= 0 || nrows >= (1LL << 30)) return false;
+    auto plain8 = [](const vnm_dcol& c) { return type_width(c.type) == 8 && !c.validity && (c.offset & 1) == 0 && ((uintptr_t)c.values & 15) == 0; };
+    const vnm_dcol& col = inputs[h->col_first_func[0]];
+    if (!plain8(keys[0]) || keys[0].type != h->plan.key_types[0] || !plain8(col) || col.type != VNM_F64) return false;
+    for (int o = 0; o < h->plan.n_ops; o++) {
+        const int k = h->plan.ops[o].kind;
+        if (k != A_COUNT_ROWS && k != A_COUNT_VALID && k != A_SUM_F64) return false;
+    }
+    for (int i = 0; i < h->n_funcs; i++)   // every function reads that one column (COUNT(*): none)
+        if (h->func_col[i] >= 0 && (inputs[i].values != col.values || inputs[i].offset != col.offset || inputs[i].validity)) return false;
+    *pred_is_v = false;
+    if (h->pred_set) {
+        if (!pred || !plain8(*pred) || pred->type != VNM_F64) return false;
+        *pred_is_v = pred->values == col.values && pred->offset == col.offset;
+    }
+    return true;
+}
+
+int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs,
+                        const vnm_dcol* pred, void* stream) {
+    if (!h) return set_error("vnm_agg_next_device: null handle");
+    if (h->async && keys && inputs) {
+        bool piv = false;
+        if (queueable(h, nrows, keys, inputs, pred, &piv) && (h->q.empty() || piv == h->q_pred_is_v)) {
+            // the first batch of an operator goes through on its own: it settles the path (estimates, code range), and its errors
+            // are raised where the caller expects them
+            if (h->rows_seen > 0) {
+                if (h->q_rows + nrows > (1LL << 30) || h->q.size() >= 256) VNM_TRY(flush_queue(h, stream));
+                vnm_agg::QBatch b{};
+                b.nrows = nrows; b.key = keys[0]; b.col = inputs[h->col_first_func[0]];
+                if (h->pred_set) b.pred = *pred;
+                h->q.push_back(b);
+                h->q_rows += nrows;
+                h->q_pred_is_v = piv;
+                invalidate_result(h);
+                return 0;
+            }
+        }
+    }
+    VNM_TRY(flush_queue(h, stream));
+    return next_device_impl(h, nrows, keys, inputs, pred, stream);
+}
+
+int vnm_agg_set_async(vnm_agg* h, int enabled) {
+    if (!h) return set_error("vnm_agg_set_async: null handle");
+    if (!enabled && !h->q.empty()) return set_error("vnm_agg_set_async: batches are waiting (call vnm_agg_sync first)");
+    h->async = enabled != 0;
+    return 0;
+}
+
+int vnm_agg_sync(vnm_agg* h, void* stream) {
+    if (!h) return set_error("vnm_agg_sync: null handle");
+    VNM_TRY(flush_queue(h, stream));
+    VNM_HIP(hipStreamSynchronize(as_stream(stream)));
+    return 0;
+}
+
+ (77 ms per
         // 1e9 rows at G = 1e7): the table's fill is the lesson for the batches that follow (checking small hints up
         // front would cost every correctly hinted query ~0.3 ms)
         if (h->single && nrows >= (1 << 22) && (int64_t)ctl[2] > 2 * 2400 && (int64_t)ctl[2] > h->hint) h->hint = (int64_t)(ctl[2] + ctl[2] / 4);
