@@ -466,7 +466,9 @@ def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream,
         parts = [(DeviceColumn.from_torch(kt[i * B:(i + 1) * B]), DeviceColumn.from_torch(vt[i * B:(i + 1) * B])) for i in range(nb)]
 
         def streamed():
-            agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())])
+            # stream_mode (vnm_agg_set_async): next() records the batch; the waiting batches go to the device as the segments of
+            # one launch -- no launch / allocation / host read-back per batch
+            agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())], stream_mode=True)
             agg.set_predicate(">", x_thr)
             for kc_, vc_ in parts:
                 agg.next([kc_], [vc_, vc_], pred=vc_, nrows=B, stream=stream)

@@ -173,6 +173,20 @@ int vnm_agg_set_hint(vnm_agg* h, int64_t expected_groups);
  * COUNT_STAR).  pred may be NULL when no predicate is set.  Asynchronous on `stream`. */
 int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs,
                         const vnm_dcol* pred, void* stream);
+/* Asynchronous streams (round 4).  The reference feeds an aggregate one record batch per Next() call (base_aggregate.cpp:23-45;
+ * TableReaderOperator / stream_reader.py:32-94 produce them) and its state does not depend on where the batches are cut.  With
+ * vnm_agg_set_async(h, 1), vnm_agg_next_device only RECORDS a batch of the hot shape (one plain 8-byte key; COUNT(*) / COUNT /
+ * SUM / AVG of one plain float64 column; a plain float64 predicate column or none): no launch, allocation or host read-back per
+ * call.  The waiting batches go to the device together, as the segments of ONE logical batch (one launch of the path's kernels
+ * over all of them), when vnm_agg_sync / vnm_agg_finish / any result call is made, when 2^30 rows or 256 batches are waiting, or
+ * when a batch of another shape arrives (that one is processed as usual, after the waiting ones).  The first batch of an operator
+ * is always processed in its own call (it settles estimates and the path; schema errors surface where they do in the reference).
+ * CONTRACT: the buffers of every batch passed while async is on must stay alive and unchanged until the next vnm_agg_sync /
+ * vnm_agg_finish / vnm_agg_result_* / vnm_agg_dense_table call on the handle returns.  Results are identical to the synchronous
+ * mode (same kernels, same merges).  Default: off. */
+int vnm_agg_set_async(vnm_agg* h, int enabled);
+/* processes every waiting batch and waits for `stream` */
+int vnm_agg_sync(vnm_agg* h, void* stream);
 /* Expressions inside aggregates -- `sum((1 - total) * (2 + tax) * (1 - tip))`, vinum/tests/test_query_results.py:436-443;
  * the reference's planner projects the expression into a temporary column first (vinum/planner/planner.py:384-417).
  * vnm_agg_set_input_expr: the input column of function `func_idx` (and of every function sharing its in_col_id; declare

@@ -81,3 +81,79 @@ def test_null_keys_first_appear_in_a_later_batch(route, later, hint, monkeypatch
     exp = _oracle(O.SINGLE, ["k"], funcs, batches, pred)
     assert got.num_rows == exp.num_rows, (got.num_rows, exp.num_rows)
     util.assert_agg_equal(got, exp, funcs, ["k"], what=f"{route}, later batch with {later}", source=pa.Table.from_batches(batches) if not pred else None)
+
+
+def _launches(name):
+    from vinum_amd import _lib as L
+    ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+    L.lib().vnm_profile_query(name, ctypes.byref(ms), ctypes.byref(cnt))
+    return cnt.value
+
+
+@pytest.mark.parametrize("pred", ["on_input", "on_other", "none"])
+@pytest.mark.parametrize("route", ["dense_two_level", "dense_one_level", "dense_split_final", "lds_scan_g7", "stream_table_g3000",
+                                   "hash_partitions", "shape_changes_midstream", "generic_program"])
+def test_async_stream_of_batches(route, pred, monkeypatch):
+    """vnm_agg_set_async: the batches of a stream wait in the operator and go to the device as the SEGMENTS of one launch (dense ring
+    scatter, hot LDS scan) or one by one (every other path).  Same result as the oracle fed batch by batch
+    (base_aggregate.cpp:23-45: the state does not depend on where the batches are cut) -- ragged batch sizes (odd, tiny, empty, not a
+    multiple of any tile), a batch of another shape in the middle of the stream, a second sync point."""
+    from oracle import oracle as O
+    from vinum_amd import _lib as L, ops
+    from vinum_amd.device import DeviceColumn
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    groups = {"dense_two_level": 1_500_000, "dense_one_level": 900_000, "dense_split_final": 40_000, "lds_scan_g7": 7,
+              "stream_table_g3000": 3_000, "hash_partitions": 200_000, "shape_changes_midstream": 900_000, "generic_program": 900_000}[route]
+    if route == "dense_two_level":
+        monkeypatch.setenv("VNM_DENSE_ONE_LEVEL", "0")
+    mult = 7919 if route == "hash_partitions" else 1
+    rng = np.random.default_rng(len(route) * 13 + len(pred))
+    sizes = [600_000, 262_144, 300_001, 77, 8192, 123_457, 499_999, 16_384 + 2, 650_000, 0]   # (sync after the seventh; the empty batch flushes too)
+
+    batches = []
+    for i, n in enumerate(sizes):
+        if n == 0:
+            batches.append(pa.RecordBatch.from_pydict({"k": pa.array([], pa.int64()), "v": pa.array([], pa.float64()), "p": pa.array([], pa.float64())}))
+            continue
+        nullable = route == "shape_changes_midstream" and i == 5
+        cols = {"k": pa.array(rng.integers(0, groups, n).astype(np.int64) * mult - 17),
+                "v": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0, mask=(rng.random(n) < 0.1) if nullable else None),
+                "p": pa.array(rng.integers(0, 2**12, n).astype(np.float64) / 64.0)}
+        batches.append(pa.RecordBatch.from_pydict(cols))
+    if route == "generic_program":
+        funcs = [(O.MIN, "v", "lo"), (O.MAX, "v", "hi"), (O.COUNT_STAR, "", "n")]
+    else:
+        funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.COUNT, "v", "c"), (O.COUNT_STAR, "", "n")]
+    predicate = {"on_input": ("v", ">", 64.0), "on_other": ("p", ">", 20.0), "none": None}[pred]
+    names = batches[0].schema.names
+    fspec = [(f, names.index(col) if col else None, pa.float64() if col else None) for f, col, _ in funcs]
+
+    def run(stream_mode):
+        agg = ops.DeviceAggregate(O.SINGLE, [pa.int64()], fspec, stream_mode=stream_mode)
+        if predicate:
+            agg.set_predicate(predicate[1], predicate[2])
+        for i, b in enumerate(batches):
+            kc, vc, pc = (DeviceColumn.from_arrow(b.column(j)) for j in range(3))
+            agg.next([kc], [vc if col else None for _, col, _ in funcs], pred={"v": vc, "p": pc}[predicate[0]] if predicate else None,
+                     nrows=b.num_rows)
+            if stream_mode and i == 6:
+                agg.sync()                                  # a sync point in the middle of the stream
+        dcols = agg.result_device([0])
+        res = agg.result_arrays([0], ["k"], [f[2] for f in funcs])
+        dev = pa.RecordBatch.from_arrays([c.to_arrow() for c in dcols], names=res.schema.names)
+        util.assert_batches_equal(dev, res, key_names=["k"], what="device finalisation vs host finalisation")
+        agg.close()
+        return res
+
+    L.lib().vnm_set_profiling(1)
+    got = run(True)
+    p1, scan = _launches(b"agg_part_scatter1"), _launches(b"agg_scan")
+    L.lib().vnm_set_profiling(0)
+    # the segment routes: the first batch on its own, then one launch per sync point -- not one per batch
+    if route in ("dense_two_level", "dense_one_level", "dense_split_final"):
+        assert p1 == 3 and scan == 0, (p1, scan)
+    elif route == "lds_scan_g7":
+        assert p1 == 0 and scan == 3, (p1, scan)
+    exp = _oracle(O.SINGLE, ["k"], funcs, batches, predicate)
+    util.assert_agg_equal(got, exp, funcs, ["k"], what=f"async stream, {route}, pred {pred}")
+    util.assert_agg_equal(run(False), exp, funcs, ["k"], what=f"the same stream batch by batch, {route}, pred {pred}")

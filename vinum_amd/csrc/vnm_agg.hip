@@ -5605,7 +5605,21 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
         VNM_HIP(hipMemcpyAsync(ctl, h->g.ctl, sizeof(ctl), hipMemcpyDeviceToHost, s));
         VNM_HIP(hipStreamSynchronize(s));
         if (ctl[1] == 2) return set_error("aggregate: HBM hash table overflow (internal error)");
-        // a hint below the partitioning threshold with far more actual groups ran this scan into flush storms// The waiting batches of an asynchronous stream (vnm_agg_set_async) -> the device: as the segments of ONE logical batch where the
+        // a hint below the partitioning threshold with far more actual groups ran this scan into flush storms (77 ms per
+        // 1e9 rows at G = 1e7): the table's fill is the lesson for the batches that follow (checking small hints up
+        // front would cost every correctly hinted query ~0.3 ms)
+        if (h->single && nrows >= (1 << 22) && (int64_t)ctl[2] > 2 * 2400 && (int64_t)ctl[2] > h->hint) h->hint = (int64_t)(ctl[2] + ctl[2] / 4);
+        if (!ctl[1]) break;  // no block ran out of room: every tile was processed
+        // grow (x4, or to the projected final size) and relaunch; blocks resume from progress[]
+        uint64_t new_cap = h->g.cap * 4;
+        if (h->hint <= 0 && round >= 1) new_cap = h->g.cap * 16;
+        VNM_TRY(table_grow(h, new_cap, s));
+    }
+    h->rows_seen += nrows;
+    return 0;
+}
+
+// The waiting batches of an asynchronous stream (vnm_agg_set_async) -> the device: as the segments of ONE logical batch where the
 // path's kernels take segments (the dense-key path's ring scatter, the hot-shape LDS scan), one by one otherwise.
 static int flush_queue(vnm_agg* h, void* stream) {
     if (h->q.empty()) return 0;
@@ -5689,20 +5703,6 @@ int vnm_agg_sync(vnm_agg* h, void* stream) {
     if (!h) return set_error("vnm_agg_sync: null handle");
     VNM_TRY(flush_queue(h, stream));
     VNM_HIP(hipStreamSynchronize(as_stream(stream)));
-    return 0;
-}
-
- (77 ms per
-        // 1e9 rows at G = 1e7): the table's fill is the lesson for the batches that follow (checking small hints up
-        // front would cost every correctly hinted query ~0.3 ms)
-        if (h->single && nrows >= (1 << 22) && (int64_t)ctl[2] > 2 * 2400 && (int64_t)ctl[2] > h->hint) h->hint = (int64_t)(ctl[2] + ctl[2] / 4);
-        if (!ctl[1]) break;  // no block ran out of room: every tile was processed
-        // grow (x4, or to the projected final size) and relaunch; blocks resume from progress[]
-        uint64_t new_cap = h->g.cap * 4;
-        if (h->hint <= 0 && round >= 1) new_cap = h->g.cap * 16;
-        VNM_TRY(table_grow(h, new_cap, s));
-    }
-    h->rows_seen += nrows;
     return 0;
 }
 
@@ -5792,6 +5792,7 @@ int vnm_agg_merge_device(vnm_agg* h, int64_t n, uint64_t* const* key_words, uint
     VNM_TRY(ensure_init());
     if (!h) return set_error("vnm_agg_merge_device: null handle");
     hipStream_t s = as_stream(stream);
+    VNM_TRY(flush_queue(h, stream));
     if (h->inner) VNM_TRY(demote_packed(h, s));
     VNM_TRY(collapse_parts(h, s));
     invalidate_result(h);
@@ -5838,6 +5839,7 @@ int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream) {
     VNM_TRY(ensure_init());
     if (!h) return set_error("vnm_agg_finish: null handle");
     hipStream_t s = as_stream(stream);
+    VNM_TRY(flush_queue(h, stream));   // (the waiting batches of an asynchronous stream)
     if (h->n_groups >= 0) {
         if (n_groups) *n_groups = h->n_groups;
         return 0;
@@ -6249,6 +6251,7 @@ int vnm_agg_result_device_alloc(vnm_agg* h, int n_cols, const int* which, void**
         out_values[c] = nullptr; out_bitmaps[c] = nullptr;
     }
     hipStream_t s = as_stream(stream);
+    VNM_TRY(flush_queue(h, stream));   // (the waiting batches of an asynchronous stream)
     auto free_outputs = [&]() { for (int c = 0; c < n_cols; c++) { pool_free(out_values[c]); pool_free(out_bitmaps[c]); out_values[c] = nullptr; out_bitmaps[c] = nullptr; } };
     DensePending* pd = h->inner ? nullptr : h->pending;
     bool fused = pd && !h->have_table && !h->have_run && h->n_groups < 0 && n_cols >= 1 && n_cols <= DF_MAX_OUT && getenv("VNM_AGG_NO_FUSED_RESULT") == nullptr;
@@ -6338,6 +6341,7 @@ int vnm_agg_dense_table(vnm_agg* h, void** table, int* bits, uint64_t* geometry,
     VNM_TRY(ensure_init());
     if (!h || !table || !bits) return set_error("vnm_agg_dense_table: bad argument");
     *table = nullptr; *bits = 0;
+    VNM_TRY(flush_queue(h, stream));
     DensePending* pd = h->inner ? nullptr : h->pending;
     if (!pd || h->have_table || h->have_run || h->n_groups >= 0) return 0;
     const int rc = complete_pending(h, as_stream(stream), DF_TABLE);

@@ -87,7 +87,10 @@ class DeviceAggregate:
 
     funcs: list of (func_id, input_column_index or None, arrow_type of the input or None)."""
 
-    def __init__(self, kind, key_types, funcs, expected_groups=0, rank_aligned=False):
+    def __init__(self, kind, key_types, funcs, expected_groups=0, rank_aligned=False, stream_mode=False):
+        """stream_mode: record batches of a stream are only RECORDED by next() and go to the device together (vnm_agg_set_async:
+        one launch of the path's kernels over all waiting batches instead of launches, allocations and a host read-back per
+        batch).  This object keeps the batches' DeviceColumns alive until they have been processed."""
         self.kind = kind
         self.key_arrow = list(key_types)
         self.funcs = list(funcs)
@@ -109,6 +112,15 @@ class DeviceAggregate:
         if rank_aligned:     # the result will be exchanged between ranks (vinum_amd.distributed)
             L.check(L.lib().vnm_agg_set_exchange_mode(self._h, 1))
         self._pred = False
+        self._waiting = []        # stream_mode: the columns of the batches the library has only recorded so far
+        self._stream_mode = bool(stream_mode)
+        if stream_mode:
+            L.check(L.lib().vnm_agg_set_async(self._h, 1))
+
+    def sync(self, stream=None):
+        """stream_mode: process every waiting batch (vnm_agg_sync); their columns may go afterwards."""
+        L.check(L.lib().vnm_agg_sync(self._h, _stream_ptr(stream)))
+        self._waiting.clear()
 
     def set_predicate(self, op, literal):
         op = CMP_OPS.get(op, op)
@@ -134,11 +146,14 @@ class DeviceAggregate:
             L.check(L.lib().vnm_agg_next_device_expr(self._h, nrows, dcol_array(keys), dcol_array(inputs), p, len(expr_cols),
                                                      dcol_array(expr_cols), _stream_ptr(stream)))
             return
+        if self._stream_mode:     # (the library reads the buffers when the waiting batches are processed)
+            self._waiting.append((keys, inputs, pred))
         L.check(L.lib().vnm_agg_next_device(self._h, nrows, dcol_array(keys), dcol_array(inputs), p, _stream_ptr(stream)))
 
     def finish(self, stream=None) -> int:
         n = ctypes.c_int64(0)
         L.check(L.lib().vnm_agg_finish(self._h, ctypes.byref(n), _stream_ptr(stream)))
+        self._waiting.clear()
         return n.value
 
     def layout(self):
@@ -260,6 +275,7 @@ class DeviceAggregate:
         if rc == 2:
             raise NeedsHostFinalize(L.last_error() or "a 64-bit SUM overflowed: decimal128 result")
         L.check(rc)
+        self._waiting.clear()
         n = ng.value
         self.result_rows = n
         cols = []
@@ -286,6 +302,7 @@ class DeviceAggregate:
         ptr, bits = ctypes.c_void_p(0), ctypes.c_int(0)
         geo = (ctypes.c_uint64 * 4)()
         L.check(L.lib().vnm_agg_dense_table(self._h, ctypes.byref(ptr), ctypes.byref(bits), geo, _stream_ptr(stream)))
+        self._waiting.clear()
         if not ptr.value:
             return None
         return ptr.value, bits.value, tuple(int(g) for g in geo)
