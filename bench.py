@@ -9,9 +9,18 @@ A "step" = one pass of the hot path over one synthetic batch already resident in
         bit-exact float aggregates), X chosen for selectivity 0.5.
     filter (BASELINE.json configs[1]):
         WHERE fare_amount > X over a 1e9-row fp64 column -> compacted column.
-Multi-GPU (--gpus N>1, launched by torch.distributed.run): batches shard by rank (weak scaling), every
-rank aggregates its shard, partial groups are exchanged key-partitioned with one RCCL all_to_all and
-merged by their owner.
+    stream (BASELINE.json configs[3]; the default with --gpus N > 1):
+        the same query over a STREAM of 2^24-row record batches (what stream_csv / TableReaderOperator hand the aggregate,
+        vinum/api/stream_reader.py:32-94), HBM-resident, dealt round-robin to the ranks: every rank streams its
+        59 batches into one operator (vnm_agg_set_async: the waiting batches go to the device as the segments of one
+        launch), G = 1e6 (--groups; G = 7 and the one-batch G = 1e8 shape under "also"), partial aggregates
+        exchanged over RCCL inside the timed region.
+Multi-GPU (--gpus N>1): one process per GPU.  Launched by `python -m torch.distributed.run ... bench.py --gpus N`, or
+by itself: without WORLD_SIZE in the environment `bench.py --gpus N` re-executes itself under torch.distributed.run
+(--nproc-per-node N, rendezvous on 127.0.0.1).  Batches shard by rank (weak scaling), every rank aggregates its shard,
+partial groups are exchanged over RCCL and merged by their owner; rank 0 prints the ONE JSON line.
+VNM_BENCH_DRY_RUN=1: no GPU work at all -- the launch, the rendezvous (gloo), the max-over-ranks timing and the JSON line only
+(tests/test_bench_launch.py runs that here).
 
 Extra keys: "roofline" (HIP-event time of the dominant kernel vs 8 TB/s HBM peak) and "cpu_baseline"
 (the reference's CPU path -- NumPy compare + pyarrow filter + the real reference C++ aggregate from
@@ -37,14 +46,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="groupby", choices=["groupby", "filter", "topk", "project"])
+    ap.add_argument("--workload", default=None, choices=["groupby", "stream", "filter", "topk", "project"],
+                    help="default: groupby (configs[2]) on one GPU, stream (configs[3]) on several")
+    ap.add_argument("--batches", type=int, default=0, help="stream: record batches of 2^24 rows per rank (default: rows // 2^24, at most 60)")
     ap.add_argument("--shape", default="hot", choices=["hot", "count_star", "minmax"],
                     help="group-by function mix: hot = sum,avg (configs[2]); count_star = configs[0]'s query shape "
                          "(no predicate); minmax = min,max -- the latter two run the generic accumulator kernel")
     ap.add_argument("--no-also", action="store_true", help="skip the side measurements (configs[1] filter, G=7 group-by)")
     ap.add_argument("--limit", type=int, default=10)
     ap.add_argument("--rows", type=float, default=1e9)
-    ap.add_argument("--groups", type=float, default=1e8)
+    ap.add_argument("--groups", type=float, default=None, help="default: 1e8 (groupby), 1e6 (stream)")
     ap.add_argument("--selectivity", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true",
@@ -55,7 +66,54 @@ def parse():
                     help="tell the operator the group count (vnm_agg_set_hint).  The reference's operator boundary has no such "
                          "argument, so the headline is the HINT-LESS run: the operator samples the keys itself")
     ap.add_argument("--no-hint", action="store_true", help=argparse.SUPPRESS)  # r01 spelling of what is now the default
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "stream" if args.gpus > 1 else "groupby"
+    if args.groups is None:
+        args.groups = 1e6 if args.workload == "stream" else 1e8
+    return args
+
+
+def self_launch(args):
+    """`bench.py --gpus N` started on its own (no WORLD_SIZE): become `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` -- one process per GPU, rank 0 prints
+    the JSON line on the inherited stdout."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def dry_run(args):
+    """VNM_BENCH_DRY_RUN=1: everything around the GPU work of an N-rank run -- rendezvous (gloo, CPU), barriers, the max-over-ranks
+    clock, ONE JSON line from rank 0 -- with a sleep where the step would be.  Marked as such; never a measurement."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "rows/sec + achieved HBM GB/s, filter->group-by over 10^9-row Arrow batches", "value": None, "unit": "rows/s",
+                          "n_gpus": world, "rccl_ranks": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t.item()) / max(args.steps, 1) * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64/int64", "data": "none",
+                          "dry_run": True, "config": {"workload": f"DRY RUN of the {world}-rank launch path ({args.workload}): no GPU work"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def gen_data(torch, n, groups, seed, device):
@@ -560,6 +618,10 @@ def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream,
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)          # (does not return)
+    if os.environ.get("VNM_BENCH_DRY_RUN") == "1":
+        return dry_run(args)
     # RCCL / HIP runtime banners are written to fd 1 by native code: keep the real stdout for the ONE JSON line
     real_stdout = os.dup(1)
     os.dup2(2, 1)
@@ -570,7 +632,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # VNM_BENCH_FORCE_EXCHANGE=1 runs the RCCL exchange + merge step with a single rank too (self-test of the
@@ -592,10 +654,19 @@ def main():
     n = int(args.rows)
     groups = int(args.groups)
     x_thr = threshold_for(args.selectivity)
+    B = 1 << 24
+    if args.workload == "stream":      # configs[3]: this rank's share of the stream, 2^24-row record batches resident in HBM
+        nb = args.batches if args.batches > 0 else min(60, max(1, n // B))
+        n = nb * B
     k, v = gen_data(torch, n, groups, seed=1 + rank, device=device)
     kcol = DeviceColumn.from_torch(k)
     vcol = DeviceColumn.from_torch(v)
     stream = torch.cuda.current_stream().cuda_stream
+
+    def batches_of(kt, vt):
+        return [(DeviceColumn.from_torch(kt[i * B:(i + 1) * B]), DeviceColumn.from_torch(vt[i * B:(i + 1) * B])) for i in range(kt.numel() // B)]
+    # what step() runs: the headline case first, the `also` cases of a multi-rank run afterwards
+    cur = {"kind": args.workload, "kcol": kcol, "vcol": vcol, "parts": batches_of(k, v) if args.workload == "stream" else None, "hint": groups}
     out_buf = None
     if args.workload == "filter":
         out_buf = torch.empty(n, dtype=torch.float64, device=device)
@@ -633,6 +704,32 @@ def main():
                                              cols, length=n, stream=stream)
             state["out_rows"] = n
             return
+        if cur["kind"] == "stream":
+            # BaseAggregate::Next per record batch (base_aggregate.cpp:23-45) into ONE operator; stream_mode: next() records the
+            # batch, the waiting batches go to the device as the segments of one launch (vnm_agg_set_async)
+            dist_mode = world > 1 or force_exchange
+            agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
+                                      expected_groups=cur["hint"] if args.hint else 0, rank_aligned=dist_mode, stream_mode=True)
+            agg.set_predicate(">", x_thr)
+            parts = cur["parts"]
+            if dist_mode:
+                from vinum_amd import distributed as D
+                if not args.hint:
+                    D.agree_on_group_count(agg, parts[0][0], B, device, stream=stream)
+                if os.environ.get("VNM_BENCH_EXCHANGE", "dense") == "dense":
+                    D.agree_on_dense_range(agg, parts[0][0], B, device, stream=stream)
+            for kc_, vc_ in parts:
+                agg.next([kc_], [vc_, vc_], pred=vc_, nrows=B, stream=stream)
+            if dist_mode:
+                ng = exchange_and_merge(agg, None)
+            else:
+                state["cols"] = agg.result_device(stream=stream)
+                ng = agg.result_rows
+            state["out_rows"] = ng
+            state.pop("agg", None)
+            state["agg"] = agg
+            return
+        kcol, vcol = cur["kcol"], cur["vcol"]
         if args.shape == "count_star":
             agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.COUNT_STAR, 0, None)],
                                       expected_groups=groups if args.hint else 0)
@@ -646,7 +743,7 @@ def main():
         else:
             agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
                                       [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
-                                      expected_groups=groups if args.hint else 0, rank_aligned=(world > 1 or force_exchange))
+                                      expected_groups=cur["hint"] if args.hint else 0, rank_aligned=(world > 1 or force_exchange))
             agg.set_predicate(">", x_thr)
             if (world > 1 or force_exchange) and not args.hint:
                 # hint-less on several ranks: agree on ONE group-count estimate, or ranks may cut their results into
@@ -751,23 +848,28 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    state.pop("phases", None)
-    lib.vnm_set_profiling(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(steps, warmup):
+        """`warmup` untimed steps, then exactly `steps` steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+        for _ in range(warmup):
+            step()
+        sync_all()
+        state.pop("phases", None)
+        lib.vnm_set_profiling(1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync_all()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    elapsed = timed(args.steps, args.warmup)
 
     check = None
-    if args.check and args.workload == "groupby" and args.shape == "hot":
+    if args.check and args.workload in ("groupby", "stream") and args.shape == "hot":
         check = check_groupby(torch, dist, state, k, v, x_thr, world, rank, device, force_exchange)
     names = {"filter": [b"filter_kernel"], "topk": [b"topk_sample", b"topk_select", b"topk_small_sort", b"sort_encode", b"radix_hist", b"radix_pass",
                                                     b"sort_sample", b"sort_scatter1", b"sort_scatter2", b"sort_local"], "project": [b"project_kernel"]}.get(
@@ -810,7 +912,10 @@ def main():
         elif args.shape == "minmax":
             workload = (f"SELECT k,min(v),max(v) WHERE v>{x_thr} GROUP BY k; N={n:.3g} rows/GPU, G={groups:.3g}, "
                         f"s={args.selectivity}")
-        pass
+        if args.workload == "stream":
+            workload = (f"configs[3]: SELECT k,sum(v),avg(v) WHERE v>{x_thr} GROUP BY k over a stream of {n // B} x 2^24-row record batches per GPU "
+                        f"(HBM-resident, dealt round-robin to {world} rank{'s' if world > 1 else ''}), G={groups:.3g}, s={args.selectivity}; "
+                        + ("partial aggregates exchanged over RCCL inside the step" if world > 1 or force_exchange else "result columns inside the step"))
     if args.workload not in ("filter",):
         dom = " + ".join(spans) + f" (dominant: {dom_name})" if len(spans) > 1 else dom_name
     # per-kernel algorithmic bytes: the scan kernels read key+value once (16 N) and write the groups; a
@@ -844,12 +949,40 @@ def main():
             traffic = ent2["bytes_per_step"]
             traffic_src = ent2.get("source", "profiles/") + " (" + ent.get("how", "") + ")"
             break
+    # ---- a multi-rank run's other configurations (every rank takes part: the exchanges are collectives), a few steps each, same
+    # bracketing: configs[3] at G = 7 (all-gather of a handful of partial groups) and the one-batch G = 1e8 shape of configs[2]
+    # (dense tables over all_to_all)
+    multi_also = None
+    if (world > 1 or force_exchange) and args.workload == "stream" and not args.no_also:
+        multi_also = {}
+        try:
+            def also_entry(tag, what, nrows):
+                exch0 = dict(state.get("phases", {}))
+                el = timed(2, 1)
+                sp = _spans(lib, ctypes, AGG_SPANS, 2)
+                lib.vnm_set_profiling(0)
+                multi_also[tag] = {"workload": what, "rows_per_s": nrows * world * 2 / el, "ms_per_step": el / 2 * 1e3, "result_rows": int(state["out_rows"]),
+                                   "exchange": state.get("exchange_kind"),
+                                   "exchange_ms_per_step": {k2: round(v2 / 2, 3) for k2, v2 in state.get("phases", {}).items()},
+                                   "kernels_ms": {k2: round(v2, 4) for k2, v2 in sp.items()}}
+            cur.update(kind="stream", parts=batches_of(torch.remainder(k, 7), v), hint=7)
+            also_entry("configs[3] stream, G=7", f"the same stream with 7 groups ({n // B} x 2^24-row batches per rank)", n)
+            cur["parts"] = None
+            state.clear()
+            gg8 = torch.Generator(device=device); gg8.manual_seed(101 + rank)
+            k8 = torch.randint(0, 10**8, (n,), device=device, dtype=torch.int64, generator=gg8)
+            cur.update(kind="groupby", kcol=DeviceColumn.from_torch(k8), vcol=vcol, hint=10**8)
+            also_entry("configs[2] shape, G=1e8", f"ONE batch of {n:.3g} rows per rank, 1e8 groups: dense tables exchanged by all_to_all", n)
+            state.clear()
+            del k8
+        except Exception as e:
+            multi_also["error"] = str(e)
     if rank == 0:
         result = {
             "metric": "rows/sec + achieved HBM GB/s, filter->group-by over 10^9-row Arrow batches",
             "value": n * world * args.steps / elapsed,
             "unit": "rows/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": dist.get_world_size() if (world > 1 or force_exchange) else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64/int64", "data": "synthetic",
@@ -870,6 +1003,8 @@ def main():
         }
         if check is not None:
             result["check"] = check
+        if multi_also is not None:
+            result["also"] = multi_also
         if world == 1 and not force_exchange and args.workload == "groupby" and args.shape == "hot" and not args.no_also:
             # the other single-GPU configurations of BASELINE.json on the same resident column, a few steps each
             # (reported beside the headline; not part of `value`)

@@ -179,8 +179,8 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
  * SUM / AVG of one plain float64 column; a plain float64 predicate column or none): no launch, allocation or host read-back per
  * call.  The waiting batches go to the device together, as the segments of ONE logical batch (one launch of the path's kernels
  * over all of them), when vnm_agg_sync / vnm_agg_finish / any result call is made, when 2^30 rows or 256 batches are waiting, or
- * when a batch of another shape arrives (that one is processed as usual, after the waiting ones).  The first batch of an operator
- * is always processed in its own call (it settles estimates and the path; schema errors surface where they do in the reference).
+ * when a batch of another shape arrives (that one is processed as usual, after the waiting ones).  Group-count estimates and the
+ * dense path's code range are sampled from the FIRST waiting batch; errors of a waiting batch surface in the call that processes it.
  * CONTRACT: the buffers of every batch passed while async is on must stay alive and unchanged until the next vnm_agg_sync /
  * vnm_agg_finish / vnm_agg_result_* / vnm_agg_dense_table call on the handle returns.  Results are identical to the synchronous
  * mode (same kernels, same merges).  Default: off. */

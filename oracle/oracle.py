@@ -410,6 +410,15 @@ class OracleSort:
 
     def sorted(self) -> pa.RecordBatch:
         table = pa.Table.from_batches(self.batches).combine_chunks()
+        if not all(_is_numeric_type(f.type) for f in table.schema):
+            # Tables with non-numeric columns (strings, booleans, decimals ...): sort.cpp:22-44 is two calls into a third-party
+            # library absent from /root/reference -- Apache Arrow (3.0.0 pinned, setup.py:33; 25 here): SortIndices over the sort
+            # keys (stable, NULLs last in both directions, NaN after every number) + Take of every column.  Restated with the same
+            # two calls of that library's Python binding; pinned by tests/golden/sortmix_* (outputs of the reference's own Sort).
+            import pyarrow.compute as pc
+            idx = pc.sort_indices(table, sort_keys=[(c, "descending" if o else "ascending") for c, o in zip(self.cols, self.orders)])
+            return table.take(idx).combine_chunks().to_batches()[0] if table.num_rows else table.schema.empty_table().to_batches()[0] \
+                if table.schema.empty_table().to_batches() else pa.RecordBatch.from_pylist([], schema=table.schema)
         idx = self.sort_indices(table)
         arrays = []
         for name in table.schema.names:

@@ -27,7 +27,10 @@ def _bench(extra_env, *args):
     ("dense_tables", {"VNM_BENCH_FORCE_EXCHANGE": "1"}, ["--rows", "3e7", "--groups", "1e7"]),
     ("partition_aligned", {"VNM_BENCH_FORCE_EXCHANGE": "1", "VNM_BENCH_EXCHANGE": "aligned"}, ["--rows", "3e7", "--groups", "1e7"]),
     ("bucketed", {"VNM_BENCH_FORCE_EXCHANGE": "1", "VNM_BENCH_EXCHANGE": "bucketed"}, ["--rows", "3e7", "--groups", "1e7"]),
-    ("allgather_small", {"VNM_BENCH_FORCE_EXCHANGE": "1"}, ["--rows", "3e7", "--groups", "1e5"]),
+    # (G = 1e5 takes the dense tables too since round 4 -- the split final pass writes them; "allgather": skip the table routes)
+    ("allgather_small", {"VNM_BENCH_FORCE_EXCHANGE": "1", "VNM_BENCH_EXCHANGE": "allgather"}, ["--rows", "3e7", "--groups", "1e5"]),
+    ("dense_tables", {"VNM_BENCH_FORCE_EXCHANGE": "1"}, ["--rows", "3e7", "--groups", "1e5"]),
+    ("dense_tables", {"VNM_BENCH_FORCE_EXCHANGE": "1"}, ["--rows", "3e7", "--groups", "3e6"]),
 ])
 def test_bench_check_exchange_routes(route, env, args):
     j = _bench(env, *args)
@@ -40,3 +43,28 @@ def test_bench_check_single_gpu_headline_with_result_columns():
     j = _bench({}, "--rows", "3e7", "--groups", "1e7")
     assert j["check"]["survivors_conserved"] and j["check"]["totals_conserved"]
     assert j["check"].get("result_columns_match") is True
+
+
+@pytest.mark.parametrize("groups,route", [("1e6", "dense_tables"), ("7", "allgather_small")])
+def test_bench_check_stream_workload_with_exchange(groups, route):
+    """configs[3] (the default of a multi-rank run): a stream of 2^24-row batches into one operator in stream mode, partial aggregates
+    exchanged -- here by ONE rank with itself, `also` cases included (they are collectives on every rank)."""
+    env = dict(os.environ)
+    env.update({"VNM_BENCH_FORCE_EXCHANGE": "1", "MASTER_PORT": str(29900 + os.getpid() % 90)})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stream", "--batches", "4", "--groups", groups, "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--check"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    j = json.loads(p.stdout.strip().splitlines()[-1])
+    assert j["check"]["exchange"] == route, j["check"]
+    assert j["check"]["survivors_conserved"] and j["check"]["totals_conserved"]
+    assert j["rccl_ranks"] == 1 and "configs[3]" in j["config"]["workload"]
+    assert "error" not in j["also"], j["also"]
+    assert j["also"]["configs[3] stream, G=7"]["exchange"] == "allgather_small"
+    assert j["also"]["configs[2] shape, G=1e8"]["exchange"] == "dense_tables"
+
+
+def test_bench_check_stream_workload_single_gpu():
+    j = _bench({}, "--workload", "stream", "--batches", "5", "--groups", "1e6")
+    assert j["check"]["survivors_conserved"] and j["check"]["totals_conserved"]
+    assert j["check"].get("result_columns_match") is True
+    assert j["roofline"]["launches_per_step"] <= 1.0     # ONE launch of the scatter pass over the five waiting batches

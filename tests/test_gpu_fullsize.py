@@ -136,6 +136,73 @@ def test_groupby_1e9_rows(groups, hint):
     _free()
 
 
+@pytest.mark.parametrize("groups,mode", [(100_000_000, "one_batch"), (1_000_000, "one_batch"), (7, "one_batch"),
+                                         (1_000_000, "stream"), (7, "stream"), (100_000_000, "stream")],
+                         ids=["G1e8", "G1e6", "G7", "G1e6-stream", "G7-stream", "G1e8-stream"])
+def test_groupby_1e9_rows_result_columns(groups, mode):
+    """The BENCHED path at full size: next() -> result_device() with NO finish() first, i.e. the deferred final pass
+    writing the result columns itself (DF_COLS) -- checked on those columns directly, against plain torch ops: survivors conserved,
+    totals conserved exactly, group count and keys == torch.unique, a 1/64 key-hash subsample bit-equal (sum, and avg = sum / count).
+    mode "stream": the same rows as 59 record batches of 2^24 rows through an operator in stream mode (vnm_agg_set_async: the
+    batches go to the device as the segments of one launch) -- bench.py's configs[3] leg."""
+    torch = _torch()
+    import bench
+    from vinum_amd import _lib as L
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    B = 1 << 24
+    n = N_FULL if mode == "one_batch" else 59 * B
+    k, v = _gen(n, groups)
+    x = bench.threshold_for(0.5)
+    agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64()), (L.COUNT_STAR, None, None)],
+                              stream_mode=(mode == "stream"))
+    agg.set_predicate(">", x)
+    if mode == "one_batch":
+        kc, vc = DeviceColumn.from_torch(k), DeviceColumn.from_torch(v)
+        agg.next([kc], [vc, vc, None], pred=vc, nrows=n)
+    else:
+        for i in range(n // B):
+            kc, vc = DeviceColumn.from_torch(k[i * B:(i + 1) * B]), DeviceColumn.from_torch(v[i * B:(i + 1) * B])
+            agg.next([kc], [vc, vc, None], pred=vc, nrows=B)
+    cols = agg.result_device()           # <- the step of bench.py ends here
+    torch.cuda.synchronize()
+    ng = agg.result_rows
+    assert [c.length for c in cols] == [ng] * 4 and all(c.validity_ptr is None for c in cols)
+    rk = _as_tensor(cols[0].values_ptr, ng)
+    rsum = _as_tensor(cols[1].values_ptr, ng, "<f8")
+    ravg = _as_tensor(cols[2].values_ptr, ng, "<f8")
+    rcnt = _as_tensor(cols[3].values_ptr, ng)
+    keep = v > x
+    assert int(rcnt.sum()) == int(keep.sum()) and int((rcnt <= 0).sum()) == 0                       # 1. survivors
+    scaled = rsum * 128.0
+    assert bool((scaled == scaled.round()).all())
+    assert int(scaled.to(torch.int64).sum()) == int((v * 128.0).to(torch.int64)[keep].sum())        # 2. exact total
+    ks = k[keep]
+    uniq = torch.unique(ks)
+    assert ng == uniq.numel()                                                                        # 3. groups and keys
+    srt, order = torch.sort(rk)
+    assert bool(torch.equal(srt, uniq))
+    del uniq
+
+    def sel(keys):
+        return (((keys * -7046029254386353131) >> 58) & 63) == 0
+    vs = v[keep]
+    m = sel(ks)
+    sub_k, sub_v = ks[m], vs[m]
+    del ks, vs, m, keep
+    uk, inv = torch.unique(sub_k, return_inverse=True)
+    ref_sum = torch.zeros(uk.numel(), dtype=torch.float64, device=k.device).index_add_(0, inv, sub_v)
+    ref_cnt = torch.bincount(inv, minlength=uk.numel())
+    ms = sel(srt)
+    assert bool(torch.equal(srt[ms], uk))                                                           # 4. subsample, bit-exact
+    assert bool(torch.equal(rsum[order][ms].view(torch.int64), ref_sum.view(torch.int64)))
+    assert bool(torch.equal(rcnt[order][ms], ref_cnt))
+    assert bool(torch.equal(ravg.view(torch.int64), (rsum / rcnt.to(torch.float64)).view(torch.int64)))   # 5. avg = sum / count, every group
+    agg.close()
+    del k, v
+    _free()
+
+
 @pytest.mark.parametrize("groups", [1_000, 100_000, 100_000_000], ids=["G1e3", "G1e5", "G1e8"])
 def test_generic_programs_1e9_rows(groups):
     """The generic dense paths at full size (whole-table LDS scan, split final pass, two scatter levels):

@@ -50,6 +50,20 @@ def test_oracle_aggregate_matches_reference_golden(case):
     util.assert_batches_equal(agg.result(), expected, key_names=case["agg_cols"], what=case["name"])
 
 
+@pytest.mark.parametrize("case", MAN["sort_mixed"], ids=lambda c: c["name"])
+def test_oracle_sort_with_non_numeric_columns_matches_reference_golden(case):
+    """Sort over tables with string / binary / boolean / decimal columns, as keys and as payload (the reference's orderby_queries
+    shapes, test_query_results.py:627-745, 1252-1266): the oracle against outputs of the reference's own Sort."""
+    table = util.read_ipc(case["input"])
+    expected = util.read_ipc(case["expected"])
+    s = O.OracleSort(case["cols"], case["orders"])
+    for b in util.sliced_batches(table, case["chunk"]):
+        s.next(b)
+    got = s.sorted()
+    assert got.schema.equals(expected.schema), (got.schema, expected.schema)
+    util.assert_batches_equal(got, expected, what=case["name"])   # every column, order-sensitive, bit-exact
+
+
 @pytest.mark.parametrize("case", MAN["sort"], ids=lambda c: c["name"])
 def test_oracle_sort_matches_reference_golden(case):
     table = util.read_ipc(case["input"])

@@ -111,6 +111,25 @@ struct VSeg {
     int64_t first_tile;
 };
 
+// The segment table is read through the CONSTANT address space (nobody writes it while the kernel runs): uniform loads from it are
+// scalar loads (s_load: the scalar cache, results in scalar registers, no wait on the wave's outstanding vector loads).  Through a
+// plain global pointer the same reads are vector loads -- the compiler cannot scalarise loads from memory the kernel also stores
+// to -- whose latency, behind a saturated memory system, sat on every tile's critical path and whose results occupied vector
+// registers (58 segments, G = 7: 4.1 ms against 2.7 for the same rows as one batch).
+typedef const VSeg __attribute__((address_space(4)))* VSegConst;
+__device__ __forceinline__ VSegConst seg_table(const VSeg* p) { return (VSegConst)(uintptr_t)p; }
+// A value every lane of the wave holds alike, moved into scalar registers.  Loads through a.segs are uniform, but the compiler
+// cannot scalarise loads from memory the kernel also stores to: the segment pointers then sit in vector registers -- two sets of
+// them, this tile's and the next one's -- and the scan kernel spilled 46-116 VGPRs (58 segments, G = 7: 4.1 ms against 2.7 for
+// the same rows as one batch).
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+template <typename T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) { return (const T*)uniform_u64((uint64_t)p); }
+
 struct AggArgs {
     AggPlan plan;
     const VSeg* segs;  // agg_hot_kernel, nseg > 0: the rows are these segments (keys[0] / cols[0] / pred describe the first one)
@@ -746,26 +765,172 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_kernel(AggArgs a) {
 
     const unsigned flush_at = (unsigned)(S * 6 / 10);
     const uint32_t smask = (uint32_t)S - 1;
+    const uint64_t* kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
+    const uint64_t* vp = HAS_VAL ? (const uint64_t*)a.cols[0].values + a.cols[0].offset : kp;
+    const uint64_t* vp2 = TWO ? (const uint64_t*)a.cols[1].values + a.cols[1].offset : kp;
+    const double* pp = (const double*)a.pred.values + a.pred.offset;
+    const int op = a.p.op;
+    const double thr = a.p.dval;
+
+    ulonglong2 kk[HOT_UNROLL], vv[HOT_UNROLL], vw[HOT_UNROLL];  // this block's current (then next) tile, see below
+    uint32_t vm[HOT_UNROLL];  // VNULL: validity bits of the pair (bit 0 / 1)
+    const uint8_t* vbm = VNULL ? a.cols[0].validity : nullptr;
+    const int64_t voff = VNULL ? a.cols[0].offset : 0;
+    double2 pv[HOT_UNROLL];
+    bool have = false;
+    uint32_t spread = 0;
+    // (no copies for short batches either: eight copies of every key are eight times the flush's atomics on the same few HBM
+    // addresses -- ~30 us per kernel with 7 groups and 256 workgroups, a third of a 2^24-row batch's 90 us; they pay from ~64
+    // tiles per workgroup on: 59 x 2^24-row batches, G = 7: 7.6 -> 5.8 ms)
+    int spread_state = ((a.debug & 4) || a.ntiles < 64 * (int64_t)gridDim.x) ? 2 : 0;  // VNM_AGG_DEBUG & 4: no key copies (measurement)
+    bool need_check = true;
+    unsigned it = a.progress[blockIdx.x];
+    for (;; it++) {
+        const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
+        if (tile >= a.ntiles) break;
+        if (need_check) {  // see agg_lds_kernel
+            if (tid == 0) s_go = table_has_room(a, &s_new) ? 1 : 0;
+            __syncthreads();
+            if (!s_go) break;
+        }
+        const int64_t base = tile * HOT_TILE + 2 * tid;
+        uint32_t sat0 = 0, sat1 = 0;  // rows (even / odd element of chunk u) whose key the LDS table could not take
+        if (base + (int64_t)(HOT_UNROLL - 1) * 2 * AGG_BLOCK + 1 < a.nrows) {
+            // Register rotation: as soon as chunk u of this tile has been copied out, chunk u of the block's NEXT
+            // tile is requested into the same registers, so HBM loads are in flight while the LDS work of this tile
+            // runs (one 1024-thread block per CU: without this the block alternates between a load phase and an
+            // LDS phase -- G=1000 ran at 4.2 ms against 3.1 ms for G=7).
+#define VNM_HOT_LOAD(u, b)                                                                                      \
+    do {                                                                                                       \
+        const int64_t r_ = (b) + (int64_t)(u) * 2 * AGG_BLOCK;                                                 \
+        if (FROM_ENT) {                                                                                        \
+            const ulonglong2 e0 = a.ent[r_], e1 = a.ent[r_ + 1];                                               \
+            kk[u].x = e0.x; kk[u].y = e1.x;                                                                    \
+            vv[u].x = e0.y; vv[u].y = e1.y;                                                                    \
+        } else {                                                                                               \
+            kk[u] = *(const ulonglong2*)(kp + r_);                                                             \
+            if (HAS_VAL) {                                                                                     \
+                if (a.has_expr) { const double2 ev_ = expr_eval2(a.expr, r_); vv[u].x = (unsigned long long)__double_as_longlong(ev_.x); vv[u].y = (unsigned long long)__double_as_longlong(ev_.y); } \
+                else vv[u] = *(const ulonglong2*)(vp + r_);                                                    \
+            }                                                                                                  \
+            if (VNULL) vm[u] = (uint32_t)vbm[(voff + r_) >> 3] >> ((voff + r_) & 7);                           \
+            if (TWO) vw[u] = *(const ulonglong2*)(vp2 + r_);                                                   \
+            if (HAS_PRED && !PRED_IS_V) pv[u] = *(const double2*)(pp + r_);                                    \
+        }                                                                                                      \
+    } while (0)
+            if (!have) {
+#pragma unroll
+                for (int u = 0; u < HOT_UNROLL; u++) VNM_HOT_LOAD(u, base);
+            }
+            const int64_t nbase = base + (int64_t)gridDim.x * HOT_TILE;
+            const bool nfull = tile + gridDim.x < a.ntiles && nbase + (int64_t)(HOT_UNROLL - 1) * 2 * AGG_BLOCK + 1 < a.nrows;
+#pragma unroll
+            for (int u = 0; u < HOT_UNROLL; u++) {
+                const ulonglong2 k = kk[u];
+                const uint64_t v0 = HAS_VAL ? vv[u].x : 0, v1 = HAS_VAL ? vv[u].y : 0;
+                const uint64_t w0 = TWO ? vw[u].x : 0, w1 = TWO ? vw[u].y : 0;
+                const bool ok0 = !VNULL || (vm[u] & 1u), ok1 = !VNULL || (vm[u] & 2u);
+                // a NULL predicate value compares like NaN (pred_eval: the reference sees NumPy NaNs there)
+                const double p0 = PRED_IS_V ? (ok0 ? __longlong_as_double((long long)v0) : __builtin_nan("")) : pv[u].x;
+                const double p1 = PRED_IS_V ? (ok1 ? __longlong_as_double((long long)v1) : __builtin_nan("")) : pv[u].y;
+                if (nfull) VNM_HOT_LOAD(u, nbase);
+                if (!HAS_PRED || cmp_apply<double>(op, p0, thr)) {
+                    int slot = hot_slot(lkey, S, smask, &s_fill, k.x, spread);
+                    if (slot >= 0) {
+                        hot_accumulate<SIMPLE>(a, lacc, stride, slot, v0, ok0);
+                        if (TWO) pa_accumulate_col(a.hot_wpack2, a.hot_vtype2, lacc, stride, slot, w0, a.hot_comp);
+                    } else if (FROM_ENT) hot_entry_to_table(a, k.x, v0, &s_new);  // no columns to re-read: merge right here
+                    else sat0 |= 1u << u;
+                }
+                if (!HAS_PRED || cmp_apply<double>(op, p1, thr)) {
+                    int slot = hot_slot(lkey, S, smask, &s_fill, k.y, spread);
+                    if (slot >= 0) {
+                        hot_accumulate<SIMPLE>(a, lacc, stride, slot, v1, ok1);
+                        if (TWO) pa_accumulate_col(a.hot_wpack2, a.hot_vtype2, lacc, stride, slot, w1, a.hot_comp);
+                    } else if (FROM_ENT) hot_entry_to_table(a, k.y, v1, &s_new);
+                    else sat1 |= 1u << u;
+                }
+            }
+            have = nfull;
+#undef VNM_HOT_LOAD
+        } else {
+            have = false;
+            for (int u = 0; u < HOT_UNROLL; u++)
+                for (int e = 0; e < 2; e++) {
+                    int64_t r = base + (int64_t)u * 2 * AGG_BLOCK + e;
+                    if (r >= a.nrows) continue;
+                    const uint64_t vb = FROM_ENT ? a.ent[r].y : (HAS_VAL ? (a.has_expr ? (uint64_t)__double_as_longlong(expr_eval1(a.expr, r)) : vp[r]) : 0);
+                    const uint64_t kb = FROM_ENT ? a.ent[r].x : kp[r];
+                    const bool ok = !VNULL || ((vbm[(voff + r) >> 3] >> ((voff + r) & 7)) & 1);
+                    const double p = PRED_IS_V ? (ok ? __longlong_as_double((long long)vb) : __builtin_nan("")) : (HAS_PRED ? pp[r] : 0.0);
+                    if (HAS_PRED && !cmp_apply<double>(op, p, thr)) continue;
+                    int slot = hot_slot(lkey, S, smask, &s_fill, kb, spread);
+                    if (slot >= 0) {
+                        hot_accumulate<SIMPLE>(a, lacc, stride, slot, vb, ok);
+                        if (TWO) pa_accumulate_col(a.hot_wpack2, a.hot_vtype2, lacc, stride, slot, vp2[r], a.hot_comp);
+                    }
+                    else if (FROM_ENT) hot_entry_to_table(a, kb, vb, &s_new);
+                    else if (e == 0) sat0 |= 1u << u;
+                    else sat1 |= 1u << u;
+                }
+        }
+        // saturated keys: straight to the HBM table, out of line (rows base + e + u * 2 * AGG_BLOCK)
+        if (!FROM_ENT && sat0) agg_rows_to_table(a, base, 2 * AGG_BLOCK, sat0, &s_new);
+        if (!FROM_ENT && sat1) agg_rows_to_table(a, base + 1, 2 * AGG_BLOCK, sat1, &s_new);
+        __syncthreads();
+        const unsigned fill_now = s_fill;
+        need_check = fill_now > (unsigned)S / 2;
+        // key copies (see hot_slot): on after the first tile when it found a handful of groups, off for good once the
+        // table holds more than that would explain
+        if (spread_state == 0) { spread_state = fill_now <= (unsigned)S / 128 ? 1 : 2; if (spread_state == 1) spread = tid & 7u; }
+        else if (spread_state == 1 && fill_now > (unsigned)S / 8) { spread_state = 2; spread = 0; }
+        if (fill_now > flush_at) {
+            lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK, &s_new);
+            __syncthreads();
+            if (tid == 0) s_fill = 0;
+        }
+    }
+    lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK, &s_new);
+    __syncthreads();
+    if (tid == 0) { fold_new(a.g, &s_new); a.progress[blockIdx.x] = it; }
+}
+
+// The same scan over the waiting batches of a STREAM (a.segs, see VSeg) -- the north-star shape only (SIMPLE: COUNT(*), COUNT, SUM of
+// one plain float64 column).  A kernel of its own: the tile -> (segment, local tile) state costs the one-batch kernel above
+// 12-36 VGPRs and, in its widest variants, spills.
+template <bool HAS_PRED, bool PRED_IS_V>
+__global__ __launch_bounds__(AGG_BLOCK) void agg_hot_seg_kernel(AggArgs a) {
+    constexpr bool HAS_VAL = true, SIMPLE = true, FROM_ENT = false, TWO = false, VNULL = false;
+    extern __shared__ uint64_t lds[];
+    __shared__ unsigned s_fill, s_new;
+    __shared__ int s_go;
+    const int S = a.lds_slots;
+    const int stride = S + 2;
+    const int W = a.plan.n_words;
+    uint64_t* lkey = lds;
+    uint64_t* lacc = lds + stride;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < stride; i += AGG_BLOCK) lkey[i] = EMPTY;
+    for (int w = 0; w < W; w++) {
+        uint64_t init = merge_init(a.plan.merge[w]);
+        for (int i = tid; i < stride; i += AGG_BLOCK) lacc[w * stride + i] = init;
+    }
+    if (tid == 0) { s_fill = 0; s_new = 0; }
+    __syncthreads();
+
+    const unsigned flush_at = (unsigned)(S * 6 / 10);
+    const uint32_t smask = (uint32_t)S - 1;
     // The rows of a tile: (segment, local tile) -- the record batches of a stream as one logical batch (VSeg; nseg = 0: the one batch
     // of a.keys / a.cols / a.pred).  Uniform over the workgroup; the segment cursor only moves forward.
     struct Cur { const uint64_t* kp; const uint64_t* vp; const uint64_t* vp2; const double* pp; const uint8_t* vbm; int64_t voff; int64_t nrows; int64_t lt; };
-    const int nseg = FROM_ENT ? 0 : a.nseg;
+    const int nseg = a.nseg;
+    const VSegConst segs = seg_table(a.segs);
     int sg = 0;
     auto locate = [&](int64_t tile, Cur& c) {
-        if (nseg == 0) {
-            c.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
-            c.vp = HAS_VAL ? (const uint64_t*)a.cols[0].values + a.cols[0].offset : c.kp;
-            c.vp2 = TWO ? (const uint64_t*)a.cols[1].values + a.cols[1].offset : c.kp;
-            c.pp = (const double*)a.pred.values + a.pred.offset;
-            c.vbm = VNULL ? a.cols[0].validity : nullptr;
-            c.voff = VNULL ? a.cols[0].offset : 0;
-            c.nrows = a.nrows; c.lt = tile;
-            return;
-        }
-        while (sg + 1 < nseg && tile >= a.segs[sg + 1].first_tile) sg++;
-        const VSeg& sgm = a.segs[sg];
-        c.kp = sgm.kp; c.vp = HAS_VAL ? sgm.vp : sgm.kp; c.vp2 = sgm.kp; c.pp = sgm.pp; c.vbm = sgm.vvalid; c.voff = sgm.voff;
-        c.nrows = sgm.nrows; c.lt = tile - sgm.first_tile;
+        while (sg + 1 < nseg && tile >= segs[sg + 1].first_tile) sg++;
+        c.kp = segs[sg].kp; c.vp = segs[sg].vp; c.vp2 = c.kp; c.pp = segs[sg].pp; c.vbm = nullptr; c.voff = 0;
+        c.nrows = segs[sg].nrows; c.lt = tile - segs[sg].first_tile;
     };
     const int op = a.p.op;
     const double thr = a.p.dval;
@@ -4014,7 +4179,6 @@ int complete_pending(vnm_agg* h, hipStream_t s, int out = DF_RUN, const DFinalAr
         df.n_out = cols->n_out;
         for (int c = 0; c < cols->n_out; c++) { df.out_kind[c] = cols->out_kind[c]; df.out_ptr[c] = cols->out_ptr[c]; }
     } else {
-        if (pd->tb > 12) return 2;   // (the exchange of 2^13-slot tables is not wired up: the caller takes another route)
         if (!pd->table) pd->table = (DTabSlot*)pool_alloc(sizeof(DTabSlot) << df.map.bits);
         if (!pd->table) return 1;
         df.table = pd->table;
@@ -4028,7 +4192,6 @@ int complete_pending(vnm_agg* h, hipStream_t s, int out = DF_RUN, const DFinalAr
     unsigned long long fl[3] = {0, 0, 0};
     uint64_t* psum = nullptr; float* plo = nullptr; uint32_t* pcnt = nullptr;
     if (pd->fsplits > 1) {   // few final partitions: each is shared by `fsplits` workgroups (partial tables + dpart_merge_kernel)
-        if (out == DF_TABLE) return 2;
         const size_t cells = (size_t)pd->nfinal * pd->fsplits << pd->tb;
         psum = (uint64_t*)pool.take(cells * 8); plo = (float*)pool.take(cells * 4); pcnt = (uint32_t*)pool.take(cells * 4);
         if (!psum || !plo || !pcnt) return 1;
@@ -4185,13 +4348,23 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
 #define VNM_DRING_B(FR_, CT_, HV_, BLK_, PR_, PV_, VN_, GRID_, ARGS_, CAP_)                                              \
     do {                                                                                                                \
         const size_t lds_ = (((size_t)(ARGS_).nparts * (CAP_) * ((HV_ ? 8 : 0) + sizeof(CT_))) + 15) & ~(size_t)15;       \
-        /* the waiting batches of a stream: one segment each, sub-tiles of 2 * PR_ * BLK_ rows */                       \
-        if (FR_ && h->segs_active && upload_segs(h, (int64_t)2 * PR_ * BLK_, &(ARGS_).segs, &(ARGS_).nseg, &(ARGS_).nsub, seg_pool, s)) { release(); pool_free(spill); return 1; } \
+        /* the waiting batches of a stream: one segment each, sub-tiles of 2 * PR_ * BLK_ rows (the SEG instantiations) */ \
+        constexpr bool SG_ = FR_ && HV_ && !VN_;                                                                        \
+        const bool seg_ = SG_ && h->segs_active != nullptr;                                                             \
+        if (seg_ && upload_segs(h, (int64_t)2 * PR_ * BLK_, &(ARGS_).segs, &(ARGS_).nseg, &(ARGS_).nsub, seg_pool, s)) { release(); pool_free(spill); return 1; } \
         /* round limit (skew): two insert / flush rounds per sub-tile, where an even spread of a sub-tile's entries (every */ \
         /* row surviving) fits ONE */                                                                                   \
         if (2 * PR_ * BLK_ <= (ARGS_).nparts * ((CAP_) - DR_FB) && ring_limit) {                                        \
-            VNM_HIP(hipFuncSetAttribute((const void*)dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
-            dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 2><<<GRID_, BLK_, lds_, s>>>(ARGS_, CAP_);          \
+            if (seg_) {                                                                                                 \
+                VNM_HIP(hipFuncSetAttribute((const void*)dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 2, SG_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+                dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 2, SG_><<<GRID_, BLK_, lds_, s>>>(ARGS_, CAP_); \
+            } else {                                                                                                    \
+                VNM_HIP(hipFuncSetAttribute((const void*)dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+                dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 2><<<GRID_, BLK_, lds_, s>>>(ARGS_, CAP_);      \
+            }                                                                                                           \
+        } else if (seg_) {                                                                                              \
+            VNM_HIP(hipFuncSetAttribute((const void*)dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 0, SG_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+            dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 0, SG_><<<GRID_, BLK_, lds_, s>>>(ARGS_, CAP_);     \
         } else {                                                                                                        \
             VNM_HIP(hipFuncSetAttribute((const void*)dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
             dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 0><<<GRID_, BLK_, lds_, s>>>(ARGS_, CAP_);          \
@@ -5563,6 +5736,16 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                     VNM_HIP(hipFuncSetAttribute((const void*)agg_hot_kernel<false, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                     agg_hot_kernel<false, false, true, false, true><<<grid, AGG_BLOCK, lds_bytes, s>>>(a);
                 }
+            } else if (hot && a.nseg > 0) {  // ... over the waiting batches of a stream
+#define VNM_HOTS(P, V)                                                                                          \
+    do {                                                                                                       \
+        VNM_HIP(hipFuncSetAttribute((const void*)agg_hot_seg_kernel<P, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        agg_hot_seg_kernel<P, V><<<grid, AGG_BLOCK, lds_bytes, s>>>(a);                                         \
+    } while (0)
+                if (!h->pred_set) VNM_HOTS(false, false);
+                else if (a.hot_pred_is_v) VNM_HOTS(true, true);
+                else VNM_HOTS(true, false);
+#undef VNM_HOTS
             } else if (hot) {  // the north-star shape
                 if (!h->pred_set) VNM_HOT(false, false, true, true);
                 else if (a.hot_pred_is_v) VNM_HOT(true, true, true, true);
@@ -5673,19 +5856,17 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     if (h->async && keys && inputs) {
         bool piv = false;
         if (queueable(h, nrows, keys, inputs, pred, &piv) && (h->q.empty() || piv == h->q_pred_is_v)) {
-            // the first batch of an operator goes through on its own: it settles the path (estimates, code range), and its errors
-            // are raised where the caller expects them
-            if (h->rows_seen > 0) {
-                if (h->q_rows + nrows > (1LL << 30) || h->q.size() >= 256) VNM_TRY(flush_queue(h, stream));
-                vnm_agg::QBatch b{};
-                b.nrows = nrows; b.key = keys[0]; b.col = inputs[h->col_first_func[0]];
-                if (h->pred_set) b.pred = *pred;
-                h->q.push_back(b);
-                h->q_rows += nrows;
-                h->q_pred_is_v = piv;
-                invalidate_result(h);
-                return 0;
-            }
+            // (the first batch waits like any other: the estimates and the code range of the path are taken from the first SEGMENT
+            // when the waiting batches are processed)
+            if (h->q_rows + nrows > (1LL << 30) || h->q.size() >= 256) VNM_TRY(flush_queue(h, stream));
+            vnm_agg::QBatch b{};
+            b.nrows = nrows; b.key = keys[0]; b.col = inputs[h->col_first_func[0]];
+            if (h->pred_set) b.pred = *pred;
+            h->q.push_back(b);
+            h->q_rows += nrows;
+            h->q_pred_is_v = piv;
+            invalidate_result(h);
+            return 0;
         }
     }
     VNM_TRY(flush_queue(h, stream));

