@@ -4126,10 +4126,12 @@ int launch_dense_final(const DFinalArgs& df, int tb, int out, bool lo64, hipStre
         else VNM_DFIN(TB_, DF_RUN, float);                                                                            \
     } while (0)
     if (lo64) {   // compensation terms beyond the float range (|sum| > ~1e54): 64-bit terms, tables of at most 2^12 slots
-        if (tb == 11) { if (out == DF_COLS) VNM_DFIN(11, DF_COLS, double); else VNM_DFIN(11, DF_RUN, double); }
+        if (tb == 9) { if (out == DF_COLS) VNM_DFIN(9, DF_COLS, double); else VNM_DFIN(9, DF_RUN, double); }
+        else if (tb == 10) { if (out == DF_COLS) VNM_DFIN(10, DF_COLS, double); else VNM_DFIN(10, DF_RUN, double); }
+        else if (tb == 11) { if (out == DF_COLS) VNM_DFIN(11, DF_COLS, double); else VNM_DFIN(11, DF_RUN, double); }
         else if (tb == 12) { if (out == DF_COLS) VNM_DFIN(12, DF_COLS, double); else VNM_DFIN(12, DF_RUN, double); }
         else return set_error("aggregate: no 64-bit compensation variant for this table size (internal error)");
-    } else if (tb == 11) VNM_DFIN_O(11); else if (tb == 12) VNM_DFIN_O(12); else VNM_DFIN_O(13);
+    } else if (tb == 9) VNM_DFIN_O(9); else if (tb == 10) VNM_DFIN_O(10); else if (tb == 11) VNM_DFIN_O(11); else if (tb == 12) VNM_DFIN_O(12); else VNM_DFIN_O(13);
 #undef VNM_DFIN_O
 #undef VNM_DFIN
     VNM_HIP(hipGetLastError());
@@ -4204,7 +4206,9 @@ int complete_pending(vnm_agg* h, hipStream_t s, int out = DF_RUN, const DFinalAr
             const int cus = device_info().num_cus;
             KernelTimer timer("agg_part_final", s);
             const int g3 = (int)std::min<int64_t>(pd->nfinal * pd->fsplits, (int64_t)cus * 8);
-            if (pd->tb == 11) dpart_final_kernel<uint16_t, 11, true><<<g3, 512, 0, s>>>(ds);
+            if (pd->tb == 9) dpart_final_kernel<uint16_t, 9, true><<<g3, 512, 0, s>>>(ds);
+            else if (pd->tb == 10) dpart_final_kernel<uint16_t, 10, true><<<g3, 512, 0, s>>>(ds);
+            else if (pd->tb == 11) dpart_final_kernel<uint16_t, 11, true><<<g3, 512, 0, s>>>(ds);
             else if (pd->tb == 12) dpart_final_kernel<uint16_t, 12, true><<<g3, 512, 0, s>>>(ds);
             else dpart_final_kernel<uint16_t, 13, true><<<g3, 1024, 0, s>>>(ds);
             if (out != DF_COLS) ds.n_out = 0;
@@ -4260,6 +4264,10 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     // ranges of up to 2^22 codes: ONE scatter level (at most 512 partitions) with the largest table that allows it
     if (mp.bits <= DP_TBITS_MAX + 9 && env_i64("VNM_DENSE_ONE_LEVEL", 1)) tb = std::max(DP_TBITS_MIN, std::min(DP_TBITS_MAX, mp.bits - (int)env_i64("VNM_DENSE_ONE_P", 8)));
     if (mp.bits < 20) tb = (int)env_i64("VNM_DENSE_SMALL_TBITS", 11);   // split final pass: few partitions, long write runs in pass 1 (r03: 2^11-slot tables, G = 2e4 / 5e4 / 1e5 / 3e5: 7.4 / 6.5 / 6.3 / 6.1 -> 5.8 / 5.6 / 5.5 / 5.8 ms with the ring scatter; 2^12 was the r02 optimum)
+    // ranges of 2^14 / 2^15 codes (G ~ 1e4 .. 3e4): 32 partitions of 2^9 / 2^10 slots, so that the ring scatter applies (round 4; before:
+    // 8 / 16 partitions through the tile-sorting scatter, pass 1 at 5.7 ms -- the G = 1e4 cliff of the sweep, 7.0 ms between 2.9 at
+    // G = 1e3 and 5.2 at G = 1e5)
+    if (mp.bits - tb < 5 && env_i64("VNM_DENSE_MIN_PARTS32", 1)) tb = std::max(9, mp.bits - 5);
     if (generic) {   // the table must fit 64 KB of LDS (80 KB at most: one workgroup per CU less)
         int tmax = DP_TBITS_MAX;
         while (tmax > 9 && ((size_t)dgen_slot_bytes(g) << tmax) > 64 * 1024) tmax--;   // (the generic kernels take the table size at run time)
@@ -4337,7 +4345,9 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     const int ring_blk = 1024;
     auto ring_cap_for = [&](int np, size_t esize) -> int {
         int cap = (int)((size_t)(env_i64("VNM_DENSE_RING_LDS", ring_blk >= 1024 ? 128 : (ring_blk >= 512 ? 72 : 48)) * 1024) / ((size_t)np * esize) / DR_FB) * DR_FB;
-        cap = std::min(cap, (int)env_i64("VNM_DENSE_RING_CAP", 80));
+        // at most 80 entries per ring -- more where few partitions share the LDS, so that an even spread of a four-pair sub-tile
+        // (8192 entries) still fits one round: 32 partitions 272, 64 partitions 144
+        cap = std::min(cap, (int)env_i64("VNM_DENSE_RING_CAP", std::max(80, ((8192 / np + DR_FB + DR_FB - 1) / DR_FB) * DR_FB)));
         // few partitions: long runs anyway (and 8192 entries per sub-tile on a handful of ring cursors: G = 1e4, four partitions,
         // pass 1 8.6 ms against 5.0 with the tile-sorting kernel)
         if (np < env_i64("VNM_DENSE_RING_MIN_NP", 32)) return 0;
@@ -4515,7 +4525,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         const int g3 = (int)std::min<int64_t>(nfinal * fsplits, (int64_t)cus * std::min(occ, 8));                     \
         dpart_final_kernel<uint16_t, TB_, true><<<g3, blk, 0, s>>>(df);                                               \
     } while (0)
-        if (tb == 11) VNM_DFINS(11); else if (tb == 12) VNM_DFINS(12); else VNM_DFINS(13);
+        if (tb == 9) VNM_DFINS(9); else if (tb == 10) VNM_DFINS(10); else if (tb == 11) VNM_DFINS(11); else if (tb == 12) VNM_DFINS(12); else VNM_DFINS(13);
 #undef VNM_DFINS
         dpart_merge_kernel<<<(int)(nfinal << (tb - 9)), 512, 0, s>>>(df, tb);
     } else if (env_i64("VNM_DENSE_DEFER", 1)) {
