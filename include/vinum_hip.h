@@ -426,6 +426,13 @@ int vnm_free(void* p);
 /* hand every block the caching allocator holds but nobody uses back to the device (hipFree); returns the
  * bytes released.  For long-lived hosts that want the HBM back between queries; live blocks are untouched. */
 int64_t vnm_pool_trim(void);
+/* The cache also gives itself back: once no allocation or release has gone through the allocator for `idle_ms` (default 2000;
+ * VNM_POOL_IDLE_MS) a background thread releases the cached blocks beyond `keep_bytes` (default 256 MiB; VNM_POOL_KEEP_BYTES),
+ * so a host that embeds the library (an unmodified Vinum process) does not sit on tens of GB of HBM after a large query, while a
+ * query in flight is never trimmed under its feet.  idle_ms < 0: never; keep_bytes < 0: leave it unchanged.
+ * vnm_pool_cached_bytes: what the cache holds right now. */
+int vnm_pool_set_idle_trim(int64_t idle_ms, int64_t keep_bytes);
+int64_t vnm_pool_cached_bytes(void);
 int vnm_memcpy_h2d(void* dst, const void* src, int64_t bytes);
 int vnm_memcpy_d2h(void* dst, const void* src, int64_t bytes);
 int vnm_memset(void* dst, int value, int64_t bytes);

@@ -149,3 +149,31 @@ def test_pool_trim_releases_cached_blocks_only():
     assert pool_trim() == 0                  # nothing cached any more
     np.testing.assert_array_equal(live.to_host(np.int64, 1 << 16), np.arange(1 << 16, dtype=np.int64))
     live.free()
+
+
+def test_pool_gives_idle_cache_back_by_itself():
+    """a host that never calls vnm_pool_trim must not sit on the cache -- the reaper thread releases cached
+    blocks beyond keep_bytes once the allocator has been idle for idle_ms; an active allocator is left alone."""
+    import time
+    from vinum_amd import _lib as L
+    from vinum_amd.device import DeviceBuffer, pool_trim
+    lib = L.lib()
+    pool_trim()
+    try:
+        lib.vnm_pool_set_idle_trim(400, 8 << 20)
+        live = DeviceBuffer.from_host(np.arange(1 << 16, dtype=np.int64))
+        for _ in range(3):
+            DeviceBuffer(96 << 20).free()
+            DeviceBuffer(40 << 20).free()
+        assert lib.vnm_pool_cached_bytes() >= 136 << 20          # cached, the allocator is busy
+        t0 = time.time()
+        while time.time() - t0 < 0.3:                             # ... and stays so while it is being used
+            DeviceBuffer(4096).free()
+            time.sleep(0.01)
+        assert lib.vnm_pool_cached_bytes() >= 136 << 20
+        time.sleep(1.5)                                           # idle: the reaper trims down to keep_bytes
+        assert lib.vnm_pool_cached_bytes() <= 8 << 20
+        np.testing.assert_array_equal(live.to_host(np.int64, 1 << 16), np.arange(1 << 16, dtype=np.int64))
+        live.free()
+    finally:
+        lib.vnm_pool_set_idle_trim(2000, 256 << 20)

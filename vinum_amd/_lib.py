@@ -116,6 +116,8 @@ PROTOTYPES = {
     "vnm_malloc": (c_void, [c_i64]),
     "vnm_free": (c_int, [c_void]),
     "vnm_pool_trim": (c_i64, []),
+    "vnm_pool_set_idle_trim": (c_int, [c_i64, c_i64]),
+    "vnm_pool_cached_bytes": (c_i64, []),
     "vnm_memcpy_h2d": (c_int, [c_void, c_void, c_i64]),
     "vnm_memcpy_d2h": (c_int, [c_void, c_void, c_i64]),
     "vnm_memset": (c_int, [c_void, c_int, c_i64]),

@@ -4806,9 +4806,11 @@ int tdict_alloc(TDict* d, uint64_t cap, int kwt, hipStream_t s) {
     d->cap = cap; d->kwt = kwt; d->sw = kwt <= 6 ? 8 : 16;
     d->slot = (uint64_t*)pool_alloc((size_t)cap * d->sw * 8);
     d->ctl = (unsigned long long*)pool_alloc(64);
-    if (!d->slot || !d->ctl) return 1;
-    VNM_HIP(hipMemsetAsync(d->slot, 0xFF, (size_t)cap * d->sw * 8, s));
-    VNM_HIP(hipMemsetAsync(d->ctl, 0, 64, s));
+    if (!d->slot || !d->ctl || hipMemsetAsync(d->slot, 0xFF, (size_t)cap * d->sw * 8, s) != hipSuccess || hipMemsetAsync(d->ctl, 0, 64, s) != hipSuccess) {
+        pool_free(d->slot); pool_free(d->ctl);   // (nothing half-allocated is left behind)
+        memset(d, 0, sizeof(*d));
+        return set_error("aggregate: tuple dictionary allocation failed");
+    }
     return 0;
 }
 
@@ -6499,7 +6501,8 @@ int vnm_agg_dense_range(vnm_agg* h, int64_t nrows, const vnm_dcol* key, uint64_t
     if (!h->single || h->plan.n_keys != 1 || nrows <= 0 || (key->type != VNM_I64 && key->type != VNM_U64) || key->validity) return 0;
     hipStream_t s = as_stream(stream);
     const uint64_t sign = key->type == VNM_I64 ? 0x8000000000000000ULL : 0ULL;
-    unsigned long long* d = (unsigned long long*)pool_alloc(64);
+    PoolScope pool;   // (every early return gives the block back)
+    unsigned long long* d = (unsigned long long*)pool.take(64);
     if (!d) return 1;
     const unsigned long long init[2] = {~0ULL, 0ULL};
     unsigned long long got[2];
@@ -6510,7 +6513,6 @@ int vnm_agg_dense_range(vnm_agg* h, int64_t nrows, const vnm_dcol* key, uint64_t
     VNM_HIP(hipGetLastError());
     VNM_HIP(hipMemcpyAsync(got, d, 16, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
-    pool_free(d);
     *lo = got[0]; *hi = got[1];
     return 0;
 }

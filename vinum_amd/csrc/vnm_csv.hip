@@ -331,6 +331,9 @@ int vnm_csv_parse_block(const char* host_text, int64_t nbytes, int skip_header, 
         }
     } cleanup{&text, out_cols, n_cols};
     PoolScope pool;
+    // (declared last, so it runs first on the way out: an error return must not hand scratch blocks, the staged text or the output
+    // columns back to the pool while kernels that use them may still be in flight -- ADVICE r03)
+    struct SyncOnError { hipStream_t s; bool ok = false; ~SyncOnError() { if (!ok) (void)hipStreamSynchronize(s); } } sync_guard{s};
     CsvArgs a{};
     a.text = (const uint8_t*)text.values;
     a.nbytes = nbytes;
@@ -386,6 +389,7 @@ int vnm_csv_parse_block(const char* host_text, int64_t nbytes, int skip_header, 
     fallback[n_cols] = fl[0] != 0;        // a quote character: the whole block needs the host reader
     fallback[n_cols + 1] = fl[20] != 0;   // a row with a different number of fields
     cleanup.keep_out = true;
+    sync_guard.ok = true;     // (the flags read-back above synchronised the stream)
     return 0;
 }
 

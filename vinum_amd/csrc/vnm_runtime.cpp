@@ -1,4 +1,6 @@
 // Runtime plumbing of libvinum_hip.so: init, errors, caching device allocator, staging, memcpy helpers.
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <cstring>
@@ -36,10 +38,25 @@ int ensure_init() {
 }
 
 // ---- caching allocator ---------------------------------------------------------------------------
+// Freed blocks are cached for reuse (a 1e9-row query recycles tens of GB of scratch between its passes and its batches).  A host
+// that embeds the library never calls vnm_pool_trim, so the cache gives itself back: a reaper thread releases the cached blocks
+// beyond VNM_POOL_KEEP_BYTES (default 256 MiB) once the allocator has been IDLE for VNM_POOL_IDLE_MS (default 2000 ms: no
+// pool_alloc / pool_free in that time -- a query in flight, or a bench loop, touches the pool every few milliseconds and is
+// never trimmed under its feet).  vnm_pool_set_idle_trim changes both at run time; idle_ms < 0 switches the reaper off.
 namespace {
-std::mutex g_pool_mu;
-std::multimap<size_t, void*> g_free;          // size -> block
-std::unordered_map<void*, size_t> g_sizes;    // live + cached blocks
+// (leaked on purpose: the reaper thread may still look at them while static destructors run at exit)
+std::mutex& g_pool_mu = *new std::mutex;
+std::multimap<size_t, void*>& g_free = *new std::multimap<size_t, void*>;               // size -> block
+std::unordered_map<void*, size_t>& g_sizes = *new std::unordered_map<void*, size_t>;    // live + cached blocks
+size_t g_cached_bytes = 0;
+std::atomic<int64_t> g_last_activity_ms{0};
+std::atomic<int64_t> g_idle_ms{-2};           // -2: not read from the environment yet
+std::atomic<int64_t> g_keep_bytes{256ll << 20};
+std::atomic<bool> g_reaper_started{false}, g_exiting{false};
+
+int64_t now_ms() {
+    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 size_t round_size(size_t b) {
     if (b < 4096) return 4096;
@@ -49,15 +66,58 @@ size_t round_size(size_t b) {
     size_t step = p / 8;
     return (b + step - 1) / step * step;
 }
+
+// releases cached blocks, largest first, until at most `keep` bytes stay cached
+size_t trim_to(size_t keep) {
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    size_t bytes = 0;
+    while (g_cached_bytes > keep && !g_free.empty()) {
+        auto it = std::prev(g_free.end());
+        bytes += it->first;
+        g_cached_bytes -= it->first;
+        g_sizes.erase(it->second);
+        (void)hipFree(it->second);
+        g_free.erase(it);
+    }
+    return bytes;
+}
+
+void reaper_main() {
+    for (;;) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(250));
+        if (g_exiting.load()) return;
+        const int64_t idle = g_idle_ms.load();
+        if (idle < 0) continue;
+        bool over;
+        { std::lock_guard<std::mutex> g(g_pool_mu); over = g_cached_bytes > (size_t)g_keep_bytes.load(); }
+        if (over && now_ms() - g_last_activity_ms.load() >= idle && !g_exiting.load()) trim_to((size_t)g_keep_bytes.load());
+    }
+}
+
+void touch_pool() {
+    g_last_activity_ms.store(now_ms(), std::memory_order_relaxed);
+    if (!g_reaper_started.load(std::memory_order_relaxed) && !g_reaper_started.exchange(true)) {
+        if (g_idle_ms.load() == -2) {
+            const char* e = getenv("VNM_POOL_IDLE_MS");
+            g_idle_ms.store(e ? atoll(e) : 2000);
+            const char* k = getenv("VNM_POOL_KEEP_BYTES");
+            if (k) g_keep_bytes.store(atoll(k));
+        }
+        std::atexit([] { g_exiting.store(true); });
+        std::thread(reaper_main).detach();
+    }
+}
 }  // namespace
 
 void* pool_alloc(size_t bytes) {
     size_t sz = round_size(bytes ? bytes : 1);
+    touch_pool();
     {
         std::lock_guard<std::mutex> g(g_pool_mu);
         auto it = g_free.lower_bound(sz);
         if (it != g_free.end() && it->first <= sz * 2) {
             void* p = it->second;
+            g_cached_bytes -= it->first;
             g_free.erase(it);
             return p;
         }
@@ -79,6 +139,7 @@ void* pool_alloc(size_t bytes) {
 
 void pool_free(void* p) {
     if (!p) return;
+    touch_pool();
     std::lock_guard<std::mutex> g(g_pool_mu);
     auto it = g_sizes.find(p);
     if (it == g_sizes.end()) {
@@ -86,19 +147,10 @@ void pool_free(void* p) {
         return;
     }
     g_free.emplace(it->second, p);
+    g_cached_bytes += it->second;
 }
 
-size_t pool_trim() {
-    std::lock_guard<std::mutex> g(g_pool_mu);
-    size_t bytes = 0;
-    for (auto& kv : g_free) {
-        bytes += kv.first;
-        g_sizes.erase(kv.second);
-        (void)hipFree(kv.second);
-    }
-    g_free.clear();
-    return bytes;
-}
+size_t pool_trim() { return trim_to(0); }
 
 Predicate make_predicate(int col_type, bool col_has_nulls, int op, int scalar_is_float, double dval, int64_t ival) {
     Predicate p{};
@@ -398,6 +450,17 @@ void* vnm_malloc(int64_t bytes) {
 
 int vnm_free(void* p) {
     pool_free(p);
+    return 0;
+}
+
+int64_t vnm_pool_cached_bytes(void) {
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    return (int64_t)g_cached_bytes;
+}
+
+int vnm_pool_set_idle_trim(int64_t idle_ms, int64_t keep_bytes) {
+    g_idle_ms.store(idle_ms < 0 ? -1 : idle_ms);
+    if (keep_bytes >= 0) g_keep_bytes.store(keep_bytes);
     return 0;
 }
 

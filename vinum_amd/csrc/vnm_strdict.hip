@@ -276,9 +276,11 @@ int sdict_alloc(SDict* d, uint64_t cap, hipStream_t s) {
     d->cap = cap;
     d->slot = (uint64_t*)pool_alloc((size_t)cap * 32);
     d->ctl = (unsigned long long*)pool_alloc(64);
-    if (!d->slot || !d->ctl) return 1;
-    VNM_HIP(hipMemsetAsync(d->slot, 0xFF, (size_t)cap * 32, s));
-    VNM_HIP(hipMemsetAsync(d->ctl, 0, 64, s));
+    if (!d->slot || !d->ctl || hipMemsetAsync(d->slot, 0xFF, (size_t)cap * 32, s) != hipSuccess || hipMemsetAsync(d->ctl, 0, 64, s) != hipSuccess) {
+        pool_free(d->slot); pool_free(d->ctl);   // (nothing half-allocated is left behind)
+        memset(d, 0, sizeof(*d));
+        return set_error("vnm_strdict: table allocation failed");
+    }
     return 0;
 }
 void sdict_free(SDict* d) {
@@ -310,6 +312,10 @@ struct vnm_strdict {
     int64_t ids = 0;                         // its host copy after the last encode
     std::vector<int32_t> new_ids, new_lens;  // the values the last encode added, in heap order
     std::vector<uint8_t> new_bytes;
+    // An encode that fails between the encode kernel and the compaction leaves slots published as `NEW | row of a batch that is gone`:
+    // the next encode would resolve them through ITS batch's offsets (wrong matches, reads out of range).  Such a handle refuses
+    // further use.
+    bool failed = false;
 };
 
 extern "C" {
@@ -329,8 +335,22 @@ void vnm_strdict_destroy(vnm_strdict* h) {
 
 int64_t vnm_strdict_ids(vnm_strdict* h) { return h ? h->ids : 0; }
 
+static int strdict_encode_device_impl(vnm_strdict* h, const vnm_dcol* offsets, const uint8_t* validity, int64_t validity_offset,
+                                      const uint8_t* data, int64_t data_base, int32_t* out_codes, int64_t* n_new, int64_t* new_bytes, void* stream);
+
 int vnm_strdict_encode_device(vnm_strdict* h, const vnm_dcol* offsets, const uint8_t* validity, int64_t validity_offset,
                               const uint8_t* data, int64_t data_base, int32_t* out_codes, int64_t* n_new, int64_t* new_bytes, void* stream) {
+    if (h && h->failed) return set_error("vnm_strdict: an earlier encode failed half-way; the dictionary cannot be used any more (create a new one)");
+    const int rc = strdict_encode_device_impl(h, offsets, validity, validity_offset, data, data_base, out_codes, n_new, new_bytes, stream);
+    if (rc && h && h->d.slot) {
+        (void)hipStreamSynchronize(as_stream(stream));   // (scratch of the failed call goes back to the pool: nothing may still be running on it)
+        h->failed = true;
+    }
+    return rc;
+}
+
+static int strdict_encode_device_impl(vnm_strdict* h, const vnm_dcol* offsets, const uint8_t* validity, int64_t validity_offset,
+                                      const uint8_t* data, int64_t data_base, int32_t* out_codes, int64_t* n_new, int64_t* new_bytes, void* stream) {
     VNM_TRY(ensure_init());
     if (!h || !offsets || !out_codes) return set_error("vnm_strdict_encode_device: null argument");
     if (offsets->type != VNM_I32 && offsets->type != VNM_I64) return set_error("vnm_strdict_encode_device: offsets must be int32 or int64");

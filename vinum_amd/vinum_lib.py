@@ -338,8 +338,26 @@ class _HashAggregateBase:
             return res
         smm = self._strmm.result()
         o_num, o_str = _canonical_order(res, self._groupby), _canonical_order(smm, self._groupby)
-        assert len(o_num) == len(o_str), "the numeric and the string results must hold the same groups"
+        if len(o_num) != len(o_str):
+            raise RuntimeError(f"aggregate: the numeric result holds {len(o_num)} groups, the string MIN / MAX result {len(o_str)} (internal error)")
         res, smm = res.take(pa.array(o_num)), smm.take(pa.array(o_str))
+        # ... and the SAME groups: after the canonical order the key columns of both results must agree in validity and bits, or the
+        # string columns would be attached to the wrong rows without anybody noticing
+        for k in self._groupby:
+            if k not in res.schema.names:
+                continue
+            a, b = res.column(res.schema.names.index(k)), smm.column(smm.schema.names.index(k))
+            same = a.is_valid().equals(b.is_valid())
+            if same and len(a):
+                ut = {8: pa.uint8(), 16: pa.uint16(), 32: pa.uint32(), 64: pa.uint64()}.get(getattr(a.type, "bit_width", 0))
+                if a.type != b.type:
+                    same = False
+                elif ut is None:
+                    same = a.equals(b)
+                else:
+                    same = a.view(ut).fill_null(0).equals(b.view(ut).fill_null(0))      # (bit patterns: NaN keys compare by payload)
+            if not same:
+                raise RuntimeError(f"aggregate: the numeric and the string MIN / MAX results disagree on the groups of key '{k}' (internal error)")
         arrays, names = [], []
         for c in self._agg_cols:
             arrays.append(res.column(res.schema.names.index(c))); names.append(c)
