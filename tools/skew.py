@@ -22,10 +22,13 @@ for p in ps:
             agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())], expected_groups=hint)
             agg.set_predicate(">", 63.9921875)
             agg.next([ck], [cv, cv], pred=cv, nrows=n)
-            ng = agg.finish()
+            if len(sys.argv) > 5 and sys.argv[5] == "cols":     # the bench's step: the result columns (fused into the final pass)
+                cols = agg.result_device(); ng = agg.result_rows; del cols
+            else:
+                ng = agg.finish()
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             spans = {}
-            for nm in (b"agg_estimate", b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final", b"agg_part_merge", b"agg_run_patch"):
+            for nm in (b"agg_estimate", b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final", b"agg_part_merge", b"agg_run_patch", b"agg_side_append", b"agg_finalize"):
                 ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
                 L.lib().vnm_profile_query(nm, ctypes.byref(ms), ctypes.byref(cnt))
                 if cnt.value:

@@ -4180,19 +4180,21 @@ int complete_pending(vnm_agg* h, hipStream_t s, int out = DF_RUN, const DFinalAr
     } else if (out == DF_COLS) {
         df.n_out = cols->n_out;
         for (int c = 0; c < cols->n_out; c++) { df.out_kind[c] = cols->out_kind[c]; df.out_ptr[c] = cols->out_ptr[c]; }
+        if (cols->has_side) { df.has_side = 1; df.side = cols->side; df.side_bloom = cols->side_bloom; df.side_bloom_mask = cols->side_bloom_mask; df.side_found = cols->side_found; }
     } else {
         if (!pd->table) pd->table = (DTabSlot*)pool_alloc(sizeof(DTabSlot) << df.map.bits);
         if (!pd->table) return 1;
         df.table = pd->table;
     }
-    df.dstride = pd->dstride;
+    df.dstride = (out == DF_COLS && cols->dstride > 0) ? cols->dstride : pd->dstride;   // (capacity of the output: + the side table's groups)
     pool_free(pd->dsets);
     pd->dsets = (DSet*)pool_alloc(pd->sets.size() * sizeof(DSet));
     if (!pd->dsets) return 1;
     VNM_HIP(hipMemcpyAsync(pd->dsets, pd->sets.data(), pd->sets.size() * sizeof(DSet), hipMemcpyHostToDevice, s));
     df.sets = pd->dsets; df.nsets = (int)pd->sets.size();
-    unsigned long long fl[3] = {0, 0, 0};
+    unsigned long long fl[5] = {0, 0, 0, 0, 0};
     uint64_t* psum = nullptr; float* plo = nullptr; uint32_t* pcnt = nullptr;
+    if (pd->fsplits > 1 && df.has_side) return set_error("aggregate: side table with a split final pass (internal error)");
     if (pd->fsplits > 1) {   // few final partitions: each is shared by `fsplits` workgroups (partial tables + dpart_merge_kernel)
         const size_t cells = (size_t)pd->nfinal * pd->fsplits << pd->tb;
         psum = (uint64_t*)pool.take(cells * 8); plo = (float*)pool.take(cells * 4); pcnt = (uint32_t*)pool.take(cells * 4);
@@ -4218,8 +4220,20 @@ int complete_pending(vnm_agg* h, hipStream_t s, int out = DF_RUN, const DFinalAr
             // 64-bit compensation terms only fit 2^12-slot tables: every partition in two halves (slot bit 12 = 0, then 1)
             df.sub_bits = 1;
             for (int sub = 0; sub < 2; sub++) { df.sub = sub; VNM_TRY(launch_dense_final(df, 12, out, true, s)); }
-        } else VNM_TRY(launch_dense_final(df, pd->tb, out, attempt == 1, s));
-        VNM_HIP(hipMemcpyAsync(fl, df.flags, 16, hipMemcpyDeviceToHost, s));
+        } else {
+            if (df.has_side) {
+                VNM_HIP(hipMemsetAsync(df.side_found, 0, (size_t)df.side.cap + 2, s));
+                VNM_HIP(hipMemsetAsync(df.flags + 4, 0, 8, s));
+            }
+            VNM_TRY(launch_dense_final(df, pd->tb, out, attempt == 1, s));
+            if (df.has_side) {
+                KernelTimer timer("agg_side_append", s);
+                dside_append_kernel<<<(int)std::min<int64_t>(((int64_t)df.side.cap + 2 + 255) / 256, (int64_t)device_info().num_cus * 8), 256, 0, s>>>(df, 0);
+                dside_append_kernel<<<1, 256, 0, s>>>(df, 1);
+                VNM_HIP(hipGetLastError());
+            }
+        }
+        VNM_HIP(hipMemcpyAsync(fl, df.flags, 40, hipMemcpyDeviceToHost, s));
         VNM_HIP(hipStreamSynchronize(s));
         if (!fl[0]) break;
         if (out == DF_TABLE) return 2;
@@ -4228,6 +4242,7 @@ int complete_pending(vnm_agg* h, hipStream_t s, int out = DF_RUN, const DFinalAr
     if (getenv("VNM_AGG_TRACE")) fprintf(stderr, "[agg] dense final (deferred, %zu batch%s): mode %d -> groups %llu\n", pd->sets.size(),
                                          pd->sets.size() == 1 ? "" : "es", out, fl[1]);
     if (n_out) *n_out = (int64_t)fl[1];
+    if (out == DF_COLS && cols->null_pos) *cols->null_pos = df.has_side ? (int64_t)fl[4] : 0;
     if (out == DF_RUN) {
         pool.keep(rk); pool.keep(ra);
         h->run_key = rk; h->run_acc = ra; h->run_stride = pd->dstride; h->run_n = (int64_t)fl[1];
@@ -6447,8 +6462,33 @@ int vnm_agg_result_device_alloc(vnm_agg* h, int n_cols, const int* which, void**
     VNM_TRY(flush_queue(h, stream));   // (the waiting batches of an asynchronous stream)
     auto free_outputs = [&]() { for (int c = 0; c < n_cols; c++) { pool_free(out_values[c]); pool_free(out_bitmaps[c]); out_values[c] = nullptr; out_bitmaps[c] = nullptr; } };
     DensePending* pd = h->inner ? nullptr : h->pending;
-    bool fused = pd && !h->have_table && !h->have_run && h->n_groups < 0 && n_cols >= 1 && n_cols <= DF_MAX_OUT && getenv("VNM_AGG_NO_FUSED_RESULT") == nullptr;
+    bool fused = pd && !h->have_run && h->n_groups < 0 && n_cols >= 1 && n_cols <= DF_MAX_OUT && getenv("VNM_AGG_NO_FUSED_RESULT") == nullptr;
+    // An HBM table next to the pending pass (spilled heavy keys, keys outside the code range, the NULL-key group, rows of batches that
+    // took the scan): while it holds FEW groups the pass folds them into its own result columns (dside_merge / dside_append_kernel)
+    int64_t side_groups = 0;
+    PoolScope side_pool;
     DFinalArgs cols{};
+    if (fused && h->have_table) {
+        unsigned long long fill = 0;
+        VNM_HIP(hipMemcpyAsync(&fill, h->g.ctl + 2, 8, hipMemcpyDeviceToHost, s));
+        VNM_HIP(hipStreamSynchronize(s));
+        fused = pd->fsplits == 1 && h->g.kwt == 0 && (int64_t)fill <= env_i64("VNM_AGG_SIDE_MAX_GROUPS", 1 << 22) && h->g.cap <= (1ULL << 26) &&
+                getenv("VNM_AGG_NO_SIDE_FUSION") == nullptr;
+        if (getenv("VNM_AGG_TRACE")) fprintf(stderr, "[agg] result columns: side table with %llu groups in %llu slots, splits %d -> %s\n", fill,
+                                             (unsigned long long)h->g.cap, pd->fsplits, fused ? "folded into the final pass" : "run + table merge");
+        if (fused) {
+            side_groups = (int64_t)fill + 2;
+            uint64_t bbits = DSIDE_BLOOM_BITS;      // ~64 filter bits per key: 2^16 (a copy in LDS) ... 2^26
+            while (bbits < fill * 64 && bbits < (1ULL << 26)) bbits <<= 1;
+            uint32_t* bloom = (uint32_t*)side_pool.take((size_t)bbits / 8);
+            uint8_t* found = (uint8_t*)side_pool.take((size_t)h->g.cap + 2);
+            if (!bloom || !found) return 1;
+            VNM_HIP(hipMemsetAsync(bloom, 0, (size_t)bbits / 8, s));
+            dside_bloom_kernel<<<(int)std::min<int64_t>(((int64_t)h->g.cap + 255) / 256, (int64_t)device_info().num_cus * 8), 256, 0, s>>>(h->g, bloom, (uint32_t)(bbits - 1));
+            VNM_HIP(hipGetLastError());
+            cols.has_side = 1; cols.side = h->g; cols.side_bloom = bloom; cols.side_bloom_mask = (uint32_t)(bbits - 1); cols.side_found = found;
+        }
+    }
     for (int c = 0; c < n_cols && fused; c++) {
         const int w = which[c];
         if (w < 0) { cols.out_kind[c] = DF_KEY; if (out_kinds) out_kinds[c] = -1; continue; }
@@ -6460,15 +6500,31 @@ int vnm_agg_result_device_alloc(vnm_agg* h, int n_cols, const int* which, void**
     }
     if (fused) {
         cols.n_out = n_cols;
+        cols.dstride = pd->dstride + side_groups;
         for (int c = 0; c < n_cols; c++) {
-            out_values[c] = pool_alloc((size_t)pd->dstride * 8);
+            out_values[c] = pool_alloc((size_t)cols.dstride * 8);
             if (!out_values[c]) { free_outputs(); return 1; }
             cols.out_ptr[c] = out_values[c];
             if (null_counts) null_counts[c] = 0;   // every group of this shape saw a non-NULL input: no NULL results
         }
-        int64_t n = 0;
+        int64_t n = 0, null_pos = 0;
+        cols.null_pos = &null_pos;
         const int rc = complete_pending(h, s, DF_COLS, &cols, &n);
         if (rc) { free_outputs(); return rc; }
+        if (null_pos > 0) {   // the NULL-key group: the key columns get a validity bitmap with that one bit cleared
+            for (int c = 0; c < n_cols; c++) {
+                if (which[c] >= 0) continue;
+                const size_t nb = (size_t)((n + 63) / 64 + 1) * 8;
+                uint8_t* bm = (uint8_t*)pool_alloc(nb);
+                if (!bm) { free_outputs(); return 1; }
+                out_bitmaps[c] = bm;
+                const int64_t p = null_pos - 1;
+                const uint8_t byte = (uint8_t)(0xFFu & ~(1u << (p & 7)));
+                if (hipMemsetAsync(bm, 0xFF, nb, s) != hipSuccess || hipMemcpyAsync(bm + (p >> 3), &byte, 1, hipMemcpyHostToDevice, s) != hipSuccess ||
+                    hipStreamSynchronize(s) != hipSuccess) { free_outputs(); return set_error("vnm_agg_result_device_alloc: key bitmap failed"); }
+                if (null_counts) null_counts[c] = 1;
+            }
+        }
         *n_groups = n;
         return 0;
     }
