@@ -416,3 +416,71 @@ def sample_sort_exchange(keys: torch.Tensor, global_ids: torch.Tensor, descendin
     perm = sort_local(rc, rid)
     out_keys = rk[perm]
     return (out_keys.view(torch.float64) if keys.dtype == torch.float64 else out_keys.to(keys.dtype)), rid[perm]
+
+
+# ---- string (non-numeric) group keys across ranks (round 4; SURVEY.md 8 f3 x 8e) -------------------------------------------------
+# GenericHashAggregate keys its map on the VALUES (generic_hash_aggregate.h:10-45).  Here every rank dictionary-encodes a
+# non-numeric key column on its own (vnm_strdict_encode): code 7 is "Berlin" on one rank and "Riva" on another, so partial groups
+# cannot be exchanged by code.  Before the exchange the ranks build ONE dictionary: every rank contributes its values (one
+# all_gather of the Arrow arrays' buffers), the union keeps them in (rank, local order) of first appearance -- the same on every
+# rank -- and each rank re-keys its partial groups by union id (one gather through a remap table).  From then on the key word is
+# an ordinary integer: owner_of / bucket_by_owner / the exchanges above apply unchanged, and the result's key column is decoded
+# through the union dictionary.
+
+def union_dictionary(values, group=None):
+    """values: this rank's dictionary as a pyarrow array (distinct values, position = local code).
+    Returns (union: pa.Array of the distinct values of all ranks, remap: np.int32 array with remap[local code] = union id).
+    Deterministic and identical on every rank: rank 0's values in its order, then the values rank 1 adds, ..."""
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sink = pa.BufferOutputStream()
+    t = pa.table({"v": values})
+    with pa.ipc.new_stream(sink, t.schema) as w:
+        w.write_table(t)
+    blob = sink.getvalue().to_pybytes()
+    blobs = [None] * world
+    dist.all_gather_object(blobs, blob, group=group)
+    parts = [pa.ipc.open_stream(b).read_all().column(0).combine_chunks() for b in blobs]
+    return union_of_dictionaries(parts, rank)
+
+
+def union_of_dictionaries(parts, rank):
+    """The pure part of union_dictionary: parts[r] = rank r's dictionary (position = local code; a NULL entry = a code that was
+    never handed out -> remap -1).  Returns (union, remap of `rank`)."""
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    union = pa.array([], type=parts[0].type)
+    remap = None
+    for r, part in enumerate(parts):
+        valid = part.is_valid().to_numpy(zero_copy_only=False) if len(part) else np.zeros(0, bool)
+        pos = np.full(len(part), -1, np.int64)
+        if valid.any():
+            live = part.filter(pa.array(valid))
+            idx = pc.index_in(live, value_set=union) if len(union) else pa.nulls(len(live), pa.int32())
+            known = idx.is_valid().to_numpy(zero_copy_only=False)
+            p_live = idx.fill_null(0).to_numpy(zero_copy_only=False).astype(np.int64)
+            n_new = int((~known).sum())
+            if n_new:
+                p_live[~known] = len(union) + np.arange(n_new, dtype=np.int64)
+                union = pa.concat_arrays([union, live.filter(pa.array(~known))])
+            pos[valid] = p_live
+        if r == rank:
+            remap = pos.astype(np.int32)
+    if len(union) >= 2**31:
+        raise RuntimeError("union_dictionary: more than 2^31 distinct key values")
+    return union, remap
+
+
+def rekey_codes(codes: torch.Tensor, null_mask: torch.Tensor, remap) -> torch.Tensor:
+    """Key word of the partial groups (local dictionary codes; the NULL group's word is 0 with its mask set) -> union ids.
+    codes / null_mask: int64 tensors (host or device); remap: what union_dictionary returned."""
+    table = torch.as_tensor(remap, dtype=torch.int64, device=codes.device)
+    if table.numel() == 0:
+        return codes.clone()
+    safe = torch.where(null_mask != 0, torch.zeros_like(codes), codes)
+    out = table[safe.clamp_(0, table.numel() - 1)]
+    return torch.where(null_mask != 0, torch.zeros_like(out), out)

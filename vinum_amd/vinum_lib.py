@@ -483,6 +483,17 @@ class KeyDictionary:
         mask = ~idx.is_valid().to_numpy(zero_copy_only=False) if idx.null_count else None
         return pa.array(codes, type=pa.int32(), mask=mask)
 
+    def values_by_code(self) -> pa.Array:
+        """The dictionary as an array indexed by CODE (a code the device never handed out: NULL) -- what the ranks exchange to build
+        one dictionary before partial groups keyed by these codes can travel (distributed.union_dictionary)."""
+        import numpy as np
+        if self._device and self._h is not None:
+            values = pa.concat_arrays(self._chunks) if self._chunks else pa.array([], type=self.type)
+            top = int(L.lib().vnm_strdict_ids(self._h))
+            pos = self._pos[:top] if self._pos is not None else np.zeros(0, np.int64)
+            return values.take(pa.array(np.where(pos < 0, 0, pos), type=pa.int64(), mask=(pos < 0) if (pos < 0).any() else None))
+        return self.values
+
     def decode(self, codes: pa.Array) -> pa.Array:
         if self._device and self._h is not None:
             import numpy as np
