@@ -311,3 +311,46 @@ def test_string_group_keys_across_simulated_ranks(ranks):
     for a in aggs:
         a.close()
     merged.close()
+
+
+@pytest.mark.parametrize("pred", ["on_input", "on_other", "none"])
+@pytest.mark.parametrize("route", ["dense_two_level", "dense_one_level", "dense_32_partitions", "sparse_keys_fall_back", "all_keys_null_batch"])
+@pytest.mark.parametrize("hint", [0, 1])
+def test_nullable_key_through_the_dense_path(route, pred, hint, monkeypatch):
+    """VERDICT r03 #5c: a NULLABLE single 8-byte key under the hot program goes through the dense path as it is -- pass 1 reads the
+    key's validity (dring_scatter_kernel<KN>) and sums the NULL-key rows into the NULL slot of the operator's table; the fused result
+    columns append that group last with a validity bitmap (single_numerical_hash_aggregate.cpp:24-32).  Garbage under the NULL slots of
+    the key column, the real key 0 next to the NULL group, sparse keys (the dense path declines -> the packed route), a batch whose
+    keys are ALL NULL, several batches."""
+    from oracle import oracle as O
+    from vinum_amd import _lib as L
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    groups = {"dense_two_level": 1_500_000, "dense_one_level": 900_000, "dense_32_partitions": 20_000, "sparse_keys_fall_back": 300_000,
+              "all_keys_null_batch": 900_000}[route]
+    if route == "dense_two_level":
+        monkeypatch.setenv("VNM_DENSE_ONE_LEVEL", "0")
+    rng = np.random.default_rng(len(route) * 3 + len(pred) + hint)
+    batches = []
+    for bi, n in enumerate([1_100_000, 400_001, 650_000]):
+        k = rng.integers(0, groups, n).astype(np.int64) * (1_000_003 if route == "sparse_keys_fall_back" else 1)
+        k[::997] = 0
+        mask = rng.random(n) < 0.12
+        if route == "all_keys_null_batch" and bi == 1:
+            mask[:] = True
+        k[mask] = rng.integers(-2**40, 2**40, int(mask.sum()))        # garbage under the NULL slots: it must never be looked at
+        batches.append(pa.RecordBatch.from_pydict({
+            "k": pa.array(k, mask=mask),
+            "v": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0),
+            "p": pa.array(rng.integers(0, 2**12, n).astype(np.float64) / 64.0)}))
+    funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.COUNT, "v", "c"), (O.COUNT_STAR, "", "n")]
+    predicate = {"on_input": ("v", ">", 64.0), "on_other": ("p", ">", 20.0), "none": None}[pred]
+    L.lib().vnm_set_profiling(1)
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=predicate, expected_groups=groups if hint else 0)
+    pack, p1 = _launches(b"agg_pack_keys"), _launches(b"agg_part_scatter1")
+    L.lib().vnm_set_profiling(0)
+    if route.startswith("dense"):
+        assert pack == 0 and p1 == len(batches), (pack, p1)      # no packing pass: the dense scatter read the nullable key itself
+    exp = _oracle(O.SINGLE, ["k"], funcs, batches, predicate)
+    util.assert_agg_equal(got, exp, funcs, ["k"], what=f"nullable key, {route}, pred {pred}, hint {hint}")
+    if route.startswith("dense"):
+        assert got.column(0)[got.num_rows - 1].as_py() is None    # the NULL group comes last, as in the reference's single-key operator

@@ -2621,7 +2621,11 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
 // Cardinality estimate for operators that were given no hint: insert a strided sample of the keys into a
 // scratch table (tags only) and count the distinct ones.  Solving d = G (1 - exp(-m / G)) for G (uniform
 // model) on the host then sizes the partitions; an underestimate only costs the fallback to the general path.
-__global__ void agg_sample_kernel(const uint64_t* keys, int64_t nrows, int64_t m, GTable g, unsigned int* cnt) {
+// (kvalid: the key column's validity bitmap or null -- rows whose key is NULL are not part of any sample: their value words are garbage)
+__device__ __forceinline__ bool key_row_valid(const uint8_t* kvalid, int64_t koff, int64_t row) {
+    return !kvalid || ((kvalid[(koff + row) >> 3] >> ((koff + row) & 7)) & 1);
+}
+__global__ void agg_sample_kernel(const uint64_t* keys, int64_t nrows, int64_t m, GTable g, unsigned int* cnt, const uint8_t* kvalid, int64_t koff) {
     __shared__ unsigned s_new;
     if (threadIdx.x == 0) s_new = 0;
     __syncthreads();
@@ -2630,7 +2634,7 @@ __global__ void agg_sample_kernel(const uint64_t* keys, int64_t nrows, int64_t m
         int64_t row = (int64_t)(((__int128)i * nrows) / m);
         uint64_t key = keys[row];
         uint64_t slot = ~0ULL;
-        if (key != EMPTY) {
+        if (key != EMPTY && key_row_valid(kvalid, koff, row)) {
             slot = gt_find_single(g, key, &s_new);
             if (slot >= g.cap) slot = ~0ULL;
         }
@@ -2669,13 +2673,14 @@ __global__ void agg_sample_heavy_kernel(const unsigned int* cnt, int64_t slots, 
 // a scratch table would cost tens of milliseconds of atomics.
 constexpr int HLL_BITS = 12;
 constexpr int HLL_M = 1 << HLL_BITS;
-__global__ __launch_bounds__(1024) void agg_hll_kernel(const uint64_t* keys, int64_t nrows, int64_t m, unsigned int* regs) {
+__global__ __launch_bounds__(1024) void agg_hll_kernel(const uint64_t* keys, int64_t nrows, int64_t m, unsigned int* regs, const uint8_t* kvalid, int64_t koff) {
     __shared__ unsigned int lreg[HLL_M];
     for (int i = threadIdx.x; i < HLL_M; i += blockDim.x) lreg[i] = 0;
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
         int64_t row = (int64_t)(((__int128)i * nrows) / m);
+        if (!key_row_valid(kvalid, koff, row)) continue;
         uint64_t key = keys[row];
         uint64_t h = ((uint64_t)hash_u64(key) << 32) | hash_u64(key * 0x9E3779B97F4A7C15ULL + 0x7F4A7C15ULL);
         unsigned idx = (unsigned)(h & (HLL_M - 1));
@@ -3328,6 +3333,11 @@ struct vnm_agg {
     int64_t q_rows = 0;
     bool q_pred_is_v = false;
     const std::vector<QBatch>* segs_active = nullptr;   // set around the one vnm_agg_next_device call that processes the queue
+    // a NULLABLE single key through the dense path (round 4): set around one next_device_impl call whose keys[0] had its validity
+    // stripped -- pass 1 reads it (dring_scatter_kernel<..., KN>) and sums the NULL-key rows into the HBM table's NULL slot
+    const uint8_t* kn_valid = nullptr;
+    int64_t kn_off = 0;
+    bool kn_failed = false;      // the dense path did not take such a batch once: later ones go straight to the packed route
     std::vector<VSeg> seg_host;                         // the segment table of the last launch (kept until the next one: H2D source)
 };
 
@@ -3469,7 +3479,7 @@ int estimate_groups(vnm_agg* h, const vnm_dcol& key, int64_t nrows, int64_t* est
         VNM_HIP(hipMemsetAsync(t.ctl, 0, 64, s));
         VNM_HIP(hipMemsetAsync(cnt, 0, t.cap * 4, s));
         int grid = (int)std::min<int64_t>((m + 255) / 256, (int64_t)device_info().num_cus * 8);
-        agg_sample_kernel<<<grid, 256, 0, s>>>(kp, nrows, m, t, cnt);
+        agg_sample_kernel<<<grid, 256, 0, s>>>(kp, nrows, m, t, cnt, h->kn_valid, h->kn_off);
         agg_sample_heavy_kernel<<<grid, 256, 0, s>>>(cnt, (int64_t)t.cap, (unsigned int)std::max<int64_t>(64, m / 256), t.ctl);
         VNM_HIP(hipGetLastError());
         unsigned long long got[6] = {0, 0, 0, 0, 0, 0};
@@ -3512,7 +3522,7 @@ int estimate_groups(vnm_agg* h, const vnm_dcol& key, int64_t nrows, int64_t* est
         if (!regs) return 1;
         VNM_HIP(hipMemsetAsync(regs, 0, HLL_M * 4, s));
         int grid = (int)std::min<int64_t>((m + 1023) / 1024, (int64_t)device_info().num_cus);
-        agg_hll_kernel<<<grid, 1024, 0, s>>>(kp, nrows, m, regs);
+        agg_hll_kernel<<<grid, 1024, 0, s>>>(kp, nrows, m, regs, h->kn_valid, h->kn_off);
         VNM_HIP(hipGetLastError());
         std::vector<unsigned int> hr(HLL_M);
         VNM_HIP(hipMemcpyAsync(hr.data(), regs, HLL_M * 4, hipMemcpyDeviceToHost, s));
@@ -3880,7 +3890,7 @@ int plan_dense(vnm_agg* h, const vnm_dcol& key, int64_t nrows, hipStream_t s) {
     VNM_HIP(hipMemcpyAsync(d, init, 16, hipMemcpyHostToDevice, s));
     const int64_t m = std::min<int64_t>(nrows, 1 << 18);
     const int grid = (int)std::min<int64_t>((m + 255) / 256, (int64_t)device_info().num_cus * 4);
-    dense_sample_range_kernel<<<grid, 256, 0, s>>>(kp, nrows, m, sign, d);
+    dense_sample_range_kernel<<<grid, 256, 0, s>>>(kp, nrows, m, sign, d, h->kn_valid, h->kn_off);
     VNM_HIP(hipGetLastError());
     VNM_HIP(hipMemcpyAsync(got, d, 16, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
@@ -4266,7 +4276,8 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     const bool has_val = generic ? g.has_val != 0 : true;
     // nullable value column: NULL flags travel with the entries (generic programs) -- or, vn_fold, the hot program filtered by that
     // column itself: pass 1 drops the NULL rows with the filter and nothing after it ever sees a flag
-    if (h->segs_active && generic) return 2;   // (stream segments: the hot program's ring scatter only)
+    if ((h->segs_active || h->kn_valid) && generic) return 2;   // (stream segments, nullable keys: the hot program's ring scatter only)
+    if (h->kn_valid && h->segs_active) return 2;
     const bool vn = has_val && a.cols[0].validity != nullptr && (generic || vn_fold);
     if (vn && ((!vn_fold && !nspill_out) || a.has_expr)) return 2;
     if (vn_fold && (generic || !a.hot_pred_is_v)) return 2;
@@ -4376,6 +4387,17 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         /* the waiting batches of a stream: one segment each, sub-tiles of 2 * PR_ * BLK_ rows (the SEG instantiations) */ \
         constexpr bool SG_ = FR_ && HV_ && !VN_;                                                                        \
         const bool seg_ = SG_ && h->segs_active != nullptr;                                                             \
+        const bool kn_ = SG_ && h->kn_valid != nullptr;   /* a nullable key: the KN instantiations (same shapes as SEG) */ \
+        if (kn_) {                                                                                                      \
+            if (2 * PR_ * BLK_ <= (ARGS_).nparts * ((CAP_) - DR_FB) && ring_limit) {                                    \
+                VNM_HIP(hipFuncSetAttribute((const void*)dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 2, false, SG_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+                dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 2, false, SG_><<<GRID_, BLK_, lds_, s>>>(ARGS_, CAP_); \
+            } else {                                                                                                    \
+                VNM_HIP(hipFuncSetAttribute((const void*)dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 0, false, SG_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+                dring_scatter_kernel<FR_, CT_, HV_, BLK_, PR_, PV_, VN_, 0, false, SG_><<<GRID_, BLK_, lds_, s>>>(ARGS_, CAP_); \
+            }                                                                                                           \
+            break;                                                                                                      \
+        }                                                                                                               \
         if (seg_ && upload_segs(h, (int64_t)2 * PR_ * BLK_, &(ARGS_).segs, &(ARGS_).nseg, &(ARGS_).nsub, seg_pool, s)) { release(); pool_free(spill); return 1; } \
         /* round limit (skew): two insert / flush rounds per sub-tile, where an even spread of a sub-tile's entries (every */ \
         /* row surviving) fits ONE */                                                                                   \
@@ -4419,7 +4441,18 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     } while (0)
     const int rcap1 = (use_ring & 1) && !a.has_expr ? ring_cap_for(np1, (has_val ? 8 : 0) + (c16_1 ? 2 : 4)) : 0;
     PoolScope seg_pool;
-    if (h->segs_active && (!rcap1 || vn)) { release(); pool_free(spill); return 2; }   // (only the ring scatter reads segments)
+    if ((h->segs_active || h->kn_valid) && (!rcap1 || vn)) { release(); pool_free(spill); return 2; }   // (only the ring scatter reads segments / key validity)
+    if (h->kn_valid) {   // the NULL-key group lives in the NULL slot of the operator's HBM table
+        if (ensure_table(h, 1024, s, true)) { release(); pool_free(spill); return 1; }
+        const GTable& g = h->g;
+        const uint64_t slot = g.cap + 1;
+        d1.kvalid = h->kn_valid; d1.koff = h->kn_off;
+        d1.nk_tag = g.tag + slot;
+        d1.nk_rows = a.hot_w_rows >= 0 ? g.acc + (uint64_t)a.hot_w_rows * g.stride + slot : nullptr;
+        d1.nk_valid = a.hot_w_valid >= 0 ? g.acc + (uint64_t)a.hot_w_valid * g.stride + slot : nullptr;
+        d1.nk_sum = a.hot_w_sum >= 0 ? g.acc + (uint64_t)a.hot_w_sum * g.stride + slot : nullptr;
+        d1.nk_lo_stride = a.hot_comp && a.hot_w_sum >= 0 ? (int64_t)g.stride : 0;
+    }
     {
         KernelTimer timer("agg_part_scatter1", s);
         if (rcap1 && vn) {
@@ -5269,7 +5302,9 @@ int vnm_agg_estimate_groups(vnm_agg* h, int64_t nrows, const vnm_dcol* key, int6
 // rc of next_device_impl when the waiting batches of a stream (h->segs_active) would have to take a path whose kernels read ONE batch:
 // nothing has been aggregated, the caller sends the batches one by one
 constexpr int VNM_RC_SINGLY = 77;
-#define VNM_SEG_ONLY(what) do { if (h->segs_active) { if (getenv("VNM_AGG_TRACE")) fprintf(stderr, "[agg] stream segments: one by one (%s)\n", what); return VNM_RC_SINGLY; } } while (0)
+#define VNM_SEG_ONLY(what) do { if (h->segs_active || h->kn_valid) { if (getenv("VNM_AGG_TRACE")) fprintf(stderr, "[agg] %s: not this way (%s)\n", h->kn_valid ? "nullable key through the dense path" : "stream segments", what); return VNM_RC_SINGLY; } } while (0)
+
+static bool queueable(const vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs, const vnm_dcol* pred, bool* pred_is_v);
 
 static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs,
                             const vnm_dcol* pred, void* stream) {
@@ -5278,6 +5313,26 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
     if (h->pred_set && !pred) return set_error("vnm_agg_next_device: predicate set but no predicate column given");
     hipStream_t s = as_stream(stream);
     invalidate_result(h);
+    // A NULLABLE single 8-byte key under the hot program: the dense path takes it as it is -- pass 1 reads the key's validity and
+    // sums the NULL-key rows up as the one group they are (single_numerical_hash_aggregate.cpp:24-32), everything after pass 1 never
+    // sees a NULL.  Before round 4 such a key was packed into one word first (key range + pack + unpack passes, the NULL code a
+    // heavy key of the inner operator, run + table merges at the end: 15.7 ms per 5e8 rows at G = 1e8 against 5.2 without NULLs).
+    // The attempt runs this function again with the validity stripped from the key and kept aside; every path but the dense ring
+    // scatter declines (VNM_RC_SINGLY, before any side effect) and the batch takes the packed route below.
+    if (!h->kn_valid && !h->kn_failed && !h->segs_active && h->single && h->plan.n_keys == 1 && !h->inner && keys && inputs && keys[0].validity &&
+        type_width(keys[0].type) == 8 && (keys[0].offset & 1) == 0 && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
+        getenv("VNM_AGG_NO_DENSE_KN") == nullptr) {
+        vnm_dcol k2 = keys[0];
+        k2.validity = nullptr;
+        bool piv = false;
+        if (queueable(h, nrows, &k2, inputs, pred, &piv)) {
+            h->kn_valid = keys[0].validity; h->kn_off = keys[0].offset;
+            const int rc = next_device_impl(h, nrows, &k2, inputs, pred, stream);
+            h->kn_valid = nullptr;
+            if (rc != VNM_RC_SINGLY) return rc;
+            h->kn_failed = true;
+        }
+    }
     // rows the samplers may read through keys[0] (the first segment of a stream's waiting batches)
     const int64_t est_rows = h->segs_active ? (*h->segs_active)[0].nrows : nrows;
     if (nrows <= 0) {
@@ -5545,10 +5600,16 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
     const bool dense_base = (hot || dense_generic) && part_ok && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
                             getenv("VNM_AGG_NO_DENSE") == nullptr;
     bool dense_shape = dense_base && (!h->rank_aligned || h->range_given);   // rank-aligned: only with a code range all ranks agreed on
+    // a batch must bring enough rows for its code range (a final pass over 2^b slots for a handful of rows is all overhead) -- unless a
+    // deferred pass over that very range is waiting anyway: a short batch of a stream then simply joins it (round 4; before, it took
+    // two hash levels -- and, with a nullable key, the general scan)
+    // (evaluated where it is used: plan_dense may only just have set the range)
+    auto span_fits_now = [&]() { return h->dense_span <= 4 * nrows || (h->pending != nullptr && h->dense_state == 1 && memcmp(&h->pending->df.map, &h->dmap, sizeof(DenseMap)) == 0); };
+#define span_fits span_fits_now()
     bool dense_go = false;
     // a stream that went dense on the sample's lower bound (no group count exists) and now brings a batch too short for the
     // code range: this batch and the rest need a number after all (without one they took the LDS scan and its flush storms)
-    if (h->dense_by_bound && h->hint == 0 && !(dense_shape && h->dense_state == 1 && h->dense_span <= 4 * nrows)) {
+    if (h->dense_by_bound && h->hint == 0 && !(dense_shape && h->dense_state == 1 && span_fits)) {
         h->estimated = false;
         h->dense_by_bound = false;
     }
@@ -5560,13 +5621,13 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
         VNM_TRY(estimate_groups(h, keys[0], est_rows, &est, s, dense_shape ? &dense_lb : nullptr));
         if (est == 0) {
             if (h->dense_state == 0) VNM_TRY(plan_dense(h, keys[0], est_rows, s));
-            if (h->dense_state == 1 && h->dense_span <= 32 * dense_lb && h->dense_span <= 4 * nrows) dense_go = true;
+            if (h->dense_state == 1 && h->dense_span <= 32 * dense_lb && span_fits) dense_go = true;
             else VNM_TRY(estimate_groups(h, keys[0], est_rows, &est, s));   // too sparse (or not a code-able key): full estimate
         }
         if (est) { h->hint = est; h->estimated = true; }
         else if (dense_go) { h->estimated = true; h->dense_by_bound = true; }   // later batches of the stream: no sample again
     }
-    if (dense_shape && !dense_go && h->dense_by_bound && h->hint == 0 && h->dense_state == 1 && h->dense_span <= 4 * nrows) dense_go = true;
+    if (dense_shape && !dense_go && h->dense_by_bound && h->hint == 0 && h->dense_state == 1 && span_fits) dense_go = true;
     // rank-aligned operators (multi-GPU) keep hash partitions so that every rank cuts its result the same way -- which only
     // the partition-aligned exchange of LARGE results needs; small results travel by one all-gather and are merged by key
     if (dense_base && h->rank_aligned && h->hint > 0 && h->hint <= env_i64("VNM_ALIGNED_DENSE_MAX", 1 << 19)) dense_shape = true;
@@ -5576,7 +5637,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
             KernelTimer timer("agg_estimate", s);
             VNM_TRY(plan_dense(h, keys[0], est_rows, s));
         }
-        if (h->dense_state == 1 && h->dense_span <= 32 * h->hint && h->dense_span <= 4 * nrows) dense_go = true;
+        if (h->dense_state == 1 && h->dense_span <= 32 * h->hint && span_fits) dense_go = true;
     }
     ulonglong2* spill = nullptr;  // entries the partitioned / dense paths could not place (heavy keys, keys outside the sampled range): aggregated below
     int64_t n_spill = 0;
@@ -5654,7 +5715,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
         bool vn_spill = false;        // the spill lists of the nullable dense path (entries + keys of NULL-value rows)
         bool spill_is_wide = false;   // the spill holds [n][E]-word entries of the wide scatter kernels (not the (key, value) pairs of the hot / dense paths)
         auto run_partitioned = [&]() {
-            if (h->segs_active) return VNM_RC_SINGLY;               // (its kernels read one batch)
+            if (h->segs_active || h->kn_valid) return VNM_RC_SINGLY;   // (its kernels read one batch of plain keys)
             if (h->pending && complete_pending(h, s)) return 1;     // (the hash-partitioned path makes a run of its own)
             if (h->have_run && merge_run_into_table(h, s)) return 1;
             const int r = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
@@ -5729,6 +5790,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
     if (h->segs_active && !a.ent) {   // the waiting batches of a stream as segments of one scan (agg_hot_kernel, the hot shape only)
         if (!(hot_scan && hot) || scan_no_pred || a.has_expr) VNM_SEG_ONLY("general scan");
     }
+    if (h->kn_valid && !a.ent) VNM_SEG_ONLY("scan over the rows");   // (only the dense path's pass 1 reads the key's validity)
     VNM_TRY(ensure_table(h, scan_n, s, spill != nullptr || nspill != nullptr));
     if (hot_scan) a.ntiles = (scan_n + HOT_TILE - 1) / HOT_TILE;
     if (h->segs_active && !a.ent) VNM_TRY(upload_segs(h, HOT_TILE, &a.segs, &a.nseg, &a.ntiles, seg_pool, s));
@@ -5829,6 +5891,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
     return 0;
 }
 
+#undef span_fits
 // The waiting batches of an asynchronous stream (vnm_agg_set_async) -> the device: as the segments of ONE logical batch where the
 // path's kernels take segments (the dense-key path's ring scatter, the hot-shape LDS scan), one by one otherwise.
 static int flush_queue(vnm_agg* h, void* stream) {
@@ -6565,7 +6628,7 @@ int vnm_agg_dense_range(vnm_agg* h, int64_t nrows, const vnm_dcol* key, uint64_t
     VNM_HIP(hipMemcpyAsync(d, init, 16, hipMemcpyHostToDevice, s));
     const int64_t m = std::min<int64_t>(nrows, 1 << 18);
     const int grid = (int)std::min<int64_t>((m + 255) / 256, (int64_t)device_info().num_cus * 4);
-    dense_sample_range_kernel<<<grid, 256, 0, s>>>((const uint64_t*)key->values + key->offset, nrows, m, sign, d);
+    dense_sample_range_kernel<<<grid, 256, 0, s>>>((const uint64_t*)key->values + key->offset, nrows, m, sign, d, nullptr, 0);
     VNM_HIP(hipGetLastError());
     VNM_HIP(hipMemcpyAsync(got, d, 16, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
