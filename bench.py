@@ -633,6 +633,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # VNM_BENCH_SHARED_GPU=1: every rank on cuda:0 with the gloo backend (RCCL refuses two ranks on one device) -- a functional run
+    # of the N-rank code path on a one-GPU box (tests/test_gpu_bench_check.py); never a measurement
+    shared_gpu = os.environ.get("VNM_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # VNM_BENCH_FORCE_EXCHANGE=1 runs the RCCL exchange + merge step with a single rank too (self-test of the
@@ -643,7 +648,10 @@ def main():
         os.environ.setdefault("NCCL_DEBUG", "WARN")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     from vinum_amd import _lib as L
     from vinum_amd import ops
@@ -985,7 +993,7 @@ def main():
             "n_gpus": world, "rccl_ranks": dist.get_world_size() if (world > 1 or force_exchange) else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64/int64", "data": "synthetic",
+            "dtype": "f64/int64", "data": "synthetic" + (" (FUNCTIONAL RUN: all ranks share one GPU over gloo; not a measurement)" if shared_gpu else ""),
             "config": {"workload": workload, "rows_per_gpu": n, "groups": groups if args.workload == "groupby" else None,
                        "selectivity": args.selectivity, "result_rows": int(out_rows),
                        "group_count_hint": "given (vnm_agg_set_hint)" if args.hint else "none: the operator samples the keys (what the reference boundary allows)",

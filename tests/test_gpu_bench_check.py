@@ -68,3 +68,24 @@ def test_bench_check_stream_workload_single_gpu():
     assert j["check"]["survivors_conserved"] and j["check"]["totals_conserved"]
     assert j["check"].get("result_columns_match") is True
     assert j["roofline"]["launches_per_step"] <= 1.0     # ONE launch of the scatter pass over the five waiting batches
+
+
+@pytest.mark.parametrize("ranks,groups,route", [(2, "1e6", "dense_tables"), (3, "7", "allgather_small"), (2, "2e7", "dense_tables")])
+def test_bench_self_launch_ranks_sharing_the_gpu(ranks, groups, route):
+    """The N-rank code path for real ("a 2-process single-GPU-shared ... run of the self-launch path"): `bench.py --gpus N`
+    starts N processes by itself; VNM_BENCH_SHARED_GPU=1 puts every rank on cuda:0 with the gloo backend (RCCL refuses two ranks on one
+    device; device tensors are staged through the host inside the collectives).  configs[3]: every rank streams its own batches,
+    the ranks agree on the group count and the code range, exchange their partial aggregates and --check reduces the properties
+    over all ranks (survivors and totals conserved, no group on two ranks)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VNM_BENCH_SHARED_GPU"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--batches", "3", "--groups", groups, "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-also", "--check"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == ranks and j["rccl_ranks"] == ranks and "configs[3]" in j["config"]["workload"]
+    assert j["check"]["world_size"] == ranks and j["check"]["exchange"] == route, j["check"]
+    assert j["check"]["survivors_conserved"] and j["check"]["totals_conserved"]
+    assert j["value"] > 0 and j["config"]["rows_per_gpu"] == 3 << 24

@@ -21,6 +21,17 @@ import torch.distributed as dist
 _MIX = -7046029254386353131  # 0x9E3779B97F4A7C15 as int64
 
 
+def _all_to_all_single(out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+    """dist.all_to_all_single -- RCCL over xGMI with the `nccl` backend.  With `gloo` (CPU tests; two ranks sharing ONE GPU in
+    tests/test_gpu_bench_check.py, where RCCL refuses two ranks on a device) device tensors are staged through the host."""
+    if out.is_cuda and dist.get_backend(group) == "gloo":
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
+        out.copy_(o)
+        return
+    dist.all_to_all_single(out, inp, output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
+
+
 def owner_of(key_words, world: int) -> torch.Tensor:
     """Owner rank per partial group.  key_words: list of int64 tensors (n_keys value words + null-mask word)."""
     h = torch.zeros_like(key_words[0])
@@ -52,7 +63,7 @@ def exchange(send: torch.Tensor, counts: torch.Tensor, group=None) -> torch.Tens
     world = dist.get_world_size(group)
     ncol = send.shape[1]
     recv_counts = torch.empty_like(counts)
-    dist.all_to_all_single(recv_counts, counts, group=group)
+    _all_to_all_single(recv_counts, counts, group=group)
     sc, rc = counts.tolist(), recv_counts.tolist()
     assert world == len(sc)
     rows_per_round = max(1, _MAX_ELEMS_PER_PEER // ncol)
@@ -67,7 +78,7 @@ def exchange(send: torch.Tensor, counts: torch.Tensor, group=None) -> torch.Tens
         r_off[o] = r_off[o - 1] + rc[o - 1]
     if rounds == 1:
         # flat 1-D buffers with element-count splits: the form both RCCL and gloo accept
-        dist.all_to_all_single(recv.view(-1), send.view(-1), output_split_sizes=[c * ncol for c in rc],
+        _all_to_all_single(recv.view(-1), send.view(-1), output_split_sizes=[c * ncol for c in rc],
                                input_split_sizes=[c * ncol for c in sc], group=group)
         return recv
     for r in range(rounds):
@@ -76,7 +87,7 @@ def exchange(send: torch.Tensor, counts: torch.Tensor, group=None) -> torch.Tens
         r_n = [max(0, min(c - lo, rows_per_round)) for c in rc]
         s_buf = torch.cat([send[s_off[o] + lo: s_off[o] + lo + s_n[o]] for o in range(world)]).contiguous()
         r_buf = torch.empty((sum(r_n), ncol), dtype=send.dtype, device=send.device)
-        dist.all_to_all_single(r_buf.view(-1), s_buf.view(-1), output_split_sizes=[c * ncol for c in r_n],
+        _all_to_all_single(r_buf.view(-1), s_buf.view(-1), output_split_sizes=[c * ncol for c in r_n],
                                input_split_sizes=[c * ncol for c in s_n], group=group)
         pos = 0
         for o in range(world):
@@ -131,11 +142,11 @@ def exchange_partition_aligned(agg, make_merged, device, group=None):
     bounds = [first_partition(o, nfin, world) for o in range(world + 1)]
     nlocal = bounds[rank + 1] - bounds[rank]
     pc_recv = torch.empty(world * nlocal, dtype=torch.int32, device=device)
-    dist.all_to_all_single(pc_recv, pc, output_split_sizes=[nlocal] * world,
+    _all_to_all_single(pc_recv, pc, output_split_sizes=[nlocal] * world,
                            input_split_sizes=[bounds[o + 1] - bounds[o] for o in range(world)], group=group)
     # row offsets of the source blocks inside recv
     rc = torch.empty(world, dtype=torch.int64, device=device)
-    dist.all_to_all_single(rc, torch.tensor(counts, dtype=torch.int64, device=device), group=group)
+    _all_to_all_single(rc, torch.tensor(counts, dtype=torch.int64, device=device), group=group)
     offs = [0]
     for c in rc.tolist():
         offs.append(offs[-1] + c)
@@ -235,7 +246,7 @@ def exchange_dense_tables(table, geometry, merge_slices, group=None):
     biggest = max(bounds[o + 1] - bounds[o] for o in range(world))
     rounds = max(1, -(-(biggest * 2) // _MAX_ELEMS_PER_PEER))
     if rounds == 1:
-        dist.all_to_all_single(recv.view(-1), table.view(-1), output_split_sizes=[nloc * 2] * world,
+        _all_to_all_single(recv.view(-1), table.view(-1), output_split_sizes=[nloc * 2] * world,
                                input_split_sizes=[(bounds[o + 1] - bounds[o]) * 2 for o in range(world)], group=group)
         return merge_slices(recv, bounds[rank], nloc)
     # slices beyond 1 GiB per peer (one or two ranks with a 2^27-slot table): several rounds over sub-ranges of every owner's
@@ -247,7 +258,7 @@ def exchange_dense_tables(table, geometry, merge_slices, group=None):
         r_lo, r_hi = min(r * step, nloc), min((r + 1) * step, nloc)
         send = table[s_lo[0]:s_hi[0]] if world == 1 else torch.cat([table[a:b] for a, b in zip(s_lo, s_hi)])
         rbuf = recv[r_lo:r_hi] if world == 1 else torch.empty((world * (r_hi - r_lo), 2), dtype=torch.int64, device=dev)
-        dist.all_to_all_single(rbuf.view(-1), send.contiguous().view(-1), output_split_sizes=[(r_hi - r_lo) * 2] * world,
+        _all_to_all_single(rbuf.view(-1), send.contiguous().view(-1), output_split_sizes=[(r_hi - r_lo) * 2] * world,
                                input_split_sizes=[(b - a) * 2 for a, b in zip(s_lo, s_hi)], group=group)
         if world > 1:
             for src in range(world):
