@@ -875,6 +875,8 @@ def main():
         return el
 
     elapsed = timed(args.steps, args.warmup)
+    headline_phases = dict(state["phases"]) if "phases" in state else None     # (the `also` cases of a multi-rank run reuse `state`)
+    headline_exchange = state.get("exchange_kind")
 
     check = None
     if args.check and args.workload in ("groupby", "stream") and args.shape == "hot":
@@ -1006,8 +1008,9 @@ def main():
                          "kernels_ms": {k: round(v[0], 4) for k, v in spans.items()},
                          "algorithmic_bytes": alg_bytes,
                          "launches_per_step": cnt.value / max(args.steps, 1)},
-            "exchange_ms_per_step": ({k2: round(v2 / max(args.steps, 1), 3) for k2, v2 in state["phases"].items()}
-                                     if "phases" in state else None),
+            "exchange_ms_per_step": ({k2: round(v2 / max(args.steps, 1), 3) for k2, v2 in headline_phases.items()}
+                                     if headline_phases is not None else None),
+            "exchange": headline_exchange,
         }
         if check is not None:
             result["check"] = check
