@@ -409,7 +409,8 @@ int vnm_strdict_fetch_new(vnm_strdict* h, int32_t* ids_host, int32_t* lens_host,
  * NULL; free with vnm_free_column).  Decimal -> float64 is exact integer arithmetic (correctly rounded, as strtod /
  * fast_float).  fallback[c] = 1: column c holds a field outside the device parser's domain (> 19 significant digits,
  * |decimal exponent| > 19, "nan" / "inf", stray characters): parse that column of this block on the host;
- * fallback[n_cols] = 1: a quote character (quoted fields are not tokenised here); fallback[n_cols + 1] = 1: a row whose
+ * fallback[n_cols] = 1: a row ends inside a quoted field (a newline in a value; quoted fields themselves are tokenised: delimiters
+ * inside quotes do not split, a quoted number is parsed from between its quotes); fallback[n_cols + 1] = 1: a row whose
  * field count differs from n_fields. */
 int vnm_csv_parse_block(const char* host_text, int64_t nbytes, int skip_header, int delimiter, int n_fields, int n_cols,
                         const int* field_idx, const int* types, vnm_dcol* out_cols, int64_t* n_rows, int* fallback,

@@ -205,3 +205,58 @@ def test_empty_lines_are_not_rows(tmp_path, ncol):
     assert got.num_rows == exp.num_rows
     for name in exp.schema.names:
         util.assert_col_equal(got.column(name).combine_chunks(), exp.column(name).combine_chunks(), name)
+
+
+def test_quoted_fields_stay_on_the_device(tmp_path):
+    """Round 4 (the remainder of SURVEY 8 f2 named in VERDICT r03 missing #5, in part): rows with QUOTED fields -- string columns with
+    delimiters inside the quotes, escaped quotes, quoted numbers, quoted empty fields -- are tokenised on the device: the numeric
+    columns of such blocks are parsed there (no whole-block fallback), quoted numbers from between their quotes; equal to
+    pyarrow.csv.read_csv (vinum/io/arrow.py:58-61,106 delegates to it).  A newline INSIDE a quoted value still sends the block to
+    pyarrow."""
+    import ctypes
+    from vinum_amd import _lib as L
+    from vinum_amd.io import stream_csv
+    rng = np.random.default_rng(5)
+    rows = ["id,city,fare,n,note"]
+    for i in range(20_000):
+        city = ['"New York, NY"', 'Berlin', '"say ""hi"", ok"', '""', '"a,b,c,,"', 'plain'][i % 6]
+        fare = [f"{i * 0.125}", f'"{i * 0.5}"', '""', "", f'"{-i}.25"'][i % 5]
+        n = [f"{i}", f'"{i * 7}"'][i % 2]
+        rows.append(f'{i},{city},{fare},{n},"x,{i}"')
+    data = ("\n".join(rows) + "\n").encode()
+    path = os.path.join(tmp_path, "quoted.csv")
+    with open(path, "wb") as f:
+        f.write(data)
+    exp = pacsv.read_csv(io.BytesIO(data), read_options=pacsv.ReadOptions(use_threads=False))
+    assert exp.schema.field("fare").type == pa.float64() and exp.schema.field("n").type == pa.int64()
+    L.lib().vnm_set_profiling(1)
+    got = _read_all(stream_csv(path, block_size=1 << 16))
+    ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+    L.lib().vnm_profile_query(b"csv_parse", ctypes.byref(ms), ctypes.byref(cnt))
+    L.lib().vnm_set_profiling(0)
+    assert cnt.value >= 1                                   # the block went through the device parser
+    assert got.schema == exp.schema
+    for name in exp.schema.names:
+        if pa.types.is_string(exp.schema.field(name).type):
+            assert got.column(name).to_pylist() == exp.column(name).to_pylist(), name
+        else:
+            util.assert_col_equal(got.column(name).combine_chunks(), exp.column(name).combine_chunks(), name)
+    # only the numeric columns: nothing of these blocks is parsed by pyarrow at all
+    got2 = _read_all(stream_csv(path, columns=["fare", "n", "id"], block_size=1 << 16))
+    for name in ("fare", "n", "id"):
+        util.assert_col_equal(got2.column(name).combine_chunks(), exp.column(name).combine_chunks(), name)
+    # a newline inside a quoted value: the device parser declines the block (a row ends inside a quote), pyarrow reads it -- whatever
+    # pyarrow makes of such a file (a table, or ArrowInvalid), this reader makes the same
+    bad = b'a,b\n1,"two\nlines"\n2,x\n'
+    p2 = os.path.join(tmp_path, "bad.csv")
+    with open(p2, "wb") as f:
+        f.write(bad)
+    try:
+        want = pacsv.read_csv(io.BytesIO(bad), read_options=pacsv.ReadOptions(use_threads=False))
+    except pa.ArrowInvalid:
+        want = None
+    if want is None:
+        with pytest.raises(pa.ArrowInvalid):
+            _read_all(stream_csv(p2))
+    else:
+        assert _read_all(stream_csv(p2)).to_pydict() == want.to_pydict()

@@ -6,11 +6,11 @@
 // and staged column by column.  Parity target: pyarrow.csv's defaults (third-party; Arrow's converters are fast_float /
 // from_chars: correctly rounded) -- comma delimiter, first line = header, empty field = NULL, int64 / float64 columns.
 //
-//   csv_count_kernel    newlines per 16 KB slab (+ a flag when a quote character is seen: quoted fields are not handled
-//                       here, the caller reads such a block with pyarrow)
+//   csv_count_kernel    newlines per 16 KB slab
 //   csv_scan_kernel     exclusive scan of the slab counts (one workgroup)
 //   csv_offsets_kernel  row start offsets (ballot ranks inside the slab)
-//   csv_parse_kernel    one lane per row: walk the fields, parse the selected ones
+//   csv_parse_kernel    one lane per row: walk the fields (quoted fields: delimiters inside quotes do not split, round 4), parse
+//                       the selected ones
 //
 // Decimal -> float64 is EXACT integer arithmetic, not floating point: a field is (sign, w, q) with w < 2^64 the significant
 // digits (at most 19) and q the decimal exponent; q >= 0: the 128-bit product w * 10^q rounded to 53 bits (half to even);
@@ -34,7 +34,7 @@ struct CsvArgs {
     uint32_t* slab_counts;            // newlines per slab, then their exclusive prefix
     int64_t nslabs;
     int64_t* row_start;               // [nrows + 1]
-    unsigned long long* flags;        // [0] quote seen  [1 + c] column c needs the host parser  [20] malformed row (field count)
+    unsigned long long* flags;        // [0] a row ends inside a quoted field  [1 + c] column c needs the host parser  [20] malformed row (field count)  [21] a quote was seen
     uint8_t delim;
     int n_fields;                     // fields per row (from the header)
     int n_cols;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void csv_count_kernel(CsvArgs a) {
     for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
     __shared__ uint32_t sc[4];
     if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = c;
-    if (__ballot(quote) && (threadIdx.x & 63) == 0) a.flags[0] = 1;
+    if (__ballot(quote) && (threadIdx.x & 63) == 0) a.flags[21] = 1;   // (statistics only: quoted fields are handled by csv_parse_kernel)
     __syncthreads();
     if (threadIdx.x == 0) a.slab_counts[blockIdx.x] = sc[0] + sc[1] + sc[2] + sc[3];
 }
@@ -268,11 +268,30 @@ __global__ __launch_bounds__(256) void csv_parse_kernel(CsvArgs a) {
         const uint8_t* p = a.text + lo;
         const int len = (int)(hi - lo);
         int field = 0, fstart = 0, c = 0;
+        // QUOTED fields (round 4; pyarrow.csv defaults: quote_char '"', double_quote, newlines_in_values = False): a field that STARTS
+        // with a quote runs to its closing quote -- delimiters inside it do not split the row, "" is a literal quote -- so rows with
+        // quoted string columns ("New York, NY") keep their numeric columns on the device.  A selected numeric field that is quoted
+        // is parsed from between its quotes; one with an escaped quote, or with text behind the closing quote, goes to the host
+        // parser; a row that ends inside a quote (a newline in a value) sends the block there.
+        bool inq = false, quoted = false, weird = false;   // inside quotes; this field began with a quote; escapes / trailing text
+        int qend = -1;                                     // index of the closing quote of this field
         for (int i = 0; i <= len; i++) {
-            if (i == len || p[i] == a.delim) {
+            const uint32_t ch = i < len ? p[i] : 0u;
+            if (i < len && inq) {
+                if (ch == '"') {
+                    if (i + 1 < len && p[i + 1] == '"') { weird = true; i++; }      // "" inside quotes
+                    else { inq = false; qend = i; }
+                }
+                continue;
+            }
+            if (i < len && i == fstart && ch == '"') { inq = true; quoted = true; continue; }
+            if (i == len || ch == a.delim) {
                 if (c < a.n_cols && field == a.field_of[c]) {
                     uint64_t bits = 0;
-                    const int rc = csv_parse_field(p + fstart, i - fstart, a.type_of[c], &bits);
+                    int rc;
+                    if (!quoted) rc = csv_parse_field(p + fstart, i - fstart, a.type_of[c], &bits);
+                    else if (weird || qend != i - 1) rc = 2;
+                    else rc = csv_parse_field(p + fstart + 1, qend - fstart - 1, a.type_of[c], &bits);   // ("" -> NULL, as pyarrow's quoted_strings_can_be_null)
                     if (rc == 2) a.flags[1 + c] = 1;
                     ((uint64_t*)a.out_values[c])[r] = bits;
                     a.out_valid[c][r] = rc == 0;
@@ -280,8 +299,10 @@ __global__ __launch_bounds__(256) void csv_parse_kernel(CsvArgs a) {
                 }
                 field++;
                 fstart = i + 1;
+                quoted = false; weird = false; qend = -1;
             }
         }
+        if (inq) a.flags[0] = 1;      // the row ended inside a quoted field
         // ragged row: pyarrow raises on it, so does the caller.  An EMPTY line is not a row at all for pyarrow (ignore_empty_lines):
         // it is flagged the same way even in a one-column file, so that the block takes pyarrow's row count.
         if (field != a.n_fields || len == 0) a.flags[20] = 1;
@@ -386,7 +407,7 @@ int vnm_csv_parse_block(const char* host_text, int64_t nbytes, int skip_header, 
     VNM_HIP(hipMemcpyAsync(fl, a.flags, sizeof(fl), hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
     for (int c = 0; c < n_cols; c++) fallback[c] = fl[1 + c] != 0;
-    fallback[n_cols] = fl[0] != 0;        // a quote character: the whole block needs the host reader
+    fallback[n_cols] = fl[0] != 0;        // a row ends inside a quoted field (a newline in a value): the whole block needs the host reader
     fallback[n_cols + 1] = fl[20] != 0;   // a row with a different number of fields
     cleanup.keep_out = true;
     sync_guard.ok = true;     // (the flags read-back above synchronised the stream)

@@ -6,8 +6,10 @@ thin wrappers around pyarrow.csv.open_csv / read_csv and parse on one CPU core.
 `DeviceRecordBatch`es whose numeric columns were never Arrow arrays in host memory.  The schema (names, which columns are
 int64 / float64) comes from pyarrow's own type inference over the first block, as `pyarrow.csv.open_csv` does it.  Only the
 columns the query needs are parsed.  What the device parser does not handle is handed to pyarrow for that block: non-numeric
-columns (strings, timestamps: dictionary-encoded as usual afterwards), blocks containing quote characters, fields outside
-the exact parser's domain ("nan", > 19 significant digits, ...) -- per column and per block, never silently guessed.
+columns (strings, timestamps: dictionary-encoded as usual afterwards), fields outside the exact parser's domain ("nan", > 19
+significant digits, a quoted number with an escaped quote ...) -- per column and per block, never silently guessed.  Quoted fields are
+handled on the device since round 4 (delimiters inside quotes do not split a row); only a row that ENDS inside a quote (a newline
+in a value) sends its block to pyarrow.
 """
 import ctypes
 import io
@@ -145,7 +147,7 @@ class GpuCsvReader:
             fb = (ctypes.c_int * (k + 2))()
             L.check(lib.vnm_csv_parse_block(text_ptr, length, 0, ord(","), len(self._names), k, fidx, types, out, ctypes.byref(n_rows), fb, None))
             owned = [_OwnedColumn(out[i], self.schema.field(n).type) for i, n in enumerate(chunk)]
-            if fb[k] or fb[k + 1]:          # quotes / ragged or empty rows: the whole block goes through pyarrow (which raises on ragged rows)
+            if fb[k] or fb[k + 1]:          # a newline inside a quoted value / ragged or empty rows: the whole block goes through pyarrow (which raises on ragged rows)
                 whole_block_on_host = True
                 break
             assert nrows is None or nrows == n_rows.value
