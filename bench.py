@@ -740,10 +740,12 @@ def main():
             parts = cur["parts"]
             if dist_mode:
                 from vinum_amd import distributed as D
-                if not args.hint:
-                    D.agree_on_group_count(agg, parts[0][0], B, device, stream=stream)
+                # the ranks agree on ONE group-count estimate and ONE key range (a single all_gather): every operator then cuts its
+                # result the same way and the dense path's tables are slot-compatible
                 if os.environ.get("VNM_BENCH_EXCHANGE", "dense") == "dense":
-                    D.agree_on_dense_range(agg, parts[0][0], B, device, stream=stream)
+                    D.agree_on_groups_and_range(agg, parts[0][0], B, device, stream=stream, estimate=not args.hint)
+                elif not args.hint:
+                    D.agree_on_group_count(agg, parts[0][0], B, device, stream=stream)
             for kc_, vc_ in parts:
                 agg.next([kc_], [vc_, vc_], pred=vc_, nrows=B, stream=stream)
             if dist_mode:
@@ -1017,7 +1019,9 @@ def main():
             "config": {"workload": workload, "rows_per_gpu": n, "groups": groups if args.workload == "groupby" else None,
                        "selectivity": args.selectivity, "result_rows": int(out_rows),
                        "group_count_hint": "given (vnm_agg_set_hint)" if args.hint else "none: the operator samples the keys (what the reference boundary allows)",
-                       "parallelism": f"batch-sharded x{world}" + (", RCCL all_to_all partial-aggregate exchange" if world > 1 else "")},
+                       "parallelism": f"batch-sharded x{world}" + (", RCCL all_to_all partial-aggregate exchange" if world > 1 else ""),
+                       "scaling_reference": ("the SAME workload on one GPU is also['configs[3] one-GPU leg, G=1e6'] of the --gpus 1 line "
+                                             "(its default workload is configs[2], one 1e9-row batch at G = 1e8)") if args.workload == "stream" and world > 1 else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,

@@ -181,6 +181,12 @@ def _worker_dense(rank, world, port, tmp, bits, mismatch, max_elems=0):
     # a rank without a range switches it off for everybody
     fake2 = _FakeRangeAgg(1, 0) if rank == world - 1 else _FakeRangeAgg(5, 10)
     assert D.agree_on_dense_range(fake2, None, 10, torch.device("cpu")) is None and fake2.got == (1, 0)
+    # ... and the fused agreement (estimate + range in ONE all_gather): MAX of the estimates as the hint, the same range rule
+    fake3 = _FakeRangeAgg(*ranges[rank])
+    fake3.estimate_groups = lambda key, nrows, stream=None: 1000 * (rank + 1)
+    fake3.set_hint = lambda g: setattr(fake3, "hint", g)
+    est, rng_ = D.agree_on_groups_and_range(fake3, None, 10, torch.device("cpu"))
+    assert est == 1000 * world and fake3.hint == est and rng_ == exp and fake3.got == exp
     # 2. the exchange: per-rank tables over `bits` bits of code
     rng = np.random.default_rng(50 + rank)
     nslots = 1 << bits

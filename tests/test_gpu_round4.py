@@ -354,3 +354,59 @@ def test_nullable_key_through_the_dense_path(route, pred, hint, monkeypatch):
     util.assert_agg_equal(got, exp, funcs, ["k"], what=f"nullable key, {route}, pred {pred}, hint {hint}")
     if route.startswith("dense"):
         assert got.column(0)[got.num_rows - 1].as_py() is None    # the NULL group comes last, as in the reference's single-key operator
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS", "64")))))
+def test_random_round4_paths_vs_oracle(seed, monkeypatch):
+    """Seeded differential test over what round 4 added to the hot shape, in combination: nullable keys (garbage under the NULLs) through
+    the dense path's pass 1, stream mode (segments of one launch) against synchronous calls, skewed keys whose spills are folded into
+    the fused result columns, the 32-partition geometry of small ranges, short batches joining a pending pass, empty and ragged
+    batches.  Result columns finalised on the device and the host finaliser over the partial state must both equal the oracle."""
+    from oracle import oracle as O
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    rng = np.random.default_rng(77_000 + seed)
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", str(int(rng.choice([50_000, 100_000]))))
+    groups = int(rng.choice([7, 900, 6_000, 12_000, 28_000, 60_000, 400_000, 1_500_000]))
+    if rng.random() < 0.3:
+        monkeypatch.setenv("VNM_DENSE_ONE_LEVEL", "0")
+    nb = int(rng.choice([1, 2, 3, 5]))
+    sizes = [int(rng.choice([0, 77, 8192, 120_001, 300_000, 700_000])) for _ in range(nb)]
+    sizes[0] = int(rng.choice([250_000, 600_000, 900_001]))
+    nullable_key = rng.random() < 0.45
+    skew = rng.random() < 0.35
+    lo = int(rng.choice([0, -groups // 2, 10**11]))
+    stream_mode = bool(rng.random() < 0.5)
+    batches = []
+    for n in sizes:
+        u = rng.random(n)
+        k = (np.floor((u ** 4 if skew else u) * groups)).astype(np.int64) + lo
+        mask = None
+        if nullable_key and n:
+            mask = rng.random(n) < rng.choice([0.02, 0.3])
+            k[mask] = rng.integers(-2**50, 2**50, int(mask.sum()))
+        batches.append(pa.RecordBatch.from_pydict({
+            "k": pa.array(k, mask=mask) if n else pa.array([], pa.int64()),
+            "v": pa.array(rng.integers(-2**13, 2**13, n).astype(np.float64) / 128.0),
+            "p": pa.array(rng.integers(0, 2**12, n).astype(np.float64) / 64.0)}))
+    funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.COUNT, "v", "c"), (O.COUNT_STAR, "", "n")]
+    funcs = [funcs[i] for i in sorted(rng.choice(4, size=int(rng.integers(1, 5)), replace=False))]
+    if not any(f[1] for f in funcs):
+        funcs.append((O.SUM, "v", "s"))
+    predicate = [("v", ">", 3.0), ("p", ">", 20.0), None][int(rng.integers(0, 3))]
+    hint = int(rng.choice([0, 0, groups]))
+    names = ["k", "v", "p"]
+    fspec = [(f, names.index(col) if col else None, pa.float64() if col else None) for f, col, _ in funcs]
+    agg = ops.DeviceAggregate(O.SINGLE, [pa.int64()], fspec, expected_groups=hint, stream_mode=stream_mode)
+    if predicate:
+        agg.set_predicate(predicate[1], predicate[2])
+    for b in batches:
+        kc, vc, pc = (DeviceColumn.from_arrow(b.column(j)) for j in range(3))
+        agg.next([kc], [vc if col else None for _, col, _ in funcs], pred={"v": vc, "p": pc}[predicate[0]] if predicate else None, nrows=b.num_rows)
+    what = f"seed {seed}: G~{groups} lo={lo} nullable_key={nullable_key} skew={skew} stream={stream_mode} hint={hint} pred={predicate} sizes={sizes}"
+    dcols = agg.result_device([0])
+    res = agg.result_arrays([0], ["k"], [f[2] for f in funcs])
+    dev = pa.RecordBatch.from_arrays([c.to_arrow() for c in dcols], names=res.schema.names)
+    util.assert_batches_equal(dev, res, key_names=["k"], what=what + ": device result columns vs host finalisation")
+    agg.close()
+    util.assert_agg_equal(res, _oracle(O.SINGLE, ["k"], funcs, batches, predicate), funcs, ["k"], what=what)

@@ -214,6 +214,31 @@ def agree_on_dense_range(agg, key, nrows, device, group=None, stream=None):
     return lo, hi
 
 
+def agree_on_groups_and_range(agg, key, nrows, device, group=None, stream=None, estimate=True):
+    """agree_on_group_count + agree_on_dense_range with ONE collective (round 4): every rank contributes (estimate, range ok, lo, hi)
+    to one all_gather -- a step of a stream pays the latency of an agreement once, not twice (two collectives plus their host
+    round trips were ~0.3 ms of a 7.4 ms step at G = 1e6).  estimate = False: the caller gave a hint, only the range is agreed on.
+    Returns (estimate or 0, (lo, hi) or None)."""
+    world = dist.get_world_size(group)
+    est = agg.estimate_groups(key, nrows, stream=stream) if estimate else 0
+    lo, hi = agg.dense_range(key, nrows, stream=stream)
+    ok = 1 if lo <= hi else 0
+    t = torch.tensor([est, ok, _u64_to_ordered_i64(lo), _u64_to_ordered_i64(hi)], dtype=torch.int64, device=device)
+    allt = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allt, t, group=group)
+    rows = [x.tolist() for x in allt]
+    est = max(r[0] for r in rows)
+    if estimate and est > 0:
+        agg.set_hint(est)
+    if not all(r[1] for r in rows):
+        agg.set_dense_range(1, 0)
+        return est, None
+    lo = _ordered_i64_to_u64(min(r[2] for r in rows))
+    hi = _ordered_i64_to_u64(max(r[3] for r in rows))
+    agg.set_dense_range(lo, hi)
+    return est, (lo, hi)
+
+
 def table_bounds(nslots: int, world: int):
     """Owner o holds the slots (= scrambled key codes) [bounds[o], bounds[o + 1])."""
     return [o * nslots // world for o in range(world + 1)]
