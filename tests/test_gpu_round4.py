@@ -410,3 +410,37 @@ def test_random_round4_paths_vs_oracle(seed, monkeypatch):
     util.assert_batches_equal(dev, res, key_names=["k"], what=what + ": device result columns vs host finalisation")
     agg.close()
     util.assert_agg_equal(res, _oracle(O.SINGLE, ["k"], funcs, batches, predicate), funcs, ["k"], what=what)
+
+
+@pytest.mark.parametrize("program", ["sum_sum", "sum_avg_counts", "avg_only_second"])
+@pytest.mark.parametrize("pred", ["on_first", "on_other", "none"])
+@pytest.mark.parametrize("groups,levels", [(1_500_000, "default"), (3_000_000, "default"), (1_200_000, "sample_misses"), (1_400_000, "two_batches")])
+def test_dense_path_two_input_columns(program, pred, groups, levels, monkeypatch):
+    """`SELECT k, sum(a), sum(b) ...` over two plain float64 columns on the dense path -- two-value entries through the ring
+    scatter (dring_scatter_kernel<V2>) and a final pass with two compensated sums per slot (dpart_final2_kernel) -- bit-exact
+    against the oracle; a key the range sample never saw fails the pass (no spill buffer for two-value entries) and the batch
+    takes the hash partitions: same result.  agg_func_factory.cpp:108-176 (one accumulator per function and column)."""
+    from oracle import oracle as O
+    from vinum_amd import _lib as L
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(groups % 1000 + len(program) + len(pred))
+    n = 2_200_000
+    k = rng.integers(0, groups, n).astype(np.int64) - groups // 5
+    if levels == "sample_misses":
+        k[7::200_003] = 90_000_000
+    t = pa.table({"k": pa.array(k), "a": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0),
+                  "b": pa.array(rng.integers(-2**13, 2**13, n).astype(np.float64) / 64.0),
+                  "p": pa.array(rng.integers(0, 2**12, n).astype(np.float64) / 64.0)})
+    funcs = {"sum_sum": [(O.SUM, "a", "sa"), (O.SUM, "b", "sb")],
+             "sum_avg_counts": [(O.SUM, "a", "sa"), (O.AVG, "b", "ab"), (O.COUNT, "a", "ca"), (O.COUNT, "b", "cb"), (O.COUNT_STAR, "", "n")],
+             "avg_only_second": [(O.COUNT, "a", "ca"), (O.AVG, "b", "ab")]}[program]
+    predicate = {"on_first": ("a", ">", 64.0), "on_other": ("p", ">", 20.0), "none": None}[pred]
+    bl = util.sliced_batches(t, n if levels != "two_batches" else 1_200_000)
+    L.lib().vnm_set_profiling(1)
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, bl, predicate=predicate)
+    p1, p2 = _launches(b"agg_part_scatter1"), _launches(b"agg_part_scatter2")
+    L.lib().vnm_set_profiling(0)
+    if levels == "default":
+        assert p1 == 1 and p2 == 1, (p1, p2)      # the two-value dense path took the batch (two scatter levels, one launch each)
+    util.assert_agg_equal(got, _oracle(O.SINGLE, ["k"], funcs, bl, predicate), funcs, ["k"], exact_float_inputs=("a", "b"),
+                          what=f"two columns, {program}, pred {pred}, G={groups} {levels}")

@@ -4641,6 +4641,123 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     return 0;
 }
 
+
+// The dense-key path for TWO plain float64 input columns (round 4): `SELECT k, sum(a), sum(b) [, avg, count ...]` used
+// to take the hash partitions' wide entries (24-byte entries through two tile-sorting levels and LDS hash tables: 24 ms per 5e8 rows
+// at G = 1e8).  Here the entry is (value 1, value 2, code remainder) -- 20 bytes after pass 1, 18 after pass 2 -- through the ring
+// scatter (dring_scatter_kernel<..., V2>: a second ring array, 32-48 entries per ring in 148 KB of LDS) and a direct-addressed
+// final pass with two compensated sums per slot (dpart_final2_kernel).  Ranges of 2^21 .. 2^27 codes; no spill buffer: an entry
+// without a place (a key outside the sampled range, a full region) fails the pass and the batch takes the hash partitions.
+// returns 0 = done (run stored), 2 = not applicable / failed, 1 = error
+int dense_two_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_t s) {
+    const int cus = device_info().num_cus;
+    const DenseMap& mp = h->dmap;
+    int tb = 11;
+    if (mp.bits - tb > 15) tb = 12;
+    const int pbits = mp.bits - tb;
+    if (pbits > 15 || pbits < 10 || a.has_expr) return 2;
+    const int p2 = std::min(8, (pbits + 1) / 2), p1 = pbits - p2;      // (pass 1 moves the 20-byte entries: at most 128 rings of them fit)
+    if (p1 > 7 || p1 < 5) return 2;
+    const int np1 = 1 << p1, np2 = 1 << p2;
+    const int64_t tile1 = PT_TILE;
+    const int grid1 = (int)std::min<int64_t>((int64_t)cus * 2, (nrows + tile1 - 1) / tile1);
+    int split2 = std::max(2, (grid1 + PT_MAX_REGIONS - 1) / PT_MAX_REGIONS);
+    split2 = std::max(split2, std::min(grid1, (cus * 2 + np1 - 1) / np1));
+    const int64_t tiles_per_wg = ((nrows + tile1 - 1) / tile1 + grid1 - 1) / grid1;
+    const int64_t rows_per_wg = tiles_per_wg * tile1;
+    int64_t cap1 = ((rows_per_wg / np1 + rows_per_wg / np1 / 5 + 512) + 15) & ~15LL;
+    if (((cap1 / 16) & 1) == 0) cap1 += 16;
+    const int64_t per_pg = (int64_t)grid1 * rows_per_wg / np1 / split2;
+    int64_t cap2 = ((per_pg / np2 + per_pg / np2 / 4 + 256) + 15) & ~15LL;
+    if (((cap2 / 16) & 1) == 0) cap2 += 16;
+    const int64_t nfinal = (int64_t)1 << pbits;
+    const int64_t dstride = std::min<int64_t>(h->dense_span, nrows) + 2;
+    PoolScope pool;
+    unsigned long long* flags = (unsigned long long*)pool.take(64);
+    double* v1 = (double*)pool.take((size_t)np1 * grid1 * cap1 * 8);
+    double* w1 = (double*)pool.take((size_t)np1 * grid1 * cap1 * 8);
+    uint32_t* c1 = (uint32_t*)pool.take((size_t)np1 * grid1 * cap1 * 4);
+    uint32_t* n1 = (uint32_t*)pool.take((size_t)np1 * grid1 * 4);
+    double* v2 = (double*)pool.take((size_t)np1 * np2 * split2 * cap2 * 8);
+    double* w2 = (double*)pool.take((size_t)np1 * np2 * split2 * cap2 * 8);
+    uint16_t* c2 = (uint16_t*)pool.take((size_t)np1 * np2 * split2 * cap2 * 2);
+    uint32_t* n2 = (uint32_t*)pool.take((size_t)np1 * np2 * split2 * 4);
+    uint64_t* rk = (uint64_t*)pool.take((size_t)dstride * 8 * 2);
+    uint64_t* ra = (uint64_t*)pool.take((size_t)dstride * 8 * h->plan.n_words);
+    if (!flags || !v1 || !w1 || !c1 || !n1 || !v2 || !w2 || !c2 || !n2 || !rk || !ra) return 1;
+    VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
+    const int lds_budget = (int)env_i64("VNM_DENSE_RING_LDS2", 148) * 1024;
+    auto ring_cap = [&](int np, int esize) { return std::min(80, lds_budget / (np * esize) / DR_FB * DR_FB); };
+    const int rcap1 = ring_cap(np1, 20), rcap2 = ring_cap(np2, 18);
+    if (rcap1 < 2 * DR_FB || rcap2 < 2 * DR_FB) return 2;
+    DPartArgs d1{};
+    d1.map = mp;
+    d1.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
+    d1.vp = (const double*)a.cols[0].values + a.cols[0].offset;
+    d1.vp2 = (const double*)a.cols[1].values + a.cols[1].offset;
+    d1.pp = h->pred_set ? (const double*)a.pred.values + a.pred.offset : nullptr;
+    d1.has_pred = h->pred_set; d1.pred_is_v = a.hot_pred_is_v; d1.op = a.p.op; d1.thr = a.p.dval;
+    d1.nrows = nrows;
+    d1.out_vals = v1; d1.out_vals2 = w1; d1.out_codes = c1; d1.out_counts = n1; d1.out_cap = cap1;
+    d1.nparts = np1; d1.out_bits = mp.bits - p1;
+    d1.nt_store = 1;
+    d1.flags = flags; d1.spill = nullptr; d1.spill_cap = 0;
+#define VNM_DRING2(FR_, CT_, PR_, PV_, GRID_, ARGS_, CAP_)                                                                       \
+    do {                                                                                                                        \
+        const size_t lds_ = (((size_t)(ARGS_).nparts * (CAP_) * (16 + sizeof(CT_))) + 15) & ~(size_t)15;                         \
+        VNM_HIP(hipFuncSetAttribute((const void*)dring_scatter_kernel<FR_, CT_, true, 1024, PR_, PV_, false, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+        dring_scatter_kernel<FR_, CT_, true, 1024, PR_, PV_, false, 0, false, false, true><<<GRID_, 1024, lds_, s>>>(ARGS_, CAP_); \
+    } while (0)
+    {
+        KernelTimer timer("agg_part_scatter1", s);
+        const bool pv = h->pred_set && !a.hot_pred_is_v;
+        const bool two_pairs = 2 * 2 * 1024 <= np1 * (rcap1 - DR_FB);
+        if (pv) { if (two_pairs) VNM_DRING2(true, uint32_t, 2, true, grid1, d1, rcap1); else VNM_DRING2(true, uint32_t, 1, true, grid1, d1, rcap1); }
+        else { if (two_pairs) VNM_DRING2(true, uint32_t, 2, false, grid1, d1, rcap1); else VNM_DRING2(true, uint32_t, 1, false, grid1, d1, rcap1); }
+    }
+    VNM_HIP(hipGetLastError());
+    DPartArgs d2{};
+    d2.map = mp;
+    d2.in_vals = v1; d2.in_vals2 = w1; d2.in_codes = c1; d2.in_counts = n1; d2.in_cap = cap1;
+    d2.in_regions = grid1; d2.in_split = split2; d2.in_bits = mp.bits - p1;
+    d2.in_pstride = grid1; d2.in_rstride = 1;
+    d2.out_vals = v2; d2.out_vals2 = w2; d2.out_codes = c2; d2.out_counts = n2; d2.out_cap = cap2;
+    d2.nparts = np2; d2.out_bits = tb;
+    d2.flags = flags; d2.spill = nullptr; d2.spill_cap = 0;
+    {
+        KernelTimer timer("agg_part_scatter2", s);
+        if (2 * 2 * 1024 <= np2 * (rcap2 - DR_FB)) VNM_DRING2(false, uint16_t, 2, false, np1 * split2, d2, rcap2);
+        else VNM_DRING2(false, uint16_t, 1, false, np1 * split2, d2, rcap2);
+    }
+#undef VNM_DRING2
+    VNM_HIP(hipGetLastError());
+    DFinalArgs df{};
+    df.map = mp;
+    df.vals = v2; df.vals2 = w2; df.codes = c2; df.counts = n2; df.cap = cap2; df.regions = split2; df.nfinal = nfinal;
+    df.pstride = split2; df.rstride = 1;
+    df.w_rows = a.hot_w[A_COUNT_ROWS];
+    df.w_valid = a.hot_w[A_COUNT_VALID]; df.w_sum = a.hot_w[A_SUM_F64]; df.w_lo = a.hot_comp && df.w_sum >= 0 ? df.w_sum + 1 : -1;
+    df.w_valid2 = a.hot_w2[A_COUNT_VALID]; df.w_sum2 = a.hot_w2[A_SUM_F64]; df.w_lo2 = a.hot_comp && df.w_sum2 >= 0 ? df.w_sum2 + 1 : -1;
+    df.dkey = rk; df.dacc = ra; df.dstride = dstride; df.flags = flags;
+    {
+        KernelTimer timer("agg_part_final", s);
+        if (tb == 11) dpart_final2_kernel<uint16_t, 11><<<(int)std::min<int64_t>(nfinal, (int64_t)cus * 2), 512, 0, s>>>(df);
+        else dpart_final2_kernel<uint16_t, 12><<<(int)std::min<int64_t>(nfinal, (int64_t)cus), 1024, 0, s>>>(df);
+    }
+    VNM_HIP(hipGetLastError());
+    unsigned long long fl[2] = {0, 0};
+    VNM_HIP(hipMemcpyAsync(fl, flags, 16, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    if (getenv("VNM_AGG_TRACE"))
+        fprintf(stderr, "[agg] dense, two columns: bits %d tb %d p1 %d p2 %d rings %d / %d -> fail %llu groups %llu\n", mp.bits, tb, p1, p2, rcap1, rcap2, fl[0], fl[1]);
+    if (fl[0]) return 2;
+    pool.keep(rk); pool.keep(ra);
+    h->run_key = rk; h->run_acc = ra; h->run_stride = dstride; h->run_n = (int64_t)fl[1];
+    h->run_dir = nullptr; h->run_nfin = 0;
+    h->have_run = true;
+    return 0;
+}
+
 }  // namespace
 
 // fold a pending run into the HBM table (needed as soon as a second source of groups shows up)
@@ -5597,7 +5714,14 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
     const bool vn_fold = dense_vn && hot_prog && h->pred_set && a.hot_pred_is_v && getenv("VNM_AGG_NO_VN_FOLD") == nullptr;
     const bool dense_generic = ((!hot && narrow_generic && hot_scan && !hot_two && !hot_vnull && !a.has_expr) || dense_vn) &&
                                getenv("VNM_AGG_NO_DENSE_GENERIC") == nullptr && getenv("VNM_AGG_NO_SPILL") == nullptr;
-    const bool dense_base = (hot || dense_generic) && part_ok && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
+    // ... and TWO plain float64 input columns under {COUNT(*), COUNT, SUM, AVG} (dense_two_aggregate: two-value entries)
+    bool dense_two = hot_scan && hot_two && !a.has_expr && !h->rank_aligned && !h->segs_active && !h->kn_valid && a.hot_vtype == VNM_F64 && a.hot_vtype2 == VNM_F64 &&
+                     getenv("VNM_AGG_NO_DENSE_TWO") == nullptr;
+    for (int o = 0; o < h->plan.n_ops && dense_two; o++) {
+        const int k = h->plan.ops[o].kind;
+        dense_two = k == A_COUNT_ROWS || k == A_COUNT_VALID || k == A_SUM_F64;
+    }
+    const bool dense_base = (hot || dense_generic || dense_two) && part_ok && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) &&
                             getenv("VNM_AGG_NO_DENSE") == nullptr;
     bool dense_shape = dense_base && (!h->rank_aligned || h->range_given);   // rank-aligned: only with a code range all ranks agreed on
     // a batch must bring enough rows for its code range (a final pass over 2^b slots for a handful of rows is all overhead) -- unless a
@@ -5670,7 +5794,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
     // a few hundred to a few thousand groups in a small key range: the direct-addressed LDS scan (vnm_agg_dense.inc)
     bool dscan_done = false;
     bool dscan_stream = false;   // the batch went into the stream table (h->scan_pending)
-    if (dense_shape && !dense_go && h->hint >= env_i64("VNM_DSCAN_MIN_GROUPS", 128) && h->hint <= (1 << DP_TBITS_MAX) &&
+    if (dense_shape && !dense_go && !dense_two && h->hint >= env_i64("VNM_DSCAN_MIN_GROUPS", 128) && h->hint <= (1 << DP_TBITS_MAX) &&
         getenv("VNM_AGG_NO_DSCAN") == nullptr) {
         if (h->dense_state == 0) {
             KernelTimer timer("agg_estimate", s);
@@ -5722,7 +5846,18 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
             spill_is_wide = r == 0 && spill != nullptr && a.part_wide != 0;
             return r;
         };
-        if (dense_go && (h->hint > part_min || h->hint == 0)) {
+        if (dense_go && dense_two && (h->hint > part_min || h->hint == 0)) {
+            if (h->pending && complete_pending(h, s)) return 1;     // (this path makes a run of its own)
+            if (h->have_run && merge_run_into_table(h, s)) return 1;
+            prc = dense_two_aggregate(h, a, nrows, s);
+            if (prc == 2) h->dense_state = -1;                      // (a key outside the range, a full region, a range it does not take: not again)
+            if (prc == 2 && h->hint == 0) {
+                int64_t est = 0;
+                VNM_TRY(estimate_groups(h, keys[0], est_rows, &est, s));
+                h->hint = est;
+                h->estimated = true;
+            }
+        } else if (dense_go && (h->hint > part_min || h->hint == 0)) {
             prc = dense_partitioned_aggregate(h, a, nrows, s, &spill, &n_spill, dense_generic && !vn_fold, &nspill, &n_nspill, vn_fold);
             vn_spill = prc == 0 && dense_vn && (spill || nspill);
             if (prc == 2 && h->hint == 0) {  // the dense attempt failed before G was ever estimated
