@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--check", action="store_true",
                     help="after the timed region: property-check the (merged) group-by result of the last step on the device -- "
                          "survivors and totals conserved across all ranks, every merged key owned by exactly one rank")
+    ap.add_argument("--no-check", action="store_true", help="skip the property check of the last step's result")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--hint", action="store_true",
                     help="tell the operator the group count (vnm_agg_set_hint).  The reference's operator boundary has no such "
@@ -258,7 +259,7 @@ def cpu_baseline_all_cores(args, x_thr, use_ref):
                       f"(range partition, merge not timed); wall {wall:.1f} s incl. process start"}
 
 
-def check_groupby(torch, dist, state, k, v, x_thr, world, rank, device, exchanged):
+def check_groupby(torch, dist, state, k, v, x_thr, world, rank, device, exchanged, strict=True):
     """Size-independent properties of the LAST step's result, evaluated on the device and reduced over all ranks
     (the data is quantised, so the float sums are exact): survivors conserved, totals conserved, no key on two ranks."""
     from vinum_amd import _lib as L
@@ -301,7 +302,9 @@ def check_groupby(torch, dist, state, k, v, x_thr, world, rank, device, exchange
         o1, o2 = torch.argsort(rk), torch.argsort(keys)
         ok["result_columns_match"] = bool(ck.length == n and torch.equal(rk[o1], keys[o2]) and torch.equal(rs[o1], sm[o2])
                                           and torch.equal(ra[o1], sm[o2] / cnt[o2].to(torch.float64)))
-    assert all(val for key, val in ok.items() if isinstance(val, bool)), f"multi-GPU result check failed: {ok}"
+    ok["ok"] = all(val for key, val in ok.items() if isinstance(val, bool))
+    if strict:
+        assert ok["ok"], f"multi-GPU result check failed: {ok}"
     return ok
 
 
@@ -899,8 +902,19 @@ def main():
     headline_exchange = state.get("exchange_kind")
 
     check = None
-    if args.check and args.workload in ("groupby", "stream") and args.shape == "hot":
-        check = check_groupby(torch, dist, state, k, v, x_thr, world, rank, device, force_exchange)
+    # The property check of the LAST step's result (after the timed region, on the device, reduced over all ranks) is part of every
+    # hot-shape line: survivors and totals conserved, (one GPU) the result columns equal to the operator's partial state.
+    # --check: a failed property aborts the run; otherwise it is reported in the line ("ok": false).  --no-check skips it.
+    if not args.no_check and args.workload in ("groupby", "stream") and args.shape == "hot":
+        try:
+            check = check_groupby(torch, dist, state, k, v, x_thr, world, rank, device, force_exchange, strict=bool(args.check))
+        except AssertionError:
+            raise
+        except Exception as e:      # noqa: BLE001 -- (out of memory for the torch reference ...): the measurement stands, the check is reported as not run
+            if args.check:
+                raise
+            check = {"ok": None, "error": repr(e)}
+        torch.cuda.empty_cache()    # (the check's torch temporaries: the side measurements need the room)
     names = {"filter": [b"filter_kernel"], "topk": [b"topk_sample", b"topk_select", b"topk_small_sort", b"sort_encode", b"radix_hist", b"radix_pass",
                                                     b"sort_sample", b"sort_scatter1", b"sort_scatter2", b"sort_local"], "project": [b"project_kernel"]}.get(
         args.workload, AGG_SPANS)

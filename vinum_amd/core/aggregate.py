@@ -80,7 +80,10 @@ class AggregateOperator(Operator):
                 spec.append((_FUNCS[f.func], names.index(f.column), batch.column(f.column).arrow_type))
             else:
                 spec.append((_FUNCS[f.func], None, None))
-        self._agg = ops.DeviceAggregate(kind, key_types, spec, expected_groups=self._expected_groups)
+        # stream mode (vnm_agg_set_async): the batches the parent yields -- TableReaderOperator / the CSV reader hand them over one
+        # by one, base_aggregate.cpp:23-45 -- are recorded and go to the device as the segments of one launch where the path
+        # takes segments (the hot shape); every other shape is processed per call as before
+        self._agg = ops.DeviceAggregate(kind, key_types, spec, expected_groups=self._expected_groups, stream_mode=True)
         if self._fused_pred:
             self._agg.set_predicate(self._fused_pred[1], self._fused_pred[2])
         if self._kernel_expr is not None:
