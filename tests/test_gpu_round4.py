@@ -444,3 +444,51 @@ def test_dense_path_two_input_columns(program, pred, groups, levels, monkeypatch
         assert p1 == 1 and p2 == 1, (p1, p2)      # the two-value dense path took the batch (two scatter levels, one launch each)
     util.assert_agg_equal(got, _oracle(O.SINGLE, ["k"], funcs, bl, predicate), funcs, ["k"], exact_float_inputs=("a", "b"),
                           what=f"two columns, {program}, pred {pred}, G={groups} {levels}")
+
+
+@pytest.mark.parametrize("program", ["sum_sum", "three_columns_mixed", "minmax_nullable", "int_columns"])
+@pytest.mark.parametrize("pred", ["on_first", "on_other", "none"])
+@pytest.mark.parametrize("groups,shape", [(1000, "one_batch"), (5000, "one_batch"), (3000, "three_batches"), (4000, "null_keys_later"),
+                                          (3000, "hinted"), (5000, "sparse_keys")])
+def test_small_range_many_columns_split_per_column(program, pred, groups, shape, monkeypatch):
+    """Round 4: a few thousand groups in a small key range under two or more 8-byte input columns -- too many groups for the hashed
+    LDS table of the multi-column scan -- are aggregated one input column at a time by the direct-addressed LDS scan (make_parts with one
+    column per part, joined by key at the end) instead of through wide partition entries.  Bit-exact against the oracle;
+    a NULL key in a later batch, several batches, a caller's hint; sparse keys of the same count keep the old path.
+    agg_func_factory.cpp:108-176 (every function has its own accumulator: the order of the columns' passes cannot matter)."""
+    from oracle import oracle as O
+    from vinum_amd import _lib as L
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(groups + len(program) * 7 + len(pred) + len(shape))
+    n = 900_000
+    k = rng.integers(0, groups, n).astype(np.int64) - groups // 4
+    if shape == "sparse_keys":
+        k = k * 1_000_003
+    kmask = None
+    if shape == "null_keys_later":
+        kmask = np.zeros(n, dtype=bool)
+        kmask[n // 2:] = rng.random(n - n // 2) < 0.05
+    cmask = (rng.random(n) < 0.1) if program == "minmax_nullable" else None
+    t = pa.table({"k": pa.array(k, mask=kmask),
+                  "a": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0),
+                  "b": pa.array(rng.integers(-2**13, 2**13, n).astype(np.float64) / 64.0, mask=cmask),
+                  "c": pa.array(rng.integers(-1000, 1000, n).astype(np.int64)),
+                  "d": pa.array(rng.integers(0, 1 << 40, n).astype(np.uint64)),
+                  "p": pa.array(rng.integers(0, 2**12, n).astype(np.float64) / 64.0)})
+    funcs = {"sum_sum": [(O.SUM, "a", "sa"), (O.SUM, "b", "sb")],
+             "three_columns_mixed": [(O.SUM, "a", "sa"), (O.AVG, "b", "ab"), (O.COUNT_STAR, "", "n"), (O.MAX, "c", "mc"), (O.COUNT, "a", "ca")],
+             "minmax_nullable": [(O.MIN, "a", "la"), (O.MAX, "b", "hb"), (O.SUM, "b", "sb"), (O.COUNT, "b", "cb")],
+             "int_columns": [(O.SUM, "c", "sc"), (O.MIN, "d", "ld"), (O.AVG, "c", "ac"), (O.COUNT_STAR, "", "n")]}[program]
+    predicate = {"on_first": ("a", ">", 64.0), "on_other": ("p", ">", 20.0), "none": None}[pred]
+    bl = util.sliced_batches(t, 300_000 if shape == "three_batches" else (450_000 if shape == "null_keys_later" else n))
+    L.lib().vnm_set_profiling(1)
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, bl, predicate=predicate, expected_groups=groups if shape == "hinted" else 0)
+    joins, p1 = _launches(b"agg_split_join"), _launches(b"agg_part_scatter1")
+    L.lib().vnm_set_profiling(0)
+    if shape == "sparse_keys":
+        assert joins == 0, joins
+    elif groups >= 3000:
+        assert joins == 1, (joins, p1)   # one part per column (1000 groups still fit the hashed table of a two-column program; a part
+                                         # with a generic program may take the four-partition form of the small range)
+    util.assert_agg_equal(got, _oracle(O.SINGLE, ["k"], funcs, bl, predicate), funcs, ["k"], exact_float_inputs=("a", "b"),
+                          what=f"split per column: {program}, pred {pred}, G={groups} {shape}")

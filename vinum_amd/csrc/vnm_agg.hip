@@ -5547,6 +5547,38 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                 VNM_TRY(make_parts(h, (int)env_i64("VNM_AGG_SPLIT_COLS", any_null ? 5 : 6)));
                 return next_parts(h, nrows, keys, inputs, pred, stream);
             }
+        } else if (h->plan.n_cols >= 2 && !h->rank_aligned && (keys[0].type == VNM_I64 || keys[0].type == VNM_U64) &&
+                   nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) && getenv("VNM_AGG_NO_SPLIT_SMALL") == nullptr) {
+            // A few thousand groups in a SMALL key range under two or more 8-byte input columns (round 4): too many groups for the
+            // scan's hashed LDS table of this many words (flush storms), so the rows used to go through wide partition entries
+            // (C = 2 / 3 / 6 columns, G = 1000, 5e8 rows: 7.9 / 12.3 / 23.6 ms).  One part per column instead: each is the
+            // direct-addressed 2^13-slot LDS scan (16 bytes per row and column at the scan's rate: 3.3 / 4.9 / 9.8 ms incl. the join
+            // of the parts, which is over a few thousand groups).
+            bool cols8 = true;
+            for (int c = 0; c < h->plan.n_cols; c++) {
+                const int t = inputs[h->col_first_func[c]].type;
+                cols8 = cols8 && (t == VNM_F64 || t == VNM_I64 || t == VNM_U64);
+            }
+            if (cols8) {
+                h->split_tried = true;
+                if (h->hint == 0 && !h->estimated && getenv("VNM_AGG_NO_ESTIMATE") == nullptr) {
+                    int64_t est = 0;
+                    KernelTimer timer("agg_estimate", s);
+                    VNM_TRY(estimate_groups(h, keys[0], est_rows, &est, s));
+                    if (est) { h->hint = est; h->estimated = true; }
+                }
+                if (h->hint > env_i64("VNM_AGG_PART_MIN_GROUPS", std::min<int64_t>(2400, (int64_t)lds_slots_for(h->plan) * 6 / 10)) &&
+                    h->hint <= (1 << DP_TBITS_MAX)) {
+                    if (h->dense_state == 0) {
+                        KernelTimer timer("agg_estimate", s);
+                        VNM_TRY(plan_dense(h, keys[0], est_rows, s));
+                    }
+                    if (h->dense_state == 2) {
+                        VNM_TRY(make_parts(h, 1));
+                        return next_parts(h, nrows, keys, inputs, pred, stream);
+                    }
+                }
+            }
         }
     }
 
