@@ -492,3 +492,54 @@ def test_small_range_many_columns_split_per_column(program, pred, groups, shape,
                                          # with a generic program may take the four-partition form of the small range)
     util.assert_agg_equal(got, _oracle(O.SINGLE, ["k"], funcs, bl, predicate), funcs, ["k"], exact_float_inputs=("a", "b"),
                           what=f"split per column: {program}, pred {pred}, G={groups} {shape}")
+
+
+@pytest.mark.parametrize("program,pred", [("three_sums", "on_first"), ("three_sums", "none"), ("four_columns_mixed", "on_first"), ("nullable_and_minmax", "none")])
+@pytest.mark.parametrize("groups,shape", [(300_000, "one_batch"), (1_500_000, "one_batch"), (1_500_000, "pairs"), (1_200_000, "two_batches"),
+                                          (1_300_000, "null_keys_later"), (1_400_000, "heavy_keys"), (1_500_000, "sparse_keys")])
+def test_many_groups_many_columns_split_over_the_dense_path(program, pred, groups, shape, monkeypatch):
+    """Round 4: three or more 8-byte input columns over a key the dense path takes are aggregated per column (or per pair of float64
+    columns under sums / counts: two-value entries) by the dense path and joined at the end -- by a plain copy when every part
+    wrote its groups in the same order (same code map), by the sort join otherwise (heavy keys that spilled to the side table,
+    a NULL-key group from the general scan).  Bit-exact against the oracle.  agg_func_factory.cpp:108-176."""
+    from oracle import oracle as O
+    from vinum_amd import _lib as L
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    monkeypatch.setenv("VNM_AGG_SPLIT_DENSE_MIN_ROWS", "100000")
+    if shape == "pairs":
+        monkeypatch.setenv("VNM_AGG_SPLIT_PAIRS_MIN_GROUPS", "1000000")
+    rng = np.random.default_rng(groups % 977 + len(program) * 5 + len(pred) + len(shape))
+    n = 2_400_000
+    k = rng.integers(0, groups, n).astype(np.int64) - groups // 4
+    if shape == "heavy_keys":
+        k[rng.random(n) < 0.3] = 17   # one key holds ~30 % of the rows
+    if shape == "sparse_keys":
+        k = k * 1_000_003
+    kmask = None
+    if shape == "null_keys_later":
+        kmask = np.zeros(n, dtype=bool)
+        kmask[n // 2:] = rng.random(n - n // 2) < 0.05
+    cmask = (rng.random(n) < 0.1) if program == "nullable_and_minmax" else None
+    t = pa.table({"k": pa.array(k, mask=kmask),
+                  "a": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0),
+                  "b": pa.array(rng.integers(-2**13, 2**13, n).astype(np.float64) / 64.0, mask=cmask),
+                  "c": pa.array(rng.integers(0, 2**10, n).astype(np.float64) / 8.0),
+                  "d": pa.array(rng.integers(-1000, 1000, n).astype(np.int64))})
+    funcs = {"three_sums": [(O.SUM, "a", "sa"), (O.SUM, "b", "sb"), (O.AVG, "c", "ac"), (O.COUNT_STAR, "", "n")],
+             "four_columns_mixed": [(O.SUM, "a", "sa"), (O.AVG, "b", "ab"), (O.MAX, "d", "md"), (O.COUNT, "c", "cc"), (O.MIN, "c", "lc"), (O.COUNT_STAR, "", "n")],
+             "nullable_and_minmax": [(O.MIN, "a", "la"), (O.SUM, "b", "sb"), (O.COUNT, "b", "cb"), (O.SUM, "d", "sd")]}[program]
+    predicate = {"on_first": ("a", ">", 64.0), "none": None}[pred]
+    bl = util.sliced_batches(t, 1_200_000 if shape in ("two_batches", "null_keys_later") else n)
+    L.lib().vnm_set_profiling(1)
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, bl, predicate=predicate)
+    joins, sorts = _launches(b"agg_split_join"), _launches(b"agg_split_sort")
+    L.lib().vnm_set_profiling(0)
+    if shape == "sparse_keys":
+        assert joins == 0, joins
+    else:
+        assert joins == 1, joins
+    if shape in ("one_batch", "pairs") or (shape == "two_batches" and program == "three_sums"):
+        assert sorts == 0, sorts        # joined by units of 64 codes: no sort, no gather (generic programs merge their batches' runs
+                                        # through the table: another order, the sort join)
+    util.assert_agg_equal(got, _oracle(O.SINGLE, ["k"], funcs, bl, predicate), funcs, ["k"], exact_float_inputs=("a", "b", "c"),
+                          what=f"dense split: {program}, pred {pred}, G={groups} {shape}")

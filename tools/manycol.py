@@ -23,7 +23,7 @@ for rep in range(3):
     ng = agg.finish()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     spans = {}
-    for nm in (b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final", b"agg_split_join"):
+    for nm in (b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final", b"agg_split_join", b"agg_split_finish", b"agg_split_sort", b"agg_split_units", b"agg_estimate"):
         ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
         lib.vnm_profile_query(nm, ctypes.byref(ms), ctypes.byref(cnt))
         if cnt.value:

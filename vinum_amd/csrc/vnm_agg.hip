@@ -5204,18 +5204,71 @@ __global__ __launch_bounds__(256) void part_join_kernel(PartJoinArgs a) {
     // The parts are sorted by key word alone; the NULL-key group (key word 0, mask 1) and a real key 0 are then the first two
     // rows in an order each part decides for itself: the real key goes first, the NULL group second, in every part.
     bool swap01 = false;
-    if (a.n >= 2) {
+    if (a.n >= 2 && a.perm) {
         const int64_t g0 = a.perm[0], g1 = a.perm[1];
         swap01 = a.key_src[g0] == 0 && a.key_src[g1] == 0 && a.mask_src[g0] != 0 && a.mask_src[g1] == 0;
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
-        const int64_t g = a.perm[swap01 && i < 2 ? 1 - i : i];
+        const int64_t g = a.perm ? a.perm[swap01 && i < 2 ? 1 - i : i] : i;   // (no permutation: the parts agree on the order)
         const uint64_t k = a.key_src[g], m = a.mask_src[g];
         if (a.check) bad = bad || a.key_out[i] != k || a.mask_out[i] != m;
         else { a.key_out[i] = k; a.mask_out[i] = m; }
         for (int w = 0; w < a.nw; w++) a.dst[w][i] = a.src[w][g];
     }
     if (bad) __hip_atomic_store(a.flag, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Parts that took the dense path over the SAME code map write their groups in runs of ascending code: the final passes place a
+// partition's groups 64 slots (one wave's ballot) at a time, the partitions wherever their workgroup's claim landed.  So a UNIT of 64
+// codes is one contiguous, equally ordered stretch of rows in every part, and the join needs neither sorts nor random gathers: a
+// table of every unit's first row per part (part_unit_starts_kernel), then row i of part 0 = row start_p[u] + (i - start_0[u]) of
+// part p (part_unit_join_kernel, which compares the keys it pairs: anything else -- groups outside the code range, a NULL-key group,
+// a part that took another path -- fails the attempt and the sort join below does the work).
+struct PartUnitArgs {
+    DenseMap map;
+    int64_t n;
+    const uint64_t* key0;   // part 0: its order is the order of the joined run
+    const uint64_t* mask0;
+    const uint64_t* key;    // the part being placed
+    const uint64_t* mask;
+    const uint32_t* start0;
+    uint32_t* start;
+    uint64_t* key_out;      // (written with part 0)
+    uint64_t* mask_out;
+    unsigned long long* bad;
+    int nw;
+    const uint64_t* src[AGG_MAX_WORDS];
+    uint64_t* dst[AGG_MAX_WORDS];
+};
+__device__ __forceinline__ bool part_unit_of(const DenseMap& m, uint64_t key, uint64_t mask, uint32_t* unit) {
+    const uint64_t d = (key ^ m.sign) - m.lo_u;
+    *unit = (((uint32_t)d * m.mul) & m.mask) >> 6;
+    return mask == 0 && d <= (uint64_t)m.mask;
+}
+__global__ __launch_bounds__(256) void part_unit_starts_kernel(PartUnitArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        uint32_t u, up = ~0u;
+        bad = bad || !part_unit_of(a.map, a.key[i], a.mask[i], &u);
+        if (i > 0) part_unit_of(a.map, a.key[i - 1], 0, &up);
+        if (u != up) a.start[u] = (uint32_t)i;
+    }
+    if (bad) __hip_atomic_store(a.bad, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(256) void part_unit_join_kernel(PartUnitArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        const uint64_t k = a.key0[i];
+        uint32_t u;
+        part_unit_of(a.map, k, 0, &u);
+        const int64_t j = (int64_t)a.start[u] + (i - (int64_t)a.start0[u]);
+        if (j < 0 || j >= a.n || a.key[j] != k || a.mask[j] != 0) { bad = true; continue; }
+        if (a.key_out) { a.key_out[i] = k; a.mask_out[i] = 0; }
+        for (int w = 0; w < a.nw; w++) a.dst[w][i] = a.src[w][j];
+    }
+    if (bad) __hip_atomic_store(a.bad, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 void drop_parts(vnm_agg* h) {
@@ -5287,23 +5340,18 @@ int collapse_parts(vnm_agg* h, hipStream_t s) {
         unsigned long long* flag = (unsigned long long*)pool.take(64);
         std::vector<int64_t*> perm(k, nullptr);
         bool ok = rk && ra && flag;
-        for (int p = 0; p < k && ok; p++) ok = (perm[p] = (int64_t*)pool.take((size_t)n * 8)) != nullptr;
         if (!ok) { pool_free(rk); pool_free(ra); return 1; }
-        int rc = hipMemsetAsync(flag, 0, 8, s) != hipSuccess;
-        const int asc = VNM_ASC;
-        for (int p = 0; p < k && !rc; p++) {
-            vnm_dcol kc{};
-            kc.values = h->parts[p]->dkey; kc.type = VNM_U64; kc.length = n;
-            KernelTimer t2("agg_split_sort", s);
-            rc = vnm_sort_indices(1, &kc, &asc, n, 0, perm[p], (void*)s);
-        }
+        int rc = hipMemsetAsync(flag, 0, 16, s) != hipSuccess;
         const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_info().num_cus * 8);
-        if (!rc) {
+        // word lists of every part (parent word <- part word)
+        std::vector<PartJoinArgs> jas(k);
+        {
             std::vector<char> done(h->plan.n_words, 0);
             for (int p = 0; p < k && !rc; p++) {
                 const vnm_agg* c = h->parts[p];
-                PartJoinArgs ja{};
-                ja.n = n; ja.perm = perm[p]; ja.key_src = c->dkey; ja.mask_src = c->dkey + c->dstride; ja.key_out = rk; ja.mask_out = rk + stride;
+                PartJoinArgs& ja = jas[p];
+                ja = PartJoinArgs{};
+                ja.n = n; ja.key_src = c->dkey; ja.mask_src = c->dkey + c->dstride; ja.key_out = rk; ja.mask_out = rk + stride;
                 ja.check = p > 0; ja.flag = flag;
                 for (size_t q = 0; q < h->part_funcs[p].size() && !rc; q++) {
                     const FuncOut& mine = h->outs[h->part_funcs[p][q]];
@@ -5317,10 +5365,53 @@ int collapse_parts(vnm_agg* h, hipStream_t s) {
                         ja.dst[ja.nw++] = ra + (size_t)pw[j] * stride;
                     }
                 }
-                if (!rc) part_join_kernel<<<grid, 256, 0, s>>>(ja);
             }
             for (int w = 0; w < h->plan.n_words && !rc; w++)
                 if (!done[w]) rc = set_error("aggregate: split program, accumulator word %d has no source (internal error)", w);
+        }
+        // the join by units of 64 codes (parts of the dense path over one code map: see part_unit_starts_kernel)
+        bool joined = false;
+        const DenseMap umap = h->parts[0]->dmap;
+        bool by_units = !rc && h->parts[0]->dense_state == 1 && n < ((int64_t)1 << 31)   /* (2: the small-range scans use maps of their own) */ && getenv("VNM_AGG_NO_UNIT_JOIN") == nullptr;
+        for (int p = 1; p < k && by_units; p++) by_units = h->parts[p]->dense_state == 1 && memcmp(&h->parts[p]->dmap, &umap, sizeof(DenseMap)) == 0;
+        if (by_units) {
+            KernelTimer t2("agg_split_units", s);
+            const size_t units = ((size_t)umap.mask + 1 + 63) >> 6;
+            std::vector<uint32_t*> start(k, nullptr);
+            for (int p = 0; p < k && by_units; p++) by_units = (start[p] = (uint32_t*)pool.take(units * 4)) != nullptr;
+            for (int p = 0; p < k && by_units && !rc; p++) {
+                PartUnitArgs ua{};
+                ua.map = umap; ua.n = n; ua.key = jas[p].key_src; ua.mask = jas[p].mask_src; ua.start = start[p]; ua.bad = flag + 1;
+                rc = hipMemsetAsync(start[p], 0xff, units * 4, s) != hipSuccess;
+                if (!rc) part_unit_starts_kernel<<<grid, 256, 0, s>>>(ua);
+            }
+            for (int p = 0; p < k && by_units && !rc; p++) {
+                PartUnitArgs ua{};
+                ua.map = umap; ua.n = n; ua.key0 = jas[0].key_src; ua.mask0 = jas[0].mask_src; ua.key = jas[p].key_src; ua.mask = jas[p].mask_src;
+                ua.start0 = start[0]; ua.start = start[p]; ua.bad = flag + 1;
+                if (p == 0) { ua.key_out = rk; ua.mask_out = rk + stride; }
+                ua.nw = jas[p].nw;
+                for (int w = 0; w < ua.nw; w++) { ua.src[w] = jas[p].src[w]; ua.dst[w] = jas[p].dst[w]; }
+                part_unit_join_kernel<<<grid, 256, 0, s>>>(ua);
+            }
+            unsigned long long ubad = 0;
+            if (by_units && !rc && (hipGetLastError() != hipSuccess || hipMemcpyAsync(&ubad, flag + 1, 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                                    hipStreamSynchronize(s) != hipSuccess))
+                rc = set_error("aggregate: joining the parts of a split program failed");
+            joined = by_units && !rc && ubad == 0;
+        }
+        const bool same_order = joined;
+        const int asc = VNM_ASC;
+        for (int p = 0; p < k && !rc && !same_order; p++) {
+            vnm_dcol kc{};
+            kc.values = h->parts[p]->dkey; kc.type = VNM_U64; kc.length = n;
+            KernelTimer t2("agg_split_sort", s);
+            if (!(perm[p] = (int64_t*)pool.take((size_t)n * 8))) { pool_free(rk); pool_free(ra); return 1; }
+            rc = vnm_sort_indices(1, &kc, &asc, n, 0, perm[p], (void*)s);
+        }
+        for (int p = 0; p < k && !rc && !joined; p++) {
+            jas[p].perm = perm[p];
+            part_join_kernel<<<grid, 256, 0, s>>>(jas[p]);
         }
         unsigned long long bad = 0;
         if (!rc && (hipGetLastError() != hipSuccess || hipMemcpyAsync(&bad, flag, 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -5567,14 +5658,28 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                     VNM_TRY(estimate_groups(h, keys[0], est_rows, &est, s));
                     if (est) { h->hint = est; h->estimated = true; }
                 }
-                if (h->hint > env_i64("VNM_AGG_PART_MIN_GROUPS", std::min<int64_t>(2400, (int64_t)lds_slots_for(h->plan) * 6 / 10)) &&
-                    h->hint <= (1 << DP_TBITS_MAX)) {
+                if (h->hint > env_i64("VNM_AGG_PART_MIN_GROUPS", std::min<int64_t>(2400, (int64_t)lds_slots_for(h->plan) * 6 / 10))) {
                     if (h->dense_state == 0) {
                         KernelTimer timer("agg_estimate", s);
                         VNM_TRY(plan_dense(h, keys[0], est_rows, s));
                     }
-                    if (h->dense_state == 2) {
+                    if (h->dense_state == 2 && h->hint <= (1 << DP_TBITS_MAX)) {
                         VNM_TRY(make_parts(h, 1));
+                        return next_parts(h, nrows, keys, inputs, pred, stream);
+                    }
+                    // ... and MANY groups over a key the dense path takes, three or more columns: the dense path per column (16-byte
+                    // entries, LDS-resident final tables) -- or per PAIR of float64 columns under sums and counts (two-value
+                    // entries) where two scatter levels are needed anyway -- instead of wide entries through hash partitions; the
+                    // parts write their groups in the same order (same code map), so the join is a copy (collapse_parts).
+                    // 5e8 rows, 3 / 6 columns: G = 1e6 20.0 / 37.6 -> 14 / 28 ms, G = 1e8 30.1 / 360 -> 22 / 45.
+                    if (h->plan.n_cols >= 3 && nrows >= env_i64("VNM_AGG_SPLIT_DENSE_MIN_ROWS", 1 << 24) && h->dense_state == 1 &&
+                        h->dense_span <= 32 * h->hint && h->dense_span <= 4 * nrows && getenv("VNM_AGG_NO_SPLIT_DENSE") == nullptr) {
+                        bool pairs = h->hint >= env_i64("VNM_AGG_SPLIT_PAIRS_MIN_GROUPS", 4000000);
+                        for (int i = 0; i < h->n_funcs && pairs; i++) {
+                            const int f = h->c_funcs[i];
+                            pairs = f == VNM_COUNT_STAR || ((f == VNM_SUM || f == VNM_AVG || f == VNM_COUNT) && inputs[i].type == VNM_F64 && !inputs[i].validity);
+                        }
+                        VNM_TRY(make_parts(h, pairs ? 2 : 1));
                         return next_parts(h, nrows, keys, inputs, pred, stream);
                     }
                 }
