@@ -5624,54 +5624,44 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
     if (!h->parts.empty()) { VNM_SEG_ONLY("split program"); return next_parts(h, nrows, keys, inputs, pred, stream); }
     if (!h->split_tried && key_plain && h->single && keys[0].type == h->plan.key_types[0] && !h->have_table && !h->have_run && !h->pending &&
         !h->expr_active && getenv("VNM_AGG_NO_SPLIT") == nullptr) {
-        bool any_null = false;
-        for (int c = 0; c < h->plan.n_cols; c++) any_null = any_null || inputs[h->col_first_func[c]].validity != nullptr;
-        if (h->plan.n_cols + (any_null ? 1 : 0) > env_i64("VNM_AGG_SPLIT_MIN_COLS", 6)) {
+        bool any_null = false, cols8 = true;
+        for (int c = 0; c < h->plan.n_cols; c++) {
+            const vnm_dcol& col = inputs[h->col_first_func[c]];
+            any_null = any_null || col.validity != nullptr;
+            cols8 = cols8 && (col.type == VNM_F64 || col.type == VNM_I64 || col.type == VNM_U64);
+        }
+        const bool est_ok = nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22);
+        // (a) more columns than an entry carries; (b) two or more 8-byte columns over a key the dense paths take (round 4)
+        const bool many = h->plan.n_cols + (any_null ? 1 : 0) > env_i64("VNM_AGG_SPLIT_MIN_COLS", 6);
+        const bool by_column = h->plan.n_cols >= 2 && cols8 && !h->rank_aligned && (keys[0].type == VNM_I64 || keys[0].type == VNM_U64) && est_ok &&
+                               getenv("VNM_AGG_NO_SPLIT_SMALL") == nullptr;
+        if (many || by_column) {
             h->split_tried = true;
-            if (h->hint == 0 && !h->estimated && nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) && getenv("VNM_AGG_NO_ESTIMATE") == nullptr) {
+            if (h->hint == 0 && !h->estimated && est_ok && getenv("VNM_AGG_NO_ESTIMATE") == nullptr) {
                 int64_t est = 0;
                 KernelTimer timer("agg_estimate", s);
                 VNM_TRY(estimate_groups(h, keys[0], est_rows, &est, s));
                 if (est) { h->hint = est; h->estimated = true; }
             }
             if (h->hint > env_i64("VNM_AGG_PART_MIN_GROUPS", std::min<int64_t>(2400, (int64_t)lds_slots_for(h->plan) * 6 / 10))) {
-                VNM_TRY(make_parts(h, (int)env_i64("VNM_AGG_SPLIT_COLS", any_null ? 5 : 6)));
-                return next_parts(h, nrows, keys, inputs, pred, stream);
-            }
-        } else if (h->plan.n_cols >= 2 && !h->rank_aligned && (keys[0].type == VNM_I64 || keys[0].type == VNM_U64) &&
-                   nrows >= env_i64("VNM_AGG_ESTIMATE_MIN_ROWS", 1 << 22) && getenv("VNM_AGG_NO_SPLIT_SMALL") == nullptr) {
-            // A few thousand groups in a SMALL key range under two or more 8-byte input columns (round 4): too many groups for the
-            // scan's hashed LDS table of this many words (flush storms), so the rows used to go through wide partition entries
-            // (C = 2 / 3 / 6 columns, G = 1000, 5e8 rows: 7.9 / 12.3 / 23.6 ms).  One part per column instead: each is the
-            // direct-addressed 2^13-slot LDS scan (16 bytes per row and column at the scan's rate: 3.3 / 4.9 / 9.8 ms incl. the join
-            // of the parts, which is over a few thousand groups).
-            bool cols8 = true;
-            for (int c = 0; c < h->plan.n_cols; c++) {
-                const int t = inputs[h->col_first_func[c]].type;
-                cols8 = cols8 && (t == VNM_F64 || t == VNM_I64 || t == VNM_U64);
-            }
-            if (cols8) {
-                h->split_tried = true;
-                if (h->hint == 0 && !h->estimated && getenv("VNM_AGG_NO_ESTIMATE") == nullptr) {
-                    int64_t est = 0;
-                    KernelTimer timer("agg_estimate", s);
-                    VNM_TRY(estimate_groups(h, keys[0], est_rows, &est, s));
-                    if (est) { h->hint = est; h->estimated = true; }
-                }
-                if (h->hint > env_i64("VNM_AGG_PART_MIN_GROUPS", std::min<int64_t>(2400, (int64_t)lds_slots_for(h->plan) * 6 / 10))) {
+                if (by_column) {
                     if (h->dense_state == 0) {
                         KernelTimer timer("agg_estimate", s);
                         VNM_TRY(plan_dense(h, keys[0], est_rows, s));
                     }
+                    // A few thousand groups in a SMALL key range: too many for the scan's hashed LDS table of this many words (flush
+                    // storms), so the rows used to go through wide partition entries (C = 2 / 3 / 6 columns, G = 1000, 5e8 rows:
+                    // 7.9 / 12.3 / 23.6 ms).  One part per column instead: each is the direct-addressed 2^13-slot LDS scan (16 bytes per
+                    // row and column at the scan's rate: 3.3 / 4.9 / 9.8 ms incl. the join over a few thousand groups).
                     if (h->dense_state == 2 && h->hint <= (1 << DP_TBITS_MAX)) {
                         VNM_TRY(make_parts(h, 1));
                         return next_parts(h, nrows, keys, inputs, pred, stream);
                     }
-                    // ... and MANY groups over a key the dense path takes, three or more columns: the dense path per column (16-byte
-                    // entries, LDS-resident final tables) -- or per PAIR of float64 columns under sums and counts (two-value
-                    // entries) where two scatter levels are needed anyway -- instead of wide entries through hash partitions; the
-                    // parts write their groups in the same order (same code map), so the join is a copy (collapse_parts).
-                    // 5e8 rows, 3 / 6 columns: G = 1e6 20.0 / 37.6 -> 14 / 28 ms, G = 1e8 30.1 / 360 -> 22 / 45.
+                    // MANY groups over a key the dense path takes, three or more columns: the dense path per column (16-byte entries,
+                    // LDS-resident final tables) -- or per PAIR of float64 columns under sums and counts (two-value entries) where
+                    // two scatter levels are needed anyway -- instead of wide entries through hash partitions; parts of the dense path
+                    // over one code map are joined by units of 64 codes (collapse_parts: no sorts, no random gathers).
+                    // 5e8 rows, 3 / 6 columns: G = 1e6 20.0 / 37.6 -> 13.9 / 26.8 ms, G = 1e8 30.1 / 360 -> 24.7 / 44.8.
                     if (h->plan.n_cols >= 3 && nrows >= env_i64("VNM_AGG_SPLIT_DENSE_MIN_ROWS", 1 << 24) && h->dense_state == 1 &&
                         h->dense_span <= 32 * h->hint && h->dense_span <= 4 * nrows && getenv("VNM_AGG_NO_SPLIT_DENSE") == nullptr) {
                         bool pairs = h->hint >= env_i64("VNM_AGG_SPLIT_PAIRS_MIN_GROUPS", 4000000);
@@ -5682,6 +5672,10 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                         VNM_TRY(make_parts(h, pairs ? 2 : 1));
                         return next_parts(h, nrows, keys, inputs, pred, stream);
                     }
+                }
+                if (many) {
+                    VNM_TRY(make_parts(h, (int)env_i64("VNM_AGG_SPLIT_COLS", any_null ? 5 : 6)));
+                    return next_parts(h, nrows, keys, inputs, pred, stream);
                 }
             }
         }
