@@ -760,17 +760,17 @@ def main():
             state.pop("agg", None)
             state["agg"] = agg
             return
-        kcol, vcol = cur["kcol"], cur["vcol"]
+        gk, gv = cur["kcol"], cur["vcol"]   # (names of their own: `vcol` is the closure variable of the other workloads)
         if args.shape == "count_star":
             agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.COUNT_STAR, 0, None)],
                                       expected_groups=groups if args.hint else 0)
-            agg.next([kcol], [None], nrows=n, stream=stream)
+            agg.next([gk], [None], nrows=n, stream=stream)
         elif args.shape == "minmax":
             agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
                                       [(L.MIN, 1, pa.float64()), (L.MAX, 1, pa.float64())],
                                       expected_groups=groups if args.hint else 0)
             agg.set_predicate(">", x_thr)
-            agg.next([kcol], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
+            agg.next([gk], [gv, gv], pred=gv, nrows=n, stream=stream)
         else:
             agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
                                       [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
@@ -780,13 +780,13 @@ def main():
                 # hint-less on several ranks: agree on ONE group-count estimate, or ranks may cut their results into
                 # different numbers of partitions (distributed.agree_on_group_count)
                 from vinum_amd import distributed as D
-                D.agree_on_group_count(agg, kcol, n, device, stream=stream)
+                D.agree_on_group_count(agg, gk, n, device, stream=stream)
             if world > 1 or force_exchange:
                 # ... and on ONE key range: the dense-key path then gives slot-compatible tables on every rank
                 from vinum_amd import distributed as D
                 if os.environ.get("VNM_BENCH_EXCHANGE", "dense") == "dense":
-                    D.agree_on_dense_range(agg, kcol, n, device, stream=stream)
-            agg.next([kcol], [vcol, vcol], pred=vcol, nrows=n, stream=stream)
+                    D.agree_on_dense_range(agg, gk, n, device, stream=stream)
+            agg.next([gk], [gv, gv], pred=gv, nrows=n, stream=stream)
         if world > 1 or force_exchange:
             ng = exchange_and_merge(agg, None)
         else:

@@ -89,3 +89,15 @@ def test_bench_self_launch_ranks_sharing_the_gpu(ranks, groups, route):
     assert j["check"]["world_size"] == ranks and j["check"]["exchange"] == route, j["check"]
     assert j["check"]["survivors_conserved"] and j["check"]["totals_conserved"]
     assert j["value"] > 0 and j["config"]["rows_per_gpu"] == 3 << 24
+
+
+@pytest.mark.parametrize("args,metric", [
+    (["--workload", "filter"], "filter"), (["--workload", "topk"], "topk"), (["--workload", "topk", "--limit", "0"], "sort"),
+    (["--workload", "project"], "project"), (["--workload", "groupby", "--shape", "count_star", "--groups", "1e6"], "groupby"),
+    (["--workload", "groupby", "--shape", "minmax", "--groups", "1e5"], "groupby")])
+def test_bench_side_workloads_run(args, metric):
+    """Every workload the profiles of a round are taken from (tools/profile.sh) still produces its JSON line: the r04 profiles of
+    filter / top-K / full sort / projection were EMPTY because a local name in step() shadowed the other workloads' value column."""
+    j = _bench({}, "--rows", "2e7", *args)
+    assert j["value"] > 0 and j["ms_per_step"] > 0, j
+    assert j["roofline"]["achieved"] > 0, j["roofline"]
