@@ -543,3 +543,38 @@ def test_many_groups_many_columns_split_over_the_dense_path(program, pred, group
                                         # through the table: another order, the sort join)
     util.assert_agg_equal(got, _oracle(O.SINGLE, ["k"], funcs, bl, predicate), funcs, ["k"], exact_float_inputs=("a", "b", "c"),
                           what=f"dense split: {program}, pred {pred}, G={groups} {shape}")
+
+
+@pytest.mark.parametrize("ncols", [3, 4, 5, 6])
+@pytest.mark.parametrize("pred", ["on_input", "on_other", "none"])
+@pytest.mark.parametrize("groups,shape", [(7, "one_batch"), (300, "three_batches"), (5, "ragged_tail"), (2000, "saturates_lds"), (40, "empty_sentinel_key")])
+def test_scan_over_three_to_six_float_columns(ncols, pred, groups, shape, monkeypatch):
+    """Round 4: `SELECT k, sum(a), avg(b), count(c), ..., count(*) GROUP BY k` over few groups and three to six plain float64 columns
+    takes agg_hotn_kernel (16-byte loads, next tile prefetched, ONE count atomic per row: the other count words are copied from it
+    before every flush) instead of the interpreted scan.  Bit-exact against the oracle: one and several batches, a ragged tail
+    (scalar path), more groups than the LDS table takes (saturated keys go to the HBM table row by row), the key that equals the
+    table's EMPTY sentinel.  agg_func_factory.cpp:108-176; base_aggregate.cpp:23-45."""
+    from oracle import oracle as O
+    from vinum_amd import _lib as L
+    rng = np.random.default_rng(ncols * 31 + groups + len(pred) + len(shape))
+    n = {"one_batch": 400_000, "three_batches": 390_000, "ragged_tail": 100_003, "saturates_lds": 300_000, "empty_sentinel_key": 65_538}[shape]
+    k = rng.integers(0, groups, n).astype(np.int64) * 977 - 1234
+    if shape == "empty_sentinel_key":
+        k[::7] = -1        # (0xFFFF...: the LDS / HBM tables' EMPTY tag has a slot of its own)
+    cols = {"k": pa.array(k)}
+    names = "abcdef"[:ncols]
+    for i, c in enumerate(names):
+        cols[c] = pa.array(rng.integers(-2**13, 2**13, n).astype(np.float64) / (64.0 * 2**i))   # (dyadic: sums are exact in any order)
+    cols["p"] = pa.array(rng.integers(0, 2**12, n).astype(np.float64) / 64.0)
+    t = pa.table(cols)
+    kinds = [O.SUM, O.AVG, O.COUNT, O.SUM, O.AVG, O.SUM]
+    funcs = [(kinds[i], c, f"f_{c}") for i, c in enumerate(names)] + [(O.COUNT_STAR, "", "n"), (O.SUM, "b", "sb2"), (O.COUNT, "a", "ca")]
+    predicate = {"on_input": ("b", ">", 0.0), "on_other": ("p", ">", 20.0), "none": None}[pred]
+    bl = util.sliced_batches(t, 130_000 if shape == "three_batches" else n)
+    L.lib().vnm_set_profiling(1)
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, bl, predicate=predicate)
+    scans = _launches(b"agg_scan")
+    L.lib().vnm_set_profiling(0)
+    assert scans >= len(bl), scans
+    util.assert_agg_equal(got, _oracle(O.SINGLE, ["k"], funcs, bl, predicate), funcs, ["k"], exact_float_inputs=tuple(names),
+                          what=f"hotn: {ncols} columns, pred {pred}, G={groups} {shape}")

@@ -21,7 +21,7 @@ def main():
     for name, n, t, mn, mx, vg, sg, lds, wg, grid in rows:
         if flt and flt not in name:
             continue
-        short = name.split("(")[0][-96:]
+        short = name.split("(")[0]   # (whole: the template arguments tell the instantiations apart, and tools/traffic_from_pmc.py matches on "vnm::")
         print(f"{short:96s} {n:6d} {t / 1e6:10.3f} {t / n / 1e3:10.1f} {mn / 1e3:9.1f} {mx / 1e3:9.1f} {100.0 * t / tot:6.2f} {vg:4d} {sg:4d} {lds:5d} {wg:4d} {grid:7d}")
     try:
         pe, pi = T("rocpd_pmc_event"), T("rocpd_info_pmc")
@@ -33,7 +33,7 @@ def main():
             for name, ctr, n, v in pm:
                 if flt and flt not in name:
                     continue
-                print(f"{name.split('(')[0][-96:]:96s} {ctr:14s} n={n:4d} avg={v:.6g}")
+                print(f"{name.split('(')[0]:96s} {ctr:14s} n={n:4d} avg={v:.6g}")
     except Exception as e:  # no counters in this run
         pass
 

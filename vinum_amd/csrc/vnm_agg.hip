@@ -165,6 +165,12 @@ struct AggArgs {
     int part_wide;       // wide entries (several input columns, NULLs, narrow types, any predicate column)
     int part_vmask;      // ... with a validity word
     int debug;  // timing experiments (VNM_AGG_DEBUG): 1 = no accumulator ops, 2 = no probes either, 4 = no room check
+    // agg_hotn_kernel: {COUNT(*), COUNT, SUM, AVG} over THREE to SIX plain float64 columns
+    int hn_w_sum[6];    // word of each column's sum (-1: the column is only counted)
+    int hn_w_base;      // the count word the kernel maintains; the others are copies of it before a flush (no NULLs: every count is the row count)
+    int hn_n_copy;
+    int hn_w_copy[7];
+    int hn_pred_col;    // the predicate column is this input column (-1: a column of its own, a.pred)
 };
 
 // ---- global table primitives ------------------------------------------------------------------------
@@ -1056,6 +1062,166 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_seg_kernel(AggArgs a) {
             if (tid == 0) s_fill = 0;
         }
     }
+    lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK, &s_new);
+    __syncthreads();
+    if (tid == 0) { fold_new(a.g, &s_new); a.progress[blockIdx.x] = it; }
+}
+
+// Kernel 1n: the hot shape over THREE to SIX input columns (round 4) -- `SELECT k, sum(a), sum(b), avg(c), ..., count(*) GROUP BY k`
+// over few groups, the shape of most reporting queries.  Every function in {COUNT(*), COUNT, SUM, AVG}, plain float64 columns, a
+// plain float64 predicate column (one of the inputs or another) or none.  The generic scan (agg_lds_kernel) interprets one
+// accumulator op at a time with 8-byte loads and ran C = 3 / 4 / 6 columns at 3.7 / 3.8 / 2.8 TB/s (G = 7); here, as in
+// agg_hot_kernel: 16-byte loads of row pairs, the next tile's loads issued into the registers of the chunk just consumed,
+// straight-line accumulation -- and ONE count atomic per row whatever the number of COUNT / AVG functions: without NULLs every
+// count is the row count, the other count words are copied from it before a flush (hn_fill_counts).
+template <int NC>
+__device__ __forceinline__ void hn_accumulate(const AggArgs& a, uint64_t* lacc, int stride, int slot, const uint64_t* v) {
+    __hip_atomic_fetch_add(&lacc[a.hn_w_base * stride + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int w = a.hn_w_sum[c];
+        if (w < 0) continue;
+        if (a.hot_comp) l_add_f64c(&lacc[w * stride + slot], stride, __longlong_as_double((long long)v[c]));
+        else __hip_atomic_fetch_add((double*)&lacc[w * stride + slot], __longlong_as_double((long long)v[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+__device__ __forceinline__ void hn_fill_counts(const AggArgs& a, uint64_t* lacc, int stride, int tid) {
+    for (int i = tid; i < stride; i += AGG_BLOCK) {
+        const uint64_t n = lacc[a.hn_w_base * stride + i];
+        for (int j = 0; j < a.hn_n_copy; j++) lacc[a.hn_w_copy[j] * stride + i] = n;
+    }
+    __syncthreads();
+}
+template <int NC, bool HAS_PRED>
+__global__ __launch_bounds__(AGG_BLOCK) void agg_hotn_kernel(AggArgs a) {
+    constexpr int U = NC == 3 && !HAS_PRED ? 4 : 2;   // row pairs per lane and tile: 16 + 16 NC (8 + 8 NC) registers of loads in flight (three columns
+                                                      // and a predicate with U = 4: 74 spilled VGPRs under the 128 a 1024-thread workgroup may hold)
+    constexpr int TILE = AGG_BLOCK * 2 * U;
+    extern __shared__ uint64_t lds[];
+    __shared__ unsigned s_fill, s_new;
+    __shared__ int s_go;
+    const int S = a.lds_slots;
+    const int stride = S + 2;
+    const int W = a.plan.n_words;
+    uint64_t* lkey = lds;
+    uint64_t* lacc = lds + stride;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < stride; i += AGG_BLOCK) lkey[i] = EMPTY;
+    for (int w = 0; w < W; w++) {
+        uint64_t init = merge_init(a.plan.merge[w]);
+        for (int i = tid; i < stride; i += AGG_BLOCK) lacc[w * stride + i] = init;
+    }
+    if (tid == 0) { s_fill = 0; s_new = 0; }
+    __syncthreads();
+
+    const unsigned flush_at = (unsigned)(S * 6 / 10);
+    const uint32_t smask = (uint32_t)S - 1;
+    const uint64_t* kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
+    const uint64_t* vp[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) vp[c] = (const uint64_t*)a.cols[c].values + a.cols[c].offset;
+    const int pc = HAS_PRED ? a.hn_pred_col : -1;
+    const double* pp = HAS_PRED && pc < 0 ? (const double*)a.pred.values + a.pred.offset : (const double*)kp;
+    const int op = a.p.op;
+    const double thr = a.p.dval;
+
+    ulonglong2 kk[U], vv[U][NC];
+    double2 pv[U];
+    bool have = false;
+    uint32_t spread = 0;
+    int spread_state = ((a.debug & 4) || a.ntiles < 64 * (int64_t)gridDim.x) ? 2 : 0;   // see agg_hot_kernel
+    bool need_check = true;
+    unsigned it = a.progress[blockIdx.x];
+    for (;; it++) {
+        const int64_t tile = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
+        if (tile >= a.ntiles) break;
+        if (need_check) {  // see agg_lds_kernel
+            if (tid == 0) s_go = table_has_room(a, &s_new) ? 1 : 0;
+            __syncthreads();
+            if (!s_go) break;
+        }
+        const int64_t base = tile * TILE + 2 * tid;
+        uint32_t sat0 = 0, sat1 = 0;
+        if (base + (int64_t)(U - 1) * 2 * AGG_BLOCK + 1 < a.nrows) {
+#define VNM_HN_LOAD(u, b)                                                                                       \
+    do {                                                                                                       \
+        const int64_t r_ = (b) + (int64_t)(u) * 2 * AGG_BLOCK;                                                 \
+        kk[u] = *(const ulonglong2*)(kp + r_);                                                                 \
+        _Pragma("unroll") for (int c_ = 0; c_ < NC; c_++) vv[u][c_] = *(const ulonglong2*)(vp[c_] + r_);       \
+        if (HAS_PRED && pc < 0) pv[u] = *(const double2*)(pp + r_);                                            \
+    } while (0)
+            if (!have) {
+#pragma unroll
+                for (int u = 0; u < U; u++) VNM_HN_LOAD(u, base);
+            }
+            const int64_t nbase = base + (int64_t)gridDim.x * TILE;
+            const bool nfull = tile + gridDim.x < a.ntiles && nbase + (int64_t)(U - 1) * 2 * AGG_BLOCK + 1 < a.nrows;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const ulonglong2 k = kk[u];
+                uint64_t v0[NC], v1[NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++) { v0[c] = vv[u][c].x; v1[c] = vv[u][c].y; }
+                double p0 = 0.0, p1 = 0.0;
+                if (HAS_PRED) {
+                    p0 = pv[u].x; p1 = pv[u].y;
+#pragma unroll
+                    for (int c = 0; c < NC; c++)
+                        if (c == pc) { p0 = __longlong_as_double((long long)v0[c]); p1 = __longlong_as_double((long long)v1[c]); }
+                }
+                if (nfull) VNM_HN_LOAD(u, nbase);
+                if (!HAS_PRED || cmp_apply<double>(op, p0, thr)) {
+                    const int slot = hot_slot(lkey, S, smask, &s_fill, k.x, spread);
+                    if (slot >= 0) hn_accumulate<NC>(a, lacc, stride, slot, v0);
+                    else sat0 |= 1u << u;
+                }
+                if (!HAS_PRED || cmp_apply<double>(op, p1, thr)) {
+                    const int slot = hot_slot(lkey, S, smask, &s_fill, k.y, spread);
+                    if (slot >= 0) hn_accumulate<NC>(a, lacc, stride, slot, v1);
+                    else sat1 |= 1u << u;
+                }
+            }
+            have = nfull;
+#undef VNM_HN_LOAD
+        } else {
+            have = false;
+            for (int u = 0; u < U; u++)
+                for (int e = 0; e < 2; e++) {
+                    const int64_t r = base + (int64_t)u * 2 * AGG_BLOCK + e;
+                    if (r >= a.nrows) continue;
+                    uint64_t v[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; c++) v[c] = vp[c][r];
+                    if (HAS_PRED) {
+                        double p = pc < 0 ? pp[r] : 0.0;
+#pragma unroll
+                        for (int c = 0; c < NC; c++) if (c == pc) p = __longlong_as_double((long long)v[c]);
+                        if (!cmp_apply<double>(op, p, thr)) continue;
+                    }
+                    const int slot = hot_slot(lkey, S, smask, &s_fill, kp[r], spread);
+                    if (slot >= 0) hn_accumulate<NC>(a, lacc, stride, slot, v);
+                    else if (e == 0) sat0 |= 1u << u;
+                    else sat1 |= 1u << u;
+                }
+        }
+        // saturated keys: straight to the HBM table, out of line (rows base + e + u * 2 * AGG_BLOCK)
+        if (sat0) agg_rows_to_table(a, base, 2 * AGG_BLOCK, sat0, &s_new);
+        if (sat1) agg_rows_to_table(a, base + 1, 2 * AGG_BLOCK, sat1, &s_new);
+        __syncthreads();
+        const unsigned fill_now = s_fill;
+        need_check = fill_now > (unsigned)S / 2;
+        if (spread_state == 0) { spread_state = fill_now <= (unsigned)S / 128 ? 1 : 2; if (spread_state == 1) spread = tid & 7u; }
+        else if (spread_state == 1 && fill_now > (unsigned)S / 8) { spread_state = 2; spread = 0; }
+        if (fill_now > flush_at) {
+            hn_fill_counts(a, lacc, stride, tid);
+            lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK, &s_new);
+            __syncthreads();
+            if (tid == 0) s_fill = 0;
+        }
+    }
+    __syncthreads();
+    hn_fill_counts(a, lacc, stride, tid);
     lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK, &s_new);
     __syncthreads();
     if (tid == 0) { fold_new(a.g, &s_new); a.progress[blockIdx.x] = it; }
@@ -5796,6 +5962,38 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
     // NULL rows in pass 1 and everything after it is the hot shape (vn_fold below); every other kernel of the hot shape reads no bitmap
     const bool hot_prog = hot;
     if (hot_vnull) hot = false;
+    // three to six plain float64 columns under {COUNT(*), COUNT, SUM, AVG}: agg_hotn_kernel takes the scan
+    bool hotn = !hot_scan && h->single && h->plan.n_cols >= 3 && h->plan.n_cols <= 6 && type_width(keys[0].type) == 8 && !keys[0].validity &&
+                (keys[0].offset & 1) == 0 && !a.has_expr && getenv("VNM_AGG_NO_HOTN") == nullptr && getenv("VNM_AGG_NO_HOT") == nullptr;
+    {
+        int w_rows = -1, w_cnt[6] = {-1, -1, -1, -1, -1, -1};
+        for (int c = 0; c < 6; c++) a.hn_w_sum[c] = -1;
+        for (int c = 0; c < h->plan.n_cols && hotn; c++) {
+            const vnm_dcol& col = a.cols[c];
+            hotn = col.type == VNM_F64 && !col.validity && (col.offset & 1) == 0 && ((uintptr_t)col.values & 15) == 0;
+        }
+        for (int o = 0; o < h->plan.n_ops && hotn; o++) {
+            const AccOp& op = h->plan.ops[o];
+            if (op.kind == A_COUNT_ROWS && w_rows < 0) w_rows = op.word;
+            else if (op.kind == A_COUNT_VALID && w_cnt[op.col] < 0) w_cnt[op.col] = op.word;
+            else if (op.kind == A_SUM_F64 && a.hn_w_sum[op.col] < 0) a.hn_w_sum[op.col] = op.word;
+            else hotn = false;
+        }
+        a.hn_w_base = w_rows;
+        a.hn_n_copy = 0;
+        for (int c = 0; c < h->plan.n_cols && hotn; c++) {
+            if (w_cnt[c] < 0) continue;
+            if (a.hn_w_base < 0) a.hn_w_base = w_cnt[c];
+            else a.hn_w_copy[a.hn_n_copy++] = w_cnt[c];
+        }
+        hotn = hotn && a.hn_w_base >= 0 && ((uintptr_t)keys[0].values & 15) == 0;
+        a.hn_pred_col = -1;
+        if (hotn && h->pred_set) {
+            hotn = a.pred.type == VNM_F64 && !a.pred.validity && (a.pred.offset & 1) == 0 && ((uintptr_t)a.pred.values & 15) == 0 && a.p.mode == CMP_F64;
+            for (int c = 0; c < h->plan.n_cols && hotn; c++)
+                if (a.pred.values == a.cols[c].values && a.pred.offset == a.cols[c].offset) a.hn_pred_col = c;
+        }
+    }
     // the partitioned path also takes ANY accumulator program over at most one 8-byte input column: its entries
     // carry (key, raw value bits) and only the final pass interprets them
     bool part_ok = hot;
@@ -6045,6 +6243,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
             a.ntiles = (n_spill + AGG_TILE - 1) / AGG_TILE;
             a.p.enabled = 0;
             hot_scan = false;
+            hotn = false;   // (columns with validity words, no predicate)
         } else if (prc == 0) {  // the scan below runs over the spilled entries only (predicate already applied)
             a.ent = spill;
             a.nrows = n_spill;
@@ -6059,11 +6258,14 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
     if (h->kn_valid && !a.ent) VNM_SEG_ONLY("scan over the rows");   // (only the dense path's pass 1 reads the key's validity)
     VNM_TRY(ensure_table(h, scan_n, s, spill != nullptr || nspill != nullptr));
     if (hot_scan) a.ntiles = (scan_n + HOT_TILE - 1) / HOT_TILE;
+    hotn = hotn && !a.ent && !scan_no_pred && !hot_scan;
+    const int hotn_tile = AGG_BLOCK * 2 * (h->plan.n_cols == 3 && !h->pred_set ? 4 : 2);   // (agg_hotn_kernel's U)
+    if (hotn) a.ntiles = (scan_n + hotn_tile - 1) / hotn_tile;
     if (h->segs_active && !a.ent) VNM_TRY(upload_segs(h, HOT_TILE, &a.segs, &a.nseg, &a.ntiles, seg_pool, s));
     const int lds_tile = AGG_TILE;
     int grid = h->single ? cus : cus * 4;
     if (grid > a.ntiles) grid = (int)a.ntiles;
-    a.margin = (int64_t)grid * (h->single ? (a.lds_slots + 2 + (hot_scan ? HOT_TILE : lds_tile)) : AGG_TILE);
+    a.margin = (int64_t)grid * (h->single ? (a.lds_slots + 2 + (hot_scan || hotn ? HOT_TILE : lds_tile)) : AGG_TILE);
     progress = (unsigned int*)pool_alloc((size_t)grid * 4);
     if (!progress) return 1;
     VNM_HIP(hipMemsetAsync(progress, 0, (size_t)grid * 4, s));
@@ -6130,6 +6332,25 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
             else if (a.hot_pred_is_v) VNM_HOT(true, true, true, false);
             else VNM_HOT(true, false, true, false);
 #undef VNM_HOT
+        } else if (hotn) {
+            size_t lds_bytes = (size_t)(a.lds_slots + 2) * 8 * (1 + h->plan.n_words);
+#define VNM_HN(NC_)                                                                                              \
+    do {                                                                                                        \
+        if (h->pred_set) {                                                                                      \
+            VNM_HIP(hipFuncSetAttribute((const void*)agg_hotn_kernel<NC_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+            agg_hotn_kernel<NC_, true><<<grid, AGG_BLOCK, lds_bytes, s>>>(a);                                   \
+        } else {                                                                                                \
+            VNM_HIP(hipFuncSetAttribute((const void*)agg_hotn_kernel<NC_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+            agg_hotn_kernel<NC_, false><<<grid, AGG_BLOCK, lds_bytes, s>>>(a);                                  \
+        }                                                                                                       \
+    } while (0)
+            switch (h->plan.n_cols) {
+                case 3: VNM_HN(3); break;
+                case 4: VNM_HN(4); break;
+                case 5: VNM_HN(5); break;
+                default: VNM_HN(6); break;
+            }
+#undef VNM_HN
         } else if (h->single) {
             size_t lds_bytes = (size_t)(a.lds_slots + 2) * 8 * (1 + h->plan.n_words);
             VNM_HIP(hipFuncSetAttribute((const void*)agg_lds_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
