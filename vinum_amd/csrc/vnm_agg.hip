@@ -1211,8 +1211,18 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hotn_kernel(AggArgs a) {
         __syncthreads();
         const unsigned fill_now = s_fill;
         need_check = fill_now > (unsigned)S / 2;
-        if (spread_state == 0) { spread_state = fill_now <= (unsigned)S / 128 ? 1 : 2; if (spread_state == 1) spread = tid & 7u; }
-        else if (spread_state == 1 && fill_now > (unsigned)S / 8) { spread_state = 2; spread = 0; }
+        // key copies (see hot_slot): with 2 NC + 1 atomics per row the accumulator addresses of a handful of groups are the bottleneck, and
+        // the sweet spot is ~50-110 (group, copy) addresses per word -- a wave's worth; more addresses cost more than they spread
+        // (ms per 5e8 rows, none / 8 / 16 / 32 copies: four columns G = 3: 6.07 / 3.38 / 3.73 / 3.90, G = 7: 4.56 / 3.81 / 3.41 / -,
+        // G = 30: 3.51 / 4.03; six columns G = 3: 8.49 / 5.53 / 5.21 / 6.91, G = 7: 6.26 / 5.04 / 4.73 / -)
+        if (spread_state == 0) {
+            const unsigned cap = (a.debug & 8) ? 8u : 16u;   // (VNM_AGG_DEBUG & 8: at most 8 copies, measurement)
+            unsigned copies = fill_now <= 8 ? 16u : fill_now <= 12 ? 8u : 1u;
+            if (copies > cap) copies = cap;
+            if (fill_now * copies > (unsigned)S / 4) copies = 1;
+            spread_state = copies > 1 ? 1 : 2;
+            spread = tid & (copies - 1);
+        } else if (spread_state == 1 && fill_now > (unsigned)S / 3) { spread_state = 2; spread = 0; }
         if (fill_now > flush_at) {
             hn_fill_counts(a, lacc, stride, tid);
             lds_flush(a, lkey, lacc, S, tid, AGG_BLOCK, &s_new);
