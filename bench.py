@@ -512,7 +512,6 @@ def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream,
                                                     n, ms_l, sp_l, 8.0 * n + 16.0 * state["ng_l"], state["ng_l"])
     out["configs[0] query shape"] = _entry(f"SELECT k,count(*) GROUP BY k; N={n:.3g}, 7 groups (the 1M-row CSV query of configs[0], at scale)",
                                            n, ms, sp, 8.0 * n + 16.0 * state["ng"], state["ng"])
-    del k7
     # ---- configs[4]: ORDER BY v DESC LIMIT 10 and `v*2+1, v-a, a*b` over 1e9 rows (v ~ N(11, 9) seed 2)
     gg = torch.Generator(device=device); gg.manual_seed(2)
     v4 = torch.randn(n, device=device, dtype=torch.float64, generator=gg) * 3.0 + 11.0
@@ -530,6 +529,20 @@ def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream,
         state["outs"] = ops.project_many([("add", ("mul", "v", 2), 1), ("sub", "v", "a"), ("mul", "a", "b")], cols, length=n, stream=stream)
     ms, sp = _measure(torch, lib, ctypes, proj, [b"project_kernel"], steps, warmup + 1)
     out["configs[4] projection"] = _entry(f"projection v*2+1, v-a, a*b over {n:.3g} fp64 rows (one fused kernel)", n, ms, sp, 48.0 * n, n)
+    # ---- the reporting-query shape: few groups, several aggregates over several float64 columns (agg_hotn_kernel)
+    acol4, bcol4 = cols["a"], cols["b"]
+
+    def rep():
+        agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
+                                  [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64()), (L.SUM, 2, pa.float64()), (L.AVG, 3, pa.float64()),
+                                   (L.COUNT_STAR, None, None)])
+        agg.next([k7], [v4col, v4col, acol4, bcol4, None], nrows=n, stream=stream)
+        state["rcols"] = agg.result_device(stream=stream)
+        state["ng"] = agg.result_rows
+    ms, sp = _measure(torch, lib, ctypes, rep, AGG_SPANS, steps, warmup + 1)
+    out["reporting query, 3 columns"] = _entry(f"SELECT k,sum(v),avg(v),sum(a),avg(b),count(*) GROUP BY k; N={n:.3g}, 7 groups, three fp64 input columns "
+                                               "(result columns included)", n, ms, sp, 32.0 * n + 48.0 * state["ng"], state["ng"])
+    del k7, acol4, bcol4
     del v4, ca, cb, cols, v4col
     state.clear()
     # ---- BASELINE configs[3], the ONE-GPU leg: the same query over 60 HBM-resident batches of 2^24 rows streamed into ONE operator

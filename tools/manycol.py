@@ -1,7 +1,7 @@
 """C input columns: SELECT k, sum(c1), ..., sum(cC), count(*) GROUP BY k  (wide partition entries carry key + C values).
 usage: manycol.py N G C"""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, pyarrow as pa
 from vinum_amd import _lib as L, ops
 from vinum_amd.device import DeviceColumn
