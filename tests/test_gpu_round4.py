@@ -496,7 +496,8 @@ def test_small_range_many_columns_split_per_column(program, pred, groups, shape,
 
 @pytest.mark.parametrize("program,pred", [("three_sums", "on_first"), ("three_sums", "none"), ("four_columns_mixed", "on_first"), ("nullable_and_minmax", "none")])
 @pytest.mark.parametrize("groups,shape", [(300_000, "one_batch"), (1_500_000, "one_batch"), (1_500_000, "pairs"), (1_200_000, "two_batches"),
-                                          (1_300_000, "null_keys_later"), (1_400_000, "heavy_keys"), (1_500_000, "sparse_keys")])
+                                          (1_300_000, "null_keys_later"), (1_400_000, "heavy_keys"), (1_500_000, "sparse_keys"),
+                                          (1_100_000, "two_batches_bounded")])
 def test_many_groups_many_columns_split_over_the_dense_path(program, pred, groups, shape, monkeypatch):
     """Round 4: three or more 8-byte input columns over a key the dense path takes are aggregated per column (or per pair of float64
     columns under sums / counts: two-value entries) by the dense path and joined at the end -- by a plain copy when every part
@@ -508,8 +509,10 @@ def test_many_groups_many_columns_split_over_the_dense_path(program, pred, group
     monkeypatch.setenv("VNM_AGG_SPLIT_DENSE_MIN_ROWS", "100000")
     if shape == "pairs":
         monkeypatch.setenv("VNM_AGG_SPLIT_PAIRS_MIN_GROUPS", "1000000")
+    if shape == "two_batches_bounded":
+        monkeypatch.setenv("VNM_SPLIT_PENDING_BYTES", "1")    # (the parts run their final passes per batch instead of keeping the scatter output)
     rng = np.random.default_rng(groups % 977 + len(program) * 5 + len(pred) + len(shape))
-    n = 1_500_000
+    n = 2_400_000 if shape.startswith("two_batches") else 1_500_000    # (a batch joins a waiting final pass from ~1e6 rows on)
     k = rng.integers(0, groups, n).astype(np.int64) - groups // 4
     if shape == "heavy_keys":
         k[rng.random(n) < 0.3] = 17   # one key holds ~30 % of the rows
@@ -529,17 +532,18 @@ def test_many_groups_many_columns_split_over_the_dense_path(program, pred, group
              "four_columns_mixed": [(O.SUM, "a", "sa"), (O.AVG, "b", "ab"), (O.MAX, "d", "md"), (O.COUNT, "c", "cc"), (O.MIN, "c", "lc"), (O.COUNT_STAR, "", "n")],
              "nullable_and_minmax": [(O.MIN, "a", "la"), (O.SUM, "b", "sb"), (O.COUNT, "b", "cb"), (O.SUM, "d", "sd")]}[program]
     predicate = {"on_first": ("a", ">", 64.0), "none": None}[pred]
-    bl = util.sliced_batches(t, 750_000 if shape in ("two_batches", "null_keys_later") else n)
+    bl = util.sliced_batches(t, 1_200_000 if shape.startswith("two_batches") else (750_000 if shape == "null_keys_later" else n))
     L.lib().vnm_set_profiling(1)
     got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, bl, predicate=predicate)
     joins, sorts = _launches(b"agg_split_join"), _launches(b"agg_split_sort")
+    routes = {nm.decode(): _launches(nm) for nm in (b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final", b"agg_split_units")}
     L.lib().vnm_set_profiling(0)
     if shape == "sparse_keys":
         assert joins == 0, joins
     else:
         assert joins == 1, joins
     if shape in ("one_batch", "pairs") or (shape == "two_batches" and program == "three_sums"):
-        assert sorts == 0, sorts        # joined by units of 64 codes: no sort, no gather (generic programs merge their batches' runs
+        assert sorts == 0, (sorts, routes)   # joined by units of 64 codes: no sort, no gather (generic programs merge their batches' runs
                                         # through the table: another order, the sort join)
     util.assert_agg_equal(got, _oracle(O.SINGLE, ["k"], funcs, bl, predicate), funcs, ["k"], exact_float_inputs=("a", "b", "c"),
                           what=f"dense split: {program}, pred {pred}, G={groups} {shape}")

@@ -3616,9 +3616,9 @@ void invalidate_result(vnm_agg* h) {
 }
 
 // ---- partitioned path orchestration -------------------------------------------------------------------
-int env_i64(const char* name, int64_t dflt) {
+int64_t env_i64(const char* name, int64_t dflt) {
     const char* v = getenv(name);
-    return v ? (int)atoll(v) : (int)dflt;
+    return v ? (int64_t)atoll(v) : dflt;
 }
 
 void drop_run(vnm_agg* h) {
@@ -5480,6 +5480,7 @@ int make_parts(vnm_agg* h, int per) {
 }
 
 int next_parts(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs, const vnm_dcol* pred, void* stream) {
+    const bool bound = (int64_t)h->parts.size() * nrows * 14 > env_i64("VNM_SPLIT_PENDING_BYTES", (int64_t)64 << 30);
     for (size_t p = 0; p < h->parts.size(); p++) {
         vnm_agg* c = h->parts[p];
         vnm_dcol in[AGG_MAX_FUNCS];
@@ -5487,6 +5488,9 @@ int next_parts(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* 
         for (int q = 0; q < nf; q++) in[q] = inputs[h->part_funcs[p][q]];
         VNM_TRY(vnm_agg_set_predicate(c, h->pred_set ? 1 : 0, h->pred_op, h->pred_is_float, h->pred_dval, h->pred_ival));
         VNM_TRY(vnm_agg_next_device(c, nrows, keys, in, pred, stream));
+        // every part of the dense path keeps its scatter output (~10-18 bytes per row) for a deferred final pass: many parts over a
+        // very large batch run their final passes right away instead of holding all of that at once
+        if (bound && c->pending) VNM_TRY(complete_pending(c, as_stream(stream)));
     }
     h->rows_seen += nrows;
     return 0;
