@@ -6088,7 +6088,11 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
         VNM_TRY(estimate_groups(h, keys[0], est_rows, &est, s, dense_shape ? &dense_lb : nullptr));
         if (est == 0) {
             if (h->dense_state == 0) VNM_TRY(plan_dense(h, keys[0], est_rows, s));
-            if (h->dense_state == 1 && h->dense_span <= 32 * dense_lb && span_fits) dense_go = true;
+            // (... or, under skew -- duplicates in the sample pull the bound down -- when the bound at least rules out the LDS scans and the
+            // rows outnumber the code range four to one: the passes over the rows dominate whatever G is, the hash partitions would
+            // cost the same, and the HyperLogLog pass (0.8 ms) buys nothing)
+            const bool rows_dominate = dense_lb >= env_i64("VNM_DENSE_SKEW_MIN_LB", 100000) && h->dense_span * 4 <= nrows;
+            if (h->dense_state == 1 && (h->dense_span <= 32 * dense_lb || rows_dominate) && span_fits) dense_go = true;
             else VNM_TRY(estimate_groups(h, keys[0], est_rows, &est, s));   // too sparse (or not a code-able key): full estimate
         }
         if (est) { h->hint = est; h->estimated = true; }
