@@ -449,6 +449,24 @@ def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream,
                                                         n, ms, sp, 16.125 * n + 24.0 * state["ng"], state["ng"])
         state.clear()
         del knull, kb
+        # ... over values that are NOT multiples of 1/128: nearly every add has a rounding error, so the compensation word of a sum
+        # (TwoSum: hi, lo) is touched by nearly every entry of the final pass -- the headline's quantised values (exact adds, which is
+        # what lets --check compare totals bit for bit) never touch it
+        gr = torch.Generator(device=device); gr.manual_seed(11)
+        vreal = torch.randn(n, device=device, dtype=torch.float64, generator=gr) * 20.0 + x_thr
+        vrcol = DeviceColumn.from_torch(vreal)
+
+        def real_values():
+            agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())])
+            agg.set_predicate(">", x_thr)
+            agg.next([kcol], [vrcol, vrcol], pred=vrcol, nrows=n, stream=stream)
+            state["cols"] = agg.result_device(stream=stream)
+            state["ng"] = agg.result_rows
+        ms, sp = _measure(torch, lib, ctypes, real_values, AGG_SPANS, steps, warmup + 1)
+        out["configs[2] over non-quantised values"] = _entry("the headline query (hint-less, result columns included) over v ~ N(X, 20): every add of the compensated sums "
+                                                             "has a rounding error", n, ms, sp, 16.0 * n + 24.0 * state["ng"], state["ng"])
+        state.clear()
+        del vreal, vrcol
     except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down
         out["configs[2] variants"] = {"error": repr(e)}
     # ---- configs[1]
