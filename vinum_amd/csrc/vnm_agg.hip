@@ -4300,7 +4300,7 @@ int launch_dense_final(const DFinalArgs& df, int tb, int out, bool lo64, hipStre
     KernelTimer timer("agg_part_final", s);
 #define VNM_DFIN(TB_, OUT_, LOT_)                                                                                      \
     do {                                                                                                              \
-        const int blk = TB_ >= 13 ? 1024 : 512;                                                                       \
+        const int blk = TB_ >= 13 ? 1024 : (TB_ == 12 ? VNM_DF12_BLOCK : 512);                                       \
         int occ = 0;                                                                                                  \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)dpart_final_kernel<uint16_t, TB_, false, OUT_, LOT_>, blk, 0) != hipSuccess || occ < 1) occ = 1; \
         const int g3 = (int)std::min<int64_t>(df.nfinal, (int64_t)cus * std::min(occ, (int)env_i64("VNM_PA_OCC", 8))); \
@@ -4397,7 +4397,7 @@ int complete_pending(vnm_agg* h, hipStream_t s, int out = DF_RUN, const DFinalAr
             if (pd->tb == 9) dpart_final_kernel<uint16_t, 9, true><<<g3, 512, 0, s>>>(ds);
             else if (pd->tb == 10) dpart_final_kernel<uint16_t, 10, true><<<g3, 512, 0, s>>>(ds);
             else if (pd->tb == 11) dpart_final_kernel<uint16_t, 11, true><<<g3, 512, 0, s>>>(ds);
-            else if (pd->tb == 12) dpart_final_kernel<uint16_t, 12, true><<<g3, 512, 0, s>>>(ds);
+            else if (pd->tb == 12) dpart_final_kernel<uint16_t, 12, true><<<g3, VNM_DF12_BLOCK, 0, s>>>(ds);
             else dpart_final_kernel<uint16_t, 13, true><<<g3, 1024, 0, s>>>(ds);
             if (out != DF_COLS) ds.n_out = 0;
             dpart_merge_kernel<<<(int)(pd->nfinal << (pd->tb - 9)), 512, 0, s>>>(ds, pd->tb);
@@ -4743,7 +4743,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         KernelTimer timer("agg_part_final", s);
 #define VNM_DFINS(TB_)                                                                                                 \
     do {                                                                                                              \
-        const int blk = TB_ >= 13 ? 1024 : 512;                                                                       \
+        const int blk = TB_ >= 13 ? 1024 : (TB_ == 12 ? VNM_DF12_BLOCK : 512);                                       \
         int occ = 0;                                                                                                  \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)dpart_final_kernel<uint16_t, TB_, true>, blk, 0) != hipSuccess || occ < 1) occ = 1; \
         const int g3 = (int)std::min<int64_t>(nfinal * fsplits, (int64_t)cus * std::min(occ, 8));                     \
