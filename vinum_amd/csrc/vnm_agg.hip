@@ -5842,15 +5842,21 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                     // two scatter levels are needed anyway -- instead of wide entries through hash partitions; parts of the dense path
                     // over one code map are joined by units of 64 codes (collapse_parts: no sorts, no random gathers).
                     // 5e8 rows, 3 / 6 columns: G = 1e6 20.0 / 37.6 -> 13.9 / 26.8 ms, G = 1e8 30.1 / 360 -> 24.7 / 44.8.
-                    if (h->plan.n_cols >= 3 && nrows >= env_i64("VNM_AGG_SPLIT_DENSE_MIN_ROWS", 1 << 24) && h->dense_state == 1 &&
+                    if (nrows >= env_i64("VNM_AGG_SPLIT_DENSE_MIN_ROWS", 1 << 24) && h->dense_state == 1 &&
                         h->dense_span <= 32 * h->hint && h->dense_span <= 4 * nrows && getenv("VNM_AGG_NO_SPLIT_DENSE") == nullptr) {
-                        bool pairs = h->hint >= env_i64("VNM_AGG_SPLIT_PAIRS_MIN_GROUPS", 4000000);
-                        for (int i = 0; i < h->n_funcs && pairs; i++) {
+                        bool sums = true;   // every function a sum / count of a plain float64 column: what the two-value entries carry
+                        for (int i = 0; i < h->n_funcs && sums; i++) {
                             const int f = h->c_funcs[i];
-                            pairs = f == VNM_COUNT_STAR || ((f == VNM_SUM || f == VNM_AVG || f == VNM_COUNT) && inputs[i].type == VNM_F64 && !inputs[i].validity);
+                            sums = f == VNM_COUNT_STAR || ((f == VNM_SUM || f == VNM_AVG || f == VNM_COUNT) && inputs[i].type == VNM_F64 && !inputs[i].validity);
                         }
-                        VNM_TRY(make_parts(h, pairs ? 2 : 1));
-                        return next_parts(h, nrows, keys, inputs, pred, stream);
+                        const bool pairs = sums && h->hint >= env_i64("VNM_AGG_SPLIT_PAIRS_MIN_GROUPS", 4000000);
+                        // (TWO columns: the two-value entries themselves from ~1.5e6 groups on -- two scatter levels -- and one part per column
+                        // below: 5e8 rows, G = 1e4 / 1e5 / 5e5 / 1e6: 8.2 / 10.9 / 14.8 / 10.1 -> 7.3 / 7.8 / 8.1 / 8.7 ms; 2e6: 9.9 against 11.4)
+                        const bool split = h->plan.n_cols >= 3 || !sums || (!pairs && h->hint <= env_i64("VNM_AGG_SPLIT_TWO_MAX_GROUPS", 1500000));
+                        if (split) {
+                            VNM_TRY(make_parts(h, pairs ? 2 : 1));
+                            return next_parts(h, nrows, keys, inputs, pred, stream);
+                        }
                     }
                 }
                 if (many) {
