@@ -510,6 +510,7 @@ def test_many_groups_many_columns_split_over_the_dense_path(program, pred, group
     monkeypatch.setenv("VNM_AGG_SPLIT_DENSE_MIN_ROWS", "100000")
     if shape == "pairs":
         monkeypatch.setenv("VNM_AGG_SPLIT_PAIRS_MIN_GROUPS", "1000000")
+        monkeypatch.setenv("VNM_AGG_PAIRS_MIN_ROWS", "100000")     # (pairs are for batches of 2^27 rows and more)
     if shape == "two_batches_bounded":
         monkeypatch.setenv("VNM_SPLIT_PENDING_BYTES", "1")    # (the parts run their final passes per batch instead of keeping the scatter output)
     rng = np.random.default_rng(groups % 977 + len(program) * 5 + len(pred) + len(shape))
@@ -588,3 +589,75 @@ def test_scan_over_three_to_six_float_columns(ncols, pred, groups, shape, monkey
     assert scans >= len(bl), scans
     util.assert_agg_equal(got, _oracle(O.SINGLE, ["k"], funcs, bl, predicate), funcs, ["k"], exact_float_inputs=tuple(names),
                           what=f"hotn: {ncols} columns, pred {pred}, G={groups} {shape}")
+
+
+@pytest.mark.parametrize("pred", ["on_input", "none"])
+@pytest.mark.parametrize("route", ["dense_per_column", "dense_range_too_wide_for_one_batch", "small_range_per_column", "few_groups_scan", "sparse_keys",
+                                   "mixed_types", "two_columns", "shape_changes_midstream"])
+def test_async_stream_with_several_input_columns(route, pred, monkeypatch):
+    """Stream mode over SEVERAL input columns (round 4): the operator records the batches and chooses the path from the stream's total
+    row count -- a code range too wide for one 2^24-row batch is fine for the stream (G = 1e8, three columns, 30 batches: 315 ->
+    31 ms) -- cuts the program into parts when a rule applies and hands them the batches one by one; the parts record them in turn
+    (one launch per part and sync point) or, for programs the segment kernels do not take, run them right away.  Same result as
+    the oracle fed batch by batch and as the synchronous mode; ragged / tiny / empty batches, a second sync point, a batch of another
+    shape in the middle.  base_aggregate.cpp:23-45."""
+    from oracle import oracle as O
+    from vinum_amd import _lib as L, ops
+    from vinum_amd.device import DeviceColumn
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    monkeypatch.setenv("VNM_AGG_SPLIT_DENSE_MIN_ROWS", "1000000")
+    groups = {"dense_per_column": 300_000, "dense_range_too_wide_for_one_batch": 1_200_000, "small_range_per_column": 3_000, "few_groups_scan": 7,
+              "sparse_keys": 200_000, "mixed_types": 400_000, "two_columns": 500_000, "shape_changes_midstream": 300_000}[route]
+    mult = 7919 if route == "sparse_keys" else 1
+    rng = np.random.default_rng(len(route) * 17 + len(pred))
+    sizes = [600_000, 262_144, 300_001, 77, 8192, 123_457, 499_999, 16_384 + 2, 650_000, 0]
+    if route == "dense_range_too_wide_for_one_batch":    # 2^21 codes: 13 times a batch's rows, half the stream's (one sync point: the result)
+        sizes = [160_000] * 23 + [160_001]
+    batches = []
+    for i, n in enumerate(sizes):
+        nullable = route == "shape_changes_midstream" and i == 5
+        cols = {"k": pa.array(rng.integers(0, groups, n).astype(np.int64) * mult - 17),
+                "a": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0),
+                "b": pa.array(rng.integers(-2**13, 2**13, n).astype(np.float64) / 64.0, mask=(rng.random(n) < 0.1) if nullable else None),
+                "c": pa.array(rng.integers(0, 2**10, n).astype(np.float64) / 8.0),
+                "d": pa.array(rng.integers(-1000, 1000, n).astype(np.int64))}
+        batches.append(pa.RecordBatch.from_pydict(cols))
+    funcs = {"mixed_types": [(O.SUM, "a", "sa"), (O.MAX, "d", "md"), (O.AVG, "c", "ac"), (O.SUM, "d", "sd"), (O.COUNT_STAR, "", "n")],
+             "two_columns": [(O.SUM, "a", "sa"), (O.AVG, "c", "ac"), (O.COUNT_STAR, "", "n")]}.get(
+                 route, [(O.SUM, "a", "sa"), (O.AVG, "b", "ab"), (O.SUM, "c", "sc"), (O.COUNT, "b", "cb"), (O.COUNT_STAR, "", "n")])
+    predicate = {"on_input": ("a", ">", 64.0), "none": None}[pred]
+    names = batches[0].schema.names
+    fspec = [(f, names.index(col) if col else None, batches[0].schema.field(col).type if col else None) for f, col, _ in funcs]
+
+    def run(stream_mode):
+        agg = ops.DeviceAggregate(O.SINGLE, [pa.int64()], fspec, stream_mode=stream_mode)
+        if predicate:
+            agg.set_predicate(predicate[1], predicate[2])
+        for i, b in enumerate(batches):
+            dc = {nm: DeviceColumn.from_arrow(b.column(j)) for j, nm in enumerate(names)}
+            agg.next([dc["k"]], [dc[col] if col else None for _, col, _ in funcs], pred=dc[predicate[0]] if predicate else None, nrows=b.num_rows)
+            if stream_mode and i == 6 and route != "dense_range_too_wide_for_one_batch":
+                agg.sync()
+        dcols = agg.result_device([0])
+        res = agg.result_arrays([0], ["k"], [f[2] for f in funcs])
+        dev = pa.RecordBatch.from_arrays([c.to_arrow() for c in dcols], names=res.schema.names)
+        util.assert_batches_equal(dev, res, key_names=["k"], what="device finalisation vs host finalisation")
+        agg.close()
+        return res
+
+    L.lib().vnm_set_profiling(1)
+    got = run(True)
+    p1, joins = _launches(b"agg_part_scatter1"), _launches(b"agg_split_join")
+    routes = {nm.decode(): _launches(nm) for nm in (b"agg_scan", b"agg_part_scatter2", b"agg_part_final", b"agg_estimate")}
+    L.lib().vnm_set_profiling(0)
+    if route == "dense_per_column":
+        assert joins == 1 and p1 == 2 * 3, (joins, p1, routes)      # three parts, one launch each per sync point -- not one per batch
+    elif route == "dense_range_too_wide_for_one_batch":
+        assert joins == 1 and p1 == 3, (joins, p1, routes)
+    elif route == "two_columns":
+        assert joins == 1 and p1 == 2 * 2, (joins, p1)
+    elif route in ("few_groups_scan", "sparse_keys"):
+        assert joins == 0, joins
+    exp = _oracle(O.SINGLE, ["k"], funcs, batches, predicate)
+    util.assert_agg_equal(got, exp, funcs, ["k"], exact_float_inputs=("a", "b", "c"), what=f"async stream, several columns, {route}, pred {pred}")
+    util.assert_agg_equal(run(False), exp, funcs, ["k"], exact_float_inputs=("a", "b", "c"), what=f"the same stream batch by batch, {route}, pred {pred}")

@@ -3504,7 +3504,8 @@ struct vnm_agg {
     // to the device together as the segments of one logical batch -- at vnm_agg_sync / finish / result, when 2^30 rows or 256
     // batches are waiting, or when a batch of another shape arrives.  No host read-back, allocation or launch per next().
     bool async = false;
-    struct QBatch { int64_t nrows; vnm_dcol key, col, pred; };
+    struct QBatch { int64_t nrows; vnm_dcol key, col, pred; std::vector<vnm_dcol> ins; };   // ins: one column per function (several input columns)
+    bool q_multi = false;                  // the waiting batches carry several input columns (they are cut into parts when they go to the device)
     std::vector<QBatch> q;
     int64_t q_rows = 0;
     bool q_pred_is_v = false;
@@ -5474,6 +5475,7 @@ int make_parts(vnm_agg* h, int per) {
         c->hint = h->hint;
         c->estimated = h->estimated;
         c->split_tried = true;
+        c->async = h->async;   // (a stream: the parts record their batches like the parent would -- one launch per part over all of them)
         h->parts.push_back(c);
     }
     return 0;
@@ -5692,7 +5694,7 @@ int vnm_agg_estimate_groups(vnm_agg* h, int64_t nrows, const vnm_dcol* key, int6
 constexpr int VNM_RC_SINGLY = 77;
 #define VNM_SEG_ONLY(what) do { if (h->segs_active || h->kn_valid) { if (getenv("VNM_AGG_TRACE")) fprintf(stderr, "[agg] %s: not this way (%s)\n", h->kn_valid ? "nullable key through the dense path" : "stream segments", what); return VNM_RC_SINGLY; } } while (0)
 
-static bool queueable(const vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs, const vnm_dcol* pred, bool* pred_is_v);
+static bool queueable(const vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs, const vnm_dcol* pred, bool* pred_is_v, bool* multi);
 
 static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs,
                             const vnm_dcol* pred, void* stream) {
@@ -5712,8 +5714,8 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
         getenv("VNM_AGG_NO_DENSE_KN") == nullptr) {
         vnm_dcol k2 = keys[0];
         k2.validity = nullptr;
-        bool piv = false;
-        if (queueable(h, nrows, &k2, inputs, pred, &piv)) {
+        bool piv = false, multi = false;
+        if (queueable(h, nrows, &k2, inputs, pred, &piv, &multi) && !multi) {   // (the hot shape: one input column)
             h->kn_valid = keys[0].validity; h->kn_off = keys[0].offset;
             const int rc = next_device_impl(h, nrows, &k2, inputs, pred, stream);
             h->kn_valid = nullptr;
@@ -5835,6 +5837,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                     // row and column at the scan's rate: 3.3 / 4.9 / 9.8 ms incl. the join over a few thousand groups).
                     if (h->dense_state == 2 && h->hint <= (1 << DP_TBITS_MAX)) {
                         VNM_TRY(make_parts(h, 1));
+                        if (h->segs_active) return VNM_RC_SINGLY;   // (the waiting batches of a stream: one by one into the parts, which record them)
                         return next_parts(h, nrows, keys, inputs, pred, stream);
                     }
                     // MANY groups over a key the dense path takes, three or more columns: the dense path per column (16-byte entries,
@@ -5849,18 +5852,24 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                             const int f = h->c_funcs[i];
                             sums = f == VNM_COUNT_STAR || ((f == VNM_SUM || f == VNM_AVG || f == VNM_COUNT) && inputs[i].type == VNM_F64 && !inputs[i].validity);
                         }
-                        const bool pairs = sums && h->hint >= env_i64("VNM_AGG_SPLIT_PAIRS_MIN_GROUPS", 4000000);
+                        // (the two-value entries have no deferred final pass and take no stream segments: every batch ends in a run that is
+                        // merged into the table -- 30 x 2^24 rows, three columns, G = 1e7: 107 ms against 17 for the same rows as one batch.
+                        // They are for BIG batches; a stream's batches go per column, whose parts record and defer like any one-column stream)
+                        const bool big = !h->segs_active && nrows >= env_i64("VNM_AGG_PAIRS_MIN_ROWS", (int64_t)1 << 27);
+                        const bool pairs = sums && big && h->hint >= env_i64("VNM_AGG_SPLIT_PAIRS_MIN_GROUPS", 4000000);
                         // (TWO columns: the two-value entries themselves from ~1.5e6 groups on -- two scatter levels -- and one part per column
                         // below: 5e8 rows, G = 1e4 / 1e5 / 5e5 / 1e6: 8.2 / 10.9 / 14.8 / 10.1 -> 7.3 / 7.8 / 8.1 / 8.7 ms; 2e6: 9.9 against 11.4)
-                        const bool split = h->plan.n_cols >= 3 || !sums || (!pairs && h->hint <= env_i64("VNM_AGG_SPLIT_TWO_MAX_GROUPS", 1500000));
+                        const bool split = h->plan.n_cols >= 3 || !sums || !big || (!pairs && h->hint <= env_i64("VNM_AGG_SPLIT_TWO_MAX_GROUPS", 1500000));
                         if (split) {
                             VNM_TRY(make_parts(h, pairs ? 2 : 1));
+                            if (h->segs_active) return VNM_RC_SINGLY;
                             return next_parts(h, nrows, keys, inputs, pred, stream);
                         }
                     }
                 }
                 if (many) {
                     VNM_TRY(make_parts(h, (int)env_i64("VNM_AGG_SPLIT_COLS", any_null ? 5 : 6)));
+                    if (h->segs_active) return VNM_RC_SINGLY;
                     return next_parts(h, nrows, keys, inputs, pred, stream);
                 }
             }
@@ -6414,7 +6423,11 @@ static int flush_queue(vnm_agg* h, void* stream) {
     int rc = VNM_RC_SINGLY;
     auto one = [&](const vnm_agg::QBatch& b, int64_t n) {
         vnm_dcol in[AGG_MAX_FUNCS];
-        for (int i = 0; i < h->n_funcs; i++) { memset(&in[i], 0, sizeof(vnm_dcol)); if (h->func_col[i] >= 0) in[i] = b.col; }
+        for (int i = 0; i < h->n_funcs; i++) {
+            memset(&in[i], 0, sizeof(vnm_dcol));
+            if (!b.ins.empty()) in[i] = b.ins[i];
+            else if (h->func_col[i] >= 0) in[i] = b.col;
+        }
         return next_device_impl(h, n, &b.key, in, h->pred_set ? &b.pred : nullptr, stream);
     };
     if (q.size() > 1 && getenv("VNM_AGG_NO_SEGMENTS") == nullptr) {
@@ -6431,10 +6444,25 @@ static int flush_queue(vnm_agg* h, void* stream) {
 
 // does this batch have the shape whose kernels take stream segments (VSeg)?  The hot shape: one plain 8-byte key, {COUNT(*), COUNT,
 // SUM, AVG} of ONE plain float64 column, a plain float64 predicate column or none.
-static bool queueable(const vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs, const vnm_dcol* pred, bool* pred_is_v) {
-    if (!h->single || h->plan.n_keys != 1 || h->plan.n_cols != 1 || h->inner || !h->parts.empty() || h->tuple_mode || h->expr_col >= 0) return false;
+static bool queueable(const vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs, const vnm_dcol* pred, bool* pred_is_v, bool* multi) {
+    *multi = false;
+    if (!h->single || h->plan.n_keys != 1 || h->plan.n_cols < 1 || h->inner || h->tuple_mode || h->expr_col >= 0) return false;
     if (nrows <= 0 || nrows >= (1LL << 30)) return false;
     auto plain8 = [](const vnm_dcol& c) { return type_width(c.type) == 8 && !c.validity && (c.offset & 1) == 0 && ((uintptr_t)c.values & 15) == 0; };
+    if (h->plan.n_cols > 1) {
+        // SEVERAL plain 8-byte input columns over a plain int64 / uint64 key (round 4): the batches wait so that the path is chosen from
+        // the stream's total row count (a 2^24-row batch alone is too short for a 2^27-code range: three columns, G = 1e8, 30 batches:
+        // 315 ms through the hash partitions); when they go to the device the program is cut into parts (next_parts), which record
+        // the batches in turn and launch once each -- or they go one by one, as before, where no part rule applies
+        if (h->rank_aligned || !plain8(keys[0]) || keys[0].type != h->plan.key_types[0] || (keys[0].type != VNM_I64 && keys[0].type != VNM_U64)) return false;
+        for (int i = 0; i < h->n_funcs; i++)
+            if (h->func_col[i] >= 0 && (!plain8(inputs[i]) || (inputs[i].type != VNM_F64 && inputs[i].type != VNM_I64 && inputs[i].type != VNM_U64))) return false;
+        if (h->pred_set && (!pred || !plain8(*pred) || pred->type != VNM_F64)) return false;
+        *pred_is_v = false;
+        *multi = true;
+        return true;
+    }
+    if (!h->parts.empty()) return false;
     const vnm_dcol& col = inputs[h->col_first_func[0]];
     if (!plain8(keys[0]) || keys[0].type != h->plan.key_types[0] || !plain8(col) || col.type != VNM_F64) return false;
     for (int o = 0; o < h->plan.n_ops; o++) {
@@ -6455,13 +6483,15 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
                         const vnm_dcol* pred, void* stream) {
     if (!h) return set_error("vnm_agg_next_device: null handle");
     if (h->async && keys && inputs) {
-        bool piv = false;
-        if (queueable(h, nrows, keys, inputs, pred, &piv) && (h->q.empty() || piv == h->q_pred_is_v)) {
+        bool piv = false, multi = false;
+        if (queueable(h, nrows, keys, inputs, pred, &piv, &multi) && (h->q.empty() || (piv == h->q_pred_is_v && multi == h->q_multi))) {
             // (the first batch waits like any other: the estimates and the code range of the path are taken from the first SEGMENT
             // when the waiting batches are processed)
             if (h->q_rows + nrows > (1LL << 30) || h->q.size() >= 256) VNM_TRY(flush_queue(h, stream));
             vnm_agg::QBatch b{};
             b.nrows = nrows; b.key = keys[0]; b.col = inputs[h->col_first_func[0]];
+            if (multi) b.ins.assign(inputs, inputs + h->n_funcs);
+            h->q_multi = multi;
             if (h->pred_set) b.pred = *pred;
             h->q.push_back(b);
             h->q_rows += nrows;
@@ -6477,6 +6507,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
 int vnm_agg_set_async(vnm_agg* h, int enabled) {
     if (!h) return set_error("vnm_agg_set_async: null handle");
     if (!enabled && !h->q.empty()) return set_error("vnm_agg_set_async: batches are waiting (call vnm_agg_sync first)");
+    for (vnm_agg* c : h->parts) VNM_TRY(vnm_agg_set_async(c, enabled));
     h->async = enabled != 0;
     return 0;
 }
@@ -6484,6 +6515,7 @@ int vnm_agg_set_async(vnm_agg* h, int enabled) {
 int vnm_agg_sync(vnm_agg* h, void* stream) {
     if (!h) return set_error("vnm_agg_sync: null handle");
     VNM_TRY(flush_queue(h, stream));
+    for (vnm_agg* c : h->parts) VNM_TRY(flush_queue(c, stream));   // (the parts of a split program record their batches themselves)
     VNM_HIP(hipStreamSynchronize(as_stream(stream)));
     return 0;
 }
