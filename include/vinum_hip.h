@@ -183,7 +183,10 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
  * dense path's code range are sampled from the FIRST waiting batch; errors of a waiting batch surface in the call that processes it.
  * CONTRACT: the buffers of every batch passed while async is on must stay alive and unchanged until the next vnm_agg_sync /
  * vnm_agg_finish / vnm_agg_result_* / vnm_agg_dense_table call on the handle returns.  Results are identical to the synchronous
- * mode (same kernels, same merges).  Default: off. */
+ * mode (same kernels, same merges).  Default: off.
+ * Batches over SEVERAL plain 8-byte input columns (int64 / uint64 key) are recorded too: when they go to the device the path is chosen
+ * from the stream's total row count, the program is cut into one part per input column where a rule applies (the parts record the
+ * batches in turn and launch once each), and otherwise the batches are processed one by one as in the synchronous mode. */
 int vnm_agg_set_async(vnm_agg* h, int enabled);
 /* processes every waiting batch and waits for `stream` */
 int vnm_agg_sync(vnm_agg* h, void* stream);
