@@ -588,6 +588,27 @@ def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream,
         out[f"configs[3] one-GPU leg, {tag}"] = _entry(
             f"{nb} batches x 2^24 rows (HBM-resident) streamed into one operator, result columns included; {tag}", nb * B, ms, sp,
             16.0 * nb * B + 24.0 * state["ng"], state["ng"], {"batches": nb, "ms_per_batch": ms / nb})
+        if gs == 1_000_000:
+            # ... and with THREE input columns: the operator records the batches, cuts the program into one part per column from the
+            # stream's total rows, the parts record in turn and launch once each
+            g3 = torch.Generator(device=device); g3.manual_seed(5)
+            c2 = torch.randint(0, 1 << 14, (nb * B,), device=device, dtype=torch.int64, generator=g3).to(torch.float64) / 128.0
+            c3 = torch.randint(0, 1 << 14, (nb * B,), device=device, dtype=torch.int64, generator=g3).to(torch.float64) / 128.0
+            parts3 = [(p_[0], p_[1], DeviceColumn.from_torch(c2[i * B:(i + 1) * B]), DeviceColumn.from_torch(c3[i * B:(i + 1) * B])) for i, p_ in enumerate(parts)]
+
+            def streamed3():
+                agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()],
+                                          [(L.SUM, 1, pa.float64()), (L.AVG, 2, pa.float64()), (L.SUM, 3, pa.float64()), (L.COUNT_STAR, None, None)], stream_mode=True)
+                agg.set_predicate(">", x_thr)
+                for kc_, a_, b_, c_ in parts3:
+                    agg.next([kc_], [a_, b_, c_, None], pred=a_, nrows=B, stream=stream)
+                state["cols"] = agg.result_device(stream=stream)
+                state["ng"] = agg.result_rows
+            ms, sp = _measure(torch, lib, ctypes, streamed3, AGG_SPANS + [b"agg_split_join"], 2, 1)
+            out["configs[3] one-GPU leg, G=1e6, three input columns"] = _entry(
+                f"{nb} batches x 2^24 rows streamed into one operator: SELECT k,sum(a),avg(b),sum(c),count(*) WHERE a>{x_thr} GROUP BY k; G=1e6, result columns included",
+                nb * B, ms, sp, 32.0 * nb * B + 48.0 * state["ng"], state["ng"], {"batches": nb})
+            del parts3, c2, c3
         del parts, kt, vt, kg
     state.clear()
     # ---- SURVEY.md 8d's second line: END TO END from HOST memory -- Arrow record batches in pageable host memory through the
