@@ -661,3 +661,83 @@ def test_async_stream_with_several_input_columns(route, pred, monkeypatch):
     exp = _oracle(O.SINGLE, ["k"], funcs, batches, predicate)
     util.assert_agg_equal(got, exp, funcs, ["k"], exact_float_inputs=("a", "b", "c"), what=f"async stream, several columns, {route}, pred {pred}")
     util.assert_agg_equal(run(False), exp, funcs, ["k"], exact_float_inputs=("a", "b", "c"), what=f"the same stream batch by batch, {route}, pred {pred}")
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("VNM_FUZZ_SEEDS_COLS", "48")))))
+def test_random_programs_over_several_columns_vs_oracle(seed, monkeypatch):
+    """Seeded differential test over the multi-column routes of round 4, in combination: 2 ... 7 input columns of float64 / int64 / uint64,
+    some nullable, any function per column; few groups (agg_hotn_kernel or the interpreted scan), a few thousand in a small range (one LDS
+    scan per column), many over a dense key (dense path per column or pair, unit join / sort join), sparse keys (wide entries); one to
+    four ragged batches, synchronous or stream mode, heavy keys, NULL keys in a later batch, a predicate on an input or another column.
+    Device-finalised result columns and the host finaliser over the partial state must both equal the oracle."""
+    from oracle import oracle as O
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    rng = np.random.default_rng(91_000 + seed)
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    monkeypatch.setenv("VNM_AGG_SPLIT_DENSE_MIN_ROWS", str(int(rng.choice([200_000, 600_000]))))
+    if rng.random() < 0.4:
+        monkeypatch.setenv("VNM_AGG_SPLIT_PAIRS_MIN_GROUPS", "1000000")
+        monkeypatch.setenv("VNM_AGG_PAIRS_MIN_ROWS", "200000")
+    if rng.random() < 0.15:
+        monkeypatch.setenv("VNM_SPLIT_PENDING_BYTES", "1")
+    groups = int(rng.choice([5, 11, 300, 3_000, 7_000, 40_000, 400_000, 1_500_000]))
+    ncols = int(rng.integers(2, 8))
+    nb = int(rng.choice([1, 1, 2, 4]))
+    sizes = [int(rng.choice([0, 77, 8192, 150_001, 400_000])) for _ in range(nb)]
+    sizes[0] = int(rng.choice([300_000, 700_000, 1_000_001]))
+    sparse = rng.random() < 0.2
+    heavy = rng.random() < 0.2
+    null_keys_later = nb > 1 and rng.random() < 0.25
+    all_float = rng.random() < 0.5
+    stream_mode = bool(rng.random() < 0.5)
+    types = [pa.float64() if all_float or rng.random() < 0.6 else (pa.int64() if rng.random() < 0.7 else pa.uint64()) for _ in range(ncols)]
+    nullable = [(not all_float) and rng.random() < 0.2 for _ in range(ncols)]
+    names = ["k"] + [f"c{i}" for i in range(ncols)] + ["p"]
+    batches = []
+    for bi, n in enumerate(sizes):
+        k = rng.integers(0, groups, n).astype(np.int64) * (1_000_003 if sparse else 1) - 5
+        if heavy and n:
+            k[rng.random(n) < 0.3] = 1
+        kmask = (rng.random(n) < 0.05) if (null_keys_later and bi > 0 and n) else None
+        cols = {"k": pa.array(k, mask=kmask)}
+        for i in range(ncols):
+            m = (rng.random(n) < 0.1) if nullable[i] and n else None
+            if types[i] == pa.float64():
+                cols[f"c{i}"] = pa.array(rng.integers(-2**13, 2**13, n).astype(np.float64) / (64.0 * 2 ** (i % 3)), mask=m)
+            elif types[i] == pa.int64():
+                cols[f"c{i}"] = pa.array(rng.integers(-2**40, 2**40, n).astype(np.int64), mask=m)
+            else:
+                cols[f"c{i}"] = pa.array(rng.integers(0, 2**41, n).astype(np.uint64), mask=m)
+        cols["p"] = pa.array(rng.integers(0, 2**12, n).astype(np.float64) / 64.0)
+        batches.append(pa.RecordBatch.from_pydict(cols))
+    kinds = [O.SUM, O.AVG, O.COUNT] if all_float else [O.SUM, O.AVG, O.COUNT, O.MIN, O.MAX]
+    funcs = []
+    for i in range(ncols):
+        for f in rng.choice(kinds, size=int(rng.integers(1, 3)), replace=False):
+            funcs.append((int(f), f"c{i}", f"f{len(funcs)}"))
+    if rng.random() < 0.6:
+        funcs.append((O.COUNT_STAR, "", "n"))
+    funcs = funcs[:14]
+    predicate = None
+    r = rng.random()
+    if r < 0.3:
+        predicate = ("p", ">", 20.0)
+    elif r < 0.6 and types[0] == pa.float64() and not nullable[0]:
+        predicate = ("c0", ">", 0.0)
+    hint = int(rng.choice([0, 0, groups]))
+    fspec = [(f, names.index(col) if col else None, batches[0].schema.field(col).type if col else None) for f, col, _ in funcs]
+    agg = ops.DeviceAggregate(O.SINGLE, [pa.int64()], fspec, expected_groups=hint, stream_mode=stream_mode)
+    if predicate:
+        agg.set_predicate(predicate[1], predicate[2])
+    for b in batches:
+        dc = {nm: DeviceColumn.from_arrow(b.column(j)) for j, nm in enumerate(names)}
+        agg.next([dc["k"]], [dc[col] if col else None for _, col, _ in funcs], pred=dc[predicate[0]] if predicate else None, nrows=b.num_rows)
+    what = (f"seed {seed}: G~{groups} C={ncols} types={[str(t) for t in types]} nullable={nullable} sparse={sparse} heavy={heavy} null_keys_later={null_keys_later} "
+            f"stream={stream_mode} hint={hint} pred={predicate} sizes={sizes} funcs={[(f, c) for f, c, _ in funcs]}")
+    dcols = agg.result_device([0])
+    res = agg.result_arrays([0], ["k"], [f[2] for f in funcs])
+    dev = pa.RecordBatch.from_arrays([c.to_arrow() for c in dcols], names=res.schema.names)
+    util.assert_batches_equal(dev, res, key_names=["k"], what=what + ": device result columns vs host finalisation")
+    agg.close()
+    util.assert_agg_equal(res, _oracle(O.SINGLE, ["k"], funcs, batches, predicate), funcs, ["k"], exact_float_inputs=tuple(f"c{i}" for i in range(ncols)), what=what)
