@@ -1,5 +1,5 @@
 """C input columns: SELECT k, sum(c1), ..., sum(cC), count(*) GROUP BY k  (wide partition entries carry key + C values).
-usage: manycol.py N G C"""
+usage: manycol.py N G C [int]"""
 import sys, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, pyarrow as pa
@@ -9,7 +9,8 @@ n = int(float(sys.argv[1])); G = int(float(sys.argv[2])); C = int(sys.argv[3])
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(1)
 k = torch.randint(0, G, (n,), device=dev, dtype=torch.int64, generator=g)
-cols = [torch.randint(0, 2**14, (n,), device=dev, dtype=torch.int64, generator=g).to(torch.float64) / 128.0 for _ in range(C)]
+INT = len(sys.argv) > 4 and sys.argv[4] == "int"     # int64 columns (128-bit sums) instead of float64
+cols = [torch.randint(0, 2**14, (n,), device=dev, dtype=torch.int64, generator=g) if INT else torch.randint(0, 2**14, (n,), device=dev, dtype=torch.int64, generator=g).to(torch.float64) / 128.0 for _ in range(C)]
 ck = DeviceColumn.from_torch(k)
 cc = [DeviceColumn.from_torch(c) for c in cols]
 import ctypes
@@ -17,7 +18,7 @@ lib = L.lib()
 for rep in range(3):
     lib.vnm_set_profiling(1)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1 + i, pa.float64()) for i in range(C)] + [(L.COUNT_STAR, None, None)],
+    agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1 + i, pa.int64() if INT else pa.float64()) for i in range(C)] + [(L.COUNT_STAR, None, None)],
                               expected_groups=G)
     agg.next([ck], cc + [None], nrows=n)
     ng = agg.finish()

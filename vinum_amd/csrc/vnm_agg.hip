@@ -171,6 +171,11 @@ struct AggArgs {
     int hn_n_copy;
     int hn_w_copy[7];
     int hn_pred_col;    // the predicate column is this input column (-1: a column of its own, a.pred)
+    int hn_ctype[6];    // VNM_F64 / VNM_I64 / VNM_U64
+    int hn_iw[6][4];    // integer sums of the column: word of A_SUM_I64 / A_SUM_LO32 / A_SUM_HI32S / A_SUM_HI32U (-1: absent)
+    int hn_any_int;
+    int hn_wmm[6][2];   // MIN / MAX words of the column (-1: absent)
+    int hn_any_mm;
 };
 
 // ---- global table primitives ------------------------------------------------------------------------
@@ -1074,15 +1079,31 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hot_seg_kernel(AggArgs a) {
 // agg_hot_kernel: 16-byte loads of row pairs, the next tile's loads issued into the registers of the chunk just consumed,
 // straight-line accumulation -- and ONE count atomic per row whatever the number of COUNT / AVG functions: without NULLs every
 // count is the row count, the other count words are copied from it before a flush (hn_fill_counts).
-template <int NC>
+template <int NC, bool PLAIN>   // PLAIN: float64 columns under sums and counts only (no integer sums, no MIN / MAX: their tests cost the plain case 5-13 %)
 __device__ __forceinline__ void hn_accumulate(const AggArgs& a, uint64_t* lacc, int stride, int slot, const uint64_t* v) {
     __hip_atomic_fetch_add(&lacc[a.hn_w_base * stride + slot], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const int w = a.hn_w_sum[c];
-        if (w < 0) continue;
-        if (a.hot_comp) l_add_f64c(&lacc[w * stride + slot], stride, __longlong_as_double((long long)v[c]));
-        else __hip_atomic_fetch_add((double*)&lacc[w * stride + slot], __longlong_as_double((long long)v[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (w >= 0) {
+            const int ct = PLAIN ? VNM_F64 : a.hn_ctype[c];
+            const double x = ct == VNM_F64 ? __longlong_as_double((long long)v[c]) : (ct == VNM_U64 ? (double)v[c] : (double)(int64_t)v[c]);
+            if (a.hot_comp) l_add_f64c(&lacc[w * stride + slot], stride, x);
+            else __hip_atomic_fetch_add((double*)&lacc[w * stride + slot], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (!PLAIN && a.hn_any_int) {   // int64 / uint64 sums: the 128-bit sum's 32-bit lanes (agg_funcs.h:366-389: decimal128 on overflow), or the plain 64-bit word
+            const int* iw = a.hn_iw[c];
+            if (iw[0] >= 0) __hip_atomic_fetch_add(&lacc[iw[0] * stride + slot], v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (iw[1] >= 0) __hip_atomic_fetch_add(&lacc[iw[1] * stride + slot], v[c] & 0xFFFFFFFFULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (iw[2] >= 0) __hip_atomic_fetch_add(&lacc[iw[2] * stride + slot], (uint64_t)((int64_t)v[c] >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (iw[3] >= 0) __hip_atomic_fetch_add(&lacc[iw[3] * stride + slot], v[c] >> 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (!PLAIN && a.hn_any_mm) {    // MIN / MAX: the total-order code of the value (MinMaxFunc, agg_funcs.h:164-216)
+            const int ct = a.hn_ctype[c];
+            const uint64_t e = ct == VNM_F64 ? enc_f64(__longlong_as_double((long long)v[c])) : (ct == VNM_U64 ? v[c] : enc_i64((int64_t)v[c]));
+            if (a.hn_wmm[c][0] >= 0) __hip_atomic_fetch_min(&lacc[a.hn_wmm[c][0] * stride + slot], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (a.hn_wmm[c][1] >= 0) __hip_atomic_fetch_max(&lacc[a.hn_wmm[c][1] * stride + slot], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
 }
 __device__ __forceinline__ void hn_fill_counts(const AggArgs& a, uint64_t* lacc, int stride, int tid) {
@@ -1092,7 +1113,7 @@ __device__ __forceinline__ void hn_fill_counts(const AggArgs& a, uint64_t* lacc,
     }
     __syncthreads();
 }
-template <int NC, bool HAS_PRED>
+template <int NC, bool HAS_PRED, bool PLAIN>
 __global__ __launch_bounds__(AGG_BLOCK) void agg_hotn_kernel(AggArgs a) {
     constexpr int U = NC == 3 && !HAS_PRED ? 4 : 2;   // row pairs per lane and tile: 16 + 16 NC (8 + 8 NC) registers of loads in flight (three columns
                                                       // and a predicate with U = 4: 74 spilled VGPRs under the 128 a 1024-thread workgroup may hold)
@@ -1173,12 +1194,12 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hotn_kernel(AggArgs a) {
                 if (nfull) VNM_HN_LOAD(u, nbase);
                 if (!HAS_PRED || cmp_apply<double>(op, p0, thr)) {
                     const int slot = hot_slot(lkey, S, smask, &s_fill, k.x, spread);
-                    if (slot >= 0) hn_accumulate<NC>(a, lacc, stride, slot, v0);
+                    if (slot >= 0) hn_accumulate<NC, PLAIN>(a, lacc, stride, slot, v0);
                     else sat0 |= 1u << u;
                 }
                 if (!HAS_PRED || cmp_apply<double>(op, p1, thr)) {
                     const int slot = hot_slot(lkey, S, smask, &s_fill, k.y, spread);
-                    if (slot >= 0) hn_accumulate<NC>(a, lacc, stride, slot, v1);
+                    if (slot >= 0) hn_accumulate<NC, PLAIN>(a, lacc, stride, slot, v1);
                     else sat1 |= 1u << u;
                 }
             }
@@ -1200,7 +1221,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_hotn_kernel(AggArgs a) {
                         if (!cmp_apply<double>(op, p, thr)) continue;
                     }
                     const int slot = hot_slot(lkey, S, smask, &s_fill, kp[r], spread);
-                    if (slot >= 0) hn_accumulate<NC>(a, lacc, stride, slot, v);
+                    if (slot >= 0) hn_accumulate<NC, PLAIN>(a, lacc, stride, slot, v);
                     else if (e == 0) sat0 |= 1u << u;
                     else sat1 |= 1u << u;
                 }
@@ -5997,16 +6018,26 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
     {
         int w_rows = -1, w_cnt[6] = {-1, -1, -1, -1, -1, -1};
         for (int c = 0; c < 6; c++) a.hn_w_sum[c] = -1;
+        a.hn_any_int = a.hn_any_mm = 0;
+        for (int c = 0; c < 6; c++) { a.hn_ctype[c] = VNM_F64; a.hn_wmm[c][0] = a.hn_wmm[c][1] = -1; for (int k = 0; k < 4; k++) a.hn_iw[c][k] = -1; }
         for (int c = 0; c < h->plan.n_cols && hotn; c++) {
             const vnm_dcol& col = a.cols[c];
-            hotn = col.type == VNM_F64 && !col.validity && (col.offset & 1) == 0 && ((uintptr_t)col.values & 15) == 0;
+            hotn = (col.type == VNM_F64 || col.type == VNM_I64 || col.type == VNM_U64) && !col.validity && (col.offset & 1) == 0 && ((uintptr_t)col.values & 15) == 0;
+            a.hn_ctype[c] = col.type;
+            if (col.type != VNM_F64) a.hn_any_int = 1;   // (not the PLAIN instantiation: its values are float64 bit patterns)
         }
         for (int o = 0; o < h->plan.n_ops && hotn; o++) {
             const AccOp& op = h->plan.ops[o];
             if (op.kind == A_COUNT_ROWS && w_rows < 0) w_rows = op.word;
             else if (op.kind == A_COUNT_VALID && w_cnt[op.col] < 0) w_cnt[op.col] = op.word;
             else if (op.kind == A_SUM_F64 && a.hn_w_sum[op.col] < 0) a.hn_w_sum[op.col] = op.word;
-            else hotn = false;
+            else if (op.kind >= A_SUM_I64 && op.kind <= A_SUM_HI32U && a.hn_ctype[op.col] != VNM_F64 && a.hn_iw[op.col][op.kind - A_SUM_I64] < 0) {
+                a.hn_iw[op.col][op.kind - A_SUM_I64] = op.word;
+                a.hn_any_int = 1;
+            } else if ((op.kind == A_MIN || op.kind == A_MAX) && a.hn_wmm[op.col][op.kind - A_MIN] < 0) {
+                a.hn_wmm[op.col][op.kind - A_MIN] = op.word;
+                a.hn_any_mm = 1;
+            } else hotn = false;
         }
         a.hn_w_base = w_rows;
         a.hn_n_copy = 0;
@@ -6367,15 +6398,16 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
 #undef VNM_HOT
         } else if (hotn) {
             size_t lds_bytes = (size_t)(a.lds_slots + 2) * 8 * (1 + h->plan.n_words);
+#define VNM_HN2(NC_, P_, PL_)                                                                                    \
+    do {                                                                                                        \
+        VNM_HIP(hipFuncSetAttribute((const void*)agg_hotn_kernel<NC_, P_, PL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        agg_hotn_kernel<NC_, P_, PL_><<<grid, AGG_BLOCK, lds_bytes, s>>>(a);                                    \
+    } while (0)
 #define VNM_HN(NC_)                                                                                              \
     do {                                                                                                        \
-        if (h->pred_set) {                                                                                      \
-            VNM_HIP(hipFuncSetAttribute((const void*)agg_hotn_kernel<NC_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-            agg_hotn_kernel<NC_, true><<<grid, AGG_BLOCK, lds_bytes, s>>>(a);                                   \
-        } else {                                                                                                \
-            VNM_HIP(hipFuncSetAttribute((const void*)agg_hotn_kernel<NC_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-            agg_hotn_kernel<NC_, false><<<grid, AGG_BLOCK, lds_bytes, s>>>(a);                                  \
-        }                                                                                                       \
+        const bool plain_ = !a.hn_any_int && !a.hn_any_mm;                                                      \
+        if (h->pred_set) { if (plain_) VNM_HN2(NC_, true, true); else VNM_HN2(NC_, true, false); }              \
+        else { if (plain_) VNM_HN2(NC_, false, true); else VNM_HN2(NC_, false, false); }                        \
     } while (0)
             switch (h->plan.n_cols) {
                 case 3: VNM_HN(3); break;
@@ -6384,6 +6416,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                 default: VNM_HN(6); break;
             }
 #undef VNM_HN
+#undef VNM_HN2
         } else if (h->single) {
             size_t lds_bytes = (size_t)(a.lds_slots + 2) * 8 * (1 + h->plan.n_words);
             VNM_HIP(hipFuncSetAttribute((const void*)agg_lds_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
