@@ -13,6 +13,9 @@ INT = len(sys.argv) > 4 and sys.argv[4] == "int"     # int64 columns (128-bit su
 cols = [torch.randint(0, 2**14, (n,), device=dev, dtype=torch.int64, generator=g) if INT else torch.randint(0, 2**14, (n,), device=dev, dtype=torch.int64, generator=g).to(torch.float64) / 128.0 for _ in range(C)]
 ck = DeviceColumn.from_torch(k)
 cc = [DeviceColumn.from_torch(c) for c in cols]
+if len(sys.argv) > 4 and sys.argv[-1] == "null":    # ~12 % NULLs in every input column
+    bits = [torch.randint(0, 256, ((n + 7) // 8,), device=dev, dtype=torch.uint8, generator=g) | torch.randint(0, 256, ((n + 7) // 8,), device=dev, dtype=torch.uint8, generator=g) | torch.randint(0, 256, ((n + 7) // 8,), device=dev, dtype=torch.uint8, generator=g) for _ in range(C)]
+    cc = [DeviceColumn(c.values_ptr, b.data_ptr(), 0, n, c.arrow_type if hasattr(c, "arrow_type") else pa.float64(), keep=(c, b)) for c, b in zip(cc, bits)]
 import ctypes
 lib = L.lib()
 for rep in range(3):
