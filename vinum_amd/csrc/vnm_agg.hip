@@ -5497,6 +5497,10 @@ int make_parts(vnm_agg* h, int per) {
         c->estimated = h->estimated;
         c->split_tried = true;
         c->async = h->async;   // (a stream: the parts record their batches like the parent would -- one launch per part over all of them)
+        c->heavy_share = h->heavy_share;   // (the parent's sample saw the same key column)
+        if (h->dense_state >= 1 && !h->range_given) {   // ... and its code map: no second range sample, and the parts' maps agree by construction
+            c->dense_state = h->dense_state; c->dmap = h->dmap; c->dense_span = h->dense_span; c->dense_rlo = h->dense_rlo; c->dense_rhi = h->dense_rhi;
+        }
         h->parts.push_back(c);
     }
     return 0;
