@@ -5578,9 +5578,12 @@ int collapse_parts(vnm_agg* h, hipStream_t s) {
         }
         // the join by units of 64 codes (parts of the dense path over one code map: see part_unit_starts_kernel)
         bool joined = false;
-        const DenseMap umap = h->parts[0]->dmap;
-        bool by_units = !rc && h->parts[0]->dense_state == 1 && n < ((int64_t)1 << 31)   /* (2: the small-range scans use maps of their own) */ && getenv("VNM_AGG_NO_UNIT_JOIN") == nullptr;
-        for (int p = 1; p < k && by_units; p++) by_units = h->parts[p]->dense_state == 1 && memcmp(&h->parts[p]->dmap, &umap, sizeof(DenseMap)) == 0;
+        DenseMap umap = h->parts[0]->dmap;
+        const int ustate = h->parts[0]->dense_state;
+        if (ustate == 2) { umap.mul = 1; umap.mul_inv = 1; }   // (the small-range scans address their tables by the plain code; a generic program that
+                                                               // re-centred its range fails the key comparison below and takes the sort join)
+        bool by_units = !rc && (ustate == 1 || ustate == 2) && n < ((int64_t)1 << 31) && getenv("VNM_AGG_NO_UNIT_JOIN") == nullptr;
+        for (int p = 1; p < k && by_units; p++) by_units = h->parts[p]->dense_state == ustate && memcmp(&h->parts[p]->dmap, &h->parts[0]->dmap, sizeof(DenseMap)) == 0;
         if (by_units) {
             KernelTimer t2("agg_split_units", s);
             const size_t units = ((size_t)umap.mask + 1 + 63) >> 6;
