@@ -494,11 +494,14 @@ def test_small_range_many_columns_split_per_column(program, pred, groups, shape,
                           what=f"split per column: {program}, pred {pred}, G={groups} {shape}")
 
 
-@pytest.mark.parametrize("program,pred", [("three_sums", "on_first"), ("three_sums", "none"), ("four_columns_mixed", "on_first"), ("nullable_and_minmax", "none"),
-                                          ("two_sums", "on_first"), ("two_minmax", "none")])
-@pytest.mark.parametrize("groups,shape", [(300_000, "one_batch"), (1_500_000, "one_batch"), (1_500_000, "pairs"), (1_200_000, "two_batches"),
-                                          (1_300_000, "null_keys_later"), (1_400_000, "heavy_keys"), (1_500_000, "sparse_keys"),
-                                          (1_100_000, "two_batches_bounded")])
+_SPLIT_SHAPES = [(300_000, "one_batch"), (1_500_000, "one_batch"), (1_500_000, "pairs"), (1_200_000, "two_batches"), (1_300_000, "null_keys_later"),
+                 (1_400_000, "heavy_keys"), (1_500_000, "sparse_keys"), (1_100_000, "two_batches_bounded")]
+_SPLIT_CASES = ([("three_sums", "on_first") + sh for sh in _SPLIT_SHAPES] + [("four_columns_mixed", "on_first") + sh for sh in _SPLIT_SHAPES] +
+                [("nullable_and_minmax", "none") + sh for sh in _SPLIT_SHAPES[:6]] + [("three_sums", "none") + sh for sh in _SPLIT_SHAPES[1:4]] +
+                [("two_sums", "on_first") + sh for sh in _SPLIT_SHAPES[:4]] + [("two_minmax", "none") + sh for sh in (_SPLIT_SHAPES[0], _SPLIT_SHAPES[3], _SPLIT_SHAPES[4])])
+
+
+@pytest.mark.parametrize("program,pred,groups,shape", _SPLIT_CASES)
 def test_many_groups_many_columns_split_over_the_dense_path(program, pred, groups, shape, monkeypatch):
     """Round 4: three or more 8-byte input columns over a key the dense path takes are aggregated per column (or per pair of float64
     columns under sums / counts: two-value entries) by the dense path and joined at the end -- by a plain copy when every part
