@@ -5874,7 +5874,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                     // over one code map are joined by units of 64 codes (collapse_parts: no sorts, no random gathers).
                     // 5e8 rows, 3 / 6 columns: G = 1e6 20.0 / 37.6 -> 13.9 / 26.8 ms, G = 1e8 30.1 / 360 -> 24.7 / 44.8.
                     if (nrows >= env_i64("VNM_AGG_SPLIT_DENSE_MIN_ROWS", 1 << 24) && h->dense_state == 1 &&
-                        h->dense_span <= 32 * h->hint && h->dense_span <= 4 * nrows && getenv("VNM_AGG_NO_SPLIT_DENSE") == nullptr) {
+                        h->dense_span <= 32 * h->hint && h->dense_span <= env_i64("VNM_DENSE_SPAN_PER_ROW", 16) * nrows && getenv("VNM_AGG_NO_SPLIT_DENSE") == nullptr) {
                         bool sums = true;   // every function a sum / count of a plain float64 column: what the two-value entries carry
                         for (int i = 0; i < h->n_funcs && sums; i++) {
                             const int f = h->c_funcs[i];
@@ -6124,7 +6124,11 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
     // deferred pass over that very range is waiting anyway: a short batch of a stream then simply joins it (round 4; before, it took
     // two hash levels -- and, with a nullable key, the general scan)
     // (evaluated where it is used: plan_dense may only just have set the range)
-    auto span_fits_now = [&]() { return h->dense_span <= 4 * nrows || (h->pending != nullptr && h->dense_state == 1 && memcmp(&h->pending->df.map, &h->dmap, sizeof(DenseMap)) == 0); };
+    // (16 codes per row of the batch: a 2^24-row batch of a stream opens -- and later batches join -- a deferred pass over 2^27 codes; with 4
+    // such a stream took the hash partitions batch by batch: 59 x 2^24 rows, G = 1e8, synchronous next(): 132.6 -> 21.6 ms; a single
+    // 2^24-row batch over that range: 1.66 -> 1.10 ms)
+    const int64_t span_per_row = env_i64("VNM_DENSE_SPAN_PER_ROW", 16);
+    auto span_fits_now = [&]() { return h->dense_span <= span_per_row * nrows || (h->pending != nullptr && h->dense_state == 1 && memcmp(&h->pending->df.map, &h->dmap, sizeof(DenseMap)) == 0); };
 #define span_fits span_fits_now()
     bool dense_go = false;
     // a stream that went dense on the sample's lower bound (no group count exists) and now brings a batch too short for the
