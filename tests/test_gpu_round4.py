@@ -779,3 +779,37 @@ def test_scan_over_several_columns_of_mixed_types(ncols, nulls, groups, shape):
     got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, bl, predicate=pred)
     util.assert_agg_equal(got, _oracle(O.SINGLE, ["k"], funcs, bl, pred), funcs, ["k"], exact_float_inputs=tuple(f"c{i}" for i in range(ncols)),
                           what=f"hotn mixed types: {ncols} columns, {nulls}, G={groups} {shape}")
+
+
+@pytest.mark.parametrize("ncols", [7, 8, 10, 13])
+@pytest.mark.parametrize("groups,shape", [(7, "one_batch"), (60, "two_batches"), (200, "hinted")])
+def test_few_groups_under_more_than_six_columns(ncols, groups, shape, monkeypatch):
+    """Few groups under MORE than six plain 8-byte columns: the program is cut into parts of up to six columns (make_parts), each through
+    agg_hotn_kernel, joined by key -- instead of the interpreted scan over all columns at once.  Bit-exact against the oracle (float64 /
+    int64 columns, sums, averages, counts, extremes, a predicate on another column; several batches; a caller's group count)."""
+    from oracle import oracle as O
+    from vinum_amd import _lib as L
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(ncols * 41 + groups)
+    n = 420_000
+    cols = {"k": pa.array(rng.integers(0, groups, n).astype(np.int64) * 13 + 5)}
+    kinds = [O.SUM, O.AVG, O.COUNT, O.MAX, O.SUM, O.MIN]
+    funcs = []
+    for i in range(ncols):
+        if i % 4 == 3:
+            cols[f"c{i}"] = pa.array(rng.integers(-2**40, 2**40, n).astype(np.int64))
+        else:
+            cols[f"c{i}"] = pa.array(rng.integers(-2**13, 2**13, n).astype(np.float64) / 32.0)
+        funcs.append((kinds[i % 6], f"c{i}", f"f{i}"))
+    funcs.append((O.COUNT_STAR, "", "n"))
+    cols["p"] = pa.array(rng.integers(0, 2**12, n).astype(np.float64) / 64.0)
+    t = pa.table(cols)
+    bl = util.sliced_batches(t, 210_000 if shape == "two_batches" else n)
+    pred = ("p", ">", 20.0)
+    L.lib().vnm_set_profiling(1)
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, bl, predicate=pred, expected_groups=groups if shape == "hinted" else 0)
+    joins = _launches(b"agg_split_join")
+    L.lib().vnm_set_profiling(0)
+    assert joins == 1, joins
+    util.assert_agg_equal(got, _oracle(O.SINGLE, ["k"], funcs, bl, pred), funcs, ["k"], exact_float_inputs=tuple(f"c{i}" for i in range(ncols)),
+                          what=f"few groups, {ncols} columns, G={groups} {shape}")
