@@ -3537,6 +3537,8 @@ struct vnm_agg {
     int64_t kn_off = 0;
     bool kn_failed = false;      // the dense path did not take such a batch once: later ones go straight to the packed route
     std::vector<VSeg> seg_host;                         // the segment table of the last launch (kept until the next one: H2D source)
+    // reference-exact float MIN / MAX under NaNs and mixed-sign zeros (round 5, vnm_agg_exact.inc): top-level handles only
+    struct vnm_agg_exact* ex = nullptr;
 };
 
 namespace {
@@ -5054,8 +5056,14 @@ extern "C" int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* ke
 extern "C" vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
                                    const int* in_types, const int* in_flags, const int* in_col_ids);
 extern "C" void vnm_agg_destroy(vnm_agg* h);
+static int agg_finish_core(vnm_agg* h, int64_t* n_groups, void* stream);
 
 namespace {
+
+// vnm_agg_create without the ordered MIN / MAX engine: the operators the library builds for itself (packed keys, program parts,
+// the suffix / merge operators of vnm_agg_exact.inc)
+vnm_agg* agg_create(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs, const int* in_types, const int* in_flags,
+                    const int* in_col_ids);
 
 // Decide the packing from the key ranges of the first batch: field j holds value codes [0, cap_j) + the NULL code.
 // Spare bits are spread over the fields and the observed range is centred in its field, so later batches may
@@ -5200,7 +5208,7 @@ int enter_tuple_mode(vnm_agg* h, int64_t nrows, hipStream_t s) {
     if (h->hint <= 0 && (uint64_t)nrows * 2 < want) want = (uint64_t)(nrows > 512 ? nrows : 512) * 2;
     VNM_TRY(tdict_alloc(&h->tdict, pow2_at_least(want < 1024 ? 1024 : want), h->plan.n_keys + 1, s));
     const int kt = VNM_U64;
-    h->inner = vnm_agg_create(VNM_SINGLE_NUMERICAL, 1, &kt, h->n_funcs, h->c_funcs, h->c_in_types, h->c_in_flags,
+    h->inner = agg_create(VNM_SINGLE_NUMERICAL, 1, &kt, h->n_funcs, h->c_funcs, h->c_in_types, h->c_in_flags,
                               h->c_has_ids ? h->c_in_col_ids : nullptr);
     if (!h->inner) return 1;
     h->inner->hint = h->hint;
@@ -5491,7 +5499,7 @@ int make_parts(vnm_agg* h, int per) {
             const int i = h->part_funcs[p][q];
             funcs[q] = h->c_funcs[i]; types[q] = h->c_in_types[i]; flags[q] = h->c_in_flags[i]; ids[q] = h->func_col[i];   // (the distinct column: sharing survives)
         }
-        vnm_agg* c = vnm_agg_create(VNM_SINGLE_NUMERICAL, 1, &kt, nf, funcs, types, flags, ids);
+        vnm_agg* c = agg_create(VNM_SINGLE_NUMERICAL, 1, &kt, nf, funcs, types, flags, ids);
         if (!c) { drop_parts(h); return 1; }
         c->hint = h->hint;
         c->estimated = h->estimated;
@@ -5635,12 +5643,8 @@ int collapse_parts(vnm_agg* h, hipStream_t s) {
     return 0;
 }
 
-}  // namespace
-
-extern "C" {
-
-vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
-                        const int* in_types, const int* in_flags, const int* in_col_ids) {
+vnm_agg* agg_create(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
+                    const int* in_types, const int* in_flags, const int* in_col_ids) {
     if (ensure_init()) return nullptr;
     vnm_agg* h = new vnm_agg();
     if (build_plan(kind, n_keys, key_types, n_funcs, funcs, in_types, in_flags, in_col_ids, &h->plan, h->outs)) {
@@ -5669,8 +5673,22 @@ vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs,
     return h;
 }
 
+}  // namespace
+
+#include "vnm_agg_exact.inc"
+
+extern "C" {
+
+vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
+                        const int* in_types, const int* in_flags, const int* in_col_ids) {
+    vnm_agg* h = agg_create(kind, n_keys, key_types, n_funcs, funcs, in_types, in_flags, in_col_ids);
+    if (h) exact_attach(h);
+    return h;
+}
+
 void vnm_agg_destroy(vnm_agg* h) {
     if (!h) return;
+    if (h->ex) { exact_drop_result(h); exact_destroy(h->ex); h->ex = nullptr; }   // (a merged result's arrays go with their owner)
     if (h->inner) { vnm_agg_destroy(h->inner); h->inner = nullptr; }
     drop_parts(h);
     leave_tuple_mode(h);
@@ -5691,6 +5709,7 @@ int vnm_agg_set_predicate(vnm_agg* h, int enabled, int op, int scalar_is_float, 
     h->pred_is_float = scalar_is_float;
     h->pred_dval = dval;
     h->pred_ival = ival;
+    if (h->ex && h->ex->post) VNM_TRY(vnm_agg_set_predicate(h->ex->post, enabled, op, scalar_is_float, dval, ival));
     return 0;
 }
 
@@ -5703,6 +5722,7 @@ int vnm_agg_set_exchange_mode(vnm_agg* h, int rank_aligned) {
 int vnm_agg_set_hint(vnm_agg* h, int64_t expected_groups) {
     if (!h) return set_error("vnm_agg_set_hint: null handle");
     h->hint = expected_groups;
+    if (h->ex && h->ex->post) h->ex->post->hint = expected_groups;
     return 0;
 }
 
@@ -5780,7 +5800,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
             int err = 0;
             if (plan_packing(h, keys, nrows, s, &err)) {
                 const int kt = VNM_U64;
-                h->inner = vnm_agg_create(VNM_SINGLE_NUMERICAL, 1, &kt, h->n_funcs, h->c_funcs, h->c_in_types, h->c_in_flags,
+                h->inner = agg_create(VNM_SINGLE_NUMERICAL, 1, &kt, h->n_funcs, h->c_funcs, h->c_in_types, h->c_in_flags,
                                           h->c_has_ids ? h->c_in_col_ids : nullptr);
                 if (!h->inner) return 1;
                 h->inner->hint = h->hint;
@@ -6533,6 +6553,11 @@ static bool queueable(const vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
 int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs,
                         const vnm_dcol* pred, void* stream) {
     if (!h) return set_error("vnm_agg_next_device: null handle");
+    if (h->ex && inputs && (keys || h->plan.n_keys == 0)) {   // float MIN / MAX: the flag pass, and the ordered mode once the stream is unclean
+        bool handled = false;
+        VNM_TRY(exact_next(h, nrows, keys, inputs, pred, stream, &handled));
+        if (handled) return 0;
+    }
     if (h->async && keys && inputs) {
         bool piv = false, multi = false;
         if (queueable(h, nrows, keys, inputs, pred, &piv, &multi) && (h->q.empty() || (piv == h->q_pred_is_v && multi == h->q_multi))) {
@@ -6559,6 +6584,7 @@ int vnm_agg_set_async(vnm_agg* h, int enabled) {
     if (!h) return set_error("vnm_agg_set_async: null handle");
     if (!enabled && !h->q.empty()) return set_error("vnm_agg_set_async: batches are waiting (call vnm_agg_sync first)");
     for (vnm_agg* c : h->parts) VNM_TRY(vnm_agg_set_async(c, enabled));
+    if (h->ex && h->ex->post) VNM_TRY(vnm_agg_set_async(h->ex->post, enabled));
     h->async = enabled != 0;
     return 0;
 }
@@ -6567,6 +6593,7 @@ int vnm_agg_sync(vnm_agg* h, void* stream) {
     if (!h) return set_error("vnm_agg_sync: null handle");
     VNM_TRY(flush_queue(h, stream));
     for (vnm_agg* c : h->parts) VNM_TRY(flush_queue(c, stream));   // (the parts of a split program record their batches themselves)
+    if (h->ex && h->ex->post) VNM_TRY(vnm_agg_sync(h->ex->post, stream));
     VNM_HIP(hipStreamSynchronize(as_stream(stream)));
     return 0;
 }
@@ -6703,6 +6730,11 @@ int vnm_agg_merge_rows(vnm_agg* h, int64_t n, const uint64_t* rows, void* stream
 int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream) {
     VNM_TRY(ensure_init());
     if (!h) return set_error("vnm_agg_finish: null handle");
+    if (h->ex && h->ex->switched) return exact_finish(h, n_groups, stream);   // prefix + suffix merged, float MIN / MAX composed in row order
+    return agg_finish_core(h, n_groups, stream);
+}
+
+static int agg_finish_core(vnm_agg* h, int64_t* n_groups, void* stream) {
     hipStream_t s = as_stream(stream);
     VNM_TRY(flush_queue(h, stream));   // (the waiting batches of an asynchronous stream)
     if (h->n_groups >= 0) {
@@ -6831,7 +6863,7 @@ int64_t vnm_agg_run_partitions(vnm_agg* h) {
     if (!h) return 0;
     int64_t n = 0;
     if (vnm_agg_finish(h, &n, nullptr) != 0) return 0;
-    if (!(h->result_is_run && h->run_dir)) return 0;
+    if (!(h->result_is_run && h->run_dir) || (h->ex && h->ex->switched)) return 0;
     // only what vnm_agg_merge_partitioned can merge: add-merge words (MIN / MAX programs and anything wider than the
     // LDS merge table go through the owner-bucketed exchange)
     if (h->plan.n_words > PM_MAX_WORDS) return 0;
@@ -7119,7 +7151,8 @@ int vnm_agg_result_device_alloc(vnm_agg* h, int n_cols, const int* which, void**
     VNM_TRY(flush_queue(h, stream));   // (the waiting batches of an asynchronous stream)
     auto free_outputs = [&]() { for (int c = 0; c < n_cols; c++) { pool_free(out_values[c]); pool_free(out_bitmaps[c]); out_values[c] = nullptr; out_bitmaps[c] = nullptr; } };
     DensePending* pd = h->inner ? nullptr : h->pending;
-    bool fused = pd && !h->have_run && h->n_groups < 0 && n_cols >= 1 && n_cols <= DF_MAX_OUT && getenv("VNM_AGG_NO_FUSED_RESULT") == nullptr;
+    bool fused = pd && !h->have_run && h->n_groups < 0 && n_cols >= 1 && n_cols <= DF_MAX_OUT && getenv("VNM_AGG_NO_FUSED_RESULT") == nullptr &&
+                 !(h->ex && h->ex->switched);   // (an ordered MIN / MAX stream: the handle's own state is the prefix only)
     // An HBM table next to the pending pass (spilled heavy keys, keys outside the code range, the NULL-key group, rows of batches that
     // took the scan): while it holds FEW groups the pass folds them into its own result columns (dside_merge / dside_append_kernel)
     int64_t side_groups = 0;
@@ -7249,7 +7282,7 @@ int vnm_agg_dense_table(vnm_agg* h, void** table, int* bits, uint64_t* geometry,
     *table = nullptr; *bits = 0;
     VNM_TRY(flush_queue(h, stream));
     DensePending* pd = h->inner ? nullptr : h->pending;
-    if (!pd || h->have_table || h->have_run || h->n_groups >= 0) return 0;
+    if (!pd || h->have_table || h->have_run || h->n_groups >= 0 || (h->ex && h->ex->switched)) return 0;
     const int rc = complete_pending(h, as_stream(stream), DF_TABLE);
     if (rc == 2) return 0;
     if (rc) return rc;
