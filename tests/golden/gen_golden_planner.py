@@ -78,10 +78,11 @@ def run(case, table):
 def main():
     vinum.set_batch_size(6000)   # several batches per query (the reference default is 10 000)
     table = P.planner_table()
-    meta = {"table_sha256": table_digest(table), "cases": {}, "pyarrow": pa.__version__,
+    tables = {"main": table, "null": P.null_table()}
+    meta = {"table_sha256": table_digest(table), "null_table_sha256": table_digest(tables["null"]), "cases": {}, "pyarrow": pa.__version__,
             "generator": "tests/golden/gen_golden_planner.py: the reference's QueryPlanner + RecursiveExecutor over hand-built Query ASTs"}
     for case in P.CASES:
-        out = run(case, table)
+        out = run(case, tables[case.get("table", "main")])
         with pa.OSFile(os.path.join(HERE, f"planner_{case['name']}.arrow"), "wb") as f:
             with pa.ipc.new_file(f, out.schema) as w:
                 w.write_table(out.combine_chunks())

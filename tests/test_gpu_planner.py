@@ -27,6 +27,7 @@ def table():
     with open(os.path.join(util.GOLDEN, "planner_cases.json")) as f:
         meta = json.load(f)
     assert table_digest(t) == meta["table_sha256"], "NumPy produced a different input table than the generator saw"
+    assert table_digest(P.null_table()) == meta["null_table_sha256"]
     return t
 
 
@@ -56,7 +57,7 @@ def test_query_matches_the_reference_planner(case, table):
     from vinum_amd import planner, set_batch_size
     set_batch_size(6000)          # several batches per query, as in the generator
     try:
-        got = planner.execute(case, table)
+        got = planner.execute(case, table if case.get("table", "main") == "main" else P.TABLES[case["table"]]())
     finally:
         set_batch_size(1 << 24)
     _compare(got, util.read_ipc(f"planner_{case['name']}.arrow"), case)

@@ -116,3 +116,86 @@ def test_ordered_min_max_result_then_more_batches():
                 util.assert_col_equal(util.canon(got, ["k"]).column("mn"), util.canon(exp, ["k"]).column("mn"), "mn")
                 util.assert_col_equal(util.canon(got, ["k"]).column("mx"), util.canon(exp, ["k"]).column("mx"), "mx")
     agg.close()
+
+
+def _check_null_table_vector(got: pa.Table):
+    from tests.golden import planner_cases as P
+    exp = P.NULL_TABLE_EXPECTED
+    rows = {r["city_from"]: r for r in got.to_pylist()}
+    for i, city in enumerate(exp["city_from"]):
+        r = rows[city]
+        for name, vals in exp.items():
+            if name == "city_from" or name not in r:
+                continue
+            e, g = vals[i], r[name]
+            if isinstance(e, float) and np.isnan(e):
+                assert g is not None and np.isnan(g), f"{city} {name}: {g!r}, the reference's test expects NaN"
+            else:
+                assert g == e, f"{city} {name}: {g!r} != {e!r}"
+
+
+def test_reference_null_vector_string_keys_through_vinum_lib():
+    """vinum/tests/test_query_results.py:1270-1301 as the reference runs it: GROUP BY the STRING column city_from
+    (GenericHashAggregate), count(*) / count(total) / count(name) / count(date) / count(is_vendor) / min / max / avg / sum
+    (total) -- min(total) and max(total) of Berlin's (NaN, 33.4, NaN) are NaN.  Expected values: the reference's own vector."""
+    from tests.golden import planner_cases as P
+    from vinum_amd import vinum_lib as V
+    t = P.null_table()
+    funcs = [V.AggFuncDef(V.COUNT_STAR, "", "cnt_all"), V.AggFuncDef(V.COUNT, "total", "cnt_total"), V.AggFuncDef(V.COUNT, "name", "cnt_name"),
+             V.AggFuncDef(V.COUNT, "date", "cnt_date_str"), V.AggFuncDef(V.COUNT, "is_vendor", "cnt_bool"),
+             V.AggFuncDef(V.MIN, "total", "min_total"), V.AggFuncDef(V.MAX, "total", "max_total"),
+             V.AggFuncDef(V.AVG, "total", "avg_total"), V.AggFuncDef(V.SUM, "total", "sum_total")]
+    for chunk in (8, 3, 1):     # one batch; the NaNs of Berlin in different batches; a batch per row
+        agg = V.GenericHashAggregate(["city_from"], ["city_from"], funcs)
+        for b in util.sliced_batches(t, chunk):
+            agg.next(b)
+        _check_null_table_vector(pa.Table.from_batches([agg.result()]))
+
+
+def test_reference_null_vector_string_keys_through_the_planner():
+    from tests.golden import planner_cases as P
+    from vinum_amd import planner
+    fn = P.fn
+    q = dict(select=["city_from", fn("count_star"), fn("count", "total"), fn("count", "name"), fn("min", "total"), fn("max", "total"),
+                     fn("avg", "total"), fn("sum", "total")],
+             aliases=[None, "cnt_all", "cnt_total", "cnt_name", "min_total", "max_total", "avg_total", "sum_total"],
+             group_by=["city_from"])
+    got = planner.execute(q, P.null_table())
+    assert got.num_rows == 4
+    _check_null_table_vector(got)
+
+
+@pytest.mark.parametrize("seed", range(SEEDS or 40))
+def test_random_plans_with_nans_and_signed_zeros_vs_oracle(seed, monkeypatch):
+    """The dispatch-space fuzzer of test_random_plans_vs_oracle (1-3 key columns of mixed widths with NULLs -> packed /
+    dictionary-coded / tuple keys, typed inputs, hints, predicates, skew, several batches, stream mode) with NaNs and signed
+    zeros under the float MIN / MAX functions: whatever path the operator picks before and after it switches to the ordered
+    mode, the result equals the reference's row-order dependent rule."""
+    from oracle import oracle as O
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    rng = np.random.default_rng(91_000 + seed)
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "1000")
+    cols, key_names, in_names, funcs, n, groups, skew = util.random_agg_case(rng, specials=True)
+    pred = None
+    if rng.random() < 0.3 and in_names:
+        pred = (in_names[0], ">", 5 if pa.types.is_integer(cols[in_names[0]].type) else 5.0)
+    t = pa.table(cols)
+    names = t.schema.names
+    kind = O.SINGLE if len(key_names) == 1 else O.MULTI
+    hint = groups if rng.random() < 0.5 else 0
+    batches = util.sliced_batches(t, int(rng.choice([n, n // 2 + 1, n // 5 + 1])))
+    stream_mode = bool(rng.random() < 0.5)
+    fspec = [(f, names.index(col) if col else None, t.schema.field(col).type if col else None) for f, col, _ in funcs]
+    agg = ops.DeviceAggregate(kind, [t.schema.field(k).type for k in key_names], fspec, expected_groups=hint, stream_mode=stream_mode)
+    if pred:
+        agg.set_predicate(pred[1], pred[2])
+    for b in batches:
+        dc = {nm: DeviceColumn.from_arrow(b.column(j)) for j, nm in enumerate(names)}
+        agg.next([dc[k] for k in key_names], [dc[col] if col else None for _, col, _ in funcs], pred=dc[pred[0]] if pred else None, nrows=b.num_rows)
+    got = agg.result_arrays(list(range(len(key_names))), key_names, [f[2] for f in funcs])
+    agg.close()
+    exp = _oracle(kind, key_names, funcs, batches, pred)
+    util.assert_agg_equal(got, exp, funcs, key_names, source=batches if pred is None else None,
+                          what=f"seed {seed}: keys {[str(cols[k].type) for k in key_names]} inputs {[str(cols[v].type) for v in in_names]} "
+                               f"G~{groups} skew={skew} hint={hint} pred={pred} stream={stream_mode} batches={len(batches)}")

@@ -249,9 +249,11 @@ def assert_agg_equal(actual, expected, funcs, key_names, exact_float_inputs=("v_
             assert_col_equal(a, e, f"{what}:{name}")
 
 
-def random_agg_case(rng):
+def random_agg_case(rng, specials=False):
     """Random aggregate query for the differential tests: (columns dict, key names, input names, funcs, n, groups,
-    skew).  1-3 key columns of mixed widths (some with NULLs), 0-3 typed input columns (some with NULLs)."""
+    skew).  1-3 key columns of mixed widths (some with NULLs), 0-3 typed input columns (some with NULLs).
+    specials: float inputs carry NaNs, -0.0 and +0.0 (everywhere, or only in the second half of the rows) and are read by
+    MIN / MAX / COUNT -- the row-order dependent part of MinMaxFunc::Update (agg_funcs.h:188-201)."""
     from oracle import oracle as O
     n = int(rng.integers(150_000, 420_000))
     groups = int(rng.choice([3, 40, 900, 5_000, 60_000, 250_000]))
@@ -298,6 +300,22 @@ def random_agg_case(rng):
         in_names.append(f"v{c}")
     funcs = [(O.COUNT_STAR, "", "n")] if (ninputs == 0 or rng.random() < 0.5) else []
     for name in in_names:
+        if specials and pa.types.is_floating(cols[name].type):
+            a = cols[name]
+            vals = a.fill_null(0).to_numpy(zero_copy_only=False).copy()
+            u = rng.random(n)
+            first = 0 if rng.random() < 0.5 else n // 2
+            u[:first] = 1.0
+            vals[u < 0.01] = np.nan
+            vals[(u >= 0.01) & (u < 0.03)] = -0.0
+            vals[(u >= 0.03) & (u < 0.06)] = 0.0
+            if rng.random() < 0.4:
+                vals = np.where(np.isnan(vals), vals, -vals)      # zero is the MAXIMUM of many groups
+            cols[name] = pa.array(vals, mask=None if a.null_count == 0 else ~np.array(a.is_valid()))
+            picks = rng.choice([O.MIN, O.MAX, O.COUNT], size=int(rng.integers(1, 4)), replace=False)
+            for f in picks:
+                funcs.append((int(f), name, f"f{len(funcs)}"))
+            continue
         picks = rng.choice([O.SUM, O.AVG, O.MIN, O.MAX, O.COUNT], size=int(rng.integers(1, 4)), replace=False)
         for f in picks:
             funcs.append((int(f), name, f"f{len(funcs)}"))
