@@ -3319,6 +3319,9 @@ __device__ __forceinline__ void fin_cell(const FinArgs& a, int64_t i, bool& vali
                 const uint64_t wa = a.words[1][i];
                 const uint64_t wb = a.words[2] ? a.words[2][i] : 0;
                 valid = cnt > 0;
+                // the (low 32, high 32) lanes of an int64 / uint64 SUM / AVG hold 2^32 - 1 inputs per group exactly: beyond, fail loudly
+                if ((a.fo.func == VNM_SUM || a.fo.func == VNM_AVG) && (t == VNM_I64 || t == VNM_U64) && cnt >= (1ULL << 32))
+                    __hip_atomic_fetch_or(&a.ctl[1], 2ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 switch (a.fo.func) {
                     case VNM_COUNT_STAR:
                     case VNM_COUNT: valid = true; bits = wa; break;
@@ -3337,7 +3340,7 @@ __device__ __forceinline__ void fin_cell(const FinArgs& a, int64_t i, bool& vali
                             bool fits;
                             if (t == VNM_I64) fits = (shi == 0 && slo <= 0x7FFFFFFFFFFFFFFFULL) || (shi == -1 && slo > 0x8000000000000000ULL);  // huge_int.cpp:334-355
                             else fits = shi == 0;
-                            if (valid && !fits) __hip_atomic_store(&a.ctl[1], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (valid && !fits) __hip_atomic_fetch_or(&a.ctl[1], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             bits = slo;
                         } else if (type_is_float(t)) {
                             bits = (uint64_t)__double_as_longlong(__longlong_as_double((long long)wa) + (a.words[2] ? __longlong_as_double((long long)wb) : 0.0));
@@ -3428,6 +3431,7 @@ struct DensePending {
     int tb = 0, levels = 0, p1 = 0, fsplits = 1;
     int64_t nfinal = 0;
     int64_t dstride = 0;   // bound of the groups the pass can produce
+    int64_t rows = 0;      // rows behind the sets: below 2^32, the slots of the final pass count a group's rows in 32 bits
     std::vector<DSet> sets;      // one per batch whose scatter passes are done
     std::vector<void*> blocks;   // pool blocks the entries live in
     DSet* dsets = nullptr;       // device copy of `sets` (refreshed by complete_pending)
@@ -4530,7 +4534,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         fsplits = (int)std::min<int64_t>(grid1, ((int64_t)cus * env_i64("VNM_DENSE_SPLIT_WGS", 4) + ((int64_t)1 << pbits) - 1) >> pbits);
         if (fsplits < 2) fsplits = 1;
     }
-    unsigned long long* flags = (unsigned long long*)pool_alloc(64);
+    unsigned long long* flags = (unsigned long long*)pool_alloc(128);   // [0..3] status words, [8..12] the NULL-key rows of this attempt (nullable key)
     double* v1 = (double*)pool_alloc(has_val ? (size_t)np1 * grid1 * cap1 * 8 : 8);
     void* c1 = pool_alloc((size_t)np1 * grid1 * cap1 * (c16_1 ? 2 : 4));
     uint32_t* n1 = (uint32_t*)pool_alloc((size_t)np1 * grid1 * 4);
@@ -4544,7 +4548,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     uint64_t* rk = nullptr; uint64_t* ra = nullptr;
     auto release = [&]() { pool_free(flags); pool_free(v1); pool_free(c1); pool_free(n1); pool_free(v2); pool_free(c2); pool_free(n2); };
     if (!flags || !v1 || !c1 || !n1 || !spill || (vn_lists && !nspill)) { release(); pool_free(spill); return 1;}
-    VNM_HIP(hipMemsetAsync(flags, 0, 64, s));
+    VNM_HIP(hipMemsetAsync(flags, 0, 128, s));
     DPartArgs d1{};
     d1.map = mp;
     d1.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
@@ -4642,16 +4646,31 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     const int rcap1 = (use_ring & 1) && !a.has_expr ? ring_cap_for(np1, (has_val ? 8 : 0) + (c16_1 ? 2 : 4)) : 0;
     PoolScope seg_pool;
     if ((h->segs_active || h->kn_valid) && (!rcap1 || vn)) { release(); pool_free(spill); return 2; }   // (only the ring scatter reads segments / key validity)
-    if (h->kn_valid) {   // the NULL-key group lives in the NULL slot of the operator's HBM table
+    // A nullable key: pass 1 sums the NULL-key rows of this ATTEMPT into scratch words; only an attempt that is known good adds them to
+    // the NULL slot of the operator's HBM table (fold_null_rows).  A failed attempt -- full spill buffer, output too small, a
+    // compensation term out of range: all known only after pass 1 -- leaves the table untouched, and the route that takes the batch
+    // instead counts those rows itself (they used to be counted twice: ADVICE r04).
+    auto fold_null_rows = [&]() -> int {
+        if (!h->kn_valid) return 0;
+        const GTable& gt = h->g;
+        const uint64_t slot = gt.cap + 1;
+        dnull_fold_kernel<<<1, 64, 0, s>>>(flags + 8, gt.tag + slot,
+                                           a.hot_w_rows >= 0 ? gt.acc + (uint64_t)a.hot_w_rows * gt.stride + slot : nullptr,
+                                           a.hot_w_valid >= 0 ? gt.acc + (uint64_t)a.hot_w_valid * gt.stride + slot : nullptr,
+                                           a.hot_w_sum >= 0 ? gt.acc + (uint64_t)a.hot_w_sum * gt.stride + slot : nullptr,
+                                           a.hot_comp && a.hot_w_sum >= 0 ? (int64_t)gt.stride : 0);
+        VNM_HIP(hipGetLastError());
+        return 0;
+    };
+    if (h->kn_valid) {
         if (ensure_table(h, 1024, s, true)) { release(); pool_free(spill); return 1; }
-        const GTable& g = h->g;
-        const uint64_t slot = g.cap + 1;
+        uint64_t* scr = (uint64_t*)(flags + 8);
         d1.kvalid = h->kn_valid; d1.koff = h->kn_off;
-        d1.nk_tag = g.tag + slot;
-        d1.nk_rows = a.hot_w_rows >= 0 ? g.acc + (uint64_t)a.hot_w_rows * g.stride + slot : nullptr;
-        d1.nk_valid = a.hot_w_valid >= 0 ? g.acc + (uint64_t)a.hot_w_valid * g.stride + slot : nullptr;
-        d1.nk_sum = a.hot_w_sum >= 0 ? g.acc + (uint64_t)a.hot_w_sum * g.stride + slot : nullptr;
-        d1.nk_lo_stride = a.hot_comp && a.hot_w_sum >= 0 ? (int64_t)g.stride : 0;
+        d1.nk_tag = scr;
+        d1.nk_rows = a.hot_w_rows >= 0 ? scr + 1 : nullptr;
+        d1.nk_valid = a.hot_w_valid >= 0 ? scr + 2 : nullptr;
+        d1.nk_sum = a.hot_w_sum >= 0 ? scr + 3 : nullptr;
+        d1.nk_lo_stride = a.hot_comp && a.hot_w_sum >= 0 ? 1 : 0;
     }
     {
         KernelTimer timer("agg_part_scatter1", s);
@@ -4786,14 +4805,18 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
             fprintf(stderr, "[agg] dense: bits %d tb %d levels %d p1 %d p2 %d -> scatter fail %llu spilled %llu, final pass deferred (bound %lld)\n",
                     mp.bits, tb, levels, p1, p2, fl0[0], fl0[2], (long long)dstride);
         if (fl0[0]) { release(); pool_free(rk); pool_free(ra); pool_free(spill); return 2; }
+        if (fold_null_rows()) { release(); pool_free(rk); pool_free(ra); pool_free(spill); return 1; }
         pool_free(rk); pool_free(ra);   // (the run is allocated when the pass runs)
         if (fl0[2]) { *spill_out = spill; *n_spill_out = (int64_t)fl0[2]; }
         else { pool_free(spill); *spill_out = nullptr; *n_spill_out = 0; }
         if ((int64_t)fl0[2] > nrows / 16) h->dense_state = -1;
         DensePending* pd = h->pending;
-        // batches join a pending pass of the same geometry; anything else (or a very long stream) runs it first
+        // batches join a pending pass of the same geometry; anything else (or a very long stream) runs it first.  A pass holds the
+        // entries of its batches (10-12 bytes per row) until it runs: at most 1.5 * 2^30 rows of them, so that a stream of any length
+        // keeps a bounded amount of HBM (and far below the 2^32 rows the 32-bit row counts of the final pass's slots could take)
+        const int64_t pending_max_rows = std::min<int64_t>(env_i64("VNM_DENSE_PENDING_MAX_ROWS", 3LL << 29), (1LL << 32) - 1);
         if (pd && (pd->tb != tb || pd->levels != levels || pd->p1 != p1 || pd->fsplits != fsplits || pd->sets.size() >= DP_MAX_SETS ||
-                   memcmp(&pd->df.map, &mp, sizeof(DenseMap)) != 0)) {
+                   pd->rows + nrows > pending_max_rows || memcmp(&pd->df.map, &mp, sizeof(DenseMap)) != 0)) {
             const int rc = complete_pending(h, s);
             if (rc) { release(); return rc; }
             pd = nullptr;
@@ -4806,6 +4829,7 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
             h->pending = pd;
         } else pool_free(flags);
         pd->dstride = std::min<int64_t>(h->dense_span, pd->dstride + nrows) + 2;
+        pd->rows += nrows;
         DSet st{};
         st.vals = fin_v; st.codes = fin_c; st.counts = fin_n; st.cap = fin_cap; st.pstride = df.pstride; st.rstride = df.rstride; st.regions = fin_regions;
         st.pad = fin_cap < 2048 ? 1 : 0;   // small regions: one wave per region in the final pass
@@ -4822,6 +4846,8 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     unsigned long long fl[4];
     VNM_HIP(hipMemcpyAsync(fl, flags, 32, hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
+    if (!fl[0] && fold_null_rows()) { release(); pool_free(psum); pool_free(plo); pool_free(pcnt); pool_free(rk); pool_free(ra); pool_free(spill); return 1; }
+    if (!fl[0]) VNM_HIP(hipStreamSynchronize(s));   // (the fold reads the flags block release() gives back)
     release();
     pool_free(psum); pool_free(plo); pool_free(pcnt);
     if (getenv("VNM_AGG_TRACE"))
@@ -5057,6 +5083,7 @@ extern "C" vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, i
                                    const int* in_types, const int* in_flags, const int* in_col_ids);
 extern "C" void vnm_agg_destroy(vnm_agg* h);
 static int agg_finish_core(vnm_agg* h, int64_t* n_groups, void* stream);
+static int flush_queue(vnm_agg* h, void* stream);
 
 namespace {
 
@@ -5704,6 +5731,9 @@ void vnm_agg_destroy(vnm_agg* h) {
 int vnm_agg_set_predicate(vnm_agg* h, int enabled, int op, int scalar_is_float, double dval, int64_t ival) {
     if (!h) return set_error("vnm_agg_set_predicate: null handle");
     if (enabled && (op < VNM_EQ || op > VNM_LE)) return set_error("vnm_agg_set_predicate: bad comparison op %d", op);
+    // the waiting batches of an asynchronous stream were recorded under the OLD predicate (and without a predicate column when none was set)
+    if (!h->q.empty()) return set_error("vnm_agg_set_predicate: batches are waiting (call vnm_agg_sync first)");
+    for (vnm_agg* c : h->parts) if (!c->q.empty()) return set_error("vnm_agg_set_predicate: batches are waiting (call vnm_agg_sync first)");
     h->pred_set = enabled != 0;
     h->pred_op = op;
     h->pred_is_float = scalar_is_float;
@@ -6598,6 +6628,32 @@ int vnm_agg_sync(vnm_agg* h, void* stream) {
     return 0;
 }
 
+// the recorded batches the handle (its parts, the suffix operator of an ordered MIN / MAX stream) still needs the buffers of
+static void waiting_of(const vnm_agg* h, int64_t* batches, int64_t* rows) {
+    int64_t pb = 0, pr = 0;
+    for (const vnm_agg* c : h->parts) {   // (each part records the batches the handle hands over: the same ones, part by part)
+        int64_t b = 0, r = 0;
+        waiting_of(c, &b, &r);
+        if (b > pb) { pb = b; pr = r; }
+    }
+    *batches = (int64_t)h->q.size() + pb;
+    *rows = h->q_rows + pr;
+    if (h->ex && h->ex->post) {           // (the prefix handle's queue was flushed at the switch: everything waiting is the suffix's)
+        int64_t b = 0, r = 0;
+        waiting_of(h->ex->post, &b, &r);
+        *batches += b; *rows += r;
+    }
+}
+
+int vnm_agg_waiting(vnm_agg* h, int64_t* batches, int64_t* rows) {
+    if (!h || !batches) return set_error("vnm_agg_waiting: null argument");
+    int64_t b = 0, r = 0;
+    waiting_of(h, &b, &r);
+    *batches = b;
+    if (rows) *rows = r;
+    return 0;
+}
+
 // ---- expressions inside aggregates ---------------------------------------------------------------------------------------
 int vnm_agg_set_input_expr(vnm_agg* h, int func_idx, int n_ins, const vnm_expr_ins* program, int n_cols) {
     if (!h || !program) return set_error("vnm_agg_set_input_expr: null argument");
@@ -7113,6 +7169,7 @@ int vnm_agg_result_device(vnm_agg* h, int n_cols, const int* which, void* const*
         pool_free(ctl);
         for (int c = 0; c < nc; c++) {
             if (null_counts) null_counts[base + c] = (int64_t)c2[2 * c];
+            if (c2[2 * c + 1] & 2ULL) return set_error("aggregate: a group holds 2^32 or more non-NULL inputs of a 64-bit integer SUM / AVG (the exact 128-bit lanes hold 2^32 - 1 per group)");
             if (c2[2 * c + 1]) rc = 2;
         }
     }

@@ -190,6 +190,8 @@ int finalize_func(const FuncOut& fo, int64_t n, const uint64_t* const* words, vo
             return 0;
         case VNM_SUM: {
             if (t == VNM_I64 || t == VNM_U64) {
+                for (int64_t r = 0; r < n; r++)
+                    if (words[fo.w_valid][r] >= (1ULL << 32)) return set_error("aggregate: a group holds 2^32 or more non-NULL inputs of a 64-bit integer SUM / AVG (the exact 128-bit lanes hold 2^32 - 1 per group)");
                 // SumOverflowFunc::Summarize agg_funcs.h:358-397: one group that does not fit promotes the
                 // whole column to decimal128(38,0)
                 bool overflow = false;
@@ -230,6 +232,7 @@ int finalize_func(const FuncOut& fo, int64_t n, const uint64_t* const* words, vo
                 valid[r] = cnt > 0;
                 if (!valid[r]) continue;
                 double avg;
+                if ((t == VNM_I64 || t == VNM_U64) && cnt >= (1ULL << 32)) return set_error("aggregate: a group holds 2^32 or more non-NULL inputs of a 64-bit integer SUM / AVG (the exact 128-bit lanes hold 2^32 - 1 per group)");
                 if (t == VNM_I64 || t == VNM_U64) {
                     i128 s = sum128(fo, words, r);
                     i128 c = (i128)(int64_t)cnt;

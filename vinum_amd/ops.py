@@ -149,6 +149,20 @@ class DeviceAggregate:
         if self._stream_mode:     # (the library reads the buffers when the waiting batches are processed)
             self._waiting.append((keys, inputs, pred))
         L.check(L.lib().vnm_agg_next_device(self._h, nrows, dcol_array(keys), dcol_array(inputs), p, _stream_ptr(stream)))
+        if self._stream_mode:
+            # keep only what the library still holds RECORDED (always the most recent batches; none when this batch's shape is
+            # processed per call): a stream larger than HBM must not stay resident until result() -- the reference streams such
+            # inputs batch by batch (vinum/api/stream_reader.py:32-94)
+            nb = ctypes.c_int64(0)
+            L.check(L.lib().vnm_agg_waiting(self._h, ctypes.byref(nb), None))
+            if nb.value < len(self._waiting):
+                del self._waiting[:len(self._waiting) - nb.value]
+
+    def waiting(self):
+        """(batches, rows) the library holds recorded (stream mode)."""
+        nb, nr = ctypes.c_int64(0), ctypes.c_int64(0)
+        L.check(L.lib().vnm_agg_waiting(self._h, ctypes.byref(nb), ctypes.byref(nr)))
+        return nb.value, nr.value
 
     def finish(self, stream=None) -> int:
         n = ctypes.c_int64(0)
