@@ -190,11 +190,13 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
 int vnm_agg_set_async(vnm_agg* h, int enabled);
 /* processes every waiting batch and waits for `stream` */
 int vnm_agg_sync(vnm_agg* h, void* stream);
-/* How many of the batches passed so far the library still only holds RECORDED (they are always the most recent ones): the caller
- * of an asynchronous stream may release the buffers of every earlier batch -- what keeps the memory of a long stream bounded
- * (the reference streams inputs larger than memory batch by batch: vinum/api/stream_reader.py:32-94, README.rst:43-45).  At most
- * 256 batches / 2^30 rows wait at any time.  *rows (optional) = their row count. */
-int vnm_agg_waiting(vnm_agg* h, int64_t* batches, int64_t* rows);
+/* Which batches of an asynchronous stream the library still only holds RECORDED.  Every vnm_agg_next_device call on the handle
+ * has a sequence number (0, 1, 2, ...; *last_seq = the latest call's); *oldest_seq = the number of the oldest call whose batch is
+ * still waiting somewhere in the operator (-1: none is).  The caller may release the buffers of every batch with a smaller number
+ * -- what keeps the memory of a long stream bounded (the reference streams inputs larger than memory batch by batch:
+ * vinum/api/stream_reader.py:32-94, README.rst:43-45).  *batches / *rows (optional): how much is waiting (at most 256 batches /
+ * 2^30 rows per queue; a batch the parts of a split program hold is counted once per part).  Any pointer may be NULL. */
+int vnm_agg_waiting(vnm_agg* h, int64_t* batches, int64_t* rows, int64_t* oldest_seq, int64_t* last_seq);
 /* Expressions inside aggregates -- `sum((1 - total) * (2 + tax) * (1 - tip))`, vinum/tests/test_query_results.py:436-443;
  * the reference's planner projects the expression into a temporary column first (vinum/planner/planner.py:384-417).
  * vnm_agg_set_input_expr: the input column of function `func_idx` (and of every function sharing its in_col_id; declare

@@ -345,3 +345,19 @@ def test_string_group_keys_across_ranks_gloo(tmp_path, world):
             assert k not in got, f"group {k!r} ended up on two ranks"
             got[k] = (int(c), float(s))
     assert got == exp
+
+
+def test_union_of_dictionaries_mixed_types_and_repeated_values():
+    """ranks whose local dictionaries differ in Arrow type (string / large_string, the null-typed empty dictionary of
+    a rank without rows) and a dictionary that repeats a value: one union type, every value once, the repeats share an id."""
+    import pyarrow as pa
+    from vinum_amd import distributed as D
+    parts = [pa.array(["a", "b", None, "a", "z", "z"]), pa.array([], pa.null()), pa.array(["c", "a", "c"], pa.large_string())]
+    unions = []
+    for r in range(3):
+        u, remap = D.union_of_dictionaries(parts, r)
+        unions.append(u)
+        assert u.type == pa.large_string() and u.to_pylist() == ["a", "b", "z", "c"]
+        back = [None if c < 0 else u[int(c)].as_py() for c in remap]
+        assert back == parts[r].to_pylist()
+    assert all(u.equals(unions[0]) for u in unions)

@@ -253,7 +253,7 @@ def random_agg_case(rng, specials=False):
     """Random aggregate query for the differential tests: (columns dict, key names, input names, funcs, n, groups,
     skew).  1-3 key columns of mixed widths (some with NULLs), 0-3 typed input columns (some with NULLs).
     specials: float inputs carry NaNs, -0.0 and +0.0 (everywhere, or only in the second half of the rows) and are read by
-    MIN / MAX / COUNT -- the row-order dependent part of MinMaxFunc::Update (agg_funcs.h:188-201)."""
+    every function -- the row-order dependent part of MinMaxFunc::Update (agg_funcs.h:188-201), the sign of an all-(-0.0) SUM."""
     from oracle import oracle as O
     n = int(rng.integers(150_000, 420_000))
     groups = int(rng.choice([3, 40, 900, 5_000, 60_000, 250_000]))
@@ -312,10 +312,8 @@ def random_agg_case(rng, specials=False):
             if rng.random() < 0.4:
                 vals = np.where(np.isnan(vals), vals, -vals)      # zero is the MAXIMUM of many groups
             cols[name] = pa.array(vals, mask=None if a.null_count == 0 else ~np.array(a.is_valid()))
-            picks = rng.choice([O.MIN, O.MAX, O.COUNT], size=int(rng.integers(1, 4)), replace=False)
-            for f in picks:
-                funcs.append((int(f), name, f"f{len(funcs)}"))
-            continue
+            # (SUM / AVG too: the inputs are quantised, so the sums are exact in any order -- a group whose inputs are all -0.0 sums
+            # to -0.0, SumFunc starts from the first value: agg_funcs.h:286-305)
         picks = rng.choice([O.SUM, O.AVG, O.MIN, O.MAX, O.COUNT], size=int(rng.integers(1, 4)), replace=False)
         for f in picks:
             funcs.append((int(f), name, f"f{len(funcs)}"))

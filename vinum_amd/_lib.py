@@ -63,7 +63,7 @@ PROTOTYPES = {
     "vnm_agg_next_device": (c_int, [c_void, c_i64, c_void, c_void, c_void, c_void]),
     "vnm_agg_set_async": (c_int, [c_void, c_int]),
     "vnm_agg_sync": (c_int, [c_void, c_void]),
-    "vnm_agg_waiting": (c_int, [c_void, c_void, c_void]),
+    "vnm_agg_waiting": (c_int, [c_void, c_void, c_void, c_void, c_void]),
     "vnm_agg_set_input_expr": (c_int, [c_void, c_int, c_int, c_void, c_int]),
     "vnm_agg_next_device_expr": (c_int, [c_void, c_i64, c_void, c_void, c_void, c_int, c_void, c_void]),
     "vnm_agg_finish": (c_int, [c_void, c_void, c_void]),

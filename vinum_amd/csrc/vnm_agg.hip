@@ -1638,7 +1638,7 @@ __global__ __launch_bounds__(OG_BLOCK) void agg_onegroup_hot_kernel(AggArgs a) {
     const double2* pp = PM == 2 ? (const double2*)((const double*)a.pred.values + a.pred.offset) : nullptr;
     const int op = a.p.op;
     const double thr = a.p.dval;
-    double sf = 0.0, sc = 0.0;  // float64 sum and the accumulated rounding errors of its adds (see M_ADD_F64C)
+    double sf = -0.0, sc = 0.0;  // float64 sum (from the additive identity -0.0, see merge_init) and the accumulated rounding errors of its adds (see M_ADD_F64C)
     uint64_t si = 0, slo = 0, shis = 0, shiu = 0, cnt = 0, mn = ~0ULL, mx = 0;
     auto take = [&](uint64_t vb, double pv) {
         const double f = VT == VNM_F64 ? __longlong_as_double((long long)vb) : (VT == VNM_U64 ? (double)vb : (double)(int64_t)vb);
@@ -1722,7 +1722,7 @@ __global__ __launch_bounds__(OG_BLOCK) void agg_onegroup_hot_kernel(AggArgs a) {
         }
         const int w = a.hot_w[tid];
         const int mk = a.plan.merge[w];
-        if (src == 0 && mk == M_ADD_F64) v = (uint64_t)__double_as_longlong(__longlong_as_double((long long)v) + comp);
+        if (src == 0 && mk == M_ADD_F64) v = (uint64_t)__double_as_longlong(fsum2(__longlong_as_double((long long)v), comp));
         if (v != merge_init(mk) || mk == M_ADD_F64 || mk == M_ADD_F64C) g_merge(&a.g.acc[(uint64_t)w * a.g.stride], mk, v, (int64_t)a.g.stride);
         if (src == 0 && mk == M_ADD_F64C && comp != 0.0)
             __hip_atomic_fetch_add((double*)&a.g.acc[(uint64_t)(w + 1) * a.g.stride], comp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2510,7 +2510,7 @@ __global__ __launch_bounds__(PA_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))
         const int part = (int)(unit % a.splits);
         for (int i = tid; i < PA_SLOTS; i += PA_BLOCK) {
             lkey[i] = i < PA_LIVE ? EMPTY : PA_RESERVED;
-            if (i < PA_LIVE + 2) { lsum[i] = 0; lcnt[i] = 0; llo[i] = 0.0f; }
+            if (i < PA_LIVE + 2) { lsum[i] = F64_NEG_ZERO; lcnt[i] = 0; llo[i] = 0.0f; }
         }
         if (tid == 0) { s_n = 0; s_fail = 0; s_sp[0] = 0; s_sp[1] = 0; }
         __syncthreads();
@@ -3343,7 +3343,7 @@ __device__ __forceinline__ void fin_cell(const FinArgs& a, int64_t i, bool& vali
                             if (valid && !fits) __hip_atomic_fetch_or(&a.ctl[1], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             bits = slo;
                         } else if (type_is_float(t)) {
-                            bits = (uint64_t)__double_as_longlong(__longlong_as_double((long long)wa) + (a.words[2] ? __longlong_as_double((long long)wb) : 0.0));
+                            bits = (uint64_t)__double_as_longlong(fsum2(__longlong_as_double((long long)wa), a.words[2] ? __longlong_as_double((long long)wb) : 0.0));
                         } else bits = wa;  // int64 / uint64 accumulators of the narrow integers; time32 keeps its low 32 bits
                         break;
                     default: {  // VNM_AVG
@@ -3374,7 +3374,7 @@ __device__ __forceinline__ void fin_cell(const FinArgs& a, int64_t i, bool& vali
                                 }
                                 avg = fin_huge_to_double(qlo, qhi) + fin_huge_to_double(rlo, rhi) / (double)cnt;  // agg_funcs.h:524-540
                             } else if (type_is_float(t)) {
-                                avg = (__longlong_as_double((long long)wa) + (a.words[2] ? __longlong_as_double((long long)wb) : 0.0)) / (double)cnt;
+                                avg = fsum2(__longlong_as_double((long long)wa), a.words[2] ? __longlong_as_double((long long)wb) : 0.0) / (double)cnt;
                             } else if (type_is_unsigned(t)) avg = (double)wa / (double)cnt;
                             else avg = (double)(int64_t)wa / (double)cnt;
                         }
@@ -3529,7 +3529,7 @@ struct vnm_agg {
     // to the device together as the segments of one logical batch -- at vnm_agg_sync / finish / result, when 2^30 rows or 256
     // batches are waiting, or when a batch of another shape arrives.  No host read-back, allocation or launch per next().
     bool async = false;
-    struct QBatch { int64_t nrows; vnm_dcol key, col, pred; std::vector<vnm_dcol> ins; };   // ins: one column per function (several input columns)
+    struct QBatch { int64_t nrows; vnm_dcol key, col, pred; std::vector<vnm_dcol> ins; int64_t seq; };   // ins: one column per function (several input columns); seq: see cur_seq
     bool q_multi = false;                  // the waiting batches carry several input columns (they are cut into parts when they go to the device)
     std::vector<QBatch> q;
     int64_t q_rows = 0;
@@ -3543,6 +3543,12 @@ struct vnm_agg {
     std::vector<VSeg> seg_host;                         // the segment table of the last launch (kept until the next one: H2D source)
     // reference-exact float MIN / MAX under NaNs and mixed-sign zeros (round 5, vnm_agg_exact.inc): top-level handles only
     struct vnm_agg_exact* ex = nullptr;
+    // Which batches a stream still needs the buffers of (vnm_agg_waiting): every vnm_agg_next_device call on a TOP-LEVEL handle takes the
+    // next sequence number; a recorded batch keeps the number of the call that brought it, also when it is handed on to the operators
+    // the handle runs for itself (parts, the suffix operator of an ordered MIN / MAX stream), which record under the caller's number.
+    bool child = false;
+    int64_t seq = 0;        // calls so far (top-level handles)
+    int64_t cur_seq = -1;   // number of the batch being handed in
 };
 
 namespace {
@@ -3561,8 +3567,12 @@ int table_alloc(vnm_agg* h, GTable* g, uint64_t cap, hipStream_t s) {
     VNM_HIP(hipMemsetAsync(g->tag, 0xFF, g->stride * 8, s));
     VNM_HIP(hipMemsetAsync(g->ctl, 0, 64, s));
     for (int w = 0; w < g->n_words; w++) {
-        int v = h->plan.merge[w] == M_MIN_U64 ? 0xFF : 0;
-        VNM_HIP(hipMemsetAsync(g->acc + (size_t)w * g->stride, v, g->stride * 8, s));
+        const uint64_t init = merge_init(h->plan.merge[w]);
+        if (init == 0 || init == ~0ULL) VNM_HIP(hipMemsetAsync(g->acc + (size_t)w * g->stride, init ? 0xFF : 0, g->stride * 8, s));
+        else {   // (float sums start at -0.0: not a byte pattern)
+            fill_u64_kernel<<<(int)std::min<uint64_t>((g->stride + 255) / 256, (uint64_t)device_info().num_cus * 8), 256, 0, s>>>(g->acc + (size_t)w * g->stride, init, (int64_t)g->stride);
+            VNM_HIP(hipGetLastError());
+        }
     }
     return 0;
 }
@@ -4284,7 +4294,8 @@ int dense_scan_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hipStream_
         sp->part_cnt = (uint32_t*)pool_alloc((size_t)cus * slots * 4);
         sp->flags = (unsigned long long*)pool_alloc(64);
         if (!sp->t.sum || !sp->t.lo || !sp->t.cnt || !sp->part_sum || !sp->part_lo || !sp->part_cnt || !sp->flags) { delete sp; return 1; }
-        if (hipMemsetAsync(sp->t.sum, 0, (size_t)slots * 8, s) != hipSuccess || hipMemsetAsync(sp->t.lo, 0, (size_t)slots * 8, s) != hipSuccess ||
+        fill_u64_kernel<<<(slots + 255) / 256, 256, 0, s>>>((uint64_t*)sp->t.sum, F64_NEG_ZERO, (int64_t)slots);   // (sums start at -0.0: merge_init)
+        if (hipGetLastError() != hipSuccess || hipMemsetAsync(sp->t.lo, 0, (size_t)slots * 8, s) != hipSuccess ||
             hipMemsetAsync(sp->t.cnt, 0, (size_t)slots * 8, s) != hipSuccess) { delete sp; return set_error("aggregate: memset of the stream table failed"); }
         h->scan_pending = sp;
     }
@@ -4549,6 +4560,8 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     auto release = [&]() { pool_free(flags); pool_free(v1); pool_free(c1); pool_free(n1); pool_free(v2); pool_free(c2); pool_free(n2); };
     if (!flags || !v1 || !c1 || !n1 || !spill || (vn_lists && !nspill)) { release(); pool_free(spill); return 1;}
     VNM_HIP(hipMemsetAsync(flags, 0, 128, s));
+    fill_u64_kernel<<<1, 1, 0, s>>>((uint64_t*)flags + 11, F64_NEG_ZERO, 1);   // (the NULL-key rows' sum starts at -0.0: merge_init)
+    VNM_HIP(hipGetLastError());
     DPartArgs d1{};
     d1.map = mp;
     d1.kp = (const uint64_t*)a.keys[0].values + a.keys[0].offset;
@@ -5299,7 +5312,7 @@ int tuple_next(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* 
     vnm_dcol gk{};
     gk.values = a.out; gk.type = VNM_U64; gk.length = nrows;
     int rc = vnm_agg_set_predicate(h->inner, h->pred_set ? 1 : 0, h->pred_op, h->pred_is_float, h->pred_dval, h->pred_ival);
-    if (!rc) rc = vnm_agg_next_device(h->inner, nrows, &gk, inputs, pred, (void*)s);
+    if (!rc) { h->inner->child = true; h->inner->cur_seq = h->cur_seq; rc = vnm_agg_next_device(h->inner, nrows, &gk, inputs, pred, (void*)s); }
     if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = set_error("aggregate: tuple-dictionary batch failed");
     if (!rc) h->rows_seen += nrows;
     return rc;
@@ -5549,6 +5562,7 @@ int next_parts(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* 
         const int nf = (int)h->part_funcs[p].size();
         for (int q = 0; q < nf; q++) in[q] = inputs[h->part_funcs[p][q]];
         VNM_TRY(vnm_agg_set_predicate(c, h->pred_set ? 1 : 0, h->pred_op, h->pred_is_float, h->pred_dval, h->pred_ival));
+        c->child = true; c->cur_seq = h->cur_seq;
         VNM_TRY(vnm_agg_next_device(c, nrows, keys, in, pred, stream));
         // every part of the dense path keeps its scatter output (~10-18 bytes per row) for a deferred final pass: many parts over a
         // very large batch run their final passes right away instead of holding all of that at once
@@ -5731,6 +5745,9 @@ void vnm_agg_destroy(vnm_agg* h) {
 int vnm_agg_set_predicate(vnm_agg* h, int enabled, int op, int scalar_is_float, double dval, int64_t ival) {
     if (!h) return set_error("vnm_agg_set_predicate: null handle");
     if (enabled && (op < VNM_EQ || op > VNM_LE)) return set_error("vnm_agg_set_predicate: bad comparison op %d", op);
+    const bool same = h->pred_set == (enabled != 0) && (!enabled || (h->pred_op == op && h->pred_is_float == scalar_is_float && h->pred_ival == ival &&
+                                                                     memcmp(&h->pred_dval, &dval, 8) == 0));
+    if (same) return 0;
     // the waiting batches of an asynchronous stream were recorded under the OLD predicate (and without a predicate column when none was set)
     if (!h->q.empty()) return set_error("vnm_agg_set_predicate: batches are waiting (call vnm_agg_sync first)");
     for (vnm_agg* c : h->parts) if (!c->q.empty()) return set_error("vnm_agg_set_predicate: batches are waiting (call vnm_agg_sync first)");
@@ -5865,7 +5882,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                 vnm_dcol pk{};
                 pk.values = packed; pk.type = VNM_U64; pk.length = nrows;
                 if (h->pred_set) rc = vnm_agg_set_predicate(h->inner, 1, h->pred_op, h->pred_is_float, h->pred_dval, h->pred_ival);
-                if (!rc) rc = vnm_agg_next_device(h->inner, nrows, &pk, inputs, pred, stream);
+                if (!rc) { h->inner->child = true; h->inner->cur_seq = h->cur_seq; rc = vnm_agg_next_device(h->inner, nrows, &pk, inputs, pred, stream); }
                 if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = set_error("aggregate: packed batch failed");
                 pool_free(packed);
                 if (!rc) h->rows_seen += nrows;
@@ -6529,7 +6546,11 @@ static int flush_queue(vnm_agg* h, void* stream) {
             if (!b.ins.empty()) in[i] = b.ins[i];
             else if (h->func_col[i] >= 0) in[i] = b.col;
         }
-        return next_device_impl(h, n, &b.key, in, h->pred_set ? &b.pred : nullptr, stream);
+        const int64_t save = h->cur_seq;
+        h->cur_seq = b.seq;     // (whoever records the batch again -- the parts of a split program -- keeps its number)
+        const int rc1 = next_device_impl(h, n, &b.key, in, h->pred_set ? &b.pred : nullptr, stream);
+        h->cur_seq = save;
+        return rc1;
     };
     if (q.size() > 1 && getenv("VNM_AGG_NO_SEGMENTS") == nullptr) {
         h->segs_active = &q;
@@ -6583,6 +6604,7 @@ static bool queueable(const vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
 int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs,
                         const vnm_dcol* pred, void* stream) {
     if (!h) return set_error("vnm_agg_next_device: null handle");
+    if (!h->child) h->cur_seq = h->seq++;
     if (h->ex && inputs && (keys || h->plan.n_keys == 0)) {   // float MIN / MAX: the flag pass, and the ordered mode once the stream is unclean
         bool handled = false;
         VNM_TRY(exact_next(h, nrows, keys, inputs, pred, stream, &handled));
@@ -6595,6 +6617,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
             // when the waiting batches are processed)
             if (h->q_rows + nrows > (1LL << 30) || h->q.size() >= 256) VNM_TRY(flush_queue(h, stream));
             vnm_agg::QBatch b{};
+            b.seq = h->cur_seq;
             b.nrows = nrows; b.key = keys[0]; b.col = inputs[h->col_first_func[0]];
             if (multi) b.ins.assign(inputs, inputs + h->n_funcs);
             h->q_multi = multi;
@@ -6629,28 +6652,22 @@ int vnm_agg_sync(vnm_agg* h, void* stream) {
 }
 
 // the recorded batches the handle (its parts, the suffix operator of an ordered MIN / MAX stream) still needs the buffers of
-static void waiting_of(const vnm_agg* h, int64_t* batches, int64_t* rows) {
-    int64_t pb = 0, pr = 0;
-    for (const vnm_agg* c : h->parts) {   // (each part records the batches the handle hands over: the same ones, part by part)
-        int64_t b = 0, r = 0;
-        waiting_of(c, &b, &r);
-        if (b > pb) { pb = b; pr = r; }
-    }
-    *batches = (int64_t)h->q.size() + pb;
-    *rows = h->q_rows + pr;
-    if (h->ex && h->ex->post) {           // (the prefix handle's queue was flushed at the switch: everything waiting is the suffix's)
-        int64_t b = 0, r = 0;
-        waiting_of(h->ex->post, &b, &r);
-        *batches += b; *rows += r;
-    }
+static void waiting_of(const vnm_agg* h, int64_t* batches, int64_t* rows, int64_t* oldest) {
+    *batches += (int64_t)h->q.size();
+    *rows += h->q_rows;
+    for (const auto& b : h->q) if (*oldest < 0 || b.seq < *oldest) *oldest = b.seq;
+    for (const vnm_agg* c : h->parts) waiting_of(c, batches, rows, oldest);
+    if (h->ex && h->ex->post) waiting_of(h->ex->post, batches, rows, oldest);
 }
 
-int vnm_agg_waiting(vnm_agg* h, int64_t* batches, int64_t* rows) {
-    if (!h || !batches) return set_error("vnm_agg_waiting: null argument");
-    int64_t b = 0, r = 0;
-    waiting_of(h, &b, &r);
-    *batches = b;
+int vnm_agg_waiting(vnm_agg* h, int64_t* batches, int64_t* rows, int64_t* oldest_seq, int64_t* last_seq) {
+    if (!h) return set_error("vnm_agg_waiting: null handle");
+    int64_t b = 0, r = 0, o = -1;
+    waiting_of(h, &b, &r, &o);
+    if (batches) *batches = b;     // (a batch the parts of a split program hold is counted once per part)
     if (rows) *rows = r;
+    if (oldest_seq) *oldest_seq = o;
+    if (last_seq) *last_seq = h->seq - 1;
     return 0;
 }
 

@@ -62,7 +62,14 @@ struct AggPlan {
     AccOp ops[AGG_MAX_OPS];
 };
 
-__host__ __device__ inline uint64_t merge_init(int mk) { return mk == M_MIN_U64 ? ~0ULL : 0ULL; }
+// Float sums start at -0.0, the additive identity of IEEE arithmetic (x + -0.0 == x for every x, -0.0 + -0.0 == -0.0, while
+// +0.0 + -0.0 == +0.0): SumFunc starts from the group's first value (agg_funcs.h:286-305), so a group whose inputs are all -0.0
+// sums to -0.0 there -- and here, as long as EVERY accumulator a row can pass through starts at -0.0 (LDS tables, per-thread
+// partials, HBM tables, merge kernels).  The compensation words may start at either zero: hi + lo goes through fsum2.
+constexpr uint64_t F64_NEG_ZERO = 0x8000000000000000ULL;
+__host__ __device__ inline uint64_t merge_init(int mk) { return mk == M_MIN_U64 ? ~0ULL : ((mk == M_ADD_F64 || mk == M_ADD_F64C) ? F64_NEG_ZERO : 0ULL); }
+// hi + lo of a compensated sum; a zero compensation term (of either sign) leaves hi as it is, -0.0 included
+__host__ __device__ inline double fsum2(double hi, double lo) { return lo == 0.0 ? hi : hi + lo; }
 
 // Lowers (funcs, input types) onto words/ops.  col_of_func[i] = index in the distinct-column list
 // (or -1), n_cols = number of distinct columns, col_first_func[c] = a function that reads column c.

@@ -154,7 +154,7 @@ static inline double fsum_word(const FuncOut& fo, const uint64_t* const* words, 
     double hi, lo = 0.0;
     memcpy(&hi, &words[fo.w_a][r], 8);
     if (fo.w_b >= 0) memcpy(&lo, &words[fo.w_b][r], 8);
-    return hi + lo;
+    return fsum2(hi, lo);
 }
 
 static inline i128 sum128(const FuncOut& fo, const uint64_t* const* words, int64_t r) {

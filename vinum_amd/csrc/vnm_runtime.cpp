@@ -5,6 +5,8 @@
 #include <functional>
 #include <cstring>
 #include <map>
+#include <new>
+#include <pthread.h>
 #include <thread>
 #include <unordered_map>
 
@@ -67,31 +69,61 @@ size_t round_size(size_t b) {
     return (b + step - 1) / step * step;
 }
 
-// releases cached blocks, largest first, until at most `keep` bytes stay cached
+// releases cached blocks, largest first, until at most `keep` bytes stay cached.  The victims are COLLECTED under the lock and
+// freed after it is released: hipFree synchronises the device, and a query thread must not wait behind it for pool_alloc / pool_free.
 size_t trim_to(size_t keep) {
-    std::lock_guard<std::mutex> g(g_pool_mu);
+    std::vector<void*> victims;
     size_t bytes = 0;
-    while (g_cached_bytes > keep && !g_free.empty()) {
-        auto it = std::prev(g_free.end());
-        bytes += it->first;
-        g_cached_bytes -= it->first;
-        g_sizes.erase(it->second);
-        (void)hipFree(it->second);
-        g_free.erase(it);
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        while (g_cached_bytes > keep && !g_free.empty()) {
+            auto it = std::prev(g_free.end());
+            bytes += it->first;
+            g_cached_bytes -= it->first;
+            g_sizes.erase(it->second);
+            victims.push_back(it->second);
+            g_free.erase(it);
+        }
     }
+    for (void* p : victims) (void)hipFree(p);
     return bytes;
 }
 
-void reaper_main() {
+std::thread* g_reaper = nullptr;
+std::mutex& g_reaper_mu = *new std::mutex;
+std::condition_variable& g_reaper_cv = *new std::condition_variable;
+
+void reaper_main(int device) {
+    if (device >= 0) (void)hipSetDevice(device);   // (the pool's blocks live on the device the process selected: vnm_init / torch's current device)
+    std::unique_lock<std::mutex> lk(g_reaper_mu);
     for (;;) {
-        std::this_thread::sleep_for(std::chrono::milliseconds(250));
+        g_reaper_cv.wait_for(lk, std::chrono::milliseconds(250));
         if (g_exiting.load()) return;
         const int64_t idle = g_idle_ms.load();
         if (idle < 0) continue;
         bool over;
         { std::lock_guard<std::mutex> g(g_pool_mu); over = g_cached_bytes > (size_t)g_keep_bytes.load(); }
-        if (over && now_ms() - g_last_activity_ms.load() >= idle && !g_exiting.load()) trim_to((size_t)g_keep_bytes.load());
+        if (over && now_ms() - g_last_activity_ms.load() >= idle && !g_exiting.load()) {
+            lk.unlock();
+            trim_to((size_t)g_keep_bytes.load());
+            lk.lock();
+        }
     }
+}
+
+void stop_reaper() {   // atexit: signal and JOIN, so that the thread is never inside hipFree while the HIP runtime tears down
+    g_exiting.store(true);
+    { std::lock_guard<std::mutex> g(g_reaper_mu); }
+    g_reaper_cv.notify_all();
+    if (g_reaper && g_reaper->joinable()) g_reaper->join();
+}
+
+void after_fork_in_child() {   // the child has no reaper thread and must not believe it has (the mutexes are leaked objects: re-made)
+    new (&g_pool_mu) std::mutex;
+    new (&g_reaper_mu) std::mutex;
+    g_reaper = nullptr;
+    g_reaper_started.store(false);
+    g_exiting.store(false);
 }
 
 void touch_pool() {
@@ -103,8 +135,15 @@ void touch_pool() {
             const char* k = getenv("VNM_POOL_KEEP_BYTES");
             if (k) g_keep_bytes.store(atoll(k));
         }
-        std::atexit([] { g_exiting.store(true); });
-        std::thread(reaper_main).detach();
+        static bool hooks = false;
+        if (!hooks) {
+            hooks = true;
+            std::atexit(stop_reaper);
+            (void)pthread_atfork(nullptr, nullptr, after_fork_in_child);
+        }
+        int device = -1;
+        if (hipGetDevice(&device) != hipSuccess) device = -1;
+        g_reaper = new std::thread(reaper_main, device);
     }
 }
 }  // namespace

@@ -489,7 +489,16 @@ def union_of_dictionaries(parts, rank):
     import numpy as np
     import pyarrow as pa
     import pyarrow.compute as pc
-    union = pa.array([], type=parts[0].type)
+    # ONE type for every rank's part: a rank without rows brings a null-typed (or differently typed) empty dictionary, string and
+    # large_string dictionaries may meet -- the first part with a real type decides (a large variant anywhere wins over the small one)
+    typed = [p.type for p in parts if not pa.types.is_null(p.type)]
+    ut = typed[0] if typed else pa.null()
+    for t in typed:
+        if pa.types.is_large_string(t) or pa.types.is_large_binary(t):
+            ut = t
+            break
+    parts = [p if p.type == ut else (pa.nulls(len(p), ut) if pa.types.is_null(p.type) else p.cast(ut)) for p in parts]
+    union = pa.array([], type=ut)
     remap = None
     for r, part in enumerate(parts):
         valid = part.is_valid().to_numpy(zero_copy_only=False) if len(part) else np.zeros(0, bool)
@@ -499,10 +508,13 @@ def union_of_dictionaries(parts, rank):
             idx = pc.index_in(live, value_set=union) if len(union) else pa.nulls(len(live), pa.int32())
             known = idx.is_valid().to_numpy(zero_copy_only=False)
             p_live = idx.fill_null(0).to_numpy(zero_copy_only=False).astype(np.int64)
-            n_new = int((~known).sum())
-            if n_new:
-                p_live[~known] = len(union) + np.arange(n_new, dtype=np.int64)
-                union = pa.concat_arrays([union, live.filter(pa.array(~known))])
+            if not known.all():
+                # the values new to the union, each ONCE (a dictionary that repeats a value would otherwise split its group): the
+                # position of a new value = the union's length + its rank among the distinct new values, in first-appearance order
+                fresh = live.filter(pa.array(~known))
+                distinct = pc.unique(fresh)
+                p_live[~known] = len(union) + pc.index_in(fresh, value_set=distinct).to_numpy(zero_copy_only=False).astype(np.int64)
+                union = pa.concat_arrays([union, distinct])
             pos[valid] = p_live
         if r == rank:
             remap = pos.astype(np.int32)

@@ -4,6 +4,7 @@ These are the building blocks of the operator mirror in vinum_amd/core/ and of b
 touch the host except for scalar results (row counts) and final result materialisation.
 """
 import ctypes
+import os
 
 import numpy as np
 import pyarrow as pa
@@ -146,22 +147,24 @@ class DeviceAggregate:
             L.check(L.lib().vnm_agg_next_device_expr(self._h, nrows, dcol_array(keys), dcol_array(inputs), p, len(expr_cols),
                                                      dcol_array(expr_cols), _stream_ptr(stream)))
             return
-        if self._stream_mode:     # (the library reads the buffers when the waiting batches are processed)
-            self._waiting.append((keys, inputs, pred))
         L.check(L.lib().vnm_agg_next_device(self._h, nrows, dcol_array(keys), dcol_array(inputs), p, _stream_ptr(stream)))
         if self._stream_mode:
-            # keep only what the library still holds RECORDED (always the most recent batches; none when this batch's shape is
-            # processed per call): a stream larger than HBM must not stay resident until result() -- the reference streams such
-            # inputs batch by batch (vinum/api/stream_reader.py:32-94)
-            nb = ctypes.c_int64(0)
-            L.check(L.lib().vnm_agg_waiting(self._h, ctypes.byref(nb), None))
-            if nb.value < len(self._waiting):
-                del self._waiting[:len(self._waiting) - nb.value]
+            # The library reads the buffers of a RECORDED batch when the waiting batches are processed: they are kept until then, and
+            # no longer -- a stream larger than HBM must not stay resident until result() (the reference streams such inputs batch by
+            # batch, vinum/api/stream_reader.py:32-94).  vnm_agg_waiting names the oldest call whose batch still waits.
+            oldest, last = ctypes.c_int64(-1), ctypes.c_int64(-1)
+            L.check(L.lib().vnm_agg_waiting(self._h, None, None, ctypes.byref(oldest), ctypes.byref(last)))
+            if oldest.value < 0:
+                self._waiting.clear()
+            else:
+                self._waiting.append((last.value, keys, inputs, pred))
+                if self._waiting[0][0] < oldest.value:
+                    self._waiting = [w for w in self._waiting if w[0] >= oldest.value]
 
     def waiting(self):
         """(batches, rows) the library holds recorded (stream mode)."""
         nb, nr = ctypes.c_int64(0), ctypes.c_int64(0)
-        L.check(L.lib().vnm_agg_waiting(self._h, ctypes.byref(nb), ctypes.byref(nr)))
+        L.check(L.lib().vnm_agg_waiting(self._h, ctypes.byref(nb), ctypes.byref(nr), None, None))
         return nb.value, nr.value
 
     def finish(self, stream=None) -> int:
