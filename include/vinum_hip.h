@@ -343,6 +343,19 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
                            int64_t* out_indices, void* out_sorted_key0, int* wrote_key0, void* stream);
 int vnm_take(const vnm_dcol* col, const int64_t* indices, int64_t n, void* out_values, uint8_t* out_valid,
              void* stream);
+/* Take for the column types vnm_take does not cover (Sort::Sorted takes EVERY column of the table, any Arrow type: sort.cpp:38-40).
+ * All pointers are DEVICE pointers unless said otherwise.
+ * vnm_take_varwidth: utf8 / binary values by row ids.  offsets: n_rows + 1 int64 offsets into `data` (int32 Arrow offsets are widened
+ *   by the caller), validity: bitmap (bit i = row i) or NULL.  out_offsets: n + 1 int64s; *out_data: the gathered bytes, a block the
+ *   CALLER frees with vnm_free (*out_bytes of them); out_valid: n bytes (1 = valid) or NULL.  A NULL row contributes no bytes.
+ * vnm_take_bits: bits (bit_offset + indices[i]) of a bitmap -> n bytes of 0 / 1 (boolean values, validity bitmaps).
+ * vnm_take_fixed16: 16-byte values (decimal128).
+ * vnm_decimal128_sort_keys: decimal128 values -> (high word int64, low word uint64): two numeric sort keys, most significant first. */
+int vnm_take_varwidth(const int64_t* offsets, const uint8_t* data, const uint8_t* validity, const int64_t* indices, int64_t n,
+                      int64_t* out_offsets, uint8_t** out_data, int64_t* out_bytes, uint8_t* out_valid, void* stream);
+int vnm_take_bits(const uint8_t* bits, int64_t bit_offset, const int64_t* indices, int64_t n, uint8_t* out_bytes, void* stream);
+int vnm_take_fixed16(const void* values, const int64_t* indices, int64_t n, void* out_values, void* stream);
+int vnm_decimal128_sort_keys(const void* values, int64_t n, int64_t* out_hi, uint64_t* out_lo, void* stream);
 typedef struct vnm_sort_op vnm_sort_op;
 vnm_sort_op* vnm_sort_op_create(int n, const char** cols, const int* orders);
 int vnm_sort_op_next(vnm_sort_op* h, struct ArrowArray* batch, struct ArrowSchema* schema);
@@ -410,6 +423,12 @@ int vnm_strdict_encode_device(vnm_strdict* h, const vnm_dcol* offsets, const uin
                               const uint8_t* data, int64_t data_base, int32_t* out_codes, int64_t* n_new, int64_t* new_bytes,
                               void* stream);
 int vnm_strdict_fetch_new(vnm_strdict* h, int32_t* ids_host, int32_t* lens_host, uint8_t* bytes_host);
+/* Order-preserving RANKS of the dictionary's values (round 5: utf8 / binary ORDER BY keys on the device -- Arrow's SortIndices compares
+ * such values byte-wise, sort.cpp:22-37).  out_rank_of_id: DEVICE array of vnm_strdict_ids(h) int32s; entry id = the position of the
+ * value with that id among all values in ascending byte order (ids never handed out are left untouched).  vnm_strdict_codes_to_ranks maps
+ * a column of codes (device; -1 = NULL -> rank 0, the row's validity bit says NULL) to its ranks: an ordinary int32 sort key column. */
+int vnm_strdict_ranks_device(vnm_strdict* h, int32_t* out_rank_of_id, void* stream);
+int vnm_strdict_codes_to_ranks(const int32_t* codes, const int32_t* rank_of_id, int64_t n, int32_t* out_ranks, void* stream);
 
 /* ---- CSV ingest ---------------------------------------------------------------------------------------
  * replaces, for numeric columns, the pyarrow.csv reader behind stream_csv() / read_csv() (vinum/io/arrow.py:58-61,106;

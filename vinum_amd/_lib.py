@@ -114,6 +114,12 @@ PROTOTYPES = {
     "vnm_strdict_encode": (c_int, [c_void, c_void, c_int, c_void, c_void, c_i64, c_i64, c_void, c_void, c_void, c_void]),
     "vnm_strdict_encode_device": (c_int, [c_void, c_void, c_void, c_i64, c_void, c_i64, c_void, c_void, c_void, c_void]),
     "vnm_strdict_fetch_new": (c_int, [c_void, c_void, c_void, c_void]),
+    "vnm_strdict_ranks_device": (c_int, [c_void, c_void, c_void]),
+    "vnm_strdict_codes_to_ranks": (c_int, [c_void, c_void, c_i64, c_void, c_void]),
+    "vnm_take_varwidth": (c_int, [c_void, c_void, c_void, c_void, c_i64, c_void, c_void, c_void, c_void, c_void]),
+    "vnm_take_bits": (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_void]),
+    "vnm_take_fixed16": (c_int, [c_void, c_void, c_i64, c_void, c_void]),
+    "vnm_decimal128_sort_keys": (c_int, [c_void, c_i64, c_void, c_void, c_void]),
     "vnm_malloc": (c_void, [c_i64]),
     "vnm_free": (c_int, [c_void]),
     "vnm_pool_trim": (c_i64, []),

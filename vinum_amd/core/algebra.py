@@ -129,20 +129,22 @@ class SortOperator(Operator):
             if f.name in self._cols and pa.types.is_boolean(f.type):   # algebra.py:191-201
                 raise RuntimeError("Sorting by boolean column is not supported yet. "
                                    "Please use float(bool_column) as a workaround.")
-        for c in self._cols:
-            if not is_supported(table.schema.field(c).type):
-                raise RuntimeError(f"ORDER BY {c}: sorting by a non-numeric column is not on the GPU path")
         dicts = {}
         dev = DeviceRecordBatch.from_arrow(table.to_batches()[0] if table.num_rows else pa.RecordBatch.from_arrays(
             [pa.array([], f.type) for f in table.schema], names=table.schema.names), dicts).columns
         n = table.num_rows
         k = self._limit if 0 < self._limit < n else 0
         m = k if k else n
+        # a string / binary / decimal ... sort key is dictionary-coded in HBM: its order-preserving ranks are the key (NULL stays
+        # NULL, equal values share a rank -- the stable sort keeps their row order like SortIndices, sort.cpp:22-37)
+        keys = [dev[c] if dev[c].dictionary is None else dev[c].dictionary.rank_column(dev[c]) for c in self._cols]
         sorted_key = None
         if k:
-            idx = ops.sort_indices([dev[c] for c in self._cols], self._orders, limit=k)
+            idx = ops.sort_indices(keys, self._orders, limit=k)
         else:   # a full sort hands its first key back sorted: one gather less
-            idx, sorted_key = ops.sort_indices_keyed([dev[c] for c in self._cols], self._orders)
+            idx, sorted_key = ops.sort_indices_keyed(keys, self._orders)
+        if dev[self._cols[0]].dictionary is not None:
+            sorted_key = None          # (the sorted ranks are not the column)
         yield DeviceRecordBatch({name: sorted_key if (sorted_key is not None and name == self._cols[0]) else ops.take(col, idx, m)
                                  for name, col in dev.items()}, m)
 

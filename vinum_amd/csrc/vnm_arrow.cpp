@@ -559,6 +559,236 @@ int vnm_agg_op_result(vnm_agg_op* h, struct ArrowArray* out, struct ArrowSchema*
 // =========================================================================================================
 // sort operator
 // =========================================================================================================
+// ---- column kinds of a table under Sort (vnm_sort_op_sorted) ---------------------------------------------------------------------
+enum { SC_NUM = 0, SC_VAR = 1, SC_BOOL = 2, SC_DEC = 3 };
+struct SortColInfo {
+    int kind = -1;
+    ColType t;
+    bool wide = false;      // large_utf8 / large_binary: 64-bit offsets
+    std::string format;
+};
+
+static SortColInfo classify_sort_col(const char* f) {
+    SortColInfo c;
+    c.format = f ? f : "";
+    c.t = parse_format(f);
+    if (c.t.type >= 0) { c.kind = SC_NUM; return c; }
+    if (c.format == "u" || c.format == "z") { c.kind = SC_VAR; return c; }
+    if (c.format == "U" || c.format == "Z") { c.kind = SC_VAR; c.wide = true; return c; }
+    if (c.format == "b") { c.kind = SC_BOOL; return c; }
+    if (c.format.rfind("d:", 0) == 0) {   // d:precision,scale[,bit width]: 128 bits unless said otherwise
+        const size_t c1 = c.format.find(','), c2 = c1 == std::string::npos ? std::string::npos : c.format.find(',', c1 + 1);
+        if (c1 != std::string::npos && (c2 == std::string::npos || c.format.substr(c2 + 1) == "128")) c.kind = SC_DEC;
+    }
+    return c;
+}
+
+struct DevSortCol {
+    vnm_dcol num{};              // SC_NUM
+    int64_t* offs = nullptr;     // SC_VAR: total + 1 offsets (rebased to one data buffer)
+    uint8_t* data = nullptr;
+    uint8_t* bits = nullptr;     // SC_BOOL: the values, bit i = row i
+    void* fixed = nullptr;       // SC_DEC: 16-byte values
+    uint8_t* validity = nullptr; // bitmap, bit i = row i (null: no NULLs); SC_NUM keeps its own in `num`
+    void free_all() {
+        vnm_free_column(&num);
+        pool_free(offs); pool_free(data); pool_free(bits); pool_free(fixed); pool_free(validity);
+        offs = nullptr; data = nullptr; bits = nullptr; fixed = nullptr; validity = nullptr;
+    }
+};
+
+// the validity bits of child `ci` of every batch laid end to end -> one device bitmap (null when the column has no NULLs)
+static int stage_validity(const std::vector<std::unique_ptr<ImportedBatch>>& batches, int ci, int64_t total, uint8_t** out) {
+    *out = nullptr;
+    bool any_null = false;
+    for (auto& b : batches) if (b->arr.children[ci]->null_count != 0 && b->arr.children[ci]->buffers[0]) any_null = true;
+    if (!any_null || total == 0) return 0;
+    std::vector<uint8_t> bits((size_t)(total + 7) / 8 + 8, 0);
+    int64_t pos = 0;
+    for (auto& b : batches) {
+        const struct ArrowArray* ch = b->arr.children[ci];
+        const int64_t off = ch->offset + b->arr.offset, len = b->arr.length;
+        const uint8_t* bm = (ch->null_count != 0) ? (const uint8_t*)ch->buffers[0] : nullptr;
+        if (bm) copy_bits(bits.data(), pos, bm, off, len); else set_bits(bits.data(), pos, len);
+        pos += len;
+    }
+    const size_t nb = (size_t)(total + 7) / 8;
+    uint8_t* db = (uint8_t*)pool_alloc(nb + 8);
+    if (!db) return 1;
+    if (hipMemcpy(db, bits.data(), nb, hipMemcpyHostToDevice) != hipSuccess) { pool_free(db); return set_error("staging the validity bits failed"); }
+    *out = db;
+    return 0;
+}
+
+static int stage_sort_col(const std::vector<std::unique_ptr<ImportedBatch>>& batches, int ci, const SortColInfo& info, int64_t total, DevSortCol* d) {
+    if (info.kind == SC_NUM) return stage_children(batches, ci, info.t, total, &d->num);
+    VNM_TRY(stage_validity(batches, ci, total, &d->validity));
+    if (info.kind == SC_VAR) {
+        std::vector<int64_t> offs((size_t)total + 1, 0);
+        std::vector<const void*> srcs;
+        std::vector<size_t> sizes;
+        int64_t row = 0, base = 0;
+        for (auto& b : batches) {
+            const struct ArrowArray* ch = b->arr.children[ci];
+            const int64_t off = ch->offset + b->arr.offset, len = b->arr.length;
+            if (!len) continue;
+            if (ch->n_buffers < 3 || !ch->buffers[1]) return set_error("Sort: a string / binary column without an offsets buffer");
+            int64_t first, last;
+            if (info.wide) {
+                const int64_t* o = (const int64_t*)ch->buffers[1] + off;
+                first = o[0]; last = o[len];
+                for (int64_t i = 0; i <= len; i++) offs[(size_t)(row + i)] = base + (o[i] - first);
+            } else {
+                const int32_t* o = (const int32_t*)ch->buffers[1] + off;
+                first = o[0]; last = o[len];
+                for (int64_t i = 0; i <= len; i++) offs[(size_t)(row + i)] = base + ((int64_t)o[i] - first);
+            }
+            if (last > first) {
+                if (!ch->buffers[2]) return set_error("Sort: a string / binary column without a data buffer");
+                srcs.push_back((const uint8_t*)ch->buffers[2] + first);
+                sizes.push_back((size_t)(last - first));
+            }
+            row += len; base += last - first;
+        }
+        d->offs = (int64_t*)pool_alloc(((size_t)total + 1) * 8);
+        d->data = (uint8_t*)pool_alloc((size_t)(base > 0 ? base : 1));
+        if (!d->offs || !d->data) return 1;
+        if (hipMemcpy(d->offs, offs.data(), ((size_t)total + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) return set_error("Sort: staging offsets failed");
+        if (!srcs.empty()) VNM_TRY(stage_chunks(d->data, srcs.data(), sizes.data(), srcs.size(), nullptr));
+        if (hipStreamSynchronize(nullptr) != hipSuccess) return set_error("staging failed");
+        return 0;
+    }
+    if (info.kind == SC_BOOL) {
+        std::vector<uint8_t> bits((size_t)(total + 7) / 8 + 8, 0);
+        int64_t pos = 0;
+        for (auto& b : batches) {
+            const struct ArrowArray* ch = b->arr.children[ci];
+            const int64_t off = ch->offset + b->arr.offset, len = b->arr.length;
+            if (len && ch->buffers[1]) copy_bits(bits.data(), pos, (const uint8_t*)ch->buffers[1], off, len);
+            pos += len;
+        }
+        d->bits = (uint8_t*)pool_alloc(bits.size());
+        if (!d->bits) return 1;
+        if (hipMemcpy(d->bits, bits.data(), bits.size(), hipMemcpyHostToDevice) != hipSuccess) return set_error("Sort: staging a boolean column failed");
+        return 0;
+    }
+    // SC_DEC: 16-byte values
+    std::vector<const void*> srcs;
+    std::vector<size_t> sizes;
+    for (auto& b : batches) {
+        const struct ArrowArray* ch = b->arr.children[ci];
+        if (!b->arr.length) continue;
+        srcs.push_back((const uint8_t*)ch->buffers[1] + (size_t)(ch->offset + b->arr.offset) * 16);
+        sizes.push_back((size_t)b->arr.length * 16);
+    }
+    d->fixed = pool_alloc((size_t)(total ? total : 1) * 16);
+    if (!d->fixed) return 1;
+    if (!srcs.empty()) VNM_TRY(stage_chunks(d->fixed, srcs.data(), sizes.data(), srcs.size(), nullptr));
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return set_error("staging failed");
+    return 0;
+}
+
+static uint8_t* pack_bits(const uint8_t* bytes, int64_t n, int64_t* zeros) {
+    uint8_t* bm = (uint8_t*)calloc((size_t)((n + 7) / 8 + 1), 1);
+    int64_t z = 0;
+    for (int64_t i = 0; i < n; i++) { if (bytes[i]) bm[i >> 3] |= (uint8_t)(1u << (i & 7)); else z++; }
+    if (zeros) *zeros = z;
+    return bm;
+}
+
+// rows `idx` of a staged column -> a freshly allocated Arrow array (host buffers)
+static int take_sort_col(const DevSortCol& d, const SortColInfo& info, const int64_t* idx, int64_t n, struct ArrowArray* out) {
+    const size_t n1 = (size_t)(n ? n : 1);
+    if (info.kind == SC_NUM) {
+        const int w = type_width(info.t.type);
+        std::vector<uint8_t> hv(n1 * w), hb(n1);
+        if (n > 0) {
+            PoolScope pool;
+            void* dv = pool.take((size_t)n * w);
+            uint8_t* db = d.num.validity ? (uint8_t*)pool.take((size_t)n) : nullptr;
+            if (!dv || (d.num.validity && !db)) return 1;
+            VNM_TRY(vnm_take(&d.num, idx, n, dv, db, nullptr));
+            VNM_HIP(hipMemcpy(hv.data(), dv, (size_t)n * w, hipMemcpyDeviceToHost));
+            if (db) VNM_HIP(hipMemcpy(hb.data(), db, (size_t)n, hipMemcpyDeviceToHost));
+        }
+        make_primitive(out, n, w, hv.data(), d.num.validity ? hb.data() : nullptr);
+        return 0;
+    }
+    PoolScope pool;
+    std::vector<uint8_t> hvalid;
+    uint8_t* dvalid = nullptr;
+    if (d.validity && n > 0) {
+        dvalid = (uint8_t*)pool.take((size_t)n);
+        if (!dvalid) return 1;
+        hvalid.resize((size_t)n);
+    }
+    memset(out, 0, sizeof(*out));
+    out->length = n;
+    out->release = release_array;
+    if (info.kind == SC_VAR) {
+        std::vector<int64_t> ho(n1 + 1, 0);
+        std::vector<uint8_t> hd;
+        if (n > 0) {
+            int64_t* doffs = (int64_t*)pool.take(((size_t)n + 1) * 8);
+            if (!doffs) return 1;
+            uint8_t* ddata = nullptr;
+            int64_t nbytes = 0;
+            VNM_TRY(vnm_take_varwidth(d.offs, d.data, d.validity, idx, n, doffs, &ddata, &nbytes, dvalid, nullptr));
+            PoolSlotGuard<uint8_t> g(&ddata);
+            hd.resize((size_t)(nbytes > 0 ? nbytes : 1));
+            VNM_HIP(hipMemcpy(ho.data(), doffs, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
+            if (nbytes > 0) VNM_HIP(hipMemcpy(hd.data(), ddata, (size_t)nbytes, hipMemcpyDeviceToHost));
+            if (dvalid) VNM_HIP(hipMemcpy(hvalid.data(), dvalid, (size_t)n, hipMemcpyDeviceToHost));
+            if (!info.wide && nbytes > 0x7FFFFFFFLL) return set_error("Sort: the sorted %s column holds more than 2 GiB of bytes (use the large type)", info.format.c_str());
+        }
+        out->n_buffers = 3;
+        out->buffers = (const void**)calloc(3, sizeof(void*));
+        if (dvalid) { int64_t z = 0; out->buffers[0] = pack_bits(hvalid.data(), n, &z); out->null_count = z; }
+        if (info.wide) {
+            int64_t* o = (int64_t*)malloc((n1 + 1) * 8);
+            memcpy(o, ho.data(), ((size_t)n + 1) * 8);
+            out->buffers[1] = o;
+        } else {
+            int32_t* o = (int32_t*)malloc((n1 + 1) * 4);
+            for (int64_t i = 0; i <= n; i++) o[i] = (int32_t)ho[(size_t)i];
+            out->buffers[1] = o;
+        }
+        const size_t nb = hd.empty() ? 1 : hd.size();
+        uint8_t* dd = (uint8_t*)malloc(nb);
+        if (!hd.empty()) memcpy(dd, hd.data(), hd.size());
+        out->buffers[2] = dd;
+        return 0;
+    }
+    if (dvalid) {
+        VNM_TRY(vnm_take_bits(d.validity, 0, idx, n, dvalid, nullptr));
+        VNM_HIP(hipMemcpy(hvalid.data(), dvalid, (size_t)n, hipMemcpyDeviceToHost));
+    }
+    out->n_buffers = 2;
+    out->buffers = (const void**)calloc(2, sizeof(void*));
+    if (dvalid) { int64_t z = 0; out->buffers[0] = pack_bits(hvalid.data(), n, &z); out->null_count = z; }
+    if (info.kind == SC_BOOL) {
+        std::vector<uint8_t> hv(n1, 0);
+        if (n > 0) {
+            uint8_t* dv = (uint8_t*)pool.take((size_t)n);
+            if (!dv) return 1;
+            VNM_TRY(vnm_take_bits(d.bits, 0, idx, n, dv, nullptr));
+            VNM_HIP(hipMemcpy(hv.data(), dv, (size_t)n, hipMemcpyDeviceToHost));
+        }
+        out->buffers[1] = pack_bits(hv.data(), n, nullptr);
+        return 0;
+    }
+    // SC_DEC
+    void* hv = malloc(n1 * 16);
+    out->buffers[1] = hv;
+    if (n > 0) {
+        void* dv = pool.take((size_t)n * 16);
+        if (!dv) return 1;
+        VNM_TRY(vnm_take_fixed16(d.fixed, idx, n, dv, nullptr));
+        VNM_HIP(hipMemcpy(hv, dv, (size_t)n * 16, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
 struct vnm_sort_op {
     std::vector<std::string> cols;
     std::vector<int> orders;
@@ -598,67 +828,99 @@ int vnm_sort_op_next_stream(vnm_sort_op* h, struct ArrowArrayStream* stream) {
 
 // Sort::Sorted (sort.cpp:15-63).  limit > 0: only the first `limit` rows are produced (LIMIT pushed into the
 // sort; the reference sorts everything and slices later, same rows).
+// Column types (round 5: every type the reference's own tests sort or carry along crosses the ABI and is handled on the device):
+//   numeric / temporal     keys through the radix / sample sort, payload through vnm_take
+//   utf8 / large_utf8 / binary / large_binary
+//                          KEY: the values' order-preserving ranks (string dictionary on the device + a sort of the distinct
+//                          values, vnm_strdict_ranks_device) as an int32 key column -- NULL stays NULL (last in both directions),
+//                          equal values share a rank, so the stable sort keeps them in row order like SortIndices;
+//                          PAYLOAD: gathered on the device (lengths -> prefix sums -> bytes, vnm_take_varwidth)
+//   decimal128             KEY: (high int64, low uint64) as two keys; PAYLOAD: 16-byte gather
+//   boolean                PAYLOAD: bit gather; as a KEY it raises like the reference (vinum/core/algebra.py:191-201)
 int vnm_sort_op_sorted(vnm_sort_op* h, int64_t limit, struct ArrowArray* out, struct ArrowSchema* out_schema) {
     if (!h || !out || !out_schema) return set_error("vnm_sort_op_sorted: null argument");
     if (h->batches.empty()) return set_error("Failed to create table from record batches.");
     const struct ArrowSchema* sch = &h->batches[0]->sch;
     const int64_t ncols = sch->n_children;
     int64_t total = 0;
-    for (auto& b : h->batches) total += b->arr.length;
-    std::vector<ColType> types((size_t)ncols);
+    for (auto& b : h->batches) {
+        if (b->sch.n_children != ncols) return set_error("Failed to create table from record batches.");
+        for (int64_t c = 0; c < ncols; c++)
+            if (strcmp(b->sch.children[c]->format, sch->children[c]->format) != 0) return set_error("Failed to create table from record batches.");
+        total += b->arr.length;
+    }
+    std::vector<SortColInfo> info((size_t)ncols);
     for (int64_t c = 0; c < ncols; c++) {
-        types[c] = parse_format(sch->children[c]->format);
-        if (types[c].type < 0) return set_error("Sort: column '%s' has a type the GPU path does not handle (format %s)",
-                                                sch->children[c]->name, sch->children[c]->format);
+        info[c] = classify_sort_col(sch->children[c]->format);
+        if (info[c].kind < 0) return set_error("Sort: column '%s' has a type the GPU path does not handle (format %s)",
+                                               sch->children[c]->name, sch->children[c]->format);
     }
     std::vector<int> key_col;
     for (auto& name : h->cols) {
         int i = find_child(sch, name);
         if (i < 0) return set_error("Failed to sort table.");
+        if (info[i].kind == SC_BOOL) return set_error("Failed to sort table.");   // (Arrow 3.0 has no boolean sort; algebra.py:191-201 rejects it first)
         key_col.push_back(i);
     }
-    // Table::FromRecordBatches: every column of all batches as ONE column in HBM (stage_children: the chunks go through the
-    // pinned ring as they are; columns with NULLs are joined on the host first)
-    std::vector<vnm_dcol> dev((size_t)ncols);
+    // Table::FromRecordBatches: every column of all batches as ONE column in HBM
+    std::vector<DevSortCol> dev((size_t)ncols);
+    PoolScope scratch;              // key helper buffers (ranks, decimal words)
+    struct DictGuard { std::vector<vnm_strdict*> d; ~DictGuard() { for (auto* x : d) vnm_strdict_destroy(x); } } dicts;
     int rc = 0;
-    for (int64_t c = 0; c < ncols && !rc; c++) {
-        memset(&dev[c], 0, sizeof(vnm_dcol));
-        rc = stage_children(h->batches, (int)c, types[c], total, &dev[c]);
-    }
+    for (int64_t c = 0; c < ncols && !rc; c++) rc = stage_sort_col(h->batches, (int)c, info[c], total, &dev[c]);
     const int64_t n_out = (limit > 0 && limit < total) ? limit : total;
     int64_t* idx = nullptr;
     if (!rc && total > 0) {
-        idx = (int64_t*)pool_alloc((size_t)total * 8);
-        if (!idx) rc = 1;
         std::vector<vnm_dcol> keys;
-        for (int kc : key_col) keys.push_back(dev[kc]);
-        if (!rc) rc = vnm_sort_indices((int)keys.size(), keys.data(), h->orders.data(), total, n_out < total ? n_out : 0, idx, nullptr);
+        std::vector<int> orders;
+        for (size_t k = 0; k < key_col.size() && !rc; k++) {
+            const int c = key_col[k];
+            DevSortCol& d = dev[c];
+            vnm_dcol kc{};
+            kc.length = total; kc.validity = d.validity;
+            if (info[c].kind == SC_NUM) { keys.push_back(d.num); orders.push_back(h->orders[k]); continue; }
+            if (info[c].kind == SC_VAR) {
+                vnm_strdict* sd = vnm_strdict_create();
+                if (!sd) { rc = 1; break; }
+                dicts.d.push_back(sd);
+                int32_t* codes = (int32_t*)scratch.take((size_t)total * 4);
+                int32_t* ranks = (int32_t*)scratch.take((size_t)total * 4);
+                if (!codes || !ranks) { rc = 1; break; }
+                vnm_dcol oc{};
+                oc.values = d.offs; oc.type = VNM_I64; oc.length = total + 1;
+                rc = vnm_strdict_encode_device(sd, &oc, d.validity, 0, d.data, 0, codes, nullptr, nullptr, nullptr);
+                int32_t* rank_of = nullptr;
+                if (!rc) { rank_of = (int32_t*)scratch.take((size_t)std::max<int64_t>(vnm_strdict_ids(sd), 1) * 4); if (!rank_of) rc = 1; }
+                if (!rc) rc = vnm_strdict_ranks_device(sd, rank_of, nullptr);
+                if (!rc) rc = vnm_strdict_codes_to_ranks(codes, rank_of, total, ranks, nullptr);
+                kc.values = ranks; kc.type = VNM_I32;
+                keys.push_back(kc); orders.push_back(h->orders[k]);
+            } else {   // SC_DEC
+                int64_t* hi = (int64_t*)scratch.take((size_t)total * 8);
+                uint64_t* lo = (uint64_t*)scratch.take((size_t)total * 8);
+                if (!hi || !lo) { rc = 1; break; }
+                rc = vnm_decimal128_sort_keys(d.fixed, total, hi, lo, nullptr);
+                kc.values = hi; kc.type = VNM_I64;
+                keys.push_back(kc); orders.push_back(h->orders[k]);
+                kc.values = lo; kc.type = VNM_U64;
+                keys.push_back(kc); orders.push_back(h->orders[k]);
+            }
+        }
+        if (!rc && keys.size() > 16) rc = set_error("Sort: more than 16 sort key words");
+        if (!rc) { idx = (int64_t*)pool_alloc((size_t)total * 8); if (!idx) rc = 1; }
+        if (!rc) rc = vnm_sort_indices((int)keys.size(), keys.data(), orders.data(), total, n_out < total ? n_out : 0, idx, nullptr);
     }
     if (!rc) {
         make_struct(out, n_out, ncols);
         make_schema(out_schema, "+s", "", ncols);
         for (int64_t c = 0; c < ncols && !rc; c++) {
-            int w = type_width(types[c].type);
-            std::vector<uint8_t> hv((size_t)(n_out ? n_out : 1) * w), hb((size_t)(n_out ? n_out : 1));
-            if (n_out > 0) {
-                void* dv = pool_alloc((size_t)n_out * w);
-                uint8_t* db = dev[c].validity ? (uint8_t*)pool_alloc((size_t)n_out) : nullptr;
-                if (!dv || (dev[c].validity && !db)) rc = 1;
-                if (!rc) rc = vnm_take(&dev[c], idx, n_out, dv, db, nullptr);
-                if (!rc && hipMemcpy(hv.data(), dv, (size_t)n_out * w, hipMemcpyDeviceToHost) != hipSuccess) rc = set_error("Sort: D2H failed");
-                if (!rc && db && hipMemcpy(hb.data(), db, (size_t)n_out, hipMemcpyDeviceToHost) != hipSuccess) rc = set_error("Sort: D2H failed");
-                pool_free(dv);
-                pool_free(db);
-            }
-            if (!rc) {
-                make_primitive(out->children[c], n_out, w, hv.data(), dev[c].validity ? hb.data() : nullptr);
-                make_schema(out_schema->children[c], types[c].format, sch->children[c]->name ? sch->children[c]->name : "", 0);
-            }
+            rc = take_sort_col(dev[c], info[c], idx, n_out, out->children[c]);
+            if (!rc) make_schema(out_schema->children[c], info[c].format, sch->children[c]->name ? sch->children[c]->name : "", 0);
         }
         if (rc) { release_array(out); release_schema(out_schema); }
     }
     pool_free(idx);
-    for (auto& d : dev) vnm_free_column(&d);
+    for (auto& d : dev) d.free_all();
     for (auto& b : h->batches) b->drop();
     h->batches.clear();
     return rc;

@@ -300,6 +300,65 @@ int sdict_grow(SDict* d, uint64_t new_cap, hipStream_t s) {
     return 0;
 }
 
+// ---- order-preserving ranks of the dictionary's values (round 5: string / binary ORDER BY keys on the device) -----------------
+// Arrow's SortIndices compares utf8 / binary values byte-wise (sort.cpp:22-37).  The dictionary's values are DISTINCT, so their sort
+// order is a rank per id; a row's sort key then is rank[code] -- an ordinary int32 column of the numeric sort (equal strings share
+// a rank, so the stable sort keeps their row order).  The values are sorted by the existing multi-key radix sort over 8-byte
+// BIG-ENDIAN chunks of their bytes (zero padded) with the length as the least significant key (a value that is a prefix of another
+// sorts first, "a" before "a\0"): up to 15 chunks + the length per sort call, longer values in several stable rounds from the last
+// chunks to the first (an LSD sort over the chunk columns; a round's keys are read through the permutation of the rounds before).
+struct SdRankArgs {
+    SDict d;
+    const uint8_t* heap;
+    uint64_t* voff;     // [D] heap offset
+    uint32_t* vlen;     // [D]
+    int32_t* vid;       // [D]
+    unsigned long long* ctl;   // [0] next list position  [1] longest value
+};
+
+__global__ __launch_bounds__(256) void sd_list_kernel(SdRankArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    unsigned long long maxlen = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)a.d.cap; i += stride) {
+        const uint64_t* s = a.d.slot + (uint64_t)i * 4;
+        const uint64_t tag = s[0];
+        if (tag == SD_EMPTY || tag == SD_LOCKED) continue;
+        const unsigned long long k = atomicAdd(&a.ctl[0], 1ULL);
+        a.voff[k] = s[2]; a.vlen[k] = (uint32_t)s[3]; a.vid[k] = (int32_t)(s[1] - 1);
+        if (s[3] > maxlen) maxlen = s[3];
+    }
+    if (maxlen) atomicMax(&a.ctl[1], maxlen);
+}
+
+// key columns of one round: out[c][i] = chunk (j0 + c) of value perm[i] (perm = null: value i); out[nchunks][i] = its length (with_len)
+__global__ __launch_bounds__(256) void sd_chunk_kernel(const uint8_t* heap, const uint64_t* voff, const uint32_t* vlen, const int64_t* perm, int64_t n,
+                                                       int j0, int nchunks, int with_len, uint64_t* out /* [nchunks + with_len][n] */) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const int64_t v = perm ? perm[i] : i;
+        const uint8_t* p = heap + voff[v];
+        const int64_t len = vlen[v];
+        for (int c = 0; c < nchunks; c++) {
+            const int64_t at = (int64_t)(j0 + c) * 8;
+            uint64_t x = 0;
+            for (int b = 0; b < 8; b++) x = (x << 8) | (at + b < len ? (uint64_t)p[at + b] : 0ULL);
+            out[(int64_t)c * n + i] = x;
+        }
+        if (with_len) out[(int64_t)nchunks * n + i] = (uint64_t)len;
+    }
+}
+
+__global__ __launch_bounds__(256) void sd_rank_scatter_kernel(const int64_t* perm, const int32_t* vid, int64_t n, int32_t* rank_of_id) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) rank_of_id[vid[perm[i]]] = (int32_t)i;
+}
+
+// rows' codes -> rows' ranks (a NULL row -- code -1 -- gets 0; its validity bit says NULL)
+__global__ __launch_bounds__(256) void sd_code_rank_kernel(const int32_t* codes, const int32_t* rank_of_id, int64_t n, int32_t* out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) { const int32_t c = codes[i]; out[i] = c < 0 ? 0 : rank_of_id[c]; }
+}
+
 }  // namespace vnm
 
 using namespace vnm;
@@ -492,6 +551,84 @@ int vnm_strdict_fetch_new(vnm_strdict* h, int32_t* ids_host, int32_t* lens_host,
         memcpy(lens_host, h->new_lens.data(), h->new_lens.size() * 4);
     }
     if (!h->new_bytes.empty()) memcpy(bytes_host, h->new_bytes.data(), h->new_bytes.size());
+    return 0;
+}
+
+// Order-preserving ranks of every value in the dictionary: out_rank_of_id[id] = position of the value in ascending byte-wise order
+// (device array of vnm_strdict_ids(h) int32s; ids that were never handed out are left untouched).
+int vnm_strdict_ranks_device(vnm_strdict* h, int32_t* out_rank_of_id, void* stream) {
+    VNM_TRY(ensure_init());
+    if (!h || !out_rank_of_id) return set_error("vnm_strdict_ranks_device: null argument");
+    if (h->failed) return set_error("vnm_strdict: an earlier encode failed half-way; the dictionary cannot be used any more (create a new one)");
+    if (!h->d.slot) return 0;
+    hipStream_t s = as_stream(stream);
+    unsigned long long fill = 0;
+    VNM_HIP(hipMemcpyAsync(&fill, h->d.ctl + 2, 8, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    const int64_t D = (int64_t)fill;
+    if (D == 0) return 0;
+    PoolScope pool;
+    SdRankArgs a{};
+    a.d = h->d; a.heap = h->heap;
+    a.voff = (uint64_t*)pool.take((size_t)D * 8);
+    a.vlen = (uint32_t*)pool.take((size_t)D * 4);
+    a.vid = (int32_t*)pool.take((size_t)D * 4);
+    a.ctl = (unsigned long long*)pool.take(64);
+    int64_t* perm = (int64_t*)pool.take((size_t)D * 8);
+    int64_t* perm2 = (int64_t*)pool.take((size_t)D * 8);
+    int64_t* perm3 = (int64_t*)pool.take((size_t)D * 8);
+    if (!a.voff || !a.vlen || !a.vid || !a.ctl || !perm || !perm2 || !perm3) return 1;
+    VNM_HIP(hipMemsetAsync(a.ctl, 0, 64, s));
+    const int grid = (int)std::min<int64_t>(((int64_t)h->d.cap + 255) / 256, (int64_t)device_info().num_cus * 8);
+    sd_list_kernel<<<grid, 256, 0, s>>>(a);
+    VNM_HIP(hipGetLastError());
+    unsigned long long ctl[2];
+    VNM_HIP(hipMemcpyAsync(ctl, a.ctl, 16, hipMemcpyDeviceToHost, s));
+    VNM_HIP(hipStreamSynchronize(s));
+    if ((int64_t)ctl[0] != D) return set_error("vnm_strdict_ranks_device: %llu values listed, %lld in the table (internal error)", ctl[0], (long long)D);
+    const int m = (int)((ctl[1] + 7) / 8);                    // chunks of the longest value
+    constexpr int PER = 15;                                   // chunk keys per sort call (+ the length: 16 keys)
+    const int rounds = m == 0 ? 1 : (m + PER - 1) / PER;
+    uint64_t* keys = (uint64_t*)pool.take((size_t)D * 8 * (size_t)(std::min(m, PER) + 1));
+    if (!keys) return 1;
+    const int g2 = (int)std::min<int64_t>((D + 255) / 256, (int64_t)device_info().num_cus * 8);
+    bool have_perm = false;
+    for (int r = 0; r < rounds; r++) {                        // least significant round first: the last chunks and the length
+        const int hi = m - r * PER, lo = std::max(0, hi - PER), nc = hi - lo;
+        const int with_len = r == 0 ? 1 : 0;
+        sd_chunk_kernel<<<g2, 256, 0, s>>>(h->heap, a.voff, a.vlen, have_perm ? perm : nullptr, D, lo, nc, with_len, keys);
+        VNM_HIP(hipGetLastError());
+        vnm_dcol kc[16];
+        int orders[16];
+        const int nk = nc + with_len;
+        for (int k = 0; k < nk; k++) {
+            memset(&kc[k], 0, sizeof(vnm_dcol));
+            kc[k].values = keys + (size_t)k * D; kc[k].type = VNM_U64; kc[k].length = D;
+            orders[k] = VNM_ASC;
+        }
+        VNM_TRY(vnm_sort_indices(nk, kc, orders, D, 0, perm2, stream));
+        if (!have_perm) std::swap(perm, perm2);
+        else {                                                // positions in this round's order -> value indices
+            vnm_dcol pc{};
+            pc.values = perm; pc.type = VNM_I64; pc.length = D;
+            VNM_TRY(vnm_take(&pc, perm2, D, perm3, nullptr, stream));
+            std::swap(perm, perm3);
+        }
+        have_perm = true;
+    }
+    sd_rank_scatter_kernel<<<g2, 256, 0, s>>>(perm, a.vid, D, out_rank_of_id);
+    VNM_HIP(hipGetLastError());
+    VNM_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+// codes (vnm_strdict_encode*) -> the rows' ranks under rank_of_id (vnm_strdict_ranks_device); all device buffers
+int vnm_strdict_codes_to_ranks(const int32_t* codes, const int32_t* rank_of_id, int64_t n, int32_t* out_ranks, void* stream) {
+    VNM_TRY(ensure_init());
+    if (n <= 0) return 0;
+    if (!codes || !rank_of_id || !out_ranks) return set_error("vnm_strdict_codes_to_ranks: null argument");
+    sd_code_rank_kernel<<<(int)std::min<int64_t>((n + 255) / 256, (int64_t)device_info().num_cus * 8), 256, 0, as_stream(stream)>>>(codes, rank_of_id, n, out_ranks);
+    VNM_HIP(hipGetLastError());
     return 0;
 }
 
