@@ -796,9 +796,16 @@ def main():
             if dist_mode:
                 from vinum_amd import distributed as D
                 # the ranks agree on ONE group-count estimate and ONE key range (a single all_gather): every operator then cuts its
-                # result the same way and the dense path's tables are slot-compatible
+                # result the same way and the dense path's tables are slot-compatible.  ONCE per standing query (ExchangePlan): the
+                # steps after the first apply what was agreed without a collective
                 if os.environ.get("VNM_BENCH_EXCHANGE", "dense") == "dense":
-                    D.agree_on_groups_and_range(agg, parts[0][0], B, device, stream=stream, estimate=not args.hint)
+                    plans = state.setdefault("plans", {})
+                    pk = ("stream", cur["hint"], len(parts))
+                    if pk not in plans:
+                        plans[pk] = D.agree_on_plan(agg, parts[0][0], B, device, stream=stream, estimate=not args.hint, hint=cur["hint"])
+                    else:
+                        plans[pk].apply(agg, use_estimate=not args.hint)
+                    state["plan"] = plans[pk]
                 elif not args.hint:
                     D.agree_on_group_count(agg, parts[0][0], B, device, stream=stream)
             for kc_, vc_ in parts:
@@ -828,16 +835,21 @@ def main():
                                       [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())],
                                       expected_groups=cur["hint"] if args.hint else 0, rank_aligned=(world > 1 or force_exchange))
             agg.set_predicate(">", x_thr)
-            if (world > 1 or force_exchange) and not args.hint:
-                # hint-less on several ranks: agree on ONE group-count estimate, or ranks may cut their results into
-                # different numbers of partitions (distributed.agree_on_group_count)
-                from vinum_amd import distributed as D
-                D.agree_on_group_count(agg, gk, n, device, stream=stream)
             if world > 1 or force_exchange:
-                # ... and on ONE key range: the dense-key path then gives slot-compatible tables on every rank
+                # several ranks: agree on ONE group-count estimate (or ranks may cut their results into different numbers of
+                # partitions) and on ONE key range (the dense-key path then gives slot-compatible tables on every rank) -- one
+                # all_gather, once per standing query (distributed.ExchangePlan)
                 from vinum_amd import distributed as D
                 if os.environ.get("VNM_BENCH_EXCHANGE", "dense") == "dense":
-                    D.agree_on_dense_range(agg, gk, n, device, stream=stream)
+                    plans = state.setdefault("plans", {})
+                    pk = ("groupby", cur["hint"], n)
+                    if pk not in plans:
+                        plans[pk] = D.agree_on_plan(agg, gk, n, device, stream=stream, estimate=not args.hint, hint=cur["hint"])
+                    else:
+                        plans[pk].apply(agg, use_estimate=not args.hint)
+                    state["plan"] = plans[pk]
+                elif not args.hint:
+                    D.agree_on_group_count(agg, gk, n, device, stream=stream)
             agg.next([gk], [gv, gv], pred=gv, nrows=n, stream=stream)
         if world > 1 or force_exchange:
             ng = exchange_and_merge(agg, None)
@@ -856,6 +868,32 @@ def main():
         from vinum_amd import distributed as D
         kw, aw = agg.layout()
         want = os.environ.get("VNM_BENCH_EXCHANGE", "dense")
+        make0 = lambda: ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64())])
+        plan = state.get("plan")
+        if want == "dense" and plan is not None and plan.route == "small":
+            # few groups (the agreed estimate says so): ONE fixed-size all_gather, merged on the device from the blocks' own headers --
+            # no route agreement, no count exchange, no slicing (distributed.exchange_small_fixed)
+            torch.cuda.synchronize()
+            t_a = time.perf_counter()
+            ng0 = agg.finish(stream=stream)
+            send = torch.empty((max(ng0, 1), kw + aw), dtype=torch.int64, device=device)
+            agg.bucket_by_owner(1, send.data_ptr(), stream=stream)
+
+            def merge_blocks(blocks, counts):
+                m = make0()
+                m.merge_row_blocks(int(blocks.shape[0]), int(blocks.shape[1]) - 1, blocks.data_ptr(), stream=stream)
+                m._keep = blocks
+                return m
+            small, _counts = D.exchange_small_fixed(send[:ng0], merge_blocks)
+            if small is not None:
+                out = small.finish(stream=stream)
+                torch.cuda.synchronize()
+                ph = state.setdefault("phases", {"bucket": 0.0, "all_to_all": 0.0, "merge": 0.0, "partition_aligned": 0.0})
+                ph["small_fixed"] = ph.get("small_fixed", 0.0) + (time.perf_counter() - t_a) * 1e3
+                state["merged"] = small
+                state["replicated"] = True
+                state["exchange_kind"] = "small_fixed"
+                return out
         # the last pass of the aggregation itself (the dense path's deferred final pass, here writing its direct-addressed tables)
         got = agg.dense_table(stream=stream) if want == "dense" else None
         torch.cuda.synchronize()

@@ -237,6 +237,10 @@ int vnm_agg_merge_partitioned(vnm_agg* h, int world, int64_t nlocal, const uint6
                               const int64_t* src_row_offsets_host, const uint32_t* part_counts, void* stream);
 /* merge row-major partial groups [n][n_key_words + n_acc_words] (layout of vnm_agg_bucket_by_owner) */
 int vnm_agg_merge_rows(vnm_agg* h, int64_t n, const uint64_t* rows, void* stream);
+/* The receive buffer of the one-collective small-result exchange (vinum_amd/distributed.py::exchange_small_fixed): `nblocks` blocks
+ * of (block_rows + 1) such rows, row 0 of every block being its header (word 0 = how many of the following rows hold partial
+ * groups).  Merged like vnm_agg_merge_rows, the counts are read on the device. */
+int vnm_agg_merge_row_blocks(vnm_agg* h, int nblocks, int64_t block_rows, const uint64_t* blocks, void* stream);
 /* BaseAggregate::Result part 2 (+ agg funcs' Summarize, agg_funcs.h:72-80,358-397,482-491,519-540):
  * D2H + host finalisation.  key j -> vals[n] raw 64-bit patterns + valid[n] bytes.
  * func i -> cells of 16 bytes (decimal128 uses all 16), valid bytes; returns the output kind. */

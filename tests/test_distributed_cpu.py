@@ -111,6 +111,19 @@ def _worker_small(rank, world, port, tmp):
 
     assert D.exchange_allgather_small(rows, merge_rows, limit=10) is None      # above the limit on every rank: agreed fallback
     uk, cnt, sm = D.exchange_allgather_small(rows, merge_rows)
+
+    # round 5: the same exchange as ONE fixed-size collective (a header row per block carries the count)
+    def merge_blocks(blocks, counts):
+        assert blocks.shape[0] == world and counts[rank] == rows.shape[0]
+        return merge_rows(torch.cat([blocks[r, 1:1 + c] for r, c in enumerate(counts)]))
+
+    res, counts = D.exchange_small_fixed(rows, merge_blocks, fixed=64)
+    uk2, cnt2, sm2 = res
+    assert np.array_equal(uk2, uk) and np.array_equal(cnt2, cnt) and np.array_equal(sm2, sm)
+    res, counts = D.exchange_small_fixed(rows, merge_blocks, fixed=45)           # rank 1 holds 50 groups: every rank sees it and falls back
+    assert res is None and counts == [40, 50][:world] + [0] * max(0, world - 2) or (res is None and max(counts) > 45)
+    plan = D.ExchangePlan(est=40, rng=None)
+    assert plan.route == "small" and D.ExchangePlan(10**6, (0, 5)).route == "dense" and D.ExchangePlan(10**6, None).route == "general"
     # distributed ORDER BY v DESC LIMIT k: local winners -> global winners
     v = rng.normal(size=5000)
     v[rng.integers(0, 5000, 40)] = np.nan

@@ -45,7 +45,7 @@ def test_bench_check_single_gpu_headline_with_result_columns():
     assert j["check"].get("result_columns_match") is True
 
 
-@pytest.mark.parametrize("groups,route", [("1e6", "dense_tables"), ("7", "allgather_small")])
+@pytest.mark.parametrize("groups,route", [("1e6", "dense_tables"), ("7", "small_fixed")])
 def test_bench_check_stream_workload_with_exchange(groups, route):
     """configs[3] (the default of a multi-rank run): a stream of 2^24-row batches into one operator in stream mode, partial aggregates
     exchanged -- here by ONE rank with itself, `also` cases included (they are collectives on every rank)."""
@@ -59,7 +59,7 @@ def test_bench_check_stream_workload_with_exchange(groups, route):
     assert j["check"]["survivors_conserved"] and j["check"]["totals_conserved"]
     assert j["rccl_ranks"] == 1 and "configs[3]" in j["config"]["workload"]
     assert "error" not in j["also"], j["also"]
-    assert j["also"]["configs[3] stream, G=7"]["exchange"] == "allgather_small"
+    assert j["also"]["configs[3] stream, G=7"]["exchange"] == "small_fixed"     # ONE fixed-size collective (round 5)
     assert j["also"]["configs[2] shape, G=1e8"]["exchange"] == "dense_tables"
 
 
@@ -70,7 +70,7 @@ def test_bench_check_stream_workload_single_gpu():
     assert j["roofline"]["launches_per_step"] <= 1.0     # ONE launch of the scatter pass over the five waiting batches
 
 
-@pytest.mark.parametrize("ranks,groups,route", [(2, "1e6", "dense_tables"), (3, "7", "allgather_small"), (2, "2e7", "dense_tables")])
+@pytest.mark.parametrize("ranks,groups,route", [(2, "1e6", "dense_tables"), (3, "7", "small_fixed"), (2, "2e7", "dense_tables")])
 def test_bench_self_launch_ranks_sharing_the_gpu(ranks, groups, route):
     """The N-rank code path for real ("a 2-process single-GPU-shared ... run of the self-launch path"): `bench.py --gpus N`
     starts N processes by itself; VNM_BENCH_SHARED_GPU=1 puts every rank on cuda:0 with the gloo backend (RCCL refuses two ranks on one

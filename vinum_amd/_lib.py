@@ -75,6 +75,7 @@ PROTOTYPES = {
     "vnm_agg_run_reorder": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void]),
     "vnm_agg_merge_partitioned": (c_int, [c_void, c_int, c_i64, c_void, c_void, c_void, c_void]),
     "vnm_agg_merge_rows": (c_int, [c_void, c_i64, c_void, c_void]),
+    "vnm_agg_merge_row_blocks": (c_int, [c_void, c_int, c_i64, c_void, c_void]),
     "vnm_agg_result_key": (c_int, [c_void, c_int, c_void, c_void]),
     "vnm_agg_result_func": (c_int, [c_void, c_int, c_void, c_void, c_void]),
     "vnm_agg_result_key_device": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void]),

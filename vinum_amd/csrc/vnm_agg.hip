@@ -1744,6 +1744,10 @@ struct MergeArgs {
     int src_is_table;
     int64_t src_cap;  // table source: entries [src_cap], [src_cap+1] are the special groups
     int64_t src_stride;  // element stride of the dense source arrays (1 = SoA, n_words = row-major rows)
+    // row-major rows in BLOCKS of (blk_rows + 1) rows whose first row is a header (word 0 = how many of the block's rows are groups):
+    // what the one-collective small-G exchange delivers (vnm_agg_merge_row_blocks); 0 = plain rows
+    int64_t blk_rows;
+    const uint64_t* blk_base;
 };
 
 __global__ __launch_bounds__(256) void agg_merge_kernel(MergeArgs m) {
@@ -1753,8 +1757,14 @@ __global__ __launch_bounds__(256) void agg_merge_kernel(MergeArgs m) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const bool single = m.g.kwt == 0;
     const int nk = m.plan.n_keys;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m.n; i += stride) {
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < m.n; i0 += stride) {
         uint64_t slot;
+        int64_t i = i0;
+        if (m.blk_rows) {   // i0 = (block, row of the block): skip what lies beyond the block's count, step over the headers
+            const int64_t b = i0 / m.blk_rows, j = i0 % m.blk_rows;
+            if ((uint64_t)j >= m.blk_base[b * (m.blk_rows + 1) * m.src_stride]) continue;
+            i = b * (m.blk_rows + 1) + 1 + j;
+        }
         if (m.src_is_table) {
             uint64_t t = m.src_tag[i];
             if (t == EMPTY || (!single && t == LOCKED)) continue;  // LOCKED (~0 - 1) is an ordinary key on the single path
@@ -6753,7 +6763,13 @@ int vnm_agg_next_device_expr(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, co
     return rc;
 }
 
+static int merge_device_impl(vnm_agg* h, int64_t n, uint64_t* const* key_words, uint64_t* const* acc_words, void* stream, int64_t blk_rows, const uint64_t* blk_base);
+
 int vnm_agg_merge_device(vnm_agg* h, int64_t n, uint64_t* const* key_words, uint64_t* const* acc_words, void* stream) {
+    return merge_device_impl(h, n, key_words, acc_words, stream, 0, nullptr);
+}
+
+static int merge_device_impl(vnm_agg* h, int64_t n, uint64_t* const* key_words, uint64_t* const* acc_words, void* stream, int64_t blk_rows, const uint64_t* blk_base) {
     VNM_TRY(ensure_init());
     if (!h) return set_error("vnm_agg_merge_device: null handle");
     hipStream_t s = as_stream(stream);
@@ -6775,6 +6791,7 @@ int vnm_agg_merge_device(vnm_agg* h, int64_t n, uint64_t* const* key_words, uint
     m.g = h->g;
     m.n = n;
     m.src_stride = h->merge_stride > 0 ? h->merge_stride : 1;
+    m.blk_rows = blk_rows; m.blk_base = blk_base;
     for (int j = 0; j < h->plan.kw; j++) m.src_key[j] = key_words[j];
     for (int w = 0; w < h->plan.n_words; w++) m.src_acc[w] = acc_words[w];
     int grid = device_info().num_cus * 8;
@@ -6796,6 +6813,21 @@ int vnm_agg_merge_rows(vnm_agg* h, int64_t n, const uint64_t* rows, void* stream
     for (int w = 0; w < h->plan.n_words; w++) aw[w] = const_cast<uint64_t*>(rows) + h->plan.kw + w;
     h->merge_stride = nw;
     int rc = vnm_agg_merge_device(h, n, kw, aw, stream);
+    h->merge_stride = 0;
+    return rc;
+}
+
+// `nblocks` blocks of (block_rows + 1) row-major rows [n_key_words + n_acc_words]; row 0 of a block is its header (word 0 = the number of
+// partial groups in rows 1 ..): the receive buffer of distributed.exchange_small_fixed, merged without a host look at the counts
+int vnm_agg_merge_row_blocks(vnm_agg* h, int nblocks, int64_t block_rows, const uint64_t* blocks, void* stream) {
+    if (!h || nblocks < 1 || block_rows < 1 || !blocks) return set_error("vnm_agg_merge_row_blocks: bad argument");
+    const int nw = h->plan.kw + h->plan.n_words;
+    uint64_t* kw[AGG_MAX_KEYS + 1];
+    uint64_t* aw[AGG_MAX_WORDS];
+    for (int j = 0; j < h->plan.kw; j++) kw[j] = const_cast<uint64_t*>(blocks) + j;
+    for (int w = 0; w < h->plan.n_words; w++) aw[w] = const_cast<uint64_t*>(blocks) + h->plan.kw + w;
+    h->merge_stride = nw;
+    const int rc = merge_device_impl(h, (int64_t)nblocks * block_rows, kw, aw, stream, block_rows, blocks);
     h->merge_stride = 0;
     return rc;
 }

@@ -230,6 +230,10 @@ class DeviceAggregate:
     def merge_rows(self, n, rows_ptr, stream=None):
         L.check(L.lib().vnm_agg_merge_rows(self._h, n, rows_ptr, _stream_ptr(stream)))
 
+    def merge_row_blocks(self, nblocks, block_rows, blocks_ptr, stream=None):
+        """blocks of (block_rows + 1) rows with a header row each (distributed.exchange_small_fixed)"""
+        L.check(L.lib().vnm_agg_merge_row_blocks(self._h, int(nblocks), int(block_rows), blocks_ptr, _stream_ptr(stream)))
+
     def result_arrays(self, key_indices, out_names_keys, out_names_funcs) -> pa.RecordBatch:
         """Column order follows BaseAggregate::Result (base_aggregate.cpp:47-68): selected group keys
         first, then the functions; output types follow agg_func_factory.cpp:13-329."""
