@@ -873,9 +873,9 @@ def main():
         if want == "dense" and plan is not None and plan.route == "small":
             # few groups (the agreed estimate says so): ONE fixed-size all_gather, merged on the device from the blocks' own headers --
             # no route agreement, no count exchange, no slicing (distributed.exchange_small_fixed)
+            ng0 = agg.finish(stream=stream)      # (the aggregation itself: the waiting batches of the stream go to the device here)
             torch.cuda.synchronize()
             t_a = time.perf_counter()
-            ng0 = agg.finish(stream=stream)
             send = torch.empty((max(ng0, 1), kw + aw), dtype=torch.int64, device=device)
             agg.bucket_by_owner(1, send.data_ptr(), stream=stream)
 
