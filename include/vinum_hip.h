@@ -116,6 +116,13 @@ int vnm_device_synchronize(void);
  * kernel they bracket ("filter_kernel", "agg_scan", ...) */
 int vnm_set_profiling(int on);
 int vnm_profile_query(const char* name, double* total_ms, int64_t* count);
+/* Which route of DESIGN.md section 4 the operators took, and why (round 5).  Every operator call that commits a batch to a path leaves
+ * a note: a route name and the reason in numbers (estimates, ranges, thresholds).  vnm_route_counts: "route=count" lines for every
+ * route taken since the library was loaded (or vnm_route_reset) into buf (cap bytes, zero terminated); returns the bytes the full
+ * text needs.  vnm_route_last: the calling thread's last note, "route: reason".  VNM_AGG_TRACE=1 prints every note to stderr. */
+int64_t vnm_route_counts(char* buf, int64_t cap);
+int64_t vnm_route_last(char* buf, int64_t cap);
+void vnm_route_reset(void);
 
 /* ---- filter: FilterOperator._kernel + RecordBatch.filter -----------------------------------------
  * replaces vinum/core/algebra.py:119-123, vinum/arrow/record_batch.py:85-90 and the NumPy comparison

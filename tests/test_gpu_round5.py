@@ -489,3 +489,19 @@ def test_string_key_order_by_on_the_device_is_timed_against_the_host_route(capsy
     assert got.column("s").equals(exp_s)
     with capsys.disabled():
         print(f"\\n[string-key ORDER BY, 1e7 rows, 1e5 distinct] device route (incl. PCIe both ways) {t_dev * 1e3:.0f} ms, host route {t_host * 1e3:.0f} ms")
+
+
+def test_wide_key_table_scan_when_the_tuple_dictionary_is_switched_off(monkeypatch):
+    """The wide-key HBM table (agg_wide_kernel: tag = 63-bit hash, key words compared) is what key sets too wide to pack fall back to
+    when the tuple dictionary is switched off -- kept reachable and equal to the oracle (route scan:wide_keys)."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_NO_TUPLE", "1")
+    monkeypatch.setenv("VNM_AGG_NO_DICT", "1")
+    rng = np.random.default_rng(8)
+    n = 200_000
+    t = pa.table({"a": pa.array(rng.integers(-2**62, 2**62, 300)[rng.integers(0, 300, n)]), "b": pa.array(rng.integers(-2**62, 2**62, 5)[rng.integers(0, 5, n)], mask=rng.random(n) < 0.02),
+                  "c": pa.array(rng.normal(0, 1, 40)[rng.integers(0, 40, n)]), "v": pa.array(rng.integers(0, 1000, n).astype(np.float64) / 8.0)})
+    funcs = [(O.SUM, "v", "s"), (O.MIN, "v", "mn"), (O.COUNT_STAR, "", "n")]
+    batches = util.sliced_batches(t, 70_000)
+    got = gpu_aggregate(O.MULTI, ["a", "b", "c"], ["a", "b", "c"], funcs, batches)
+    util.assert_agg_equal(got, _oracle(O.MULTI, ["a", "b", "c"], funcs, batches), funcs, ["a", "b", "c"], what="wide-key table")

@@ -126,6 +126,9 @@ PROTOTYPES = {
     "vnm_pool_trim": (c_i64, []),
     "vnm_pool_set_idle_trim": (c_int, [c_i64, c_i64]),
     "vnm_pool_cached_bytes": (c_i64, []),
+    "vnm_route_counts": (c_i64, [c_void, c_i64]),
+    "vnm_route_last": (c_i64, [c_void, c_i64]),
+    "vnm_route_reset": (None, []),
     "vnm_memcpy_h2d": (c_int, [c_void, c_void, c_i64]),
     "vnm_memcpy_d2h": (c_int, [c_void, c_void, c_i64]),
     "vnm_memset": (c_int, [c_void, c_int, c_i64]),

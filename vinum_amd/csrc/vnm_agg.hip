@@ -4824,6 +4824,9 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
         unsigned long long fl0[3];
         VNM_HIP(hipMemcpyAsync(fl0, flags, 24, hipMemcpyDeviceToHost, s));
         VNM_HIP(hipStreamSynchronize(s));
+        route_note(h->kn_valid ? "dense:nullable_key" : (h->segs_active ? "dense:stream_segments" : (vn ? "dense:nullable_value" : (fsplits > 1 ? "dense:split_final" :
+                   (levels == 2 ? "dense:two_levels" : (p1 == 5 && tb <= 10 ? "dense:32_partitions" : "dense:one_level"))))),
+                   "2^%d codes, 2^%d-slot final tables, p1 %d p2 %d, final pass deferred%s: %s", mp.bits, tb, p1, p2, vn ? ", nullable value" : "", fl0[0] ? "scatter FAILED (the batch goes another way)" : "ok");
         if (getenv("VNM_AGG_TRACE"))
             fprintf(stderr, "[agg] dense: bits %d tb %d levels %d p1 %d p2 %d -> scatter fail %llu spilled %llu, final pass deferred (bound %lld)\n",
                     mp.bits, tb, levels, p1, p2, fl0[0], fl0[2], (long long)dstride);
@@ -4873,6 +4876,8 @@ int dense_partitioned_aggregate(vnm_agg* h, const AggArgs& a, int64_t nrows, hip
     if (!fl[0]) VNM_HIP(hipStreamSynchronize(s));   // (the fold reads the flags block release() gives back)
     release();
     pool_free(psum); pool_free(plo); pool_free(pcnt);
+    route_note(generic ? (fsplits > 1 ? "dense:generic_split_final" : "dense:generic") : (vn ? "dense:nullable_value" : (fsplits > 1 ? "dense:split_final" : "dense:run")),
+               "2^%d codes, 2^%d-slot final tables, levels %d, p1 %d p2 %d, %d final splits: %s", mp.bits, tb, levels, p1, p2, fsplits, fl[0] ? "FAILED (the batch goes another way)" : "ok");
     if (getenv("VNM_AGG_TRACE"))
         fprintf(stderr, "[agg] dense%s%s: bits %d tb %d levels %d p1 %d p2 %d splits %d -> fail %llu groups %llu spilled %llu + %llu NULL-value rows (dstride %lld)\n",
                 generic ? " generic" : "", vn ? " nullable" : "", mp.bits, tb, levels, p1, p2, fsplits, fl[0], fl[1], fl[2], fl[3], (long long)dstride);
@@ -5871,8 +5876,13 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                 VNM_TRY(enter_tuple_mode(h, nrows, s));
             }
         }
-        if (h->tuple_mode) return tuple_next(h, nrows, keys, inputs, pred, s);
+        if (h->tuple_mode) { route_note("keys:tuple_dictionary", "%d key columns: tuple -> group id", h->plan.n_keys); return tuple_next(h, nrows, keys, inputs, pred, s); }
         if (h->inner) {
+            {
+                int ndict = 0;
+                for (int j = 0; j < h->plan.n_keys; j++) ndict += h->pack.dtab[j] != nullptr;
+                route_note(ndict ? "keys:packed_with_dictionary_fields" : "keys:packed", "%d key columns in one 64-bit word (%d dictionary-coded)", h->plan.n_keys, ndict);
+            }
             for (int j = 0; j < h->plan.n_keys; j++) h->pack.cols[j] = keys[j];
             uint64_t* packed = (uint64_t*)pool_alloc((size_t)nrows * 8);
             unsigned long long* flag = (unsigned long long*)pool_alloc(64);
@@ -5901,6 +5911,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
             pool_free(packed);
             if (!h->single && getenv("VNM_AGG_NO_TUPLE") == nullptr) {   // keys outside the packed ranges: on through the tuple dictionary
                 VNM_TRY(packed_to_tuple(h, nrows, s));
+                route_note("keys:tuple_dictionary", "a batch outgrew the packed ranges");
                 return tuple_next(h, nrows, keys, inputs, pred, s);
             }
             VNM_TRY(demote_packed(h, s));  // (a packed SINGLE key: its own general path; or the dictionary switched off: the wide-key table)
@@ -5908,7 +5919,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
     }
 
     // more input columns than a partition entry carries (or as many, plus a validity word) and many groups: split the program
-    if (!h->parts.empty()) { VNM_SEG_ONLY("split program"); return next_parts(h, nrows, keys, inputs, pred, stream); }
+    if (!h->parts.empty()) { VNM_SEG_ONLY("split program"); route_note("split_program:batch", "%zu parts", h->parts.size()); return next_parts(h, nrows, keys, inputs, pred, stream); }
     if (!h->split_tried && key_plain && h->single && keys[0].type == h->plan.key_types[0] && !h->have_table && !h->have_run && !h->pending &&
         !h->expr_active && getenv("VNM_AGG_NO_SPLIT") == nullptr) {
         bool any_null = false, cols8 = true;
@@ -5941,6 +5952,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                     // 7.9 / 12.3 / 23.6 ms).  One part per column instead: each is the direct-addressed 2^13-slot LDS scan (16 bytes per
                     // row and column at the scan's rate: 3.3 / 4.9 / 9.8 ms incl. the join over a few thousand groups).
                     if (h->dense_state == 2 && h->hint <= (1 << DP_TBITS_MAX)) {
+                        route_note("split_program:small_range_per_column", "%d columns, ~%lld groups in a range of <= 2^13 codes", h->plan.n_cols, (long long)h->hint);
                         VNM_TRY(make_parts(h, 1));
                         if (h->segs_active) return VNM_RC_SINGLY;   // (the waiting batches of a stream: one by one into the parts, which record them)
                         return next_parts(h, nrows, keys, inputs, pred, stream);
@@ -5966,6 +5978,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                         // below: 5e8 rows, G = 1e4 / 1e5 / 5e5 / 1e6: 8.2 / 10.9 / 14.8 / 10.1 -> 7.3 / 7.8 / 8.1 / 8.7 ms; 2e6: 9.9 against 11.4)
                         const bool split = h->plan.n_cols >= 3 || !sums || !big || (!pairs && h->hint <= env_i64("VNM_AGG_SPLIT_TWO_MAX_GROUPS", 1500000));
                         if (split) {
+                            route_note(pairs ? "split_program:dense_per_pair" : "split_program:dense_per_column", "%d columns, ~%lld groups over %lld codes, %lld rows", h->plan.n_cols, (long long)h->hint, (long long)h->dense_span, (long long)nrows);
                             VNM_TRY(make_parts(h, pairs ? 2 : 1));
                             if (h->segs_active) return VNM_RC_SINGLY;
                             return next_parts(h, nrows, keys, inputs, pred, stream);
@@ -5973,6 +5986,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                     }
                 }
                 if (many) {
+                    route_note("split_program:many_columns", "%d columns (+%d validity word), ~%lld groups", h->plan.n_cols, any_null ? 1 : 0, (long long)h->hint);
                     VNM_TRY(make_parts(h, (int)env_i64("VNM_AGG_SPLIT_COLS", any_null ? 5 : 6)));
                     if (h->segs_active) return VNM_RC_SINGLY;
                     return next_parts(h, nrows, keys, inputs, pred, stream);
@@ -5981,6 +5995,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                        getenv("VNM_AGG_NO_SPLIT_FEW") == nullptr) {
                 // FEW groups under more than six plain 8-byte columns: parts of up to six columns, each through agg_hotn_kernel, instead of the
                 // interpreted scan over all of them (5e8 rows, G = 7: 7 / 8 / 10 columns 11.5 / 12.9 / 15.7 ms at 2.8 TB/s)
+                route_note("split_program:few_groups_many_columns", "%d columns, ~%lld groups", h->plan.n_cols, (long long)h->hint);
                 VNM_TRY(make_parts(h, 6));
                 if (h->segs_active) return VNM_RC_SINGLY;
                 return next_parts(h, nrows, keys, inputs, pred, stream);
@@ -6032,6 +6047,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
             og_hot = a.pred.type == VNM_F64 && !a.pred.validity && (a.pred.offset & 1) == 0 && a.p.mode == CMP_F64;
             pm = og_hot && vt == VNM_F64 && a.pred.values == a.cols[0].values && a.pred.offset == a.cols[0].offset ? 1 : 2;
         }
+        route_note(og_hot ? "onegroup:register_scan" : "onegroup:lds_scan", "%lld rows, %d columns, %d words", (long long)nrows, h->plan.n_cols, h->plan.n_words);
         if (og_hot) {
             const int g2 = (int)std::min<int64_t>((int64_t)cus * 8, std::max<int64_t>(1, (nrows / 2 + OG_BLOCK - 1) / OG_BLOCK));
 #define VNM_OG(VT_)                                                                                                 \
@@ -6293,6 +6309,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
             if (h->pending) VNM_TRY(complete_pending(h, s));   // (this path makes a run of its own)
             if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
             if (dense_generic && h->scan_pending) VNM_TRY(flush_scan_pending(h, s));
+            route_note(dense_generic ? "dense_scan:generic" : "dense_scan:hot", "~%lld groups in a sampled range of %lld codes (<= 2^13): direct-addressed LDS table, no scatter", (long long)h->hint, (long long)h->dense_span);
             int prc = dense_scan_aggregate(h, a, nrows, s, &spill, &n_spill, dense_generic, &nspill, &n_nspill);
             dscan_stream = prc == 0 && !dense_generic;
             // a generic program whose table for this range does not fit LDS: the same 2^13 codes through one scatter level
@@ -6330,6 +6347,8 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
             if (h->segs_active || h->kn_valid) return VNM_RC_SINGLY;   // (its kernels read one batch of plain keys)
             if (h->pending && complete_pending(h, s)) return 1;     // (the hash-partitioned path makes a run of its own)
             if (h->have_run && merge_run_into_table(h, s)) return 1;
+            route_note(a.part_wide ? "hash_partitions:wide_entries" : (a.part_generic ? "hash_partitions:generic" : "hash_partitions:hot"), "~%lld groups > %lld (the scan's LDS table), dense path %s", (long long)h->hint, (long long)part_min,
+                       h->dense_state == 1 ? "declined or failed" : "not applicable");
             const int r = partitioned_aggregate(h, a, nrows, s, can_spill ? &spill : nullptr, can_spill ? &n_spill : nullptr);
             spill_is_wide = r == 0 && spill != nullptr && a.part_wide != 0;
             return r;
@@ -6337,6 +6356,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
         if (dense_go && dense_two && (h->hint > part_min || h->hint == 0)) {
             if (h->pending && complete_pending(h, s)) return 1;     // (this path makes a run of its own)
             if (h->have_run && merge_run_into_table(h, s)) return 1;
+            route_note("dense:two_values", "%lld codes, ~%lld groups, %lld rows: (value, value, code) entries", (long long)h->dense_span, (long long)h->hint, (long long)nrows);
             prc = dense_two_aggregate(h, a, nrows, s);
             if (prc == 2) h->dense_state = -1;                      // (a key outside the range, a full region, a range it does not take: not again)
             if (prc == 2 && h->hint == 0) {
@@ -6436,6 +6456,10 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
         a.g = h->g;
         a.fill_limit = (int64_t)(h->g.cap * 7 / 10);
         {
+        if (round == 0)
+            route_note(a.ent ? "scan:spilled_entries" : (hot_scan ? (hot && a.nseg > 0 ? "scan:hot_segments" : (hot ? "scan:hot" : (hot_vnull ? "scan:hot_nullable_value" : (hot_two ? "scan:hot_two_columns" : "scan:hot_generic"))))
+                                                                   : (hotn ? "scan:hotn" : (h->single ? "scan:lds_generic" : "scan:wide_keys"))),
+                       "%lld rows, hint %lld (<= %lld or no partition rule applied), %d words per group, %d LDS slots", (long long)scan_n, (long long)h->hint, (long long)part_min, h->plan.n_words, a.lds_slots);
         KernelTimer timer("agg_scan", s);
         if (hot_scan) {
             size_t lds_bytes = (size_t)(S + 2) * 8 * (1 + h->plan.n_words);
@@ -6566,8 +6590,10 @@ static int flush_queue(vnm_agg* h, void* stream) {
         h->segs_active = &q;
         rc = one(q[0], total);
         h->segs_active = nullptr;
+        if (rc != VNM_RC_SINGLY) route_note("stream:segments_of_one_launch", "%zu recorded batches, %lld rows", q.size(), (long long)total);
     }
     if (rc == VNM_RC_SINGLY) {
+        if (q.size() > 1) route_note("stream:batches_singly", "%zu recorded batches (the path's kernels read one batch)", q.size());
         rc = 0;
         for (size_t i = 0; i < q.size() && !rc; i++) rc = one(q[i], q[i].nrows);
     }
@@ -7305,6 +7331,7 @@ int vnm_agg_result_device_alloc(vnm_agg* h, int n_cols, const int* which, void**
         }
         int64_t n = 0, null_pos = 0;
         cols.null_pos = &null_pos;
+        route_note(cols.has_side ? "result:fused_columns_with_side_table" : "result:fused_columns", "%d columns written by the deferred final pass (%zu batches, %lld side groups)", n_cols, pd->sets.size(), (long long)side_groups);
         const int rc = complete_pending(h, s, DF_COLS, &cols, &n);
         if (rc) { free_outputs(); return rc; }
         if (null_pos > 0) {   // the NULL-key group: the key columns get a validity bitmap with that one bit cleared
@@ -7325,6 +7352,7 @@ int vnm_agg_result_device_alloc(vnm_agg* h, int n_cols, const int* which, void**
         return 0;
     }
     int64_t n = 0;
+    route_note("result:finish_then_finalize", "%d columns from the dense partial state", n_cols);
     VNM_TRY(vnm_agg_finish(h, &n, stream));
     *n_groups = n;
     std::vector<int64_t> nulls((size_t)std::max(n_cols, 1), 0);

@@ -103,6 +103,12 @@ struct KernelTimer {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Which ROUTE an operator call took and why (round 5): every place that commits a batch to a path of DESIGN.md section 4 leaves a note
+// -- a route name (the vocabulary of DESIGN.md) and the reason in numbers.  The library counts the notes per route
+// (vnm_route_counts: what the GPU test suite's route-coverage check reads) and keeps the last note of the calling thread
+// (vnm_route_last: "which way did that batch go, and why").  A handful of string operations per operator call, nothing per row.
+void route_note(const char* route, const char* reason_fmt = nullptr, ...);
+
 // ---------------------------------------------------------------------------------------------
 // device-side column access
 // ---------------------------------------------------------------------------------------------

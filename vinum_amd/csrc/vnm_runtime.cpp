@@ -1,4 +1,5 @@
 // Runtime plumbing of libvinum_hip.so: init, errors, caching device allocator, staging, memcpy helpers.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -215,6 +216,29 @@ Predicate make_predicate(int col_type, bool col_has_nulls, int op, int scalar_is
     return p;
 }
 
+// ---- route notes -----------------------------------------------------------------------------------------
+namespace {
+std::mutex& g_route_mu = *new std::mutex;
+std::map<std::string, int64_t>& g_route_counts = *new std::map<std::string, int64_t>;
+thread_local std::string t_route_last;
+}  // namespace
+
+void route_note(const char* route, const char* reason_fmt, ...) {
+    char buf[512];
+    buf[0] = 0;
+    if (reason_fmt) {
+        va_list ap;
+        va_start(ap, reason_fmt);
+        vsnprintf(buf, sizeof(buf), reason_fmt, ap);
+        va_end(ap);
+    }
+    t_route_last = std::string(route) + (buf[0] ? std::string(": ") + buf : std::string());
+    static const bool trace = getenv("VNM_AGG_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[route] %s\n", t_route_last.c_str());
+    std::lock_guard<std::mutex> g(g_route_mu);
+    g_route_counts[route]++;
+}
+
 // ---- kernel timing ------------------------------------------------------------------------------------
 namespace {
 struct TimedSpan { std::string name; hipEvent_t a, b; };
@@ -423,6 +447,26 @@ int stage_chunks(void* dst, const void* const* srcs, const size_t* sizes, size_t
 using namespace vnm;
 
 extern "C" {
+// "route=count" lines of every route taken since the library was loaded (or vnm_route_reset); returns the bytes needed incl. the 0
+int64_t vnm_route_counts(char* buf, int64_t cap) {
+    std::string out;
+    {
+        std::lock_guard<std::mutex> g(g_route_mu);
+        for (auto& kv : g_route_counts) out += kv.first + "=" + std::to_string(kv.second) + "\n";
+    }
+    if (buf && cap > 0) { const size_t n = std::min<size_t>(out.size(), (size_t)cap - 1); memcpy(buf, out.data(), n); buf[n] = 0; }
+    return (int64_t)out.size() + 1;
+}
+// the last note of the calling thread: "route: reason"
+int64_t vnm_route_last(char* buf, int64_t cap) {
+    if (buf && cap > 0) { const size_t n = std::min<size_t>(t_route_last.size(), (size_t)cap - 1); memcpy(buf, t_route_last.data(), n); buf[n] = 0; }
+    return (int64_t)t_route_last.size() + 1;
+}
+void vnm_route_reset(void) {
+    std::lock_guard<std::mutex> g(g_route_mu);
+    g_route_counts.clear();
+}
+
 int vnm_set_profiling(int on) {
     g_profiling = on != 0;
     for (auto& sp : g_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }

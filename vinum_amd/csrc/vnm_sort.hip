@@ -932,6 +932,7 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
     const bool try_topk = limit > 0 && limit * 8 < n && n >= (1 << 16) && getenv("VNM_SORT_NO_TOPK") == nullptr &&
                           (n_keys == 1 || getenv("VNM_SORT_NO_TOPK_MULTI") == nullptr);
     if (try_topk) {
+        route_note("sort:topk_threshold", "LIMIT %lld of %lld rows, %d keys: sampled threshold, candidates through the full sort", (long long)limit, (long long)n, n_keys);
         const int desc = orders[0] == VNM_DESC;
         static bool ts_attr = false;
         if (!ts_attr) {
@@ -1104,6 +1105,7 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
     if (n_keys == 1 && (!keys[0].validity || getenv("VNM_SSORT_NO_NULLS") == nullptr) && (keys[0].type == VNM_F64 || keys[0].type == VNM_I64 || keys[0].type == VNM_U64) &&
         n >= env_sort_i64("VNM_SSORT_MIN_ROWS", (int64_t)1 << 25) && getenv("VNM_SORT_NO_SAMPLE") == nullptr) {
         bool wk = false;
+        route_note("sort:sample_sort", "%lld rows, one 8-byte key: splitters from a sample, two bucket scatters, per-bucket LDS sort", (long long)n);
         const int rc = sample_sort(keys[0], orders[0] == VNM_DESC, n, out_indices, (uint64_t*)out_sorted_key0, &wk, s);
         if (rc == 1) return 1;
         if (rc == 0) { if (wrote_key0) *wrote_key0 = wk ? 1 : 0; return 0; }
@@ -1111,6 +1113,7 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
     RadixBufs r{};
     VNM_TRY(radix_alloc(&r, n));
     bool wrote = false, wrote_key = false;
+    route_note("sort:lsd_radix", "%lld rows, %d keys: stable LSD passes over order-preserving codes, last key first", (long long)n, n_keys);
     int rc = full_sort(n_keys, keys, orders, n, &r, s, out_indices, &wrote, (uint64_t*)out_sorted_key0, &wrote_key);
     if (!rc && wrote_key0) *wrote_key0 = wrote_key ? 1 : 0;
     if (!rc) {

@@ -587,6 +587,7 @@ int vnm_strdict_ranks_device(vnm_strdict* h, int32_t* out_rank_of_id, void* stre
     VNM_HIP(hipStreamSynchronize(s));
     if ((int64_t)ctl[0] != D) return set_error("vnm_strdict_ranks_device: %llu values listed, %lld in the table (internal error)", ctl[0], (long long)D);
     const int m = (int)((ctl[1] + 7) / 8);                    // chunks of the longest value
+    route_note("sort:string_key_ranks", "%lld distinct values, longest %llu bytes: %d round(s) of up to 15 chunk keys + the length", (long long)D, ctl[1], m == 0 ? 1 : (m + 14) / 15);
     constexpr int PER = 15;                                   // chunk keys per sort call (+ the length: 16 keys)
     const int rounds = m == 0 ? 1 : (m + PER - 1) / PER;
     uint64_t* keys = (uint64_t*)pool.take((size_t)D * 8 * (size_t)(std::min(m, PER) + 1));
