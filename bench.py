@@ -1063,7 +1063,7 @@ def main():
     # HBM bytes per step from the PMC passes of the SAME command (tools/profile.sh -> profiles/rNN_rocprofv3_pmc_*.txt),
     # newest round first; hinted and hint-less runs take different paths, so they have different entries
     key = f"{args.workload}_N{n:.0e}_G{groups:.0e}_s{args.selectivity}" + ("_hint" if args.hint else "")
-    for tf in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for tf in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", tf)) as f:
                 tj = json.load(f)

@@ -505,3 +505,32 @@ def test_wide_key_table_scan_when_the_tuple_dictionary_is_switched_off(monkeypat
     batches = util.sliced_batches(t, 70_000)
     got = gpu_aggregate(O.MULTI, ["a", "b", "c"], ["a", "b", "c"], funcs, batches)
     util.assert_agg_equal(got, _oracle(O.MULTI, ["a", "b", "c"], funcs, batches), funcs, ["a", "b", "c"], what="wide-key table")
+
+
+@pytest.mark.parametrize("cls", ["SingleNumericalHashAggregate", "MultiNumericalHashAggregate", "GenericHashAggregate", "OneGroupAggregate"])
+def test_minmax_reference_golden_through_the_vinum_lib_classes(cls):
+    """minmax_ref.arrow (NaNs, all-NaN groups, mixed-sign zeros: outputs of the real reference) through the four operator classes of
+    the Arrow-level seam (vinum_amd.vinum_lib -> vnm_agg_op_*): bit for bit in every group; OneGroupAggregate over one group's rows
+    against the oracle's row loop."""
+    from oracle import oracle as O
+    from tests.golden import float_cases as C
+    from vinum_amd import vinum_lib as V
+    t = C.minmax_table()
+    defs = [V.AggFuncDef(V.AggFuncType(f), col, out) for f, col, out in C.MINMAX_FUNCS]
+    if cls == "OneGroupAggregate":
+        for g in (3, 61, 70, 125, 200):          # plain / NaNs / all NaN / mixed zeros / both
+            rows = t.filter(pa.compute.equal(t.column("k"), g)).select(["v"])
+            agg = V.OneGroupAggregate(defs)
+            o = O.OracleAggregate(O.ONE_GROUP, [], [], C.MINMAX_FUNCS)
+            for b in util.sliced_batches(rows, 7):
+                agg.next(b)
+                o.next(b)
+            util.assert_batches_equal(agg.result(), o.result(), what=f"OneGroupAggregate, group {g}")
+        return
+    agg = getattr(V, cls)(["k"], ["k"], defs)
+    for b in util.sliced_batches(t, C.MINMAX_CHUNK):
+        agg.next(b)
+    got = util.canon(agg.result(), ["k"])
+    ref = util.canon(util.read_ipc("minmax_ref.arrow"), ["k"])
+    for name in ref.schema.names:
+        util.assert_col_equal(got.column(name), ref.column(name), f"{cls}: {name}")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the rocprofv3 summaries kept under profiles/ (run on the GPU box: gpurun -- 'bash tools/profile.sh r01').
 # Kernel trace and each PMC counter are collected in SEPARATE runs (MI355X_MICROARCH.md, HBM section).
-R=${1:-r04}
+R=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
@@ -17,7 +17,7 @@ prof() {  # name, rocprof args..., -- bench args
     echo
 }
 for wl in "groupby --groups 1e8" "groupby --groups 7" "groupby --groups 1e3" "groupby --groups 1e5" "groupby --groups 1e6" \
-          "groupby --groups 1e8 --shape count_star" "stream --groups 1e6" "stream --groups 7" "filter" "topk" "topk --limit 0" "project"; do
+          "groupby --groups 1e8 --shape count_star" "groupby --groups 1e8 --shape minmax" "stream --groups 1e6" "stream --groups 7" "filter" "topk" "topk --limit 0" "project"; do
     tag=$(echo $wl | tr -d ' -' ); 
     prof ks_$tag --kernel-trace -- --workload $wl --steps 5 --warmup 2 > $OUT/${R}_rocprofv3_kernel_stats_$tag.txt
 done
