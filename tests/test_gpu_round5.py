@@ -534,3 +534,45 @@ def test_minmax_reference_golden_through_the_vinum_lib_classes(cls):
     ref = util.canon(util.read_ipc("minmax_ref.arrow"), ["k"])
     for name in ref.schema.names:
         util.assert_col_equal(got.column(name), ref.column(name), f"{cls}: {name}")
+
+
+def test_predicates_on_dictionary_coded_columns_through_the_planner():
+    """`WHERE city = 'Berlin'`, `!=`, `<` `<=` `>` `>=` against a string literal, `IN (...)`, inside AND / OR trees, literals the
+    dictionary does not hold: comparisons of codes / order-preserving ranks in HBM (FilterOperator.lower_dictionary_predicates);
+    equal to pyarrow.compute over the host table (NULL compares False; `!=` True, as the reference's NumPy masks do)."""
+    import pyarrow.compute as pc
+    from vinum_amd import planner
+    rng = np.random.default_rng(12)
+    n = 200_000
+    cities = np.array(["Berlin", "Munich", "Riva", "Naples", "San Francisco", "", "berlin", "Berlin ", "Zürich"], dtype=object)
+    t = pa.table({"city": pa.array(cities[rng.integers(0, len(cities), n)], type=pa.string(), mask=rng.random(n) < 0.05),
+                  "tag": pa.array([bytes([int(x)]) * int(k) for x, k in zip(rng.integers(65, 70, n), rng.integers(0, 3, n))], type=pa.binary()),
+                  "v": pa.array(rng.integers(0, 1000, n).astype(np.float64) / 8.0), "id": pa.array(np.arange(n, dtype=np.int64))})
+    lit = lambda x: ["lit", x]
+    col = t.column("city")
+    nn = pc.fill_null  # NULL -> the mask value numpy semantics give
+    cases = [
+        (["eq", "city", lit("Berlin")], nn(pc.equal(col, "Berlin"), False)),
+        (["ne", "city", lit("Berlin")], nn(pc.not_equal(col, "Berlin"), True)),
+        (["eq", "city", lit("Paris")], nn(pc.equal(col, "Paris"), False)),
+        (["lt", "city", lit("Munich")], nn(pc.less(col, "Munich"), False)),
+        (["le", "city", lit("Munich")], nn(pc.less_equal(col, "Munich"), False)),
+        (["gt", "city", lit("Munich")], nn(pc.greater(col, "Munich"), False)),
+        (["ge", "city", lit("N")], nn(pc.greater_equal(col, "N"), False)),
+        (["lt", lit("Munich"), "city"], nn(pc.greater(col, "Munich"), False)),
+        (["in", "city", ["Riva", "Naples", "nowhere"]], nn(pc.is_in(col, value_set=pa.array(["Riva", "Naples", "nowhere"])), False)),
+        (["and", ["ge", "city", lit("B")], ["lt", "city", lit("O")], ["gt", "v", 60.0]],
+         pc.and_(pc.and_(nn(pc.greater_equal(col, "B"), False), nn(pc.less(col, "O"), False)), pc.greater(t.column("v"), 60.0))),
+        (["or", ["eq", "tag", lit(b"AA")], ["eq", "city", lit("")]], pc.or_(nn(pc.equal(t.column("tag"), b"AA"), False), nn(pc.equal(col, ""), False))),
+    ]
+    for where, mask in cases:
+        got = planner.execute(dict(select=["id", "city"], where=where), t)
+        exp = t.filter(mask)
+        assert got.column("id").to_pylist() == exp.column("id").to_pylist(), where
+        assert got.column("city").to_pylist() == exp.column("city").to_pylist(), where
+    # and under an aggregate: SELECT city, count(*) WHERE city >= 'M' GROUP BY city ORDER BY city
+    got = planner.execute(dict(select=["city", ["fn", "count_star"]], aliases=[None, "n"], where=["ge", "city", lit("M")], group_by=["city"],
+                               order_by=["city"], sort_order=["DESC"]), t)
+    exp = t.filter(nn(pc.greater_equal(col, "M"), False)).group_by(["city"], use_threads=False).aggregate([([], "count_all")]).sort_by([("city", "descending")])
+    assert got.column("city").to_pylist() == exp.column("city").to_pylist()
+    assert got.column("n").to_pylist() == exp.column("count_all").to_pylist()

@@ -63,16 +63,70 @@ class FilterOperator(Operator):
         return (isinstance(pred, tuple) and len(pred) == 3 and isinstance(pred[0], str) and pred[1] in ops.CMP_OPS
                 and isinstance(pred[2], (int, float)) and not isinstance(pred[2], bool))
 
+    _FLIP = {"lt": "gt", "le": "ge", "gt": "lt", "ge": "le", "eq": "eq", "ne": "ne"}
+    _SYM = {"==": "eq", "!=": "ne", ">": "gt", ">=": "ge", "<": "lt", "<=": "le"}
+
+    @classmethod
+    def lower_dictionary_predicates(cls, pred, batch: DeviceRecordBatch):
+        """Comparisons of a dictionary-coded column (strings, binaries: int32 codes in HBM) with a LITERAL -- `city = 'Berlin'`,
+        `name < 'M'`, `city IN ('a', 'b')`; literals are ("lit", value) nodes, a bare str is a column name -- become numeric
+        comparisons: = / != / IN on the literal's CODE (a value the dictionary does not hold matches no row), < <= > >= on the
+        column's order-preserving RANKS (KeyDictionary.rank_column: byte-wise order, as Arrow / NumPy compare such values) against
+        the literal's position among the dictionary's values.  NULL rows behave as in every other predicate (compare False,
+        `!=` True: vinum/arrow/record_batch.py:112-118).  Returns (predicate, extra columns the predicate reads)."""
+        extra = {}
+
+        def is_dict(x):
+            return isinstance(x, str) and x in batch.columns and batch.columns[x].dictionary is not None
+
+        def is_lit(x):
+            return isinstance(x, tuple) and len(x) == 2 and x[0] == "lit" and isinstance(x[1], (str, bytes))
+
+        def walk(e):
+            if not isinstance(e, tuple) or not e:
+                return e
+            op = e[0]
+            if op in cls._FLIP and len(e) == 3:
+                a, b = e[1], e[2]
+                if is_lit(a) and is_dict(b):
+                    a, b, op = b, a, cls._FLIP[op]
+                if is_dict(a) and is_lit(b):
+                    d = batch.columns[a].dictionary
+                    if op in ("eq", "ne"):
+                        c = d.code_of(b[1])
+                        return (op, a, -2 if c is None else c)            # (codes are >= 0)
+                    name = f"__rank_{a}"
+                    if name not in extra:
+                        extra[name] = d.rank_column(batch.columns[a])
+                    less, present = d.rank_bounds(b[1])
+                    return {"lt": ("lt", name, less), "le": ("lt", name, less + present),
+                            "gt": ("ge", name, less + present), "ge": ("ge", name, less)}[op]
+            if op in ("in", "not_in") and is_dict(e[1]) and all(isinstance(v, (str, bytes)) or is_lit(v) for v in e[2]):
+                d = batch.columns[e[1]].dictionary
+                codes = [d.code_of(v[1] if is_lit(v) else v) for v in e[2]]
+                return (op, e[1], tuple(c for c in codes if c is not None) or (-2,))
+            if op in ("in", "not_in"):
+                return (op, walk(e[1]), e[2])
+            return tuple([op] + [walk(x) for x in e[1:]])
+        return walk(pred), extra
+
     def _kernel(self, batch: DeviceRecordBatch) -> DeviceRecordBatch:
         names = batch.column_names
         cols = [batch.columns[n] for n in names]
-        if self.is_simple(self.predicate):
-            col, op, lit = self.predicate
-            outs, k = ops.filter_cmp(batch.column(col), op, lit, cols)
-        else:
-            # general boolean expression tree: one fused mask kernel, then one compaction pass
-            mask = ops.predicate_mask(self.predicate, batch.columns, batch.num_rows)
-            outs, k = ops.filter_mask(mask, None, batch.num_rows, cols)
+        pred = self.predicate
+        if self.is_simple(pred) or (isinstance(pred, tuple) and len(pred) == 3 and pred[1] in self._SYM and isinstance(pred[2], (str, bytes))):
+            col, op, lit = pred
+            if isinstance(lit, (str, bytes)):       # (column, "==", "Berlin") over a dictionary-coded column
+                pred = (self._SYM[op], col, ("lit", lit))
+            else:
+                outs, k = ops.filter_cmp(batch.column(col), op, lit, cols)
+                return DeviceRecordBatch(dict(zip(names, outs)), k)
+        pred, extra = self.lower_dictionary_predicates(pred, batch)
+        # general boolean expression tree: one fused mask kernel, then one compaction pass
+        columns = dict(batch.columns)
+        columns.update(extra)
+        mask = ops.predicate_mask(pred, columns, batch.num_rows)
+        outs, k = ops.filter_mask(mask, None, batch.num_rows, cols)
         return DeviceRecordBatch(dict(zip(names, outs)), k)
 
 

@@ -598,6 +598,8 @@ def columns_of(expr):
             if e not in seen:
                 seen.append(e)
         elif isinstance(e, tuple):
+            if e[0] == "lit":            # ("lit", "Berlin"): a string / bytes LITERAL (a bare str is a column name)
+                return
             if e[0] in ("is_null", "is_not_null"):
                 walk(e[1])
             elif e[0] in ("in", "not_in"):

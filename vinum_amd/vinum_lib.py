@@ -483,6 +483,28 @@ class KeyDictionary:
         mask = ~idx.is_valid().to_numpy(zero_copy_only=False) if idx.null_count else None
         return pa.array(codes, type=pa.int32(), mask=mask)
 
+    def code_of(self, value):
+        """The code of `value` in this dictionary, or None (predicates on a dictionary-coded column: `city = 'Berlin'` is a
+        comparison of int32 codes in HBM)."""
+        import pyarrow.compute as pc
+        vals = self.values_by_code()
+        if not len(vals):
+            return None
+        i = pc.index(vals, pa.scalar(value, type=self.type)).as_py()
+        return None if i < 0 else int(i)
+
+    def rank_bounds(self, value):
+        """(number of dictionary values < value, 1 if value is in the dictionary else 0): with r = rank_column's rank of a row,
+        v < value <=> r < less, v <= value <=> r < less + present, v > value <=> r >= less + present, v >= value <=> r >= less
+        (byte-wise order, as Arrow compares utf8 / binary)."""
+        import pyarrow.compute as pc
+        vals = self.values_by_code()
+        if not len(vals):
+            return 0, 0
+        lit = pa.scalar(value, type=self.type)
+        less = int(pc.sum(pc.less(vals, lit)).as_py() or 0)
+        return less, 0 if self.code_of(value) is None else 1
+
     def rank_column(self, codes_col):
         """ORDER BY a dictionary-coded column: the rows' order-preserving RANKS as an int32 DeviceColumn (same validity as the
         codes: NULL stays NULL).  utf8 / binary dictionaries are ranked on the device (vnm_strdict_ranks_device: the distinct values
