@@ -115,10 +115,10 @@ class _StringMinMax:
     """MIN / MAX of string / binary columns (StringMinMaxFunc, agg_funcs.h:219-261: NULLs skipped, all-NULL group -> NULL, byte-wise
     `row < last`), for every operator class (the reference runs Single_/Multi_/Generic_Int64Grp_StringArgFuncs,
     hash_agg_test.cpp:866-894).  The GPU aggregates order-preserving RANKS: per batch the column is dictionary-encoded (on the
-    device, vnm_strdict_encode), the batch's dictionary is sorted, and a numeric operator of the caller's class takes MIN / MAX of the int32 ranks per
+    device, vnm_strdict_encode) and the batch's dictionary is ranked there (vnm_strdict_ranks_device), and a numeric operator of the caller's class takes MIN / MAX of the int32 ranks per
     group; the winners go back to strings -- one candidate per group, batch and function.  result() ranks the candidates of all
     batches against each other and takes MIN / MAX once more.  String comparisons happen once per distinct value (the
-    dictionary sort on the host), not once per row."""
+    dictionary's sort on the device), not once per row."""
 
     def __init__(self, op_cls, groupby_cols, funcs):
         self._cls, self._groupby = op_cls, list(groupby_cols)
@@ -145,17 +145,24 @@ class _StringMinMax:
         if len(column) and (pa.types.is_string(t) or pa.types.is_large_string(t) or pa.types.is_binary(t) or pa.types.is_large_binary(t)):
             # the batch's dictionary from the device (vnm_strdict_encode, a fresh handle: every value of the batch is new to it);
             # the host sorts the DISTINCT values and turns codes into ranks (one gather)
+            # ... and ranks them there too (round 5, vnm_strdict_ranks_device: the distinct values sorted byte-wise by the multi-key radix
+            # sort over their 8-byte chunks); the host only gathers rank[code] and lines the dictionary up by rank
+            from .device import DeviceBuffer
             kd = KeyDictionary(t)
             codes = kd.encode(column)
             d = pa.concat_arrays(kd._chunks) if kd._chunks else pa.array([], type=t)
-            d_sort = d.cast(pa.large_binary()) if pa.types.is_large_string(t) else (d.cast(pa.binary()) if pa.types.is_string(t) else d)
-            order = pc.sort_indices(d_sort).to_numpy(zero_copy_only=False)
-            rank_of = np.empty(max(len(d), 1), np.int32)
-            rank_of[order] = np.arange(len(d), dtype=np.int32)
             c = codes.fill_null(0).to_numpy(zero_copy_only=False).astype(np.int64)
-            ranks = rank_of[kd._pos[c]] if len(d) else np.zeros(len(c), np.int32)
             mask = ~codes.is_valid().to_numpy(zero_copy_only=False) if codes.null_count else None
-            return pa.array(ranks, type=pa.int32(), mask=mask), d.take(pa.array(order))
+            if not len(d):
+                return pa.array(np.zeros(len(c), np.int32), type=pa.int32(), mask=mask), d
+            top = int(L.lib().vnm_strdict_ids(kd._h))
+            dev = DeviceBuffer(max(top, 1) * 4)
+            L.check(L.lib().vnm_strdict_ranks_device(kd._h, dev.ptr, None))
+            rank_of_id = dev.to_host(np.int32, top)               # (ids never handed out: garbage, never looked at)
+            live = np.nonzero(kd._pos[:top] >= 0)[0]
+            by_rank = np.empty(len(d), np.int64)
+            by_rank[rank_of_id[live]] = kd._pos[live]              # rank -> position in `d`
+            return pa.array(rank_of_id[c], type=pa.int32(), mask=mask), d.take(pa.array(by_rank))
         enc = column.dictionary_encode()
         d = enc.dictionary
         if pa.types.is_string(d.type) or pa.types.is_large_string(d.type):
