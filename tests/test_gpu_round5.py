@@ -327,7 +327,8 @@ def test_int64_sum_beyond_2e32_rows_per_group_raises():
     agg.close()
 
 
-@pytest.mark.parametrize("shape", ["hot_dense", "hot_scan", "small_range", "generic", "one_group", "multi_key", "stream", "nullable_key", "two_columns"])
+@pytest.mark.parametrize("shape", ["hot_dense", "hot_scan", "small_range", "generic", "one_group", "multi_key", "stream", "nullable_key", "two_columns",
+                                   "sparse_keys_hash_partitions", "sparse_keys_generic", "three_columns_few_groups", "three_columns_sparse_keys", "float_key_wide"])
 def test_sum_of_negative_zeros_is_negative_zero(shape, monkeypatch):
     """SumFunc starts from the group's first value (agg_funcs.h:286-305): a group whose non-NULL inputs are ALL -0.0 sums (and
     averages) to -0.0, any +0.0 or cancellation makes it +0.0.  Every float sum accumulator starts at -0.0, the additive identity
@@ -339,7 +340,8 @@ def test_sum_of_negative_zeros_is_negative_zero(shape, monkeypatch):
     rng = np.random.default_rng(len(shape))
     n = 900_000
     groups = {"hot_dense": 300_000, "hot_scan": 9, "small_range": 3000, "generic": 40_000, "one_group": 1, "multi_key": 5000, "stream": 300_000,
-              "nullable_key": 300_000, "two_columns": 500_000}[shape]
+              "nullable_key": 300_000, "two_columns": 500_000, "sparse_keys_hash_partitions": 200_000, "sparse_keys_generic": 200_000,
+              "three_columns_few_groups": 8, "three_columns_sparse_keys": 100_000, "float_key_wide": 4000}[shape]
     k = rng.integers(0, groups, n).astype(np.int64)
     v = rng.integers(-64, 64, n).astype(np.float64) / 8.0
     cls = k % 4                                   # groups = 0 mod 4: all -0.0; 1: -0.0 and +0.0; 2: values cancelling to zero; 3: anything
@@ -349,13 +351,23 @@ def test_sum_of_negative_zeros_is_negative_zero(shape, monkeypatch):
     w = np.where(rng.random(n) < 0.7, -0.0, rng.integers(0, 3, n).astype(np.float64))
     cols = {"k": pa.array(k, mask=(rng.random(n) < 0.05) if shape == "nullable_key" else None), "k2": pa.array((k % 3).astype(np.int32)),
             "v": pa.array(v, mask=(rng.random(n) < 0.1) if shape == "generic" else None), "w": pa.array(w)}
+    if "sparse" in shape:
+        cols["k"] = pa.array(k * 1_000_003 - 12345)          # (the groups' classes follow k, the operator sees sparse keys: hash partitions)
+    if shape == "float_key_wide":
+        cols["k2"] = pa.array(rng.integers(-2**62, 2**62, 7)[k % 7])
     t = pa.table(cols)
     funcs = [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.COUNT_STAR, "", "n")]
+    if shape in ("sparse_keys_generic",):
+        funcs = [(O.SUM, "v", "s"), (O.MAX, "v", "mx"), (O.AVG, "v", "a")]
+    if shape.startswith("three_columns"):
+        cols3 = {"x": np.where(cls == 0, -0.0, v), "y": np.where(cls <= 1, -0.0, 1.0)}
+        t = t.append_column("x", pa.array(cols3["x"])).append_column("y", pa.array(cols3["y"]))
+        funcs = [(O.SUM, "v", "s"), (O.SUM, "x", "sx"), (O.AVG, "y", "ay"), (O.SUM, "w", "sw"), (O.COUNT_STAR, "", "n")]
     if shape == "generic":
         funcs += [(O.MIN, "v", "mn"), (O.SUM, "w", "sw")]
     if shape == "two_columns":
         funcs = [(O.SUM, "v", "s"), (O.SUM, "w", "sw"), (O.COUNT_STAR, "", "n")]
-    kind, groupby = {"one_group": (O.ONE_GROUP, []), "multi_key": (O.MULTI, ["k", "k2"])}.get(shape, (O.SINGLE, ["k"]))
+    kind, groupby = {"one_group": (O.ONE_GROUP, []), "multi_key": (O.MULTI, ["k", "k2"]), "float_key_wide": (O.MULTI, ["k", "k2"])}.get(shape, (O.SINGLE, ["k"]))
     if shape == "one_group":
         t = t.filter(pa.array(cls == 0))
     batches = util.sliced_batches(t, {"stream": 100_000}.get(shape, 400_000))
