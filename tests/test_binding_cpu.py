@@ -83,7 +83,7 @@ def test_installed_operators_hold_the_programs_our_planner_derives(case, ref_env
     from vinum.planner import planner as RP
     from vinum_amd import binding as B
     from vinum_amd import planner as OP
-    table = P.planner_table()
+    table = P.TABLES[case.get("table", "main")]()
     saved = (RP.FilterOperator, RP.ProjectOperator)
     try:
         B.install(vinum)
