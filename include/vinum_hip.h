@@ -455,6 +455,30 @@ int vnm_strdict_codes_to_ranks(const int32_t* codes, const int32_t* rank_of_id, 
 int vnm_csv_parse_block(const char* host_text, int64_t nbytes, int skip_header, int delimiter, int n_fields, int n_cols,
                         const int* field_idx, const int* types, vnm_dcol* out_cols, int64_t* n_rows, int* fallback,
                         void* stream);
+/* Round 5: the non-numeric columns pyarrow.csv infers for such files stay on the device too (the same reader, its `string`,
+ * `date32[day]`, `timestamp[s]` and `timestamp[ns]` conversions: vinum/io/arrow.py:58-61,106).  types[c] may also be
+ *   VNM_CSV_STRING        utf8: out_cols[c] = int32 codes of dicts[c] (a vnm_strdict the caller keeps for the column across blocks; never
+ *                         NULL -- pyarrow reads an empty field of a string column as the empty string); the field bytes are encoded where
+ *                         they lie in the staged text (vnm_strdict_encode_spans) and checked to be well-formed UTF-8 (fallback otherwise:
+ *                         pyarrow raises on them); after the call vnm_strdict_last_new / vnm_strdict_fetch_new hand over the values
+ *                         the block added, as after vnm_strdict_encode.  A field with an escaped quote ("" inside quotes): fallback.
+ *   VNM_CSV_DATE32        YYYY-MM-DD -> int32 days since 1970-01-01
+ *   VNM_CSV_TIMESTAMP_S   YYYY-MM-DD | YYYY-MM-DD[ T]hh:mm | ...:ss -> int64 seconds
+ *   VNM_CSV_TIMESTAMP_NS  the same plus .f{1,9} -> int64 nanoseconds (years 1678 .. 2261)
+ * Calendar-checked (month, day of month, leap years, hh < 24, mm / ss < 60); any other spelling Arrow's ISO 8601 parser knows (zone
+ * offsets, hour-only times, "Z") raises the column's fallback flag.  dicts: n_cols entries (NULL where the column is no string) or NULL. */
+#define VNM_CSV_STRING 200
+#define VNM_CSV_DATE32 201
+#define VNM_CSV_TIMESTAMP_S 202
+#define VNM_CSV_TIMESTAMP_NS 203
+int vnm_csv_parse_block_ex(const char* host_text, int64_t nbytes, int skip_header, int delimiter, int n_fields, int n_cols,
+                           const int* field_idx, const int* types, vnm_strdict* const* dicts, vnm_dcol* out_cols, int64_t* n_rows,
+                           int* fallback, void* stream);
+/* vnm_strdict_encode_device over SPANS of one device buffer: row r = the lens[r] bytes at data[starts[r]] (no NULLs). */
+int vnm_strdict_encode_spans(vnm_strdict* h, const int64_t* starts, const int32_t* lens, int64_t n, const uint8_t* data,
+                             int32_t* out_codes, int64_t* n_new, int64_t* new_bytes, void* stream);
+/* how many values (and bytes) the last encode of this handle added: the sizes vnm_strdict_fetch_new fills */
+int vnm_strdict_last_new(vnm_strdict* h, int64_t* n_new, int64_t* new_bytes);
 
 /* device memory helpers for hosts without a GPU allocator of their own (ctypes / cgo bindings).
  * vnm_malloc / vnm_free go through the library's caching allocator: a freed block is handed to the NEXT

@@ -260,3 +260,222 @@ def test_quoted_fields_stay_on_the_device(tmp_path):
             _read_all(stream_csv(p2))
     else:
         assert _read_all(stream_csv(p2)).to_pydict() == want.to_pydict()
+
+
+# ---- round 5: string / date32 / timestamp columns on the device (vnm_csv_parse_block_ex) ------------------------------------------
+_CITIES = ["Berlin", "Zürich", "São Paulo", '"New York, NY"', "", '""', "東京", "plain text with spaces", '"a,b,c,,"', "x", "Ḽơᶉëᶆ ȋṕšᶙṁ"]
+
+
+def _mixed(n, seed=0, odd=False):
+    """id, city (utf8: non-ASCII, quoted with delimiters, empty), day (date32), ts (timestamp[s]: ' ' / 'T' / date only / hh:mm), tsn
+    (timestamp[ns]), amount (float64), n (int64, NULLs).  odd: also rows only pyarrow parses (escaped quotes, zone-less oddities)."""
+    rng = np.random.default_rng(seed)
+    rows = ["id,city,day,ts,tsn,amount,n"]
+    days = rng.integers(-25567, 47482, n)           # 1900-01-01 .. 2100-01-01
+    secs = rng.integers(-2_208_988_800, 4_102_444_800, n)
+    for i in range(n):
+        city = _CITIES[int(rng.integers(0, len(_CITIES)))] if i % 7 else f"town{int(rng.integers(0, 5000))}"
+        if odd and i % 1000 == 999:
+            city = '"say ""hi"", ok"'
+        day = "" if i % 53 == 0 else str(np.datetime64(int(days[i]), "D"))
+        t = np.datetime64(int(secs[i]), "s")
+        ts = str(t)                                                       # 'YYYY-MM-DDThh:mm:ss'
+        k = i % 5
+        if k == 1:
+            ts = ts.replace("T", " ")
+        elif k == 2:
+            ts = ts[:10]
+        elif k == 3:
+            ts = ts[:16].replace("T", " ")
+        elif k == 4 and i % 35 == 4:
+            ts = ""
+        nd = int(rng.integers(0, 10))
+        tsn = str(np.datetime64(int(secs[i]) % 4_000_000_000, "s")).replace("T", " ")
+        if nd:
+            tsn += "." + "".join(str(d) for d in rng.integers(0, 10, nd))
+        if i == 0:
+            tsn = "2009-06-15 17:26:21.123456789"                         # (so that the probe infers nanoseconds)
+        amount = f"{rng.normal(10, 3):.3f}"
+        cnt = "" if i % 97 == 0 else str(int(rng.integers(0, 7)))
+        rows.append(f"{i},{city},{day},{ts},{tsn},{amount},{cnt}")
+    return ("\n".join(rows) + "\n").encode()
+
+
+def _same_table(got, exp):
+    assert got.schema == exp.schema
+    assert got.num_rows == exp.num_rows
+    for name in exp.schema.names:
+        a, e = got.column(name).combine_chunks(), exp.column(name).combine_chunks()
+        if pa.types.is_string(e.type):
+            assert a.to_pylist() == e.to_pylist(), name
+        elif pa.types.is_temporal(e.type):
+            assert a.null_count == e.null_count, name
+            st = pa.int32() if pa.types.is_date32(e.type) else pa.int64()
+            assert a.cast(st).to_pylist() == e.cast(st).to_pylist(), name
+        else:
+            util.assert_col_equal(a, e, name)
+
+
+@pytest.mark.parametrize("block_size", [1 << 15, 1 << 20, 64 << 20])
+def test_string_date_and_timestamp_columns_stay_on_the_device(block_size, tmp_path, monkeypatch):
+    """VERDICT r04 missing #4 (the remainder of SURVEY 8 f2): utf8, date32, timestamp[s] and timestamp[ns] columns are parsed by
+    vnm_csv_parse_block_ex -- equal to pyarrow.csv.read_csv (what vinum/io/arrow.py:58-61,106 delegates to), and pyarrow is never
+    asked for a column of these blocks."""
+    from vinum_amd import io as vio
+    data = _mixed(60_000, seed=1)
+    path = os.path.join(tmp_path, "mixed.csv")
+    with open(path, "wb") as f:
+        f.write(data)
+    exp = pacsv.read_csv(io.BytesIO(data), read_options=pacsv.ReadOptions(use_threads=False))
+    assert [str(f.type) for f in exp.schema] == ["int64", "string", "date32[day]", "timestamp[s]", "timestamp[ns]", "double", "int64"]
+
+    def no_host(self, text, names):
+        raise AssertionError(f"pyarrow was asked to parse {names}")
+    monkeypatch.setattr(vio.GpuCsvReader, "_host_parse", no_host)
+    got = _read_all(vio.stream_csv(path, block_size=block_size))
+    _same_table(got, exp)
+
+
+def test_string_and_time_fields_the_device_declines_go_to_pyarrow(tmp_path):
+    """Escaped quotes inside a quoted string, zone-less oddities (hour only), leading blanks: the column of THAT block is parsed by
+    pyarrow, with the same running dictionary -- the table is pyarrow's either way."""
+    from vinum_amd.io import stream_csv
+    data = _mixed(30_000, seed=2, odd=True)
+    lines = data.split(b"\n")
+    for i in (1500, 9000, 20_000):
+        f = lines[i].split(b",")
+        if len(f) == 7:
+            f[3] = b"2020-01-01 10"              # ISO 8601 hour only: Arrow reads it, the device parser declines
+            f[2] = b" 2020-03-04"                # Arrow trims blanks of non-string fields
+            lines[i] = b",".join(f)
+    data = b"\n".join(lines)
+    path = os.path.join(tmp_path, "odd.csv")
+    with open(path, "wb") as f:
+        f.write(data)
+    exp = pacsv.read_csv(io.BytesIO(data), read_options=pacsv.ReadOptions(use_threads=False))
+    assert exp.schema.field("ts").type == pa.timestamp("s") and exp.schema.field("day").type == pa.date32()
+    _same_table(_read_all(stream_csv(path, block_size=1 << 16)), exp)
+
+
+def test_calendar_arithmetic_against_numpy():
+    """Every accepted date / timestamp spelling over the whole proleptic Gregorian range 0001 .. 9999 (leap years, century rules,
+    negative epochs): bit-equal to numpy.datetime64; impossible dates and times raise the fallback flag, never a value."""
+    import ctypes
+    from vinum_amd import _lib as L
+    rng = np.random.default_rng(11)
+    n = 200_000
+    days = rng.integers(-719162, 2932896, n)                       # 0001-01-01 .. 9999-12-31
+    days[:6] = [-719162, 2932896, 0, -1, 11016, -25509]             # ... 2000-02-29, 1900-02-28
+    sod = rng.integers(0, 86400, n)
+    d = days.astype("datetime64[D]")
+    text_d = [str(x) for x in d]
+    ts = (days.astype(np.int64) * 86400 + sod)
+    text_s = [f"{a}{'T' if i % 2 else ' '}{s // 3600:02d}:{s // 60 % 60:02d}:{s % 60:02d}" for i, (a, s) in enumerate(zip(text_d, sod.tolist()))]
+    body = "\n".join(f"{a},{b}" for a, b in zip(text_d, text_s))
+    text = ("d,t\n" + body + "\n").encode()
+    lib = L.lib()
+
+    def parse(text, kinds):
+        k = len(kinds)
+        out = (L.DCol * k)()
+        n_rows = ctypes.c_int64(0)
+        fb = (ctypes.c_int * (k + 2))()
+        L.check(lib.vnm_csv_parse_block_ex(text, len(text), 1, ord(","), k, k, (ctypes.c_int * k)(*range(k)), (ctypes.c_int * k)(*kinds), None, out,
+                                           ctypes.byref(n_rows), fb, None))
+        cols = []
+        for i, kind in enumerate(kinds):
+            a = np.empty(n_rows.value, np.int32 if kind == L.CSV_DATE32 else np.int64)
+            if a.nbytes:
+                L.check(lib.vnm_memcpy_d2h(a.ctypes.data, out[i].values, a.nbytes))
+            bits = np.empty((n_rows.value + 7) // 8, np.uint8)
+            if bits.nbytes:
+                L.check(lib.vnm_memcpy_d2h(bits.ctypes.data, out[i].validity, bits.nbytes))
+            cols.append((a, np.unpackbits(bits, bitorder="little")[:n_rows.value].astype(bool)))
+            lib.vnm_free_column(ctypes.byref(out[i]))
+        return cols, list(fb)
+
+    (dd, tt), fb = parse(text, [L.CSV_DATE32, L.CSV_TIMESTAMP_S])
+    assert fb == [0, 0, 0, 0]
+    assert dd[1].all() and tt[1].all()
+    assert (dd[0] == days).all()
+    assert (tt[0] == ts).all()
+    # nanoseconds: 1678 .. 2261, one to nine fractional digits
+    m = 50_000
+    secs = rng.integers(-9_200_000_000, 9_200_000_000, m)          # 1678-06 .. 2261-07
+    lines = []
+    exp = np.empty(m, np.int64)
+    for i in range(m):
+        nd = int(rng.integers(0, 10))
+        digits = "".join(str(x) for x in rng.integers(0, 10, nd))
+        s = str(np.datetime64(int(secs[i]), "s")).replace("T", " ") + ("." + digits if nd else "")
+        lines.append(s)
+        exp[i] = int(secs[i]) * 10**9 + (int(digits) * 10**(9 - nd) if nd else 0)
+    text = ("t\n" + "\n".join(lines) + "\n").encode()
+    (nn,), fb = parse(text, [L.CSV_TIMESTAMP_NS])
+    assert fb == [0, 0, 0] and nn[1].all()
+    assert (nn[0] == exp).all()
+    # never a guessed value
+    for bad in ["2021-02-29", "1900-02-29", "2020-13-01", "2020-00-10", "2020-04-31", "2020-01-00", "2020-1-01", "20200101", "2020-01-01x", "abcd-01-01"]:
+        ((_, v),), fb = parse(f"d\n2020-01-01\n{bad}\n".encode(), [L.CSV_DATE32])
+        assert fb[0] == 1 and not v[1], bad
+    for bad in ["2020-01-01 24:00:00", "2020-01-01 10:60:00", "2020-01-01 10:11:60", "2020-01-01 10", "2020-01-01 10:11:12Z", "2020-01-01 10:11:12+01:00",
+                "2020-01-01 10:11:12.5", "2020-01-01_10:11:12", " 2020-01-01"]:
+        ((_, v),), fb = parse(f"t\n2020-01-01 00:00:00\n{bad}\n".encode(), [L.CSV_TIMESTAMP_S])
+        assert fb[0] == 1 and not v[1], bad
+    for bad in ["2020-01-01 10:11:12.", "2020-01-01 10:11:12.1234567891", "1677-12-31 00:00:00", "2262-01-01 00:00:00", "2020-01-01 10:11:12.12a"]:
+        ((_, v),), fb = parse(f"t\n2020-01-01 00:00:00\n{bad}\n".encode(), [L.CSV_TIMESTAMP_NS])
+        assert fb[0] == 1 and not v[1], bad
+    # the empty field is NULL
+    ((_, v), (_, w)), fb = parse(b"i,d\n1,2020-01-01\n2,\n3,2020-01-03\n", [L.I64, L.CSV_DATE32])
+    assert fb == [0, 0, 0, 0] and w.tolist() == [True, False, True]
+
+
+def test_invalid_utf8_is_not_accepted(tmp_path):
+    """pyarrow checks string columns (check_utf8) and raises; the device parser flags the column, so the reader raises the same way."""
+    from vinum_amd.io import stream_csv
+    rows = [b"id,name"] + [b"%d,ok%d" % (i, i) for i in range(200_000)]      # (beyond the 1 MB the schema is inferred from)
+    for bad in (b"\xff", b"\xc3", b"\xe0\x80\x80", b"\xed\xa0\x80", b"\xf4\x90\x80\x80", b"\xc0\xaf"):
+        r = list(rows)
+        r[150_000] = b"150000,bad" + bad + b"x"
+        data = b"\n".join(r) + b"\n"
+        path = os.path.join(tmp_path, "bad_utf8.csv")
+        with open(path, "wb") as f:
+            f.write(data)
+        with pytest.raises(pa.ArrowInvalid):      # the streaming reader the reference uses: types from the first block, then strict
+            for _ in pacsv.open_csv(io.BytesIO(data), read_options=pacsv.ReadOptions(block_size=1 << 20)):
+                pass
+        reader = stream_csv(path, block_size=1 << 20)
+        assert reader.schema.field("name").type == pa.string()
+        with pytest.raises(pa.ArrowInvalid):
+            _read_all(reader)
+    # ... and every well-formed sequence length is taken
+    good = "a,b\n1,é\n2,€\n3,😀\n4,߿ࠀ￿\U00010000\U0010ffff\n".encode()
+    path = os.path.join(tmp_path, "good_utf8.csv")
+    with open(path, "wb") as f:
+        f.write(good)
+    _same_table(_read_all(stream_csv(path)), pacsv.read_csv(io.BytesIO(good)))
+
+
+def test_group_by_a_string_column_of_a_csv_stream(tmp_path, monkeypatch):
+    """SELECT city, count(*), sum(n), min(day), max(ts) FROM stream_csv(...) GROUP BY city: the string key reaches the aggregate as
+    dictionary codes that were never an Arrow string array on the host."""
+    from vinum_amd import io as vio
+    from vinum_amd import planner
+    data = _mixed(80_000, seed=5)
+    path = os.path.join(tmp_path, "mixed.csv")
+    with open(path, "wb") as f:
+        f.write(data)
+
+    def no_host(self, text, names):
+        raise AssertionError(f"pyarrow was asked to parse {names}")
+    monkeypatch.setattr(vio.GpuCsvReader, "_host_parse", no_host)
+    q = dict(select=["city", ["fn", "count_star"], ["fn", "sum", "n"], ["fn", "min", "day"], ["fn", "max", "ts"]], aliases=[None, "c", "s", "d", "t"],
+             group_by=["city"])
+    got = planner.execute(q, vio.stream_csv(path, block_size=1 << 20)).sort_by("city")
+    t = pacsv.read_csv(io.BytesIO(data))
+    exp = t.group_by("city", use_threads=False).aggregate([([], "count_all"), ("n", "sum"), ("day", "min"), ("ts", "max")]).sort_by("city")
+    assert got.column("city").to_pylist() == exp.column("city").to_pylist()
+    assert got.column("c").cast(pa.int64()).to_pylist() == exp.column("count_all").to_pylist()
+    assert [None if x is None else int(x) for x in got.column("s").to_pylist()] == exp.column("n_sum").to_pylist()
+    assert got.column("d").cast(pa.date32()).to_pylist() == exp.column("day_min").to_pylist()
+    assert got.column("t").cast(pa.timestamp("s")).to_pylist() == exp.column("ts_max").to_pylist()

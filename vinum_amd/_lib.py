@@ -30,6 +30,7 @@ class ExprIns(ctypes.Structure):
 
 # enums (include/vinum_hip.h)
 I8, I16, I32, I64, U8, U16, U32, U64, F32, F64 = range(10)
+CSV_STRING, CSV_DATE32, CSV_TIMESTAMP_S, CSV_TIMESTAMP_NS = 200, 201, 202, 203   # vnm_csv_parse_block_ex column kinds
 COUNT_STAR, COUNT, MIN, MAX, SUM, AVG = range(6)
 ONE_GROUP, SINGLE_NUMERICAL, MULTI_NUMERICAL = range(3)
 ASC, DESC = 0, 1
@@ -107,6 +108,7 @@ PROTOTYPES = {
     "vnm_stage_column": (c_int, [c_void, c_void, c_i64, c_i64, ctypes.c_int32, c_void, c_void]),
     "vnm_free_column": (c_int, [c_void]),
     "vnm_csv_parse_block": (c_int, [c_void, c_i64, c_int, c_int, c_int, c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
+    "vnm_csv_parse_block_ex": (c_int, [c_void, c_i64, c_int, c_int, c_int, c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
     "vnm_agg_op_next_stream": (c_int, [c_void, c_void]),
     "vnm_sort_op_next_stream": (c_int, [c_void, c_void]),
     "vnm_strdict_create": (c_void, []),
@@ -117,6 +119,8 @@ PROTOTYPES = {
     "vnm_strdict_fetch_new": (c_int, [c_void, c_void, c_void, c_void]),
     "vnm_strdict_ranks_device": (c_int, [c_void, c_void, c_void]),
     "vnm_strdict_codes_to_ranks": (c_int, [c_void, c_void, c_i64, c_void, c_void]),
+    "vnm_strdict_encode_spans": (c_int, [c_void, c_void, c_void, c_i64, c_void, c_void, c_void, c_void, c_void]),
+    "vnm_strdict_last_new": (c_int, [c_void, c_void, c_void]),
     "vnm_take_varwidth": (c_int, [c_void, c_void, c_void, c_void, c_i64, c_void, c_void, c_void, c_void, c_void]),
     "vnm_take_bits": (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_void]),
     "vnm_take_fixed16": (c_int, [c_void, c_void, c_i64, c_void, c_void]),

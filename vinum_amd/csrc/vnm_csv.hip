@@ -18,6 +18,13 @@
 // the correctly rounded value of the decimal string -- what strtod / fast_float / Python's float() return.  Fields outside
 // that domain (more than 19 significant digits, |q| > 19, "inf", "nan", hex floats, thousands separators, whitespace) are
 // not guessed at: the lane raises the column's fallback flag and the caller has pyarrow parse that column of that block.
+//
+// Round 5: string, date and timestamp columns stay on the device too (vnm_csv_parse_block_ex).  A utf8 field is a SPAN of the staged
+// text (quotes stripped, UTF-8 checked as pyarrow's check_utf8 does); the spans of a column go through the column's string dictionary
+// where they lie (vnm_strdict_encode_spans) and the column is born as int32 dictionary codes -- what the host route
+// (pyarrow -> dictionary_encode -> stage) produced, without the Arrow string array in between.  "YYYY-MM-DD" and
+// "YYYY-MM-DD[ T]hh:mm[:ss[.fffffffff]]" become date32 / timestamp[s] / timestamp[ns] by integer arithmetic (days_from_civil); other
+// ISO 8601 spellings (zone offsets, week dates, hour-only times) raise the fallback flag like the numeric corner cases.
 #include <algorithm>
 
 #include "vnm_common.hpp"
@@ -39,8 +46,9 @@ struct CsvArgs {
     int n_fields;                     // fields per row (from the header)
     int n_cols;
     int field_of[CSV_MAX_COLS];       // ascending field indices of the parsed columns
-    int type_of[CSV_MAX_COLS];        // VNM_I64 / VNM_F64
-    void* out_values[CSV_MAX_COLS];
+    int type_of[CSV_MAX_COLS];        // VNM_I64 / VNM_F64 / VNM_CSV_*
+    void* out_values[CSV_MAX_COLS];   // 8 bytes per row (VNM_CSV_STRING: the span's start in the text; VNM_CSV_DATE32: 4 bytes per row)
+    int32_t* span_len[CSV_MAX_COLS];  // VNM_CSV_STRING: the span's length
     uint8_t* out_valid[CSV_MAX_COLS]; // byte per row (packed into bitmaps afterwards)
     int64_t nrows;
 };
@@ -259,6 +267,91 @@ __device__ __noinline__ int csv_parse_field(const uint8_t* p, int len, int type,
     return 0;
 }
 
+
+// days since 1970-01-01 of a proleptic Gregorian date (the civil-calendar identity: eras of 400 years = 146097 days)
+__device__ __forceinline__ int64_t csv_days_from_civil(int y, int m, int d) {
+    y -= m <= 2;
+    const int era = (y >= 0 ? y : y - 399) / 400;
+    const int yoe = y - era * 400;
+    const int doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
+    const int doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+    return (int64_t)era * 146097 + doe - 719468;
+}
+__device__ __forceinline__ bool csv_two(const uint8_t* p, int* v) {
+    const uint32_t a = p[0] - 48u, b = p[1] - 48u;
+    *v = (int)(a * 10 + b);
+    return a <= 9u && b <= 9u;
+}
+
+// one date / timestamp field: 0 = ok, 1 = NULL (empty), 2 = needs the host parser.  Accepted: YYYY-MM-DD, and for timestamps
+// YYYY-MM-DD[ T]hh:mm, ...:ss, ...:ss.f{1,9} (nanoseconds only).  Anything else Arrow's ISO 8601 parser may or may not take: host.
+__device__ __noinline__ int csv_parse_time_field(const uint8_t* p, int len, int type, uint64_t* bits) {
+    if (len == 0) return 1;
+    if (len < 10) return 2;
+    int c1, c2, mo, dd;
+    if (!csv_two(p, &c1) || !csv_two(p + 2, &c2) || p[4] != '-' || !csv_two(p + 5, &mo) || p[7] != '-' || !csv_two(p + 8, &dd)) return 2;
+    const int y = c1 * 100 + c2;
+    if (mo < 1 || mo > 12 || dd < 1) return 2;
+    const bool leap = (y % 4 == 0 && y % 100 != 0) || y % 400 == 0;
+    const int mdays = mo == 2 ? (leap ? 29 : 28) : ((mo == 4 || mo == 6 || mo == 9 || mo == 11) ? 30 : 31);
+    if (dd > mdays) return 2;
+    const int64_t days = csv_days_from_civil(y, mo, dd);
+    if (type == VNM_CSV_DATE32) {
+        if (len != 10) return 2;
+        *bits = (uint64_t)days;
+        return 0;
+    }
+    int hh = 0, mi = 0, ss = 0;
+    int64_t frac = 0;
+    if (len > 10) {
+        if (len < 16 || (p[10] != ' ' && p[10] != 'T') || !csv_two(p + 11, &hh) || p[13] != ':' || !csv_two(p + 14, &mi)) return 2;
+        if (len > 16) {
+            if (len < 19 || p[16] != ':' || !csv_two(p + 17, &ss)) return 2;
+            if (len > 19) {
+                if (type != VNM_CSV_TIMESTAMP_NS || p[19] != '.' || len == 20 || len > 29) return 2;
+                int64_t scale = 1000000000;
+                for (int i = 20; i < len; i++) {
+                    const uint32_t dg = p[i] - 48u;
+                    if (dg > 9u) return 2;
+                    scale /= 10;
+                    frac += (int64_t)dg * scale;
+                }
+            }
+        }
+        if (hh > 23 || mi > 59 || ss > 59) return 2;
+    }
+    const int64_t secs = days * 86400 + hh * 3600 + mi * 60 + ss;
+    if (type == VNM_CSV_TIMESTAMP_S) { *bits = (uint64_t)secs; return 0; }
+    if (y < 1678 || y > 2261) return 2;          // int64 nanoseconds cover 1677-09-21 .. 2262-04-11: the edges go to the host parser
+    *bits = (uint64_t)(secs * 1000000000LL + frac);
+    return 0;
+}
+
+// well-formed UTF-8 (shortest forms, no surrogates, <= U+10FFFF): what pyarrow's check_utf8 demands of a string column
+__device__ __noinline__ bool csv_utf8_ok(const uint8_t* p, int len) {
+    int i = 0;
+    while (i < len) {
+        const uint32_t b = p[i];
+        if (b < 0x80u) { i++; continue; }
+        int need;
+        uint32_t lo = 0x80u, hi = 0xBFu;
+        if (b >= 0xC2u && b <= 0xDFu) need = 1;
+        else if (b == 0xE0u) { need = 2; lo = 0xA0u; }
+        else if (b == 0xEDu) { need = 2; hi = 0x9Fu; }
+        else if (b >= 0xE1u && b <= 0xEFu) need = 2;
+        else if (b == 0xF0u) { need = 3; lo = 0x90u; }
+        else if (b >= 0xF1u && b <= 0xF3u) need = 3;
+        else if (b == 0xF4u) { need = 3; hi = 0x8Fu; }
+        else return false;
+        if (i + need >= len) return false;      // the sequence is cut off by the end of the field
+        const uint32_t c1 = p[i + 1];
+        if (c1 < lo || c1 > hi) return false;
+        for (int k = 2; k <= need; k++) { const uint32_t c = p[i + k]; if (c < 0x80u || c > 0xBFu) return false; }
+        i += need + 1;
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(256) void csv_parse_kernel(CsvArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.nrows; r += stride) {
@@ -289,11 +382,20 @@ __global__ __launch_bounds__(256) void csv_parse_kernel(CsvArgs a) {
                 if (c < a.n_cols && field == a.field_of[c]) {
                     uint64_t bits = 0;
                     int rc;
-                    if (!quoted) rc = csv_parse_field(p + fstart, i - fstart, a.type_of[c], &bits);
-                    else if (weird || qend != i - 1) rc = 2;
-                    else rc = csv_parse_field(p + fstart + 1, qend - fstart - 1, a.type_of[c], &bits);   // ("" -> NULL, as pyarrow's quoted_strings_can_be_null)
+                    const int type = a.type_of[c];
+                    const uint8_t* f = quoted ? p + fstart + 1 : p + fstart;             // the field between its quotes
+                    const int flen = quoted ? qend - fstart - 1 : i - fstart;
+                    if (quoted && (weird || qend != i - 1)) rc = 2;                      // an escaped quote, or text behind the closing quote
+                    else if (type == VNM_CSV_STRING) {
+                        // a string field is never NULL (pyarrow: strings_can_be_null = False; an empty field is the empty string)
+                        rc = csv_utf8_ok(f, flen) ? 0 : 2;
+                        bits = (uint64_t)(lo + (f - p));
+                        a.span_len[c][r] = rc == 0 ? flen : 0;
+                    } else if (type == VNM_I64 || type == VNM_F64) rc = csv_parse_field(f, flen, type, &bits);   // (quoted "" -> NULL, as pyarrow's quoted_strings_can_be_null)
+                    else rc = csv_parse_time_field(f, flen, type, &bits);
                     if (rc == 2) a.flags[1 + c] = 1;
-                    ((uint64_t*)a.out_values[c])[r] = bits;
+                    if (type == VNM_CSV_DATE32) ((int32_t*)a.out_values[c])[r] = (int32_t)bits;
+                    else ((uint64_t*)a.out_values[c])[r] = bits;
                     a.out_valid[c][r] = rc == 0;
                     c++;
                 }
@@ -306,7 +408,11 @@ __global__ __launch_bounds__(256) void csv_parse_kernel(CsvArgs a) {
         // ragged row: pyarrow raises on it, so does the caller.  An EMPTY line is not a row at all for pyarrow (ignore_empty_lines):
         // it is flagged the same way even in a one-column file, so that the block takes pyarrow's row count.
         if (field != a.n_fields || len == 0) a.flags[20] = 1;
-        for (; c < a.n_cols; c++) { ((uint64_t*)a.out_values[c])[r] = 0; a.out_valid[c][r] = 0; }
+        for (; c < a.n_cols; c++) {
+            if (a.type_of[c] == VNM_CSV_DATE32) ((int32_t*)a.out_values[c])[r] = 0; else ((uint64_t*)a.out_values[c])[r] = 0;
+            if (a.span_len[c]) a.span_len[c][r] = 0;
+            a.out_valid[c][r] = 0;
+        }
     }
 }
 
@@ -321,13 +427,22 @@ int vnm_pack_validity(const uint8_t* valid_bytes, int64_t n, uint8_t* bitmap, vo
 int vnm_csv_parse_block(const char* host_text, int64_t nbytes, int skip_header, int delimiter, int n_fields, int n_cols,
                         const int* field_idx, const int* types, vnm_dcol* out_cols, int64_t* n_rows, int* fallback /* [n_cols + 2] */,
                         void* stream) {
+    return vnm_csv_parse_block_ex(host_text, nbytes, skip_header, delimiter, n_fields, n_cols, field_idx, types, nullptr, out_cols, n_rows, fallback, stream);
+}
+
+int vnm_csv_parse_block_ex(const char* host_text, int64_t nbytes, int skip_header, int delimiter, int n_fields, int n_cols,
+                           const int* field_idx, const int* types, vnm_strdict* const* dicts, vnm_dcol* out_cols, int64_t* n_rows,
+                           int* fallback /* [n_cols + 2] */, void* stream) {
     VNM_TRY(ensure_init());
     if (!host_text || !out_cols || !n_rows || !fallback) return set_error("vnm_csv_parse_block: null argument");
     if (n_cols < 1 || n_cols > CSV_MAX_COLS) return set_error("vnm_csv_parse_block: 1..%d columns per call", CSV_MAX_COLS);
     if (nbytes <= 0 || host_text[nbytes - 1] != '\n') return set_error("vnm_csv_parse_block: a block must end with a newline");
     if (nbytes >= (1LL << 31)) return set_error("vnm_csv_parse_block: blocks must be < 2 GiB");
     for (int c = 0; c < n_cols; c++) {
-        if (types[c] != VNM_I64 && types[c] != VNM_F64) return set_error("vnm_csv_parse_block: column %d: int64 / float64 only", c);
+        const int t = types[c];
+        if (t != VNM_I64 && t != VNM_F64 && t != VNM_CSV_STRING && t != VNM_CSV_DATE32 && t != VNM_CSV_TIMESTAMP_S && t != VNM_CSV_TIMESTAMP_NS)
+            return set_error("vnm_csv_parse_block: column %d: int64 / float64 / VNM_CSV_* only", c);
+        if (t == VNM_CSV_STRING && (!dicts || !dicts[c])) return set_error("vnm_csv_parse_block: column %d: a string column needs its dictionary", c);
         if (c && field_idx[c] <= field_idx[c - 1]) return set_error("vnm_csv_parse_block: field indices must ascend");
         if (field_idx[c] < 0 || field_idx[c] >= n_fields) return set_error("vnm_csv_parse_block: field index out of range");
     }
@@ -382,7 +497,13 @@ int vnm_csv_parse_block(const char* host_text, int64_t nbytes, int skip_header, 
         a.row_start = (int64_t*)pool.take((size_t)(a.nrows + 1) * 8);
         if (!a.row_start) return 1;
         for (int c = 0; c < n_cols; c++) {
-            out_cols[c].values = a.out_values[c] = pool_alloc((size_t)a.nrows * 8);      // (owned by out_cols from here: Cleanup)
+            if (types[c] == VNM_CSV_STRING) {       // spans now (scratch), codes behind the parse kernel
+                a.out_values[c] = pool.take((size_t)a.nrows * 8);
+                a.span_len[c] = (int32_t*)pool.take((size_t)a.nrows * 4);
+                out_cols[c].values = pool_alloc((size_t)a.nrows * 4);
+                if (!a.span_len[c] || !out_cols[c].values) return 1;
+            } else
+                out_cols[c].values = a.out_values[c] = pool_alloc((size_t)a.nrows * (types[c] == VNM_CSV_DATE32 ? 4 : 8));      // (owned by out_cols from here: Cleanup)
             a.out_valid[c] = (uint8_t*)pool.take((size_t)a.nrows);
             if (!a.out_values[c] || !a.out_valid[c]) return 1;
         }
@@ -395,17 +516,25 @@ int vnm_csv_parse_block(const char* host_text, int64_t nbytes, int skip_header, 
         if (hipGetLastError() != hipSuccess) return set_error("vnm_csv_parse_block: kernel launch failed");
         // Arrow validity bitmaps
         for (int c = 0; c < n_cols; c++) {
+            out_cols[c].length = a.nrows;
+            out_cols[c].type = types[c] == VNM_CSV_STRING || types[c] == VNM_CSV_DATE32 ? VNM_I32 : (types[c] == VNM_F64 ? VNM_F64 : VNM_I64);
+            if (types[c] == VNM_CSV_STRING) continue;       // never NULL
             uint8_t* bm = (uint8_t*)pool_alloc((size_t)((a.nrows + 63) / 64) * 8);
             if (!bm) return 1;
             out_cols[c].validity = bm;
-            out_cols[c].length = a.nrows;
-            out_cols[c].type = types[c];
             VNM_TRY(vnm_pack_validity(a.out_valid[c], a.nrows, bm, stream));
         }
     }
     unsigned long long fl[21] = {};
     VNM_HIP(hipMemcpyAsync(fl, a.flags, sizeof(fl), hipMemcpyDeviceToHost, s));
     VNM_HIP(hipStreamSynchronize(s));
+    // string columns: the spans -> dictionary codes, while the text is still staged.  A column (or block) that goes to the host parser
+    // anyway is not encoded: its values would enter the dictionary twice over otherwise harmlessly, but an invalid UTF-8 field must not
+    if (a.nrows > 0 && !fl[0] && !fl[20])
+        for (int c = 0; c < n_cols; c++)
+            if (types[c] == VNM_CSV_STRING && !fl[1 + c])
+                VNM_TRY(vnm_strdict_encode_spans(dicts[c], (const int64_t*)a.out_values[c], a.span_len[c], a.nrows, a.text, (int32_t*)out_cols[c].values,
+                                                 nullptr, nullptr, stream));
     for (int c = 0; c < n_cols; c++) fallback[c] = fl[1 + c] != 0;
     fallback[n_cols] = fl[0] != 0;        // a row ends inside a quoted field (a newline in a value): the whole block needs the host reader
     fallback[n_cols + 1] = fl[20] != 0;   // a row with a different number of fields

@@ -34,6 +34,7 @@ struct SDict {
 
 struct SdArgs {
     const void* offs;              // Arrow offsets (int32 / int64), element `first` belongs to row 0
+    const int32_t* lens;           // SPANS (null for Arrow offsets): row r is the lens[r] bytes at offs[r] (int64) -- fields of a CSV block in place
     int wide;
     int64_t first;
     const uint8_t* valid;          // bitmap, bit `vfirst` belongs to row 0 (or null)
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void sd_encode_kernel(SdArgs a) {
             const int64_t row = tile * SD_TILE + (int64_t)r * 256 + tid;
             if (row >= a.nrows) continue;
             if (a.valid && !((a.valid[(a.vfirst + row) >> 3] >> ((a.vfirst + row) & 7)) & 1)) { a.out[row] = -1; continue; }
-            const int64_t o0 = sd_off(a, row), len = sd_off(a, row + 1) - o0;
+            const int64_t o0 = sd_off(a, row), len = a.lens ? (int64_t)a.lens[row] : sd_off(a, row + 1) - o0;
             const uint8_t* p = a.data + (o0 - a.data_base);
             const uint64_t tagv = sd_hash(p, len);
             uint64_t h = (tagv ^ (tagv >> 29)) & mask;
@@ -394,13 +395,13 @@ void vnm_strdict_destroy(vnm_strdict* h) {
 
 int64_t vnm_strdict_ids(vnm_strdict* h) { return h ? h->ids : 0; }
 
-static int strdict_encode_device_impl(vnm_strdict* h, const vnm_dcol* offsets, const uint8_t* validity, int64_t validity_offset,
+static int strdict_encode_device_impl(vnm_strdict* h, const vnm_dcol* offsets, const int32_t* span_lens, const uint8_t* validity, int64_t validity_offset,
                                       const uint8_t* data, int64_t data_base, int32_t* out_codes, int64_t* n_new, int64_t* new_bytes, void* stream);
 
 int vnm_strdict_encode_device(vnm_strdict* h, const vnm_dcol* offsets, const uint8_t* validity, int64_t validity_offset,
                               const uint8_t* data, int64_t data_base, int32_t* out_codes, int64_t* n_new, int64_t* new_bytes, void* stream) {
     if (h && h->failed) return set_error("vnm_strdict: an earlier encode failed half-way; the dictionary cannot be used any more (create a new one)");
-    const int rc = strdict_encode_device_impl(h, offsets, validity, validity_offset, data, data_base, out_codes, n_new, new_bytes, stream);
+    const int rc = strdict_encode_device_impl(h, offsets, nullptr, validity, validity_offset, data, data_base, out_codes, n_new, new_bytes, stream);
     if (rc && h && h->d.slot) {
         (void)hipStreamSynchronize(as_stream(stream));   // (scratch of the failed call goes back to the pool: nothing may still be running on it)
         h->failed = true;
@@ -408,7 +409,30 @@ int vnm_strdict_encode_device(vnm_strdict* h, const vnm_dcol* offsets, const uin
     return rc;
 }
 
-static int strdict_encode_device_impl(vnm_strdict* h, const vnm_dcol* offsets, const uint8_t* validity, int64_t validity_offset,
+// The same over SPANS of one device byte buffer: row r is the lens[r] bytes at data[starts[r]] (no NULLs).  How vnm_csv_parse_block_ex
+// encodes the string columns of a CSV block where they lie in the staged text.
+int vnm_strdict_encode_spans(vnm_strdict* h, const int64_t* starts, const int32_t* lens, int64_t n, const uint8_t* data, int32_t* out_codes,
+                             int64_t* n_new, int64_t* new_bytes, void* stream) {
+    if (h && h->failed) return set_error("vnm_strdict: an earlier encode failed half-way; the dictionary cannot be used any more (create a new one)");
+    if (n > 0 && (!starts || !lens || !data)) return set_error("vnm_strdict_encode_spans: null argument");
+    vnm_dcol offs{};
+    offs.values = (void*)starts; offs.type = VNM_I64; offs.offset = 0; offs.length = n + 1;
+    const int rc = strdict_encode_device_impl(h, &offs, lens, nullptr, 0, data, 0, out_codes, n_new, new_bytes, stream);
+    if (rc && h && h->d.slot) {
+        (void)hipStreamSynchronize(as_stream(stream));
+        h->failed = true;
+    }
+    return rc;
+}
+
+int vnm_strdict_last_new(vnm_strdict* h, int64_t* n_new, int64_t* new_bytes) {
+    if (!h) return set_error("vnm_strdict_last_new: null handle");
+    if (n_new) *n_new = (int64_t)h->new_ids.size();
+    if (new_bytes) *new_bytes = (int64_t)h->new_bytes.size();
+    return 0;
+}
+
+static int strdict_encode_device_impl(vnm_strdict* h, const vnm_dcol* offsets, const int32_t* span_lens, const uint8_t* validity, int64_t validity_offset,
                                       const uint8_t* data, int64_t data_base, int32_t* out_codes, int64_t* n_new, int64_t* new_bytes, void* stream) {
     VNM_TRY(ensure_init());
     if (!h || !offsets || !out_codes) return set_error("vnm_strdict_encode_device: null argument");
@@ -428,6 +452,7 @@ static int strdict_encode_device_impl(vnm_strdict* h, const vnm_dcol* offsets, c
     PoolScope pool;
     SdArgs a{};
     a.offs = offsets->values; a.wide = offsets->type == VNM_I64; a.first = offsets->offset;
+    a.lens = span_lens;
     a.valid = validity; a.vfirst = validity_offset;
     a.data = data; a.data_base = data_base;
     a.nrows = nrows;

@@ -5,11 +5,16 @@ thin wrappers around pyarrow.csv.open_csv / read_csv and parse on one CPU core.
 (`vnm_csv_parse_block`: one H2D copy, newline scan, one lane per row, exact decimal -> float64) and yields
 `DeviceRecordBatch`es whose numeric columns were never Arrow arrays in host memory.  The schema (names, which columns are
 int64 / float64) comes from pyarrow's own type inference over the first block, as `pyarrow.csv.open_csv` does it.  Only the
-columns the query needs are parsed.  What the device parser does not handle is handed to pyarrow for that block: non-numeric
-columns (strings, timestamps: dictionary-encoded as usual afterwards), fields outside the exact parser's domain ("nan", > 19
+columns the query needs are parsed.  What the device parser does not handle is handed to pyarrow for that block: columns of
+other types (dictionary-encoded as usual afterwards), fields outside the exact parser's domain ("nan", > 19
 significant digits, a quoted number with an escaped quote ...) -- per column and per block, never silently guessed.  Quoted fields are
 handled on the device since round 4 (delimiters inside quotes do not split a row); only a row that ENDS inside a quote (a newline
 in a value) sends its block to pyarrow.
+
+Round 5: `string`, `date32`, `timestamp[s]` and `timestamp[ns]` columns are parsed on the device as well
+(`vnm_csv_parse_block_ex`): a string column is born as the int32 codes of its running dictionary (the field bytes are hashed where
+they lie in the staged text), dates and timestamps by integer calendar arithmetic.  What is left to pyarrow per column and block:
+booleans, times, zone-aware timestamps, other ISO 8601 spellings, strings with an escaped quote.
 """
 import ctypes
 import io
@@ -43,7 +48,8 @@ class GpuCsvReader:
     """Streaming CSV reader with the protocol FileReaderOperator expects (`read_next_batch`, StopIteration at the end),
     plus `read_next_device_batch()` for the GPU operators.  columns: the column names the query touches (None = all)."""
 
-    def __init__(self, source, columns: Optional[Sequence[str]] = None, block_size: int = 64 << 20):
+    def __init__(self, source, columns: Optional[Sequence[str]] = None, block_size: int = 64 << 20, numeric_only: bool = False):
+        self._numeric_only = bool(numeric_only)     # True: the round-4 split (strings, dates, timestamps through pyarrow) -- for comparisons
         self._f = open(source, "rb", buffering=0) if isinstance(source, (str, bytes)) else source
         self._block = int(block_size)
         # one reusable buffer: [carry from the previous block | freshly read bytes]; blocks are handed to the library as
@@ -127,10 +133,35 @@ class GpuCsvReader:
         finally:
             self._advance()
 
+    def _device_type(self, name: str):
+        """the library's parser for this column's inferred Arrow type, or None (pyarrow parses the column)"""
+        t = self.schema.field(name).type
+        if t == pa.int64():
+            return L.I64
+        if t == pa.float64():
+            return L.F64
+        if self._numeric_only:
+            return None
+        if t == pa.string():
+            return L.CSV_STRING
+        if t == pa.date32():
+            return L.CSV_DATE32
+        if t == pa.timestamp("s"):
+            return L.CSV_TIMESTAMP_S
+        if t == pa.timestamp("ns"):
+            return L.CSV_TIMESTAMP_NS
+        return None
+
+    def _dictionary(self, name: str):
+        from .vinum_lib import KeyDictionary
+        if name not in self._dicts:
+            self._dicts[name] = KeyDictionary(self.schema.field(name).type)
+        return self._dicts[name]
+
     def _parse_block(self, off: int, length: int) -> DeviceRecordBatch:
         lib = L.lib()
         text_ptr = ctypes.addressof((ctypes.c_char * length).from_buffer(self._buf, off))
-        gpu_cols = [n for n in self._want if self.schema.field(n).type in (pa.int64(), pa.float64())]
+        gpu_cols = [n for n in self._want if self._device_type(n) is not None]
         gpu_cols.sort(key=self._names.index)
         cols = {}
         nrows = None
@@ -140,13 +171,24 @@ class GpuCsvReader:
         for c0 in range(0, len(gpu_cols), 16):
             chunk = gpu_cols[c0:c0 + 16]
             k = len(chunk)
+            kinds = [self._device_type(n) for n in chunk]
             fidx = (ctypes.c_int * k)(*[self._names.index(n) for n in chunk])
-            types = (ctypes.c_int * k)(*[L.I64 if self.schema.field(n).type == pa.int64() else L.F64 for n in chunk])
+            types = (ctypes.c_int * k)(*kinds)
+            # a string column is born as the int32 codes of its running dictionary (the one from_arrow() fills on the host route)
+            dicts = (ctypes.c_void_p * k)(*[self._dictionary(n).handle() if t == L.CSV_STRING else None for n, t in zip(chunk, kinds)])
             out = (L.DCol * k)()
             n_rows = ctypes.c_int64(0)
             fb = (ctypes.c_int * (k + 2))()
-            L.check(lib.vnm_csv_parse_block(text_ptr, length, 0, ord(","), len(self._names), k, fidx, types, out, ctypes.byref(n_rows), fb, None))
-            owned = [_OwnedColumn(out[i], self.schema.field(n).type) for i, n in enumerate(chunk)]
+            L.check(lib.vnm_csv_parse_block_ex(text_ptr, length, 0, ord(","), len(self._names), k, fidx, types, dicts, out, ctypes.byref(n_rows), fb, None))
+            owned = []
+            for i, (n, t) in enumerate(zip(chunk, kinds)):
+                if t == L.CSV_STRING:
+                    col = _OwnedColumn(out[i], pa.int32())
+                    col.dictionary = self._dictionary(n)
+                    col.dictionary.absorb_new()
+                else:
+                    col = _OwnedColumn(out[i], self.schema.field(n).type)
+                owned.append(col)
             if fb[k] or fb[k + 1]:          # a newline inside a quoted value / ragged or empty rows: the whole block goes through pyarrow (which raises on ragged rows)
                 whole_block_on_host = True
                 break
@@ -181,6 +223,7 @@ class GpuCsvReader:
             pass
 
 
-def stream_csv(input_file, columns: Optional[Sequence[str]] = None, block_size: int = 64 << 20) -> GpuCsvReader:
-    """vinum.stream_csv (vinum/io/arrow.py:9-61) with the numeric columns tokenised and parsed on the device."""
-    return GpuCsvReader(input_file, columns=columns, block_size=block_size)
+def stream_csv(input_file, columns: Optional[Sequence[str]] = None, block_size: int = 64 << 20, numeric_only: bool = False) -> GpuCsvReader:
+    """vinum.stream_csv (vinum/io/arrow.py:9-61) with the int64 / float64 / string / date32 / timestamp columns tokenised and parsed
+    on the device."""
+    return GpuCsvReader(input_file, columns=columns, block_size=block_size, numeric_only=numeric_only)

@@ -432,38 +432,52 @@ class KeyDictionary:
             except Exception:
                 pass
 
+    def handle(self):
+        """the device dictionary (vnm_strdict*) behind a utf8 / binary column, created on first use"""
+        if self._h is None:
+            self._h = L.lib().vnm_strdict_create()
+            if not self._h:
+                raise RuntimeError(L.last_error())
+        return self._h
+
+    def absorb_new(self):
+        """after an encode through this dictionary's handle (vnm_strdict_encode here, vnm_csv_parse_block_ex in io.py): fetch the values
+        it added -- the host copy of the dictionary is the concatenation of these"""
+        import numpy as np
+        lib = L.lib()
+        n_new, new_bytes = ctypes.c_int64(0), ctypes.c_int64(0)
+        L.check(lib.vnm_strdict_last_new(self._h, ctypes.byref(n_new), ctypes.byref(new_bytes)))
+        if not n_new.value:
+            return
+        wide = pa.types.is_large_string(self.type) or pa.types.is_large_binary(self.type)
+        ids = np.empty(n_new.value, np.int32)
+        lens = np.empty(n_new.value, np.int32)
+        data = np.empty(max(new_bytes.value, 1), np.uint8)
+        L.check(lib.vnm_strdict_fetch_new(self._h, ids.ctypes.data, lens.ctypes.data, data.ctypes.data))
+        offs = np.zeros(n_new.value + 1, np.int64 if wide else np.int32)
+        np.cumsum(lens, out=offs[1:])
+        self._chunks.append(pa.Array.from_buffers(self.type, n_new.value, [None, pa.py_buffer(offs), pa.py_buffer(data[:new_bytes.value])]))
+        top = int(lib.vnm_strdict_ids(self._h))
+        if self._pos is None or len(self._pos) < top:
+            grown = np.full(max(top, 2 * (len(self._pos) if self._pos is not None else 0)), -1, np.int64)
+            if self._pos is not None:
+                grown[:len(self._pos)] = self._pos
+            self._pos = grown
+        self._pos[ids] = self._n_values + np.arange(n_new.value, dtype=np.int64)
+        self._n_values += n_new.value
+
     def _encode_device(self, column: pa.Array) -> pa.Array:
         import numpy as np
         lib = L.lib()
-        if self._h is None:
-            self._h = lib.vnm_strdict_create()
-            if not self._h:
-                raise RuntimeError(L.last_error())
         n = len(column)
         wide = pa.types.is_large_string(self.type) or pa.types.is_large_binary(self.type)
         vbuf, obuf, dbuf = column.buffers()
         codes = np.empty(max(n, 1), np.int32)
-        n_new, new_bytes = ctypes.c_int64(0), ctypes.c_int64(0)
-        L.check(lib.vnm_strdict_encode(self._h, obuf.address if obuf is not None else None, 1 if wide else 0,
+        L.check(lib.vnm_strdict_encode(self.handle(), obuf.address if obuf is not None else None, 1 if wide else 0,
                                        dbuf.address if dbuf is not None and dbuf.size else None,
                                        vbuf.address if (vbuf is not None and column.null_count) else None,
-                                       column.offset, n, codes.ctypes.data, ctypes.byref(n_new), ctypes.byref(new_bytes), None))
-        if n_new.value:
-            ids = np.empty(n_new.value, np.int32)
-            lens = np.empty(n_new.value, np.int32)
-            data = np.empty(max(new_bytes.value, 1), np.uint8)
-            L.check(lib.vnm_strdict_fetch_new(self._h, ids.ctypes.data, lens.ctypes.data, data.ctypes.data))
-            offs = np.zeros(n_new.value + 1, np.int64 if wide else np.int32)
-            np.cumsum(lens, out=offs[1:])
-            self._chunks.append(pa.Array.from_buffers(self.type, n_new.value, [None, pa.py_buffer(offs), pa.py_buffer(data[:new_bytes.value])]))
-            top = int(lib.vnm_strdict_ids(self._h))
-            if self._pos is None or len(self._pos) < top:
-                grown = np.full(max(top, 2 * (len(self._pos) if self._pos is not None else 0)), -1, np.int64)
-                if self._pos is not None:
-                    grown[:len(self._pos)] = self._pos
-                self._pos = grown
-            self._pos[ids] = self._n_values + np.arange(n_new.value, dtype=np.int64)
-            self._n_values += n_new.value
+                                       column.offset, n, codes.ctypes.data, None, None, None))
+        self.absorb_new()
         codes = codes[:n]
         mask = (codes < 0) if column.null_count else None
         return pa.array(codes, type=pa.int32(), mask=mask)
