@@ -386,3 +386,66 @@ def test_projection_1e9_rows():
         del ref, got
     del outs, v, a, b
     _free()
+
+
+def test_ordered_min_max_1e9_rows_against_torch():
+    """Round 5: MinMaxFunc's row-order rule (agg_funcs.h:188-201) at full size -- 1e9 rows in four record batches, G = 1e6, a thousand
+    NaNs and a thousand -0.0 among values that hold +0.0 anyway.  MIN = NaN iff the group's first row is NaN, else the smallest
+    number, the EARLIEST of tied zeros; MAX = the largest value after the group's LAST NaN (NaN if that is its last row), the LATEST of
+    tied zeros.  The expectation is built from global row positions with plain torch scatter_reduce; every group is compared bit for
+    bit (the first batch is clean: the operator switches to the ordered side table in the second)."""
+    torch = _torch()
+    from vinum_amd import _lib as L
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    n, groups = N_FULL, 1_000_000
+    k, v = _gen(n, groups)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    idx = torch.randint(n // 4, n, (2000,), device=k.device, generator=gen)
+    v[idx[:1000]] = float("nan")
+    v[idx[1000:]] = -0.0
+    idx2 = torch.randint(0, n, (200_000,), device=k.device, generator=gen)       # make zero the minimum of many groups' rows a tie
+    v[idx2[idx2 >= n // 4]] = 0.0
+    agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.MIN, 1, pa.float64()), (L.MAX, 1, pa.float64()), (L.COUNT_STAR, None, None)])
+    keep = []
+    for b in range(4):
+        lo, hi = b * (n // 4), (b + 1) * (n // 4)
+        kc, vc = DeviceColumn.from_torch(k[lo:hi]), DeviceColumn.from_torch(v[lo:hi])
+        keep.append((kc, vc))
+        agg.next([kc], [vc, vc, None], nrows=hi - lo)
+    ng = agg.finish()
+    cols = agg.result_device()
+    fk = _as_tensor(cols[0].values_ptr, ng)
+    fmin = _as_tensor(cols[1].values_ptr, ng)
+    fmax = _as_tensor(cols[2].values_ptr, ng)
+    fc = _as_tensor(cols[3].values_ptr, ng)
+    assert ng == groups and int(fc.sum()) == n
+    dev = k.device
+    pos = torch.arange(n, device=dev)
+    isn = torch.isnan(v)
+    inf = float("inf")
+    # ---- MIN
+    first = torch.full((groups,), n, dtype=torch.int64, device=dev).scatter_reduce_(0, k, pos, "amin")
+    first_nan = isn[first]
+    rmin = torch.full((groups,), inf, dtype=torch.float64, device=dev).scatter_reduce_(0, k, torch.where(isn, inf, v), "amin")
+    zero = v == 0
+    fz = torch.full((groups,), n, dtype=torch.int64, device=dev).scatter_reduce_(0, k, torch.where(zero, pos, n), "amin")
+    zsel = (rmin == 0) & (fz < n)
+    rmin = torch.where(zsel, v[fz.clamp(max=n - 1)], rmin)              # the earliest zero, with its sign
+    rmin = torch.where(first_nan, float("nan"), rmin)
+    assert bool(torch.equal(rmin.view(torch.int64)[fk], fmin)), "min(v) differs from the row-order rule for some group"
+    del first, first_nan, rmin, fz, zsel
+    # ---- MAX
+    lastnan = torch.full((groups,), -1, dtype=torch.int64, device=dev).scatter_reduce_(0, k, torch.where(isn, pos, -1), "amax")
+    after = pos > lastnan[k]
+    rmax = torch.full((groups,), -inf, dtype=torch.float64, device=dev).scatter_reduce_(0, k, torch.where(after, v, -inf), "amax")
+    lz = torch.full((groups,), -1, dtype=torch.int64, device=dev).scatter_reduce_(0, k, torch.where(after & zero, pos, -1), "amax")
+    zsel = (rmax == 0) & (lz >= 0)
+    rmax = torch.where(zsel, v[lz.clamp(min=0)], rmax)                 # the latest zero, with its sign
+    rmax = torch.where(rmax == -inf, float("nan"), rmax)               # nothing after the last NaN: it was the group's last row
+    assert bool(torch.equal(rmax.view(torch.int64)[fk], fmax)), "max(v) differs from the row-order rule for some group"
+    assert int(torch.isnan(rmax).sum()) + int(isn.sum()) > 0
+    agg.close()
+    del k, v, pos, isn, after, rmax, lz, zero, lastnan
+    _free()

@@ -588,3 +588,53 @@ def test_predicates_on_dictionary_coded_columns_through_the_planner():
     exp = t.filter(nn(pc.greater_equal(col, "M"), False)).group_by(["city"], use_threads=False).aggregate([([], "count_all")]).sort_by([("city", "descending")])
     assert got.column("city").to_pylist() == exp.column("city").to_pylist()
     assert got.column("n").to_pylist() == exp.column("count_all").to_pylist()
+
+
+# ---- COUNT(*) alone over many groups: one scatter level + one-byte counters (dcount8_final_kernel) ---------------------
+def _route_counts():
+    import ctypes
+    from vinum_amd import _lib as L
+    lib = L.lib()
+    need = lib.vnm_route_counts(None, 0)
+    buf = ctypes.create_string_buffer(int(need) + 16)
+    lib.vnm_route_counts(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        k, _, v = line.rpartition("=")
+        out[k] = int(v)
+    return out
+
+
+@pytest.mark.parametrize("span_bits", [23, 24, 26, 27])
+@pytest.mark.parametrize("variant", ["plain", "where", "two_batches", "overflow"])
+def test_count_star_over_many_groups_counts_in_bytes(span_bits, variant):
+    """`SELECT k, count(*) [WHERE w > x] GROUP BY k` over 2^23 .. 2^27 key codes: ONE scatter level, then one-byte counters over
+    sub-ranges of at most 2^17 codes (a 2^18-code partition is read once per half).  Counts equal to numpy's; a key with 300 rows in
+    one batch overflows its byte -- the lane that sees 255 fails the attempt, the two scatter levels take the batch (and the operator's
+    later batches), the counts are still exact.  CountStarFunc: agg_funcs.h:97-127."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(span_bits * 7 + len(variant))
+    n = 20_000_000
+    span = int(0.74 * (1 << span_bits))          # (the sampled range is padded: this lands in 2^span_bits codes)
+    k = rng.integers(0, span, n).astype(np.int64) + 1_000_003
+    if variant == "overflow":
+        k[rng.integers(0, n, 300)] = k[17]
+    w = rng.integers(0, 1000, n).astype(np.float64)
+    t = pa.table({"k": pa.array(k), "w": pa.array(w)})
+    funcs = [(O.COUNT_STAR, "", "n")]
+    pred = ("w", ">", 250.0) if variant == "where" else None
+    bl = util.sliced_batches(t, n if variant != "two_batches" else n // 2)
+    before = _route_counts()
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, bl, predicate=pred)
+    after = _route_counts()
+    took = after.get("dense:count_bytes", 0) - before.get("dense:count_bytes", 0)
+    assert took >= 1, {r: after[r] - before.get(r, 0) for r in after if after[r] != before.get(r, 0)}
+    if variant == "overflow":
+        assert took == 1 and after.get("dense:generic", 0) > before.get("dense:generic", 0)     # failed once, the two levels took the batch
+    keep = k[w > 250.0] if pred else k
+    uk, uc = np.unique(keep, return_counts=True)
+    gk = got.column("k").to_numpy()
+    order = np.argsort(gk, kind="stable")
+    assert got.num_rows == len(uk)
+    assert (gk[order] == uk).all()
+    assert (got.column("n").to_numpy().astype(np.int64)[order] == uc).all()
