@@ -1062,7 +1062,8 @@ def main():
     traffic_src = None
     # HBM bytes per step from the PMC passes of the SAME command (tools/profile.sh -> profiles/rNN_rocprofv3_pmc_*.txt),
     # newest round first; hinted and hint-less runs take different paths, so they have different entries
-    key = f"{args.workload}_N{n:.0e}_G{groups:.0e}_s{args.selectivity}" + ("_hint" if args.hint else "")
+    key = (f"{args.workload}_N{n:.0e}_G{groups:.0e}_s{args.selectivity}" + (f"_{args.shape}" if args.shape != "hot" else "")
+           + ("_hint" if args.hint else ""))      # (the keys tools/traffic_from_pmc.py writes: other shapes run other kernels)
     for tf in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", tf)) as f:

@@ -2,6 +2,7 @@
 # Regenerates the rocprofv3 summaries kept under profiles/ (run on the GPU box: gpurun -- 'bash tools/profile.sh r01').
 # Kernel trace and each PMC counter are collected in SEPARATE runs (MI355X_MICROARCH.md, HBM section).
 R=${1:-r05}
+ONLY=${2:-}     # optional: only the workloads whose argument string contains this (e.g. 'count_star')
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
@@ -18,16 +19,19 @@ prof() {  # name, rocprof args..., -- bench args
 }
 for wl in "groupby --groups 1e8" "groupby --groups 7" "groupby --groups 1e3" "groupby --groups 1e5" "groupby --groups 1e6" \
           "groupby --groups 1e8 --shape count_star" "groupby --groups 1e8 --shape minmax" "stream --groups 1e6" "stream --groups 7" "filter" "topk" "topk --limit 0" "project"; do
+    [[ -n "$ONLY" && "$wl" != *"$ONLY"* ]] && continue
     tag=$(echo $wl | tr -d ' -' ); 
     prof ks_$tag --kernel-trace -- --workload $wl --steps 5 --warmup 2 > $OUT/${R}_rocprofv3_kernel_stats_$tag.txt
 done
-for wl in "groupby --groups 1e8" "filter" "groupby --groups 1e6" "stream --groups 1e6" "topk --limit 0"; do
+for wl in "groupby --groups 1e8" "filter" "groupby --groups 1e6" "stream --groups 1e6" "topk --limit 0" "groupby --groups 1e8 --shape count_star"; do
+    [[ -n "$ONLY" && "$wl" != *"$ONLY"* ]] && continue
     tag=$(echo $wl | tr -d ' -' )
     { prof pf_$tag --pmc FETCH_SIZE --kernel-trace -- --workload $wl --steps 2 --warmup 1
       prof pw_$tag --pmc WRITE_SIZE --kernel-trace -- --workload $wl --steps 2 --warmup 1; } > $OUT/${R}_rocprofv3_pmc_$tag.txt
 done
 # several input columns (tools/manycol.py N G C): the few-groups scan (agg_hotn_kernel) and the per-column / per-pair dense split
 for mc in "5e8 7 4" "5e8 7 6" "5e8 1e6 3" "5e8 1e8 3"; do
+    [[ -n "$ONLY" && "manycol $mc" != *"$ONLY"* ]] && continue
     tag=manycol_$(echo $mc | tr ' ' '_')
     rm -rf /tmp/rp_$tag
     timeout 600 rocprofv3 --kernel-trace -d /tmp/rp_$tag -- python $ROOT/tools/manycol.py $mc > /tmp/rp_$tag.log 2>&1
