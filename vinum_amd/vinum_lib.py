@@ -597,8 +597,13 @@ class GenericHashAggregate:
             if not _is_numeric(t):
                 self._dicts[c] = KeyDictionary(t)
         # (functions over non-numeric columns -- COUNT, string MIN / MAX -- are the numeric classes' business: _first_batch)
+        # A non-numeric column that is group key AND aggregate input (`SELECT city, min(city), count(city) ... GROUP BY city`,
+        # generic_hash_aggregate.h:10-45 + StringMinMaxFunc agg_funcs.h:219-261 take it): the key travels as dictionary codes under its
+        # own name, the functions read the column itself under a second name
+        self._alias = {f.column_name: "__vnm_in_" + f.column_name for f in self._funcs if f.column_name in self._dicts}
+        funcs = [AggFuncDef(f.func, self._alias.get(f.column_name, f.column_name), f.out_col_name) for f in self._funcs]
         cls = SingleNumericalHashAggregate if len(self._groupby) == 1 else MultiNumericalHashAggregate
-        self._inner = cls(self._groupby, self._agg_cols, self._funcs)
+        self._inner = cls(self._groupby, self._agg_cols, funcs)
 
     def next(self, batch: pa.RecordBatch) -> None:
         # the first batch fixes the schema (and raises what the reference raises); later small batches are encoded together:
@@ -630,8 +635,9 @@ class GenericHashAggregate:
         for i, name in enumerate(batch.schema.names):
             col = batch.column(i)
             if name in self._dicts:
-                if name in fn_inputs:
-                    raise RuntimeError("a non-numeric column cannot be a group key and an aggregate input at once on the GPU path")
+                if name in self._alias:
+                    arrays.append(col)
+                    names.append(self._alias[name])
                 col = self._dicts[name].encode(col)
             elif not _is_numeric(col.type) and name not in fn_inputs:
                 continue                                     # neither a key nor an input: never staged
