@@ -477,7 +477,8 @@ int vnm_csv_parse_block_ex(const char* host_text, int64_t nbytes, int skip_heade
 /* vnm_strdict_encode_device over SPANS of one device buffer: row r = the lens[r] bytes at data[starts[r]] (no NULLs). */
 int vnm_strdict_encode_spans(vnm_strdict* h, const int64_t* starts, const int32_t* lens, int64_t n, const uint8_t* data,
                              int32_t* out_codes, int64_t* n_new, int64_t* new_bytes, void* stream);
-/* how many values (and bytes) the last encode of this handle added: the sizes vnm_strdict_fetch_new fills */
+/* how many values (and bytes) the last encode of this handle added and vnm_strdict_fetch_new has not handed over yet: the sizes it
+ * fills (a fetch hands them over ONCE) */
 int vnm_strdict_last_new(vnm_strdict* h, int64_t* n_new, int64_t* new_bytes);
 
 /* device memory helpers for hosts without a GPU allocator of their own (ctypes / cgo bindings).

@@ -354,7 +354,12 @@ def test_string_and_time_fields_the_device_declines_go_to_pyarrow(tmp_path):
         f.write(data)
     exp = pacsv.read_csv(io.BytesIO(data), read_options=pacsv.ReadOptions(use_threads=False))
     assert exp.schema.field("ts").type == pa.timestamp("s") and exp.schema.field("day").type == pa.date32()
-    _same_table(_read_all(stream_csv(path, block_size=1 << 16)), exp)
+    reader = stream_csv(path, block_size=1 << 16)
+    _same_table(_read_all(reader), exp)
+    # the blocks whose string column went to pyarrow were encoded by the SAME dictionary, and no value entered its host copy twice
+    # (a block that is not encoded on the device must not hand the previous block's new values over again)
+    vals = pa.concat_arrays(reader._dicts["city"]._chunks).to_pylist()       # (the values as the encodes handed them over, in order)
+    assert len(vals) == len(set(vals)) == len(set(exp.column("city").to_pylist()))
 
 
 def test_calendar_arithmetic_against_numpy():

@@ -576,6 +576,7 @@ int vnm_strdict_fetch_new(vnm_strdict* h, int32_t* ids_host, int32_t* lens_host,
         memcpy(lens_host, h->new_lens.data(), h->new_lens.size() * 4);
     }
     if (!h->new_bytes.empty()) memcpy(bytes_host, h->new_bytes.data(), h->new_bytes.size());
+    h->new_ids.clear(); h->new_lens.clear(); h->new_bytes.clear();   // (handed over once: a second fetch without an encode in between brings nothing)
     return 0;
 }
 

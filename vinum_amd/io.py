@@ -185,7 +185,8 @@ class GpuCsvReader:
                 if t == L.CSV_STRING:
                     col = _OwnedColumn(out[i], pa.int32())
                     col.dictionary = self._dictionary(n)
-                    col.dictionary.absorb_new()
+                    if not (fb[k] or fb[k + 1] or fb[i]):      # (the column was encoded in this call: its new values join the host copy)
+                        col.dictionary.absorb_new()
                 else:
                     col = _OwnedColumn(out[i], self.schema.field(n).type)
                 owned.append(col)
