@@ -471,6 +471,11 @@ int vnm_csv_parse_block(const char* host_text, int64_t nbytes, int skip_header, 
 #define VNM_CSV_DATE32 201
 #define VNM_CSV_TIMESTAMP_S 202
 #define VNM_CSV_TIMESTAMP_NS 203
+/*   VNM_CSV_BOOL          true / True / TRUE / 1 and false / False / FALSE / 0 (pyarrow's true_values / false_values) -> int32 1 / 0: the
+ *                         codes of a dictionary [false, true] (booleans travel dictionary-coded like every non-numeric column)
+ *   VNM_CSV_TIME32_S      hh:mm | hh:mm:ss (hh < 24) -> int32 seconds since midnight */
+#define VNM_CSV_BOOL 204
+#define VNM_CSV_TIME32_S 205
 int vnm_csv_parse_block_ex(const char* host_text, int64_t nbytes, int skip_header, int delimiter, int n_fields, int n_cols,
                            const int* field_idx, const int* types, vnm_strdict* const* dicts, vnm_dcol* out_cols, int64_t* n_rows,
                            int* fallback, void* stream);

@@ -30,7 +30,7 @@ class ExprIns(ctypes.Structure):
 
 # enums (include/vinum_hip.h)
 I8, I16, I32, I64, U8, U16, U32, U64, F32, F64 = range(10)
-CSV_STRING, CSV_DATE32, CSV_TIMESTAMP_S, CSV_TIMESTAMP_NS = 200, 201, 202, 203   # vnm_csv_parse_block_ex column kinds
+CSV_STRING, CSV_DATE32, CSV_TIMESTAMP_S, CSV_TIMESTAMP_NS, CSV_BOOL, CSV_TIME32_S = 200, 201, 202, 203, 204, 205   # vnm_csv_parse_block_ex column kinds
 COUNT_STAR, COUNT, MIN, MAX, SUM, AVG = range(6)
 ONE_GROUP, SINGLE_NUMERICAL, MULTI_NUMERICAL = range(3)
 ASC, DESC = 0, 1

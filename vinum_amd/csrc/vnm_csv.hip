@@ -53,6 +53,8 @@ struct CsvArgs {
     int64_t nrows;
 };
 
+__host__ __device__ inline bool csv_is32(int type) { return type == VNM_CSV_DATE32 || type == VNM_CSV_BOOL || type == VNM_CSV_TIME32_S; }   // four bytes per row
+
 __global__ __launch_bounds__(256) void csv_count_kernel(CsvArgs a) {
     const int64_t base = (int64_t)blockIdx.x * CSV_SLAB;   // slabs are aligned in the buffer (16-byte loads); bytes before `first` are skipped
     uint32_t c = 0;
@@ -327,6 +329,23 @@ __device__ __noinline__ int csv_parse_time_field(const uint8_t* p, int len, int 
     return 0;
 }
 
+// a boolean field, pyarrow's spellings (ConvertOptions.true_values / false_values defaults) and nothing else; a time of day hh:mm[:ss]
+__device__ __noinline__ int csv_parse_small_field(const uint8_t* p, int len, int type, uint64_t* bits) {
+    if (len == 0) return 1;
+    if (type == VNM_CSV_TIME32_S) {
+        int hh, mi, ss = 0;
+        if ((len != 5 && len != 8) || !csv_two(p, &hh) || p[2] != ':' || !csv_two(p + 3, &mi)) return 2;
+        if (len == 8 && (p[5] != ':' || !csv_two(p + 6, &ss))) return 2;
+        if (hh > 23 || mi > 59 || ss > 59) return 2;
+        *bits = (uint64_t)(hh * 3600 + mi * 60 + ss);
+        return 0;
+    }
+    auto is = [&](const char* w, int n) { if (len != n) return false; for (int i = 0; i < n; i++) if (p[i] != (uint8_t)w[i]) return false; return true; };
+    if (is("1", 1) || is("true", 4) || is("True", 4) || is("TRUE", 4)) { *bits = 1; return 0; }
+    if (is("0", 1) || is("false", 5) || is("False", 5) || is("FALSE", 5)) { *bits = 0; return 0; }
+    return 2;
+}
+
 // well-formed UTF-8 (shortest forms, no surrogates, <= U+10FFFF): what pyarrow's check_utf8 demands of a string column
 __device__ __noinline__ bool csv_utf8_ok(const uint8_t* p, int len) {
     int i = 0;
@@ -392,9 +411,10 @@ __global__ __launch_bounds__(256) void csv_parse_kernel(CsvArgs a) {
                         bits = (uint64_t)(lo + (f - p));
                         a.span_len[c][r] = rc == 0 ? flen : 0;
                     } else if (type == VNM_I64 || type == VNM_F64) rc = csv_parse_field(f, flen, type, &bits);   // (quoted "" -> NULL, as pyarrow's quoted_strings_can_be_null)
+                    else if (type == VNM_CSV_BOOL || type == VNM_CSV_TIME32_S) rc = csv_parse_small_field(f, flen, type, &bits);
                     else rc = csv_parse_time_field(f, flen, type, &bits);
                     if (rc == 2) a.flags[1 + c] = 1;
-                    if (type == VNM_CSV_DATE32) ((int32_t*)a.out_values[c])[r] = (int32_t)bits;
+                    if (csv_is32(type)) ((int32_t*)a.out_values[c])[r] = (int32_t)bits;
                     else ((uint64_t*)a.out_values[c])[r] = bits;
                     a.out_valid[c][r] = rc == 0;
                     c++;
@@ -409,7 +429,7 @@ __global__ __launch_bounds__(256) void csv_parse_kernel(CsvArgs a) {
         // it is flagged the same way even in a one-column file, so that the block takes pyarrow's row count.
         if (field != a.n_fields || len == 0) a.flags[20] = 1;
         for (; c < a.n_cols; c++) {
-            if (a.type_of[c] == VNM_CSV_DATE32) ((int32_t*)a.out_values[c])[r] = 0; else ((uint64_t*)a.out_values[c])[r] = 0;
+            if (csv_is32(a.type_of[c])) ((int32_t*)a.out_values[c])[r] = 0; else ((uint64_t*)a.out_values[c])[r] = 0;
             if (a.span_len[c]) a.span_len[c][r] = 0;
             a.out_valid[c][r] = 0;
         }
@@ -440,7 +460,7 @@ int vnm_csv_parse_block_ex(const char* host_text, int64_t nbytes, int skip_heade
     if (nbytes >= (1LL << 31)) return set_error("vnm_csv_parse_block: blocks must be < 2 GiB");
     for (int c = 0; c < n_cols; c++) {
         const int t = types[c];
-        if (t != VNM_I64 && t != VNM_F64 && t != VNM_CSV_STRING && t != VNM_CSV_DATE32 && t != VNM_CSV_TIMESTAMP_S && t != VNM_CSV_TIMESTAMP_NS)
+        if (t != VNM_I64 && t != VNM_F64 && (t < VNM_CSV_STRING || t > VNM_CSV_TIME32_S))
             return set_error("vnm_csv_parse_block: column %d: int64 / float64 / VNM_CSV_* only", c);
         if (t == VNM_CSV_STRING && (!dicts || !dicts[c])) return set_error("vnm_csv_parse_block: column %d: a string column needs its dictionary", c);
         if (c && field_idx[c] <= field_idx[c - 1]) return set_error("vnm_csv_parse_block: field indices must ascend");
@@ -503,7 +523,7 @@ int vnm_csv_parse_block_ex(const char* host_text, int64_t nbytes, int skip_heade
                 out_cols[c].values = pool_alloc((size_t)a.nrows * 4);
                 if (!a.span_len[c] || !out_cols[c].values) return 1;
             } else
-                out_cols[c].values = a.out_values[c] = pool_alloc((size_t)a.nrows * (types[c] == VNM_CSV_DATE32 ? 4 : 8));      // (owned by out_cols from here: Cleanup)
+                out_cols[c].values = a.out_values[c] = pool_alloc((size_t)a.nrows * (csv_is32(types[c]) ? 4 : 8));      // (owned by out_cols from here: Cleanup)
             a.out_valid[c] = (uint8_t*)pool.take((size_t)a.nrows);
             if (!a.out_values[c] || !a.out_valid[c]) return 1;
         }
@@ -517,7 +537,7 @@ int vnm_csv_parse_block_ex(const char* host_text, int64_t nbytes, int skip_heade
         // Arrow validity bitmaps
         for (int c = 0; c < n_cols; c++) {
             out_cols[c].length = a.nrows;
-            out_cols[c].type = types[c] == VNM_CSV_STRING || types[c] == VNM_CSV_DATE32 ? VNM_I32 : (types[c] == VNM_F64 ? VNM_F64 : VNM_I64);
+            out_cols[c].type = types[c] == VNM_CSV_STRING || csv_is32(types[c]) ? VNM_I32 : (types[c] == VNM_F64 ? VNM_F64 : VNM_I64);
             if (types[c] == VNM_CSV_STRING) continue;       // never NULL
             uint8_t* bm = (uint8_t*)pool_alloc((size_t)((a.nrows + 63) / 64) * 8);
             if (!bm) return 1;

@@ -14,7 +14,8 @@ in a value) sends its block to pyarrow.
 Round 5: `string`, `date32`, `timestamp[s]` and `timestamp[ns]` columns are parsed on the device as well
 (`vnm_csv_parse_block_ex`): a string column is born as the int32 codes of its running dictionary (the field bytes are hashed where
 they lie in the staged text), dates and timestamps by integer calendar arithmetic.  What is left to pyarrow per column and block:
-booleans, times, zone-aware timestamps, other ISO 8601 spellings, strings with an escaped quote.
+zone-aware timestamps, other ISO 8601 spellings, strings with an escaped quote (booleans -- as codes of [false, true] -- and
+times of day hh:mm[:ss] are parsed on the device as well).
 """
 import ctypes
 import io
@@ -77,6 +78,10 @@ class GpuCsvReader:
             if c not in self._names:
                 raise ValueError(f'Column "{c}" is not found.')
         self._dicts = {}
+        if not self._numeric_only:
+            for n in self._want:          # (boolean columns: the dictionary [false, true] must exist before any block, whichever parser reads it)
+                if self.schema.field(n).type == pa.bool_():
+                    self._dictionary(n)
 
     # -- block reading: every block handed on ends with a newline ----------------------------------------------------
     def _fill(self):
@@ -150,12 +155,19 @@ class GpuCsvReader:
             return L.CSV_TIMESTAMP_S
         if t == pa.timestamp("ns"):
             return L.CSV_TIMESTAMP_NS
+        if t == pa.bool_():
+            return L.CSV_BOOL
+        if t == pa.time32("s"):
+            return L.CSV_TIME32_S
         return None
 
     def _dictionary(self, name: str):
         from .vinum_lib import KeyDictionary
         if name not in self._dicts:
-            self._dicts[name] = KeyDictionary(self.schema.field(name).type)
+            t = self.schema.field(name).type
+            self._dicts[name] = KeyDictionary(t)
+            if t == pa.bool_():      # the device parser writes 0 / 1: the codes of [false, true], whatever value a file shows first
+                self._dicts[name].values = pa.array([False, True])
         return self._dicts[name]
 
     def _parse_block(self, off: int, length: int) -> DeviceRecordBatch:
@@ -187,6 +199,9 @@ class GpuCsvReader:
                     col.dictionary = self._dictionary(n)
                     if not (fb[k] or fb[k + 1] or fb[i]):      # (the column was encoded in this call: its new values join the host copy)
                         col.dictionary.absorb_new()
+                elif t == L.CSV_BOOL:
+                    col = _OwnedColumn(out[i], pa.int32())
+                    col.dictionary = self._dictionary(n)
                 else:
                     col = _OwnedColumn(out[i], self.schema.field(n).type)
                 owned.append(col)
