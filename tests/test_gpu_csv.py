@@ -532,3 +532,77 @@ def test_boolean_and_time_columns_on_the_device(tmp_path, monkeypatch):
         assert calls, "the padded fields should have gone to pyarrow"
         for name in exp2.schema.names:
             assert got2.column(name).to_pylist() == exp2.column(name).to_pylist(), name
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VNM_FUZZ_SEEDS", "0")) or 32))
+def test_csv_fuzz_vs_pyarrow(seed, tmp_path):
+    """Random CSV files -- columns of every kind the device parses (int64, float64 in many spellings, utf8 with quotes / delimiters /
+    non-ASCII, date32, timestamp[s] / [ns] in every accepted spelling, bool, time32) plus fields only pyarrow understands (NA tokens,
+    blanks, escaped quotes, exponents, signs), random NULL shares and block sizes: the reader's table is pyarrow's, or both raise."""
+    from vinum_amd.io import stream_csv
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(200, 6000))
+    kinds = [str(k) for k in rng.choice(["int", "float", "str", "date", "ts", "tsn", "bool", "time", "mixed"], int(rng.integers(2, 9)))]
+
+    def field(kind, i):
+        if rng.random() < 0.04:
+            return ""
+        odd = rng.random() < 0.01
+        if kind == "int":
+            v = int(rng.integers(-10**12, 10**12))
+            return (f"+{v}" if v > 0 else f" {v}") if odd else str(v)
+        if kind == "float":
+            v = float(rng.normal(0, 1000))
+            if odd:
+                return str(rng.choice(["nan", "NA", "1e5", "-inf", " 2.5", "1_000.5", "0x10"]))
+            return [f"{v:.3f}", f"{v:.0f}", repr(v), f"{v:.2e}", f"{v:.17g}"][int(rng.integers(0, 5))]
+        if kind == "str":
+            w = str(rng.choice(["a", "Berlin", "São Paulo", "x y", "東京", "", "N/A", "1", "true"]))
+            if odd:
+                return '"say ""hi"""'
+            return f'"{w},{i % 7}"' if rng.random() < 0.2 else w
+        if kind == "date":
+            d = str(np.datetime64(int(rng.integers(-40000, 60000)), "D"))
+            return (d.replace("-", "/") if rng.random() < 0.5 else " " + d) if odd else d
+        if kind in ("ts", "tsn"):
+            t = str(np.datetime64(int(rng.integers(-2_000_000_000, 4_000_000_000)), "s"))
+            sp = int(rng.integers(0, 4))
+            out = [t, t.replace("T", " "), t[:16].replace("T", " "), t[:10]][sp]
+            if kind == "tsn" and sp < 2 and rng.random() < 0.7:
+                out += "." + "".join(str(x) for x in rng.integers(0, 10, int(rng.integers(1, 10))))
+            if odd:
+                out = str(rng.choice([t + "Z", t[:13], t + "+01:00", "2021-02-30 00:00:00"]))
+            return out
+        if kind == "bool":
+            return str(rng.choice(["yes", "T", " true"])) if odd else str(rng.choice(["true", "false", "True", "FALSE", "1", "0"]))
+        if kind == "time":
+            s = int(rng.integers(0, 86400))
+            t = f"{s // 3600:02d}:{s // 60 % 60:02d}:{s % 60:02d}"
+            return (t + ".5" if rng.random() < 0.5 else "24:00:00") if odd else (t if rng.random() < 0.8 else t[:5])
+        return str(rng.choice(["12", "x", "2020-01-01", "1.5", "true", ""]))
+
+    rows = [",".join(f"c{j}_{k}" for j, k in enumerate(kinds))]
+    for i in range(n):
+        rows.append(",".join(field(k, i) for k in kinds))
+    data = ("\n".join(rows) + "\n").encode()
+    path = os.path.join(tmp_path, "fuzz.csv")
+    with open(path, "wb") as f:
+        f.write(data)
+    try:
+        exp = pacsv.read_csv(io.BytesIO(data), read_options=pacsv.ReadOptions(use_threads=False))
+    except pa.ArrowInvalid:
+        exp = None
+    block = int(rng.choice([1 << 12, 1 << 14, 1 << 20]))
+    if exp is None:
+        with pytest.raises(pa.ArrowInvalid):
+            _read_all(stream_csv(path, block_size=block))
+        return
+    got = _read_all(stream_csv(path, block_size=block))
+    assert got.schema == exp.schema, (got.schema, exp.schema)
+    assert got.num_rows == exp.num_rows
+    for name in exp.schema.names:
+        a, e = got.column(name).combine_chunks(), exp.column(name).combine_chunks()
+        if pa.types.is_floating(e.type):
+            util.assert_col_equal(a, e, name)
+        else:
+            assert a.to_pylist() == e.to_pylist(), name

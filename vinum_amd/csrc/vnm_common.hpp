@@ -54,7 +54,7 @@ size_t pool_trim();  // releases the cached blocks, returns their bytes
 // Pool blocks owned by a scope: every early return (VNM_HIP / VNM_TRY included) gives them back.  take() = pool_alloc
 // registered with the scope; keep(p) = ownership moves elsewhere (a handle, the caller); done(p) = free it now.
 struct PoolScope {
-    static constexpr int MAX = 24;
+    static constexpr int MAX = 64;     // (vnm_csv_parse_block_ex: up to 16 string columns x 3 scratch blocks + 3; 24 was too few and said nothing)
     void* blocks[MAX];
     int n = 0;
     PoolScope() = default;
@@ -64,7 +64,7 @@ struct PoolScope {
         void* p = pool_alloc(bytes);
         if (p) {
             if (n < MAX) blocks[n++] = p;
-            else { pool_free(p); p = nullptr; }
+            else { pool_free(p); p = nullptr; set_error("internal error: more than %d scratch blocks in one scope", MAX); }
         }
         return p;
     }
