@@ -606,19 +606,24 @@ def _route_counts():
 
 
 @pytest.mark.parametrize("span_bits", [23, 24, 26, 27])
-@pytest.mark.parametrize("variant", ["plain", "where", "two_batches", "overflow"])
+@pytest.mark.parametrize("variant", ["plain", "where", "two_batches", "overflow", "overflow16", "rows200"])
 def test_count_star_over_many_groups_counts_in_bytes(span_bits, variant):
     """`SELECT k, count(*) [WHERE w > x] GROUP BY k` over 2^23 .. 2^27 key codes: ONE scatter level, then one-byte counters over
     sub-ranges of at most 2^17 codes (a 2^18-code partition is read once per half).  Counts equal to numpy's; a key with 300 rows in
-    one batch overflows its byte -- the lane that sees 255 fails the attempt, the two scatter levels take the batch (and the operator's
-    later batches), the counts are still exact.  CountStarFunc: agg_funcs.h:97-127."""
+    one batch overflows its byte -- the lane that sees 255 fails the attempt and the same entries go through two-byte counters; a key
+    with 66 000 rows overflows those too and the two scatter levels take the batch (and the operator's later batches); the counts
+    are exact every time.  CountStarFunc: agg_funcs.h:97-127."""
     from oracle import oracle as O
     rng = np.random.default_rng(span_bits * 7 + len(variant))
     n = 20_000_000
     span = int(0.74 * (1 << span_bits))          # (the sampled range is padded: this lands in 2^span_bits codes)
     k = rng.integers(0, span, n).astype(np.int64) + 1_000_003
-    if variant == "overflow":
+    if variant == "overflow":          # one group of 300 rows: the bytes overflow, the same entries go through two-byte counters
         k[rng.integers(0, n, 300)] = k[17]
+    if variant == "overflow16":        # ... of 66 000 rows (0.33 % of the batch: below what the estimator calls a heavy key): two scatter levels
+        k[rng.integers(0, n, 66_000)] = k[17]
+    if variant == "rows200":           # every 24th code only: ~77 rows per group at 2^23 codes -- two-byte counters from the start (or after
+        k = rng.integers(0, span // 24, n).astype(np.int64) * 24 + 1_000_003      # the bytes overflowed), a handful of rows at 2^27
     w = rng.integers(0, 1000, n).astype(np.float64)
     t = pa.table({"k": pa.array(k), "w": pa.array(w)})
     funcs = [(O.COUNT_STAR, "", "n")]
@@ -629,7 +634,7 @@ def test_count_star_over_many_groups_counts_in_bytes(span_bits, variant):
     after = _route_counts()
     took = after.get("dense:count_bytes", 0) - before.get("dense:count_bytes", 0)
     assert took >= 1, {r: after[r] - before.get(r, 0) for r in after if after[r] != before.get(r, 0)}
-    if variant == "overflow":
+    if variant == "overflow16":
         assert took == 1 and after.get("dense:generic", 0) > before.get("dense:generic", 0)     # failed once, the two levels took the batch
     keep = k[w > 250.0] if pred else k
     uk, uc = np.unique(keep, return_counts=True)

@@ -432,7 +432,8 @@ struct vnm_agg {
     // vnm_agg_result_device_alloc -> the result columns themselves, vnm_agg_dense_table -> the tables for the multi-GPU exchange
     struct DensePending* pending = nullptr;
     double heavy_share = 0.0;   // share of the rows held by heavy keys in the estimator's sample (0: none seen, or never sampled)
-    bool count8_off = false;    // the one-byte counters of COUNT(*)-only programs overflowed once (dcount8_final_kernel): not again
+    bool count8_off = false;    // the counters of COUNT(*)-only programs overflowed once (dcount8_final_kernel): not again
+    int count_cb = 0;           // ... their width once the bytes overflowed: 16
     struct DScanPending* scan_pending = nullptr;   // a stream of small-range batches: their table (see dense_scan_aggregate)
     bool dense_by_bound = false;   // the first batch went dense on the sample's LOWER bound of the group count (no estimate exists)
     bool range_given = false;   // vnm_agg_set_dense_range: the code range is the caller's (agreed by all ranks), not a sample's
