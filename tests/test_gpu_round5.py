@@ -643,3 +643,46 @@ def test_count_star_over_many_groups_counts_in_bytes(span_bits, variant):
     assert got.num_rows == len(uk)
     assert (gk[order] == uk).all()
     assert (got.column("n").to_numpy().astype(np.int64)[order] == uc).all()
+
+
+@pytest.mark.parametrize("outside", [False, True])
+def test_stream_over_a_small_key_range_is_one_launch(outside, monkeypatch):
+    """Stream mode over a few thousand groups in a small key range (the direct-addressed LDS scan): the waiting batches are the segments
+    of ONE launch of dscan_kernel (before: a launch and a table merge per batch -- 59 x 2^24 rows, G = 1000: 6.3 -> 3.3 ms).  `outside`: a
+    later batch brings keys outside the range the first segment was sampled for -- the segmented scan declines before it has added
+    anything, the batches go another way, the sums are still exact.  base_aggregate.cpp:23-45."""
+    from vinum_amd import _lib as L, ops
+    from vinum_amd.device import DeviceColumn
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(77 + outside)
+    sizes = [400_000, 262_144, 300_001, 77, 123_457, 0, 350_000]
+    ks, vs = [], []
+    for i, n in enumerate(sizes):
+        hi = 9000 if (outside and i >= 4) else 3000
+        ks.append(rng.integers(0, hi, n).astype(np.int64) - 11)
+        vs.append(rng.integers(0, 2**14, n).astype(np.float64) / 128.0)
+    before = _route_counts()
+    agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1, pa.float64()), (L.AVG, 1, pa.float64()), (L.COUNT_STAR, None, None)], stream_mode=True)
+    agg.set_predicate(">", 64.0)
+    keep = []
+    for k, v in zip(ks, vs):
+        kc, vc = DeviceColumn.from_arrow(pa.array(k)), DeviceColumn.from_arrow(pa.array(v))
+        keep.append((kc, vc))
+        agg.next([kc], [vc, vc, None], pred=vc, nrows=len(k))
+    res = agg.result_arrays([0], ["k"], ["s", "a", "n"])
+    after = _route_counts()
+    if not outside:
+        assert after.get("stream:segments_of_one_launch", 0) > before.get("stream:segments_of_one_launch", 0)
+        assert after.get("dense_scan:hot", 0) > before.get("dense_scan:hot", 0)
+    k, v = np.concatenate(ks), np.concatenate(vs)
+    m = v > 64.0
+    uk, inv = np.unique(k[m], return_inverse=True)
+    es = np.bincount(inv, weights=v[m])                  # (quantised values: every partial sum is exact)
+    ec = np.bincount(inv)
+    gk = res.column("k").to_numpy()
+    order = np.argsort(gk)
+    assert (gk[order] == uk).all()
+    assert (res.column("s").to_numpy()[order] == es).all()
+    assert (res.column("n").to_numpy().astype(np.int64)[order] == ec).all()
+    assert (res.column("a").to_numpy()[order] == es / ec).all()
+    agg.close()

@@ -1427,7 +1427,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
             VNM_TRY(plan_dense(h, keys[0], est_rows, s));
         }
         if (h->dense_state == 2) {
-            VNM_SEG_ONLY("small-range LDS scan");
+            if (h->kn_valid || (h->segs_active && (dense_generic || a.has_expr))) VNM_SEG_ONLY("small-range LDS scan");   // (the hot program's scan takes segments)
             if (h->pending) VNM_TRY(complete_pending(h, s));   // (this path makes a run of its own)
             if (h->have_run) VNM_TRY(merge_run_into_table(h, s));
             if (dense_generic && h->scan_pending) VNM_TRY(flush_scan_pending(h, s));
