@@ -686,3 +686,48 @@ def test_stream_over_a_small_key_range_is_one_launch(outside, monkeypatch):
     assert (res.column("n").to_numpy().astype(np.int64)[order] == ec).all()
     assert (res.column("a").to_numpy()[order] == es / ec).all()
     agg.close()
+
+
+@pytest.mark.parametrize("ktype", ["int8", "int16", "int32", "uint8", "uint16", "uint32"])
+@pytest.mark.parametrize("mode", ["sync", "stream", "stream_three_columns"])
+def test_narrow_integer_keys_are_widened_on_arrival(ktype, mode, monkeypatch):
+    """A single narrow integer key column is widened to 64 bits when a batch arrives (widen_key_kernel) and takes the int64 / uint64 paths;
+    the key column of the result keeps its type, negative keys and NULL keys included; in stream mode the widened buffers must outlive
+    the call (they are released by sequence number once no recorded batch needs them).  Key words: array_iterators.h:215-217."""
+    from oracle import oracle as O
+    from vinum_amd import _lib as L, ops
+    from vinum_amd.device import DeviceColumn
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(len(ktype) * 31 + len(mode))
+    np_t = np.dtype(ktype)
+    info = np.iinfo(np_t)
+    span = min(int(info.max) - int(info.min), 60_000)
+    lo = int(info.min) if info.min < 0 else 0
+    sizes = [300_000, 131_072, 77, 250_001, 0, 199_999]
+    batches = []
+    for i, n in enumerate(sizes):
+        k = (rng.integers(0, span + 1, n) + lo).astype(np_t)
+        mask = (rng.random(n) < 0.03) if i in (2, 3) else None           # NULL keys in some batches (odd sizes: odd validity offsets after slicing)
+        cols = {"k": pa.array(k, mask=mask), "a": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0),
+                "b": pa.array(rng.integers(-2**13, 2**13, n).astype(np.float64) / 64.0), "c": pa.array(rng.integers(0, 2**10, n).astype(np.float64) / 8.0)}
+        batches.append(pa.RecordBatch.from_pydict(cols))
+    if mode == "stream_three_columns":
+        funcs = [(O.SUM, "a", "sa"), (O.AVG, "b", "ab"), (O.SUM, "c", "sc"), (O.COUNT_STAR, "", "n")]
+    else:
+        funcs = [(O.SUM, "a", "sa"), (O.AVG, "a", "aa"), (O.COUNT_STAR, "", "n")]
+    names = batches[0].schema.names
+    fspec = [(f, names.index(col) if col else None, pa.float64() if col else None) for f, col, _ in funcs]
+    agg = ops.DeviceAggregate(O.SINGLE, [pa.from_numpy_dtype(np_t)], fspec, stream_mode=mode != "sync")
+    agg.set_predicate(">", 30.0)
+    keep = []
+    for b in batches:
+        cols = {n: DeviceColumn.from_arrow(b.column(i)) for i, n in enumerate(names)}
+        keep.append(cols)
+        agg.next([cols["k"]], [cols[col] if col else None for _, col, _ in funcs], pred=cols["a"], nrows=b.num_rows)
+    got = agg.result_arrays([0], ["k"], [o for _, _, o in funcs])
+    assert got.schema.field("k").type == pa.from_numpy_dtype(np_t)
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in batches:
+        o.next(O.filter_batch(b, O.cmp_mask(b.column(1), O.GT, 30.0)))
+    util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"{ktype} {mode}")
+    agg.close()

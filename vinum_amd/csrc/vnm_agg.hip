@@ -432,6 +432,12 @@ struct vnm_agg {
     // vnm_agg_result_device_alloc -> the result columns themselves, vnm_agg_dense_table -> the tables for the multi-GPU exchange
     struct DensePending* pending = nullptr;
     double heavy_share = 0.0;   // share of the rows held by heavy keys in the estimator's sample (0: none seen, or never sampled)
+    // A single narrow integer key (int8 .. uint32) is WIDENED to int64 / uint64 on arrival (round 5): every specialised path reads plain
+    // 8-byte keys, and such keys took the interpreted scan and the generic entries at 1.5-2.9 x the time for fewer bytes.  The plan then
+    // says int64 / uint64 (the key WORD of a narrow key is its sign- / zero-extended value anyway: array_iterators.h:215-217), the result
+    // columns keep the type the caller declared.  The widened buffers live until no recorded batch needs them (sequence numbers).
+    int key_out_type = -1;
+    std::vector<std::pair<int64_t, void*>> widened;
     bool count8_off = false;    // the counters of COUNT(*)-only programs overflowed once (dcount8_final_kernel): not again
     int count_cb = 0;           // ... their width once the bytes overflowed: 16
     struct DScanPending* scan_pending = nullptr;   // a stream of small-range batches: their table (see dense_scan_aggregate)
@@ -859,9 +865,76 @@ extern "C" {
 
 vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
                         const int* in_types, const int* in_flags, const int* in_col_ids) {
-    vnm_agg* h = agg_create(kind, n_keys, key_types, n_funcs, funcs, in_types, in_flags, in_col_ids);
+    int wide_type = -1;
+    if (kind == VNM_SINGLE_NUMERICAL && n_keys == 1 && key_types && getenv("VNM_AGG_NO_WIDEN_KEYS") == nullptr) {
+        const int t = key_types[0];
+        if (t == VNM_I8 || t == VNM_I16 || t == VNM_I32) wide_type = VNM_I64;
+        else if (t == VNM_U8 || t == VNM_U16 || t == VNM_U32) wide_type = VNM_U64;
+    }
+    vnm_agg* h = agg_create(kind, n_keys, wide_type >= 0 ? &wide_type : key_types, n_funcs, funcs, in_types, in_flags, in_col_ids);
+    if (h && wide_type >= 0) h->key_out_type = key_types[0];
     if (h) exact_attach(h);
     return h;
+}
+
+namespace vnm {
+// narrow integer key values -> 64-bit words, sign- or zero-extended; dst[i] belongs to row i (src index first + i)
+__global__ __launch_bounds__(256) void widen_key_kernel(const void* src, int type, int64_t first, int64_t n, uint64_t* dst) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const int64_t k = first + i;
+        uint64_t v;
+        switch (type) {
+            case VNM_I8: v = (uint64_t)(int64_t)((const int8_t*)src)[k]; break;
+            case VNM_I16: v = (uint64_t)(int64_t)((const int16_t*)src)[k]; break;
+            case VNM_I32: v = (uint64_t)(int64_t)((const int32_t*)src)[k]; break;
+            case VNM_U8: v = ((const uint8_t*)src)[k]; break;
+            case VNM_U16: v = ((const uint16_t*)src)[k]; break;
+            default: v = ((const uint32_t*)src)[k]; break;
+        }
+        dst[i] = v;
+    }
+}
+}  // namespace vnm
+
+// the key column of this call as the operator's kernels want it: *keys stays, or becomes `wide` (values in a pool block the handle keeps
+// until no recorded batch needs it)
+static int widen_key(vnm_agg* h, int64_t nrows, const vnm_dcol** keys, vnm_dcol* wide, hipStream_t s) {
+    if (h->key_out_type < 0 || !*keys) return 0;
+    const vnm_dcol& k = (*keys)[0];
+    if (k.type != h->key_out_type) return set_error("vnm_agg_next_device: key 0 changed type between batches");
+    *wide = k;
+    wide->type = h->plan.key_types[0];
+    if (nrows > 0) {
+        // the validity bitmap keeps its bit offset modulo 8 (the column's offset addresses values and validity alike)
+        const int64_t off = k.validity ? (k.offset & 7) : 0;
+        uint64_t* buf = (uint64_t*)pool_alloc((size_t)(off + nrows) * 8);
+        if (!buf) return 1;
+        h->widened.push_back({h->cur_seq, buf});
+        if (off) VNM_HIP(hipMemsetAsync(buf, 0, (size_t)off * 8, s));
+        const int grid = (int)std::min<int64_t>((nrows + 255) / 256, (int64_t)device_info().num_cus * 16);
+        widen_key_kernel<<<grid, 256, 0, s>>>(k.values, k.type, k.offset, nrows, buf + off);
+        VNM_HIP(hipGetLastError());
+        wide->values = buf;
+        wide->validity = k.validity ? k.validity + (k.offset >> 3) : nullptr;
+        wide->offset = off;
+        wide->length = nrows;
+    }
+    *keys = wide;
+    return 0;
+}
+static void waiting_of(const vnm_agg* h, int64_t* batches, int64_t* rows, int64_t* oldest);
+// widened key buffers no recorded batch needs any more go back to the pool (stream-ordered: the kernels that read them were enqueued before)
+static void release_widened(vnm_agg* h) {
+    if (h->widened.empty()) return;
+    int64_t b = 0, r = 0, o = -1;
+    waiting_of(h, &b, &r, &o);
+    size_t keep = 0;
+    for (size_t i = 0; i < h->widened.size(); i++) {
+        if (b > 0 && o >= 0 && h->widened[i].first >= o) h->widened[keep++] = h->widened[i];
+        else pool_free(h->widened[i].second);
+    }
+    h->widened.resize(keep);
 }
 
 void vnm_agg_destroy(vnm_agg* h) {
@@ -876,6 +949,7 @@ void vnm_agg_destroy(vnm_agg* h) {
     drop_run(h);
     delete h->pending;
     delete h->scan_pending;
+    for (auto& w : h->widened) pool_free(w.second);
     delete h;
 }
 
@@ -1759,10 +1833,20 @@ static bool queueable(const vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
     return true;
 }
 
+static int next_device_body(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs, const vnm_dcol* pred, void* stream);
+
 int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs,
                         const vnm_dcol* pred, void* stream) {
     if (!h) return set_error("vnm_agg_next_device: null handle");
     if (!h->child) h->cur_seq = h->seq++;
+    vnm_dcol wide;
+    if (h->key_out_type >= 0) { VNM_TRY(ensure_init()); VNM_TRY(widen_key(h, nrows, &keys, &wide, as_stream(stream))); }
+    const int rc = next_device_body(h, nrows, keys, inputs, pred, stream);
+    if (h->key_out_type >= 0) release_widened(h);
+    return rc;
+}
+
+static int next_device_body(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const vnm_dcol* inputs, const vnm_dcol* pred, void* stream) {
     if (h->ex && inputs && (keys || h->plan.n_keys == 0)) {   // float MIN / MAX: the flag pass, and the ordered mode once the stream is unclean
         bool handled = false;
         VNM_TRY(exact_next(h, nrows, keys, inputs, pred, stream, &handled));
@@ -1806,6 +1890,7 @@ int vnm_agg_sync(vnm_agg* h, void* stream) {
     for (vnm_agg* c : h->parts) VNM_TRY(flush_queue(c, stream));   // (the parts of a split program record their batches themselves)
     if (h->ex && h->ex->post) VNM_TRY(vnm_agg_sync(h->ex->post, stream));
     VNM_HIP(hipStreamSynchronize(as_stream(stream)));
+    release_widened(h);
     return 0;
 }
 
@@ -1983,8 +2068,10 @@ int vnm_agg_merge_row_blocks(vnm_agg* h, int nblocks, int64_t block_rows, const 
 int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream) {
     VNM_TRY(ensure_init());
     if (!h) return set_error("vnm_agg_finish: null handle");
-    if (h->ex && h->ex->switched) return exact_finish(h, n_groups, stream);   // prefix + suffix merged, float MIN / MAX composed in row order
-    return agg_finish_core(h, n_groups, stream);
+    const int rc = h->ex && h->ex->switched ? exact_finish(h, n_groups, stream)   // prefix + suffix merged, float MIN / MAX composed in row order
+                                            : agg_finish_core(h, n_groups, stream);
+    release_widened(h);
+    return rc;
 }
 
 static int agg_finish_core(vnm_agg* h, int64_t* n_groups, void* stream) {
