@@ -157,3 +157,33 @@ def test_filter_launch_schemes(scheme, monkeypatch):
     L.lib().vnm_set_profiling(0)
     # the retry counter: every filter repeated when the look-backs give up at once, none otherwise
     assert retries.value == (3 if scheme == "flat_gives_up" else 0), retries.value
+
+
+@pytest.mark.parametrize("n", [0, 1, 4095, 8192, 8193, 100_003, 1 << 21])
+@pytest.mark.parametrize("kind", ["int64", "timestamp", "int64_with_payload", "int64_nullable"])
+@pytest.mark.parametrize("op", [">", "<=", "==", "!="])
+def test_int64_predicate_hot_path(n, kind, op):
+    """Round 5: an int64 (or timestamp / date64: int64 storage) predicate column without NULLs against an INTEGER literal takes the same
+    register-resident 16-byte-load kernel as float64 (before: the generic per-row path, 2.5 x the time).  Survivors and payload columns
+    equal NumPy's boolean indexing; negative values, the literal at the extremes, a nullable column (generic path) for comparison."""
+    from vinum_amd.device import DeviceColumn
+    from vinum_amd import ops
+    rng = np.random.default_rng(n + len(kind) + len(op))
+    x = rng.integers(-50, 50, n).astype(np.int64) * 1_000_003
+    lit = int(x[n // 2]) if n else 7
+    mask = (rng.random(n) < 0.1) if kind == "int64_nullable" else None
+    t = pa.timestamp("us") if kind == "timestamp" else pa.int64()
+    pred_arr = pa.array(x, mask=mask).cast(t)
+    pay = pa.array(rng.integers(0, 1000, n).astype(np.int32))
+    cols = [DeviceColumn.from_arrow(pred_arr)] + ([DeviceColumn.from_arrow(pay)] if kind == "int64_with_payload" else [])
+    outs, k = ops.filter_cmp(cols[0], op, lit, cols)
+    keep = {">": x > lit, "<=": x <= lit, "==": x == lit, "!=": x != lit}[op]
+    if mask is not None:          # a NULL compares like NaN (the reference hands NumPy NaNs there): only `!=` is true for it
+        keep = (keep | mask) if op == "!=" else (keep & ~mask)
+    assert k == int(keep.sum())
+    got = outs[0].to_arrow().cast(pa.int64())
+    valid = np.ones(k, bool) if mask is None else ~mask[keep]
+    assert got.null_count == int((~valid).sum())
+    assert (got.fill_null(0).to_numpy(zero_copy_only=False)[valid] == x[keep][valid]).all()
+    if kind == "int64_with_payload":
+        assert (outs[1].to_arrow().to_numpy() == pay.to_numpy()[keep]).all()

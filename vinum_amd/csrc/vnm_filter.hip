@@ -173,14 +173,16 @@ __device__ __forceinline__ void filter_tile(const FilterArgs& a, const int64_t t
     const int64_t first = a.phys_base + tile * TILE - a.pred.offset;
     const bool full = first >= 0 && first + TILE <= a.length;
 
-    double v0[CH], v1[CH];
+    // HOT: a float64 predicate column (MODE = CMP_F64) or, round 5, an int64 one against an integer literal (MODE = CMP_I64: timestamps,
+    // ids, counts -- they took the generic per-row path at 2.5 x the time): raw 64-bit values, 16-byte loads, kept in registers
+    uint64_t v0[CH], v1[CH];
     if (HOT) {
-        const double* vals = (const double*)a.pred.values;
+        const uint64_t* vals = (const uint64_t*)a.pred.values;
         if (full) {
-            const double2* src = (const double2*)(vals + pb);
+            const ulonglong2* src = (const ulonglong2*)(vals + pb);
 #pragma unroll
             for (int j = 0; j < CH; j++) {
-                double2 t = src[j * FB];
+                ulonglong2 t = src[j * FB];
                 v0[j] = t.x; v1[j] = t.y;
             }
         } else {
@@ -188,8 +190,8 @@ __device__ __forceinline__ void filter_tile(const FilterArgs& a, const int64_t t
             for (int j = 0; j < CH; j++) {
                 int64_t p0 = pb + (int64_t)j * (2 * FB);
                 int64_t r0 = p0 - a.pred.offset;
-                v0[j] = (r0 >= 0 && r0 < a.length) ? vals[p0] : 0.0;
-                v1[j] = (r0 + 1 >= 0 && r0 + 1 < a.length) ? vals[p0 + 1] : 0.0;
+                v0[j] = (r0 >= 0 && r0 < a.length) ? vals[p0] : 0ULL;
+                v1[j] = (r0 + 1 >= 0 && r0 + 1 < a.length) ? vals[p0 + 1] : 0ULL;
             }
         }
     }
@@ -202,9 +204,12 @@ __device__ __forceinline__ void filter_tile(const FilterArgs& a, const int64_t t
         if (MODE == MODE_MASK) {
             if (in0) f0 = a.mask_valid && !a.mask_valid[r0] ? true : a.mask[r0] != 0;
             if (in1) f1 = a.mask_valid && !a.mask_valid[r1] ? true : a.mask[r1] != 0;
+        } else if (HOT && MODE == CMP_I64) {
+            f0 = in0 && cmp_apply<int64_t>(a.p.op, (int64_t)v0[j], a.p.ival);
+            f1 = in1 && cmp_apply<int64_t>(a.p.op, (int64_t)v1[j], a.p.ival);
         } else if (HOT) {
-            f0 = in0 && cmp_apply<double>(a.p.op, v0[j], a.p.dval);
-            f1 = in1 && cmp_apply<double>(a.p.op, v1[j], a.p.dval);
+            f0 = in0 && cmp_apply<double>(a.p.op, __longlong_as_double((long long)v0[j]), a.p.dval);
+            f1 = in1 && cmp_apply<double>(a.p.op, __longlong_as_double((long long)v1[j]), a.p.dval);
         } else {
             f0 = in0 && pred_eval(a.p, a.pred, r0);
             f1 = in1 && pred_eval(a.p, a.pred, r1);
@@ -270,8 +275,8 @@ __device__ __forceinline__ void filter_tile(const FilterArgs& a, const int64_t t
             for (int j = 0; j < CH; j++) {
                 uint32_t fj = (flags >> (2 * j)) & 3u;
                 uint32_t pos = s_excl[j * NW + wave] + ((rank[j >> 2] >> (8 * (j & 3))) & 0xffu);
-                if (fj & 1u) out[pos++] = (uint64_t)__double_as_longlong(v0[j]);
-                if (fj & 2u) out[pos] = (uint64_t)__double_as_longlong(v1[j]);
+                if (fj & 1u) out[pos++] = v0[j];
+                if (fj & 2u) out[pos] = v1[j];
             }
         }
         if (!PAYLOOP || a.n_payload <= (a.reuse_idx == 0 ? 1 : 0)) return;
@@ -369,8 +374,10 @@ static int env_int(const char* name, int dflt) {
 static int launch_filter(FilterArgs& a, int mode, int64_t* out_count, hipStream_t s) {
     // hot_pred: float64 predicate column without NULLs (16-byte loads, values kept in registers);
     // hot: ... and its survivors are the only output (BASELINE configs[1])
-    const bool hot_pred = mode == CMP_F64 && a.pred.type == VNM_F64 && !a.pred.validity &&
-                          !(a.reuse_idx == 0 && a.out_valid[0]);
+    const bool hot_i64 = mode == CMP_I64 && a.pred.type == VNM_I64 && !a.pred.validity && !(a.reuse_idx == 0 && a.out_valid[0]) &&
+                         env_int("VNM_FILTER_NO_HOT_I64", 0) == 0;
+    const bool hot_pred = (mode == CMP_F64 && a.pred.type == VNM_F64 && !a.pred.validity &&
+                           !(a.reuse_idx == 0 && a.out_valid[0])) || hot_i64;
     const bool hot = hot_pred && (a.n_payload == 0 || (a.n_payload == 1 && a.reuse_idx == 0));
     // hot: 256 threads x 32 rows (8192-row tiles, four workgroups = four tiles in flight per CU: 2.71 ms; 1024 x 8
     // rows, two per CU: 2.94); other shapes: 512 threads x 16 rows
@@ -423,11 +430,16 @@ static int launch_filter(FilterArgs& a, int mode, int64_t* out_count, hipStream_
             //  a filter paid twice -- the first attempt's output positions were garbage and are overwritten here)
             KernelTimer timer(persist && env_int("VNM_FILTER_PERSIST", 0) == 0 ? "filter_retry" : "filter_kernel", s);
             int rc;
-            if (hot) {
+            if (hot && hot_i64) {
+                if (fb == 256) rc = VNM_FL(CMP_I64, 256, 16, true, false, false) 256);
+                else rc = VNM_FL(CMP_I64, 512, 8, true, false, false) 512);
+            } else if (hot) {
                 if (fb == 1024 && (a.debug & 8)) rc = VNM_FL(CMP_F64, 1024, 4, true, true, false) 1024);
                 else if (fb == 1024) rc = VNM_FL(CMP_F64, 1024, 4, true, false, false) 1024);
                 else if (fb == 256) rc = VNM_FL(CMP_F64, 256, 16, true, false, false) 256);
                 else rc = VNM_FL(CMP_F64, 512, 8, true, false, false) 512);
+            } else if (hot_pred && hot_i64) {
+                rc = VNM_FL(CMP_I64, 512, 8, true, false, true) 512);  // int64 predicate, several payload columns
             } else if (hot_pred) {
                 rc = VNM_FL(CMP_F64, 512, 8, true, false, true) 512);  // float64 predicate, several payload columns
             } else if (mode == MODE_MASK) {
