@@ -576,3 +576,51 @@ def test_distributed_sample_sort_simulated(world, desc):
             got.append(rid[perm])
     got = torch.cat(got)
     assert bool(torch.equal(got, ref)), f"world {world} desc {desc}: {int((got != ref).sum())} positions differ"
+
+
+@pytest.mark.parametrize("case", ["f32_normal", "f32_desc_nan_negzero", "i32_few_dups", "u32_desc", "i32_heavy_value", "f32_offset"])
+def test_sample_sort_of_a_four_byte_key_equals_the_lsd_sort(case, monkeypatch):
+    """Round 5: one float32 / int32 / uint32 sort key without NULLs is widened to 8 bytes (float32 -> float64 is exact and order-preserving,
+    NaNs and signed zeros included) and ordered by the sample sort; the row ids must be those of the LSD passes over the original
+    4-byte column (the order is total: key, then row id -- Sort::Sorted is stable, sort.cpp:22-40)."""
+    import ctypes
+    import torch
+    from vinum_amd import _lib as L
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    rng = np.random.default_rng(len(case) * 7)
+    n = 2_000_003
+    order = L.ASC
+    if case == "f32_normal":
+        v = rng.normal(11.0, 3.0, n).astype(np.float32)
+    elif case == "f32_desc_nan_negzero":
+        v = rng.normal(0.0, 1.0, n).astype(np.float32); v[::977] = np.nan; v[5::1201] = -0.0; v[7::1201] = 0.0; order = L.DESC
+    elif case == "i32_few_dups":
+        v = (rng.integers(0, n // 4, n) - n // 8).astype(np.int32)
+    elif case == "u32_desc":
+        v = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32); order = L.DESC
+    elif case == "i32_heavy_value":
+        v = rng.integers(-2**31, 2**31, n).astype(np.int32); v[::9] = 12345
+    else:
+        v = rng.normal(0.0, 5.0, n + 7).astype(np.float32)
+    arr = pa.array(v)
+    if case == "f32_offset":
+        arr = arr.slice(5, n)
+    col = DeviceColumn.from_arrow(arr)
+    monkeypatch.setenv("VNM_SSORT_MIN_ROWS", "1000")
+    monkeypatch.setenv("VNM_SORT_NO_WIDEN", "1")
+    ref_idx = ops.sort_indices([col], [order])
+    ref = torch.as_tensor(_RawI64(ref_idx.ptr, n), device="cuda").clone()
+    monkeypatch.delenv("VNM_SORT_NO_WIDEN")
+    L.lib().vnm_set_profiling(1)
+    got_idx = ops.sort_indices([col], [order])
+    ms, local = ctypes.c_double(0), ctypes.c_int64(0)
+    L.lib().vnm_profile_query(b"sort_local", ctypes.byref(ms), ctypes.byref(local))
+    L.lib().vnm_set_profiling(0)
+    assert local.value >= 1, case                        # the sample sort ran
+    got = torch.as_tensor(_RawI64(got_idx.ptr, n), device="cuda")
+    assert bool(torch.equal(got, ref)), f"{case}: {int((got != ref).sum())} positions differ"
+    # ... and the order is right (against NumPy's stable sort of the same keys; NaN last in both directions)
+    keys = arr.to_numpy()
+    if order == L.ASC and not np.isnan(keys.astype(np.float64)).any():
+        assert (got.cpu().numpy() == np.argsort(keys, kind="stable")).all()
