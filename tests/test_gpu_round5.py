@@ -731,3 +731,53 @@ def test_narrow_integer_keys_are_widened_on_arrival(ktype, mode, monkeypatch):
         o.next(O.filter_batch(b, O.cmp_mask(b.column(1), O.GT, 30.0)))
     util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"{ktype} {mode}")
     agg.close()
+
+
+@pytest.mark.parametrize("mode", ["sync", "stream"])
+@pytest.mark.parametrize("op", [">", ">=", "==", "<"])
+@pytest.mark.parametrize("groups", [7, 3000, 400_000])
+def test_float32_inputs_are_widened_and_the_literal_compares_in_float32(mode, op, groups, monkeypatch):
+    """float32 input columns under SUM / AVG / COUNT are widened to float64 on arrival (SumFunc<float, double> sums in double anyway) and take
+    the float64 kernels.  `WHERE v <op> 0.1` over a float32 column compares in float32 in the reference (NumPy: float32 array against a
+    Python scalar): rows holding float32(0.1) are NOT greater than 0.1 -- the widened values are compared with the literal rounded to
+    float32, which is the same thing.  Expected values from NumPy in float32 / float64 directly."""
+    from vinum_amd import _lib as L, ops
+    from vinum_amd.device import DeviceColumn
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(groups + len(op) + len(mode))
+    sizes = [500_000, 262_144, 77, 300_001]
+    ks, vs = [], []
+    for n in sizes:
+        ks.append(rng.integers(0, groups, n).astype(np.int64))
+        v = (rng.integers(-3, 6, n) * np.float32(0.1)).astype(np.float32)          # many rows hold exactly float32(0.1), float32(0.2) ...
+        v[rng.random(n) < 0.3] = np.float32(0.1)
+        vs.append(v)
+    masks = [rng.random(n) < 0.05 for n in sizes]
+    agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int64()], [(L.SUM, 1, pa.float32()), (L.AVG, 1, pa.float32()), (L.COUNT, 1, pa.float32()), (L.COUNT_STAR, None, None)],
+                              stream_mode=mode == "stream")
+    agg.set_predicate(op, 0.1)
+    keep = []
+    for k, v, m in zip(ks, vs, masks):
+        kc, vc = DeviceColumn.from_arrow(pa.array(k)), DeviceColumn.from_arrow(pa.array(v, mask=m))
+        keep.append((kc, vc))
+        agg.next([kc], [vc, vc, vc, None], pred=vc, nrows=len(k))
+    res = agg.result_arrays([0], ["k"], ["s", "a", "c", "n"])
+    k, v, m = np.concatenate(ks), np.concatenate(vs), np.concatenate(masks)
+    lit = np.float32(0.1)
+    passed = {">": v > lit, ">=": v >= lit, "==": v == lit, "<": v < lit}[op] & ~m        # (a NULL fails the predicate)
+    uk, inv = np.unique(k[passed], return_inverse=True)
+    import math
+    gk = res.column("k").to_numpy()
+    order = np.argsort(gk)
+    assert (gk[order] == uk).all()
+    cnt = np.bincount(inv)
+    assert (res.column("n").to_numpy().astype(np.int64)[order] == cnt).all()
+    assert (res.column("c").to_numpy().astype(np.int64)[order] == cnt).all()
+    sums = res.column("s").to_numpy()[order]
+    vd = v[passed].astype(np.float64)
+    by = np.argsort(inv, kind="stable")
+    bounds = np.concatenate([[0], np.cumsum(cnt)])
+    exact = np.array([math.fsum(vd[by[bounds[i]:bounds[i + 1]]].tolist()) for i in range(min(len(uk), 2000))])
+    assert (util._ulp_diff(sums[:len(exact)], exact) <= 1).all()
+    assert res.schema.field("s").type == pa.float64() and res.schema.field("a").type == pa.float64()
+    agg.close()

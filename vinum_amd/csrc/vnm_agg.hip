@@ -438,6 +438,16 @@ struct vnm_agg {
     // columns keep the type the caller declared.  The widened buffers live until no recorded batch needs them (sequence numbers).
     int key_out_type = -1;
     std::vector<std::pair<int64_t, void*>> widened;
+    // ... and float32 INPUT columns under SUM / AVG / COUNT only (the reference sums float32 in double anyway: SumFunc<float, double>,
+    // AvgFunc<float, double, double>, agg_func_factory.cpp:126-131, 206-211): widened to float64 on arrival, so that `sum(v), avg(v) WHERE v > x`
+    // over a float32 column takes the float64 kernels.  A predicate over such a column compares in float32 in the reference (NumPy:
+    // float32 array against a Python scalar) -- the same as comparing the widened values with the literal ROUNDED to float32.
+    bool widen_in[AGG_MAX_FUNCS] = {};
+    bool any_widen_in = false;
+    bool pred_lit_rounded = false;   // pred_dval holds the literal rounded to float32 (the caller's literal: pred_user_*)
+    int pred_user_is_float = 0;
+    double pred_user_dval = 0.0;
+    int64_t pred_user_ival = 0;
     bool count8_off = false;    // the counters of COUNT(*)-only programs overflowed once (dcount8_final_kernel): not again
     int count_cb = 0;           // ... their width once the bytes overflowed: 16
     struct DScanPending* scan_pending = nullptr;   // a stream of small-range batches: their table (see dense_scan_aggregate)
@@ -871,8 +881,26 @@ vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs,
         if (t == VNM_I8 || t == VNM_I16 || t == VNM_I32) wide_type = VNM_I64;
         else if (t == VNM_U8 || t == VNM_U16 || t == VNM_U32) wide_type = VNM_U64;
     }
-    vnm_agg* h = agg_create(kind, n_keys, wide_type >= 0 ? &wide_type : key_types, n_funcs, funcs, in_types, in_flags, in_col_ids);
+    // float32 input columns whose every function is a SUM / AVG / COUNT: declared float64 to the plan, widened on arrival
+    std::vector<int> types2;
+    bool widen_in[AGG_MAX_FUNCS] = {};
+    bool any_widen = false;
+    if (funcs && in_types && n_funcs > 0 && n_funcs <= AGG_MAX_FUNCS && getenv("VNM_AGG_NO_WIDEN_INPUTS") == nullptr) {
+        types2.assign(in_types, in_types + n_funcs);
+        for (int i = 0; i < n_funcs; i++) {
+            if (in_types[i] != VNM_F32 || funcs[i] == VNM_COUNT_STAR) continue;
+            bool ok = true;      // every function over the same column (same id; without ids: this function alone) must allow it
+            for (int j = 0; j < n_funcs && ok; j++) {
+                const bool same_col = in_col_ids ? (in_col_ids[j] >= 0 && in_col_ids[j] == in_col_ids[i]) : j == i;
+                if (same_col && funcs[j] != VNM_SUM && funcs[j] != VNM_AVG && funcs[j] != VNM_COUNT) ok = false;
+                if (same_col && in_types[j] != VNM_F32) ok = false;
+            }
+            if (ok) { widen_in[i] = true; types2[(size_t)i] = VNM_F64; any_widen = true; }
+        }
+    }
+    vnm_agg* h = agg_create(kind, n_keys, wide_type >= 0 ? &wide_type : key_types, n_funcs, funcs, any_widen ? types2.data() : in_types, in_flags, in_col_ids);
     if (h && wide_type >= 0) h->key_out_type = key_types[0];
+    if (h && any_widen) { memcpy(h->widen_in, widen_in, sizeof(widen_in)); h->any_widen_in = true; }
     if (h) exact_attach(h);
     return h;
 }
@@ -895,7 +923,59 @@ __global__ __launch_bounds__(256) void widen_key_kernel(const void* src, int typ
         dst[i] = v;
     }
 }
+// float32 values -> float64 (exact); dst[i] belongs to row i (src index first + i)
+__global__ __launch_bounds__(256) void widen_f32_kernel(const float* src, int64_t first, int64_t n, double* dst) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = (double)src[first + i];
+}
 }  // namespace vnm
+
+// the float32 input columns of this call that the plan took as float64 (vnm_agg_create): `win` = the inputs with those columns replaced
+// by widened copies (one per distinct column); a predicate column that IS one of them follows, and the literal is rounded to float32 once
+static int widen_inputs(vnm_agg* h, int64_t nrows, const vnm_dcol** inputs, vnm_dcol* win, const vnm_dcol** pred, vnm_dcol* wpred, hipStream_t s) {
+    if (!h->any_widen_in || !*inputs) return 0;
+    const vnm_dcol* in = *inputs;
+    for (int i = 0; i < h->n_funcs; i++) win[i] = in[i];
+    for (int i = 0; i < h->n_funcs; i++) {
+        if (!h->widen_in[i]) continue;
+        if (in[i].type != VNM_F32) return set_error("vnm_agg_next_device: input %d was declared float32, the batch brings type %d", i, in[i].type);
+        int prev = -1;
+        for (int j = 0; j < i && prev < 0; j++)
+            if (h->widen_in[j] && in[j].values == in[i].values && in[j].offset == in[i].offset && in[j].validity == in[i].validity) prev = j;
+        if (prev >= 0) { win[i] = win[prev]; continue; }
+        win[i].type = VNM_F64;
+        if (nrows > 0) {
+            const int64_t off = in[i].validity ? (in[i].offset & 7) : 0;
+            double* buf = (double*)pool_alloc((size_t)(off + nrows) * 8);
+            if (!buf) return 1;
+            h->widened.push_back({h->cur_seq, buf});
+            if (off) VNM_HIP(hipMemsetAsync(buf, 0, (size_t)off * 8, s));
+            const int grid = (int)std::min<int64_t>((nrows + 255) / 256, (int64_t)device_info().num_cus * 16);
+            widen_f32_kernel<<<grid, 256, 0, s>>>((const float*)in[i].values, in[i].offset, nrows, buf + off);
+            VNM_HIP(hipGetLastError());
+            win[i].values = buf;
+            win[i].validity = in[i].validity ? in[i].validity + (in[i].offset >> 3) : nullptr;
+            win[i].offset = off;
+            win[i].length = nrows;
+        }
+    }
+    if (*pred && (*pred)->type == VNM_F32) {
+        for (int i = 0; i < h->n_funcs; i++) {
+            if (!h->widen_in[i] || in[i].values != (*pred)->values || in[i].offset != (*pred)->offset || in[i].validity != (*pred)->validity) continue;
+            *wpred = win[i];
+            *pred = wpred;
+            if (h->pred_set && !h->pred_lit_rounded) {
+                const double lit = h->pred_is_float ? h->pred_dval : (double)h->pred_ival;
+                h->pred_dval = (double)(float)lit;
+                h->pred_is_float = 1;
+                h->pred_lit_rounded = true;
+            }
+            break;
+        }
+    }
+    *inputs = win;
+    return 0;
+}
 
 // the key column of this call as the operator's kernels want it: *keys stays, or becomes `wide` (values in a pool block the handle keeps
 // until no recorded batch needs it)
@@ -956,8 +1036,12 @@ void vnm_agg_destroy(vnm_agg* h) {
 int vnm_agg_set_predicate(vnm_agg* h, int enabled, int op, int scalar_is_float, double dval, int64_t ival) {
     if (!h) return set_error("vnm_agg_set_predicate: null handle");
     if (enabled && (op < VNM_EQ || op > VNM_LE)) return set_error("vnm_agg_set_predicate: bad comparison op %d", op);
-    const bool same = h->pred_set == (enabled != 0) && (!enabled || (h->pred_op == op && h->pred_is_float == scalar_is_float && h->pred_ival == ival &&
-                                                                     memcmp(&h->pred_dval, &dval, 8) == 0));
+    // (a literal that was rounded to float32 for a widened float32 predicate column: the caller's own values are compared)
+    const int cur_is_float = h->pred_lit_rounded ? h->pred_user_is_float : h->pred_is_float;
+    const double cur_dval = h->pred_lit_rounded ? h->pred_user_dval : h->pred_dval;
+    const int64_t cur_ival = h->pred_lit_rounded ? h->pred_user_ival : h->pred_ival;
+    const bool same = h->pred_set == (enabled != 0) && (!enabled || (h->pred_op == op && cur_is_float == scalar_is_float && cur_ival == ival &&
+                                                                     memcmp(&cur_dval, &dval, 8) == 0));
     if (same) return 0;
     // the waiting batches of an asynchronous stream were recorded under the OLD predicate (and without a predicate column when none was set)
     if (!h->q.empty()) return set_error("vnm_agg_set_predicate: batches are waiting (call vnm_agg_sync first)");
@@ -967,6 +1051,8 @@ int vnm_agg_set_predicate(vnm_agg* h, int enabled, int op, int scalar_is_float, 
     h->pred_is_float = scalar_is_float;
     h->pred_dval = dval;
     h->pred_ival = ival;
+    h->pred_lit_rounded = false;
+    h->pred_user_is_float = scalar_is_float; h->pred_user_dval = dval; h->pred_user_ival = ival;
     if (h->ex && h->ex->post) VNM_TRY(vnm_agg_set_predicate(h->ex->post, enabled, op, scalar_is_float, dval, ival));
     return 0;
 }
@@ -1839,10 +1925,12 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
                         const vnm_dcol* pred, void* stream) {
     if (!h) return set_error("vnm_agg_next_device: null handle");
     if (!h->child) h->cur_seq = h->seq++;
-    vnm_dcol wide;
+    vnm_dcol wide, wpred;
+    vnm_dcol win[AGG_MAX_FUNCS];
     if (h->key_out_type >= 0) { VNM_TRY(ensure_init()); VNM_TRY(widen_key(h, nrows, &keys, &wide, as_stream(stream))); }
+    if (h->any_widen_in) { VNM_TRY(ensure_init()); VNM_TRY(widen_inputs(h, nrows, &inputs, win, &pred, &wpred, as_stream(stream))); }
     const int rc = next_device_body(h, nrows, keys, inputs, pred, stream);
-    if (h->key_out_type >= 0) release_widened(h);
+    if (h->key_out_type >= 0 || h->any_widen_in) release_widened(h);
     return rc;
 }
 
@@ -1920,7 +2008,7 @@ int vnm_agg_set_input_expr(vnm_agg* h, int func_idx, int n_ins, const vnm_expr_i
     if (func_idx < 0 || func_idx >= h->n_funcs || h->func_col[func_idx] < 0) return set_error("vnm_agg_set_input_expr: function %d has no input column", func_idx);
     if (h->expr_col >= 0 && h->expr_col != h->func_col[func_idx]) return set_error("vnm_agg_set_input_expr: one expression input per operator (project the others first)");
     if (n_ins < 1 || n_ins > 64 || n_cols < 1 || n_cols > 16) return set_error("vnm_agg_set_input_expr: bad program size");
-    if (h->c_in_types[func_idx] != VNM_F64) return set_error("vnm_agg_set_input_expr: declare the function's input type as float64 (the expression's result type)");
+    if (h->c_in_types[func_idx] != VNM_F64 || h->widen_in[func_idx]) return set_error("vnm_agg_set_input_expr: declare the function's input type as float64 (the expression's result type)");
     h->expr_col = h->func_col[func_idx];
     h->expr_prog.assign(program, program + n_ins);
     h->expr_ncols = n_cols;
