@@ -156,7 +156,11 @@ struct vnm_expr_ins;   /* defined with the projection below */
 
 /* in_col_ids (may be NULL): functions with equal NON-NEGATIVE ids read the same input column (they then share loads
  * and accumulators, e.g. SUM(v) and AVG(v)); a negative id means "a column of its own" (never shared); ignored for
- * COUNT(*). */
+ * COUNT(*).
+ * Narrow columns (round 5): a SINGLE narrow integer key (int8 .. uint32) and float32 input columns whose functions are SUM / AVG / COUNT
+ * only are widened to 64 bits inside vnm_agg_next_device (one extra pass, 12 B/row) and take the int64 / float64 kernels; the caller
+ * declares and passes the columns as they are, result columns keep the declared key type (sums / averages of float32 are float64 in the
+ * reference too: agg_func_factory.cpp:126-131, 206-211), and a predicate over a widened float32 column compares in float32 as NumPy does. */
 vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs, const int* funcs,
                         const int* in_types, const int* in_flags, const int* in_col_ids);
 void vnm_agg_destroy(vnm_agg* h);
