@@ -781,3 +781,41 @@ def test_float32_inputs_are_widened_and_the_literal_compares_in_float32(mode, op
     assert (util._ulp_diff(sums[:len(exact)], exact) <= 1).all()
     assert res.schema.field("s").type == pa.float64() and res.schema.field("a").type == pa.float64()
     agg.close()
+
+
+@pytest.mark.parametrize("groups", [7, 5000, 700_000])
+def test_widened_and_unwidened_paths_agree(groups, monkeypatch):
+    """The same query -- int32 key, float32 value under SUM / AVG / COUNT, `WHERE v >= 0.7` -- with the arrival-time widening on and
+    off (VNM_AGG_NO_WIDEN_KEYS / VNM_AGG_NO_WIDEN_INPUTS: the interpreted scan and generic entries as before round 5): identical groups,
+    counts and -- the values are multiples of 1/8, every partial sum exact -- identical sums and averages, bit for bit."""
+    from vinum_amd import _lib as L, ops
+    from vinum_amd.device import DeviceColumn
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(groups)
+    n = 900_001
+    k = (rng.integers(0, groups, n) - groups // 2).astype(np.int32)
+    v = (rng.integers(-40, 40, n) / 8.0).astype(np.float32)
+    m = rng.random(n) < 0.04
+
+    def run():
+        agg = ops.DeviceAggregate(L.SINGLE_NUMERICAL, [pa.int32()], [(L.SUM, 1, pa.float32()), (L.AVG, 1, pa.float32()), (L.COUNT, 1, pa.float32()), (L.COUNT_STAR, None, None)])
+        agg.set_predicate(">=", 0.7)
+        kc, vc = DeviceColumn.from_arrow(pa.array(k)), DeviceColumn.from_arrow(pa.array(v, mask=m))
+        for lo in range(0, n, 300_000):
+            hi = min(n, lo + 300_000)
+            agg.next([kc.slice(lo, hi - lo)], [vc.slice(lo, hi - lo)] * 3 + [None], pred=vc.slice(lo, hi - lo), nrows=hi - lo)
+        batch = agg.result_arrays([0], ["k"], ["s", "a", "c", "n"])
+        agg.close()
+        assert batch.schema.field("k").type == pa.int32() and batch.schema.field("s").type == pa.float64()
+        res = batch.to_pydict()
+        order = np.argsort(np.array(res["k"]))
+        return {name: np.array(col)[order] for name, col in res.items()}
+
+    wide = run()
+    monkeypatch.setenv("VNM_AGG_NO_WIDEN_KEYS", "1")
+    monkeypatch.setenv("VNM_AGG_NO_WIDEN_INPUTS", "1")
+    plain = run()
+    assert wide.keys() == plain.keys()
+    for name in wide:
+        assert wide[name].dtype == plain[name].dtype, name
+        assert (wide[name].view(np.int64 if wide[name].dtype.itemsize == 8 else np.int32) == plain[name].view(np.int64 if plain[name].dtype.itemsize == 8 else np.int32)).all(), name
