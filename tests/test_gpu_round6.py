@@ -1,0 +1,204 @@
+"""Round 6 parity: the data-dependent fast routes of the dense path -- fixed-point entry words (DPartArgs::fx_q) and the final pass
+without compensation words (exact_track) -- against the oracle, with every way out of them: a value the sample did not announce
+(finer fraction, larger magnitude, -0.0, NaN / Inf), totals beyond 2^53 quanta, batches that join or cannot join a pending pass."""
+import ctypes
+import math
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from tests import util
+from tests.test_gpu_agg import gpu_aggregate
+
+pytestmark = pytest.mark.gpu
+
+
+def _routes():
+    from vinum_amd import _lib as L
+    lib = L.lib()
+    need = lib.vnm_route_counts(None, 0)
+    buf = ctypes.create_string_buffer(int(need) + 16)
+    lib.vnm_route_counts(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        k, _, v = line.rpartition("=")
+        out[k] = int(v)
+    return out
+
+
+def _took(before, name):
+    return _routes().get(name, 0) - before.get(name, 0)
+
+
+def _oracle(funcs, batches, pred=None):
+    from oracle import oracle as O
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in batches:
+        if pred is not None:
+            b = O.filter_batch(b, O.cmp_mask(b.column(1), O.GT, pred[2]))
+        o.next(b)
+    return o.result()
+
+
+def _hot_funcs():
+    from oracle import oracle as O
+    return [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.COUNT_STAR, "", "n")]
+
+
+@pytest.mark.parametrize("groups", [1_500_000, 40_000_000])          # one scatter level / two levels
+@pytest.mark.parametrize("values", ["k/128", "integers", "halves_negative", "zeros"])
+@pytest.mark.parametrize("pred", [True, False])
+def test_fixed_point_entries_vs_oracle(groups, values, pred, monkeypatch):
+    """Values that are m * 2^qe with few bits travel as 8-byte entry words and are summed as integers: same bits as the oracle, on the
+    fused result columns and through finish() (gpu_aggregate compares the two), one level and two levels, two batches."""
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(groups % 1000 + len(values) + int(pred))
+    n = 3_000_000
+    k = rng.integers(0, groups, n).astype(np.int64) - 17
+    if values == "k/128":
+        v = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
+    elif values == "integers":
+        v = rng.integers(-10**6, 10**6, n).astype(np.float64)
+    elif values == "halves_negative":
+        v = -rng.integers(0, 5000, n).astype(np.float64) / 2.0 + 100.0
+    else:
+        v = np.zeros(n)
+    t = pa.table({"k": pa.array(k), "v": pa.array(v)})
+    batches = util.sliced_batches(t, n // 2)
+    predicate = ("v", ">", 1.0 if values != "zeros" else -1.0) if pred else None
+    before = _routes()
+    got = gpu_aggregate(__import__("oracle.oracle", fromlist=["x"]).SINGLE, ["k"], ["k"], _hot_funcs(), batches, predicate=predicate)
+    assert _took(before, "dense:fixed_point") >= 1, "the fixed-point route was not taken"
+    assert _took(before, "dense:fixed_point_misfit") == 0
+    util.assert_agg_equal(got, _oracle(_hot_funcs(), batches, predicate), _hot_funcs(), ["k"], what=f"fixed point {values} G={groups} pred={pred}")
+
+
+@pytest.mark.parametrize("misfit", ["finer_fraction", "large", "negative_zero", "nan", "inf", "tenth"])
+@pytest.mark.parametrize("where", ["first_batch_late_row", "second_batch"])
+def test_fixed_point_misfit_falls_back(misfit, where, monkeypatch):
+    """ONE value the sample cannot have announced: a fraction below the quantum, a magnitude beyond 31 bits of quanta, -0.0 (its sign
+    would be lost), NaN, Inf, 0.1.  Pass 1 checks every row: the attempt fails, the batch is redone with float64 entries and the
+    operator stays there; in the second batch of a stream the first batch's pending fixed-point pass runs first.  Bit-equal to the
+    oracle either way (NaN / Inf sums included)."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(len(misfit) * 7 + len(where))
+    n, groups = 2_400_000, 1_500_000
+    k = rng.integers(0, groups, n).astype(np.int64)
+    v = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
+    bad = {"finer_fraction": 3.0 + 2.0**-30, "large": 2.0**40 + 0.5, "negative_zero": -0.0, "nan": float("nan"), "inf": float("inf"), "tenth": 0.1}[misfit]
+    half = n // 2
+    at = half - 12345 if where == "first_batch_late_row" else n - 777
+    # (the value sample reads rows i * rows / 65536 of the first batch: the planted row is not one of them)
+    sampled = set(((np.arange(65536, dtype=np.int64) * half) // 65536).tolist())
+    while at in sampled:
+        at += 1
+    v[at] = bad
+    t = pa.table({"k": pa.array(k), "v": pa.array(v)})
+    batches = util.sliced_batches(t, half)
+    funcs = _hot_funcs()
+    before = _routes()
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches)
+    assert _took(before, "dense:fixed_point_misfit") == 1, _routes()
+    if where == "second_batch":
+        assert _took(before, "dense:fixed_point") == 1
+    util.assert_agg_equal(got, _oracle(funcs, batches), funcs, ["k"], what=f"misfit {misfit} {where}", source=batches)
+
+
+def test_fixed_point_heavy_group_total_beyond_2e53_quanta(monkeypatch):
+    """One group holds 85 % of 1.2e7 rows of values near 2^31 quanta: its total exceeds 2^53 quanta.  Whatever share of it the rings
+    spill to the side table (compensated float sums) and whatever share the integer sums of the final pass take, the merged result is
+    the correctly rounded exact sum (math.fsum), like the oracle's group count; every other group bit-equal to the oracle."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(11)
+    n, groups = 12_000_000, 1_500_000
+    k = rng.integers(0, groups, n).astype(np.int64)
+    v = rng.integers(2**30, 2**31 - 1, n).astype(np.float64) * 0.25
+    v[::1000] = 0.25                           # (the quantum itself is in the sample)
+    heavy = rng.random(n) < 0.85
+    k[heavy] = 123456
+    t = pa.table({"k": pa.array(k), "v": pa.array(v)})
+    batches = util.sliced_batches(t, n // 2)
+    funcs = _hot_funcs()
+    got = util.canon(gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches), ["k"])
+    kk = got.column(0).to_numpy()
+    i = int(np.searchsorted(kk, 123456))
+    exact = math.fsum(v[k == 123456].tolist())
+    assert exact > 2.0**53 * 0.25
+    assert got.column(1)[i].as_py() == exact, (got.column(1)[i].as_py(), exact)
+    assert got.column(3)[i].as_py() == int((k == 123456).sum())
+    util.assert_agg_equal(got, _oracle(funcs, batches), funcs, ["k"], what="totals beyond 2^53 quanta", source=batches)
+
+
+@pytest.mark.parametrize("groups", [1_500_000, 6_000_000])           # one scatter level / two levels
+def test_exact_adds_without_compensation_words(groups, monkeypatch):
+    """Values that do NOT fit 31 bits of one quantum (45 significant bits) but whose sums are provably exact (rows * max < 2^53 quanta):
+    float64 entries, final pass with {sum, count} slots and non-returning atomics (route dense:exact_adds).  Bit-equal to the oracle."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(groups % 977)
+    n = 2_400_000
+    k = rng.integers(0, groups, n).astype(np.int64)
+    # 33 significant bits of the quantum 2^-6 (|m| up to 2^32: no 31-bit entry word), 2^20 rows: 20 + 32 = 52 <= 53 bits -- provable
+    n = 1 << 20
+    k = k[:n]
+    v = rng.integers(-2**32, 2**32, n).astype(np.float64) * 2.0**-6
+    v[5] = (2.0**32 - 1) * 2.0**-6      # (the extremes are there whatever the generator drew)
+    v[6] = 2.0**-6
+    t = pa.table({"k": pa.array(k), "v": pa.array(v)})
+    batches = t.combine_chunks().to_batches()
+    funcs = _hot_funcs()
+    before = _routes()
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches)
+    assert _took(before, "dense:fixed_point") == 0
+    assert _took(before, "dense:exact_adds") >= 1, _routes()
+    util.assert_agg_equal(got, _oracle(funcs, batches), funcs, ["k"], what=f"exact adds G={groups}", source=batches)
+
+
+def test_inexact_values_keep_the_compensated_pass(monkeypatch):
+    """Lognormal values: neither route applies; the compensated pass gives the correctly rounded exact sum as before."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(3)
+    n, groups = 2_000_000, 1_500_000
+    k = rng.integers(0, groups, n).astype(np.int64)
+    v = rng.lognormal(2.0, 1.0, n)
+    t = pa.table({"k": pa.array(k), "v": pa.array(v)})
+    batches = util.sliced_batches(t, n // 2)
+    funcs = _hot_funcs()
+    before = _routes()
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches)
+    assert _took(before, "dense:fixed_point") == 0 and _took(before, "dense:exact_adds") == 0
+    util.assert_agg_equal(got, _oracle(funcs, batches), funcs, ["k"], what="lognormal", source=batches)
+
+
+@pytest.mark.parametrize("mode", ["stream", "sync"])
+def test_fixed_point_stream_of_batches(mode, monkeypatch):
+    """A stream of record batches (stream mode: the segments of one launch; synchronous: a pending pass the batches join) with
+    fixed-point entries; a ragged last batch; predicate on the value column.  Equal to the oracle."""
+    from oracle import oracle as O
+    from vinum_amd.device import DeviceColumn
+    from vinum_amd import ops
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(21)
+    n, groups = 3_300_001, 1_500_000
+    k = rng.integers(0, groups, n).astype(np.int64)
+    v = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
+    t = pa.table({"k": pa.array(k), "v": pa.array(v)})
+    batches = util.sliced_batches(t, 1 << 20)
+    funcs = _hot_funcs()
+    fspec = [(f, 1 if col else None, pa.float64() if col else None) for f, col, _ in funcs]
+    before = _routes()
+    agg = ops.DeviceAggregate(O.SINGLE, [pa.int64()], fspec, stream_mode=(mode == "stream"))
+    agg.set_predicate(">", 64.0)
+    keep = []
+    for b in batches:
+        kc, vc = DeviceColumn.from_arrow(b.column(0)), DeviceColumn.from_arrow(b.column(1))
+        keep.append((kc, vc))
+        agg.next([kc], [vc, vc, None], pred=vc, nrows=b.num_rows)
+    res = agg.result_arrays([0], ["k"], [f[2] for f in funcs])
+    agg.close()
+    assert _took(before, "dense:fixed_point") >= 1, _routes()
+    util.assert_agg_equal(res, _oracle(funcs, batches, ("v", ">", 64.0)), funcs, ["k"], what=f"fixed-point stream ({mode})")

@@ -365,6 +365,10 @@ struct DensePending {
     int64_t nfinal = 0;
     int64_t dstride = 0;   // bound of the groups the pass can produce
     int64_t rows = 0;      // rows behind the sets: below 2^32, the slots of the final pass count a group's rows in 32 bits
+    // exact-add statistics over the batches of the pass (exact_track): known only while every batch came through a scatter that keeps them
+    bool x_known = true;
+    uint32_t x_inv = 0, x_exp = 0;
+    bool exact_ok() const { return x_known && exact_adds_proved(((unsigned long long)x_exp << 32) | x_inv, rows); }
     std::vector<DSet> sets;      // one per batch whose scatter passes are done
     std::vector<void*> blocks;   // pool blocks the entries live in
     DSet* dsets = nullptr;       // device copy of `sets` (refreshed by complete_pending)
@@ -448,6 +452,9 @@ struct vnm_agg {
     int pred_user_is_float = 0;
     double pred_user_dval = 0.0;
     int64_t pred_user_ival = 0;
+    // fixed-point entries on the dense path (round 6, DPartArgs::fx_q): 0 = the value column has not been sampled yet, 1 = on (every value of
+    // the sample is m * 2^fx_qe with |m| < 2^31 and room to spare), -1 = off (the sample or a later row does not fit)
+    int fx_state = 0, fx_qe = 0;
     bool count8_off = false;    // the counters of COUNT(*)-only programs overflowed once (dcount8_final_kernel): not again
     int count_cb = 0;           // ... their width once the bytes overflowed: 16
     struct DScanPending* scan_pending = nullptr;   // a stream of small-range batches: their table (see dense_scan_aggregate)
