@@ -1011,15 +1011,17 @@ static int widen_key(vnm_agg* h, int64_t nrows, const vnm_dcol** keys, vnm_dcol*
     return 0;
 }
 static void waiting_of(const vnm_agg* h, int64_t* batches, int64_t* rows, int64_t* oldest);
-// widened key buffers no recorded batch needs any more go back to the pool (stream-ordered: the kernels that read them were enqueued before)
-static void release_widened(vnm_agg* h) {
+// widened key buffers no recorded batch needs any more go back to the pool -- behind an event on the stream whose kernels read them
+// (pool_free_after: the pool is shared with other streams and threads; `synced`: the stream has just been synchronised)
+static void release_widened(vnm_agg* h, void* stream, bool synced = false) {
     if (h->widened.empty()) return;
     int64_t b = 0, r = 0, o = -1;
     waiting_of(h, &b, &r, &o);
     size_t keep = 0;
     for (size_t i = 0; i < h->widened.size(); i++) {
         if (b > 0 && o >= 0 && h->widened[i].first >= o) h->widened[keep++] = h->widened[i];
-        else pool_free(h->widened[i].second);
+        else if (synced) pool_free(h->widened[i].second);
+        else pool_free_after(h->widened[i].second, as_stream(stream));
     }
     h->widened.resize(keep);
 }
@@ -1937,7 +1939,7 @@ int vnm_agg_next_device(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, const v
     if (h->key_out_type >= 0) { VNM_TRY(ensure_init()); VNM_TRY(widen_key(h, nrows, &keys, &wide, as_stream(stream))); }
     if (h->any_widen_in) { VNM_TRY(ensure_init()); VNM_TRY(widen_inputs(h, nrows, &inputs, win, &pred, &wpred, as_stream(stream))); }
     const int rc = next_device_body(h, nrows, keys, inputs, pred, stream);
-    if (h->key_out_type >= 0 || h->any_widen_in) release_widened(h);
+    if (h->key_out_type >= 0 || h->any_widen_in) release_widened(h, stream);
     return rc;
 }
 
@@ -1985,7 +1987,7 @@ int vnm_agg_sync(vnm_agg* h, void* stream) {
     for (vnm_agg* c : h->parts) VNM_TRY(flush_queue(c, stream));   // (the parts of a split program record their batches themselves)
     if (h->ex && h->ex->post) VNM_TRY(vnm_agg_sync(h->ex->post, stream));
     VNM_HIP(hipStreamSynchronize(as_stream(stream)));
-    release_widened(h);
+    release_widened(h, stream, true);
     return 0;
 }
 
@@ -2165,7 +2167,7 @@ int vnm_agg_finish(vnm_agg* h, int64_t* n_groups, void* stream) {
     if (!h) return set_error("vnm_agg_finish: null handle");
     const int rc = h->ex && h->ex->switched ? exact_finish(h, n_groups, stream)   // prefix + suffix merged, float MIN / MAX composed in row order
                                             : agg_finish_core(h, n_groups, stream);
-    release_widened(h);
+    release_widened(h, stream);
     return rc;
 }
 

@@ -50,6 +50,7 @@ int ensure_init();
 int stage_chunks(void* dst, const void* const* srcs, const size_t* sizes, size_t n_chunks, hipStream_t stream);
 void* pool_alloc(size_t bytes);
 void pool_free(void* p);
+void pool_free_after(void* p, hipStream_t stream);   // reusable only once the work enqueued on `stream` so far has completed
 size_t pool_trim();  // releases the cached blocks, returns their bytes
 // Pool blocks owned by a scope: every early return (VNM_HIP / VNM_TRY included) gives them back.  take() = pool_alloc
 // registered with the scope; keep(p) = ownership moves elsewhere (a handle, the caller); done(p) = free it now.

@@ -70,6 +70,21 @@ size_t round_size(size_t b) {
     return (b + step - 1) / step * step;
 }
 
+// blocks waiting for an event before they may be reused (pool_free_after)
+struct DeferredFree { hipEvent_t ev; void* p; };
+std::vector<DeferredFree>& g_deferred = *new std::vector<DeferredFree>;
+std::vector<hipEvent_t>& g_spare_events = *new std::vector<hipEvent_t>;
+void reap_deferred_locked() {   // g_pool_mu held
+    size_t keep = 0;
+    for (size_t i = 0; i < g_deferred.size(); i++) {
+        if (hipEventQuery(g_deferred[i].ev) == hipErrorNotReady) { g_deferred[keep++] = g_deferred[i]; continue; }
+        g_spare_events.push_back(g_deferred[i].ev);
+        auto it = g_sizes.find(g_deferred[i].p);
+        if (it != g_sizes.end()) { g_free.emplace(it->second, g_deferred[i].p); g_cached_bytes += it->second; }
+    }
+    g_deferred.resize(keep);
+}
+
 // releases cached blocks, largest first, until at most `keep` bytes stay cached.  The victims are COLLECTED under the lock and
 // freed after it is released: hipFree synchronises the device, and a query thread must not wait behind it for pool_alloc / pool_free.
 size_t trim_to(size_t keep) {
@@ -77,6 +92,7 @@ size_t trim_to(size_t keep) {
     size_t bytes = 0;
     {
         std::lock_guard<std::mutex> g(g_pool_mu);
+        if (!g_deferred.empty()) reap_deferred_locked();
         while (g_cached_bytes > keep && !g_free.empty()) {
             auto it = std::prev(g_free.end());
             bytes += it->first;
@@ -154,6 +170,7 @@ void* pool_alloc(size_t bytes) {
     touch_pool();
     {
         std::lock_guard<std::mutex> g(g_pool_mu);
+        if (!g_deferred.empty()) reap_deferred_locked();
         auto it = g_free.lower_bound(sz);
         if (it != g_free.end() && it->first <= sz * 2) {
             void* p = it->second;
@@ -188,6 +205,30 @@ void pool_free(void* p) {
     }
     g_free.emplace(it->second, p);
     g_cached_bytes += it->second;
+}
+
+// A block that kernels already enqueued on `stream` still read (the widened key / input buffers of an aggregate, released
+// right after the launches): it joins the free list only once an event recorded on that stream NOW has completed, so that an
+// allocation from ANOTHER stream or thread -- the CSV reader, a second operator, torch's side streams in distributed.py -- cannot be
+// handed the block while those kernels run.  The waiting blocks are looked at by every pool_alloc (hipEventQuery: no blocking).
+void pool_free_after(void* p, hipStream_t stream) {
+    if (!p) return;
+    touch_pool();
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        if (!g_spare_events.empty()) { ev = g_spare_events.back(); g_spare_events.pop_back(); }
+    }
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+    if (!ev || hipEventRecord(ev, stream) != hipSuccess) {   // no event to wait for: wait for the stream itself, then a plain free
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(stream);
+        if (ev) { std::lock_guard<std::mutex> g(g_pool_mu); g_spare_events.push_back(ev); }
+        pool_free(p);
+        return;
+    }
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    g_deferred.push_back({ev, p});
 }
 
 size_t pool_trim() { return trim_to(0); }
