@@ -202,3 +202,100 @@ def test_fixed_point_stream_of_batches(mode, monkeypatch):
     agg.close()
     assert _took(before, "dense:fixed_point") >= 1, _routes()
     util.assert_agg_equal(res, _oracle(funcs, batches, ("v", ">", 64.0)), funcs, ["k"], what=f"fixed-point stream ({mode})")
+
+
+def _ncol_table(rng, n, groups, ncols, misfit_at=None):
+    k = rng.integers(0, groups, n).astype(np.int64) + 3
+    cols = {"k": pa.array(k)}
+    for j, name in enumerate("abc"[:ncols]):
+        v = rng.integers(-2**13, 2**13, n).astype(np.float64) / (128.0 if j != 1 else 4.0)
+        if misfit_at is not None and j == 1:
+            v[misfit_at] = 0.1
+        cols[name] = pa.array(v)
+    cols["p"] = pa.array(rng.integers(0, 100, n).astype(np.float64))
+    return pa.table(cols)
+
+
+def _ncol_oracle(funcs, batches, pred):
+    from oracle import oracle as O
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in batches:
+        if pred is not None:
+            b = O.filter_batch(b, O.cmp_mask(b.column(b.schema.names.index(pred[0])), O.GT, pred[2]))
+        o.next(b)
+    return o.result()
+
+
+@pytest.mark.parametrize("ncols", [2, 3])
+@pytest.mark.parametrize("groups", [60_000, 1_500_000, 12_000_000])      # one scatter level / two / two with 256-way fan-outs
+@pytest.mark.parametrize("pred", ["input_column", "own_column", "none"])
+def test_fixed_point_columns_one_pass_vs_oracle(ncols, groups, pred, monkeypatch):
+    """SELECT k, sum(a), avg(b)[, sum(c)], count(b), count(*) ... GROUP BY k over fixed-point-able float64 columns: ONE pass over the rows,
+    16-byte entries of two / three values (vnm_agg_fxn.inc).  Two batches (the second one's run is merged with the first's), the
+    predicate on an input column, on a column of its own, or none.  Bit-equal to the oracle."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    monkeypatch.setenv("VNM_AGG_SPLIT_DENSE_MIN_ROWS", "500000")
+    monkeypatch.setenv("VNM_FXN_MIN_ROWS", "500000")
+    rng = np.random.default_rng(groups % 991 + ncols * 13 + len(pred))
+    n = 2_400_000
+    t = _ncol_table(rng, n, groups, ncols)
+    batches = util.sliced_batches(t, n // 2)
+    funcs = [(O.SUM, "a", "sa"), (O.AVG, "b", "ab"), (O.COUNT, "b", "cb"), (O.COUNT_STAR, "", "n")]
+    if ncols == 3:
+        funcs.insert(2, (O.SUM, "c", "sc"))
+    predicate = {"input_column": ("a", ">", -20.0), "own_column": ("p", ">", 30.0), "none": None}[pred]
+    before = _routes()
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=predicate)
+    assert _took(before, "dense:fixed_point_columns") >= 1, _routes()
+    util.assert_agg_equal(got, _ncol_oracle(funcs, batches, predicate), funcs, ["k"], exact_float_inputs=("a", "b", "c"), what=f"fixed-point columns C={ncols} G={groups} pred={pred}")
+
+
+def test_fixed_point_columns_misfit_takes_the_per_column_route(monkeypatch):
+    """One 0.1 in the second column, off the sample's lattice: the one-pass attempt fails before anything is written and the batch is cut
+    per column as before; equal to the oracle (the float sums of that column within the exact-sum bound)."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    monkeypatch.setenv("VNM_AGG_SPLIT_DENSE_MIN_ROWS", "500000")
+    monkeypatch.setenv("VNM_FXN_MIN_ROWS", "500000")
+    rng = np.random.default_rng(77)
+    n, groups = 2_000_000, 1_500_000
+    at = 1_234_567
+    sampled = set(((np.arange(65536, dtype=np.int64) * n) // 65536).tolist())
+    while at in sampled:
+        at += 1
+    t = _ncol_table(rng, n, groups, 3, misfit_at=at)
+    batches = t.combine_chunks().to_batches()
+    funcs = [(O.SUM, "a", "sa"), (O.AVG, "b", "ab"), (O.SUM, "c", "sc"), (O.COUNT_STAR, "", "n")]
+    before = _routes()
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=("a", ">", -20.0))
+    assert _took(before, "dense:fixed_point_columns_failed") == 1 and _took(before, "dense:fixed_point_columns") == 0, _routes()
+    src = [O.filter_batch(b, O.cmp_mask(b.column(1), O.GT, -20.0)) for b in batches]
+    util.assert_agg_equal(got, _ncol_oracle(funcs, batches, ("a", ">", -20.0)), funcs, ["k"], exact_float_inputs=("a", "c"), what="misfit in column b", source=src)
+
+
+def test_fixed_point_columns_stream_segments(monkeypatch):
+    """The bench's three-column stream (configs[3] one-GPU leg): recorded batches as the segments of one launch, a ragged last batch."""
+    from oracle import oracle as O
+    from vinum_amd.device import DeviceColumn
+    from vinum_amd import ops
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    monkeypatch.setenv("VNM_AGG_SPLIT_DENSE_MIN_ROWS", "500000")
+    rng = np.random.default_rng(5)
+    n, groups = 3_000_001, 1_000_000
+    t = _ncol_table(rng, n, groups, 3)
+    batches = util.sliced_batches(t, 1 << 19)
+    funcs = [(O.SUM, "a", "sa"), (O.AVG, "b", "ab"), (O.SUM, "c", "sc"), (O.COUNT_STAR, "", "n")]
+    fspec = [(O.SUM, 1, pa.float64()), (O.AVG, 2, pa.float64()), (O.SUM, 3, pa.float64()), (O.COUNT_STAR, None, None)]
+    before = _routes()
+    agg = ops.DeviceAggregate(O.SINGLE, [pa.int64()], fspec, stream_mode=True)
+    agg.set_predicate(">", -20.0)
+    keep = []
+    for b in batches:
+        cols = [DeviceColumn.from_arrow(b.column(i)) for i in range(4)]
+        keep.append(cols)
+        agg.next([cols[0]], [cols[1], cols[2], cols[3], None], pred=cols[1], nrows=b.num_rows)
+    res = agg.result_arrays([0], ["k"], [f[2] for f in funcs])
+    agg.close()
+    assert _took(before, "dense:fixed_point_columns") >= 1, _routes()
+    util.assert_agg_equal(res, _ncol_oracle(funcs, batches, ("a", ">", -20.0)), funcs, ["k"], exact_float_inputs=("a", "b", "c"), what="fixed-point columns, stream")

@@ -455,6 +455,7 @@ struct vnm_agg {
     // fixed-point entries on the dense path (round 6, DPartArgs::fx_q): 0 = the value column has not been sampled yet, 1 = on (every value of
     // the sample is m * 2^fx_qe with |m| < 2^31 and room to spare), -1 = off (the sample or a later row does not fit)
     int fx_state = 0, fx_qe = 0;
+    int fxn_state = 0, fxn_qe[3] = {0, 0, 0};   // ... and of the entries of two or three values (vnm_agg_fxn.inc)
     bool count8_off = false;    // the counters of COUNT(*)-only programs overflowed once (dcount8_final_kernel): not again
     int count_cb = 0;           // ... their width once the bytes overflowed: 16
     struct DScanPending* scan_pending = nullptr;   // a stream of small-range batches: their table (see dense_scan_aggregate)
@@ -874,6 +875,7 @@ static int merge_table_into_run(vnm_agg* h, hipStream_t s, bool* done) {
     return 0;
 }
 
+#include "vnm_agg_fxn.inc"
 #include "vnm_agg_multikey.inc"
 
 #include "vnm_agg_exact.inc"
@@ -1268,6 +1270,13 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                         // (TWO columns: the two-value entries themselves from ~1.5e6 groups on -- two scatter levels -- and one part per column
                         // below: 5e8 rows, G = 1e4 / 1e5 / 5e5 / 1e6: 8.2 / 10.9 / 14.8 / 10.1 -> 7.3 / 7.8 / 8.1 / 8.7 ms; 2e6: 9.9 against 11.4)
                         const bool split = h->plan.n_cols >= 3 || !sums || !big || (!pairs && h->hint <= env_i64("VNM_AGG_SPLIT_TWO_MAX_GROUPS", 1500000));
+                        // two or three float64 columns whose values are fixed-point words: ONE pass over the rows (vnm_agg_fxn.inc) before the
+                        // program is cut per column
+                        if (sums && h->plan.n_cols <= 3 && h->parts.empty()) {
+                            const int frc = dense_fxn_aggregate(h, nrows, keys, inputs, pred, s);
+                            if (frc == 1) return 1;
+                            if (frc == 0) { h->rows_seen += nrows; return 0; }
+                        }
                         if (split) {
                             route_note(pairs ? "split_program:dense_per_pair" : "split_program:dense_per_column", "%d columns, ~%lld groups over %lld codes, %lld rows", h->plan.n_cols, (long long)h->hint, (long long)h->dense_span, (long long)nrows);
                             VNM_TRY(make_parts(h, pairs ? 2 : 1));
