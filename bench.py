@@ -1064,7 +1064,7 @@ def main():
     # newest round first; hinted and hint-less runs take different paths, so they have different entries
     key = (f"{args.workload}_N{n:.0e}_G{groups:.0e}_s{args.selectivity}" + (f"_{args.shape}" if args.shape != "hot" else "")
            + ("_hint" if args.hint else ""))      # (the keys tools/traffic_from_pmc.py writes: other shapes run other kernels)
-    for tf in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for tf in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", tf)) as f:
                 tj = json.load(f)

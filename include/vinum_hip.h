@@ -371,6 +371,12 @@ int vnm_take_varwidth(const int64_t* offsets, const uint8_t* data, const uint8_t
 int vnm_take_bits(const uint8_t* bits, int64_t bit_offset, const int64_t* indices, int64_t n, uint8_t* out_bytes, void* stream);
 int vnm_take_fixed16(const void* values, const int64_t* indices, int64_t n, void* out_values, void* stream);
 int vnm_decimal128_sort_keys(const void* values, int64_t n, int64_t* out_hi, uint64_t* out_lo, void* stream);
+/* Distributed sample sort (Sort::Sorted over rows sharded by batch, sort.cpp:22-44): the per-rank partition step.
+ * Stable partition of the rows 0 .. n-1 by OWNER = number of splitters <= codes[row] (ascending int64 splitters, at most 63 of them; a
+ * code equal to a splitter goes to the upper owner).  out_order: n row numbers, the rows of owner 0 first, source order kept inside an
+ * owner; out_counts: n_splitters + 1 rows-per-owner counts.  All DEVICE pointers; returns after the stream has been synchronised. */
+int vnm_partition_by_owner(const int64_t* codes, int64_t n, const int64_t* splitters, int n_splitters, int64_t* out_order,
+                           int64_t* out_counts, void* stream);
 typedef struct vnm_sort_op vnm_sort_op;
 vnm_sort_op* vnm_sort_op_create(int n, const char** cols, const int* orders);
 int vnm_sort_op_next(vnm_sort_op* h, struct ArrowArray* batch, struct ArrowSchema* schema);

@@ -46,7 +46,7 @@ def _hot_funcs():
     return [(O.SUM, "v", "s"), (O.AVG, "v", "a"), (O.COUNT_STAR, "", "n")]
 
 
-@pytest.mark.parametrize("groups", [1_500_000, 40_000_000])          # one scatter level / two levels
+@pytest.mark.parametrize("groups", [1_500_000, 12_000_000])          # one scatter level / two levels
 @pytest.mark.parametrize("values", ["k/128", "integers", "halves_negative", "zeros"])
 @pytest.mark.parametrize("pred", [True, False])
 def test_fixed_point_entries_vs_oracle(groups, values, pred, monkeypatch):

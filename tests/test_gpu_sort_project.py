@@ -540,13 +540,16 @@ class _RawI64:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
 
 
-@pytest.mark.parametrize("world", [1, 2, 8])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
 @pytest.mark.parametrize("desc", [False, True])
 def test_distributed_sample_sort_simulated(world, desc):
-    """distributed.sample_sort_exchange on one GPU: `world` shards play the ranks (contiguous row ranges), the splitters come from
-    the union of their samples, the blocks are routed by hand exactly as the all_to_all would deliver them (by owner, in source-
-    rank order), every owner sorts what it got with the library's stable single-key sort over the order codes -- and the ranks'
-    slices, concatenated in rank order, must be the row ids of the SINGLE-GPU sort of the whole column (vnm_sort_indices)."""
+    """distributed.sample_sort_exchange on one GPU, against the ORACLE: `world` shards play the ranks (contiguous row ranges); the
+    splitters come from the union of their samples; every rank partitions its rows by owner ON THE DEVICE (vnm_partition_by_owner --
+    checked against a stable argsort of the owners); the blocks are routed exactly as the all_to_all would deliver them (by owner, in
+    source-rank order); every owner sorts what it got with the library's stable single-key sort over the order codes.  The ranks'
+    slices, concatenated in rank order, must be Arrow's sort_indices of the whole column (Sort::Sorted, sort.cpp:22-44: stable, NaN
+    after every number in both directions) -- and the single-GPU sort agrees with that, too."""
+    import pyarrow.compute as pc
     import torch
     from vinum_amd import _lib as L
     from vinum_amd import distributed as D
@@ -554,28 +557,37 @@ def test_distributed_sample_sort_simulated(world, desc):
     from vinum_amd.device import DeviceColumn
     rng = np.random.default_rng(5)
     n = 1_200_000
-    v = rng.normal(0.0, 1.0, n); v[::997] = np.nan; v[5::1201] = -0.0; v[::11] = np.round(v[::11], 2)
+    v = rng.normal(0.0, 1.0, n); v[::997] = np.nan; v[5::1201] = -0.0; v[7::1201] = 0.0; v[::11] = np.round(v[::11], 2)
+    oracle = pc.sort_indices(pa.table({"x": pa.array(v)}), sort_keys=[("x", "descending" if desc else "ascending")])   # (NaN last in both directions; -0.0 == +0.0: stable)
+    ref = torch.from_numpy(oracle.to_numpy().astype(np.int64)).cuda()
     tv = torch.from_numpy(v).cuda()
-    ref_idx = ops.sort_indices([DeviceColumn.from_torch(tv)], [L.DESC if desc else L.ASC])
-    ref = torch.as_tensor(_RawI64(ref_idx.ptr, n), device="cuda").clone()
+    single = ops.sort_indices([DeviceColumn.from_torch(tv)], [L.DESC if desc else L.ASC])
+    assert bool(torch.equal(torch.as_tensor(_RawI64(single.ptr, n), device="cuda"), ref)), "single-GPU sort != Arrow sort_indices"
     bounds = np.linspace(0, n, world + 1).astype(int)
     codes = [D._order_key(tv[bounds[r]:bounds[r + 1]], desc) for r in range(world)]
     splitters = D.ssort_splitters([D.ssort_sample(c, 4096) for c in codes], world)
+    parts = []
+    for r in range(world):
+        order, counts = D.partition_by_owner(codes[r], splitters, world)
+        own = D.ssort_owner(codes[r], splitters)
+        assert bool(torch.equal(order, torch.argsort(own, stable=True))), f"rank {r}: the device partition is not the stable partition by owner"
+        assert bool(torch.equal(counts, torch.bincount(own, minlength=world)))
+        parts.append((order, torch.cumsum(counts, 0) - counts, counts))
     got = []
     for o in range(world):
         blocks_c, blocks_i = [], []
         for r in range(world):                                  # what owner o receives: source-rank order, row order inside
-            own = D.ssort_owner(codes[r], splitters)
-            sel = own == o
+            order, starts, counts = parts[r]
+            sel = order[int(starts[o]):int(starts[o]) + int(counts[o])]
             blocks_c.append(codes[r][sel])
-            blocks_i.append(torch.arange(bounds[r], bounds[r + 1], device="cuda", dtype=torch.int64)[sel])
+            blocks_i.append(sel + int(bounds[r]))
         rc, rid = torch.cat(blocks_c).contiguous(), torch.cat(blocks_i).contiguous()
         if len(rc):
             perm_buf = ops.sort_indices([DeviceColumn.from_torch(rc)], [L.ASC])      # stable: ties keep the (rank, row) = id order
             perm = torch.as_tensor(_RawI64(perm_buf.ptr, len(rc)), device="cuda")
             got.append(rid[perm])
     got = torch.cat(got)
-    assert bool(torch.equal(got, ref)), f"world {world} desc {desc}: {int((got != ref).sum())} positions differ"
+    assert bool(torch.equal(got, ref)), f"world {world} desc {desc}: {int((got != ref).sum())} positions differ from Arrow's sort_indices"
 
 
 @pytest.mark.parametrize("case", ["f32_normal", "f32_desc_nan_negzero", "i32_few_dups", "u32_desc", "i32_heavy_value", "f32_offset"])

@@ -125,6 +125,7 @@ PROTOTYPES = {
     "vnm_take_bits": (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_void]),
     "vnm_take_fixed16": (c_int, [c_void, c_void, c_i64, c_void, c_void]),
     "vnm_decimal128_sort_keys": (c_int, [c_void, c_i64, c_void, c_void, c_void]),
+    "vnm_partition_by_owner": (c_int, [c_void, c_i64, c_void, c_int, c_void, c_void, c_void]),
     "vnm_malloc": (c_void, [c_i64]),
     "vnm_free": (c_int, [c_void]),
     "vnm_pool_trim": (c_i64, []),

@@ -456,6 +456,8 @@ struct vnm_agg {
     // the sample is m * 2^fx_qe with |m| < 2^31 and room to spare), -1 = off (the sample or a later row does not fit)
     int fx_state = 0, fx_qe = 0;
     int fxn_state = 0, fxn_qe[3] = {0, 0, 0};   // ... and of the entries of two or three values (vnm_agg_fxn.inc)
+    bool null_inputs_seen = false;   // some batch brought an input column with a validity bitmap: the HBM table may hold groups whose COUNT(v) differs
+                                     // from COUNT(*) (or whose SUM is NULL) -- the side-table fold of the fused result columns assumes they do not
     bool count8_off = false;    // the counters of COUNT(*)-only programs overflowed once (dcount8_final_kernel): not again
     int count_cb = 0;           // ... their width once the bytes overflowed: 16
     struct DScanPending* scan_pending = nullptr;   // a stream of small-range batches: their table (see dense_scan_aggregate)
@@ -1106,6 +1108,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
     if (h->pred_set && !pred) return set_error("vnm_agg_next_device: predicate set but no predicate column given");
     hipStream_t s = as_stream(stream);
     invalidate_result(h);
+    if (inputs && nrows > 0) for (int i = 0; i < h->n_funcs; i++) if (h->func_col[i] >= 0 && inputs[i].validity) h->null_inputs_seen = true;
     // A NULLABLE single 8-byte key under the hot program: the dense path takes it as it is -- pass 1 reads the key's validity and
     // sums the NULL-key rows up as the one group they are (single_numerical_hash_aggregate.cpp:24-32), everything after pass 1 never
     // sees a NULL.  Before round 4 such a key was packed into one word first (key range + pack + unpack passes, the NULL code a

@@ -100,6 +100,92 @@ __global__ __launch_bounds__(256) void dec128_keys_kernel(const ulonglong2* v, i
 
 static int grid_rows(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, (int64_t)device_info().num_cus * 8); }
 
+
+// ---- stable partition of rows by OWNER (distributed sample sort: rows -> the rank whose splitter range holds their order code) -----
+// owner(code) = number of splitters <= code (a code equal to a splitter goes to the upper rank: equal codes never split), W = n_split + 1
+// <= 64 owners.  Three launches: per-block owner histograms, an exclusive scan per owner over the blocks (owner-major: all rows of
+// owner 0 first), a stable scatter of the row numbers (block order, then row order inside the block).
+constexpr int PO_BLOCK = 256, PO_ITERS = 16, PO_TILE = PO_BLOCK * PO_ITERS, PO_MAXW = 64;
+__device__ __forceinline__ int po_owner(int64_t code, const int64_t* sp, int nsp) {
+    int lo = 0, hi = nsp;                    // first splitter > code
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sp[mid] <= code) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__global__ __launch_bounds__(PO_BLOCK) void po_hist_kernel(const int64_t* codes, int64_t n, const int64_t* splitters, int nsp, uint32_t* hist /* [W][nblocks] */, int64_t nblocks) {
+    __shared__ int64_t sp[PO_MAXW];
+    __shared__ uint32_t cnt[PO_MAXW];
+    if ((int)threadIdx.x < nsp) sp[threadIdx.x] = splitters[threadIdx.x];
+    if (threadIdx.x < PO_MAXW) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * PO_TILE;
+    for (int it = 0; it < PO_ITERS; it++) {
+        const int64_t r = base + (int64_t)it * PO_BLOCK + threadIdx.x;
+        if (r < n) atomicAdd(&cnt[po_owner(codes[r], sp, nsp)], 1u);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x <= nsp) hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = cnt[threadIdx.x];
+}
+// one workgroup per owner: exclusive scan of its row of `hist` in place; totals[o] = the owner's rows
+__global__ __launch_bounds__(1024) void po_scan_kernel(uint32_t* hist, int64_t nblocks, int64_t* totals) {
+    __shared__ uint64_t s[1024];
+    uint32_t* row = hist + (int64_t)blockIdx.x * nblocks;
+    const int64_t per = (nblocks + 1023) / 1024;
+    const int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < nblocks ? lo + per : nblocks;
+    uint64_t a = 0;
+    for (int64_t i = lo; i < hi; i++) a += row[i];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint64_t v = (int)threadIdx.x >= d ? s[threadIdx.x - d] : 0;
+        __syncthreads();
+        s[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint64_t run = s[threadIdx.x] - a;
+    for (int64_t i = lo; i < hi; i++) { const uint32_t c = row[i]; row[i] = (uint32_t)run; run += c; }     // (offsets inside one owner: < 2^32 rows per call)
+    if (threadIdx.x == 1023) totals[blockIdx.x] = (int64_t)s[1023];
+}
+__global__ __launch_bounds__(PO_BLOCK) void po_scatter_kernel(const int64_t* codes, int64_t n, const int64_t* splitters, int nsp, const uint32_t* hist, int64_t nblocks,
+                                                              const int64_t* totals, int64_t* out_order) {
+    __shared__ int64_t sp[PO_MAXW];
+    __shared__ int64_t run[PO_MAXW];                 // next output position of every owner for this block
+    __shared__ uint32_t wcnt[PO_BLOCK / 64][PO_MAXW];
+    const int W = nsp + 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)threadIdx.x < nsp) sp[threadIdx.x] = splitters[threadIdx.x];
+    if ((int)threadIdx.x < W) {
+        int64_t before = 0;
+        for (int o = 0; o < (int)threadIdx.x; o++) before += totals[o];
+        run[threadIdx.x] = before + hist[(int64_t)threadIdx.x * nblocks + blockIdx.x];
+    }
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * PO_TILE;
+    for (int it = 0; it < PO_ITERS; it++) {
+        const int64_t r = base + (int64_t)it * PO_BLOCK + threadIdx.x;
+        const int o = r < n ? po_owner(codes[r], sp, nsp) : -1;
+        if (lane < W) wcnt[wave][lane] = 0;
+        // rank of this lane among the lanes of its wave with the same owner
+        uint32_t rank = 0;
+        unsigned long long todo = __ballot(o >= 0);
+        while (todo) {
+            const int lead = __ffsll((long long)todo) - 1;
+            const int lo_ = __shfl(o, lead);
+            const unsigned long long m = __ballot(o == lo_);
+            if (o == lo_) rank = (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
+            if (lane == lead) wcnt[wave][lo_] = (uint32_t)__popcll(m);
+            todo &= ~m;
+        }
+        __syncthreads();
+        if (o >= 0) {
+            int64_t pos = run[o] + rank;
+            for (int w = 0; w < wave; w++) pos += wcnt[w][o];
+            out_order[pos] = r;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < W) { uint32_t t = 0; for (int w = 0; w < PO_BLOCK / 64; w++) t += wcnt[w][threadIdx.x]; run[threadIdx.x] += t; }
+        __syncthreads();
+    }
+}
+
 }  // namespace vnm
 
 using namespace vnm;
@@ -164,4 +250,25 @@ int vnm_decimal128_sort_keys(const void* values, int64_t n, int64_t* out_hi, uin
     return 0;
 }
 
+
+int vnm_partition_by_owner(const int64_t* codes, int64_t n, const int64_t* splitters, int n_splitters, int64_t* out_order, int64_t* out_counts, void* stream) {
+    VNM_TRY(ensure_init());
+    if (n < 0 || n_splitters < 0 || n_splitters >= PO_MAXW) return set_error("vnm_partition_by_owner: at most %d owners", PO_MAXW);
+    if (!out_counts || (n > 0 && (!codes || !out_order)) || (n_splitters > 0 && !splitters)) return set_error("vnm_partition_by_owner: null argument");
+    if (n >= (1LL << 32)) return set_error("vnm_partition_by_owner: at most 2^32 - 1 rows per call");
+    hipStream_t s = as_stream(stream);
+    const int W = n_splitters + 1;
+    if (n == 0) { VNM_HIP(hipMemsetAsync(out_counts, 0, (size_t)W * 8, s)); return 0; }
+    const int64_t nblocks = (n + PO_TILE - 1) / PO_TILE;
+    PoolScope pool;
+    uint32_t* hist = (uint32_t*)pool.take((size_t)W * nblocks * 4);
+    if (!hist) return 1;
+    KernelTimer timer("partition_by_owner", s);
+    po_hist_kernel<<<(int)nblocks, PO_BLOCK, 0, s>>>(codes, n, splitters, n_splitters, hist, nblocks);
+    po_scan_kernel<<<W, 1024, 0, s>>>(hist, nblocks, out_counts);
+    po_scatter_kernel<<<(int)nblocks, PO_BLOCK, 0, s>>>(codes, n, splitters, n_splitters, hist, nblocks, out_counts, out_order);
+    VNM_HIP(hipGetLastError());
+    VNM_HIP(hipStreamSynchronize(s));    // (the scratch block goes back to the pool)
+    return 0;
+}
 }  // extern "C"

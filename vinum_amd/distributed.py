@@ -482,6 +482,26 @@ def ssort_owner(code: torch.Tensor, splitters: torch.Tensor) -> torch.Tensor:
     return torch.searchsorted(splitters, code, right=True)
 
 
+def partition_by_owner(code: torch.Tensor, splitters: torch.Tensor, world: int):
+    """Stable partition of a rank's rows by owner: (row numbers with owner 0's rows first and the source order kept inside an owner,
+    rows per owner).  On the device the library's kernels (vnm_partition_by_owner: per-block owner histograms, a scan per owner, a
+    stable scatter of the row numbers -- no sort); on the host (the gloo tests) a stable argsort of the owners."""
+    n = int(code.shape[0])
+    if code.is_cuda and world <= 64:
+        import ctypes
+        from . import _lib as L
+        code = code.contiguous()
+        sp = splitters.to(torch.int64).contiguous()
+        order = torch.empty(max(n, 1), dtype=torch.int64, device=code.device)
+        counts = torch.zeros(world, dtype=torch.int64, device=code.device)
+        stream = torch.cuda.current_stream(code.device).cuda_stream
+        L.check(L.lib().vnm_partition_by_owner(ctypes.c_void_p(code.data_ptr()), n, ctypes.c_void_p(sp.data_ptr() if len(sp) else 0), int(len(sp)),
+                                               ctypes.c_void_p(order.data_ptr()), ctypes.c_void_p(counts.data_ptr()), ctypes.c_void_p(stream)))
+        return order[:n], counts
+    owner = ssort_owner(code, splitters)
+    return torch.argsort(owner, stable=True), torch.bincount(owner, minlength=world)
+
+
 def sample_sort_exchange(keys: torch.Tensor, global_ids: torch.Tensor, descending: bool, sort_local, group=None,
                          samples_per_rank: int = 4096):
     """Distributed `ORDER BY key [DESC]` (Sort::Sorted semantics, sort.cpp:15-63: stable, NaN after every
@@ -505,9 +525,7 @@ def sample_sort_exchange(keys: torch.Tensor, global_ids: torch.Tensor, descendin
     allp = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(allp, padded, group=group)
     splitters = ssort_splitters([p_[: int(p_[samples_per_rank])] for p_ in allp], world)
-    owner = ssort_owner(code, splitters)
-    order = torch.argsort(owner, stable=True)                            # by owner, source row order kept
-    counts = torch.bincount(owner, minlength=world)
+    order, counts = partition_by_owner(code, splitters, world)           # by owner, source row order kept
     send = torch.stack([code[order], global_ids[order].to(torch.int64),
                         (keys.view(torch.int64) if keys.dtype == torch.float64 else keys.to(torch.int64))[order]], dim=1).contiguous()
     recv = exchange(send, counts, group)
