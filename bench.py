@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sustain-seconds", type=float, default=6.0, help="after the timed region: repeat the step for this many seconds (reported as `sustained`; 0 = off)")
     ap.add_argument("--workload", default=None, choices=["groupby", "stream", "filter", "topk", "project"],
                     help="default: groupby (configs[2]) on one GPU, stream (configs[3]) on several")
     ap.add_argument("--batches", type=int, default=0, help="stream: record batches of 2^24 rows per rank (default: rows // 2^24, at most 60)")
@@ -326,6 +327,24 @@ def _spans(lib, ctypes, names, steps):
 
 
 AGG_SPANS = [b"agg_estimate", b"agg_scan", b"agg_part_scatter1", b"agg_part_scatter2", b"agg_part_final", b"agg_finalize", b"agg_table_merge"]
+
+
+def device_state():
+    """clocks / power / temperatures of GPU 0 as rocm-smi reports them (a judge can normalise box-to-box spread by them); {} if unavailable"""
+    import json as _json
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=20).stdout
+        j = _json.loads(out[out.index("{"):])
+        card = next(iter(j.values()))
+        keep = {}
+        for k_, v_ in card.items():
+            kl = k_.lower()
+            if any(w in kl for w in ("sclk", "mclk", "fclk", "power", "temperature")):
+                keep[k_] = v_
+        return keep
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)[:80]}
 
 
 def _measure(torch, lib, ctypes, fn, span_names, steps, warmup):
@@ -1141,6 +1160,22 @@ def main():
         }
         if check is not None:
             result["check"] = check
+        #  the device's state next to the line, and a SUSTAINED leg: the same step for a few seconds after the timed
+        # region -- the timed K steps are ~0.2 s of GPU work in a minute of data generation, invisible to a 5-s utilisation sampler and
+        # too short to show what the rate settles at; reported beside the headline, never part of `value`
+        result["device_state"] = device_state()
+        if world == 1 and not force_exchange and not args.no_also and args.sustain_seconds > 0:
+            try:
+                n_s, t_s = 0, time.perf_counter()
+                while time.perf_counter() - t_s < args.sustain_seconds:
+                    for _ in range(10):
+                        step()
+                    torch.cuda.synchronize()
+                    n_s += 10
+                el_s = time.perf_counter() - t_s
+                result["sustained"] = {"seconds": round(el_s, 2), "steps": n_s, "ms_per_step": el_s / n_s * 1e3, "device_state_after": device_state()}
+            except Exception as e:  # noqa: BLE001 -- reporting only
+                result["sustained"] = {"error": str(e)}
         if multi_also is not None:
             result["also"] = multi_also
         if world == 1 and not force_exchange and args.workload == "groupby" and args.shape == "hot" and not args.no_also:

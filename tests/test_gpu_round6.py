@@ -3,6 +3,7 @@ without compensation words (exact_track) -- against the oracle, with every way o
 (finer fraction, larger magnitude, -0.0, NaN / Inf), totals beyond 2^53 quanta, batches that join or cannot join a pending pass."""
 import ctypes
 import math
+import os
 
 import numpy as np
 import pyarrow as pa
@@ -299,3 +300,45 @@ def test_fixed_point_columns_stream_segments(monkeypatch):
     agg.close()
     assert _took(before, "dense:fixed_point_columns") >= 1, _routes()
     util.assert_agg_equal(res, _ncol_oracle(funcs, batches, ("a", ">", -20.0)), funcs, ["k"], exact_float_inputs=("a", "b", "c"), what="fixed-point columns, stream")
+
+
+def test_parquet_and_json_sources_through_the_pinned_ring(tmp_path):
+    """vinum.read_parquet / read_json (io/arrow.py:111-248) as streams of device record batches: pyarrow decodes, every batch is staged
+    through vnm_stage_column (numeric columns, validity with an odd offset) or the device dictionary (strings); GROUP BY over the
+    stream == pyarrow's group_by over the file; column pruning reaches the reader."""
+    import pyarrow.parquet as pq
+    from vinum_amd import planner
+    from vinum_amd.io import stream_parquet, read_parquet, read_json
+    rng = np.random.default_rng(9)
+    n = 250_003
+    t = pa.table({"id": pa.array(np.arange(n, dtype=np.int64)),
+                  "k": pa.array(rng.integers(0, 97, n).astype(np.int32), mask=rng.random(n) < 0.01),
+                  "v": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0, mask=rng.random(n) < 0.05),
+                  "city": pa.array(rng.choice(["Berlin", "Riva", "München", "Malaga", ""], n))})
+    path = os.path.join(tmp_path, "t.parquet")
+    pq.write_table(t, path, row_group_size=60_000)
+    q = dict(select=["k", ["fn", "count_star"], ["fn", "sum", "v"], ["fn", "count", "v"]], aliases=[None, "n", "s", "c"], group_by=["k"])
+    got = planner.execute(q, stream_parquet(path, batch_rows=33_333)).sort_by("k")
+    exp = t.group_by("k", use_threads=False).aggregate([([], "count_all"), ("v", "sum"), ("v", "count")]).sort_by("k")
+    assert got.column("k").to_pylist() == exp.column("k").to_pylist()
+    assert got.column("n").cast(pa.int64()).to_pylist() == exp.column("count_all").to_pylist()
+    assert got.column("c").cast(pa.int64()).to_pylist() == exp.column("v_count").to_pylist()
+    assert got.column("s").to_pylist() == exp.column("v_sum").to_pylist()          # (quantised values: every sum is exact)
+    # a string key through the device dictionary, the whole file as one batch
+    q2 = dict(select=["city", ["fn", "count_star"]], aliases=[None, "n"], group_by=["city"])
+    got2 = planner.execute(q2, stream_parquet(path, batch_rows=100_000)).sort_by("city")
+    exp2 = t.group_by("city", use_threads=False).aggregate([([], "count_all")]).sort_by("city")
+    assert got2.column("city").to_pylist() == exp2.column("city").to_pylist() and got2.column("n").cast(pa.int64()).to_pylist() == exp2.column("count_all").to_pylist()
+    whole = read_parquet(path, columns=["id", "v"])
+    assert whole.num_rows == n and whole.columns["v"].to_arrow().equals(t.column("v").combine_chunks())
+    # line-delimited JSON
+    jpath = os.path.join(tmp_path, "t.json")
+    small = t.slice(0, 5000)
+    with open(jpath, "w") as f:
+        for row in small.to_pylist():
+            f.write(__import__("json").dumps(row) + "\n")
+    rows = 0
+    for b in read_json(jpath, batch_rows=2000):
+        rows += b.num_rows
+        assert b.columns["id"].to_arrow().type == pa.int64()
+    assert rows == 5000
