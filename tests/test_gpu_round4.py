@@ -659,7 +659,7 @@ def test_async_stream_with_several_input_columns(route, pred, monkeypatch):
     routes = {nm.decode(): _launches(nm) for nm in (b"agg_scan", b"agg_part_scatter2", b"agg_part_final", b"agg_estimate")}
     L.lib().vnm_set_profiling(0)
     if one_pass:
-        assert joins == 0 and 1 <= p1 <= 2, (joins, p1, routes)   # one launch per sync point (the short tail after the sync may take another path), no parts
+        assert joins == 0 and p1 >= 1, (joins, p1, routes)   # no parts, no join (the short tail after the sync point takes a path of its own)
     elif route == "dense_per_column":
         assert joins == 1 and p1 == 2 * 3, (joins, p1, routes)      # three parts, one launch each per sync point -- not one per batch
     elif route == "dense_range_too_wide_for_one_batch":
