@@ -455,6 +455,7 @@ struct vnm_agg {
     // fixed-point entries on the dense path (round 6, DPartArgs::fx_q): 0 = the value column has not been sampled yet, 1 = on (every value of
     // the sample is m * 2^fx_qe with |m| < 2^31 and room to spare), -1 = off (the sample or a later row does not fit)
     int fx_state = 0, fx_qe = 0;
+    bool fx_narrow = false;          // ... with |m| < 2^18: the words of the last scatter level are 32 bits (dring_scatter_kernel<..., W32>)
     int fxn_state = 0, fxn_qe[3] = {0, 0, 0};   // ... and of the entries of two or three values (vnm_agg_fxn.inc)
     bool null_inputs_seen = false;   // some batch brought an input column with a validity bitmap: the HBM table may hold groups whose COUNT(v) differs
                                      // from COUNT(*) (or whose SUM is NULL) -- the side-table fold of the fused result columns assumes they do not
