@@ -109,7 +109,7 @@ def test_fixed_point_misfit_falls_back(misfit, where, monkeypatch):
 
 @pytest.mark.parametrize("groups", [1_500_000, 12_000_000])
 def test_narrow_words_fall_back_to_wide_words(groups, monkeypatch):
-    """k / 128 values travel as 32-bit words after the last scatter level (|m| < 2^18); ONE value of 2^22 + 0.5, off the sample's lattice,
+    """k / 128 values travel as 32-bit words after the last scatter level (|m| < 2^18); ONE value of 1000.5, off the sample's lattice,
     does not fit them but fits the 64-bit words: the attempt is redone with those (one misfit note, the fixed-point route still taken)."""
     from oracle import oracle as O
     monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
@@ -122,7 +122,7 @@ def test_narrow_words_fall_back_to_wide_words(groups, monkeypatch):
     sampled = set(((np.arange(65536, dtype=np.int64) * half) // 65536).tolist())
     while at in sampled:
         at += 1
-    v[at] = 2.0**22 + 0.5
+    v[at] = 1000.5
     t = pa.table({"k": pa.array(k), "v": pa.array(v)})
     batches = util.sliced_batches(t, half)
     funcs = _hot_funcs()
