@@ -455,6 +455,7 @@ struct vnm_agg {
     // fixed-point entries on the dense path (round 6, DPartArgs::fx_q): 0 = the value column has not been sampled yet, 1 = on (every value of
     // the sample is m * 2^fx_qe with |m| < 2^31 and room to spare), -1 = off (the sample or a later row does not fit)
     int fx_state = 0, fx_qe = 0;
+    bool pack_null_seen = false;     // packed composite keys: some batch brought a key column with a validity bitmap (NULL codes may be in the words)
     bool fx_narrow = false;          // ... with |m| < 2^18: the words of the last scatter level are 32 bits (dring_scatter_kernel<..., W32>)
     int fxn_state = 0, fxn_qe[3] = {0, 0, 0};   // ... and of the entries of two or three values (vnm_agg_fxn.inc)
     bool null_inputs_seen = false;   // some batch brought an input column with a validity bitmap: the HBM table may hold groups whose COUNT(v) differs
@@ -1180,7 +1181,7 @@ static int next_device_impl(vnm_agg* h, int64_t nrows, const vnm_dcol* keys, con
                 for (int j = 0; j < h->plan.n_keys; j++) ndict += h->pack.dtab[j] != nullptr;
                 route_note(ndict ? "keys:packed_with_dictionary_fields" : "keys:packed", "%d key columns in one 64-bit word (%d dictionary-coded)", h->plan.n_keys, ndict);
             }
-            for (int j = 0; j < h->plan.n_keys; j++) h->pack.cols[j] = keys[j];
+            for (int j = 0; j < h->plan.n_keys; j++) { h->pack.cols[j] = keys[j]; if (keys[j].validity) h->pack_null_seen = true; }
             uint64_t* packed = (uint64_t*)pool_alloc((size_t)nrows * 8);
             unsigned long long* flag = (unsigned long long*)pool_alloc(64);
             if (!packed || !flag) return 1;
