@@ -368,3 +368,67 @@ def test_parquet_and_json_sources_through_the_pinned_ring(tmp_path):
         rows += b.num_rows
         assert b.columns["id"].to_arrow().type == pa.int64()
     assert rows == 5000
+
+
+def _raw_aggregate(kind, groupby, agg_cols, funcs, batches) -> pa.RecordBatch:
+    """vnm_agg_op_create / _next / _result through ctypes and the Arrow C Data Interface only -- what a binding of include/vinum_hip.h
+    in any language does (vinum/core/vinum_lib.cpp:54-124).  No vinum_lib.py between the test and the library."""
+    from vinum_amd import _lib as L
+    lib = L.lib()
+    cs = lambda xs: (ctypes.c_char_p * max(len(xs), 1))(*[x.encode() for x in xs])
+    ft = (ctypes.c_int * len(funcs))(*[int(f[0]) for f in funcs])
+    h = lib.vnm_agg_op_create(int(kind), len(groupby), cs(groupby), len(agg_cols), cs(agg_cols), len(funcs), ft, cs([f[1] for f in funcs]), cs([f[2] for f in funcs]))
+    assert h, L.last_error()
+    try:
+        for b in batches:
+            arr, sch = ctypes.create_string_buffer(80), ctypes.create_string_buffer(72)
+            b._export_to_c(ctypes.addressof(arr), ctypes.addressof(sch))
+            L.check(lib.vnm_agg_op_next(h, ctypes.addressof(arr), ctypes.addressof(sch)))
+        arr, sch = ctypes.create_string_buffer(80), ctypes.create_string_buffer(72)
+        L.check(lib.vnm_agg_op_result(h, ctypes.addressof(arr), ctypes.addressof(sch)))
+        return pa.RecordBatch._import_from_c(ctypes.addressof(arr), ctypes.addressof(sch))
+    finally:
+        lib.vnm_agg_op_destroy(h)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_generic_keys_through_the_raw_c_abi(seed):
+    """GenericHashAggregate's keys (generic_hash_aggregate.h:10-45; bound at vinum_lib.cpp:92-109) below the C ABI: utf8 / large_utf8 /
+    binary / boolean / decimal128 group keys -- alone, mixed with an int64 key -- with NULLs, empty strings and values first seen in a later
+    batch (small batches wait and are staged together, a large one goes alone), COUNT over a string column next to numeric functions:
+    raw ctypes calls on vnm_agg_op_*, equal to the oracle's restatement (OracleGenericAggregate) group for group, types included."""
+    import decimal
+    from oracle import oracle as O
+    rng = np.random.default_rng(4200 + seed)
+    n = int(rng.integers(4000, 15000))
+    words = ["", "a", "A", "ab", "Berlin", "Munich", "San Francisco", "zürich", "0", "00", "été"] + [f"w{int(x)}" for x in rng.integers(0, 300, 50)]
+    kt = [pa.string(), pa.large_string(), pa.binary(), pa.bool_(), pa.decimal128(12, 2), pa.string()][seed % 6]
+    def key_col():
+        if pa.types.is_boolean(kt):
+            return pa.array([None if rng.random() < 0.1 else bool(x) for x in rng.integers(0, 2, n)], type=kt)
+        if pa.types.is_decimal(kt):
+            return pa.array([None if rng.random() < 0.05 else decimal.Decimal(int(x)) / 100 for x in rng.integers(-500, 500, n)], type=kt)
+        v = [None if rng.random() < 0.05 else str(x) for x in rng.choice(words, n)]
+        return pa.array([x.encode() if (x is not None and pa.types.is_binary(kt)) else x for x in v], type=kt)
+    t = pa.table({"g": key_col(), "k": pa.array(rng.integers(-5, 5, n).astype(np.int64), mask=rng.random(n) < 0.05),
+                  "s": pa.array([None if rng.random() < 0.2 else str(x) for x in rng.choice(words, n)], type=pa.string()),
+                  "v": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0, mask=rng.random(n) < 0.1)})
+    two_keys = seed >= 6
+    groupby = ["g", "k"] if two_keys else ["g"]
+    funcs = [(O.COUNT_STAR, "", "n"), (O.COUNT, "s", "cs"), (O.SUM, "v", "sv"), (O.MAX, "v", "xv"), (O.COUNT, "g", "cg")]
+    cuts = sorted(set(int(x) for x in rng.integers(1, n - 1, 3)))
+    bounds = [0] + cuts + [n]
+    batches = [t.slice(a, b - a).combine_chunks().to_batches()[0] for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+    kind = O.MULTI if two_keys else O.SINGLE
+    got = _raw_aggregate(kind, groupby, groupby, funcs, batches)
+    o = O.OracleGenericAggregate(3, groupby, groupby, funcs)
+    for b in batches:
+        o.next(b)
+    exp = o.result()
+    assert got.schema.names == exp.schema.names and [f.type for f in got.schema] == [f.type for f in exp.schema], (got.schema, exp.schema)
+    def keyed(batch):
+        rows = list(zip(*[batch.column(i).to_pylist() for i in range(batch.num_columns)]))
+        return sorted(rows, key=lambda r: tuple((x is None, x if x is not None else 0) for x in r[:len(groupby)]))
+    g_rows, e_rows = keyed(got), keyed(exp)
+    assert len(g_rows) == len(e_rows), f"{len(g_rows)} groups vs {len(e_rows)}"
+    assert g_rows == e_rows, f"first difference {[(a, b) for a, b in zip(g_rows, e_rows) if a != b][:2]}"

@@ -2,8 +2,11 @@
 // (vinum/core/vinum_lib.cpp:54-142: next(batch) per RecordBatch, one result()/sorted()).
 // Batches cross as Arrow C Data Interface structs (no libarrow dependency); columns are staged into HBM,
 // the device-level operators run there, and results come back as freshly allocated Arrow arrays.
+#include <algorithm>
 #include <map>
 #include <memory>
+#include <string>
+#include <vector>
 
 #include "vnm_agg.hpp"
 
@@ -234,8 +237,154 @@ int stage_children(const std::vector<std::unique_ptr<ImportedBatch>>& batches, i
     return rc;
 }
 
+// ---- non-numeric GROUP BY keys and COUNT inputs below the C ABI (round 6) ------------------------------------------------------------
+// GenericHashAggregate (vinum_cpp/src/operators/aggregate/generic_hash_aggregate.h:10-45, bound at vinum/core/vinum_lib.cpp:92-109) keys
+// its map on arrow::Scalar vectors of ANY type.  Here a utf8 / large_utf8 / binary / large_binary key column becomes the int32 codes of a
+// per-operator device string dictionary (vnm_strdict: the bytes cross PCIe once, equal bytes <=> equal code across all batches), a boolean
+// key its 0 / 1, a decimal128 key the index of its 16-byte value in a host map; the codes are an ordinary int32 key column of the numeric
+// operators (NULL stays NULL through the column's own validity bitmap), and result() turns the groups' codes back into values of the
+// column's type.  COUNT over a non-numeric column counts through an int8 stand-in with the column's validity (CountFunc, agg_funcs.h:
+// 129-161, reads nothing but the validity).  MIN / MAX of strings (StringMinMaxFunc, agg_funcs.h:219-261) are not here: the Python shim
+// runs them as MIN / MAX of order-preserving ranks (vinum_lib._StringMinMax).
+enum { GK_NUM = 0, GK_STR, GK_BOOL, GK_DEC };
+struct GenKey {
+    int kind = GK_NUM;
+    bool wide = false;             // 64-bit offsets (large_utf8 / large_binary)
+    vnm_strdict* dict = nullptr;   // GK_STR
+    std::vector<std::string> by_id;       // id -> bytes (ids are handed out in chunks: not dense)
+    std::map<std::pair<uint64_t, uint64_t>, int32_t> dec_id;      // GK_DEC: (low, high) words -> code
+    std::vector<std::pair<uint64_t, uint64_t>> dec_val;
+    ~GenKey() { if (dict) vnm_strdict_destroy(dict); }
+};
+static int generic_kind(const std::string& f, bool* wide) {
+    *wide = f == "U" || f == "Z";
+    if (f == "u" || f == "U" || f == "z" || f == "Z") return GK_STR;
+    if (f == "b") return GK_BOOL;
+    if (f.rfind("d:", 0) == 0 && (f.find(",128") != std::string::npos || std::count(f.begin(), f.end(), ',') == 1)) return GK_DEC;
+    return GK_NUM;
+}
+struct ColChunk { const struct ArrowArray* col; int64_t off, len; };   // rows [off, off + len) of a child array
+static const uint8_t* chunk_validity(const ColChunk& c) { return (c.col->null_count != 0 && c.col->n_buffers > 0) ? (const uint8_t*)c.col->buffers[0] : nullptr; }
+// the chunks' validity laid end to end; empty = no NULL anywhere
+static std::vector<uint8_t> joined_validity(const std::vector<ColChunk>& chunks, int64_t total) {
+    bool any = false;
+    for (auto& c : chunks) any = any || chunk_validity(c) != nullptr;
+    std::vector<uint8_t> bits;
+    if (!any) return bits;
+    bits.assign((size_t)(total + 7) / 8 + 8, 0);
+    int64_t pos = 0;
+    for (auto& c : chunks) {
+        const uint8_t* bm = chunk_validity(c);
+        if (bm) copy_bits(bits.data(), pos, bm, c.off, c.len); else set_bits(bits.data(), pos, c.len);
+        pos += c.len;
+    }
+    return bits;
+}
+// a non-numeric key column -> int32 codes in HBM
+static int stage_generic_key(GenKey& g, const std::vector<ColChunk>& chunks, int64_t total, vnm_dcol* out) {
+    std::vector<int32_t> codes((size_t)(total ? total : 1), -1);
+    int64_t pos = 0;
+    for (auto& c : chunks) {
+        if (!c.len) continue;
+        const uint8_t* valid = chunk_validity(c);
+        auto is_valid = [&](int64_t i) { return !valid || ((valid[(c.off + i) >> 3] >> ((c.off + i) & 7)) & 1); };
+        if (g.kind == GK_STR) {
+            int64_t n_new = 0, new_bytes = 0;
+            VNM_TRY(vnm_strdict_encode(g.dict, c.col->buffers[1], g.wide ? 1 : 0, (const uint8_t*)c.col->buffers[2], valid, c.off, c.len, codes.data() + pos, &n_new, &new_bytes, nullptr));
+            if (n_new > 0) {
+                std::vector<int32_t> ids((size_t)n_new), lens((size_t)n_new);
+                std::vector<uint8_t> bytes((size_t)(new_bytes ? new_bytes : 1));
+                VNM_TRY(vnm_strdict_fetch_new(g.dict, ids.data(), lens.data(), bytes.data()));
+                size_t o = 0;
+                for (int64_t i = 0; i < n_new; i++) {
+                    if ((size_t)ids[(size_t)i] >= g.by_id.size()) g.by_id.resize((size_t)ids[(size_t)i] + 1);
+                    g.by_id[(size_t)ids[(size_t)i]].assign((const char*)bytes.data() + o, (size_t)lens[(size_t)i]);
+                    o += (size_t)lens[(size_t)i];
+                }
+            }
+        } else if (g.kind == GK_BOOL) {
+            const uint8_t* v = (const uint8_t*)c.col->buffers[1];
+            for (int64_t i = 0; i < c.len; i++) if (is_valid(i)) codes[(size_t)(pos + i)] = (v[(c.off + i) >> 3] >> ((c.off + i) & 7)) & 1;
+        } else {
+            const uint64_t* v = (const uint64_t*)c.col->buffers[1];
+            for (int64_t i = 0; i < c.len; i++) {
+                if (!is_valid(i)) continue;
+                const std::pair<uint64_t, uint64_t> key(v[2 * (c.off + i)], v[2 * (c.off + i) + 1]);
+                auto it = g.dec_id.find(key);
+                if (it == g.dec_id.end()) { it = g.dec_id.emplace(key, (int32_t)g.dec_val.size()).first; g.dec_val.push_back(key); }
+                codes[(size_t)(pos + i)] = it->second;
+            }
+        }
+        pos += c.len;
+    }
+    const std::vector<uint8_t> bits = joined_validity(chunks, total);
+    VNM_TRY(vnm_stage_column(codes.data(), bits.empty() ? nullptr : bits.data(), 0, total, VNM_I32, out, nullptr));
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return set_error("staging a key column's codes failed");   // (codes / bits are locals)
+    return 0;
+}
+// COUNT over a non-numeric column: zeros with the column's validity
+static int stage_count_standin(const std::vector<ColChunk>& chunks, int64_t total, vnm_dcol* out) {
+    const std::vector<uint8_t> zeros((size_t)(total ? total : 1), 0);
+    const std::vector<uint8_t> bits = joined_validity(chunks, total);
+    VNM_TRY(vnm_stage_column(zeros.data(), bits.empty() ? nullptr : bits.data(), 0, total, VNM_I8, out, nullptr));
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return set_error("staging a COUNT stand-in failed");
+    return 0;
+}
+// the groups' codes (host: int32 values + validity bytes) -> an Arrow array of the key column's type
+static void make_generic_key_array(struct ArrowArray* a, const GenKey& g, int64_t n, const int32_t* codes, const uint8_t* valid_bytes) {
+    memset(a, 0, sizeof(*a));
+    a->length = n;
+    a->release = release_array;
+    int64_t nulls = 0;
+    for (int64_t i = 0; i < n; i++) nulls += !valid_bytes[i];
+    a->null_count = nulls;
+    uint8_t* bm = nullptr;
+    if (nulls) {
+        bm = (uint8_t*)calloc((size_t)((n + 7) / 8 + 1), 1);
+        for (int64_t i = 0; i < n; i++) if (valid_bytes[i]) bm[i >> 3] |= (uint8_t)(1u << (i & 7));
+    }
+    if (g.kind == GK_STR) {
+        a->n_buffers = 3;
+        a->buffers = (const void**)calloc(3, sizeof(void*));
+        a->buffers[0] = bm;
+        size_t bytes = 0;
+        for (int64_t i = 0; i < n; i++) if (valid_bytes[i] && codes[i] >= 0 && (size_t)codes[i] < g.by_id.size()) bytes += g.by_id[(size_t)codes[i]].size();
+        uint8_t* data = (uint8_t*)malloc(bytes ? bytes : 1);
+        int32_t* o32 = g.wide ? nullptr : (int32_t*)malloc((size_t)(n + 1) * 4);
+        int64_t* o64 = g.wide ? (int64_t*)malloc((size_t)(n + 1) * 8) : nullptr;
+        size_t at = 0;
+        for (int64_t i = 0; i < n; i++) {
+            if (g.wide) o64[i] = (int64_t)at; else o32[i] = (int32_t)at;
+            if (valid_bytes[i] && codes[i] >= 0 && (size_t)codes[i] < g.by_id.size()) {
+                const std::string& v = g.by_id[(size_t)codes[i]];
+                memcpy(data + at, v.data(), v.size());
+                at += v.size();
+            }
+        }
+        if (g.wide) o64[n] = (int64_t)at; else o32[n] = (int32_t)at;
+        a->buffers[1] = g.wide ? (void*)o64 : (void*)o32;
+        a->buffers[2] = data;
+        return;
+    }
+    a->n_buffers = 2;
+    a->buffers = (const void**)calloc(2, sizeof(void*));
+    a->buffers[0] = bm;
+    if (g.kind == GK_BOOL) {
+        uint8_t* v = (uint8_t*)calloc((size_t)((n + 7) / 8 + 1), 1);
+        for (int64_t i = 0; i < n; i++) if (valid_bytes[i] && codes[i] == 1) v[i >> 3] |= (uint8_t)(1u << (i & 7));
+        a->buffers[1] = v;
+        return;
+    }
+    uint64_t* v = (uint64_t*)calloc((size_t)(n ? n : 1) * 2, 8);
+    for (int64_t i = 0; i < n; i++)
+        if (valid_bytes[i] && codes[i] >= 0 && (size_t)codes[i] < g.dec_val.size()) { v[2 * i] = g.dec_val[(size_t)codes[i]].first; v[2 * i + 1] = g.dec_val[(size_t)codes[i]].second; }
+    a->buffers[1] = v;
+}
+
 struct vnm_agg_op {
     int kind;
+    std::vector<std::unique_ptr<GenKey>> gkeys;   // per group-by column: how a non-numeric key travels (GK_NUM: as it is)
+    std::vector<char> standin;                    // per function: COUNT over a non-numeric column (int8 stand-in with its validity)
     std::vector<std::string> groupby, agg_cols, in_cols, out_cols;
     std::vector<int> funcs;
     vnm_agg* dev = nullptr;
@@ -250,7 +399,7 @@ struct vnm_agg_op {
 
 static int agg_op_init(vnm_agg_op* h, const struct ArrowSchema* sch) {
     // a failed earlier attempt (unknown column, unsupported type) must not leave half-filled index vectors behind
-    h->key_idx.clear(); h->key_t.clear(); h->in_idx.clear(); h->in_t.clear(); h->aggcol_key.clear();
+    h->key_idx.clear(); h->key_t.clear(); h->in_idx.clear(); h->in_t.clear(); h->aggcol_key.clear(); h->gkeys.clear(); h->standin.clear();
     if (h->dev) { vnm_agg_destroy(h->dev); h->dev = nullptr; }
     // lookup_col_indices base_aggregate.cpp:121-131
     for (auto& c : h->groupby) {
@@ -258,7 +407,14 @@ static int agg_op_init(vnm_agg_op* h, const struct ArrowSchema* sch) {
         if (i < 0) return set_error("Column not found: %s", c.c_str());
         h->key_idx.push_back(i);
         h->key_t.push_back(parse_format(sch->children[i]->format));
-        if (h->key_t.back().type < 0) return set_error("Unsupported data type for aggregation column.");
+        std::unique_ptr<GenKey> g(new GenKey());
+        if (h->key_t.back().type < 0) {   // a non-numeric key: its codes travel (the column keeps its format for the result)
+            g->kind = generic_kind(h->key_t.back().format, &g->wide);
+            if (g->kind == GK_NUM || h->kind == VNM_ONE_GROUP) return set_error("Unsupported data type for aggregation column.");
+            if (g->kind == GK_STR && !(g->dict = vnm_strdict_create())) return 1;
+            h->key_t.back().type = VNM_I32;
+        }
+        h->gkeys.push_back(std::move(g));
     }
     for (auto& c : h->agg_cols) {
         int pos = -1;
@@ -270,6 +426,7 @@ static int agg_op_init(vnm_agg_op* h, const struct ArrowSchema* sch) {
     std::vector<int> ktypes, itypes, iflags, ids;
     for (auto& t : h->key_t) ktypes.push_back(t.type);
     for (size_t i = 0; i < h->funcs.size(); i++) {
+        h->standin.push_back(0);
         if (h->funcs[i] == VNM_COUNT_STAR || h->in_cols[i].empty()) {
             h->in_idx.push_back(-1);
             h->in_t.push_back(ColType());
@@ -288,7 +445,13 @@ static int agg_op_init(vnm_agg_op* h, const struct ArrowSchema* sch) {
                 default: return set_error("Column data type is not supported by avg().");
             }
         }
-        if (t.type < 0) return set_error("count() over non-numeric columns is not supported on the GPU path yet");
+        if (t.type < 0) {   // COUNT over a non-numeric column: an int8 stand-in with the column's validity (its own column id: the same
+                            // column may also be a key, which travels as codes)
+            h->standin.back() = 1;
+            h->in_t.back().type = VNM_I8;
+            itypes.push_back(VNM_I8); iflags.push_back(0); ids.push_back(1000000 + ci);
+            continue;
+        }
         itypes.push_back(t.type); iflags.push_back(t.flags); ids.push_back(ci);
     }
     h->dev = vnm_agg_create(h->kind, (int)ktypes.size(), ktypes.data(), (int)h->funcs.size(), h->funcs.data(),
@@ -358,23 +521,31 @@ static int agg_op_flush(vnm_agg_op* h) {
     if (h->pending.empty()) return 0;
     const int64_t total = h->pending_rows;
     std::vector<vnm_dcol> keys(h->key_idx.size()), inputs(h->funcs.size());
-    std::map<int, vnm_dcol> staged;
+    std::map<std::pair<int, int>, vnm_dcol> staged;   // (child, form: 0 as it is / 1 key codes / 2 COUNT stand-in)
     int rc = 0;
-    auto get = [&](int ci, const ColType& t, vnm_dcol* out) -> int {
-        auto it = staged.find(ci);
+    auto chunks_of = [&](int ci) {
+        std::vector<ColChunk> v;
+        for (auto& b : h->pending) v.push_back(ColChunk{b->arr.children[ci], b->arr.children[ci]->offset + b->arr.offset, b->arr.length});
+        return v;
+    };
+    auto get = [&](int ci, const ColType& t, vnm_dcol* out, GenKey* g = nullptr, bool standin = false) -> int {
+        const int form = g && g->kind != GK_NUM ? 1 : (standin ? 2 : 0);
+        auto it = staged.find({ci, form});
         if (it == staged.end()) {
             vnm_dcol d;
-            VNM_TRY(stage_children(h->pending, ci, t, total, &d));
-            it = staged.emplace(ci, d).first;
+            if (form == 1) VNM_TRY(stage_generic_key(*g, chunks_of(ci), total, &d));
+            else if (form == 2) VNM_TRY(stage_count_standin(chunks_of(ci), total, &d));
+            else VNM_TRY(stage_children(h->pending, ci, t, total, &d));
+            it = staged.emplace(std::make_pair(ci, form), d).first;
         }
         *out = it->second;
         return 0;
     };
-    for (size_t j = 0; !rc && j < h->key_idx.size(); j++) rc = get(h->key_idx[j], h->key_t[j], &keys[j]);
+    for (size_t j = 0; !rc && j < h->key_idx.size(); j++) rc = get(h->key_idx[j], h->key_t[j], &keys[j], h->gkeys[j].get());
     for (size_t i = 0; !rc && i < h->funcs.size(); i++) {
         memset(&inputs[i], 0, sizeof(vnm_dcol));
         inputs[i].length = total;
-        if (h->in_idx[i] >= 0) rc = get(h->in_idx[i], h->in_t[i], &inputs[i]);
+        if (h->in_idx[i] >= 0) rc = get(h->in_idx[i], h->in_t[i], &inputs[i], nullptr, h->standin[i] != 0);
     }
     if (!rc && total > 0) rc = vnm_agg_next_device(h->dev, total, keys.data(), inputs.data(), nullptr, nullptr);
     if (hipStreamSynchronize(nullptr) != hipSuccess && !rc) rc = set_error("vnm_agg_op_next: stream synchronisation failed");
@@ -421,23 +592,27 @@ int vnm_agg_op_next(vnm_agg_op* h, struct ArrowArray* batch, struct ArrowSchema*
     rc = agg_op_flush(h);   // (rows that arrived earlier go first; the order does not matter to the result)
     if (rc) { ib.drop(); return rc; }
     std::vector<vnm_dcol> keys(h->key_idx.size()), inputs(h->funcs.size());
-    std::map<int, vnm_dcol> staged;
+    std::map<std::pair<int, int>, vnm_dcol> staged;
     hipStream_t s = nullptr;
-    auto get = [&](int ci, const ColType& t, vnm_dcol* out) -> int {
-        auto it = staged.find(ci);
+    auto get = [&](int ci, const ColType& t, vnm_dcol* out, GenKey* g = nullptr, bool standin = false) -> int {
+        const int form = g && g->kind != GK_NUM ? 1 : (standin ? 2 : 0);
+        auto it = staged.find({ci, form});
         if (it == staged.end()) {
             vnm_dcol d;
-            VNM_TRY(stage_child(&ib.arr, ci, t, &d, s));
-            it = staged.emplace(ci, d).first;
+            const std::vector<ColChunk> one{ColChunk{ib.arr.children[ci], ib.arr.children[ci]->offset + ib.arr.offset, ib.arr.length}};
+            if (form == 1) VNM_TRY(stage_generic_key(*g, one, ib.arr.length, &d));
+            else if (form == 2) VNM_TRY(stage_count_standin(one, ib.arr.length, &d));
+            else VNM_TRY(stage_child(&ib.arr, ci, t, &d, s));
+            it = staged.emplace(std::make_pair(ci, form), d).first;
         }
         *out = it->second;
         return 0;
     };
-    for (size_t j = 0; !rc && j < h->key_idx.size(); j++) rc = get(h->key_idx[j], h->key_t[j], &keys[j]);
+    for (size_t j = 0; !rc && j < h->key_idx.size(); j++) rc = get(h->key_idx[j], h->key_t[j], &keys[j], h->gkeys[j].get());
     for (size_t i = 0; !rc && i < h->funcs.size(); i++) {
         memset(&inputs[i], 0, sizeof(vnm_dcol));
         inputs[i].length = ib.arr.length;
-        if (h->in_idx[i] >= 0) rc = get(h->in_idx[i], h->in_t[i], &inputs[i]);
+        if (h->in_idx[i] >= 0) rc = get(h->in_idx[i], h->in_t[i], &inputs[i], nullptr, h->standin[i] != 0);
     }
     if (!rc) rc = vnm_agg_next_device(h->dev, ib.arr.length, keys.data(), inputs.data(), nullptr, (void*)s);
     if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = set_error("vnm_agg_op_next: stream synchronisation failed");
@@ -474,7 +649,16 @@ int vnm_agg_op_result(vnm_agg_op* h, struct ArrowArray* out, struct ArrowSchema*
             const ColType& t = h->key_t[j];
             int64_t nulls = 0;
             rc = vnm_agg_result_key_device(h->dev, j, dv, db, &nulls, nullptr);
-            if (!rc) rc = make_primitive_from_device(out->children[col], n, type_width(t.type), dv, db, nulls);
+            if (!rc && h->gkeys[j]->kind != GK_NUM) {   // the groups' codes -> values of the key column's type
+                std::vector<int32_t> codes((size_t)(n ? n : 1));
+                std::vector<uint8_t> bm((size_t)((n + 7) / 8 + 8), 0xFF), vb((size_t)(n ? n : 1), 1);
+                if (n && hipMemcpy(codes.data(), dv, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = set_error("result: device to host copy failed");
+                if (!rc && nulls && hipMemcpy(bm.data(), db, (size_t)((n + 7) / 8), hipMemcpyDeviceToHost) != hipSuccess) rc = set_error("result: device to host copy failed");
+                if (!rc) {
+                    if (nulls) for (int64_t r = 0; r < n; r++) vb[(size_t)r] = (bm[(size_t)(r >> 3)] >> (r & 7)) & 1;
+                    make_generic_key_array(out->children[col], *h->gkeys[j], n, codes.data(), vb.data());
+                }
+            } else if (!rc) rc = make_primitive_from_device(out->children[col], n, type_width(t.type), dv, db, nulls);
             make_schema(out_schema->children[col], t.format, h->agg_cols[a], 0);
         }
         for (size_t i = 0; !rc && i < h->funcs.size(); i++, col++) {
@@ -514,6 +698,13 @@ int vnm_agg_op_result(vnm_agg_op* h, struct ArrowArray* out, struct ArrowSchema*
         VNM_TRY(vnm_agg_result_key(h->dev, j, vals.data(), valid.data()));
         const ColType& t = h->key_t[j];
         int w = type_width(t.type);
+        if (h->gkeys[j]->kind != GK_NUM) {
+            std::vector<int32_t> codes((size_t)(n ? n : 1));
+            for (int64_t r = 0; r < n; r++) codes[(size_t)r] = (int32_t)vals[(size_t)r];
+            make_generic_key_array(out->children[col], *h->gkeys[j], n, codes.data(), valid.data());
+            make_schema(out_schema->children[col], t.format, h->agg_cols[a], 0);
+            continue;
+        }
         std::vector<uint8_t> narrow((size_t)(n ? n : 1) * w);
         for (int64_t r = 0; r < n; r++) memcpy(&narrow[(size_t)r * w], &vals[r], (size_t)w);  // little endian truncation
         make_primitive(out->children[col], n, w, narrow.data(), valid.data());

@@ -104,11 +104,35 @@ def _canonical_order(batch: pa.RecordBatch, key_names):
     for k in key_names:
         a = batch.column(batch.schema.names.index(k))
         valid = np.ones(len(a), bool) if a.null_count == 0 else a.is_valid().to_numpy(zero_copy_only=False)
+        if _abi_generic_key(a.type) or not hasattr(a.type, "bit_width") or a.type.bit_width not in (8, 16, 32, 64):
+            # strings / binaries / bools / decimals (group keys the library encodes itself since round 6): ranks of the distinct values
+            import pyarrow.compute as pc
+            enc = (a.combine_chunks() if isinstance(a, pa.ChunkedArray) else a).dictionary_encode()
+            d = enc.dictionary
+            if pa.types.is_string(d.type) or pa.types.is_large_string(d.type):
+                d = d.cast(pa.large_binary() if pa.types.is_large_string(d.type) else pa.binary())
+            order = pc.sort_indices(d).to_numpy(zero_copy_only=False) if len(d) else np.zeros(0, np.int64)
+            rank_of = np.empty(len(d), np.uint64)
+            rank_of[order] = np.arange(len(d), dtype=np.uint64)
+            idx = enc.indices.fill_null(0).to_numpy(zero_copy_only=False).astype(np.int64)
+            raw = rank_of[idx] if len(d) else np.zeros(len(a), np.uint64)
+            keys.append((~valid).astype(np.uint8))
+            keys.append(np.where(valid, raw, 0))
+            continue
         w = a.type.bit_width // 8
         raw = a.view({1: pa.uint8(), 2: pa.uint16(), 4: pa.uint32(), 8: pa.uint64()}[w]).fill_null(0).to_numpy(zero_copy_only=False)
         keys.append((~valid).astype(np.uint8))
         keys.append(np.where(valid, raw.astype(np.uint64), 0))
     return np.lexsort(keys[::-1])
+
+
+def _abi_generic_key(t) -> bool:
+    """non-numeric key types vnm_agg_op_* encode below the C ABI (vnm_arrow.cpp: GenKey)"""
+    import os
+    if os.environ.get("VNM_GENERIC_BELOW_ABI", "1") == "0":
+        return False
+    return (pa.types.is_string(t) or pa.types.is_large_string(t) or pa.types.is_binary(t) or pa.types.is_large_binary(t) or
+            pa.types.is_boolean(t) or (pa.types.is_decimal(t) and t.bit_width == 128))
 
 
 class _StringMinMax:
@@ -260,14 +284,18 @@ class _HashAggregateBase:
             self._strmm = _StringMinMax(type(self), self._groupby, str_funcs)
 
     def _numeric_view(self, batch: pa.RecordBatch) -> pa.RecordBatch:
-        """what crosses the boundary: numeric columns as they are, COUNT-only non-numeric columns as their int8 stand-ins"""
+        """what crosses the boundary: numeric columns as they are, COUNT-only non-numeric columns as their int8 stand-ins; group-by
+        columns of the types the library dictionary-encodes itself (round 6: vnm_agg_op_* take utf8 / binary / bool / decimal128 keys)
+        as they are"""
         import numpy as np
         if not self._stand_in and self._strmm is None:
             return batch
         arrays, names = [], []
         for i, name in enumerate(batch.schema.names):
             col = batch.column(i)
-            if name in self._stand_in:
+            if name in self._groupby and _abi_generic_key(col.type):
+                pass
+            elif name in self._stand_in:
                 col = pa.array(np.zeros(len(col), np.int8), mask=(~col.is_valid().to_numpy(zero_copy_only=False)) if col.null_count else None)
             elif not _is_numeric(col.type):
                 continue
@@ -594,7 +622,7 @@ class GenericHashAggregate:
             if c not in schema.names:
                 raise RuntimeError(f"Column not found: {c}")       # base_aggregate.cpp:121-131
             t = schema.field(c).type
-            if not _is_numeric(t):
+            if not _is_numeric(t) and not _abi_generic_key(t):     # (strings, binaries, bools, decimal128: the library's own dictionary since round 6)
                 self._dicts[c] = KeyDictionary(t)
         # (functions over non-numeric columns -- COUNT, string MIN / MAX -- are the numeric classes' business: _first_batch)
         # A non-numeric column that is group key AND aggregate input (`SELECT city, min(city), count(city) ... GROUP BY city`,
@@ -639,7 +667,7 @@ class GenericHashAggregate:
                     arrays.append(col)
                     names.append(self._alias[name])
                 col = self._dicts[name].encode(col)
-            elif not _is_numeric(col.type) and name not in fn_inputs:
+            elif not _is_numeric(col.type) and name not in fn_inputs and name not in self._groupby:
                 continue                                     # neither a key nor an input: never staged
             arrays.append(col)
             names.append(name)
