@@ -432,3 +432,38 @@ def test_generic_keys_through_the_raw_c_abi(seed):
     g_rows, e_rows = keyed(got), keyed(exp)
     assert len(g_rows) == len(e_rows), f"{len(g_rows)} groups vs {len(e_rows)}"
     assert g_rows == e_rows, f"first difference {[(a, b) for a, b in zip(g_rows, e_rows) if a != b][:2]}"
+
+
+def test_string_min_max_over_a_long_stream_keeps_a_bounded_number_of_partials():
+    """string MIN / MAX kept one partial result (groups x functions, as host strings) per input batch until
+    result().  300 batches: the partials are folded every eight batches; same answer as pyarrow's group_by."""
+    from vinum_amd import vinum_lib as vl
+    rng = np.random.default_rng(12)
+    words = [f"w{int(x):04d}" for x in range(500)] + ["", "Zebra", "äpfel"]
+    agg = vl.SingleNumericalHashAggregate(["k"], ["k"], [vl.AggFuncDef(vl.MIN, "s", "mn"), vl.AggFuncDef(vl.MAX, "s", "mx"), vl.AggFuncDef(vl.COUNT_STAR, "", "n")])
+    agg._SMALL_ROWS = 1            # (every batch crosses the boundary on its own: no coalescing in the wrapper)
+    tables = []
+    for i in range(300):
+        n = 2000
+        t = pa.table({"k": pa.array(rng.integers(0, 40, n).astype(np.int64)),
+                      "s": pa.array([None if rng.random() < 0.1 else str(x) for x in rng.choice(words, n)], type=pa.string())})
+        tables.append(t)
+        for b in t.to_batches():
+            agg.next(b)
+        if agg._strmm is not None:
+            assert len(agg._strmm._partials) <= 8
+    got = agg.result().to_pydict()
+    exp = pa.concat_tables(tables).group_by("k", use_threads=False).aggregate([("s", "min"), ("s", "max"), ([], "count_all")]).to_pydict()
+    g = {k: (a, b, int(c)) for k, a, b, c in zip(got["k"], got["mn"], got["mx"], got["n"])}
+    e = {k: (a.encode() if a is not None else None, b.encode() if b is not None else None, c) for k, a, b, c in zip(exp["k"], exp["s_min"], exp["s_max"], exp["count_all"])}
+    # (byte-wise order, as StringMinMaxFunc compares string_views: agg_funcs.h:219-261)
+    import collections
+    by = collections.defaultdict(list)
+    for t in tables:
+        for k, s_ in zip(t.column("k").to_pylist(), t.column("s").to_pylist()):
+            if s_ is not None:
+                by[k].append(s_.encode())
+    for k in e:
+        mn, mx = (min(by[k]), max(by[k])) if by[k] else (None, None)
+        ga = g[k]
+        assert (ga[0].encode() if ga[0] is not None else None, ga[1].encode() if ga[1] is not None else None, ga[2]) == (mn, mx, e[k][2]), (k, ga, mn, mx)
