@@ -159,7 +159,7 @@ def test_fixed_point_heavy_group_total_beyond_2e53_quanta(monkeypatch):
     util.assert_agg_equal(got, _oracle(funcs, batches), funcs, ["k"], exact_float_inputs=(), what="totals beyond 2^53 quanta", source=batches)
 
 
-@pytest.mark.parametrize("groups", [1_500_000, 6_000_000])           # one scatter level / two levels
+@pytest.mark.parametrize("groups", [6_000_000, 12_000_000])          # (two scatter levels: the split final pass of smaller ranges keeps its compensation words)
 def test_exact_adds_without_compensation_words(groups, monkeypatch):
     """Values that do NOT fit 31 bits of one quantum (45 significant bits) but whose sums are provably exact (rows * max < 2^53 quanta):
     float64 entries, final pass with {sum, count} slots and non-returning atomics (route dense:exact_adds).  Bit-equal to the oracle."""
@@ -467,3 +467,38 @@ def test_string_min_max_over_a_long_stream_keeps_a_bounded_number_of_partials():
         mn, mx = (min(by[k]), max(by[k])) if by[k] else (None, None)
         ga = g[k]
         assert (ga[0].encode() if ga[0] is not None else None, ga[1].encode() if ga[1] is not None else None, ga[2]) == (mn, mx, e[k][2]), (k, ga, mn, mx)
+
+
+def test_float32_predicate_literal_after_the_ordered_switch():
+    """`WHERE v > 0.1` over a float32 column compares in float32 (NumPy: float32 array against a Python scalar): float32(0.1)
+    is NOT above the literal.  The column travels widened and the literal rounded; an operator that has switched to the ordered
+    float MIN / MAX mode (a NaN in batch 2) feeds its suffix operator the widened column too -- a set_predicate after the switch must reach
+    it as the same rounded number."""
+    from oracle import oracle as O
+    from vinum_amd.device import DeviceColumn
+    from vinum_amd import ops
+    rng = np.random.default_rng(8)
+    tenth = np.float32(0.1)
+    def batch(n, with_nan):
+        v = rng.choice(np.array([0.05, 0.1, 0.25, 3.0, -1.0], np.float32), n)
+        if with_nan:
+            v[::97] = np.nan
+        return pa.RecordBatch.from_pydict({"k": pa.array(rng.integers(0, 50, n).astype(np.int64)), "v": pa.array(v)})
+    batches = [batch(40_000, False), batch(40_000, True), batch(40_000, False)]
+    funcs = [(O.MIN, "v", "lo"), (O.MAX, "v", "hi"), (O.COUNT, "v", "c"), (O.SUM, "v", "s")]
+    fspec = [(f, 1, pa.float32()) for f, _, _ in funcs]
+    agg = ops.DeviceAggregate(O.SINGLE, [pa.int64()], fspec)
+    agg.set_predicate(">", 0.1)
+    for i, b in enumerate(batches):
+        if i == 2:
+            agg.set_predicate(">", 0.1)        # (again, after the switch: the suffix operator exists by now)
+        kc, vc = DeviceColumn.from_arrow(b.column(0)), DeviceColumn.from_arrow(b.column(1))
+        agg.next([kc], [vc] * 4, pred=vc, nrows=b.num_rows)
+    got = agg.result_arrays([0], ["k"], [f[2] for f in funcs])
+    agg.close()
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in batches:
+        v = b.column(1).to_numpy(zero_copy_only=False)
+        with np.errstate(invalid="ignore"):
+            o.next(O.filter_batch(b, np.asarray(v > tenth)))   # float32 comparison (NaN > x is False)
+    util.assert_agg_equal(got, o.result(), funcs, ["k"], exact_float_inputs=("v",), what="float32 predicate literal after the switch")

@@ -972,19 +972,31 @@ static int widen_inputs(vnm_agg* h, int64_t nrows, const vnm_dcol** inputs, vnm_
             win[i].length = nrows;
         }
     }
+    bool pred_widened = false;
     if (*pred && (*pred)->type == VNM_F32) {
         for (int i = 0; i < h->n_funcs; i++) {
             if (!h->widen_in[i] || in[i].values != (*pred)->values || in[i].offset != (*pred)->offset || in[i].validity != (*pred)->validity) continue;
             *wpred = win[i];
             *pred = wpred;
-            if (h->pred_set && !h->pred_lit_rounded) {
-                const double lit = h->pred_is_float ? h->pred_dval : (double)h->pred_ival;
-                h->pred_dval = (double)(float)lit;
-                h->pred_is_float = 1;
-                h->pred_lit_rounded = true;
-            }
+            pred_widened = true;
             break;
         }
+    }
+    // The EFFECTIVE literal of this batch: the caller's literal rounded to float32 when the predicate column is a float32 column
+    // that travels widened (NumPy compares float32 against the literal in float32), the caller's own literal otherwise -- a later batch
+    // whose predicate column is not widened gets it back -- and the suffix operator of an ordered MIN / MAX stream (fed the widened
+    // column) compares with the same number as this handle.
+    if (h->pred_set) {
+        if (pred_widened) {
+            const double lit = h->pred_user_is_float ? h->pred_user_dval : (double)h->pred_user_ival;
+            h->pred_dval = (double)(float)lit;
+            h->pred_is_float = 1;
+            h->pred_lit_rounded = true;
+        } else if (h->pred_lit_rounded) {
+            h->pred_dval = h->pred_user_dval; h->pred_is_float = h->pred_user_is_float; h->pred_ival = h->pred_user_ival;
+            h->pred_lit_rounded = false;
+        }
+        if (h->ex && h->ex->post) { h->ex->post->pred_dval = h->pred_dval; h->ex->post->pred_is_float = h->pred_is_float; h->ex->post->pred_ival = h->pred_ival; }
     }
     *inputs = win;
     return 0;
