@@ -198,7 +198,7 @@ def test_inexact_values_keep_the_compensated_pass(monkeypatch):
     before = _routes()
     got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches)
     assert _took(before, "dense:fixed_point") == 0 and _took(before, "dense:exact_adds") == 0
-    util.assert_agg_equal(got, _oracle(funcs, batches), funcs, ["k"], what="lognormal", source=batches)
+    util.assert_agg_equal(got, _oracle(funcs, batches), funcs, ["k"], exact_float_inputs=(), what="lognormal", source=batches)
 
 
 @pytest.mark.parametrize("mode", ["stream", "sync"])
@@ -502,3 +502,81 @@ def test_float32_predicate_literal_after_the_ordered_switch():
         with np.errstate(invalid="ignore"):
             o.next(O.filter_batch(b, np.asarray(v > tenth)))   # float32 comparison (NaN > x is False)
     util.assert_agg_equal(got, o.result(), funcs, ["k"], exact_float_inputs=("v",), what="float32 predicate literal after the switch")
+
+
+class _RawI64w:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+
+
+@pytest.mark.parametrize("case", ["f64_uniform", "f64_normal_desc", "f64_lognormal", "i64_wide", "u64_desc", "few_duplicates", "nan_and_zeros", "outside_the_sample",
+                                  "duplicates_decline", "lumpy_declines", "fanout_64", "fanout_512", "fanout_16_native", "odd_unaligned", "f32_widened"])
+def test_entry_word_sample_sort_equals_the_lsd_sort(case, monkeypatch):
+    """vnm_sort_indices over one 8-byte key when only the order is asked for (vnm_sort_apx.inc): rows travel as 8-byte words
+    (a32 << 32 | row id) where a32 comes from an equalising piecewise-linear map of the code; two entries with the same a32 are
+    ordered through the key column.  The row ids must equal the eight-pass LSD sort's (the order is total: key, then row id --
+    Sort::Sorted is stable, sort.cpp:22-40).  Data with duplicated keys or a lumpy distribution must decline (and still be right)."""
+    import torch
+    from vinum_amd import _lib as L
+    from vinum_amd import ops
+    from vinum_amd.device import DeviceColumn
+    rng = np.random.default_rng(4242)
+    n = 3_000_000
+    order = L.ASC
+    taken = True
+    if case == "f64_uniform":
+        v = rng.random(n)
+    elif case == "f64_normal_desc":
+        v = rng.normal(0.0, 1.0, n); order = L.DESC
+    elif case == "f64_lognormal":
+        v = np.exp(rng.normal(0.0, 6.0, n))
+    elif case == "i64_wide":
+        v = rng.integers(-2**62, 2**62, n).astype(np.int64)
+    elif case == "u64_desc":
+        v = rng.integers(0, 2**63, n).astype(np.uint64) * 2 + rng.integers(0, 2, n).astype(np.uint64); order = L.DESC
+    elif case == "few_duplicates":                     # 1 % of the rows repeat another row's key: ordered through the key column
+        v = rng.normal(0.0, 1.0, n); src = rng.integers(0, n, n // 100); v[rng.integers(0, n, n // 100)] = v[src]
+    elif case in ("nan_and_zeros", "outside_the_sample"):
+        # rows the strided sample (row i * n / m) does not see: NaN / -0.0 / +0.0, values below and above everything sampled
+        m = 65536
+        monkeypatch.setenv("VNM_XSORT_SAMPLE", str(m))
+        sampled = np.zeros(n, dtype=bool); sampled[(np.arange(m, dtype=np.int64) * n) // m] = True
+        free = np.nonzero(~sampled)[0]
+        pick = free[rng.choice(len(free), 200, replace=False)]
+        v = rng.normal(0.0, 1.0, n)
+        if case == "nan_and_zeros":
+            v[pick[:60]] = np.nan; v[pick[60:120]] = -0.0; v[pick[120:180]] = 0.0
+        else:
+            v[pick[:80]] = -1e300; v[pick[80:160]] = 1e300; v[pick[160]] = -np.inf; v[pick[161]] = np.inf; v[pick[162:200]] = 1e-300
+    elif case == "duplicates_decline":
+        v = rng.integers(0, n // 4, n).astype(np.float64); taken = False
+    elif case == "lumpy_declines":                     # tight clusters: not linear inside a cell
+        v = rng.integers(0, 50, n).astype(np.float64) * 1000.0 + rng.random(n) * 1e-6; taken = False
+    elif case in ("fanout_64", "fanout_512"):
+        monkeypatch.setenv("VNM_XSORT_L2", case.split("_")[1]); v = rng.normal(5.0, 2.0, n)
+    elif case == "fanout_16_native":
+        n = (1 << 25) + 12345; v = rng.random(n) * 1e6 - 5e5; order = L.DESC
+    elif case == "odd_unaligned":
+        n = 2_999_999 + 4096 * 3 + 17; v = rng.normal(0.0, 1.0, n)
+    elif case == "f32_widened":
+        n = (1 << 21) + 77; v = rng.permutation(np.arange(n, dtype=np.int64) * 2000 - 2**31 + 5).astype(np.int32)    # distinct int32 keys
+    else:
+        raise AssertionError(case)
+    if case == "odd_unaligned":
+        arr = pa.array(np.concatenate([[0.0] * 3, v])).slice(3, n)      # an odd Arrow offset: no 16-byte pairs
+        col = DeviceColumn.from_arrow(arr)
+    else:
+        t = torch.from_numpy(v.view(np.int64) if v.dtype == np.uint64 else v).cuda()
+        col = DeviceColumn.from_torch(t)
+        if v.dtype == np.uint64:
+            col = DeviceColumn(col._values, None, 0, n, pa.uint64(), keep=t)
+    monkeypatch.setenv("VNM_SORT_NO_SAMPLE", "1")
+    ref_idx = ops.sort_indices([col], [order])
+    ref = torch.as_tensor(_RawI64w(ref_idx.ptr, n), device="cuda").clone()
+    monkeypatch.delenv("VNM_SORT_NO_SAMPLE")
+    monkeypatch.setenv("VNM_SSORT_MIN_ROWS", "1000")
+    before = _routes()
+    got_idx = ops.sort_indices([col], [order])
+    assert (_took(before, "sort:sample_sort_words") >= 1) == taken, (case, _took(before, "sort:sample_sort_words"))
+    got = torch.as_tensor(_RawI64w(got_idx.ptr, n), device="cuda")
+    assert bool(torch.equal(got, ref)), f"{case}: {int((got != ref).sum())} positions differ"

@@ -664,6 +664,7 @@ static int grid_for(int64_t n, int per_cu = 8) {
 }
 
 #include "vnm_sort_sample.inc"
+#include "vnm_sort_apx.inc"
 
 // Sample sort of one 8-byte key without a validity bitmap (see vnm_sort_sample.inc).  0 = done (idx_out written, *wrote_key),
 // 2 = not applicable / a bucket outgrew its room (the caller sorts with the LSD passes), 1 = error.
@@ -1117,6 +1118,17 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
     if (n_keys == 1 && (!keys[0].validity || getenv("VNM_SSORT_NO_NULLS") == nullptr) && (keys[0].type == VNM_F64 || keys[0].type == VNM_I64 || keys[0].type == VNM_U64) &&
         n >= env_sort_i64("VNM_SSORT_MIN_ROWS", (int64_t)1 << 25) && getenv("VNM_SORT_NO_SAMPLE") == nullptr) {
         bool wk = false;
+        // only the order is asked for: 8-byte entry words (an equalising map of the code + row id) instead of (code, row id) -- the
+        // sample decides (duplicated keys, lumpy distributions keep the splitters)
+        if (!out_sorted_key0 && env_sort_i64("VNM_SORT_APX", 1)) {
+            const int rx = sample_sort_apx(keys[0], orders[0] == VNM_DESC, n, out_indices, s);
+            if (rx == 1) return 1;
+            if (rx == 0) {
+                route_note("sort:sample_sort_words", "%lld rows, one 8-byte key, order only: an equalising map from a sample, two scatters of 8-byte entry words, per-bucket LDS sort", (long long)n);
+                if (wrote_key0) *wrote_key0 = 0;
+                return 0;
+            }
+        }
         route_note("sort:sample_sort", "%lld rows, one 8-byte key: splitters from a sample, two bucket scatters, per-bucket LDS sort", (long long)n);
         const int rc = sample_sort(keys[0], orders[0] == VNM_DESC, n, out_indices, (uint64_t*)out_sorted_key0, &wk, s);
         if (rc == 1) return 1;
@@ -1135,6 +1147,17 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
             wk8.values = wide; wk8.length = n;
             wk8.type = keys[0].type == VNM_F32 ? VNM_F64 : (keys[0].type == VNM_I32 ? VNM_I64 : VNM_U64);
             bool wkey = false;
+            if (env_sort_i64("VNM_SORT_APX", 1)) {
+                const int rx = sample_sort_apx(wk8, orders[0] == VNM_DESC, n, out_indices, s);
+                if (rx == 1) { pool_free(wide); return 1; }
+                if (rx == 0) {
+                    route_note("sort:sample_sort_words", "%lld rows, one 4-byte key widened to 8 bytes, order only: two scatters of 8-byte entry words, per-bucket LDS sort", (long long)n);
+                    (void)hipStreamSynchronize(s);
+                    pool_free(wide);
+                    if (wrote_key0) *wrote_key0 = 0;
+                    return 0;
+                }
+            }
             route_note("sort:sample_sort", "%lld rows, one 4-byte key widened to 8 bytes: splitters from a sample, two bucket scatters, per-bucket LDS sort", (long long)n);
             rc = sample_sort(wk8, orders[0] == VNM_DESC, n, out_indices, nullptr, &wkey, s);
         }

@@ -206,12 +206,15 @@ class _StringMinMax:
         return pa.array(ranks, type=pa.int32(), mask=mask), d.take(pa.array(order))
 
     def next(self, key_arrays, batch: pa.RecordBatch) -> None:
-        ranks, dicts, names_of = {}, {}, []
+        # (the rank columns get names of their own: the aggregated column may be a group-by column as well, and a batch with two
+        #  columns of one name has no field-by-name)
+        ranks, dicts, names_of, rank_name = {}, {}, [], {}
         for f in self._funcs:
             c = f.column_name
-            if c not in ranks:
-                ranks[c], dicts[c] = self._ranks(batch.column(batch.schema.names.index(c)))
-            names_of.append(c)
+            if c not in rank_name:
+                rank_name[c] = f"__vnm_rank{len(rank_name)}"
+                ranks[rank_name[c]], dicts[c] = self._ranks(batch.column(batch.schema.names.index(c)))
+            names_of.append(rank_name[c])
         res = self._aggregate(key_arrays, ranks, names_of)
         nk = len(self._groupby)
         cand = [dicts[f.column_name].take(res.column(nk + i)) for i, f in enumerate(self._funcs)]     # NULL rank -> NULL string
