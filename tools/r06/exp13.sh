@@ -13,9 +13,10 @@ j=json.loads(open('gpurun_out/r06/sort_apx_$apx.json').read())
 print(j['ms_per_step'], j.get('check'), j['roofline'].get('kernels_ms'))
 PY
 done
-for v in "VNM_XSORT_GRID1_PER_CU=2" "VNM_XSORT_PAIRS1=1" "VNM_XSORT_PAIRS2=1" "VNM_XSORT_NT=1" "VNM_XSORT_LOCAL_PER_CU=24" "VNM_XSORT_LOCAL_PER_CU=12" "VNM_XSORT_GRID1_PER_CU=2 VNM_XSORT_PAIRS1=1 VNM_XSORT_PAIRS2=1"; do
+for v in "VNM_XSORT_GRID1_PER_CU=2" "VNM_XSORT_NT=1" "VNM_XSORT_LOCAL_PER_CU=24" "VNM_XSORT_LOCAL_PER_CU=96" "VNM_XSORT_SAMPLE=1048576" "VNM_XSORT_SPLIT2=2"; do
   echo "== $v"
-  env $v timeout 600 python bench.py --no-cpu-baseline --no-also --no-check --workload topk --limit 0 --steps 5 --warmup 2 2>/dev/null | tail -1 | python -c "
+  env $v VNM_SORT_TRACE=1 timeout 600 python bench.py --no-cpu-baseline --no-also --no-check --workload topk --limit 0 --steps 5 --warmup 2 2>gpurun_out/r06/x.err | tail -1 | python -c "
 import json,sys
 j=json.loads(sys.stdin.read()); print(j['ms_per_step'], j['roofline'].get('kernels_ms'))"
+  grep "long kernel" gpurun_out/r06/x.err | tail -1
 done
