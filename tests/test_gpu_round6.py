@@ -580,3 +580,45 @@ def test_entry_word_sample_sort_equals_the_lsd_sort(case, monkeypatch):
     assert (_took(before, "sort:sample_sort_words") >= 1) == taken, (case, _took(before, "sort:sample_sort_words"))
     got = torch.as_tensor(_RawI64w(got_idx.ptr, n), device="cuda")
     assert bool(torch.equal(got, ref)), f"{case}: {int((got != ref).sum())} positions differ"
+
+
+@pytest.mark.parametrize("groups", [1_500_000, 12_000_000])
+@pytest.mark.parametrize("what", ["null_keys", "null_keys_pred_on_other", "null_values", "null_values_misfit"])
+def test_fixed_point_entries_with_nulls_vs_oracle(what, groups, monkeypatch):
+    """Fixed-point entry words with a NULLABLE key (pass 1 sums the NULL-key rows aside, dring_scatter_kernel<..., KN, ..., FX>) and with a
+    nullable VALUE column that the query's own filter reads (vn_fold: NULL > x is not true, the rows never become entries).  Equal to the oracle;
+    a misfit among the surviving values still redoes the batch with float64 entries."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(groups % 911 + len(what))
+    n = 2_400_000
+    k = rng.integers(0, groups, n).astype(np.int64)
+    v = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
+    kmask = vmask = None
+    cols = {}
+    if what.startswith("null_keys"):
+        kmask = rng.random(n) < 0.12
+    else:
+        vmask = rng.random(n) < 0.05
+        if what == "null_values_misfit":
+            v[n // 2 + 7] = 100.0 + 2.0**-30        # (a surviving value that is no multiple of the quantum)
+            v[5] = 1e-300; vmask[5] = True          # (a NULL slot with bits that would not fit: never looked at)
+    cols["k"] = pa.array(k, mask=kmask)
+    cols["v"] = pa.array(v, mask=vmask)
+    pred_col = "v"
+    if what == "null_keys_pred_on_other":
+        cols["p"] = pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0)
+        pred_col = "p"
+    t = pa.table(cols)
+    batches = t.combine_chunks().to_batches()
+    predicate = (pred_col, ">", 64.0)
+    funcs = _hot_funcs()
+    before = _routes()
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=predicate)
+    assert _took(before, "dense:fixed_point") >= 1, _routes()
+    if what == "null_values_misfit":
+        assert _took(before, "dense:fixed_point_misfit") >= 1
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in batches:
+        o.next(O.filter_batch(b, O.cmp_mask(b.column(b.schema.names.index(pred_col)), O.GT, 64.0)))
+    util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"fixed point + {what} G={groups}")
