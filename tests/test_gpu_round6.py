@@ -623,3 +623,73 @@ def test_fixed_point_entries_with_nulls_vs_oracle(what, groups, monkeypatch):
     for b in batches:
         o.next(O.filter_batch(b, O.cmp_mask(b.column(b.schema.names.index(pred_col)), O.GT, 64.0)))
     util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"fixed point + {what} G={groups}")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_string_min_max_through_the_raw_c_abi(seed):
+    """StringMinMaxFunc (agg_funcs.h:219-261; Single_/Multi_/Generic_Int64Grp_StringArgFuncs, hash_agg_test.cpp:866-894) below the C ABI:
+    MIN / MAX over utf8 / large_utf8 / binary / large_binary columns next to numeric functions and COUNT over the same column, with an
+    int64 key, a string key, two keys, no key at all; NULLs, all-NULL groups, empty strings, values first seen in later batches, small
+    batches that wait and a large one that goes alone.  Raw ctypes calls on vnm_agg_op_*; equal to the oracle's row loop, types included."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(5200 + seed)
+    n = int(rng.integers(4000, 15000))
+    words = ["", "a", "A", "ab", "abc", "Berlin", "Munich", "San Francisco", "zürich", "0", "00", "été", "a\x00b", "a\x00"] + [f"w{int(x)}" for x in rng.integers(0, 300, 50)]
+    st = [pa.string(), pa.large_string(), pa.binary(), pa.large_binary()][seed % 4]
+    def str_col(null_p, typ=st, pool=words):
+        v = [None if rng.random() < null_p else str(x) for x in rng.choice(pool, n)]
+        return pa.array([x.encode() if (x is not None and (pa.types.is_binary(typ) or pa.types.is_large_binary(typ))) else x for x in v], type=typ)
+    k = rng.integers(-20, 20, n).astype(np.int64)
+    s = str_col(0.2).to_pylist()
+    for i in range(n):                      # (some groups see NULLs only)
+        if k[i] in (-7, 3):
+            s[i] = None
+    t = pa.table({"k": pa.array(k, mask=rng.random(n) < 0.05), "g": str_col(0.05, pa.string(), ["x", "y", "zz", "", "Ω"]),
+                  "s": pa.array(s, type=st), "s2": str_col(0.5, pa.string()),
+                  "v": pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0, mask=rng.random(n) < 0.1)})
+    shape = ["int_key", "string_key", "two_keys", "one_group", "strings_only", "int_key"][seed % 6]
+    groupby = {"int_key": ["k"], "string_key": ["g"], "two_keys": ["g", "k"], "one_group": [], "strings_only": ["k"]}[shape]
+    funcs = [(O.MIN, "s", "mn"), (O.COUNT_STAR, "", "n"), (O.MAX, "s", "mx"), (O.COUNT, "s", "cs"), (O.SUM, "v", "sv"), (O.MIN, "s2", "mn2"), (O.MAX, "v", "xv")]
+    if shape == "strings_only":
+        funcs = [(O.MAX, "s", "mx"), (O.MIN, "s", "mn")]
+    cuts = sorted(set(int(x) for x in rng.integers(1, n - 1, 3)))
+    bounds = [0] + cuts + [n]
+    batches = [t.slice(a, b - a).combine_chunks().to_batches()[0] for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+    kind = {0: O.ONE_GROUP, 1: O.SINGLE, 2: O.MULTI}[len(groupby)]
+    got = _raw_aggregate(kind, groupby, groupby, funcs, batches)
+    o = O.OracleGenericAggregate(3 if groupby else O.ONE_GROUP, groupby, groupby, funcs)
+    for b in batches:
+        o.next(b)
+    exp = o.result()
+    assert got.schema.names == exp.schema.names and [f.type for f in got.schema] == [f.type for f in exp.schema], (got.schema, exp.schema)
+    def keyed(batch):
+        rows = list(zip(*[batch.column(i).to_pylist() for i in range(batch.num_columns)]))
+        return sorted(rows, key=lambda r: tuple((x is None, x if x is not None else 0) for x in r[:len(groupby)]))
+    g_rows, e_rows = keyed(got), keyed(exp)
+    assert len(g_rows) == len(e_rows), f"{len(g_rows)} groups vs {len(e_rows)}"
+    assert g_rows == e_rows, f"first difference {[(a, b) for a, b in zip(g_rows, e_rows) if a != b][:2]}"
+
+
+def test_string_min_max_below_the_abi_folds_its_candidates():
+    """Many groups and several device-sized batches: every batch leaves one candidate per group and function in HBM, and the chunks are
+    folded when they hold more than twice the groups -- the candidates' ids are ranked against the dictionary of THAT moment (values that
+    arrive later sort between earlier ones).  Equal to pyarrow's group_by over the binary column (byte-wise order)."""
+    rng = np.random.default_rng(99)
+    groups, nb, rows = 90_000, 6, (1 << 20) + 4096
+    tables = []
+    for i in range(nb):
+        k = rng.integers(0, groups, rows).astype(np.int64)
+        # later batches bring values that sort BEFORE and BETWEEN the earlier ones
+        x = rng.integers(0, 400_000, rows) * (nb - i)
+        sv = pa.array(np.char.add("v", np.char.zfill(x.astype(str), 8)), mask=rng.random(rows) < 0.1)
+        tables.append(pa.table({"k": pa.array(k), "s": sv.cast(pa.binary())}))
+    from oracle import oracle as O
+    funcs = [(O.MIN, "s", "mn"), (O.MAX, "s", "mx"), (O.COUNT_STAR, "", "n")]
+    got = _raw_aggregate(O.SINGLE, ["k"], ["k"], funcs, [t.combine_chunks().to_batches()[0] for t in tables])
+    exp = pa.concat_tables(tables).group_by("k", use_threads=False).aggregate([("s", "min"), ("s", "max"), ([], "count_all")])
+    g = pa.Table.from_batches([got]).sort_by("k")
+    e = exp.sort_by("k")
+    assert g.num_rows == e.num_rows == len(set(np.concatenate([t.column("k").to_numpy() for t in tables]).tolist()))
+    assert g.column("mn").combine_chunks().equals(e.column("s_min").combine_chunks())
+    assert g.column("mx").combine_chunks().equals(e.column("s_max").combine_chunks())
+    assert g.column("n").to_pylist() == e.column("count_all").to_pylist()

@@ -3,9 +3,11 @@
 // Batches cross as Arrow C Data Interface structs (no libarrow dependency); columns are staged into HBM,
 // the device-level operators run there, and results come back as freshly allocated Arrow arrays.
 #include <algorithm>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "vnm_agg.hpp"
@@ -381,6 +383,40 @@ static void make_generic_key_array(struct ArrowArray* a, const GenKey& g, int64_
     a->buffers[1] = v;
 }
 
+// ---- MIN / MAX over utf8 / large_utf8 / binary / large_binary columns below the C ABI -------------------------------------------------
+// StringMinMaxFunc (agg_funcs.h:219-261): NULLs skipped, a group of NULLs only gives NULL, values compared byte-wise.  The device
+// aggregates order-preserving RANKS: a column's values go through ONE dictionary that grows with the operator (vnm_strdict: the bytes of
+// a value cross PCIe once), and for every device-sized batch a throw-away operator of the caller's kind takes MIN / MAX of
+// rank(value) per group, ranks taken over the dictionary as it stands (vnm_strdict_ranks_device).  What it leaves is one CANDIDATE per
+// group and function -- the id of the winning value, which does not depend on later growth -- kept in HBM as a chunk (group keys +
+// ids).  Chunks are folded (the same operator over the chunks, ids ranked against the dictionary of that moment) whenever they
+// hold more than twice the groups of the last fold: nothing accumulates per batch.  result() folds once more and lines the
+// candidates up with the numeric operator's groups by key.
+struct StrCol { int child = -1; GenKey dict; };
+struct StrFn { int func = 0; int op_idx = 0; int col = 0; };          // VNM_MIN / VNM_MAX, index among the operator's functions, index into strcols
+struct CandChunk {
+    int64_t n = 0;
+    std::vector<void*> kv; std::vector<uint8_t*> kb; std::vector<int64_t> knull;      // per key column: values of the key's width, bitmap, NULL count
+    std::vector<int32_t*> ids; std::vector<uint8_t*> idb; std::vector<int64_t> idnull;  // per string function: candidate ids (-1 = NULL), bitmap
+    void drop() {
+        for (void* p : kv) pool_free(p);
+        for (uint8_t* p : kb) pool_free(p);
+        for (int32_t* p : ids) pool_free(p);
+        for (uint8_t* p : idb) pool_free(p);
+        kv.clear(); kb.clear(); ids.clear(); idb.clear(); knull.clear(); idnull.clear(); n = 0;
+    }
+};
+__global__ void strmm_invert_kernel(const int32_t* rank_of_id, int64_t top, int32_t* id_of_rank) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < top && rank_of_id[id] >= 0) id_of_rank[rank_of_id[id]] = (int32_t)id;
+}
+__global__ void strmm_rank_to_id_kernel(const int32_t* ranks, const uint8_t* bitmap, int64_t n, const int32_t* id_of_rank, int32_t* ids) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool valid = !bitmap || ((bitmap[i >> 3] >> (i & 7)) & 1);
+    ids[i] = valid ? id_of_rank[ranks[i]] : -1;
+}
+
 struct vnm_agg_op {
     int kind;
     std::vector<std::unique_ptr<GenKey>> gkeys;   // per group-by column: how a non-numeric key travels (GK_NUM: as it is)
@@ -395,11 +431,21 @@ struct vnm_agg_op {
     std::vector<std::unique_ptr<ImportedBatch>> pending;
     int64_t pending_rows = 0;
     std::vector<std::string> formats;   // child formats of the first batch: later batches must match on the columns used
+    // MIN / MAX over utf8 / binary columns (StringMinMaxFunc, agg_funcs.h:219-261), see strmm_* below
+    std::vector<std::unique_ptr<StrCol>> strcols;   // one device dictionary per such column
+    std::vector<StrFn> strfns;
+    std::vector<int> dev_of;                        // operator function -> function of the device operator (-1: a string function)
+    std::vector<CandChunk> cands;
+    int64_t cand_rows = 0, cand_floor = 0;
+    int n_dev = 0;                                  // functions of the device operator
 };
 
 static int agg_op_init(vnm_agg_op* h, const struct ArrowSchema* sch) {
     // a failed earlier attempt (unknown column, unsupported type) must not leave half-filled index vectors behind
     h->key_idx.clear(); h->key_t.clear(); h->in_idx.clear(); h->in_t.clear(); h->aggcol_key.clear(); h->gkeys.clear(); h->standin.clear();
+    h->strcols.clear(); h->strfns.clear(); h->dev_of.clear();
+    for (auto& c : h->cands) c.drop();
+    h->cands.clear(); h->cand_rows = 0; h->cand_floor = 0;
     if (h->dev) { vnm_agg_destroy(h->dev); h->dev = nullptr; }
     // lookup_col_indices base_aggregate.cpp:121-131
     for (auto& c : h->groupby) {
@@ -423,14 +469,15 @@ static int agg_op_init(vnm_agg_op* h, const struct ArrowSchema* sch) {
         if (pos < 0) return set_error("aggregate column %s is not a group-by column", c.c_str());
         h->aggcol_key.push_back(pos);
     }
-    std::vector<int> ktypes, itypes, iflags, ids;
+    std::vector<int> ktypes, itypes, iflags, ids, dfuncs;
     for (auto& t : h->key_t) ktypes.push_back(t.type);
     for (size_t i = 0; i < h->funcs.size(); i++) {
         h->standin.push_back(0);
+        h->dev_of.push_back((int)dfuncs.size());
         if (h->funcs[i] == VNM_COUNT_STAR || h->in_cols[i].empty()) {
             h->in_idx.push_back(-1);
             h->in_t.push_back(ColType());
-            itypes.push_back(VNM_U64); iflags.push_back(0); ids.push_back(-1);
+            dfuncs.push_back(h->funcs[i]); itypes.push_back(VNM_U64); iflags.push_back(0); ids.push_back(-1);
             continue;
         }
         int ci = find_child(sch, h->in_cols[i]);
@@ -438,6 +485,23 @@ static int agg_op_init(vnm_agg_op* h, const struct ArrowSchema* sch) {
         ColType t = parse_format(sch->children[ci]->format);
         h->in_idx.push_back(ci);
         h->in_t.push_back(t);
+        bool wide_str = false;
+        if (t.type < 0 && (h->funcs[i] == VNM_MIN || h->funcs[i] == VNM_MAX) && generic_kind(t.format, &wide_str) == GK_STR) {
+            // MIN / MAX of strings / binaries: not a function of the device operator (strmm_* below)
+            int col = -1;
+            for (size_t q = 0; q < h->strcols.size(); q++) if (h->strcols[q]->child == ci) col = (int)q;
+            if (col < 0) {
+                std::unique_ptr<StrCol> sc(new StrCol());
+                sc->child = ci; sc->dict.kind = GK_STR; sc->dict.wide = wide_str;
+                if (!(sc->dict.dict = vnm_strdict_create())) return 1;
+                col = (int)h->strcols.size();
+                h->strcols.push_back(std::move(sc));
+            }
+            StrFn sf; sf.func = h->funcs[i]; sf.op_idx = (int)i; sf.col = col;
+            h->strfns.push_back(sf);
+            h->dev_of.back() = -1;
+            continue;
+        }
         if (t.type < 0 && h->funcs[i] != VNM_COUNT) {
             switch (h->funcs[i]) {
                 case VNM_MIN: case VNM_MAX: return set_error("Column data type is not supported by min()/max().");
@@ -449,12 +513,16 @@ static int agg_op_init(vnm_agg_op* h, const struct ArrowSchema* sch) {
                             // column may also be a key, which travels as codes)
             h->standin.back() = 1;
             h->in_t.back().type = VNM_I8;
-            itypes.push_back(VNM_I8); iflags.push_back(0); ids.push_back(1000000 + ci);
+            dfuncs.push_back(h->funcs[i]); itypes.push_back(VNM_I8); iflags.push_back(0); ids.push_back(1000000 + ci);
             continue;
         }
-        itypes.push_back(t.type); iflags.push_back(t.flags); ids.push_back(ci);
+        dfuncs.push_back(h->funcs[i]); itypes.push_back(t.type); iflags.push_back(t.flags); ids.push_back(ci);
     }
-    h->dev = vnm_agg_create(h->kind, (int)ktypes.size(), ktypes.data(), (int)h->funcs.size(), h->funcs.data(),
+    if (dfuncs.empty() && !h->strfns.empty()) {   // string functions only: the device operator still lists the groups (a COUNT(*) nobody reads)
+        dfuncs.push_back(VNM_COUNT_STAR); itypes.push_back(VNM_U64); iflags.push_back(0); ids.push_back(-1);
+    }
+    h->n_dev = (int)dfuncs.size();
+    h->dev = vnm_agg_create(h->kind, (int)ktypes.size(), ktypes.data(), (int)dfuncs.size(), dfuncs.data(),
                             itypes.data(), iflags.data(), ids.data());
     if (!h->dev) return 1;
     h->inited = true;
@@ -513,14 +581,221 @@ void vnm_agg_op_destroy(vnm_agg_op* h) {
     if (!h) return;
     for (auto& b : h->pending) b->drop();
     if (h->dev) vnm_agg_destroy(h->dev);
+    for (auto& c : h->cands) c.drop();
     delete h;
 }
+
+}  // extern "C"
+
+// ---- string MIN / MAX: one throw-away operator over (keys, ranks) -> a chunk of candidates --------------------------------------------
+struct StrmmBatch { int64_t n; std::vector<vnm_dcol> keys; std::vector<vnm_dcol> ids; };   // ids: per string FUNCTION, int32 dictionary ids with validity
+static int strmm_run(vnm_agg_op* h, const std::vector<StrmmBatch>& batches, CandChunk* out) {
+    const int nk = (int)h->key_idx.size(), nf = (int)h->strfns.size(), nc = (int)h->strcols.size();
+    std::vector<int> ktypes, funcs, itypes, iflags, ids;
+    for (auto& t : h->key_t) ktypes.push_back(t.type);
+    for (int f = 0; f < nf; f++) { funcs.push_back(h->strfns[f].func); itypes.push_back(VNM_I32); iflags.push_back(0); ids.push_back(f); }
+    vnm_agg* tmp = vnm_agg_create(h->kind, nk, ktypes.data(), nf, funcs.data(), itypes.data(), iflags.data(), ids.data());
+    if (!tmp) return 1;
+    PoolScope pool;
+    int rc = 0;
+    // ranks of every dictionary as it stands now, and their inverse
+    std::vector<int32_t*> rank_of(nc, nullptr), id_of(nc, nullptr);
+    for (int c = 0; !rc && c < nc; c++) {
+        const int64_t top = std::max<int64_t>(1, vnm_strdict_ids(h->strcols[c]->dict.dict));
+        rank_of[c] = (int32_t*)pool.take((size_t)top * 4);
+        id_of[c] = (int32_t*)pool.take((size_t)top * 4);
+        if (!rank_of[c] || !id_of[c]) { rc = 1; break; }
+        if (hipMemsetAsync(rank_of[c], 0xFF, (size_t)top * 4, nullptr) != hipSuccess || hipMemsetAsync(id_of[c], 0xFF, (size_t)top * 4, nullptr) != hipSuccess) { rc = set_error("string min / max: memset failed"); break; }
+        rc = vnm_strdict_ranks_device(h->strcols[c]->dict.dict, rank_of[c], nullptr);
+        if (!rc) {
+            strmm_invert_kernel<<<(int)((top + 255) / 256), 256, 0, nullptr>>>(rank_of[c], top, id_of[c]);
+            if (hipGetLastError() != hipSuccess) rc = set_error("string min / max: kernel launch failed");
+        }
+    }
+    for (size_t b = 0; !rc && b < batches.size(); b++) {
+        const StrmmBatch& sb = batches[b];
+        if (sb.n <= 0) continue;
+        PoolScope bp;
+        std::vector<vnm_dcol> inputs((size_t)nf);
+        for (int f = 0; !rc && f < nf; f++) {
+            int same = -1;   // (two functions over one column of a data batch share the rank column)
+            for (int g = 0; g < f; g++) if (sb.ids[g].values == sb.ids[f].values && sb.ids[g].offset == sb.ids[f].offset) same = g;
+            if (same >= 0) { inputs[f] = inputs[same]; continue; }
+            int32_t* r = (int32_t*)bp.take((size_t)sb.n * 4);
+            if (!r) { rc = 1; break; }
+            rc = vnm_strdict_codes_to_ranks((const int32_t*)sb.ids[f].values + sb.ids[f].offset, rank_of[h->strfns[f].col], sb.n, r, nullptr);
+            inputs[f] = sb.ids[f];
+            inputs[f].values = r - sb.ids[f].offset;      // (the validity bitmap keeps the column's own offset)
+        }
+        if (!rc) rc = vnm_agg_next_device(tmp, sb.n, sb.keys.data(), inputs.data(), nullptr, nullptr);
+        if (hipStreamSynchronize(nullptr) != hipSuccess && !rc) rc = set_error("string min / max: stream synchronisation failed");
+    }
+    int64_t n = 0;
+    if (!rc) rc = vnm_agg_finish(tmp, &n, nullptr);
+    if (!rc) {
+        out->n = n;
+        const size_t bm_bytes = (size_t)((n + 63) / 64 + 1) * 8;
+        for (int j = 0; !rc && j < nk; j++) {
+            void* v = pool_alloc((size_t)(n ? n : 1) * 8);
+            uint8_t* bm = (uint8_t*)pool_alloc(bm_bytes);
+            int64_t nulls = 0;
+            out->kv.push_back(v); out->kb.push_back(bm); out->knull.push_back(0);
+            if (!v || !bm) { rc = 1; break; }
+            rc = vnm_agg_result_key_device(tmp, j, v, bm, &nulls, nullptr);
+            out->knull.back() = nulls;
+        }
+        for (int f = 0; !rc && f < nf; f++) {
+            int32_t* rv = (int32_t*)pool.take((size_t)(n ? n : 1) * 8);
+            int32_t* idv = (int32_t*)pool_alloc((size_t)(n ? n : 1) * 4);
+            uint8_t* bm = (uint8_t*)pool_alloc(bm_bytes);
+            int kind = 0;
+            int64_t nulls = 0;
+            out->ids.push_back(idv); out->idb.push_back(bm); out->idnull.push_back(0);
+            if (!rv || !idv || !bm) { rc = 1; break; }
+            rc = vnm_agg_result_func_device(tmp, f, rv, bm, &kind, &nulls, nullptr);
+            out->idnull.back() = nulls;
+            if (!rc && n) {
+                strmm_rank_to_id_kernel<<<(int)((n + 255) / 256), 256, 0, nullptr>>>(rv, nulls ? bm : nullptr, n, id_of[h->strfns[f].col], idv);
+                if (hipGetLastError() != hipSuccess) rc = set_error("string min / max: kernel launch failed");
+            }
+        }
+        if (hipStreamSynchronize(nullptr) != hipSuccess && !rc) rc = set_error("string min / max: stream synchronisation failed");
+    }
+    vnm_agg_destroy(tmp);
+    if (rc) out->drop();
+    return rc;
+}
+// all chunks -> one (the candidates of every chunk ranked against the dictionary of this moment)
+static int strmm_fold(vnm_agg_op* h) {
+    if (h->cands.size() <= 1) return 0;
+    const int nk = (int)h->key_idx.size(), nf = (int)h->strfns.size();
+    std::vector<StrmmBatch> bs;
+    for (auto& ch : h->cands) {
+        StrmmBatch sb; sb.n = ch.n;
+        for (int j = 0; j < nk; j++) {
+            vnm_dcol d; memset(&d, 0, sizeof(d));
+            d.values = ch.kv[j]; d.validity = ch.knull[j] ? ch.kb[j] : nullptr; d.length = ch.n; d.type = h->key_t[j].type; d.flags = h->key_t[j].flags;
+            sb.keys.push_back(d);
+        }
+        for (int f = 0; f < nf; f++) {
+            vnm_dcol d; memset(&d, 0, sizeof(d));
+            d.values = ch.ids[f]; d.validity = ch.idnull[f] ? ch.idb[f] : nullptr; d.length = ch.n; d.type = VNM_I32;
+            sb.ids.push_back(d);
+        }
+        bs.push_back(std::move(sb));
+    }
+    CandChunk folded;
+    VNM_TRY(strmm_run(h, bs, &folded));
+    for (auto& ch : h->cands) ch.drop();
+    h->cands.clear();
+    h->cand_rows = folded.n;
+    h->cand_floor = folded.n;
+    h->cands.push_back(std::move(folded));
+    return 0;
+}
+// the string columns of one device batch (chunks_of(child) = where its rows lie) -> one more chunk of candidates
+template <class ChunksOf>
+static int strmm_batch(vnm_agg_op* h, int64_t total, const std::vector<vnm_dcol>& keys, ChunksOf chunks_of) {
+    if (h->strfns.empty() || total <= 0) return 0;
+    const int nc = (int)h->strcols.size();
+    std::vector<vnm_dcol> idcols((size_t)nc);
+    int rc = 0, staged = 0;
+    for (int c = 0; !rc && c < nc; c++, staged += !rc) rc = stage_generic_key(h->strcols[c]->dict, chunks_of(h->strcols[c]->child), total, &idcols[c]);
+    if (!rc) {
+        StrmmBatch sb; sb.n = total; sb.keys = keys;
+        for (auto& f : h->strfns) sb.ids.push_back(idcols[f.col]);
+        CandChunk ch;
+        rc = strmm_run(h, std::vector<StrmmBatch>{sb}, &ch);
+        if (!rc) { h->cand_rows += ch.n; h->cands.push_back(std::move(ch)); }
+    }
+    for (int c = 0; c < staged; c++) vnm_free_column(&idcols[c]);
+    if (!rc && h->cands.size() > 1 && h->cand_rows > 2 * std::max<int64_t>(h->cand_floor, (int64_t)1 << 16)) rc = strmm_fold(h);
+    return rc;
+}
+
+// result(): the folded candidates lined up with the numeric operator's groups by key -> per string function, the winning id of every group
+static int strmm_join(vnm_agg_op* h, int64_t n, std::vector<std::vector<int32_t>>* ids_of_fn) {
+    const int nk = (int)h->key_idx.size(), nf = (int)h->strfns.size();
+    ids_of_fn->assign((size_t)nf, std::vector<int32_t>((size_t)(n ? n : 1), -1));
+    if (h->cands.empty() || n == 0) return 0;
+    const CandChunk& ch = h->cands[0];
+    const int64_t m = ch.n;
+    std::vector<int> width((size_t)nk);
+    size_t klen = 0;
+    for (int j = 0; j < nk; j++) { width[j] = type_width(h->key_t[j].type); klen += 1 + (size_t)width[j]; }
+    // candidates: key bytes -> row
+    std::vector<std::vector<uint8_t>> cv((size_t)nk), cb((size_t)nk);
+    for (int j = 0; j < nk; j++) {
+        cv[j].resize((size_t)(m ? m : 1) * width[j]);
+        if (m && hipMemcpy(cv[j].data(), ch.kv[j], (size_t)m * width[j], hipMemcpyDeviceToHost) != hipSuccess) return set_error("string min / max: device to host copy failed");
+        if (ch.knull[j]) {
+            cb[j].resize((size_t)(m + 7) / 8);
+            if (hipMemcpy(cb[j].data(), ch.kb[j], cb[j].size(), hipMemcpyDeviceToHost) != hipSuccess) return set_error("string min / max: device to host copy failed");
+        }
+    }
+    auto key_of = [&](std::string& k, int64_t r, const std::vector<const uint8_t*>& vals, const std::vector<int>& stride, const std::vector<std::function<bool(int64_t)>>& valid) {
+        k.assign(klen, '\0');
+        size_t at = 0;
+        for (int j = 0; j < nk; j++) {
+            const bool v = valid[j](r);
+            k[at++] = v ? 1 : 0;
+            if (v) memcpy(&k[at], vals[j] + (size_t)r * stride[j], (size_t)width[j]);
+            at += (size_t)width[j];
+        }
+    };
+    std::unordered_map<std::string, int64_t> row_of;
+    row_of.reserve((size_t)m * 2 + 16);
+    {
+        std::vector<const uint8_t*> vals; std::vector<int> stride; std::vector<std::function<bool(int64_t)>> valid;
+        for (int j = 0; j < nk; j++) {
+            vals.push_back(cv[j].data()); stride.push_back(width[j]);
+            const uint8_t* bm = ch.knull[j] ? cb[j].data() : nullptr;
+            valid.push_back([bm](int64_t r) { return !bm || ((bm[r >> 3] >> (r & 7)) & 1); });
+        }
+        std::string k;
+        for (int64_t r = 0; r < m; r++) { key_of(k, r, vals, stride, valid); row_of.emplace(k, r); }
+    }
+    std::vector<std::vector<int32_t>> cid((size_t)nf);
+    for (int f = 0; f < nf; f++) {
+        cid[f].resize((size_t)(m ? m : 1));
+        if (m && hipMemcpy(cid[f].data(), ch.ids[f], (size_t)m * 4, hipMemcpyDeviceToHost) != hipSuccess) return set_error("string min / max: device to host copy failed");
+    }
+    // the numeric operator's groups
+    std::vector<std::vector<uint64_t>> mv((size_t)nk);
+    std::vector<std::vector<uint8_t>> mb((size_t)nk);
+    for (int j = 0; j < nk; j++) {
+        mv[j].resize((size_t)n); mb[j].resize((size_t)n);
+        VNM_TRY(vnm_agg_result_key(h->dev, j, mv[j].data(), mb[j].data()));
+    }
+    std::vector<const uint8_t*> vals; std::vector<int> stride; std::vector<std::function<bool(int64_t)>> valid;
+    for (int j = 0; j < nk; j++) {
+        vals.push_back((const uint8_t*)mv[j].data()); stride.push_back(8);
+        const uint8_t* vb = mb[j].data();
+        valid.push_back([vb](int64_t r) { return vb[r] != 0; });
+    }
+    std::string k;
+    for (int64_t r = 0; r < n; r++) {
+        key_of(k, r, vals, stride, valid);
+        auto it = row_of.find(k);
+        if (it == row_of.end()) continue;
+        for (int f = 0; f < nf; f++) (*ids_of_fn)[f][(size_t)r] = cid[f][(size_t)it->second];
+    }
+    return 0;
+}
+static void strmm_column(vnm_agg_op* h, int f, int64_t n, const std::vector<int32_t>& ids, struct ArrowArray* out) {
+    std::vector<uint8_t> vb((size_t)(n ? n : 1));
+    for (int64_t r = 0; r < n; r++) vb[(size_t)r] = ids[(size_t)r] >= 0;
+    make_generic_key_array(out, h->strcols[(size_t)h->strfns[(size_t)f].col]->dict, n, ids.data(), vb.data());
+}
+
+extern "C" {
 
 // one device batch out of everything that is pending
 static int agg_op_flush(vnm_agg_op* h) {
     if (h->pending.empty()) return 0;
     const int64_t total = h->pending_rows;
-    std::vector<vnm_dcol> keys(h->key_idx.size()), inputs(h->funcs.size());
+    std::vector<vnm_dcol> keys(h->key_idx.size()), inputs((size_t)std::max(h->n_dev, 1));
+    for (auto& d : inputs) { memset(&d, 0, sizeof(vnm_dcol)); d.length = total; }
     std::map<std::pair<int, int>, vnm_dcol> staged;   // (child, form: 0 as it is / 1 key codes / 2 COUNT stand-in)
     int rc = 0;
     auto chunks_of = [&](int ci) {
@@ -542,13 +817,11 @@ static int agg_op_flush(vnm_agg_op* h) {
         return 0;
     };
     for (size_t j = 0; !rc && j < h->key_idx.size(); j++) rc = get(h->key_idx[j], h->key_t[j], &keys[j], h->gkeys[j].get());
-    for (size_t i = 0; !rc && i < h->funcs.size(); i++) {
-        memset(&inputs[i], 0, sizeof(vnm_dcol));
-        inputs[i].length = total;
-        if (h->in_idx[i] >= 0) rc = get(h->in_idx[i], h->in_t[i], &inputs[i], nullptr, h->standin[i] != 0);
-    }
+    for (size_t i = 0; !rc && i < h->funcs.size(); i++)
+        if (h->dev_of[i] >= 0 && h->in_idx[i] >= 0) rc = get(h->in_idx[i], h->in_t[i], &inputs[(size_t)h->dev_of[i]], nullptr, h->standin[i] != 0);
     if (!rc && total > 0) rc = vnm_agg_next_device(h->dev, total, keys.data(), inputs.data(), nullptr, nullptr);
     if (hipStreamSynchronize(nullptr) != hipSuccess && !rc) rc = set_error("vnm_agg_op_next: stream synchronisation failed");
+    if (!rc) rc = strmm_batch(h, total, keys, chunks_of);
     for (auto& kv : staged) vnm_free_column(&kv.second);
     for (auto& b : h->pending) b->drop();
     h->pending.clear();
@@ -591,7 +864,8 @@ int vnm_agg_op_next(vnm_agg_op* h, struct ArrowArray* batch, struct ArrowSchema*
     }
     rc = agg_op_flush(h);   // (rows that arrived earlier go first; the order does not matter to the result)
     if (rc) { ib.drop(); return rc; }
-    std::vector<vnm_dcol> keys(h->key_idx.size()), inputs(h->funcs.size());
+    std::vector<vnm_dcol> keys(h->key_idx.size()), inputs((size_t)std::max(h->n_dev, 1));
+    for (auto& d : inputs) { memset(&d, 0, sizeof(vnm_dcol)); d.length = ib.arr.length; }
     std::map<std::pair<int, int>, vnm_dcol> staged;
     hipStream_t s = nullptr;
     auto get = [&](int ci, const ColType& t, vnm_dcol* out, GenKey* g = nullptr, bool standin = false) -> int {
@@ -609,13 +883,11 @@ int vnm_agg_op_next(vnm_agg_op* h, struct ArrowArray* batch, struct ArrowSchema*
         return 0;
     };
     for (size_t j = 0; !rc && j < h->key_idx.size(); j++) rc = get(h->key_idx[j], h->key_t[j], &keys[j], h->gkeys[j].get());
-    for (size_t i = 0; !rc && i < h->funcs.size(); i++) {
-        memset(&inputs[i], 0, sizeof(vnm_dcol));
-        inputs[i].length = ib.arr.length;
-        if (h->in_idx[i] >= 0) rc = get(h->in_idx[i], h->in_t[i], &inputs[i], nullptr, h->standin[i] != 0);
-    }
+    for (size_t i = 0; !rc && i < h->funcs.size(); i++)
+        if (h->dev_of[i] >= 0 && h->in_idx[i] >= 0) rc = get(h->in_idx[i], h->in_t[i], &inputs[(size_t)h->dev_of[i]], nullptr, h->standin[i] != 0);
     if (!rc) rc = vnm_agg_next_device(h->dev, ib.arr.length, keys.data(), inputs.data(), nullptr, (void*)s);
     if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = set_error("vnm_agg_op_next: stream synchronisation failed");
+    if (!rc) rc = strmm_batch(h, ib.arr.length, keys, [&](int ci) { return std::vector<ColChunk>{ColChunk{ib.arr.children[ci], ib.arr.children[ci]->offset + ib.arr.offset, ib.arr.length}}; });
     for (auto& kv : staged) vnm_free_column(&kv.second);
     ib.drop();
     return rc;
@@ -632,6 +904,13 @@ int vnm_agg_op_result(vnm_agg_op* h, struct ArrowArray* out, struct ArrowSchema*
     VNM_TRY(agg_op_flush(h));
     int64_t n = 0;
     VNM_TRY(vnm_agg_finish(h->dev, &n, nullptr));
+    std::vector<std::vector<int32_t>> str_ids;      // per string function: the winning dictionary id of every group (-1 = NULL)
+    std::vector<int> strfn_of(h->funcs.size(), -1);
+    if (!h->strfns.empty()) {
+        VNM_TRY(strmm_fold(h));
+        VNM_TRY(strmm_join(h, n, &str_ids));
+        for (size_t f = 0; f < h->strfns.size(); f++) strfn_of[(size_t)h->strfns[f].op_idx] = (int)f;
+    }
     const int64_t ncols = (int64_t)h->agg_cols.size() + (int64_t)h->funcs.size();
     make_struct(out, n, ncols);
     make_schema(out_schema, "+s", "", ncols);
@@ -664,7 +943,12 @@ int vnm_agg_op_result(vnm_agg_op* h, struct ArrowArray* out, struct ArrowSchema*
         for (size_t i = 0; !rc && i < h->funcs.size(); i++, col++) {
             int kind = 0;
             int64_t nulls = 0;
-            rc = vnm_agg_result_func_device(h->dev, (int)i, dv, db, &kind, &nulls, nullptr);
+            if (strfn_of[i] >= 0) {
+                strmm_column(h, strfn_of[i], n, str_ids[(size_t)strfn_of[i]], out->children[col]);
+                make_schema(out_schema->children[col], h->in_t[i].format, h->out_cols[i], 0);
+                continue;
+            }
+            rc = vnm_agg_result_func_device(h->dev, h->dev_of[i], dv, db, &kind, &nulls, nullptr);
             if (rc) break;
             const ColType& t = h->in_t[i];
             const int f = h->funcs[i];
@@ -712,7 +996,12 @@ int vnm_agg_op_result(vnm_agg_op* h, struct ArrowArray* out, struct ArrowSchema*
     }
     for (size_t i = 0; i < h->funcs.size(); i++, col++) {
         int kind = 0;
-        VNM_TRY(vnm_agg_result_func(h->dev, (int)i, cells.data(), valid.data(), &kind));
+        if (strfn_of[i] >= 0) {
+            strmm_column(h, strfn_of[i], n, str_ids[(size_t)strfn_of[i]], out->children[col]);
+            make_schema(out_schema->children[col], h->in_t[i].format, h->out_cols[i], 0);
+            continue;
+        }
+        VNM_TRY(vnm_agg_result_func(h->dev, h->dev_of[i], cells.data(), valid.data(), &kind));
         const ColType& t = h->in_t[i];
         std::string fmt;
         int w = 8;

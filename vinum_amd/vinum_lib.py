@@ -17,6 +17,7 @@ Same names, constructor arguments, methods and error behaviour as the reference:
 """
 import ctypes
 import enum
+import os
 
 import pyarrow as pa
 
@@ -252,6 +253,7 @@ class _HashAggregateBase:
         self._h = None
         self._strmm = None          # _StringMinMax for MIN / MAX over non-numeric columns
         self._stand_in = set()      # non-numeric columns that are only COUNTed: an int8 column with the same validity stands in
+        self._abi_str = set()       # string / binary columns under MIN / MAX: passed to the library as they are (round 6)
         self._create(self._groupby, self._agg_cols, self._funcs)
 
     def _create(self, groupby_cols, agg_cols, agg_funcs):
@@ -279,7 +281,12 @@ class _HashAggregateBase:
                 self._stand_in.add(c)
             elif f.func in (AggFuncType.MIN, AggFuncType.MAX) and (pa.types.is_string(t) or pa.types.is_large_string(t) or pa.types.is_binary(t)
                                                                   or pa.types.is_large_binary(t)):
-                str_funcs.append(f)
+                # round 6: vnm_agg_op_* take such columns themselves (one growing device dictionary per column, candidates per group
+                # in HBM); the shim's own route stays reachable for A / B runs
+                if os.environ.get("VNM_STRING_MINMAX_IN_SHIM"):
+                    str_funcs.append(f)
+                else:
+                    self._abi_str.add(c)
             else:
                 raise RuntimeError({AggFuncType.MIN: "Column data type is not supported by min()/max().",
                                     AggFuncType.MAX: "Column data type is not supported by min()/max().",
@@ -301,13 +308,15 @@ class _HashAggregateBase:
         columns of the types the library dictionary-encodes itself (round 6: vnm_agg_op_* take utf8 / binary / bool / decimal128 keys)
         as they are"""
         import numpy as np
-        if not self._stand_in and self._strmm is None:
+        if not self._stand_in and self._strmm is None and not self._abi_str:
             return batch
         arrays, names = [], []
         for i, name in enumerate(batch.schema.names):
             col = batch.column(i)
             if name in self._groupby and _abi_generic_key(col.type):
                 pass
+            elif name in self._abi_str:
+                pass                                      # MIN / MAX of a string / binary column: the library's own (round 6; a COUNT over it as well)
             elif name in self._stand_in:
                 col = pa.array(np.zeros(len(col), np.int8), mask=(~col.is_valid().to_numpy(zero_copy_only=False)) if col.null_count else None)
             elif not _is_numeric(col.type):
