@@ -510,7 +510,8 @@ class _RawI64w:
 
 
 @pytest.mark.parametrize("case", ["f64_uniform", "f64_normal_desc", "f64_lognormal", "i64_wide", "u64_desc", "few_duplicates", "nan_and_zeros", "outside_the_sample",
-                                  "duplicates_decline", "lumpy_declines", "fanout_64", "fanout_512", "fanout_16_native", "odd_unaligned", "f32_widened"])
+                                  "duplicates_decline", "lumpy_declines", "fanout_64", "fanout_512", "fanout_16_native", "odd_unaligned", "f32_widened",
+                                  "nulls_asc", "nulls_desc_unaligned", "mostly_null_declines"])
 def test_entry_word_sample_sort_equals_the_lsd_sort(case, monkeypatch):
     """vnm_sort_indices over one 8-byte key when only the order is asked for (vnm_sort_apx.inc): rows travel as 8-byte words
     (a32 << 32 | row id) where a32 comes from an equalising piecewise-linear map of the code; two entries with the same a32 are
@@ -560,9 +561,20 @@ def test_entry_word_sample_sort_equals_the_lsd_sort(case, monkeypatch):
         n = 2_999_999 + 4096 * 3 + 17; v = rng.normal(0.0, 1.0, n)
     elif case == "f32_widened":
         n = (1 << 21) + 77; v = rng.permutation(np.arange(n, dtype=np.int64) * 2000 - 2**31 + 5).astype(np.int32)    # distinct int32 keys
+    elif case in ("nulls_asc", "nulls_desc_unaligned", "mostly_null_declines"):
+        v = rng.normal(0.0, 1.0, n)
+        order = L.DESC if "desc" in case else L.ASC
+        taken = case != "mostly_null_declines"
     else:
         raise AssertionError(case)
-    if case == "odd_unaligned":
+    if case.startswith("nulls") or case == "mostly_null_declines":
+        # NULL keys: their rows stand behind every value in both directions, in row order (SortIndices' null placement, sort.cpp:22-37)
+        mask = rng.random(n) < (0.02 if case == "nulls_asc" else (0.3 if case != "mostly_null_declines" else 0.8))
+        arr = pa.array(v, mask=mask)
+        if "unaligned" in case:
+            arr = arr.slice(5, n - 11); n = len(arr)
+        col = DeviceColumn.from_arrow(arr)
+    elif case == "odd_unaligned":
         arr = pa.array(np.concatenate([[0.0] * 3, v])).slice(3, n)      # an odd Arrow offset: no 16-byte pairs
         col = DeviceColumn.from_arrow(arr)
     else:
