@@ -1050,7 +1050,7 @@ def main():
         dom = "topk_select"
         if args.limit == 0:                          # full-sort variant: read keys, write the sorted order (int64 row ids)
             alg_bytes = 16.0 * n
-            workload = f"configs[4]: ORDER BY v DESC over {n:.3g} fp64 rows (full stable radix sort, row ids out)"
+            workload = f"configs[4]: ORDER BY v DESC over {n:.3g} fp64 rows (full stable sort -- sample sort over 8-byte entry words --, int64 row ids out)"
     elif args.workload == "project":
         alg_bytes = 8.0 * n * 3 + 8.0 * n * 3       # three distinct inputs, three outputs
         workload = f"configs[4]: projection v*2+1, v-a, a*b over {n:.3g} fp64 rows"

@@ -857,6 +857,9 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
     const bool keyed = key_out != nullptr && fl[1] == 0 && !has_null;   // (a sorted key column with NULLs in it: the caller gathers)
     la.key_out = keyed ? key_out : nullptr; la.key_type = key.type; la.key_desc = desc; la.flags = flags;
     la.debug = (int)env_sort_i64("VNM_SSORT_DEBUG", 0);
+    la.crowded = (uint32_t*)pool.take((size_t)nb * 4);
+    if (!la.crowded) return 1;
+    VNM_HIP(hipMemsetAsync(la.crowded, 0, (size_t)nb * 4, s));
     {
         KernelTimer timer("sort_local", s);
         ssort_local_kernel<512, 10, 4096, false><<<(int)std::min<int64_t>(nb, (int64_t)cus * 64), 512, (size_t)SS_SMALL * 12 + 4096 * 4, s>>>(la);
