@@ -903,12 +903,14 @@ vnm_agg* vnm_agg_create(int kind, int n_keys, const int* key_types, int n_funcs,
         for (int i = 0; i < n_funcs; i++) {
             if (in_types[i] != VNM_F32 || funcs[i] == VNM_COUNT_STAR) continue;
             bool ok = true;      // every function over the same column (same id; without ids: this function alone) must allow it
+            bool sums = false;   // ... and one of them must be a SUM / AVG: a column that is only COUNTed is read for its validity alone
             for (int j = 0; j < n_funcs && ok; j++) {
                 const bool same_col = in_col_ids ? (in_col_ids[j] >= 0 && in_col_ids[j] == in_col_ids[i]) : j == i;
                 if (same_col && funcs[j] != VNM_SUM && funcs[j] != VNM_AVG && funcs[j] != VNM_COUNT) ok = false;
                 if (same_col && in_types[j] != VNM_F32) ok = false;
+                if (same_col && (funcs[j] == VNM_SUM || funcs[j] == VNM_AVG)) sums = true;
             }
-            if (ok) { widen_in[i] = true; types2[(size_t)i] = VNM_F64; any_widen = true; }
+            if (ok && sums) { widen_in[i] = true; types2[(size_t)i] = VNM_F64; any_widen = true; }
         }
     }
     vnm_agg* h = agg_create(kind, n_keys, wide_type >= 0 ? &wide_type : key_types, n_funcs, funcs, any_widen ? types2.data() : in_types, in_flags, in_col_ids);

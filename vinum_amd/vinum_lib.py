@@ -608,10 +608,18 @@ class KeyDictionary:
         one dictionary before partial groups keyed by these codes can travel (distributed.union_dictionary)."""
         import numpy as np
         if self._device and self._h is not None:
-            values = pa.concat_arrays(self._chunks) if self._chunks else pa.array([], type=self.type)
+            # (cached until the dictionary grows: a predicate on a dictionary column asks once per batch and literal -- ADVICE r05 --, and
+            #  the concat + take is O(distinct values))
             top = int(L.lib().vnm_strdict_ids(self._h))
+            stamp = (top, len(self._chunks))
+            cached = getattr(self, "_by_code_cache", None)
+            if cached is not None and cached[0] == stamp:
+                return cached[1]
+            values = pa.concat_arrays(self._chunks) if self._chunks else pa.array([], type=self.type)
             pos = self._pos[:top] if self._pos is not None else np.zeros(0, np.int64)
-            return values.take(pa.array(np.where(pos < 0, 0, pos), type=pa.int64(), mask=(pos < 0) if (pos < 0).any() else None))
+            out = values.take(pa.array(np.where(pos < 0, 0, pos), type=pa.int64(), mask=(pos < 0) if (pos < 0).any() else None))
+            self._by_code_cache = (stamp, out)
+            return out
         return self.values
 
     def decode(self, codes: pa.Array) -> pa.Array:
