@@ -744,6 +744,12 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
         }
         ssort_splitters_kernel<<<(int)((nb + 255) / 256), 256, 0, s>>>(sr.code[sr.cur], m_valid, nb, split, flags, heavy, nheavy_d);
         VNM_HIP(hipGetLastError());
+        // rows that arrive clustered (a sorted column): the ring scatters would crawl -- the LSD passes do not care
+        unsigned long long min_span = ~0ULL;
+        VNM_HIP(hipMemsetAsync(flags + 7, 0xFF, 8, s));
+        ssort_cluster_kernel<<<64, 256, 0, s>>>(key, desc, n, sr.code[sr.cur], m_valid, flags + 7);
+        VNM_HIP(hipGetLastError());
+        VNM_HIP(hipMemcpyAsync(&min_span, flags + 7, 8, hipMemcpyDeviceToHost, s));
         unsigned long long too_many = 0;
         unsigned int nh = 0;
         VNM_HIP(hipMemcpyAsync(&eq_pairs, flags + 3, 8, hipMemcpyDeviceToHost, s));
@@ -752,6 +758,10 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
         VNM_HIP(hipMemcpyAsync(&nh, nheavy_d, 4, hipMemcpyDeviceToHost, s));
         VNM_HIP(hipMemcpyAsync(hcodes, heavy, sizeof(hcodes), hipMemcpyDeviceToHost, s));
         VNM_HIP(hipStreamSynchronize(s));    // (sr goes back to the pool here)
+        if (min_span != ~0ULL && (int64_t)min_span < m_valid / 8 && env_sort_i64("VNM_SSORT_CLUSTER_CHECK", 1)) {
+            if (getenv("VNM_SORT_TRACE")) fprintf(stderr, "[sort] sample sort declined: the rows arrive clustered (a tile of 4096 consecutive rows spans %llu of %lld samples)\n", min_span, (long long)m_valid);
+            return 2;
+        }
         if (too_many || nh > (unsigned int)SS_MAX_HEAVY || getenv("VNM_SSORT_NO_HEAVY") != nullptr && nh) {
             if (getenv("VNM_SORT_TRACE")) fprintf(stderr, "[sort] sample sort declined: %u heavily duplicated values\n", nh);
             return 2;
