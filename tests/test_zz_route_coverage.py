@@ -24,7 +24,7 @@ REQUIRED = {
     "result:fused_columns": "4.2", "result:fused_columns_with_side_table": "4.2b'", "result:finish_then_finalize": "3",
     "dense:count_bytes": "4.2d", "dense:fixed_point": "4.2e", "dense:fixed_point_misfit": "4.2e", "dense:exact_adds": "4.2e", "dense:fixed_point_columns": "4.2f", "dense:fixed_point_columns_failed": "4.2f",
     "minmax:ordered_mode": "2", "minmax:compose_prefix_suffix": "2",
-    "sort:topk_threshold": "4.3", "sort:sample_sort": "4.3", "sort:sample_sort_words": "4.3", "sort:lsd_radix": "4.3", "sort:string_key_ranks": "4.3",
+    "sort:topk_threshold": "4.3", "sort:sample_sort": "4.3", "sort:sample_sort_words": "4.3", "sort:already_sorted": "4.3", "sort:lsd_radix": "4.3", "sort:string_key_ranks": "4.3",
 }
 
 

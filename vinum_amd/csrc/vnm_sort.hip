@@ -663,8 +663,26 @@ static int grid_for(int64_t n, int per_cu = 8) {
     return g > need ? (int)need : g;
 }
 
+static thread_local bool g_rows_clustered = false;   // set by the sample sorts when they decline rows that arrive clustered (ssort_cluster_kernel)
+
 #include "vnm_sort_sample.inc"
 #include "vnm_sort_apx.inc"
+
+// A column that arrives clustered is often simply SORTED already (a time series ordered by its timestamp).  One pass counts the rows
+// whose code is below their predecessor's; none: the order asked for is the row order (stable: equal keys keep it), the indices are 0 .. n - 1.
+__global__ __launch_bounds__(256) void sort_inversions_kernel(vnm_dcol key, int desc, int64_t n, unsigned long long* out) {
+    unsigned special = 0;
+    unsigned int mine = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += stride)
+        mine += ss_code_of(key, i, desc, &special) < ss_code_of(key, i - 1, desc, &special) ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, (unsigned long long)mine);
+}
+__global__ void sort_iota64_kernel(int64_t* idx, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) idx[i] = i;
+}
 
 // Sample sort of one 8-byte key without a validity bitmap (see vnm_sort_sample.inc).  0 = done (idx_out written, *wrote_key),
 // 2 = not applicable / a bucket outgrew its room (the caller sorts with the LSD passes), 1 = error.
@@ -759,6 +777,7 @@ static int sample_sort(const vnm_dcol& key, int desc, int64_t n, int64_t* idx_ou
         VNM_HIP(hipMemcpyAsync(hcodes, heavy, sizeof(hcodes), hipMemcpyDeviceToHost, s));
         VNM_HIP(hipStreamSynchronize(s));    // (sr goes back to the pool here)
         if (min_span != ~0ULL && (int64_t)min_span < m_valid / 8 && env_sort_i64("VNM_SSORT_CLUSTER_CHECK", 1)) {
+            g_rows_clustered = true;
             if (getenv("VNM_SORT_TRACE")) fprintf(stderr, "[sort] sample sort declined: the rows arrive clustered (a tile of 4096 consecutive rows spans %llu of %lld samples)\n", min_span, (long long)m_valid);
             return 2;
         }
@@ -1180,6 +1199,29 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
         if (rc == 0) { if (wrote_key0) *wrote_key0 = 0; return 0; }
         // (rc 2: the sample sort declined -- heavy values, an overflowing bucket: the LSD passes over the original column)
     }
+    if (g_rows_clustered && n_keys == 1 && !keys[0].validity && !out_sorted_key0 && type_width(keys[0].type) == 8 && getenv("VNM_SORT_NO_SORTED_CHECK") == nullptr) {
+        g_rows_clustered = false;
+        unsigned long long* inv = (unsigned long long*)pool_alloc(64);
+        if (!inv) return 1;
+        unsigned long long ninv = 1;
+        int rc = 0;
+        if (hipMemsetAsync(inv, 0, 8, s) != hipSuccess) rc = set_error("vnm_sort_indices: memset failed");
+        if (!rc) {
+            sort_inversions_kernel<<<grid_for(n, 16), 256, 0, s>>>(keys[0], orders[0] == VNM_DESC, n, inv);
+            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&ninv, inv, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+                rc = set_error("vnm_sort_indices: the sortedness check failed");
+        }
+        pool_free(inv);
+        if (rc) return rc;
+        if (ninv == 0) {
+            route_note("sort:already_sorted", "%lld rows, one 8-byte key: the rows arrive in the order asked for (no row below its predecessor): the indices are the row numbers", (long long)n);
+            sort_iota64_kernel<<<grid_for(n, 16), 256, 0, s>>>(out_indices, n);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return set_error("vnm_sort_indices: kernel launch failed");
+            if (wrote_key0) *wrote_key0 = 0;
+            return 0;
+        }
+    }
+    g_rows_clustered = false;
     RadixBufs r{};
     VNM_TRY(radix_alloc(&r, n));
     bool wrote = false, wrote_key = false;
