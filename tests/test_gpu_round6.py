@@ -600,10 +600,10 @@ def test_entry_word_sample_sort_equals_the_lsd_sort(case, monkeypatch):
     assert (_took(before, "sort:sample_sort_words") >= 1) == taken, (case, _took(before, "sort:sample_sort_words"))
     if case.startswith("sorted_"):
         assert _took(before, "sort:lsd_radix") >= 1, "rows in key order must go to the LSD passes"
+    got = torch.as_tensor(_RawI64w(got_idx.ptr, n), device="cuda")
     if case.startswith("already_sorted"):
         assert _took(before, "sort:already_sorted") >= 1 and _took(before, "sort:lsd_radix") == 0
         assert bool(torch.equal(got, torch.arange(n, device="cuda")))
-    got = torch.as_tensor(_RawI64w(got_idx.ptr, n), device="cuda")
     assert bool(torch.equal(got, ref)), f"{case}: {int((got != ref).sum())} positions differ"
 
 
