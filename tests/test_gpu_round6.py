@@ -511,7 +511,7 @@ class _RawI64w:
 
 @pytest.mark.parametrize("case", ["f64_uniform", "f64_normal_desc", "f64_lognormal", "i64_wide", "u64_desc", "few_duplicates", "nan_and_zeros", "outside_the_sample",
                                   "duplicates_decline", "lumpy_declines", "fanout_64", "fanout_512", "fanout_16_native", "odd_unaligned", "f32_widened",
-                                  "nulls_asc", "nulls_desc_unaligned", "mostly_null_declines", "sorted_input_declines", "sorted_runs_decline", "already_sorted", "already_sorted_desc_with_ties"])
+                                  "nulls_asc", "nulls_desc_unaligned", "mostly_null_declines", "sorted_input_declines", "sorted_runs_decline", "already_sorted", "already_sorted_desc_with_ties", "already_sorted_backwards"])
 def test_entry_word_sample_sort_equals_the_lsd_sort(case, monkeypatch):
     """vnm_sort_indices over one 8-byte key when only the order is asked for (vnm_sort_apx.inc): rows travel as 8-byte words
     (a32 << 32 | row id) where a32 comes from an equalising piecewise-linear map of the code; two entries with the same a32 are
@@ -567,6 +567,8 @@ def test_entry_word_sample_sort_equals_the_lsd_sort(case, monkeypatch):
         v = np.sort(rng.normal(0.0, 1.0, n)); v[-3:] = np.nan; taken = False
     elif case == "already_sorted_desc_with_ties":
         v = -np.sort(rng.integers(0, n // 3, n).astype(np.float64)); v[v == 0.0] = 0.0; v[5] = v[4]; order = L.DESC; taken = False
+    elif case == "already_sorted_backwards":           # strictly ascending, asked for descending, no ties: the row numbers backwards
+        v = np.sort(rng.permutation(n).astype(np.float64) * 0.5); order = L.DESC; taken = False
     elif case == "sorted_runs_decline":                # ... or in sorted runs of 2^16 rows
         v = rng.normal(0.0, 1.0, n); v = np.concatenate([np.sort(v[i:i + 65536]) for i in range(0, n, 65536)]); taken = False
     elif case in ("nulls_asc", "nulls_desc_unaligned", "mostly_null_declines"):
@@ -603,7 +605,7 @@ def test_entry_word_sample_sort_equals_the_lsd_sort(case, monkeypatch):
     got = torch.as_tensor(_RawI64w(got_idx.ptr, n), device="cuda")
     if case.startswith("already_sorted"):
         assert _took(before, "sort:already_sorted") >= 1 and _took(before, "sort:lsd_radix") == 0
-        assert bool(torch.equal(got, torch.arange(n, device="cuda")))
+        assert bool(torch.equal(got, torch.arange(n, device="cuda") if case != "already_sorted_backwards" else torch.arange(n - 1, -1, -1, device="cuda")))
     assert bool(torch.equal(got, ref)), f"{case}: {int((got != ref).sum())} positions differ"
 
 

@@ -670,18 +670,22 @@ static thread_local bool g_rows_clustered = false;   // set by the sample sorts 
 
 // A column that arrives clustered is often simply SORTED already (a time series ordered by its timestamp).  One pass counts the rows
 // whose code is below their predecessor's; none: the order asked for is the row order (stable: equal keys keep it), the indices are 0 .. n - 1.
+// (out[0]: rows below their predecessor, out[1]: rows above or EQUAL to it -- none of the latter: the column is strictly in the opposite order,
+//  and without ties the stable answer is the row numbers backwards)
 __global__ __launch_bounds__(256) void sort_inversions_kernel(vnm_dcol key, int desc, int64_t n, unsigned long long* out) {
     unsigned special = 0;
-    unsigned int mine = 0;
+    unsigned int below = 0, not_below = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += stride)
-        mine += ss_code_of(key, i, desc, &special) < ss_code_of(key, i - 1, desc, &special) ? 1u : 0u;
-    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, (unsigned long long)mine);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += stride) {
+        const bool b = ss_code_of(key, i, desc, &special) < ss_code_of(key, i - 1, desc, &special);
+        below += b ? 1u : 0u; not_below += b ? 0u : 1u;
+    }
+    for (int o = 32; o > 0; o >>= 1) { below += __shfl_xor(below, o); not_below += __shfl_xor(not_below, o); }
+    if ((threadIdx.x & 63) == 0) { if (below) atomicAdd(out, (unsigned long long)below); if (not_below) atomicAdd(out + 1, (unsigned long long)not_below); }
 }
-__global__ void sort_iota64_kernel(int64_t* idx, int64_t n) {
+__global__ void sort_iota64_kernel(int64_t* idx, int64_t n, int backwards) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) idx[i] = i;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) idx[i] = backwards ? n - 1 - i : i;
 }
 
 // Sample sort of one 8-byte key without a validity bitmap (see vnm_sort_sample.inc).  0 = done (idx_out written, *wrote_key),
@@ -1203,19 +1207,21 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
         g_rows_clustered = false;
         unsigned long long* inv = (unsigned long long*)pool_alloc(64);
         if (!inv) return 1;
-        unsigned long long ninv = 1;
+        unsigned long long ninv[2] = {1, 1};
         int rc = 0;
-        if (hipMemsetAsync(inv, 0, 8, s) != hipSuccess) rc = set_error("vnm_sort_indices: memset failed");
+        if (hipMemsetAsync(inv, 0, 16, s) != hipSuccess) rc = set_error("vnm_sort_indices: memset failed");
         if (!rc) {
             sort_inversions_kernel<<<grid_for(n, 16), 256, 0, s>>>(keys[0], orders[0] == VNM_DESC, n, inv);
-            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&ninv, inv, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(ninv, inv, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
                 rc = set_error("vnm_sort_indices: the sortedness check failed");
         }
         pool_free(inv);
         if (rc) return rc;
-        if (ninv == 0) {
-            route_note("sort:already_sorted", "%lld rows, one 8-byte key: the rows arrive in the order asked for (no row below its predecessor): the indices are the row numbers", (long long)n);
-            sort_iota64_kernel<<<grid_for(n, 16), 256, 0, s>>>(out_indices, n);
+        if (ninv[0] == 0 || ninv[1] == 0) {
+            const int backwards = ninv[0] != 0;
+            route_note("sort:already_sorted", "%lld rows, one 8-byte key: the rows arrive %s: the indices are the row numbers%s", (long long)n,
+                       backwards ? "strictly in the opposite order (every row below its predecessor, no ties)" : "in the order asked for (no row below its predecessor)", backwards ? " backwards" : "");
+            sort_iota64_kernel<<<grid_for(n, 16), 256, 0, s>>>(out_indices, n, backwards);
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return set_error("vnm_sort_indices: kernel launch failed");
             if (wrote_key0) *wrote_key0 = 0;
             return 0;
