@@ -562,7 +562,7 @@ def test_entry_word_sample_sort_equals_the_lsd_sort(case, monkeypatch):
     elif case == "f32_widened":
         n = (1 << 21) + 77; v = rng.permutation(np.arange(n, dtype=np.int64) * 2000 - 2**31 + 5).astype(np.int32)    # distinct int32 keys
     elif case == "sorted_input_declines":              # rows that arrive in key order: every sub-tile would go to one ring -- both sample sorts decline
-        v = np.sort(rng.normal(0.0, 1.0, n)); order = L.DESC; taken = False
+        v = np.sort(rng.normal(0.0, 1.0, n)); v[100] = v[99]; order = L.DESC; taken = False      # (a tie: not simply the row numbers backwards)
     elif case == "already_sorted":                     # ... and when that order IS the order asked for, the indices are the row numbers
         v = np.sort(rng.normal(0.0, 1.0, n)); v[-3:] = np.nan; taken = False
     elif case == "already_sorted_desc_with_ties":
