@@ -1154,6 +1154,7 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
     if (n_keys == 1 && (!keys[0].validity || getenv("VNM_SSORT_NO_NULLS") == nullptr) && (keys[0].type == VNM_F64 || keys[0].type == VNM_I64 || keys[0].type == VNM_U64) &&
         n >= env_sort_i64("VNM_SSORT_MIN_ROWS", (int64_t)1 << 25) && getenv("VNM_SORT_NO_SAMPLE") == nullptr) {
         bool wk = false;
+        g_rows_clustered = false;
         // only the order is asked for: 8-byte entry words (an equalising map of the code + row id) instead of (code, row id) -- the
         // sample decides (duplicated keys, lumpy distributions keep the splitters)
         if (!out_sorted_key0 && env_sort_i64("VNM_SORT_APX", 1)) {
@@ -1165,10 +1166,12 @@ int vnm_sort_indices_keyed(int n_keys, const vnm_dcol* keys, const int* orders, 
                 return 0;
             }
         }
-        route_note("sort:sample_sort", "%lld rows, one 8-byte key: splitters from a sample, two bucket scatters, per-bucket LDS sort", (long long)n);
-        const int rc = sample_sort(keys[0], orders[0] == VNM_DESC, n, out_indices, (uint64_t*)out_sorted_key0, &wk, s);
-        if (rc == 1) return 1;
-        if (rc == 0) { if (wrote_key0) *wrote_key0 = wk ? 1 : 0; return 0; }
+        if (!g_rows_clustered) {   // (rows that arrive clustered: the splitter sort would decline them as well)
+            route_note("sort:sample_sort", "%lld rows, one 8-byte key: splitters from a sample, two bucket scatters, per-bucket LDS sort", (long long)n);
+            const int rc = sample_sort(keys[0], orders[0] == VNM_DESC, n, out_indices, (uint64_t*)out_sorted_key0, &wk, s);
+            if (rc == 1) return 1;
+            if (rc == 0) { if (wrote_key0) *wrote_key0 = wk ? 1 : 0; return 0; }
+        }
     }
     // ... one 4-byte key (float32 / int32 / uint32) the same way (round 5): widened to 8 bytes -- float32 -> float64 is exact and keeps the
     // order, NaNs and signed zeros -- the sample sort orders the copy; 5e8 float32 keys through the LSD passes: 27.9 ms, float64: 15.7
