@@ -456,6 +456,7 @@ struct vnm_agg {
     // the sample is m * 2^fx_qe with |m| < 2^31 and room to spare), -1 = off (the sample or a later row does not fit)
     int fx_state = 0, fx_qe = 0;
     bool pack_null_seen = false;     // packed composite keys: some batch brought a key column with a validity bitmap (NULL codes may be in the words)
+    bool pring_off = false;          // the ring form of the hash-partition scatter failed once (a heavy key, a full region): the tile-sorting scatter from then on
     bool fx_narrow = false;          // ... with |m| < 2^18: the words of the last scatter level are 32 bits (dring_scatter_kernel<..., W32>)
     int fxn_state = 0, fxn_qe[3] = {0, 0, 0};   // ... and of the entries of two or three values (vnm_agg_fxn.inc)
     bool null_inputs_seen = false;   // some batch brought an input column with a validity bitmap: the HBM table may hold groups whose COUNT(v) differs
