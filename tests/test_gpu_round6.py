@@ -720,3 +720,37 @@ def test_string_min_max_below_the_abi_folds_its_candidates():
     assert g.column("mn").combine_chunks().equals(e.column("s_min").combine_chunks())
     assert g.column("mx").combine_chunks().equals(e.column("s_max").combine_chunks())
     assert g.column("n").to_pylist() == e.column("count_all").to_pylist()
+
+
+@pytest.mark.parametrize("case", ["one_level_100k", "two_levels_2m", "pred_on_other", "heavy_key_falls_back"])
+def test_sparse_keys_through_the_ring_form_of_the_hash_partitions(case, monkeypatch):
+    """Keys that are no dense range (random 62-bit values): the hash partitions.  Where a level has 128 .. 256 partitions its (key, value)
+    entries go through LDS rings (pring_scatter_kernel); a heavy key fails that attempt and the tile-sorting scatter redoes the batch.  Equal to
+    the oracle either way."""
+    from oracle import oracle as O
+    monkeypatch.setenv("VNM_AGG_ESTIMATE_MIN_ROWS", "100000")
+    rng = np.random.default_rng(len(case))
+    groups = 100_000 if case == "one_level_100k" else 2_000_000
+    n = 3_000_000
+    vals = rng.integers(-2**62, 2**62, groups).astype(np.int64)
+    k = vals[rng.integers(0, groups, n)]
+    if case == "heavy_key_falls_back":
+        k[rng.random(n) < 0.3] = vals[0]
+    v = rng.integers(0, 2**14, n).astype(np.float64) / 128.0
+    cols = {"k": pa.array(k), "v": pa.array(v)}
+    pred_col = "v"
+    if case == "pred_on_other":
+        cols["p"] = pa.array(rng.integers(0, 2**14, n).astype(np.float64) / 128.0); pred_col = "p"
+    t = pa.table(cols)
+    batches = util.sliced_batches(t, n // 2)
+    funcs = _hot_funcs()
+    before = _routes()
+    got = gpu_aggregate(O.SINGLE, ["k"], ["k"], funcs, batches, predicate=(pred_col, ">", 64.0), expected_groups=groups)
+    assert _took(before, "hash_partitions:hot") >= 1, _routes()
+    assert _took(before, "hash_partitions:rings") + _took(before, "hash_partitions:rings_failed") >= 1, _routes()
+    if case == "heavy_key_falls_back":
+        assert _took(before, "hash_partitions:rings_failed") >= 1, _routes()
+    o = O.OracleAggregate(O.SINGLE, ["k"], ["k"], funcs)
+    for b in batches:
+        o.next(O.filter_batch(b, O.cmp_mask(b.column(b.schema.names.index(pred_col)), O.GT, 64.0)))
+    util.assert_agg_equal(got, o.result(), funcs, ["k"], what=f"sparse keys {case}")

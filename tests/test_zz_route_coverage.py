@@ -16,7 +16,7 @@ REQUIRED = {
     "scan:hotn": "4.2c", "scan:lds_generic": "4.1", "scan:wide_keys": "4.2b", "scan:spilled_entries": "4.2",
     "dense_scan:hot": "4.1", "dense_scan:generic": "4.1", "dense:two_levels": "4.2", "dense:32_partitions": "4.2", "dense:stream_segments": "4.2a", "dense:nullable_key": "4.2",
     "dense:split_final": "4.2", "dense:generic": "4.2", "dense:generic_split_final": "4.2", "dense:nullable_value": "4.2", "dense:two_values": "4.2c",
-    "hash_partitions:hot": "4.2", "hash_partitions:wide_entries": "4.2c", "hash_partitions:generic": "4.2",
+    "hash_partitions:hot": "4.2", "hash_partitions:rings": "4.2", "hash_partitions:rings_failed": "4.2", "hash_partitions:wide_entries": "4.2c", "hash_partitions:generic": "4.2",
     "keys:packed": "4.2b", "keys:packed_with_dictionary_fields": "4.2b", "keys:tuple_dictionary": "4.2b",
     "split_program:small_range_per_column": "4.2c", "split_program:dense_per_column": "4.2c", "split_program:many_columns": "4.2c",
     "split_program:few_groups_many_columns": "4.2c", "split_program:batch": "4.2c",
