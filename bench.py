@@ -558,6 +558,13 @@ def side_workloads(torch, lib, L, ops, pa, ctypes, kcol, vcol, n, x_thr, stream,
         state["idx"] = ops.sort_indices([v4col], [L.DESC], limit=10, stream=stream)
     ms, sp = _measure(torch, lib, ctypes, topk, [b"topk_sample", b"topk_select", b"topk_small_sort", b"radix_pass"], steps + 2, warmup + 1)
     out["configs[4] top-K"] = _entry(f"ORDER BY v DESC LIMIT 10 over {n:.3g} fp64 rows (row ids out)", n, ms, sp, 8.0 * n + 80.0, 10)
+
+    def fullsort():
+        state["idx"] = ops.sort_indices([v4col], [L.DESC], limit=0, stream=stream)
+    ms, sp = _measure(torch, lib, ctypes, fullsort, [b"sort_sample", b"sort_scatter1", b"sort_scatter2", b"sort_local", b"radix_pass"], max(3, steps // 2), warmup)
+    out["configs[4] full sort"] = _entry(f"ORDER BY v DESC over {n:.3g} fp64 rows, int64 row ids out (`--workload topk --limit 0`: sample sort over 8-byte entry words)",
+                                         n, ms, sp, 16.0 * n, n)
+    state.pop("idx", None)
     ca = torch.randn(n, device=device, dtype=torch.float64, generator=gg)
     cb = torch.rand(n, device=device, dtype=torch.float64, generator=gg)
     cols = {"v": v4col, "a": DeviceColumn.from_torch(ca), "b": DeviceColumn.from_torch(cb)}
