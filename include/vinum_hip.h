@@ -345,8 +345,11 @@ void vnm_agg_op_destroy(vnm_agg_op* h);
 
 /* ---- sort: Sort.next / Sort.sorted ------------------------------------------------------------------
  * replaces vinum/core/vinum_lib.cpp:126-142, vinum_cpp/src/operators/sort/sort.cpp:11-63
- * (arrow::compute::SortIndices + Take).  Stable LSD radix sort on order-preserving key encodings;
- * NaN after all numbers and NULL after NaN for both ASC and DESC. */
+ * (arrow::compute::SortIndices + Take).  The order is total -- order-preserving key encodings, then the row id (stable) --
+ * with NaN after all numbers and NULL after NaN for both ASC and DESC, whichever of the library's sorts produces it: the sample
+ * sort over 8-byte entry words (one 8-byte key, order only, distinct keys: vnm_sort_apx.inc), the splitter sample sort (keyed
+ * results, duplicated keys), the stable LSD radix sort (several keys, heavily duplicated keys, rows that arrive in key order),
+ * top-K selection for limit > 0. */
 int vnm_sort_indices(int n_keys, const vnm_dcol* keys, const int* orders, int64_t length,
                      int64_t limit /* <=0: full sort; >0: only the first `limit` rows are needed */,
                      int64_t* out_indices /* device, length entries (first `limit` valid) */, void* stream);
